@@ -1,0 +1,257 @@
+/*
+ * servicegraph.h — C ABI of the MI355X-native ServiceGraph engine.
+ *
+ * This is the drop-in boundary for the hot path of getanteon/alaz:
+ *
+ *   L7Event -> processL7 -> process<Proto>Event -> setFromToV2 -> ds.PersistRequest
+ *   (aggregator/data.go:310-337, 1364-1383, 1208-1249, 827-870; datastore/backend.go:819-847)
+ *
+ * The reference resolves every L7 event to an edge (FromUID -> ToUID) on the CPU and ships one
+ * 16-field row per request.  The engine behind this header does the same resolution on the GPU,
+ * accumulates per-edge integer statistics, builds a CSR adjacency, runs GraphSAGE-mean message
+ * passing and emits one scored row per *edge* per window.
+ *
+ * Everything here is plain C: pointers, sizes, fixed-width integers.  All functions return
+ * 0 (SG_OK) or a negative SG_E* code and never throw.  They may be called from arbitrary OS
+ * threads (cgo hands calls to whichever thread runs the goroutine); calls on one handle are
+ * serialised internally.  The library never keeps a caller pointer after the call returns
+ * (cgo rule: C must not retain Go memory; datastore/backend.go:824-839 copies out likewise).
+ *
+ * There is NO CPU fallback.  sg_create() fails with SG_ENODEV when no gfx950 device is usable.
+ */
+#ifndef SERVICEGRAPH_H
+#define SERVICEGRAPH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_ABI_VERSION 1u
+
+/* ---- return codes ---------------------------------------------------------------------- */
+#define SG_OK        0
+#define SG_EINVAL   (-22)  /* bad argument                                                   */
+#define SG_ENOMEM   (-12)  /* device or host allocation failed                               */
+#define SG_ENODEV   (-19)  /* no usable HIP device / HIP runtime error (see sg_last_error)   */
+#define SG_ENOSPC   (-28)  /* a capacity in sg_config was exceeded (edges, outbound ips, …)  */
+#define SG_EAGAIN   (-11)  /* staging ring full: the batch was dropped and counted           */
+#define SG_ESTATE   (-71)  /* call made in the wrong window phase                            */
+
+/* ---- L7 protocol numbers: the BPF enum, ebpf/l7_req/l7.go:19-29 ------------------------- */
+#define SG_PROTO_UNKNOWN  0
+#define SG_PROTO_HTTP     1
+#define SG_PROTO_AMQP     2
+#define SG_PROTO_POSTGRES 3
+#define SG_PROTO_HTTP2    4
+#define SG_PROTO_REDIS    5
+#define SG_PROTO_KAFKA    6
+#define SG_PROTO_MYSQL    7
+#define SG_PROTO_MONGO    8
+
+/* ---- sg_event.flags -------------------------------------------------------------------- */
+#define SG_EV_TLS      0x01u /* L7Event.Tls                          ebpf/l7_req/l7.go:402  */
+#define SG_EV_REVERSE  0x02u /* AMQP DELIVER / Redis PUSHED_EVENT: ReverseDirection() after
+                                the join            aggregator/data.go:1110-1112,1151-1153  */
+#define SG_EV_CONSUME  0x04u /* Kafka CONSUME record (informational) data.go:1043-1076       */
+
+/*
+ * One L7 request, packed.  32 bytes, little-endian, naturally aligned.
+ * It carries exactly the fields of l7_req.L7Event (ebpf/l7_req/l7.go:396-417) that decide the
+ * edge identity and the per-edge statistics; the 1 KiB payload stays on the host.
+ *
+ *  saddr/daddr  numeric a<<24|b<<16|c<<8|d, as in L7Event.Saddr/Daddr (l7.go:413,415), i.e. the
+ *               value IntToIPv4() formats (aggregator/data.go:1751-1767).
+ *  host_label   0, or a host-interned id (>=1) of the HTTP "Host:" header value that
+ *               parseHttpPayload extracts (data.go:508-531).  Only consulted when daddr is neither
+ *               a service nor a pod IP: ToUID = Host header (data.go:851-854).
+ *  status       L7Event.Status (HTTP status code, or the 1/2/3 protocol status of
+ *               ebpf/c/{postgres,redis,mysql}.c), saturated to 16 bits.
+ *  protocol     SG_PROTO_*.
+ *  duration_ns  L7Event.Duration, Request.Latency (data.go:1220).
+ *  write_time_ns L7Event.WriteTimeNs (kernel monotonic); StartTime is derived as
+ *               convertKernelTimeToUserspaceTime()/1e6 (data.go:1219,1740-1743).
+ */
+typedef struct sg_event {
+    uint32_t saddr;
+    uint32_t daddr;
+    uint32_t host_label;
+    uint16_t status;
+    uint8_t  protocol;
+    uint8_t  flags;
+    uint64_t duration_ns;
+    uint64_t write_time_ns;
+} sg_event;
+
+/* ---- node references -------------------------------------------------------------------- *
+ * A node of the service map is what the reference calls (Type, UID): FromType/FromUID,
+ * ToType/ToUID (datastore/dto.go:177-195).  Across this ABI a node is a tagged 32-bit ref:
+ *   KNOWN  pod or service; payload = the id the host passed to sg_upsert_pod/_service
+ *          (the host interns UID -> id in arrival order).
+ *   LABEL  outbound, named by a Host header; payload = host_label - 1.
+ *   OBIP   outbound, named by the raw destination IP (data.go:862-863); payload = index into
+ *          the window's ascending outbound-IP list (sg_window_outbound_ips).
+ */
+#define SG_REF_TYPE(r)    ((uint32_t)(r) >> 30)
+#define SG_REF_VALUE(r)   ((uint32_t)(r) & 0x3FFFFFFFu)
+#define SG_REF_KNOWN      0u
+#define SG_REF_LABEL      1u
+#define SG_REF_OBIP       2u
+#define SG_MAKE_REF(t, v) (((uint32_t)(t) << 30) | ((uint32_t)(v) & 0x3FFFFFFFu))
+
+/* node kinds stored per KNOWN id */
+#define SG_NODE_POD       1u
+#define SG_NODE_SERVICE   2u
+
+/*
+ * One scored edge of a closed window.  Rows come out sorted by (dense(from), dense(to)) where
+ * dense() orders KNOWN ids first, then LABEL, then OBIP — the canonical CSR order.
+ *
+ *  count/err_count/sum_ns/max_ns/sumsq_us  integer accumulators over the window's events on this
+ *        edge: bit-exact.  "error" = HTTP/HTTP2 status >= 500, or status == 2 for
+ *        POSTGRES/REDIS/MYSQL (ebpf/c/postgres.c:91, redis.c:10, mysql.c:36).
+ *        sumsq_us = sum of (duration_ns / 1000)^2, wrapping u64.
+ *  score      GraphSAGE + factorised MLP anomaly score in (0,1)          (fp32, |d| <= 1e-5)
+ *  lat_z      (mean_us(edge) - mean_us(src out-events)) / max(std_us(src), 1)  (fp32)
+ *  err_ratio  err_count / count                                            (fp32)
+ */
+typedef struct sg_edge_out {
+    uint64_t sum_ns;
+    uint64_t max_ns;
+    uint64_t sumsq_us;
+    uint32_t from_ref;
+    uint32_t to_ref;
+    uint32_t count;
+    uint32_t err_count;
+    float    score;
+    float    lat_z;
+    float    err_ratio;
+    uint32_t _pad;
+} sg_edge_out;
+
+typedef struct sg_config {
+    uint32_t abi_version;       /* SG_ABI_VERSION                                              */
+    int32_t  device;            /* HIP device ordinal                                          */
+    uint32_t max_known_nodes;   /* capacity of the pod+service id space                        */
+    uint32_t max_labels;        /* capacity of the Host-header label space                     */
+    uint32_t max_outbound_ips;  /* distinct raw-IP outbound destinations per window            */
+    uint32_t max_ips;           /* distinct pod+service IPs in the join tables                 */
+    uint64_t max_edges;         /* distinct edges per window                                   */
+    uint32_t max_batch;         /* largest n accepted by one sg_ingest()                       */
+    uint32_t layers;            /* GraphSAGE layers L, 1..SG_MAX_LAYERS                         */
+    uint32_t rank;              /* this shard                                                   */
+    uint32_t world;             /* number of shards (1 = unsharded)                             */
+    uint32_t k1_variant;        /* 0 = default; others select tuning variants of K1             */
+} sg_config;
+
+#define SG_MAX_LAYERS 4u
+#define SG_F_IN    32u   /* node feature width                                                  */
+#define SG_F_HID   64u   /* hidden width of every SAGE layer and of the score head               */
+#define SG_F_EDGE   8u   /* edge feature width                                                  */
+#define SG_NODE_STAT_SUM_WORDS 10u /* u64 words per node in the SUM-reduced stats block           */
+#define SG_NODE_STAT_MAX_WORDS  2u /* u64 words per node in the MAX-reduced stats block           */
+
+typedef struct sg_stats {
+    uint64_t events_in;            /* events handed to K1 since create                         */
+    uint64_t events_dropped_src;   /* saddr not a pod IP (data.go:829-832)                     */
+    uint64_t events_dropped_ring;  /* SG_EAGAIN drops                                          */
+    uint64_t events_dropped_cap;   /* edge / outbound-ip capacity overflow                     */
+    uint64_t windows;              /* closed windows                                           */
+    uint64_t last_window_events;   /* accepted events in the last closed window                */
+    uint64_t last_window_edges;
+    uint64_t last_window_nodes;
+    int64_t  last_window_tmin_ms;  /* min/max Request.StartTime in the window (data.go:1219)    */
+    int64_t  last_window_tmax_ms;
+    uint64_t h2d_bytes;
+} sg_stats;
+
+typedef struct sg_engine* sg_handle;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int  sg_create(const sg_config* cfg, sg_handle* out);
+int  sg_destroy(sg_handle h);
+const char* sg_last_error(sg_handle h);          /* thread-unsafe diagnostic string             */
+uint32_t sg_abi_version(void);
+size_t   sg_weights_count(uint32_t layers);      /* number of fp32 values sg_load_weights wants  */
+
+/* ---- join tables: replaces ClusterInfo.PodIPToPodUid / ServiceIPToServiceUid ------------- *
+ * (aggregator/cluster.go:13-17) and their maintenance in processPod / processSvc
+ * (aggregator/persist.go:55-71, 114-130).  ADD and UPDATE are both "upsert"; DELETE erases the
+ * IP.  Pods without an IP are skipped by the caller (persist.go:37-40).                        */
+int sg_upsert_pod(sg_handle h, uint32_t ip, uint32_t node_id);
+int sg_delete_pod(sg_handle h, uint32_t ip);
+int sg_upsert_service(sg_handle h, uint32_t ip, uint32_t node_id);
+int sg_delete_service(sg_handle h, uint32_t ip);
+
+/* FirstKernelTime / FirstUserspaceTime (ebpf/l7_req/l7.go:707-710) for StartTime conversion.   */
+int sg_set_clock(sg_handle h, uint64_t first_kernel_ns, uint64_t first_user_ns);
+
+/* fp32 weight blob, layout documented in DESIGN.md §"weights"; copied.                         */
+int sg_load_weights(sg_handle h, const float* w, size_t n);
+
+/* ---- ingest: replaces processL7 .. setFromToV2 .. PersistRequest for the edge fields ------ *
+ * sg_ingest copies n events from host memory into the engine's pinned staging ring, uploads
+ * them and launches K1 asynchronously.  Non-blocking: a full ring drops the batch, counts it
+ * and returns SG_EAGAIN (the reference's PersistRequest would block here, backend.go:844).      */
+int sg_ingest(sg_handle h, const sg_event* events, size_t n);
+
+/* Same, for events already resident in device memory (bench, sharded feeder).  `stream` is a
+ * hipStream_t (NULL = the engine's own stream); K1 is ordered after prior work of that stream. */
+int sg_ingest_device(sg_handle h, const sg_event* d_events, size_t n, void* stream);
+
+/* ---- window close ------------------------------------------------------------------------ *
+ * One call for the unsharded case: K2..K5, copy-out, reset.  `out` receives up to `cap` rows,
+ * *n the number of edges of the window (may exceed cap; then only cap rows were written).       */
+int sg_flush_window(sg_handle h, uint64_t window_end_ms, sg_edge_out* out, size_t cap, size_t* n);
+
+/* The same pipeline in stages, so that a sharded driver can run its exchanges in between.
+ * Order: close -> [allreduce node stats] -> features -> for l in 0..L-1 { layer(l) ->
+ * [halo exchange of layer l+1 rows] } -> score -> read -> reset.
+ * All stage calls enqueue on `stream` (NULL = engine stream) and do not synchronise.            */
+int sg_window_close(sg_handle h, void* stream);      /* K2: canonical ids, CSR; K3a: partial node stats */
+int sg_window_features(sg_handle h, void* stream);   /* K3b: node + edge features from reduced stats    */
+int sg_window_layer(sg_handle h, uint32_t l, void* stream);  /* K4: rows with out-edges owned here + all rows without out-edges */
+int sg_window_score(sg_handle h, void* stream);      /* K5 */
+int sg_window_read(sg_handle h, sg_edge_out* out, size_t cap, size_t* n); /* syncs, copies out   */
+int sg_window_reset(sg_handle h, void* stream);      /* clears the window state                  */
+
+/* Device buffers a sharded driver reduces / exchanges (all device pointers, engine-owned):
+ *  stats_sum: [n_nodes_cap][SG_NODE_STAT_SUM_WORDS] u64, SUM-reduce across shards
+ *  stats_max: [n_nodes_cap][SG_NODE_STAT_MAX_WORDS] u64, MAX-reduce across shards
+ *  counters : [8] u64 — {n_known, n_labels, n_obip, n_edges, n_events, dropped_src, dropped_cap, 0}
+ *  feat(l)  : [n_nodes_cap][SG_F_HID] fp32 rows of layer l output (l = 1..L); l = 0 gives the
+ *             [n_nodes_cap][SG_F_IN] input features.                                           */
+int sg_window_buffers(sg_handle h, void** stats_sum, void** stats_max, void** counters,
+                      size_t* n_nodes_cap);
+int sg_window_feat_buffer(sg_handle h, uint32_t l, void** rows, size_t* row_floats);
+
+/* Halo support (K6).  Fill `ids` (device, u32[cap]) with the dense node indices this shard
+ * needs from others: destinations of local edges that are not owned here and have out-edges
+ * elsewhere.  *n_dev is a device u32 counter.  pack/unpack move rows of layer l between the
+ * feature buffer and a contiguous exchange buffer.                                             */
+int sg_halo_build(sg_handle h, uint32_t* d_ids, uint32_t cap, uint32_t* d_n, void* stream);
+int sg_halo_pack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, float* d_rows, void* stream);
+int sg_halo_unpack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, const float* d_rows, void* stream);
+
+/* Ascending raw IPs of the last read window's OBIP nodes.                                       */
+int sg_window_outbound_ips(sg_handle h, uint32_t* ips, size_t cap, size_t* n);
+
+int sg_stats_get(sg_handle h, sg_stats* out);
+
+/* Per-kernel timing of the last N launches, measured with hipEvents on the launch stream.
+ * kernel: 1..6 = K1..K6.  Returns the average duration in microseconds over the recorded
+ * launches since sg_timing_reset(), and the launch count.  Timing must be enabled first.        */
+int sg_timing_enable(sg_handle h, int on);
+int sg_timing_reset(sg_handle h);
+int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
+
+/* Owner shard of a node / routing shard of an event: murmur3 fmix32(ip) % world.
+ * The feeder routes an event by the IP of its from-endpoint: daddr if SG_EV_REVERSE else saddr. */
+uint32_t sg_hash32(uint32_t x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SERVICEGRAPH_H */

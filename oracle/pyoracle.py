@@ -1,0 +1,219 @@
+"""ctypes binding of oracle/libsgoracle.so.  TEST INFRASTRUCTURE ONLY (see sg_oracle.h):
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by alaz_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgoracle.so")
+OR_UID_MAX = 160
+L7_WIRE_SIZE = 1096
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("sg_oracle.c", "sg_oracle.h")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    return LIB_PATH
+
+
+class EdgeOut(C.Structure):
+    _fields_ = [("sum_ns", C.c_uint64), ("max_ns", C.c_uint64), ("sumsq_us", C.c_uint64),
+                ("from_ref", C.c_uint32), ("to_ref", C.c_uint32), ("count", C.c_uint32), ("err_count", C.c_uint32),
+                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float), ("_pad", C.c_uint32)]
+
+
+class OrEdge(C.Structure):
+    _fields_ = [("row", EdgeOut), ("from_type", C.c_char * 10), ("to_type", C.c_char * 10),
+                ("from_uid", C.c_char * OR_UID_MAX), ("to_uid", C.c_char * OR_UID_MAX)]
+
+
+class ReqInfo(C.Structure):
+    _fields_ = [("start_time", C.c_int64), ("latency", C.c_uint64),
+                ("from_ip", C.c_char * 16), ("from_type", C.c_char * 10), ("from_uid", C.c_char * OR_UID_MAX), ("from_port", C.c_uint16),
+                ("to_ip", C.c_char * 16), ("to_type", C.c_char * 10), ("to_uid", C.c_char * OR_UID_MAX), ("to_port", C.c_uint16),
+                ("protocol", C.c_char * 10), ("status_code", C.c_uint32), ("fail_reason", C.c_char * 4),
+                ("method", C.c_char * 24), ("path", C.c_char * 1100), ("tls", C.c_uint8), ("is_kafka", C.c_uint8)]
+
+    def as_tuple(self):
+        """The 16 slots of ReqInfo in reference order (datastore/backend.go:824-839)."""
+        d = lambda b: b.decode("latin-1")
+        return (self.start_time, self.latency, d(self.from_ip), d(self.from_type), d(self.from_uid), self.from_port,
+                d(self.to_ip), d(self.to_type), d(self.to_uid), self.to_port, d(self.protocol), self.status_code,
+                d(self.fail_reason), d(self.method), d(self.path), bool(self.tls))
+
+
+def _load():
+    lib = C.CDLL(build())
+    P = C.c_void_p
+    sig = {
+        "or_create": (P, []), "or_destroy": (None, [P]),
+        "or_set_clock": (None, [P, C.c_uint64, C.c_uint64]), "or_set_log_limit": (None, [P, C.c_size_t]),
+        "or_process_pod": (C.c_int, [P, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "or_process_svc": (C.c_int, [P, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "or_process_l7_wire": (C.c_size_t, [P, C.c_void_p, C.c_size_t, C.c_void_p]),
+        "or_process_packed": (C.c_size_t, [P, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t]),
+        "or_reqinfo_count": (C.c_size_t, [P]), "or_reqinfo_logged": (C.c_size_t, [P]),
+        "or_reqinfo_at": (C.POINTER(ReqInfo), [P, C.c_size_t]),
+        "or_dropped_src": (C.c_uint64, [P]), "or_dropped_parse": (C.c_uint64, [P]),
+        "or_label_count": (C.c_size_t, [P]), "or_label_at": (C.c_char_p, [P, C.c_size_t]), "or_known_count": (C.c_size_t, [P]),
+        "or_window_close": (C.c_size_t, [P, C.c_void_p, C.c_uint32]),
+        "or_edge_count": (C.c_size_t, [P]), "or_edge_at": (C.POINTER(OrEdge), [P, C.c_size_t]),
+        "or_node_count": (C.c_size_t, [P]),
+        "or_node_features": (C.POINTER(C.c_float), [P]), "or_layer_output": (C.POINTER(C.c_float), [P, C.c_uint32]),
+        "or_node_stats_sum": (C.POINTER(C.c_uint64), [P]), "or_node_stats_max": (C.POINTER(C.c_uint64), [P]),
+        "or_outbound_ips": (C.POINTER(C.c_uint32), [P, C.POINTER(C.c_size_t)]),
+        "or_window_tmin": (C.c_int64, [P]), "or_window_tmax": (C.c_int64, [P]), "or_window_events": (C.c_uint64, [P]),
+        "or_parse_http_payload": (None, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "or_parse_postgres": (C.c_int, [P, C.c_uint32, C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+        "or_int_to_ipv4": (None, [C.c_uint32, C.c_char_p]),
+        "or_weights_count": (C.c_size_t, [C.c_uint32]), "or_hash32": (C.c_uint32, [C.c_uint32]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name); f.restype = res; f.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+class Oracle:
+    def __init__(self, first_kernel_ns: int = 0, first_user_ns: int = 0, log_limit: int = 0):
+        self._l = lib()
+        self._o = self._l.or_create()
+        self._l.or_set_clock(self._o, first_kernel_ns, first_user_ns)
+        self._l.or_set_log_limit(self._o, log_limit)
+
+    def close(self):
+        if self._o:
+            self._l.or_destroy(self._o); self._o = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- k8s ---
+    def pod(self, event_type: str, uid: str, ip: str) -> int:
+        return self._l.or_process_pod(self._o, event_type.encode(), uid.encode(), ip.encode())
+
+    def svc(self, event_type: str, uid: str, ip: str) -> int:
+        return self._l.or_process_svc(self._o, event_type.encode(), uid.encode(), ip.encode())
+
+    def apply_ops(self, ops):
+        for kind, et, uid, ip in ops:
+            (self.pod if kind == "pod" else self.svc)(et, uid, ip)
+
+    # --- events ---
+    def l7_wire(self, recs: bytes, kafka_msgs: Optional[np.ndarray] = None) -> int:
+        n = len(recs) // L7_WIRE_SIZE
+        km = None
+        if kafka_msgs is not None:
+            kafka_msgs = np.ascontiguousarray(kafka_msgs, dtype=np.uint32); km = kafka_msgs.ctypes.data
+        buf = (C.c_char * len(recs)).from_buffer_copy(recs)
+        return self._l.or_process_l7_wire(self._o, C.addressof(buf), n, km)
+
+    def packed(self, events: np.ndarray, labels: Sequence[str]) -> int:
+        ev = np.ascontiguousarray(events)
+        arr = (C.c_char_p * max(1, len(labels)))(*[s.encode() for s in labels])
+        return self._l.or_process_packed(self._o, ev.ctypes.data, len(ev), arr, len(labels))
+
+    # --- results ---
+    def window_close(self, weights: np.ndarray, layers: int) -> int:
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        assert len(w) == self._l.or_weights_count(layers)
+        return self._l.or_window_close(self._o, w.ctypes.data, layers)
+
+    def edges(self) -> List[OrEdge]:
+        n = self._l.or_edge_count(self._o)
+        return [self._l.or_edge_at(self._o, i).contents for i in range(n)]
+
+    def edge_rows(self) -> np.ndarray:
+        """Closed-window edges as a numpy array with the sg_edge_out layout."""
+        from alaz_amd.replay import EDGE_OUT_DTYPE
+        n = self._l.or_edge_count(self._o)
+        out = np.zeros(n, dtype=EDGE_OUT_DTYPE)
+        for i in range(n):
+            e = self._l.or_edge_at(self._o, i).contents
+            out[i] = np.frombuffer(bytes(e.row), dtype=EDGE_OUT_DTYPE)[0]
+        return out
+
+    def edge_dict(self):
+        """{(from_type, from_uid, to_type, to_uid): (count, err, sum, max, sumsq, score, lat_z, err_ratio)}"""
+        d = {}
+        for e in self.edges():
+            k = (e.from_type.decode(), e.from_uid.decode(), e.to_type.decode(), e.to_uid.decode())
+            r = e.row
+            d[k] = (r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio)
+        return d
+
+    def reqinfos(self):
+        n = self._l.or_reqinfo_logged(self._o)
+        return [self._l.or_reqinfo_at(self._o, i).contents.as_tuple() for i in range(n)]
+
+    @property
+    def persisted(self): return self._l.or_reqinfo_count(self._o)
+    @property
+    def dropped_src(self): return self._l.or_dropped_src(self._o)
+    @property
+    def dropped_parse(self): return self._l.or_dropped_parse(self._o)
+    @property
+    def n_nodes(self): return self._l.or_node_count(self._o)
+    @property
+    def n_known(self): return self._l.or_known_count(self._o)
+    @property
+    def labels(self): return [self._l.or_label_at(self._o, i).decode() for i in range(self._l.or_label_count(self._o))]
+    @property
+    def window_tmin(self): return self._l.or_window_tmin(self._o)
+    @property
+    def window_tmax(self): return self._l.or_window_tmax(self._o)
+    @property
+    def window_events(self): return self._l.or_window_events(self._o)
+
+    def node_features(self) -> np.ndarray:
+        n = self.n_nodes
+        return np.ctypeslib.as_array(self._l.or_node_features(self._o), shape=(n, 32)).copy()
+
+    def layer_output(self, l: int) -> np.ndarray:
+        n = self.n_nodes
+        return np.ctypeslib.as_array(self._l.or_layer_output(self._o, l), shape=(n, 64)).copy()
+
+    def node_stats(self):
+        n = self.n_nodes
+        s = np.ctypeslib.as_array(self._l.or_node_stats_sum(self._o), shape=(n, 10)).copy()
+        m = np.ctypeslib.as_array(self._l.or_node_stats_max(self._o), shape=(n, 2)).copy()
+        return s, m
+
+    def outbound_ips(self) -> np.ndarray:
+        k = C.c_size_t(0)
+        p = self._l.or_outbound_ips(self._o, C.byref(k))
+        return np.ctypeslib.as_array(p, shape=(k.value,)).copy() if k.value else np.zeros(0, np.uint32)
+
+    # --- stand-alone pieces ---
+    def parse_postgres(self, pid: int, fd: int, method: str, payload: bytes):
+        out = C.create_string_buffer(2048)
+        rc = self._l.or_parse_postgres(self._o, pid, fd, method.encode(), payload, len(payload), out, 2048)
+        return rc, out.value.decode("latin-1")
+
+
+def parse_http_payload(req: bytes):
+    m = C.create_string_buffer(64); p = C.create_string_buffer(1100); v = C.create_string_buffer(64); h = C.create_string_buffer(OR_UID_MAX)
+    lib().or_parse_http_payload(req, len(req), m, p, v, h)
+    return m.value.decode("latin-1"), p.value.decode("latin-1"), v.value.decode("latin-1"), h.value.decode("latin-1")
+
+
+def int_to_ipv4(ip: int) -> str:
+    b = C.create_string_buffer(16); lib().or_int_to_ipv4(ip, b); return b.value.decode()
