@@ -1,0 +1,666 @@
+// servicegraph.hip — host engine + C ABI (include/servicegraph.h) of the MI355X ServiceGraph engine.
+//
+// One sg_engine owns one device: the join tables, the open window's edge table, the closed
+// window's CSR / feature / score buffers, a pinned staging ring for host-fed events and one HIP
+// stream.  All kernels live in sg_kernels.h.  There is no CPU compute path in this file: every
+// entry point that produces results launches HIP kernels, and sg_create() fails without a device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "sg_kernels.h"
+
+namespace {
+
+constexpr int kStageSlots = 4;
+
+struct TimingRec { hipEvent_t a, b; int kernel; };
+
+u32 next_pow2(u64 v) { u64 p = 1; while (p < v) p <<= 1; return (u32)p; }
+
+}  // namespace
+
+struct sg_engine {
+    sg_config cfg{};
+    std::mutex mu;
+    std::string err;
+    hipStream_t stream = nullptr;
+    Dev d{};
+    std::vector<void*> allocs;
+
+    // host mirror of the join tables (authoritative; the device table is rebuilt from it)
+    std::unordered_map<u32, u32> pod_ip, svc_ip;
+    std::vector<uint8_t> kind;
+    u32 n_known = 0;
+    bool tab_dirty = true;
+    IpEnt* h_iptab = nullptr; IpEnt* d_iptab = nullptr; u32 ipcap = 0;
+    uint8_t* h_kind = nullptr; uint8_t* d_kind = nullptr;
+    hipEvent_t tab_ev = nullptr;
+
+    // staging ring for sg_ingest()
+    sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
+    int stage_next = 0;
+
+    u64 first_kernel = 0, first_user = 0;
+    float* d_W = nullptr; bool have_w = false;
+    u32 n_labels_decl = 0;
+    u32 ecap = 0, obcap = 0, ob_list_cap = 0;
+    u32* d_ob_list = nullptr; u32* d_ob_n = nullptr;
+
+    sg_stats st{};
+    u64 h_ctr[C_COUNT] = {};
+    std::vector<u32> last_obips;
+    bool closed = false;       // window_close has run; rows readable after score
+    bool use_mfma = true;
+    int k1_grid = 0;
+
+    unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
+    std::vector<TimingRec> trecs;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+#define HIP_TRY(e, call)                                                                       \
+    do {                                                                                       \
+        hipError_t _r = (call);                                                                \
+        if (_r != hipSuccess) {                                                                \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_r);                      \
+            return _r == hipErrorOutOfMemory ? SG_ENOMEM : SG_ENODEV;                          \
+        }                                                                                      \
+    } while (0)
+
+template <typename T>
+int dev_alloc(sg_engine* e, T** p, size_t n, int fill = 0) {
+    void* q = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIP_TRY(e, hipMalloc(&q, bytes));
+    HIP_TRY(e, hipMemsetAsync(q, fill, bytes, e->stream));
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return SG_OK;
+}
+
+hipStream_t pick(sg_engine* e, void* s) { return s ? (hipStream_t)s : e->stream; }
+
+hipEvent_t get_event(sg_engine* e) {
+    if (!e->ev_pool.empty()) { hipEvent_t v = e->ev_pool.back(); e->ev_pool.pop_back(); return v; }
+    hipEvent_t v; hipEventCreate(&v); return v;
+}
+
+struct Timed {
+    sg_engine* e; hipStream_t s; TimingRec r; bool on;
+    Timed(sg_engine* e_, hipStream_t s_, int kernel) : e(e_), s(s_), on((e_->timing >> kernel) & 1u) {
+        if (on) { r.kernel = kernel; r.a = get_event(e); r.b = get_event(e); hipEventRecord(r.a, s); }
+    }
+    ~Timed() { if (on) { hipEventRecord(r.b, s); e->trecs.push_back(r); } }
+};
+
+// rebuild + upload the combined IP table if the host mirror changed (processPod/processSvc analogue)
+int sync_tables(sg_engine* e, hipStream_t s) {
+    if (!e->tab_dirty) return SG_OK;
+    HIP_TRY(e, hipEventSynchronize(e->tab_ev));            // previous upload finished reading h_iptab
+    std::memset(e->h_iptab, 0, (size_t)e->ipcap * sizeof(IpEnt));
+    const u32 mask = e->ipcap - 1;
+    auto put = [&](u32 ip, u32 pod, u32 svc) {
+        u32 h = sg_fmix32(ip) & mask;
+        for (;;) {
+            IpEnt& t = e->h_iptab[h];
+            if (!t.used) { t.ip = ip; t.pod = pod; t.svc = svc; t.used = 1; return; }
+            if (t.ip == ip) { if (pod != SG_NONE) t.pod = pod; if (svc != SG_NONE) t.svc = svc; return; }
+            h = (h + 1) & mask;
+        }
+    };
+    for (auto& kv : e->pod_ip) put(kv.first, kv.second, SG_NONE);
+    for (auto& kv : e->svc_ip) put(kv.first, SG_NONE, kv.second);
+    std::memcpy(e->h_kind, e->kind.data(), e->kind.size());
+    HIP_TRY(e, hipMemcpyAsync(e->d_iptab, e->h_iptab, (size_t)e->ipcap * sizeof(IpEnt), hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(e->d_kind, e->h_kind, e->kind.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipEventRecord(e->tab_ev, s));
+    e->tab_dirty = false;
+    return SG_OK;
+}
+
+int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
+    if (n == 0) return SG_OK;
+    int rc = sync_tables(e, s);
+    if (rc) return rc;
+    u64 want = (n + 255) / 256;
+    int grid = (int)std::min<u64>(want, (u64)e->k1_grid);
+    {
+        Timed t(e, s, 1);
+        hipLaunchKernelGGL(k1_resolve_aggregate, dim3(grid), dim3(256), 0, s, e->d, d_ev, (u64)n);
+    }
+    HIP_TRY(e, hipGetLastError());
+    e->st.events_in += n;
+    return SG_OK;
+}
+
+int table_upsert(sg_engine* e, std::unordered_map<u32, u32>& m, u32 ip, u32 node_id, uint8_t kind) {
+    if (node_id >= e->cfg.max_known_nodes) { e->err = "node_id beyond max_known_nodes"; return SG_ENOSPC; }
+    auto it = m.find(ip);
+    if (it == m.end() && e->pod_ip.size() + e->svc_ip.size() >= e->cfg.max_ips) { e->err = "join table full (max_ips)"; return SG_ENOSPC; }
+    if (it == m.end() || it->second != node_id) { m[ip] = node_id; e->tab_dirty = true; }
+    if (e->kind[node_id] != kind) { e->kind[node_id] = kind; e->tab_dirty = true; }
+    e->n_known = std::max(e->n_known, node_id + 1);
+    return SG_OK;
+}
+
+size_t weights_count(u32 L) {
+    size_t n = 0;
+    for (u32 l = 0; l < L; l++) n += 2 * (size_t)(l == 0 ? SG_F_IN : SG_F_HID) * SG_F_HID + SG_F_HID;
+    return n + 2 * SG_F_HID * SG_F_HID + SG_F_EDGE * SG_F_HID + SG_F_HID + SG_F_HID + 1;
+}
+size_t layer_offset(u32 l) {
+    size_t n = 0;
+    for (u32 k = 0; k < l; k++) n += 2 * (size_t)(k == 0 ? SG_F_IN : SG_F_HID) * SG_F_HID + SG_F_HID;
+    return n;
+}
+
+int grid_for(u64 items, int per_block, int cap = 2048) {
+    u64 g = (items + per_block - 1) / per_block;
+    return (int)std::max<u64>(1, std::min<u64>(g, (u64)cap));
+}
+
+int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union_n) {
+    int rc = sync_tables(e, s);
+    if (rc) return rc;
+    const Dev& d = e->d;
+    {
+    Timed t(e, s, 2);
+    hipLaunchKernelGGL(k2_reduce_wgstat, dim3(1), dim3(256), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl);
+    if (d_union == nullptr) {
+        hipLaunchKernelGGL(k2_ob_collect, dim3(1), dim3(1024), 0, s, d, e->d_ob_list, e->ob_list_cap, e->d_ob_n);
+        hipLaunchKernelGGL(k2_ob_sort_unique, dim3(1), dim3(1024), 0, s, d, e->d_ob_list, e->d_ob_n, e->ob_list_cap);
+    } else {
+        hipLaunchKernelGGL(k2_ob_sort_unique, dim3(1), dim3(1024), 0, s, d, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap);
+    }
+    const u32 ntiles = e->ecap / K2_TILE;
+    hipLaunchKernelGGL(k2_edge_count, dim3(ntiles), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k2_scan_tiles, dim3(1), dim3(1024), 0, s, d, ntiles);
+    hipLaunchKernelGGL(k2_edge_compact, dim3(ntiles), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k2_rowptr, dim3(1), dim3(1024), 0, s, d);
+    hipLaunchKernelGGL(k2_scatter, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k2_rowsort, dim3(grid_for(d.ncap, 1)), dim3(256), 0, s, d);
+    }
+    HIP_TRY(e, hipGetLastError());
+    {
+        Timed t3(e, s, 3);
+        hipLaunchKernelGGL(k3_gather, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k3_out_stats, dim3(grid_for(d.ncap, 4)), dim3(256), 0, s, d);
+    }
+    HIP_TRY(e, hipGetLastError());
+    e->closed = true;
+    return SG_OK;
+}
+
+int do_features(sg_engine* e, hipStream_t s) {
+    const Dev& d = e->d;
+    Timed t(e, s, 3);
+    hipLaunchKernelGGL(k3_node_features, dim3(grid_for(d.ncap, 256)), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k3_edge_features, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
+}
+
+int do_layer(sg_engine* e, u32 l, hipStream_t s) {
+    const Dev& d = e->d;
+    if (!e->have_w) { e->err = "sg_load_weights not called"; return SG_ESTATE; }
+    const float* Wl = e->d_W + layer_offset(l);
+    const int grid = grid_for(d.ncap, 16);
+    Timed t(e, s, 4);
+    if (l == 0) {
+        if (e->use_mfma) hipLaunchKernelGGL((k4_sage_layer<32, true>), dim3(grid), dim3(256), 0, s, d, d.x0, d.h[1], Wl);
+        else hipLaunchKernelGGL((k4_sage_layer<32, false>), dim3(grid), dim3(256), 0, s, d, d.x0, d.h[1], Wl);
+    } else {
+        if (e->use_mfma) hipLaunchKernelGGL((k4_sage_layer<64, true>), dim3(grid), dim3(256), 0, s, d, d.h[l], d.h[l + 1], Wl);
+        else hipLaunchKernelGGL((k4_sage_layer<64, false>), dim3(grid), dim3(256), 0, s, d, d.h[l], d.h[l + 1], Wl);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
+}
+
+int do_score(sg_engine* e, hipStream_t s) {
+    const Dev& d = e->d;
+    if (!e->have_w) { e->err = "sg_load_weights not called"; return SG_ESTATE; }
+    const float* Wh = e->d_W + layer_offset(e->cfg.layers);
+    Timed t(e, s, 5);
+    if (e->use_mfma) hipLaunchKernelGGL((k5_node_proj<true>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
+    else hipLaunchKernelGGL((k5_node_proj<false>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
+    hipLaunchKernelGGL(k5_edge_score, dim3(grid_for(e->cfg.max_edges, 4)), dim3(256), 0, s, d, Wh);
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
+}
+
+int do_reset(sg_engine* e, hipStream_t s) {
+    const Dev& d = e->d;
+    const size_t nc = (size_t)d.ncap + 1;
+    HIP_TRY(e, hipMemsetAsync(d.deg, 0, nc * sizeof(u32), s));
+    HIP_TRY(e, hipMemsetAsync(d.cursor, 0, nc * sizeof(u32), s));
+    HIP_TRY(e, hipMemsetAsync(d.st_sum, 0, (size_t)d.ncap * SG_NODE_STAT_SUM_WORDS * sizeof(u64), s));
+    HIP_TRY(e, hipMemsetAsync(d.st_max, 0, (size_t)d.ncap * SG_NODE_STAT_MAX_WORDS * sizeof(u64), s));
+    HIP_TRY(e, hipMemsetAsync(d.obkeys, 0, (size_t)e->obcap * sizeof(u64), s));
+    if (e->h_ctr[C_EDGES_FOUND] > e->cfg.max_edges) {     // unlisted slots survive k3_gather: full clear
+        HIP_TRY(e, hipMemsetAsync(d.ekeys, 0xFF, (size_t)e->ecap * sizeof(u64), s));
+        HIP_TRY(e, hipMemsetAsync(d.eacc, 0, (size_t)e->ecap * 4 * sizeof(u64), s));
+        e->h_ctr[C_EDGES_FOUND] = 0;
+    }
+    e->closed = false;
+    return SG_OK;
+}
+
+int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n) {
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpy(e->h_ctr, e->d.ctr, sizeof(e->h_ctr), hipMemcpyDeviceToHost));
+    const size_t E = (size_t)e->h_ctr[C_N_EDGES];
+    if (n) *n = E;
+    const size_t take = std::min(E, cap);
+    if (out && take) HIP_TRY(e, hipMemcpy(out, e->d.rows, take * sizeof(sg_edge_out), hipMemcpyDeviceToHost));
+    const size_t nob = (size_t)e->h_ctr[C_N_OBIP];
+    e->last_obips.resize(nob);
+    if (nob) HIP_TRY(e, hipMemcpy(e->last_obips.data(), e->d.ob_sorted, nob * sizeof(u32), hipMemcpyDeviceToHost));
+    sg_stats& st = e->st;
+    st.windows++;
+    st.last_window_events = e->h_ctr[C_N_EVENTS];
+    st.last_window_edges = E;
+    st.last_window_nodes = e->h_ctr[C_N_NODES];
+    st.events_dropped_src += e->h_ctr[C_DROPPED_SRC];
+    st.events_dropped_cap += e->h_ctr[C_DROPPED_CAP] + (e->h_ctr[C_EDGES_FOUND] > e->cfg.max_edges ? e->h_ctr[C_EDGES_FOUND] - e->cfg.max_edges : 0);
+    if (e->h_ctr[C_N_EVENTS]) {
+        // convertKernelTimeToUserspaceTime()/1e6 — aggregator/data.go:1740-1743, :1219 (u64 wrap arithmetic)
+        st.last_window_tmin_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMIN_NS])) / 1000000ull);
+        st.last_window_tmax_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMAX_NS])) / 1000000ull);
+    } else { st.last_window_tmin_ms = st.last_window_tmax_ms = 0; }
+    return SG_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+uint32_t sg_abi_version(void) { return SG_ABI_VERSION; }
+size_t sg_weights_count(uint32_t layers) { return weights_count(layers); }
+uint32_t sg_hash32(uint32_t x) { return sg_fmix32(x); }
+
+const char* sg_last_error(sg_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int sg_create(const sg_config* cfg, sg_handle* out) {
+    if (!cfg || !out) return SG_EINVAL;
+    *out = nullptr;
+    if (cfg->abi_version != SG_ABI_VERSION || cfg->layers < 1 || cfg->layers > SG_MAX_LAYERS || cfg->max_edges == 0 ||
+        cfg->max_known_nodes == 0 || cfg->world == 0 || cfg->rank >= cfg->world || cfg->max_known_nodes > 0x3FFFFFFFu)
+        return SG_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return SG_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return SG_ENODEV;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SG_ENODEV;   // MI355X only: the kernels are gfx950 code objects
+    sg_engine* e = new sg_engine();
+    e->cfg = *cfg;
+    if (e->cfg.max_batch == 0) e->cfg.max_batch = 1u << 20;
+    if (e->cfg.max_ips == 0) e->cfg.max_ips = e->cfg.max_known_nodes;
+    auto fail = [&](int rc) { std::fprintf(stderr, "sg_create: %s\n", e->err.c_str()); sg_destroy(e); return rc; };
+#define CR(call) do { int _rc = (call); if (_rc) return fail(_rc); } while (0)
+#define CH(call) do { hipError_t _r = (call); if (_r != hipSuccess) { e->err = std::string(#call) + ": " + hipGetErrorString(_r); return fail(_r == hipErrorOutOfMemory ? SG_ENOMEM : SG_ENODEV); } } while (0)
+    CH(hipSetDevice(cfg->device));
+    CH(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CH(hipEventCreateWithFlags(&e->tab_ev, hipEventDisableTiming));
+    e->k1_grid = std::min<int>(SG_MAX_K1_WGS, prop.multiProcessorCount * 8);
+    const char* env = std::getenv("SG_DENSE_VALU");
+    e->use_mfma = !(env && env[0] == '1');
+
+    Dev& d = e->d;
+    const u64 ME = cfg->max_edges;
+    e->ecap = next_pow2(std::max<u64>(2 * ME, K2_TILE));
+    e->obcap = next_pow2(std::max<u64>(2 * (u64)cfg->max_outbound_ips, 64));
+    e->ob_list_cap = next_pow2(std::max<u64>((u64)cfg->max_outbound_ips * std::max<u32>(cfg->world, 1), 64));
+    e->ipcap = next_pow2(std::max<u64>(2 * (u64)e->cfg.max_ips, 64));
+    d.max_known = cfg->max_known_nodes; d.max_labels = cfg->max_labels; d.max_obip = std::max<u32>(cfg->max_outbound_ips, 1);
+    d.rank = cfg->rank; d.world = cfg->world; d.max_edges = ME; d.layers = cfg->layers;
+    d.ncap = cfg->max_known_nodes + cfg->max_labels + d.max_obip;
+    d.emask = e->ecap - 1; d.obmask = e->obcap - 1; d.ipmask = e->ipcap - 1;
+
+    CR(dev_alloc(e, &e->d_iptab, e->ipcap));
+    CR(dev_alloc(e, &e->d_kind, cfg->max_known_nodes));
+    d.iptab = e->d_iptab; d.kind = e->d_kind;
+    CH(hipHostMalloc((void**)&e->h_iptab, (size_t)e->ipcap * sizeof(IpEnt)));
+    CH(hipHostMalloc((void**)&e->h_kind, cfg->max_known_nodes));
+    e->kind.assign(cfg->max_known_nodes, 0);
+    CR(dev_alloc(e, &d.ekeys, e->ecap, 0xFF));
+    CR(dev_alloc(e, &d.eacc, (size_t)e->ecap * 4));
+    CR(dev_alloc(e, &d.obkeys, e->obcap));
+    CR(dev_alloc(e, &d.wgstat, (size_t)SG_MAX_K1_WGS * WS_WORDS));
+    CR(dev_alloc(e, &d.ctr, C_COUNT));
+    CR(dev_alloc(e, &d.ob_sorted, d.max_obip));
+    CR(dev_alloc(e, &e->d_ob_list, e->ob_list_cap));
+    CR(dev_alloc(e, &e->d_ob_n, 4));
+    CR(dev_alloc(e, &d.tile_cnt, e->ecap / K2_TILE));
+    CR(dev_alloc(e, &d.tile_off, e->ecap / K2_TILE));
+    CR(dev_alloc(e, &d.e_slot, ME)); CR(dev_alloc(e, &d.e_from, ME)); CR(dev_alloc(e, &d.e_to, ME));
+    CR(dev_alloc(e, &d.deg, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.rowptr, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.cursor, (size_t)d.ncap + 1));
+    CR(dev_alloc(e, &d.col, ME)); CR(dev_alloc(e, &d.cslot, ME)); CR(dev_alloc(e, &d.csr_from, ME));
+    CR(dev_alloc(e, &d.sort_k, 2 * ME)); CR(dev_alloc(e, &d.sort_v, 2 * ME));
+    CR(dev_alloc(e, &d.acc_csr, ME * 4));
+    CR(dev_alloc(e, &d.st_sum, (size_t)d.ncap * SG_NODE_STAT_SUM_WORDS)); CR(dev_alloc(e, &d.st_max, (size_t)d.ncap * SG_NODE_STAT_MAX_WORDS));
+    CR(dev_alloc(e, &d.x0, (size_t)d.ncap * SG_F_IN));
+    for (u32 l = 1; l <= cfg->layers; l++) CR(dev_alloc(e, &d.h[l], (size_t)d.ncap * SG_F_HID));
+    CR(dev_alloc(e, &d.P, (size_t)d.ncap * SG_F_HID)); CR(dev_alloc(e, &d.Q, (size_t)d.ncap * SG_F_HID));
+    CR(dev_alloc(e, &d.efeat, ME * SG_F_EDGE)); CR(dev_alloc(e, &d.latz, ME)); CR(dev_alloc(e, &d.errr, ME));
+    CR(dev_alloc(e, &d.rows, ME));
+    CR(dev_alloc(e, &e->d_W, weights_count(cfg->layers)));
+    d.W = e->d_W;
+    for (int i = 0; i < kStageSlots; i++) {
+        CH(hipHostMalloc((void**)&e->h_stage[i], (size_t)e->cfg.max_batch * sizeof(sg_event)));
+        CR(dev_alloc(e, &e->d_stage[i], e->cfg.max_batch));
+        CH(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
+    }
+    // arm the per-workgroup statistic slots (tmin = ~0)
+    {
+        std::vector<u64> init((size_t)SG_MAX_K1_WGS * WS_WORDS, 0);
+        for (int i = 0; i < SG_MAX_K1_WGS; i++) init[(size_t)i * WS_WORDS + WS_TMIN] = ~0ull;
+        CH(hipMemcpyAsync(d.wgstat, init.data(), init.size() * sizeof(u64), hipMemcpyHostToDevice, e->stream));
+        CH(hipStreamSynchronize(e->stream));
+    }
+#undef CR
+#undef CH
+    *out = e;
+    return SG_OK;
+}
+
+int sg_destroy(sg_handle e) {
+    if (!e) return SG_EINVAL;
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) hipFree(p);
+    if (e->h_iptab) hipHostFree(e->h_iptab);
+    if (e->h_kind) hipHostFree(e->h_kind);
+    for (int i = 0; i < kStageSlots; i++) { if (e->h_stage[i]) hipHostFree(e->h_stage[i]); if (e->stage_ev[i]) hipEventDestroy(e->stage_ev[i]); }
+    for (auto& r : e->trecs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto v : e->ev_pool) hipEventDestroy(v);
+    if (e->tab_ev) hipEventDestroy(e->tab_ev);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return SG_OK;
+}
+
+int sg_upsert_pod(sg_handle e, uint32_t ip, uint32_t node_id) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    return table_upsert(e, e->pod_ip, ip, node_id, SG_NODE_POD);
+}
+int sg_upsert_service(sg_handle e, uint32_t ip, uint32_t node_id) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    return table_upsert(e, e->svc_ip, ip, node_id, SG_NODE_SERVICE);
+}
+int sg_delete_pod(sg_handle e, uint32_t ip) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->pod_ip.erase(ip)) e->tab_dirty = true;
+    return SG_OK;
+}
+int sg_delete_service(sg_handle e, uint32_t ip) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->svc_ip.erase(ip)) e->tab_dirty = true;
+    return SG_OK;
+}
+
+int sg_set_clock(sg_handle e, uint64_t first_kernel_ns, uint64_t first_user_ns) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->first_kernel = first_kernel_ns; e->first_user = first_user_ns;
+    return SG_OK;
+}
+
+int sg_set_label_count(sg_handle e, uint32_t n_labels) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n_labels > e->cfg.max_labels) { e->err = "label count beyond max_labels"; return SG_ENOSPC; }
+    e->n_labels_decl = std::max(e->n_labels_decl, n_labels);
+    return SG_OK;
+}
+
+int sg_load_weights(sg_handle e, const float* w, size_t n) {
+    if (!e || !w) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n != weights_count(e->cfg.layers)) { e->err = "weight count mismatch"; return SG_EINVAL; }
+    HIP_TRY(e, hipMemcpy(e->d_W, w, n * sizeof(float), hipMemcpyHostToDevice));
+    e->have_w = true;
+    return SG_OK;
+}
+
+int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
+    if (!e || (!events && n)) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n > e->cfg.max_batch) { e->err = "batch larger than max_batch"; return SG_EINVAL; }
+    if (n == 0) return SG_OK;
+    const int slot = e->stage_next;
+    if (hipEventQuery(e->stage_ev[slot]) == hipErrorNotReady) {          // ring full: drop, never block
+        e->st.events_dropped_ring += n;
+        return SG_EAGAIN;
+    }
+    e->stage_next = (slot + 1) % kStageSlots;
+    std::memcpy(e->h_stage[slot], events, n * sizeof(sg_event));          // the caller's memory is not retained
+    HIP_TRY(e, hipMemcpyAsync(e->d_stage[slot], e->h_stage[slot], n * sizeof(sg_event), hipMemcpyHostToDevice, e->stream));
+    e->st.h2d_bytes += n * sizeof(sg_event);
+    int rc = launch_k1(e, e->d_stage[slot], n, e->stream);
+    HIP_TRY(e, hipEventRecord(e->stage_ev[slot], e->stream));
+    return rc;
+}
+
+int sg_ingest_device(sg_handle e, const sg_event* d_events, size_t n, void* stream) {
+    if (!e || (!d_events && n)) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    return launch_k1(e, d_events, n, pick(e, stream));
+}
+
+int sg_window_close(sg_handle e, void* stream) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    return do_close(e, pick(e, stream), nullptr, nullptr);
+}
+
+int sg_window_obip_list(sg_handle e, uint32_t** d_list, uint32_t** d_n, uint32_t* cap, void* stream) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = pick(e, stream);
+    hipLaunchKernelGGL(k2_ob_collect, dim3(1), dim3(1024), 0, s, e->d, e->d_ob_list, e->cfg.max_outbound_ips ? e->cfg.max_outbound_ips : 1u, e->d_ob_n);
+    HIP_TRY(e, hipGetLastError());
+    if (d_list) *d_list = e->d_ob_list;
+    if (d_n) *d_n = e->d_ob_n;
+    if (cap) *cap = e->cfg.max_outbound_ips;
+    return SG_OK;
+}
+
+int sg_window_close_sharded(sg_handle e, const uint32_t* d_union_ips, const uint32_t* d_union_n, void* stream) {
+    if (!e || !d_union_ips || !d_union_n) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    return do_close(e, pick(e, stream), d_union_ips, d_union_n);
+}
+
+int sg_window_features(sg_handle e, void* stream) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->closed) { e->err = "sg_window_features before sg_window_close"; return SG_ESTATE; }
+    return do_features(e, pick(e, stream));
+}
+int sg_window_layer(sg_handle e, uint32_t l, void* stream) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->closed || l >= e->cfg.layers) { e->err = "sg_window_layer: bad phase or layer"; return SG_ESTATE; }
+    return do_layer(e, l, pick(e, stream));
+}
+int sg_window_score(sg_handle e, void* stream) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->closed) { e->err = "sg_window_score before sg_window_close"; return SG_ESTATE; }
+    return do_score(e, pick(e, stream));
+}
+int sg_window_read(sg_handle e, sg_edge_out* out, size_t cap, size_t* n) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->closed) { e->err = "sg_window_read before sg_window_close"; return SG_ESTATE; }
+    return do_read(e, out, cap, n);
+}
+int sg_window_reset(sg_handle e, void* stream) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    return do_reset(e, pick(e, stream));
+}
+
+int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_t cap, size_t* n) {
+    (void)window_end_ms;
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = e->stream;
+    int rc;
+    if ((rc = do_close(e, s, nullptr, nullptr))) return rc;
+    if ((rc = do_features(e, s))) return rc;
+    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s))) return rc;
+    if ((rc = do_score(e, s))) return rc;
+    if ((rc = do_read(e, out, cap, n))) return rc;
+    return do_reset(e, s);
+}
+
+// enqueue-only variant of the whole window pipeline (no read-back, no host sync): what bench.py times.
+int sg_window_run(sg_handle e, void* stream) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = pick(e, stream);
+    int rc;
+    if ((rc = do_close(e, s, nullptr, nullptr))) return rc;
+    if ((rc = do_features(e, s))) return rc;
+    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s))) return rc;
+    if ((rc = do_score(e, s))) return rc;
+    return do_reset(e, s);
+}
+
+int sg_window_buffers(sg_handle e, void** stats_sum, void** stats_max, void** counters, size_t* n_nodes_cap) {
+    if (!e) return SG_EINVAL;
+    if (stats_sum) *stats_sum = e->d.st_sum;
+    if (stats_max) *stats_max = e->d.st_max;
+    if (counters) *counters = e->d.ctr;
+    if (n_nodes_cap) *n_nodes_cap = e->d.ncap;
+    return SG_OK;
+}
+int sg_window_feat_buffer(sg_handle e, uint32_t l, void** rows, size_t* row_floats) {
+    if (!e || l > e->cfg.layers) return SG_EINVAL;
+    if (rows) *rows = l == 0 ? (void*)e->d.x0 : (void*)e->d.h[l];
+    if (row_floats) *row_floats = l == 0 ? SG_F_IN : SG_F_HID;
+    return SG_OK;
+}
+int sg_window_rows_buffer(sg_handle e, void** rows) {
+    if (!e || !rows) return SG_EINVAL;
+    *rows = e->d.rows;
+    return SG_OK;
+}
+
+int sg_halo_build(sg_handle e, uint32_t* d_ids, uint32_t cap, uint32_t* d_n, void* stream) {
+    if (!e || !d_ids || !d_n) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = pick(e, stream);
+    Timed t(e, s, 6);
+    hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
+    hipLaunchKernelGGL(k6_halo_build, dim3(1), dim3(256), 0, s, e->d, d_ids, cap, d_n);
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
+}
+int sg_halo_pack(sg_handle e, uint32_t l, const uint32_t* d_ids, uint32_t n, float* d_rows, void* stream) {
+    if (!e || l < 1 || l > e->cfg.layers) return SG_EINVAL;
+    if (n == 0) return SG_OK;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = pick(e, stream);
+    Timed t(e, s, 6);
+    hipLaunchKernelGGL(k6_pack, dim3(grid_for((u64)n * 16, 256)), dim3(256), 0, s, e->d.h[l], d_ids, n, d_rows);
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
+}
+int sg_halo_unpack(sg_handle e, uint32_t l, const uint32_t* d_ids, uint32_t n, const float* d_rows, void* stream) {
+    if (!e || l < 1 || l > e->cfg.layers) return SG_EINVAL;
+    if (n == 0) return SG_OK;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = pick(e, stream);
+    Timed t(e, s, 6);
+    hipLaunchKernelGGL(k6_unpack, dim3(grid_for((u64)n * 16, 256)), dim3(256), 0, s, e->d.h[l], d_ids, n, d_rows);
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
+}
+
+int sg_window_outbound_ips(sg_handle e, uint32_t* ips, size_t cap, size_t* n) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (n) *n = e->last_obips.size();
+    if (ips) std::memcpy(ips, e->last_obips.data(), std::min(cap, e->last_obips.size()) * sizeof(u32));
+    return SG_OK;
+}
+
+int sg_stats_get(sg_handle e, sg_stats* out) {
+    if (!e || !out) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    *out = e->st;
+    return SG_OK;
+}
+
+int sg_timing_enable(sg_handle e, int on) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->timing = on == 0 ? 0u : (on == 1 ? ~0u : (unsigned)on);
+    return SG_OK;
+}
+int sg_timing_reset(sg_handle e) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (auto& r : e->trecs) { e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b); }
+    e->trecs.clear();
+    return SG_OK;
+}
+int sg_timing_get(sg_handle e, int kernel, double* avg_us, uint64_t* launches) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    double tot = 0; uint64_t cnt = 0;
+    for (auto& r : e->trecs) if (r.kernel == kernel) {
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += (double)ms * 1000.0; cnt++; }
+    }
+    if (avg_us) *avg_us = cnt ? tot / (double)cnt : 0.0;
+    if (launches) *launches = cnt;
+    return SG_OK;
+}
+
+// Shard an event is routed to: owner of its from-endpoint after the join and the optional
+// ReverseDirection — exactly what K1 checks.  Host-side, uses the host mirror of the join tables.
+int sg_route(sg_handle e, const sg_event* ev, size_t n, uint32_t world, uint32_t* shard_out) {
+    if (!e || (!ev && n) || !shard_out || world == 0) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (size_t i = 0; i < n; i++) {
+        const sg_event& x = ev[i];
+        u32 owner;
+        auto sp = e->pod_ip.find(x.saddr);
+        if (sp == e->pod_ip.end()) { shard_out[i] = sg_fmix32(x.saddr) % world; continue; }   // will be dropped wherever it lands
+        owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, sp->second));
+        if (x.flags & SG_EV_REVERSE) {
+            auto ds = e->svc_ip.find(x.daddr);
+            if (ds != e->svc_ip.end()) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, ds->second));
+            else {
+                auto dp = e->pod_ip.find(x.daddr);
+                if (dp != e->pod_ip.end()) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, dp->second));
+                else if (x.host_label) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_LABEL, x.host_label - 1));
+                else owner = owner_hash_obip(x.daddr);
+            }
+        }
+        shard_out[i] = owner % world;
+    }
+    return SG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// sg_device.h — device-side data layout shared by the kernels and the host engine.
+// gfx950 only (wave64, 160 KiB LDS/CU, 8 XCDs); no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/servicegraph.h"
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+#define SG_NONE       0xFFFFFFFFu
+#define SG_EKEY_EMPTY (~0ull)
+#define SG_WAVE       64
+
+// join-table entry: one 16-byte probe resolves an IP against BOTH reference maps
+// (PodIPToPodUid and ServiceIPToServiceUid, aggregator/cluster.go:13-17).
+struct IpEnt { u32 ip, pod, svc, used; };
+
+// device counters (u64 each)
+enum {
+    C_N_KNOWN = 0,    // set by host before close
+    C_N_LABELS,       // max(host-declared, max label seen)
+    C_N_OBIP,         // distinct raw-IP outbound nodes of the window
+    C_N_EDGES,        // edges of the window (min(found, max_edges))
+    C_N_EVENTS,       // accepted events of the window
+    C_DROPPED_SRC,    // window
+    C_DROPPED_CAP,    // window
+    C_MISROUTED,      // window
+    C_TMIN_NS,        // min write_time_ns over accepted events
+    C_TMAX_NS,
+    C_N_NODES,        // NK + NL + NOB
+    C_EDGES_FOUND,    // edges found in the table before clamping
+    C_HALO_N,
+    C_COUNT = 16
+};
+
+// per-workgroup statistics slots written by K1 (one 64-byte line per workgroup: no cross-WG
+// contention), reduced at window close.
+enum { WS_TMIN = 0, WS_TMAX, WS_MAXLABEL, WS_DROPPED_SRC, WS_DROPPED_CAP, WS_MISROUTED, WS_ACCEPTED, WS_PAD, WS_WORDS };
+#define SG_MAX_K1_WGS 2048
+
+// node statistics words (SUM block), see include/servicegraph.h SG_NODE_STAT_SUM_WORDS
+enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, ST_OUT_SUM, ST_IN_SUM, ST_OUT_SSQ, ST_IN_SSQ };
+
+#define SG_MEAN_SLOTS 16
+
+// Everything the kernels need, passed by value as one kernel argument.
+struct Dev {
+    // ---- persistent across windows ----
+    const IpEnt* iptab; u32 ipmask;
+    const uint8_t* kind;            // [max_known] SG_NODE_POD / SG_NODE_SERVICE
+    u32 max_known, max_labels, max_obip;
+    u32 rank, world;
+    // ---- open window (K1 state) ----
+    u64* ekeys;  u64* eacc;  u32 emask;      // edge table: key, 4 x u64 accumulators per slot
+    u64* obkeys; u32 obmask;                  // outbound-ip table: key = ip | 1<<32, 0 = empty
+    u64* wgstat;                              // [SG_MAX_K1_WGS][WS_WORDS]
+    u64* ctr;                                 // [C_COUNT]
+    u64 max_edges;
+    // ---- closed window ----
+    u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs
+    u32* tile_cnt;  u32* tile_off;            // compaction scratch
+    u32* e_slot;    u32* e_from;  u32* e_to;  // [max_edges] compacted (table order)
+    u32* deg;       u32* rowptr;  u32* cursor;// [ncap+1]
+    u32* col;       u32* cslot;               // [max_edges] CSR order: destination, table slot
+    u32* csr_from;                            // [max_edges] CSR order: source (row id per edge)
+    u32* sort_k;    u32* sort_v;              // [2*max_edges] scratch for rows longer than the LDS sort
+    u64* acc_csr;                             // [max_edges][4]
+    u64* st_sum;    u64* st_max;              // [ncap][10], [ncap][2]
+    float* x0;                                // [ncap][32]
+    float* h[SG_MAX_LAYERS + 1];              // h[l] = output of layer l (l>=1): [ncap][64]
+    float* P; float* Q;                       // [ncap][64]
+    float* efeat;                             // [max_edges][8]
+    float* latz; float* errr;                 // [max_edges]
+    sg_edge_out* rows;                        // [max_edges]
+    const float* W;                           // weights blob
+    u32 ncap; u32 layers;
+};

@@ -1,0 +1,761 @@
+// sg_kernels.h — hand-written gfx950 kernels of the ServiceGraph engine (K1..K6).
+// Included once by servicegraph.hip.  Every kernel is HBM/L2-bound integer or gather work except
+// the per-node dense blocks of K4/K5, which run on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
+#pragma once
+#include "sg_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ u32 sg_fmix32(u32 h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
+}
+__device__ __forceinline__ u32 hash_key64(u64 k) { return sg_fmix32((u32)k ^ sg_fmix32((u32)(k >> 32) + 0x9e3779b9u)); }
+
+// owner shard of a node: by its stable ref; OBIP nodes (window-local indices) by their IP.
+__host__ __device__ __forceinline__ u32 owner_hash_ref(u32 ref) { return sg_fmix32(ref); }
+__host__ __device__ __forceinline__ u32 owner_hash_obip(u32 ip) { return sg_fmix32(ip ^ 0xA5A5F00Du); }
+
+__device__ __forceinline__ bool ip_lookup(const IpEnt* __restrict__ t, u32 mask, u32 ip, u32& pod, u32& svc) {
+    u32 h = sg_fmix32(ip) & mask;
+    for (u32 p = 0; p <= mask; ++p) {
+        const uint4 e = reinterpret_cast<const uint4*>(t)[h];
+        if (!e.w) return false;
+        if (e.x == ip) { pod = e.y; svc = e.z; return true; }
+        h = (h + 1) & mask;
+    }
+    return false;
+}
+
+// find-or-insert in an open-addressing u64 key table.  A plain load may return a stale EMPTY (the
+// XCD L2s are not coherent); every EMPTY observation is confirmed by the device-scope CAS, and a
+// slot never changes once it holds a key, so a non-EMPTY observation is always final.
+__device__ __forceinline__ bool table_slot(u64* keys, u32 mask, u64 key, u64 empty, u32 h, u32& slot) {
+    for (u32 p = 0; p <= mask; ++p) {
+        u64 k = keys[h];
+        if (k == empty) {
+            k = atomicCAS(&keys[h], empty, key);
+            if (k == empty) { slot = h; return true; }
+        }
+        if (k == key) { slot = h; return true; }
+        h = (h + 1) & mask;
+    }
+    return false;
+}
+
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { u64 o = __shfl_xor(v, s, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { u64 o = __shfl_xor(v, s, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// "error" classification: HTTP/HTTP2 >= 500; POSTGRES/REDIS/MYSQL == 2 (ebpf/c/postgres.c:91,
+// redis.c:10, mysql.c:36).
+__device__ __forceinline__ u32 is_error(u32 proto, u32 status) {
+    const bool http = (proto == SG_PROTO_HTTP) | (proto == SG_PROTO_HTTP2);
+    const bool sql = (proto == SG_PROTO_POSTGRES) | (proto == SG_PROTO_REDIS) | (proto == SG_PROTO_MYSQL);
+    return (http & (status >= 500u)) | (sql & (status == 2u)) ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  resolve_aggregate: events -> (from, to) node refs -> edge slot -> integer accumulators.
+// Replaces extractAddressPair + setFromToV2 + ReverseDirection + the per-request PersistRequest
+// (aggregator/data.go:1760-1767, 827-870; datastore/dto.go:226-231; backend.go:819-847).
+// Algorithmic bytes: 32 per event read; accumulators (32 B/edge) are written when the window closes.
+// ------------------------------------------------------------------------------------------------
+struct K1Local { u64 tmin, tmax; u32 maxlabel, dsrc, dcap, misr, acc; };
+
+__device__ __forceinline__ void k1_one(const Dev& d, const uint4 a, const uint4 b, K1Local& L) {
+    const u32 saddr = a.x, daddr = a.y, label = a.z;
+    const u32 status = a.w & 0xFFFFu, proto = (a.w >> 16) & 0xFFu, flags = a.w >> 24;
+    const u64 dur = (u64)b.x | ((u64)b.y << 32), wt = (u64)b.z | ((u64)b.w << 32);
+
+    u32 spod = SG_NONE, ssvc = SG_NONE;
+    const bool sf = ip_lookup(d.iptab, d.ipmask, saddr, spod, ssvc);
+    if (!sf || spod == SG_NONE) { L.dsrc++; return; }           // data.go:829-832: source must be a pod
+    u32 from = SG_MAKE_REF(SG_REF_KNOWN, spod);
+    u32 from_owner = owner_hash_ref(from);
+
+    u32 dpod = SG_NONE, dsvc = SG_NONE, to, to_owner;
+    const bool df = ip_lookup(d.iptab, d.ipmask, daddr, dpod, dsvc);
+    if (df && dsvc != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dsvc); to_owner = owner_hash_ref(to); }       // service first (:840-843)
+    else if (df && dpod != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dpod); to_owner = owner_hash_ref(to); }  // then pod (:845-849)
+    else if (label != 0) {                                       // outbound, Host header (:851-854)
+        if (label > d.max_labels) { L.dcap++; return; }
+        to = SG_MAKE_REF(SG_REF_LABEL, label - 1); to_owner = owner_hash_ref(to);
+        L.maxlabel = label > L.maxlabel ? label : L.maxlabel;
+    } else {                                                     // outbound, raw IP (:862-863)
+        u32 os;
+        if (!table_slot(d.obkeys, d.obmask, (u64)daddr | (1ull << 32), 0ull, sg_fmix32(daddr) & d.obmask, os)) { L.dcap++; return; }
+        to = SG_MAKE_REF(SG_REF_OBIP, os); to_owner = owner_hash_obip(daddr);
+    }
+    if (flags & SG_EV_REVERSE) { u32 t = from; from = to; to = t; t = from_owner; from_owner = to_owner; to_owner = t; }  // dto.go:226-231
+    if (d.world > 1 && (from_owner % d.world) != d.rank) { L.misr++; return; }
+
+    const u64 key = ((u64)from << 32) | (u64)to;
+    u32 slot;
+    if (!table_slot(d.ekeys, d.emask, key, SG_EKEY_EMPTY, hash_key64(key) & d.emask, slot)) { L.dcap++; return; }
+    u64* acc = d.eacc + (size_t)slot * 4;
+    const u64 us = dur / 1000ull;
+    atomicAdd(&acc[0], 1ull | ((u64)is_error(proto, status) << 32));
+    atomicAdd(&acc[1], dur);
+    atomicMax(&acc[2], dur);
+    atomicAdd(&acc[3], us * us);
+    L.acc++;
+    L.tmin = wt < L.tmin ? wt : L.tmin;
+    L.tmax = wt > L.tmax ? wt : L.tmax;
+}
+
+__global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_event* __restrict__ ev, u64 n) {
+    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
+    const uint4* __restrict__ p = reinterpret_cast<const uint4*>(ev);
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint4 a = p[2 * i], b = p[2 * i + 1];
+        k1_one(d, a, b, L);
+    }
+    // per-workgroup statistics: wave reduce, then one update of this workgroup's private line
+    const u64 tmin = wave_min_u64(L.tmin), tmax = wave_max_u64(L.tmax);
+    const u32 ml = (u32)wave_max_u64(L.maxlabel);
+    const u32 ds = wave_sum_u32(L.dsrc), dc = wave_sum_u32(L.dcap), mr = wave_sum_u32(L.misr), ac = wave_sum_u32(L.acc);
+    if ((threadIdx.x & 63) == 0) {
+        u64* w = d.wgstat + (size_t)(blockIdx.x % SG_MAX_K1_WGS) * WS_WORDS;
+        if (ac) { atomicMin(&w[WS_TMIN], tmin); atomicMax(&w[WS_TMAX], tmax); atomicAdd(&w[WS_ACCEPTED], (u64)ac); }
+        if (ml) atomicMax(&w[WS_MAXLABEL], (u64)ml);
+        if (ds) atomicAdd(&w[WS_DROPPED_SRC], (u64)ds);
+        if (dc) atomicAdd(&w[WS_DROPPED_CAP], (u64)dc);
+        if (mr) atomicAdd(&w[WS_MISROUTED], (u64)mr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  csr_build: canonical node numbering, edge compaction, CSR with sorted rows.
+// ------------------------------------------------------------------------------------------------
+
+// one workgroup: fold the per-workgroup K1 statistics into the counters and re-arm the slots.
+__global__ __launch_bounds__(256) void k2_reduce_wgstat(Dev d, u64 n_known, u64 n_labels_decl) {
+    u64 tmin = ~0ull, tmax = 0, ml = 0, ds = 0, dc = 0, mr = 0, ac = 0;
+    for (u32 i = threadIdx.x; i < SG_MAX_K1_WGS; i += 256) {
+        u64* w = d.wgstat + (size_t)i * WS_WORDS;
+        tmin = w[WS_TMIN] < tmin ? w[WS_TMIN] : tmin; tmax = w[WS_TMAX] > tmax ? w[WS_TMAX] : tmax;
+        ml = w[WS_MAXLABEL] > ml ? w[WS_MAXLABEL] : ml;
+        ds += w[WS_DROPPED_SRC]; dc += w[WS_DROPPED_CAP]; mr += w[WS_MISROUTED]; ac += w[WS_ACCEPTED];
+        w[WS_TMIN] = ~0ull; w[WS_TMAX] = 0; w[WS_MAXLABEL] = 0; w[WS_DROPPED_SRC] = 0; w[WS_DROPPED_CAP] = 0; w[WS_MISROUTED] = 0; w[WS_ACCEPTED] = 0;
+    }
+    __shared__ u64 s[7][4];
+    tmin = wave_min_u64(tmin); tmax = wave_max_u64(tmax); ml = wave_max_u64(ml);
+    ds = wave_sum_u64(ds); dc = wave_sum_u64(dc); mr = wave_sum_u64(mr); ac = wave_sum_u64(ac);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s[0][w] = tmin; s[1][w] = tmax; s[2][w] = ml; s[3][w] = ds; s[4][w] = dc; s[5][w] = mr; s[6][w] = ac; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) {
+            s[0][0] = s[0][k] < s[0][0] ? s[0][k] : s[0][0]; s[1][0] = s[1][k] > s[1][0] ? s[1][k] : s[1][0];
+            s[2][0] = s[2][k] > s[2][0] ? s[2][k] : s[2][0]; s[3][0] += s[3][k]; s[4][0] += s[4][k]; s[5][0] += s[5][k]; s[6][0] += s[6][k];
+        }
+        d.ctr[C_TMIN_NS] = s[0][0]; d.ctr[C_TMAX_NS] = s[1][0];
+        u64 nl = d.ctr[C_N_LABELS];                          // labels are cumulative across windows
+        nl = s[2][0] > nl ? s[2][0] : nl; nl = n_labels_decl > nl ? n_labels_decl : nl;
+        d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known;
+        d.ctr[C_DROPPED_SRC] = s[3][0]; d.ctr[C_DROPPED_CAP] = s[4][0]; d.ctr[C_MISROUTED] = s[5][0]; d.ctr[C_N_EVENTS] = s[6][0];
+    }
+}
+
+// one workgroup (1024 threads): collect the distinct raw outbound IPs of the window.
+__global__ __launch_bounds__(1024) void k2_ob_collect(Dev d, u32* list, u32 list_cap, u32* n_out) {
+    __shared__ u32 cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i <= d.obmask; i += 1024) {
+        const u64 k = d.obkeys[i];
+        if (k) { const u32 pos = atomicAdd(&cnt, 1u); if (pos < list_cap) list[pos] = (u32)k; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *n_out = cnt < list_cap ? cnt : list_cap;
+}
+
+// one workgroup (1024 threads): sort list[0..*n_in) ascending (bitonic, in global memory), drop
+// duplicates, write the result to d.ob_sorted and its length to ctr[C_N_OBIP]; finalise N.
+__global__ __launch_bounds__(1024) void k2_ob_sort_unique(Dev d, u32* list, const u32* n_in, u32 cap_pow2) {
+    const u32 n = *n_in;
+    u32 np = 1; while (np < n) np <<= 1;
+    if (np > cap_pow2) np = cap_pow2;
+    for (u32 i = n + threadIdx.x; i < np; i += 1024) list[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 k = 2; k <= np; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 i = threadIdx.x; i < np; i += 1024) {
+                const u32 x = i ^ j;
+                if (x > i) {
+                    const u32 a = list[i], b = list[x];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { list[i] = b; list[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // unique: count of distinct predecessors gives the output position (n is small: raw-IP outbound)
+    __shared__ u32 total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    // sequential chunks keep the output ordered
+    __shared__ u32 chunk_cnt[1024];
+    const u32 per = (n + 1023) / 1024;
+    const u32 beg = threadIdx.x * per, end = (beg + per < n) ? beg + per : n;
+    u32 c = 0;
+    for (u32 i = beg; i < end; i++) c += (i == 0 || list[i] != list[i - 1]) ? 1u : 0u;
+    chunk_cnt[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 run = 0; for (u32 t = 0; t < 1024; t++) { const u32 v = chunk_cnt[t]; chunk_cnt[t] = run; run += v; } total = run; }
+    __syncthreads();
+    u32 pos = chunk_cnt[threadIdx.x];
+    for (u32 i = beg; i < end; i++) if (i == 0 || list[i] != list[i - 1]) { if (pos < d.max_obip) d.ob_sorted[pos] = list[i]; pos++; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 nob = total < d.max_obip ? total : d.max_obip;
+        d.ctr[C_N_OBIP] = nob;
+        d.ctr[C_N_NODES] = d.ctr[C_N_KNOWN] + d.ctr[C_N_LABELS] + nob;
+    }
+}
+
+__device__ __forceinline__ u32 lower_bound_u32(const u32* a, u32 n, u32 v) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+// canonical dense index of a node ref: KNOWN ids, then LABEL ids, then OBIP by ascending IP.
+__device__ __forceinline__ u32 dense_of(const Dev& d, u32 ref, u32 nk, u32 nl, u32 nob) {
+    const u32 t = SG_REF_TYPE(ref), v = SG_REF_VALUE(ref);
+    if (t == SG_REF_KNOWN) return v;
+    if (t == SG_REF_LABEL) return nk + v;
+    const u32 ip = (u32)d.obkeys[v];
+    return nk + nl + lower_bound_u32(d.ob_sorted, nob, ip);
+}
+__device__ __forceinline__ u32 ref_of_dense(u32 v, u32 nk, u32 nl) {
+    if (v < nk) return SG_MAKE_REF(SG_REF_KNOWN, v);
+    if (v < nk + nl) return SG_MAKE_REF(SG_REF_LABEL, v - nk);
+    return SG_MAKE_REF(SG_REF_OBIP, v - nk - nl);
+}
+__device__ __forceinline__ u32 owner_of_dense(const Dev& d, u32 v, u32 nk, u32 nl) {
+    if (v < nk + nl) return owner_hash_ref(ref_of_dense(v, nk, nl)) % d.world;
+    return owner_hash_obip(d.ob_sorted[v - nk - nl]) % d.world;
+}
+
+#define K2_TILE 2048   // table slots per workgroup (256 threads x 8)
+
+__global__ __launch_bounds__(256) void k2_edge_count(Dev d) {
+    const u32 tile = blockIdx.x;
+    const u64* __restrict__ k = d.ekeys + (size_t)tile * K2_TILE + threadIdx.x * 8;
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) c += k[j] != SG_EKEY_EMPTY;
+    c = wave_sum_u32(c);
+    __shared__ u32 s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) d.tile_cnt[tile] = s[0] + s[1] + s[2] + s[3];
+}
+
+// one workgroup: exclusive scan of the tile counts.
+__global__ __launch_bounds__(1024) void k2_scan_tiles(Dev d, u32 ntiles) {
+    __shared__ u32 part[1024];
+    const u32 per = (ntiles + 1023) / 1024;
+    const u32 beg = threadIdx.x * per, end = beg + per < ntiles ? beg + per : ntiles;
+    u32 c = 0;
+    for (u32 i = beg; i < end; i++) c += d.tile_cnt[i];
+    part[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 run = 0;
+        for (u32 t = 0; t < 1024; t++) { const u32 v = part[t]; part[t] = (u32)run; run += v; }
+        d.ctr[C_EDGES_FOUND] = run;
+        d.ctr[C_N_EDGES] = run < d.max_edges ? run : d.max_edges;
+    }
+    __syncthreads();
+    u32 run = part[threadIdx.x];
+    for (u32 i = beg; i < end; i++) { const u32 v = d.tile_cnt[i]; d.tile_off[i] = run; run += v; }
+}
+
+// compaction in ascending slot order (deterministic), dense endpoints, out-degree histogram.
+__global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
+    const u32 tile = blockIdx.x;
+    if (d.tile_cnt[tile] == 0) return;
+    const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
+    const u32 base_slot = tile * K2_TILE + threadIdx.x * 8;
+    u64 k[8]; u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { k[j] = d.ekeys[(size_t)base_slot + j]; c += k[j] != SG_EKEY_EMPTY; }
+    // block exclusive scan of c
+    __shared__ u32 wsum[4];
+    u32 incl = c;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const u32 o = __shfl_up(incl, s, 64); if ((int)(threadIdx.x & 63) >= s) incl += o; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 w = 0; w < (threadIdx.x >> 6); w++) woff += wsum[w];
+    u64 pos = (u64)d.tile_off[tile] + woff + incl - c;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (k[j] != SG_EKEY_EMPTY) {
+        if (pos < d.max_edges) {
+            const u32 f = dense_of(d, (u32)(k[j] >> 32), nk, nl, nob), t = dense_of(d, (u32)k[j], nk, nl, nob);
+            d.e_slot[pos] = base_slot + j; d.e_from[pos] = f; d.e_to[pos] = t;
+            atomicAdd(&d.deg[f], 1u);
+        }
+        pos++;
+    }
+}
+
+// one workgroup: rowptr = exclusive scan of deg[0..N); rowptr[N] = E.
+__global__ __launch_bounds__(1024) void k2_rowptr(Dev d) {
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    __shared__ u32 part[1024];
+    const u32 per = (N + 1023) / 1024;
+    const u32 beg = threadIdx.x * per, end = beg + per < N ? beg + per : N;
+    u32 c = 0;
+    for (u32 i = beg; i < end; i++) c += d.deg[i];
+    part[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 run = 0; for (u32 t = 0; t < 1024; t++) { const u32 v = part[t]; part[t] = run; run += v; } d.rowptr[N] = run; }
+    __syncthreads();
+    u32 run = part[threadIdx.x];
+    for (u32 i = beg; i < end; i++) { d.rowptr[i] = run; run += d.deg[i]; }
+}
+
+__global__ __launch_bounds__(256) void k2_scatter(Dev d) {
+    const u32 E = (u32)d.ctr[C_N_EDGES];
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < E; i += gridDim.x * 256) {
+        const u32 f = d.e_from[i];
+        const u32 pos = d.rowptr[f] + atomicAdd(&d.cursor[f], 1u);
+        d.col[pos] = d.e_to[i]; d.cslot[pos] = d.e_slot[i]; d.csr_from[pos] = f;
+    }
+}
+
+#define K2_SORT_LDS 4096
+// one workgroup per row: sort the row by destination (keys are distinct), carrying the slot.
+__global__ __launch_bounds__(256) void k2_rowsort(Dev d) {
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
+    for (u32 r = blockIdx.x; r < N; r += gridDim.x) {
+        const u32 beg = d.rowptr[r], n = d.rowptr[r + 1] - beg;
+        if (n <= 1) continue;
+        u32* key = d.col + beg; u32* val = d.cslot + beg;
+        if (n <= 64) {
+            if (threadIdx.x < 64) {
+                const u32 l = threadIdx.x;
+                const u32 k = l < n ? key[l] : 0xFFFFFFFFu, v = l < n ? val[l] : 0;
+                u32 rank = 0;
+                for (u32 j = 0; j < n; j++) rank += __shfl(k, (int)j, 64) < k;
+                if (l < n) { key[rank] = k; val[rank] = v; }
+            }
+        } else if (n <= K2_SORT_LDS) {
+            u32 np = 1; while (np < n) np <<= 1;
+            for (u32 i = threadIdx.x; i < np; i += 256) { sk[i] = i < n ? key[i] : 0xFFFFFFFFu; sv[i] = i < n ? val[i] : 0; }
+            __syncthreads();
+            for (u32 k = 2; k <= np; k <<= 1)
+                for (u32 j = k >> 1; j > 0; j >>= 1) {
+                    for (u32 i = threadIdx.x; i < np; i += 256) {
+                        const u32 x = i ^ j;
+                        if (x > i) {
+                            const u32 a = sk[i], b = sk[x];
+                            if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[x] = a; const u32 t = sv[i]; sv[i] = sv[x]; sv[x] = t; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (u32 i = threadIdx.x; i < n; i += 256) { key[i] = sk[i]; val[i] = sv[i]; }
+        } else {
+            // very long row (> LDS capacity): bitonic sort in a private, power-of-two padded slice of
+            // the global scratch (offset 2*beg: slices of different rows never overlap).
+            u32 np = 1; while (np < n) np <<= 1;
+            u32* gk = d.sort_k + 2 * (size_t)beg; u32* gv = d.sort_v + 2 * (size_t)beg;
+            for (u32 i = threadIdx.x; i < np; i += 256) { gk[i] = i < n ? key[i] : 0xFFFFFFFFu; gv[i] = i < n ? val[i] : 0; }
+            __syncthreads();
+            for (u32 k = 2; k <= np; k <<= 1)
+                for (u32 j = k >> 1; j > 0; j >>= 1) {
+                    for (u32 i = threadIdx.x; i < np; i += 256) {
+                        const u32 x = i ^ j;
+                        if (x > i) {
+                            const u32 a = gk[i], b = gk[x];
+                            if ((a > b) == ((i & k) == 0)) { gk[i] = b; gk[x] = a; const u32 t = gv[i]; gv[i] = gv[x]; gv[x] = t; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (u32 i = threadIdx.x; i < n; i += 256) { key[i] = gk[i]; val[i] = gv[i]; }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  node_features: accumulators -> CSR order, integer node statistics, fp32 features.
+// ------------------------------------------------------------------------------------------------
+
+// thread per CSR position: move the accumulator into CSR order, clear the table slot (this is the
+// window reset of the edge table), and add the edge into its destination's in-statistics.
+__global__ __launch_bounds__(256) void k3_gather(Dev d) {
+    const u32 E = (u32)d.ctr[C_N_EDGES];
+    for (u32 pos = blockIdx.x * 256 + threadIdx.x; pos < E; pos += gridDim.x * 256) {
+        const u32 slot = d.cslot[pos];
+        ulonglong2* src = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)slot * 4);
+        const ulonglong2 a = src[0], b = src[1];
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)pos * 4);
+        dst[0] = a; dst[1] = b;
+        src[0] = make_ulonglong2(0, 0); src[1] = make_ulonglong2(0, 0);
+        d.ekeys[slot] = SG_EKEY_EMPTY;
+        const u64 cnt = a.x & 0xFFFFFFFFull, err = a.x >> 32;
+        u64* t = d.st_sum + (size_t)d.col[pos] * SG_NODE_STAT_SUM_WORDS;
+        atomicAdd(&t[ST_IN_DEG], 1ull); atomicAdd(&t[ST_IN_CNT], cnt); atomicAdd(&t[ST_IN_ERR], err);
+        atomicAdd(&t[ST_IN_SUM], a.y); atomicAdd(&t[ST_IN_SSQ], b.y);
+        atomicMax(&d.st_max[(size_t)d.col[pos] * 2 + 1], b.x);
+    }
+}
+
+// wave per row: out-statistics by a plain reduction over the row (no atomics; one wave owns a row).
+__global__ __launch_bounds__(256) void k3_out_stats(Dev d) {
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    const u32 lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    for (u32 r = wave; r < N; r += nw) {
+        const u32 beg = d.rowptr[r], end = d.rowptr[r + 1];
+        if (beg == end) continue;
+        u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
+        for (u32 p = beg + lane; p < end; p += 64) {
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
+            const ulonglong2 x = a[0], y = a[1];
+            cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
+        }
+        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+        if (lane == 0) {
+            u64* t = d.st_sum + (size_t)r * SG_NODE_STAT_SUM_WORDS;
+            t[ST_OUT_DEG] = end - beg; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+            d.st_max[(size_t)r * 2] = mx;
+        }
+    }
+}
+
+__device__ __forceinline__ double mean_us(u64 sum_ns, u64 cnt) { return cnt ? ((double)sum_ns / 1000.0) / (double)cnt : 0.0; }
+__device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
+    if (!cnt) return 0.0;
+    const double m = mean_us(sum_ns, cnt);
+    const double v = (double)ssq_us / (double)cnt - m * m;
+    return v > 0.0 ? sqrt(v) : 0.0;
+}
+
+// thread per node: x_v (DESIGN.md "node features"); fp64 intermediates, one rounding to fp32.
+__global__ __launch_bounds__(256) void k3_node_features(Dev d) {
+    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN];
+    for (u32 v = blockIdx.x * 256 + threadIdx.x; v < N; v += gridDim.x * 256) {
+        const u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS; const u64* mx = d.st_max + (size_t)v * 2;
+        const u32 kind = v < nk ? d.kind[v] : 0u;
+        const u64 oc = s[ST_OUT_CNT], ic = s[ST_IN_CNT];
+        float x[SG_F_IN];
+#pragma unroll
+        for (int k = 0; k < (int)SG_F_IN; k++) x[k] = 0.0f;
+        x[0] = (float)log1p((double)s[ST_OUT_DEG]);
+        x[1] = (float)log1p((double)s[ST_IN_DEG]);
+        x[2] = (float)log1p((double)oc);
+        x[3] = (float)log1p((double)ic);
+        x[4] = (float)log1p(mean_us(s[ST_OUT_SUM], oc) / 1000.0);
+        x[5] = (float)log1p(mean_us(s[ST_IN_SUM], ic) / 1000.0);
+        x[6] = oc ? (float)((double)s[ST_OUT_ERR] / (double)oc) : 0.0f;
+        x[7] = ic ? (float)((double)s[ST_IN_ERR] / (double)ic) : 0.0f;
+        x[8] = (float)log1p((double)mx[0] / 1e6);
+        x[9] = (float)log1p((double)mx[1] / 1e6);
+        x[10] = kind == SG_NODE_POD ? 1.0f : 0.0f;
+        x[11] = kind == SG_NODE_SERVICE ? 1.0f : 0.0f;
+        x[12] = kind == 0 ? 1.0f : 0.0f;
+        x[13] = (float)log1p(std_us(s[ST_OUT_SUM], s[ST_OUT_SSQ], oc) / 1000.0);
+        x[14] = (float)log1p(std_us(s[ST_IN_SUM], s[ST_IN_SSQ], ic) / 1000.0);
+        x[15] = 1.0f;
+        float4* o = reinterpret_cast<float4*>(d.x0 + (size_t)v * SG_F_IN);
+#pragma unroll
+        for (int q = 0; q < (int)SG_F_IN / 4; q++) o[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    }
+}
+
+// thread per edge: e_uv, lat_z, err_ratio.
+__global__ __launch_bounds__(256) void k3_edge_features(Dev d) {
+    const u32 E = (u32)d.ctr[C_N_EDGES];
+    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < E; p += gridDim.x * 256) {
+        const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
+        const ulonglong2 x = a[0], y = a[1];
+        const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
+        const u64* su = d.st_sum + (size_t)d.csr_from[p] * SG_NODE_STAT_SUM_WORDS;
+        const double m_e = mean_us(sum, cnt), s_e = std_us(sum, ssq, cnt);
+        const double mu = mean_us(su[ST_OUT_SUM], su[ST_OUT_CNT]), sd = std_us(su[ST_OUT_SUM], su[ST_OUT_SSQ], su[ST_OUT_CNT]);
+        const double z = (m_e - mu) / (sd > 1.0 ? sd : 1.0);
+        const float lat_z = (float)z;
+        const float err_ratio = cnt ? (float)((double)err / (double)cnt) : 0.0f;
+        const float zc = lat_z < -8.0f ? -8.0f : (lat_z > 8.0f ? 8.0f : lat_z);
+        float4* e = reinterpret_cast<float4*>(d.efeat + (size_t)p * SG_F_EDGE);
+        e[0] = make_float4((float)log1p((double)cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
+        e[1] = make_float4(err_ratio, (float)log1p((double)err), zc * 0.125f, 1.0f);
+        d.latz[p] = lat_z; d.errr[p] = err_ratio;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  sage_layer: h'_v = ReLU(b + h_v Ws + mean_{u in N_out(v)} h_u Wn)  on 16-node tiles.
+//   gather-mean : one wave per node, lanes across features, 16 interleaved partial sums in the
+//                 canonical order (neighbour i -> slot i % 16; slots combined 0..15; / deg).
+//   dense       : 4 waves x v_mfma_f32_16x16x4_f32, k-ordered chain == the oracle's fmaf chain.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D[16 x 16] (+)= A[16 x K] * B[K x 16 cols jb..jb+15], C initialised with bias.  A in LDS (row
+// stride lda), B = W[K][64] in global memory.  lane l: A[l&15][k=l>>4], B[k=l>>4][l&15];
+// D reg r -> row (l>>4)*4 + r, col l&15.
+template <int K>
+__device__ __forceinline__ f32x4 dense_tile_mfma(const float* A, int lda, const float* __restrict__ W, int jb, f32x4 c) {
+    const int l = threadIdx.x & 63, i = l & 15, kq = l >> 4;
+#pragma unroll 4
+    for (int kb = 0; kb < K / 4; kb++) {
+        const float a = A[i * lda + kb * 4 + kq];
+        const float b = W[(size_t)(kb * 4 + kq) * SG_F_HID + jb + i];
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    return c;
+}
+
+// gather-mean of one node into dst[0..FI): executed by one wave.
+template <int FI>
+__device__ __forceinline__ void gather_mean(const Dev& d, const float* __restrict__ hin, u32 v, float* dst) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 beg = d.rowptr[v], deg = d.rowptr[v + 1] - beg;
+    const u32* __restrict__ nb = d.col + beg;
+    if (FI == 32) {
+        const u32 g = lane >> 5, k = lane & 31;
+        float acc[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) acc[a] = 0.0f;
+        for (u32 i0 = 0; i0 < deg; i0 += 16) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                const u32 i = i0 + 2 * a + g;                    // slot = i % 16 = 2a + g
+                if (i < deg) acc[a] = acc[a] + hin[(size_t)nb[i] * 32 + k];
+            }
+        }
+        float t = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const float o = __shfl_xor(acc[a], 32, 64);
+            const float even = g == 0 ? acc[a] : o, odd = g == 0 ? o : acc[a];
+            t = a == 0 ? even : t + even;
+            t = t + odd;
+        }
+        if (g == 0) dst[k] = deg ? t / (float)deg : 0.0f;
+    } else {
+        float acc[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) acc[a] = 0.0f;
+        for (u32 i0 = 0; i0 < deg; i0 += 16) {
+#pragma unroll
+            for (int a = 0; a < 16; a++) {
+                const u32 i = i0 + a;
+                if (i < deg) acc[a] = acc[a] + hin[(size_t)nb[i] * 64 + lane];
+            }
+        }
+        float t = acc[0];
+#pragma unroll
+        for (int a = 1; a < 16; a++) t = t + acc[a];
+        dst[lane] = deg ? t / (float)deg : 0.0f;
+    }
+}
+
+template <int FI, bool USE_MFMA>
+__global__ __launch_bounds__(256) void k4_sage_layer(Dev d, const float* __restrict__ hin, float* __restrict__ hout, const float* __restrict__ Wl) {
+    constexpr int LDA = 2 * FI + 2;                               // +2 floats: conflict-free A-fragment reads
+    __shared__ float A[16 * LDA];
+    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* __restrict__ bias = Wl + 2 * FI * SG_F_HID;
+    for (u32 tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
+        const u32 v0 = tile * 16;
+        __shared__ u32 skip[16];
+        // phase 1: self row + gather-mean, 4 nodes per wave
+        for (u32 q = 0; q < 4; q++) {
+            const u32 r = wave * 4 + q, v = v0 + r;
+            float* row = A + r * LDA;
+            bool sk = v >= N;
+            if (!sk && d.world > 1) {
+                const bool has_out = d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0;
+                sk = has_out && owner_of_dense(d, v, nk, nl) != d.rank;   // computed by its owner, arrives by halo exchange
+            }
+            if (lane == 0) skip[r] = sk ? 1u : 0u;
+            if (sk) { for (u32 k = lane; k < 2 * FI; k += 64) row[k] = 0.0f; continue; }
+            for (u32 k = lane; k < FI; k += 64) row[k] = hin[(size_t)v * FI + k];
+            gather_mean<FI>(d, hin, v, row + FI);
+        }
+        __syncthreads();
+        // phase 2: dense 16 x 64, wave w -> columns 16w..16w+15
+        if (USE_MFMA) {
+            const int jb = wave * 16, i = lane & 15;
+            const float bj = bias[jb + i];
+            f32x4 c = { bj, bj, bj, bj };
+            c = dense_tile_mfma<2 * FI>(A, LDA, Wl, jb, c);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const u32 row = (lane >> 4) * 4 + r;
+                if (!skip[row]) hout[(size_t)(v0 + row) * SG_F_HID + jb + i] = c[r] > 0.0f ? c[r] : 0.0f;
+            }
+        } else {
+            const u32 row = threadIdx.x >> 4, jq = (threadIdx.x & 15) * 4;
+            float acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = bias[jq + c];
+            for (int k = 0; k < 2 * FI; k++) {
+                const float a = A[row * LDA + k];
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c] = fmaf(a, Wl[(size_t)k * SG_F_HID + jq + c], acc[c]);
+            }
+            if (!skip[row])
+#pragma unroll
+                for (int c = 0; c < 4; c++) hout[(size_t)(v0 + row) * SG_F_HID + jq + c] = acc[c] > 0.0f ? acc[c] : 0.0f;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  edge_score: P = b1 + h Wu, Q = h Wv per node (MFMA), then per edge
+//     s = sigmoid(b2 + tree_sum_j( ReLU(P[u][j] + Q[v][j] + sum_k e[k] We[k][j]) * w2[j] )).
+// ------------------------------------------------------------------------------------------------
+template <bool USE_MFMA>
+__global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restrict__ hL, const float* __restrict__ Wh) {
+    constexpr int LDA = SG_F_HID + 2;
+    __shared__ float A[16 * LDA];
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    const float* __restrict__ Wu = Wh; const float* __restrict__ Wv = Wh + SG_F_HID * SG_F_HID;
+    const float* __restrict__ b1 = Wv + SG_F_HID * SG_F_HID + SG_F_EDGE * SG_F_HID;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (u32 tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
+        const u32 v0 = tile * 16;
+        for (u32 idx = threadIdx.x; idx < 16 * SG_F_HID; idx += 256) {
+            const u32 r = idx >> 6, k = idx & 63;
+            A[r * LDA + k] = (v0 + r < N) ? hL[(size_t)(v0 + r) * SG_F_HID + k] : 0.0f;
+        }
+        __syncthreads();
+        if (USE_MFMA) {
+            const int jb = wave * 16, i = lane & 15;
+            const float bj = b1[jb + i];
+            f32x4 p = { bj, bj, bj, bj }, q = { 0.0f, 0.0f, 0.0f, 0.0f };
+            p = dense_tile_mfma<SG_F_HID>(A, LDA, Wu, jb, p);
+            q = dense_tile_mfma<SG_F_HID>(A, LDA, Wv, jb, q);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const u32 row = (lane >> 4) * 4 + r;
+                if (v0 + row < N) { d.P[(size_t)(v0 + row) * SG_F_HID + jb + i] = p[r]; d.Q[(size_t)(v0 + row) * SG_F_HID + jb + i] = q[r]; }
+            }
+        } else {
+            const u32 row = threadIdx.x >> 4, jq = (threadIdx.x & 15) * 4;
+            float p[4], q[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { p[c] = b1[jq + c]; q[c] = 0.0f; }
+            for (int k = 0; k < (int)SG_F_HID; k++) {
+                const float a = A[row * LDA + k];
+#pragma unroll
+                for (int c = 0; c < 4; c++) { p[c] = fmaf(a, Wu[(size_t)k * SG_F_HID + jq + c], p[c]); q[c] = fmaf(a, Wv[(size_t)k * SG_F_HID + jq + c], q[c]); }
+            }
+            if (v0 + row < N)
+#pragma unroll
+                for (int c = 0; c < 4; c++) { d.P[(size_t)(v0 + row) * SG_F_HID + jq + c] = p[c]; d.Q[(size_t)(v0 + row) * SG_F_HID + jq + c] = q[c]; }
+        }
+        __syncthreads();
+    }
+}
+
+// wave per edge, lane = hidden unit j.
+__global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
+    const u32 E = (u32)d.ctr[C_N_EDGES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    const float* __restrict__ We = Wh + 2 * SG_F_HID * SG_F_HID;
+    const float* __restrict__ w2 = We + SG_F_EDGE * SG_F_HID + SG_F_HID;
+    const float b2 = w2[SG_F_HID];
+    const u32 lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    float we[SG_F_EDGE];
+#pragma unroll
+    for (int k = 0; k < (int)SG_F_EDGE; k++) we[k] = We[k * SG_F_HID + lane];
+    const float w2j = w2[lane];
+    for (u32 p = wave; p < E; p += nw) {
+        const u32 u = d.csr_from[p], v = d.col[p];
+        float t = d.P[(size_t)u * SG_F_HID + lane] + d.Q[(size_t)v * SG_F_HID + lane];
+        const float ev = lane < SG_F_EDGE ? d.efeat[(size_t)p * SG_F_EDGE + lane] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < (int)SG_F_EDGE; k++) t = fmaf(__shfl(ev, k, 64), we[k], t);
+        t = t > 0.0f ? t : 0.0f;
+        float r = t * w2j;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) r = r + __shfl_xor(r, s, 64);
+        if (lane == 0) {
+            const float logit = r + b2;
+            const float score = 1.0f / (1.0f + expf(-logit));
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
+            const ulonglong2 x = a[0], y = a[1];
+            sg_edge_out o;
+            o.sum_ns = x.y; o.max_ns = y.x; o.sumsq_us = y.y;
+            o.from_ref = ref_of_dense(u, nk, nl); o.to_ref = ref_of_dense(v, nk, nl);
+            o.count = (u32)(x.x & 0xFFFFFFFFull); o.err_count = (u32)(x.x >> 32);
+            o.score = score; o.lat_z = d.latz[p]; o.err_ratio = d.errr[p]; o._pad = 0;
+            d.rows[p] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  halo: which remote rows this shard needs, and pack / unpack of feature rows.
+// ------------------------------------------------------------------------------------------------
+// thread per node: v is in the halo if it is the destination of a local edge (local in-degree > 0
+// is tracked in `cursor`, reused as a mark array), is not owned here, and has out-edges somewhere.
+__global__ __launch_bounds__(256) void k6_halo_mark(Dev d) {
+    const u32 E = (u32)d.ctr[C_N_EDGES];
+    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < E; p += gridDim.x * 256) d.cursor[d.col[p]] = 0xFFFFFFFFu;
+}
+__global__ __launch_bounds__(256) void k6_halo_build(Dev d, u32* ids, u32 cap, u32* n_out) {
+    // single workgroup, ordered output (ascending dense id) so that every run produces the same list
+    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    __shared__ u32 part[256];
+    const u32 per = (N + 255) / 256, beg = threadIdx.x * per, end = beg + per < N ? beg + per : N;
+    u32 c = 0;
+    for (u32 v = beg; v < end; v++) {
+        const bool need = d.cursor[v] == 0xFFFFFFFFu && d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0 && owner_of_dense(d, v, nk, nl) != d.rank;
+        c += need;
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 run = 0; for (int t = 0; t < 256; t++) { const u32 x = part[t]; part[t] = run; run += x; } *n_out = run < cap ? run : cap; }
+    __syncthreads();
+    u32 pos = part[threadIdx.x];
+    for (u32 v = beg; v < end; v++) {
+        const bool need = d.cursor[v] == 0xFFFFFFFFu && d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0 && owner_of_dense(d, v, nk, nl) != d.rank;
+        if (need) { if (pos < cap) ids[pos] = v; pos++; }
+    }
+}
+// rows[i][:] = feat[ids[i]][:]   (16 lanes x float4 per 64-float row)
+__global__ __launch_bounds__(256) void k6_pack(const float* __restrict__ feat, const u32* __restrict__ ids, u32 n, float* __restrict__ rows) {
+    for (u32 t = blockIdx.x * 256 + threadIdx.x; t < n * 16; t += gridDim.x * 256) {
+        const u32 i = t >> 4, q = t & 15;
+        reinterpret_cast<float4*>(rows)[(size_t)i * 16 + q] = reinterpret_cast<const float4*>(feat)[(size_t)ids[i] * 16 + q];
+    }
+}
+__global__ __launch_bounds__(256) void k6_unpack(float* __restrict__ feat, const u32* __restrict__ ids, u32 n, const float* __restrict__ rows) {
+    for (u32 t = blockIdx.x * 256 + threadIdx.x; t < n * 16; t += gridDim.x * 256) {
+        const u32 i = t >> 4, q = t & 15;
+        reinterpret_cast<float4*>(feat)[(size_t)ids[i] * 16 + q] = reinterpret_cast<const float4*>(rows)[(size_t)i * 16 + q];
+    }
+}

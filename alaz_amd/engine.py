@@ -1,0 +1,246 @@
+"""ctypes front end of libservicegraph.so (the C ABI of include/servicegraph.h).
+
+This module is plumbing: it owns no algorithm.  Every result it returns was produced by the HIP
+kernels behind the C ABI.  If the library is missing, or no gfx950 device is usable, it raises —
+there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .replay import EDGE_OUT_DTYPE, EVENT_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libservicegraph.so")
+
+SG_OK, SG_EINVAL, SG_ENOMEM, SG_ENODEV, SG_ENOSPC, SG_EAGAIN, SG_ESTATE = 0, -22, -12, -19, -28, -11, -71
+F_IN, F_HID, F_EDGE = 32, 64, 8
+STAT_SUM_WORDS, STAT_MAX_WORDS = 10, 2
+REF_KNOWN, REF_LABEL, REF_OBIP = 0, 1, 2
+
+#: every symbol include/servicegraph.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "sg_abi_version", "sg_weights_count", "sg_hash32", "sg_last_error", "sg_create", "sg_destroy",
+    "sg_upsert_pod", "sg_delete_pod", "sg_upsert_service", "sg_delete_service", "sg_set_clock",
+    "sg_set_label_count", "sg_load_weights", "sg_ingest", "sg_ingest_device", "sg_flush_window",
+    "sg_window_run", "sg_window_rows_buffer", "sg_window_close", "sg_window_obip_list",
+    "sg_window_close_sharded", "sg_window_features", "sg_window_layer", "sg_window_score",
+    "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
+    "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_outbound_ips", "sg_stats_get",
+    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_route",
+]
+
+
+class SgConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("max_known_nodes", C.c_uint32),
+                ("max_labels", C.c_uint32), ("max_outbound_ips", C.c_uint32), ("max_ips", C.c_uint32),
+                ("max_edges", C.c_uint64), ("max_batch", C.c_uint32), ("layers", C.c_uint32),
+                ("rank", C.c_uint32), ("world", C.c_uint32), ("k1_variant", C.c_uint32)]
+
+
+class SgStats(C.Structure):
+    _fields_ = [("events_in", C.c_uint64), ("events_dropped_src", C.c_uint64), ("events_dropped_ring", C.c_uint64),
+                ("events_dropped_cap", C.c_uint64), ("windows", C.c_uint64), ("last_window_events", C.c_uint64),
+                ("last_window_edges", C.c_uint64), ("last_window_nodes", C.c_uint64),
+                ("last_window_tmin_ms", C.c_int64), ("last_window_tmax_ms", C.c_int64), ("h2d_bytes", C.c_uint64)]
+
+
+class ServiceGraphError(RuntimeError):
+    def __init__(self, rc: int, msg: str):
+        super().__init__(f"servicegraph rc={rc}: {msg}")
+        self.rc = rc
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the engine.  torch is imported first so that the HIP runtime torch ships is the one
+    both share (same soname, one copy per process): device pointers of torch tensors are then
+    valid arguments of sg_ingest_device / the halo calls."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m alaz_amd.build` "
+                           "(hipcc, gfx950). The ServiceGraph engine has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 with RTLD_GLOBAL semantics first)
+    except Exception:
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    H, P = C.c_void_p, C.c_void_p
+    u32, u64, sz = C.c_uint32, C.c_uint64, C.c_size_t
+    sig = {
+        "sg_abi_version": (u32, []), "sg_weights_count": (sz, [u32]), "sg_hash32": (u32, [u32]),
+        "sg_last_error": (C.c_char_p, [H]),
+        "sg_create": (C.c_int, [C.POINTER(SgConfig), C.POINTER(H)]), "sg_destroy": (C.c_int, [H]),
+        "sg_upsert_pod": (C.c_int, [H, u32, u32]), "sg_delete_pod": (C.c_int, [H, u32]),
+        "sg_upsert_service": (C.c_int, [H, u32, u32]), "sg_delete_service": (C.c_int, [H, u32]),
+        "sg_set_clock": (C.c_int, [H, u64, u64]), "sg_set_label_count": (C.c_int, [H, u32]),
+        "sg_load_weights": (C.c_int, [H, P, sz]),
+        "sg_ingest": (C.c_int, [H, P, sz]), "sg_ingest_device": (C.c_int, [H, P, sz, P]),
+        "sg_flush_window": (C.c_int, [H, u64, P, sz, C.POINTER(sz)]),
+        "sg_window_run": (C.c_int, [H, P]), "sg_window_rows_buffer": (C.c_int, [H, C.POINTER(P)]),
+        "sg_window_close": (C.c_int, [H, P]),
+        "sg_window_obip_list": (C.c_int, [H, C.POINTER(P), C.POINTER(P), C.POINTER(u32), P]),
+        "sg_window_close_sharded": (C.c_int, [H, P, P, P]),
+        "sg_window_features": (C.c_int, [H, P]), "sg_window_layer": (C.c_int, [H, u32, P]),
+        "sg_window_score": (C.c_int, [H, P]), "sg_window_read": (C.c_int, [H, P, sz, C.POINTER(sz)]),
+        "sg_window_reset": (C.c_int, [H, P]),
+        "sg_window_buffers": (C.c_int, [H, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(sz)]),
+        "sg_window_feat_buffer": (C.c_int, [H, u32, C.POINTER(P), C.POINTER(sz)]),
+        "sg_halo_build": (C.c_int, [H, P, u32, P, P]), "sg_halo_pack": (C.c_int, [H, u32, P, u32, P, P]),
+        "sg_halo_unpack": (C.c_int, [H, u32, P, u32, P, P]),
+        "sg_window_outbound_ips": (C.c_int, [H, P, sz, C.POINTER(sz)]),
+        "sg_stats_get": (C.c_int, [H, C.POINTER(SgStats)]),
+        "sg_timing_enable": (C.c_int, [H, C.c_int]), "sg_timing_reset": (C.c_int, [H]),
+        "sg_timing_get": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "sg_route": (C.c_int, [H, P, sz, u32, P]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)          # AttributeError if the library does not export it
+        f.restype = res; f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ip_u32(s: str) -> int:
+    a, b, c, d = (int(x) for x in s.split("."))
+    return (a << 24) | (b << 16) | (c << 8) | d
+
+
+class ServiceGraph:
+    """One engine handle (one GPU / one shard)."""
+
+    def __init__(self, *, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 1024,
+                 max_outbound_ips: int = 1024, max_ips: int = 0, max_batch: int = 1 << 20, device: int = 0,
+                 rank: int = 0, world: int = 1):
+        self._l = load_library()
+        cfg = SgConfig(self._l.sg_abi_version(), device, max_known_nodes, max_labels, max_outbound_ips,
+                       max_ips or max_known_nodes, max_edges, max_batch, layers, rank, world, 0)
+        h = C.c_void_p()
+        rc = self._l.sg_create(C.byref(cfg), C.byref(h))
+        if rc != SG_OK:
+            raise ServiceGraphError(rc, "sg_create failed (no usable gfx950 device, or bad config); there is no CPU fallback")
+        self._h = h
+        self.layers = layers
+        self.max_edges = max_edges
+        self.rank, self.world = rank, world
+
+    # ---- plumbing ----
+    def _ck(self, rc: int, allow=()):
+        if rc != SG_OK and rc not in allow:
+            raise ServiceGraphError(rc, (self._l.sg_last_error(self._h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.sg_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- join tables (aggregator/persist.go:55-71,114-130) ----
+    def upsert_pod(self, ip: int, node_id: int): self._ck(self._l.sg_upsert_pod(self._h, ip, node_id))
+    def delete_pod(self, ip: int): self._ck(self._l.sg_delete_pod(self._h, ip))
+    def upsert_service(self, ip: int, node_id: int): self._ck(self._l.sg_upsert_service(self._h, ip, node_id))
+    def delete_service(self, ip: int): self._ck(self._l.sg_delete_service(self._h, ip))
+    def set_clock(self, first_kernel_ns: int, first_user_ns: int): self._ck(self._l.sg_set_clock(self._h, first_kernel_ns, first_user_ns))
+    def set_label_count(self, n: int): self._ck(self._l.sg_set_label_count(self._h, n))
+
+    def load_weights(self, w: np.ndarray):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        self._ck(self._l.sg_load_weights(self._h, w.ctypes.data, len(w)))
+
+    # ---- ingest ----
+    def ingest(self, events: np.ndarray) -> int:
+        ev = np.ascontiguousarray(events)
+        assert ev.dtype == EVENT_DTYPE
+        return self._ck(self._l.sg_ingest(self._h, ev.ctypes.data, len(ev)), allow=(SG_EAGAIN,))
+
+    def ingest_device(self, dev_ptr: int, n: int, stream: int = 0):
+        self._ck(self._l.sg_ingest_device(self._h, dev_ptr, n, stream or None))
+
+    # ---- window ----
+    def flush_window(self, window_end_ms: int = 0, cap: Optional[int] = None) -> np.ndarray:
+        cap = self.max_edges if cap is None else cap
+        out = np.zeros(cap, dtype=EDGE_OUT_DTYPE)
+        n = C.c_size_t(0)
+        self._ck(self._l.sg_flush_window(self._h, window_end_ms, out.ctypes.data, cap, C.byref(n)))
+        return out[: min(n.value, cap)]
+
+    def window_run(self, stream: int = 0): self._ck(self._l.sg_window_run(self._h, stream or None))
+    def window_close(self, stream: int = 0): self._ck(self._l.sg_window_close(self._h, stream or None))
+    def window_features(self, stream: int = 0): self._ck(self._l.sg_window_features(self._h, stream or None))
+    def window_layer(self, l: int, stream: int = 0): self._ck(self._l.sg_window_layer(self._h, l, stream or None))
+    def window_score(self, stream: int = 0): self._ck(self._l.sg_window_score(self._h, stream or None))
+    def window_reset(self, stream: int = 0): self._ck(self._l.sg_window_reset(self._h, stream or None))
+
+    def window_close_sharded(self, d_union_ips: int, d_union_n: int, stream: int = 0):
+        self._ck(self._l.sg_window_close_sharded(self._h, d_union_ips, d_union_n, stream or None))
+
+    def window_obip_list(self, stream: int = 0) -> Tuple[int, int, int]:
+        lst, n, cap = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        self._ck(self._l.sg_window_obip_list(self._h, C.byref(lst), C.byref(n), C.byref(cap), stream or None))
+        return lst.value, n.value, cap.value
+
+    def window_read(self, cap: Optional[int] = None) -> np.ndarray:
+        cap = self.max_edges if cap is None else cap
+        out = np.zeros(cap, dtype=EDGE_OUT_DTYPE)
+        n = C.c_size_t(0)
+        self._ck(self._l.sg_window_read(self._h, out.ctypes.data, cap, C.byref(n)))
+        return out[: min(n.value, cap)]
+
+    def window_buffers(self):
+        a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._ck(self._l.sg_window_buffers(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return a.value, b.value, c.value, n.value
+
+    def feat_buffer(self, l: int):
+        p, w = C.c_void_p(), C.c_size_t()
+        self._ck(self._l.sg_window_feat_buffer(self._h, l, C.byref(p), C.byref(w)))
+        return p.value, w.value
+
+    def rows_buffer(self) -> int:
+        p = C.c_void_p()
+        self._ck(self._l.sg_window_rows_buffer(self._h, C.byref(p)))
+        return p.value
+
+    def halo_build(self, d_ids: int, cap: int, d_n: int, stream: int = 0): self._ck(self._l.sg_halo_build(self._h, d_ids, cap, d_n, stream or None))
+    def halo_pack(self, l: int, d_ids: int, n: int, d_rows: int, stream: int = 0): self._ck(self._l.sg_halo_pack(self._h, l, d_ids, n, d_rows, stream or None))
+    def halo_unpack(self, l: int, d_ids: int, n: int, d_rows: int, stream: int = 0): self._ck(self._l.sg_halo_unpack(self._h, l, d_ids, n, d_rows, stream or None))
+
+    def outbound_ips(self) -> np.ndarray:
+        n = C.c_size_t(0)
+        self._ck(self._l.sg_window_outbound_ips(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            self._ck(self._l.sg_window_outbound_ips(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def stats(self) -> SgStats:
+        s = SgStats()
+        self._ck(self._l.sg_stats_get(self._h, C.byref(s)))
+        return s
+
+    def timing_enable(self, mask: int = 1): self._ck(self._l.sg_timing_enable(self._h, int(mask)))
+    def timing_reset(self): self._ck(self._l.sg_timing_reset(self._h))
+
+    def timing(self, kernel: int) -> Tuple[float, int]:
+        us, n = C.c_double(), C.c_uint64()
+        self._ck(self._l.sg_timing_get(self._h, kernel, C.byref(us), C.byref(n)))
+        return us.value, n.value
+
+    def route(self, events: np.ndarray, world: int) -> np.ndarray:
+        ev = np.ascontiguousarray(events)
+        out = np.zeros(len(ev), dtype=np.uint32)
+        self._ck(self._l.sg_route(self._h, ev.ctypes.data, len(ev), world, out.ctypes.data))
+        return out

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — L7 edge-events/s ingested -> scored service map on MI355X (BASELINE.json metric).
+
+A step = one window of the hot path over one batch of synthetic events that is already resident
+in HBM: K1 resolve_aggregate over the batch, then K2..K5 (CSR build, node/edge features, SAGE
+layer(s), edge scores) and the window reset.  N=1 workload = BASELINE config 2 (1k pods / 500
+services / 50k edges / 1M events per window, L=1).  Steps cycle through a ring of distinct batches
+larger than the 256 MiB Infinity Cache, so every step streams its events from HBM.
+
+One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel K1 (algorithmic bytes
+32*Ev + 32*E per launch, SURVEY.md §8d / DESIGN.md), timed with HIP events on the launch stream.
+`cpu_baseline` is the CPU oracle (a C restatement of the reference's aggregator path; the Go
+binary cannot be built here) timed single-threaded on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3])
+    ap.add_argument("--batches", type=int, default=0, help="distinct event batches in the HBM ring (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(topo, events, labels, layers, seconds):
+    """The reference's CPU path restated (oracle/sg_oracle.c): full 1096-byte records through
+    processL7 -> processHttpEvent -> setFromToV2 -> PersistRequest, then the window close."""
+    from alaz_amd import replay, weights
+    from oracle import pyoracle
+    sample = events[: min(len(events), 200_000)]
+    wire = replay.to_wire(sample, labels)
+    W = weights.make_weights(layers)
+    o = pyoracle.Oracle(1_000_000_000, 1_700_000_000_000_000_000)
+    o.apply_ops(topo.k8s_ops())
+    done, t0 = 0, time.perf_counter()
+    while True:
+        o.l7_wire(wire)
+        o.window_close(W, layers)
+        done += len(sample)
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"value": done / dt, "unit": "events/s", "cores": 1, "kind": "port",
+            "sample": f"{len(sample)} events of the same workload as full 1096-B l7_event records, repeated "
+                      f"{done // len(sample)}x ({dt:.1f} s): C restatement of processL7..PersistRequest + window close "
+                      "(oracle/sg_oracle.c); the Go aggregator itself cannot be built here (no Go toolchain)"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from alaz_amd import engine, replay, weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    if world > 1:
+        from alaz_amd import sharded
+        res = sharded.bench(a, rank, world, local)
+    else:
+        res = bench_single(a, local)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_single(a, device):
+    import torch
+    from alaz_amd import engine, replay, weights
+
+    c = replay.CONFIGS[a.config]
+    seed = replay.SEED_BASE + a.config
+    Ev, L = c["events"], c["layers"]
+    nb = a.batches or max(2, -(-(320 << 20) // (Ev * 32)))          # ring >= 320 MB > 256 MiB Infinity Cache
+    topo = replay.make_topology(c["pods"], c["edges"], seed)
+    ev_all, labels = replay.make_events(topo, Ev * nb, seed)
+    g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.25) + 4096, layers=L,
+                            max_labels=max(64, len(labels)), max_outbound_ips=64, device=device)
+    g.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
+    g.load_weights(weights.make_weights(L))
+    for i in range(topo.n_pods):
+        g.upsert_pod(int(topo.pod_ips[i]), i)
+    for j in range(topo.n_svcs):
+        g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
+    g.set_label_count(len(labels))
+
+    stream = torch.cuda.Stream()
+    s = stream.cuda_stream
+    dev = [torch.from_numpy(ev_all[i * Ev:(i + 1) * Ev].view(np.uint8).reshape(-1)).cuda() for i in range(nb)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        g.ingest_device(dev[i % nb].data_ptr(), Ev, s)
+        g.window_run(s)
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    g.timing_reset(); g.timing_enable(1 << 1)            # HIP events around every K1 launch, on its stream
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    g.timing_enable(0)
+    k1 = g.timing(1)
+    # untimed diagnostic pass: per-group durations of the rest of the window pipeline
+    g.timing_reset(); g.timing_enable(1)
+    for i in range(min(20, a.steps)):
+        step(i)
+    torch.cuda.synchronize()
+    g.timing_enable(0)
+    k_us = {k: g.timing(k) for k in range(1, 6)}
+    k_us[1] = k1
+
+    # one untimed window with copy-out: how many edges / nodes a window of this workload has
+    g.ingest_device(dev[0].data_ptr(), Ev, s)
+    torch.cuda.synchronize()
+    rows = g.flush_window()
+    st = g.stats()
+    E = int(st.last_window_edges)
+    k1_us = k_us[1][0]
+    alg_bytes = 32.0 * Ev + 32.0 * E
+    achieved = alg_bytes / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
+    res = {
+        "metric": "L7 edge-events/s ingested->scored service-map", "value": Ev * a.steps / dt, "unit": "events/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"C{a.config}: {c['pods']} pods / {topo.n_svcs} services / {c['edges']} edges, "
+                               f"{Ev} HTTP l7 events per window, {L}-layer SAGE + MLP score; {nb}-batch HBM ring",
+                   "events_per_window": Ev, "edges_per_window": E, "nodes": int(st.last_window_nodes), "layers": L,
+                   "parallelism": "1 GPU"},
+        "roofline": {"bound": "hbm", "kernel": "k1_resolve_aggregate", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": k1_us, "launches": k_us[1][1]},
+        "kernel_group_us": {f"K{k}": round(v[0], 2) for k, v in k_us.items()},
+    }
+    if not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(topo, ev_all[:Ev], labels, L, a.cpu_seconds)
+    g.close()
+    return res
+
+
+if __name__ == "__main__":
+    main()

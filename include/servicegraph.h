@@ -188,6 +188,11 @@ int sg_delete_service(sg_handle h, uint32_t ip);
 /* FirstKernelTime / FirstUserspaceTime (ebpf/l7_req/l7.go:707-710) for StartTime conversion.   */
 int sg_set_clock(sg_handle h, uint64_t first_kernel_ns, uint64_t first_user_ns);
 
+/* Number of Host-header labels the host packer has interned so far (labels are cumulative).
+ * The engine also tracks the largest label id it has seen; the larger of the two sizes the
+ * LABEL id range of the next closed window.                                                    */
+int sg_set_label_count(sg_handle h, uint32_t n_labels);
+
 /* fp32 weight blob, layout documented in DESIGN.md §"weights"; copied.                         */
 int sg_load_weights(sg_handle h, const float* w, size_t n);
 
@@ -206,15 +211,26 @@ int sg_ingest_device(sg_handle h, const sg_event* d_events, size_t n, void* stre
  * *n the number of edges of the window (may exceed cap; then only cap rows were written).       */
 int sg_flush_window(sg_handle h, uint64_t window_end_ms, sg_edge_out* out, size_t cap, size_t* n);
 
+/* Enqueue-only form of the same pipeline (K2..K5 + reset, no copy-out, no host sync) for
+ * callers that keep results on the device (sg_window_rows_buffer) or time the pipeline.         */
+int sg_window_run(sg_handle h, void* stream);
+int sg_window_rows_buffer(sg_handle h, void** d_rows);   /* device sg_edge_out[max_edges]        */
+
 /* The same pipeline in stages, so that a sharded driver can run its exchanges in between.
  * Order: close -> [allreduce node stats] -> features -> for l in 0..L-1 { layer(l) ->
  * [halo exchange of layer l+1 rows] } -> score -> read -> reset.
  * All stage calls enqueue on `stream` (NULL = engine stream) and do not synchronise.            */
 int sg_window_close(sg_handle h, void* stream);      /* K2: canonical ids, CSR; K3a: partial node stats */
+/* Sharded close: OBIP numbering must agree on every shard, so the driver gathers every shard's
+ * raw outbound IPs (sg_window_obip_list: device list + device count, local cap), concatenates
+ * them into d_union_ips (device, capacity >= next_pow2(world * max_outbound_ips), duplicates
+ * allowed) and passes the total count in *d_union_n (device).                                   */
+int sg_window_obip_list(sg_handle h, uint32_t** d_list, uint32_t** d_n, uint32_t* cap, void* stream);
+int sg_window_close_sharded(sg_handle h, const uint32_t* d_union_ips, const uint32_t* d_union_n, void* stream);
 int sg_window_features(sg_handle h, void* stream);   /* K3b: node + edge features from reduced stats    */
 int sg_window_layer(sg_handle h, uint32_t l, void* stream);  /* K4: rows with out-edges owned here + all rows without out-edges */
 int sg_window_score(sg_handle h, void* stream);      /* K5 */
-int sg_window_read(sg_handle h, sg_edge_out* out, size_t cap, size_t* n); /* syncs, copies out   */
+int sg_window_read(sg_handle h, sg_edge_out* out, size_t cap, size_t* n); /* device-syncs, copies out */
 int sg_window_reset(sg_handle h, void* stream);      /* clears the window state                  */
 
 /* Device buffers a sharded driver reduces / exchanges (all device pointers, engine-owned):
@@ -243,13 +259,17 @@ int sg_stats_get(sg_handle h, sg_stats* out);
 /* Per-kernel timing of the last N launches, measured with hipEvents on the launch stream.
  * kernel: 1..6 = K1..K6.  Returns the average duration in microseconds over the recorded
  * launches since sg_timing_reset(), and the launch count.  Timing must be enabled first.        */
-int sg_timing_enable(sg_handle h, int on);
+int sg_timing_enable(sg_handle h, int on);   /* 0 = off, 1 = every group, else bitmask: bit k = group Kk */
 int sg_timing_reset(sg_handle h);
 int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
 
 /* Owner shard of a node / routing shard of an event: murmur3 fmix32(ip) % world.
  * The feeder routes an event by the IP of its from-endpoint: daddr if SG_EV_REVERSE else saddr. */
 uint32_t sg_hash32(uint32_t x);
+/* Shard each event must be fed to when world > 1: owner of its from-endpoint after the join and
+ * the optional direction reversal — the same rule K1 enforces (misrouted events are dropped and
+ * counted).  Host-only: uses the host mirror of the join tables, launches nothing.              */
+int sg_route(sg_handle h, const sg_event* events, size_t n, uint32_t world, uint32_t* shard_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,221 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same traces.
+Edge identities and integer accumulators bit-exact; fp32 scores within 1e-5 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+from alaz_amd import replay, weights
+from tests.helpers import CLOCK, HostShim, compare_edge_dicts, engine_edge_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(topo_nodes, max_edges, layers, **kw):
+    from alaz_amd import engine
+    g = engine.ServiceGraph(max_known_nodes=topo_nodes, max_edges=max_edges, layers=layers,
+                            max_labels=kw.pop("max_labels", 256), max_outbound_ips=kw.pop("max_outbound_ips", 512), **kw)
+    g.set_clock(*CLOCK)
+    g.load_weights(weights.make_weights(layers))
+    return g
+
+
+def _oracle(topo_ops, layers):
+    from oracle import pyoracle
+    o = pyoracle.Oracle(*CLOCK)
+    o.apply_ops(topo_ops)
+    return o
+
+
+def _run_both(topo, batches, labels, layers, *, max_edges=None, chunk=1 << 18):
+    ops = topo.k8s_ops()
+    g = _engine(topo.n_nodes + 8, max_edges or 4 * len(topo.edge_src) + 1024, layers)
+    shim = HostShim(); shim.apply(g, ops)
+    o = _oracle(ops, layers)
+    W = weights.make_weights(layers)
+    worst = 0.0
+    for ev in batches:
+        for i in range(0, len(ev), chunk):              # ragged host batches through the staging ring
+            rc = g.ingest(ev[i:i + chunk])
+            while rc != 0:                               # SG_EAGAIN: ring full -> the test retries, production drops
+                rc = g.ingest(ev[i:i + chunk])
+        g.set_label_count(len(labels))
+        rows = g.flush_window()
+        o.packed(ev, labels)
+        o.window_close(W, layers)
+        got = engine_edge_dict(rows, shim, labels, g.outbound_ips())
+        worst = max(worst, compare_edge_dicts(got, o.edge_dict()))
+        st = g.stats()
+        assert st.last_window_events == o.window_events
+        assert st.last_window_edges == len(rows) == len(o.edge_dict())
+        assert st.last_window_nodes == o.n_nodes
+        if o.window_events:
+            assert (st.last_window_tmin_ms, st.last_window_tmax_ms) == (o.window_tmin, o.window_tmax)
+        assert np.array_equal(g.outbound_ips(), o.outbound_ips())
+        # canonical order of the emitted rows == the oracle's row order
+        assert np.array_equal(rows["from_ref"], o.edge_rows()["from_ref"]) and np.array_equal(rows["to_ref"], o.edge_rows()["to_ref"])
+    return g, o, worst
+
+
+def test_config1_full_reference_path():
+    """BASELINE config 1: the oracle consumes the full 1096-byte wire records (payload parse, string
+    tables — the reference's own path); the engine consumes the packed events."""
+    from oracle import pyoracle
+    topo, ev, labels, L = replay.make_config(1)
+    g = _engine(topo.n_nodes + 8, 4096, L)
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    assert g.ingest(ev) == 0
+    g.set_label_count(len(labels))
+    rows = g.flush_window()
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops())
+    o.l7_wire(replay.to_wire(ev, labels))
+    assert o.labels == labels
+    o.window_close(weights.make_weights(L), L)
+    compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
+    st = g.stats()
+    assert st.events_dropped_src == o.dropped_src > 0 and st.events_in == len(ev)
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_edge_cases_mixed_trace(layers):
+    """raw-IP outbound, Host-header outbound, unknown sources, AMQP/Redis reversal, TLS, Kafka and
+    Postgres status semantics, two windows, ragged batches."""
+    topo = replay.make_topology(150, 1500, seed=31)
+    ev1, labels = replay.make_events(topo, 60_000, seed=32, mixed=True, with_raw_outbound=True, with_reverse=True)
+    ev2, labels2 = replay.make_events(topo, 45_001, seed=33, mixed=True, with_raw_outbound=True, with_reverse=True, stream_base=300)
+    # second window reuses the first window's label table prefix (labels are cumulative)
+    lab_all = list(labels)
+    remap = np.zeros(len(labels2) + 1, dtype=np.uint32)
+    for i, s in enumerate(labels2):
+        if s not in lab_all:
+            lab_all.append(s)
+        remap[i + 1] = lab_all.index(s) + 1
+    ev2 = ev2.copy(); ev2["host_label"] = remap[ev2["host_label"]]
+    # oracle interns labels in first-use order: feed it the same cumulative table
+    _run_both(topo, [ev1, ev2], lab_all, layers, chunk=7777)
+
+
+def test_empty_and_tiny_windows():
+    topo = replay.make_topology(20, 40, seed=5)
+    ev, labels = replay.make_events(topo, 3, seed=6)
+    g, o, _ = _run_both(topo, [ev[:0], ev[:1], ev, ev[:0]], labels, 1)
+    assert g.stats().windows == 4
+
+
+def test_table_updates_between_windows():
+    """ADD / UPDATE / DELETE between windows (persist.go:55-71,114-130), incl. an IP that is both a
+    pod and a service (service wins, data.go:840-849) and a deleted source (events dropped)."""
+    from alaz_amd import engine
+    from oracle import pyoracle
+    topo = replay.make_topology(30, 120, seed=9)
+    ev, labels = replay.make_events(topo, 20_000, seed=10)
+    ops0 = topo.k8s_ops()
+    g = _engine(topo.n_nodes + 16, 4096, 1)
+    shim = HostShim(); shim.apply(g, ops0)
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(ops0)
+    W = weights.make_weights(1)
+
+    def window(e):
+        assert g.ingest(e) == 0
+        g.set_label_count(len(labels))
+        rows = g.flush_window()
+        o.packed(e, labels); o.window_close(W, 1)
+        compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
+        assert g.stats().last_window_events == o.window_events
+    window(ev[:8000])
+    pod0_ip = replay.ip_str(int(topo.pod_ips[0])); pod1_ip = replay.ip_str(int(topo.pod_ips[1]))
+    ops1 = [("pod", "DELETE", topo.pod_uid(0), pod0_ip),                       # its events are dropped now
+            ("svc", "ADD", "svc-shadowing-pod1", pod1_ip),                      # same IP as pod 1: service wins as destination
+            ("pod", "UPDATE", topo.pod_uid(2), "10.9.9.9"),                     # pod 2 gets a second IP
+            ("pod", "ADD", "pod-without-ip", "")]                               # skipped
+    shim.apply(g, ops1); o.apply_ops(ops1)
+    e2 = ev[8000:].copy()
+    e2["saddr"][:50] = engine.ip_u32("10.9.9.9")
+    window(e2)
+    assert g.stats().events_dropped_src == o.dropped_src
+
+
+def test_config2_full_size_bit_exact_and_deterministic():
+    """BASELINE config 2 (1k pods / 50k edges / 1M events, L=1) against the oracle, run twice: the
+    second run must reproduce the first bit for bit (integer atomics + canonical CSR order)."""
+    topo, ev, labels, L = replay.make_config(2)
+    g, o, worst = _run_both(topo, [ev], labels, L, max_edges=1 << 17)
+    rows_a = None
+    for _ in range(2):
+        for i in range(0, len(ev), 1 << 18):
+            assert g.ingest(ev[i:i + (1 << 18)]) == 0
+        rows = g.flush_window()
+        if rows_a is None:
+            rows_a = rows.copy()
+    assert rows.tobytes() == rows_a.tobytes()
+    assert worst <= 1e-5
+    # size-independent properties at full size
+    acc = np.isin(ev["saddr"], topo.pod_ips)
+    assert int(rows["count"].sum()) == int(acc.sum())
+    assert int(rows["sum_ns"].sum()) == int(ev["duration_ns"][acc].astype(np.uint64).sum())
+    assert int(rows["max_ns"].max()) == int(ev["duration_ns"][acc].max())
+    assert int(rows["err_count"].sum()) == int((ev["status"][acc] >= 500).sum())
+
+
+def test_mfma_dense_equals_valu_dense_bitwise():
+    """K4/K5 dense blocks: v_mfma_f32_16x16x4_f32 chain vs a VALU fmaf chain, same k order."""
+    topo = replay.make_topology(200, 3000, seed=41)
+    ev, labels = replay.make_events(topo, 100_000, seed=42)
+    out = []
+    for valu in ("0", "1"):
+        os.environ["SG_DENSE_VALU"] = valu
+        try:
+            g = _engine(topo.n_nodes + 8, 8192, 2)
+            HostShim().apply(g, topo.k8s_ops())
+            assert g.ingest(ev) == 0
+            g.set_label_count(len(labels))
+            out.append(g.flush_window().copy())
+            g.close()
+        finally:
+            os.environ.pop("SG_DENSE_VALU", None)
+    assert out[0].tobytes() == out[1].tobytes()
+
+
+def test_device_resident_ingest_and_staged_pipeline():
+    """sg_ingest_device on a torch-owned buffer + the staged window calls == sg_ingest + sg_flush_window."""
+    import torch
+    topo = replay.make_topology(80, 600, seed=51)
+    ev, labels = replay.make_events(topo, 30_000, seed=52)
+    g = _engine(topo.n_nodes + 8, 4096, 2)
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    assert g.ingest(ev) == 0
+    g.set_label_count(len(labels))
+    a = g.flush_window().copy()
+    t = torch.from_numpy(ev.view(np.uint8).reshape(-1)).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    g.ingest_device(t.data_ptr(), len(ev), s)
+    g.window_close(s); g.window_features(s)
+    for l in range(2):
+        g.window_layer(l, s)
+    g.window_score(s)
+    b = g.window_read().copy()
+    g.window_reset(s)
+    assert a.tobytes() == b.tobytes()
+    # enqueue-only pipeline leaves the rows on the device
+    g.ingest_device(t.data_ptr(), len(ev), s)
+    g.window_run(s)
+    torch.cuda.synchronize()
+    rows = torch.empty(len(a) * 56, dtype=torch.uint8, device="cuda")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(g.rows_buffer()), len(a) * 56, 3) == 0
+    assert rows.cpu().numpy().tobytes() == a.tobytes()
+
+
+def test_capacity_overflow_is_counted_not_silent():
+    topo = replay.make_topology(60, 800, seed=61)
+    ev, labels = replay.make_events(topo, 30_000, seed=62)
+    g = _engine(topo.n_nodes + 8, 256, 1)          # far fewer edge slots than edges
+    HostShim().apply(g, topo.k8s_ops())
+    assert g.ingest(ev) == 0
+    rows = g.flush_window()
+    st = g.stats()
+    assert len(rows) == 256 and st.events_dropped_cap > 0
+    # the next window starts clean
+    assert g.ingest(ev[:10]) == 0
+    assert len(g.flush_window()) <= 10
