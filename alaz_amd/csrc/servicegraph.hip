@@ -246,11 +246,8 @@ int do_reset(sg_engine* e, hipStream_t s) {
     HIP_TRY(e, hipMemsetAsync(d.st_sum, 0, (size_t)d.ncap * SG_NODE_STAT_SUM_WORDS * sizeof(u64), s));
     HIP_TRY(e, hipMemsetAsync(d.st_max, 0, (size_t)d.ncap * SG_NODE_STAT_MAX_WORDS * sizeof(u64), s));
     HIP_TRY(e, hipMemsetAsync(d.obkeys, 0, (size_t)e->obcap * sizeof(u64), s));
-    if (e->h_ctr[C_EDGES_FOUND] > e->cfg.max_edges) {     // unlisted slots survive k3_gather: full clear
-        HIP_TRY(e, hipMemsetAsync(d.ekeys, 0xFF, (size_t)e->ecap * sizeof(u64), s));
-        HIP_TRY(e, hipMemsetAsync(d.eacc, 0, (size_t)e->ecap * 4 * sizeof(u64), s));
-        e->h_ctr[C_EDGES_FOUND] = 0;
-    }
+    hipLaunchKernelGGL(k3_reset_overflow, dim3(1024), dim3(256), 0, s, d);   // no-op unless max_edges overflowed
+    HIP_TRY(e, hipGetLastError());
     e->closed = false;
     return SG_OK;
 }

@@ -511,6 +511,17 @@ __global__ __launch_bounds__(256) void k3_edge_features(Dev d) {
     }
 }
 
+// Window reset of the edge table when more distinct edges were found than max_edges: the unlisted
+// slots were not cleared by k3_gather, so the whole table is wiped.  Exits at once otherwise.
+__global__ __launch_bounds__(256) void k3_reset_overflow(Dev d) {
+    if (d.ctr[C_EDGES_FOUND] <= d.max_edges) return;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i <= d.emask; i += (u64)gridDim.x * 256) {
+        d.ekeys[i] = SG_EKEY_EMPTY;
+        ulonglong2* a = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)i * 4);
+        a[0] = make_ulonglong2(0, 0); a[1] = make_ulonglong2(0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4  sage_layer: h'_v = ReLU(b + h_v Ws + mean_{u in N_out(v)} h_u Wn)  on 16-node tiles.
 //   gather-mean : one wave per node, lanes across features, 16 interleaved partial sums in the

@@ -202,7 +202,8 @@ def test_device_resident_ingest_and_staged_pipeline():
     torch.cuda.synchronize()
     rows = torch.empty(len(a) * 56, dtype=torch.uint8, device="cuda")
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = ctypes.CDLL(None)          # the HIP runtime already loaded by torch / the engine
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     assert hip.hipMemcpy(ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(g.rows_buffer()), len(a) * 56, 3) == 0
     assert rows.cpu().numpy().tobytes() == a.tobytes()
 
