@@ -466,15 +466,23 @@ int sg_window_close(sg_handle e, void* stream) {
     return do_close(e, pick(e, stream), nullptr, nullptr);
 }
 
-int sg_window_obip_list(sg_handle e, uint32_t** d_list, uint32_t** d_n, uint32_t* cap, void* stream) {
-    if (!e) return SG_EINVAL;
+int sg_window_obip_list(sg_handle e, uint32_t* d_list, uint32_t cap, uint32_t* d_n, void* stream) {
+    if (!e || !d_list || !d_n) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
     hipStream_t s = pick(e, stream);
-    hipLaunchKernelGGL(k2_ob_collect, dim3(1), dim3(1024), 0, s, e->d, e->d_ob_list, e->cfg.max_outbound_ips ? e->cfg.max_outbound_ips : 1u, e->d_ob_n);
+    hipLaunchKernelGGL(k2_ob_collect, dim3(1), dim3(1024), 0, s, e->d, d_list, cap, d_n);
     HIP_TRY(e, hipGetLastError());
-    if (d_list) *d_list = e->d_ob_list;
-    if (d_n) *d_n = e->d_ob_n;
-    if (cap) *cap = e->cfg.max_outbound_ips;
+    return SG_OK;
+}
+
+// Use caller-owned device memory for the buffers a sharded driver reduces / exchanges, so that the
+// collectives can run on them in place (torch.distributed tensors).  NULL keeps the current buffer.
+int sg_bind_buffers(sg_handle e, void* stats_sum, void* stats_max, void* const* feat_rows, uint32_t n_feat) {
+    if (!e || n_feat > e->cfg.layers) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (stats_sum) e->d.st_sum = (u64*)stats_sum;
+    if (stats_max) e->d.st_max = (u64*)stats_max;
+    for (u32 l = 0; l < n_feat; l++) if (feat_rows && feat_rows[l]) e->d.h[l + 1] = (float*)feat_rows[l];
     return SG_OK;
 }
 
@@ -561,13 +569,14 @@ int sg_window_rows_buffer(sg_handle e, void** rows) {
     return SG_OK;
 }
 
-int sg_halo_build(sg_handle e, uint32_t* d_ids, uint32_t cap, uint32_t* d_n, void* stream) {
-    if (!e || !d_ids || !d_n) return SG_EINVAL;
+int sg_halo_build(sg_handle e, uint32_t* d_ids, uint32_t cap, uint32_t* d_counts, void* stream) {
+    if (!e || !d_ids || !d_counts) return SG_EINVAL;
+    if (e->cfg.world > 8) { e->err = "halo lists support at most 8 shards (one node)"; return SG_EINVAL; }
     std::lock_guard<std::mutex> g(e->mu);
     hipStream_t s = pick(e, stream);
     Timed t(e, s, 6);
     hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
-    hipLaunchKernelGGL(k6_halo_build, dim3(1), dim3(256), 0, s, e->d, d_ids, cap, d_n);
+    hipLaunchKernelGGL(k6_halo_build, dim3(1), dim3(256), 0, s, e->d, d_ids, cap, d_counts);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }

@@ -737,24 +737,45 @@ __global__ __launch_bounds__(256) void k6_halo_mark(Dev d) {
     const u32 E = (u32)d.ctr[C_N_EDGES];
     for (u32 p = blockIdx.x * 256 + threadIdx.x; p < E; p += gridDim.x * 256) d.cursor[d.col[p]] = 0xFFFFFFFFu;
 }
-__global__ __launch_bounds__(256) void k6_halo_build(Dev d, u32* ids, u32 cap, u32* n_out) {
-    // single workgroup, ordered output (ascending dense id) so that every run produces the same list
+__global__ __launch_bounds__(256) void k6_halo_build(Dev d, u32* ids, u32 cap, u32* counts) {
+    // single workgroup; output grouped by owner shard, ascending dense id inside a group, so every
+    // run (and every shard, for the ids it is asked for) sees the same lists.
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
-    __shared__ u32 part[256];
+    __shared__ u32 part[8][256];
+    __shared__ u32 base[8];
+    const u32 W = d.world < 8 ? d.world : 8;
     const u32 per = (N + 255) / 256, beg = threadIdx.x * per, end = beg + per < N ? beg + per : N;
-    u32 c = 0;
+    u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (u32 v = beg; v < end; v++) {
-        const bool need = d.cursor[v] == 0xFFFFFFFFu && d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0 && owner_of_dense(d, v, nk, nl) != d.rank;
-        c += need;
+        if (d.cursor[v] != 0xFFFFFFFFu || d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0) continue;
+        const u32 o = owner_of_dense(d, v, nk, nl);
+        if (o == d.rank) continue;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] += (o == (u32)k);
     }
-    part[threadIdx.x] = c;
+#pragma unroll
+    for (int k = 0; k < 8; k++) part[k][threadIdx.x] = c[k];
     __syncthreads();
-    if (threadIdx.x == 0) { u32 run = 0; for (int t = 0; t < 256; t++) { const u32 x = part[t]; part[t] = run; run += x; } *n_out = run < cap ? run : cap; }
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (u32 k = 0; k < W; k++) {
+            base[k] = run;
+            u32 tot = 0;
+            for (int t = 0; t < 256; t++) { const u32 x = part[k][t]; part[k][t] = run + tot; tot += x; }
+            counts[k] = (run + tot <= cap) ? tot : (run < cap ? cap - run : 0);
+            run += tot;
+        }
+    }
     __syncthreads();
-    u32 pos = part[threadIdx.x];
+    u32 pos[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) pos[k] = part[k][threadIdx.x];
     for (u32 v = beg; v < end; v++) {
-        const bool need = d.cursor[v] == 0xFFFFFFFFu && d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0 && owner_of_dense(d, v, nk, nl) != d.rank;
-        if (need) { if (pos < cap) ids[pos] = v; pos++; }
+        if (d.cursor[v] != 0xFFFFFFFFu || d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0) continue;
+        const u32 o = owner_of_dense(d, v, nk, nl);
+        if (o == d.rank) continue;
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (o == (u32)k) { if (pos[k] < cap) ids[pos[k]] = v; pos[k]++; }
     }
 }
 // rows[i][:] = feat[ids[i]][:]   (16 lanes x float4 per 64-float row)

@@ -28,7 +28,7 @@ EXPORTS = [
     "sg_upsert_pod", "sg_delete_pod", "sg_upsert_service", "sg_delete_service", "sg_set_clock",
     "sg_set_label_count", "sg_load_weights", "sg_ingest", "sg_ingest_device", "sg_flush_window",
     "sg_window_run", "sg_window_rows_buffer", "sg_window_close", "sg_window_obip_list",
-    "sg_window_close_sharded", "sg_window_features", "sg_window_layer", "sg_window_score",
+    "sg_window_close_sharded", "sg_bind_buffers", "sg_window_features", "sg_window_layer", "sg_window_score",
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_outbound_ips", "sg_stats_get",
     "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_route",
@@ -87,7 +87,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_flush_window": (C.c_int, [H, u64, P, sz, C.POINTER(sz)]),
         "sg_window_run": (C.c_int, [H, P]), "sg_window_rows_buffer": (C.c_int, [H, C.POINTER(P)]),
         "sg_window_close": (C.c_int, [H, P]),
-        "sg_window_obip_list": (C.c_int, [H, C.POINTER(P), C.POINTER(P), C.POINTER(u32), P]),
+        "sg_window_obip_list": (C.c_int, [H, P, u32, P, P]),
+        "sg_bind_buffers": (C.c_int, [H, P, P, C.POINTER(P), u32]),
         "sg_window_close_sharded": (C.c_int, [H, P, P, P]),
         "sg_window_features": (C.c_int, [H, P]), "sg_window_layer": (C.c_int, [H, u32, P]),
         "sg_window_score": (C.c_int, [H, P]), "sg_window_read": (C.c_int, [H, P, sz, C.POINTER(sz)]),
@@ -187,10 +188,12 @@ class ServiceGraph:
     def window_close_sharded(self, d_union_ips: int, d_union_n: int, stream: int = 0):
         self._ck(self._l.sg_window_close_sharded(self._h, d_union_ips, d_union_n, stream or None))
 
-    def window_obip_list(self, stream: int = 0) -> Tuple[int, int, int]:
-        lst, n, cap = C.c_void_p(), C.c_void_p(), C.c_uint32()
-        self._ck(self._l.sg_window_obip_list(self._h, C.byref(lst), C.byref(n), C.byref(cap), stream or None))
-        return lst.value, n.value, cap.value
+    def window_obip_list(self, d_list: int, cap: int, d_n: int, stream: int = 0):
+        self._ck(self._l.sg_window_obip_list(self._h, d_list, cap, d_n, stream or None))
+
+    def bind_buffers(self, stats_sum: int, stats_max: int, feat_rows):
+        arr = (C.c_void_p * max(1, len(feat_rows)))(*feat_rows)
+        self._ck(self._l.sg_bind_buffers(self._h, stats_sum, stats_max, arr, len(feat_rows)))
 
     def window_read(self, cap: Optional[int] = None) -> np.ndarray:
         cap = self.max_edges if cap is None else cap
@@ -214,7 +217,7 @@ class ServiceGraph:
         self._ck(self._l.sg_window_rows_buffer(self._h, C.byref(p)))
         return p.value
 
-    def halo_build(self, d_ids: int, cap: int, d_n: int, stream: int = 0): self._ck(self._l.sg_halo_build(self._h, d_ids, cap, d_n, stream or None))
+    def halo_build(self, d_ids: int, cap: int, d_counts: int, stream: int = 0): self._ck(self._l.sg_halo_build(self._h, d_ids, cap, d_counts, stream or None))
     def halo_pack(self, l: int, d_ids: int, n: int, d_rows: int, stream: int = 0): self._ck(self._l.sg_halo_pack(self._h, l, d_ids, n, d_rows, stream or None))
     def halo_unpack(self, l: int, d_ids: int, n: int, d_rows: int, stream: int = 0): self._ck(self._l.sg_halo_unpack(self._h, l, d_ids, n, d_rows, stream or None))
 

@@ -222,10 +222,10 @@ int sg_window_rows_buffer(sg_handle h, void** d_rows);   /* device sg_edge_out[m
  * All stage calls enqueue on `stream` (NULL = engine stream) and do not synchronise.            */
 int sg_window_close(sg_handle h, void* stream);      /* K2: canonical ids, CSR; K3a: partial node stats */
 /* Sharded close: OBIP numbering must agree on every shard, so the driver gathers every shard's
- * raw outbound IPs (sg_window_obip_list: device list + device count, local cap), concatenates
+ * raw outbound IPs (sg_window_obip_list fills a caller-owned device list + device count), concatenates
  * them into d_union_ips (device, capacity >= next_pow2(world * max_outbound_ips), duplicates
  * allowed) and passes the total count in *d_union_n (device).                                   */
-int sg_window_obip_list(sg_handle h, uint32_t** d_list, uint32_t** d_n, uint32_t* cap, void* stream);
+int sg_window_obip_list(sg_handle h, uint32_t* d_list, uint32_t cap, uint32_t* d_n, void* stream);
 int sg_window_close_sharded(sg_handle h, const uint32_t* d_union_ips, const uint32_t* d_union_n, void* stream);
 int sg_window_features(sg_handle h, void* stream);   /* K3b: node + edge features from reduced stats    */
 int sg_window_layer(sg_handle h, uint32_t l, void* stream);  /* K4: rows with out-edges owned here + all rows without out-edges */
@@ -243,11 +243,17 @@ int sg_window_buffers(sg_handle h, void** stats_sum, void** stats_max, void** co
                       size_t* n_nodes_cap);
 int sg_window_feat_buffer(sg_handle h, uint32_t l, void** rows, size_t* row_floats);
 
-/* Halo support (K6).  Fill `ids` (device, u32[cap]) with the dense node indices this shard
- * needs from others: destinations of local edges that are not owned here and have out-edges
- * elsewhere.  *n_dev is a device u32 counter.  pack/unpack move rows of layer l between the
- * feature buffer and a contiguous exchange buffer.                                             */
-int sg_halo_build(sg_handle h, uint32_t* d_ids, uint32_t cap, uint32_t* d_n, void* stream);
+/* Caller-owned device memory for the buffers a sharded driver reduces / exchanges in place
+ * (stats_sum [ncap][10] u64, stats_max [ncap][2] u64, feat_rows[l] = layer l+1 rows [ncap][64] f32).
+ * NULL entries keep the engine's own buffer.                                                    */
+int sg_bind_buffers(sg_handle h, void* stats_sum, void* stats_max, void* const* feat_rows, uint32_t n_feat);
+
+/* Halo support (K6).  Fill `ids` (device, u32[cap]) with the dense node indices this shard needs
+ * from other shards — destinations of local edges that are not owned here and have out-edges —
+ * grouped by owner shard (ascending id inside a group); counts[k] (device, u32[world]) = number
+ * of ids owned by shard k.  pack/unpack move rows of layer l between the feature buffer and a
+ * contiguous exchange buffer.  Call after the node statistics have been reduced.                */
+int sg_halo_build(sg_handle h, uint32_t* d_ids, uint32_t cap, uint32_t* d_counts, void* stream);
 int sg_halo_pack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, float* d_rows, void* stream);
 int sg_halo_unpack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, const float* d_rows, void* stream);
 

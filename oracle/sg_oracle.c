@@ -607,6 +607,12 @@ size_t or_process_l7_wire(oracle_t* o, const uint8_t* recs, size_t n, const uint
 
 size_t or_process_packed(oracle_t* o, const sg_event* ev, size_t n, const char* const* labels, size_t n_labels) {
     size_t total = 0;
+    /* the packer owns the label ids: host_label i+1 <-> labels[i]; register them in table order so
+     * that the oracle's LABEL numbering is the packer's (and the label count is the table size) */
+    for (size_t i = 0; i < n_labels; i++) {
+        uint32_t id = intern_label(o, labels[i]);
+        (void)id;
+    }
     for (size_t i = 0; i < n; i++) {
         const sg_event* e = &ev[i];
         const char* host = "";
