@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -59,6 +60,8 @@ struct sg_engine {
     bool closed = false;       // window_close has run; rows readable after score
     bool use_mfma = true;
     int k1_grid = 0;
+    size_t k1a_lds = 0, k1b_lds = 0;
+    u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
     std::vector<TimingRec> trecs;
@@ -131,14 +134,19 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     if (n == 0) return SG_OK;
     int rc = sync_tables(e, s);
     if (rc) return rc;
-    u64 want = (n + 255) / 256;
-    int grid = (int)std::min<u64>(want, (u64)e->k1_grid);
     {
         Timed t(e, s, 1);
-        hipLaunchKernelGGL(k1_resolve_aggregate, dim3(grid), dim3(256), 0, s, e->d, d_ev, (u64)n);
+        if (e->d.variant == 0) {
+            hipLaunchKernelGGL(k1a_partition, dim3(e->d.nwg), dim3(K1A_THREADS), e->k1a_lds, s, e->d, d_ev, (u64)n);
+        } else {
+            u64 want = (n + 255) / 256;
+            int grid = (int)std::min<u64>(want, (u64)e->k1_grid);
+            hipLaunchKernelGGL(k1_resolve_aggregate, dim3(grid), dim3(256), 0, s, e->d, d_ev, (u64)n);
+        }
     }
     HIP_TRY(e, hipGetLastError());
     e->st.events_in += n;
+    e->window_events_in += n;
     return SG_OK;
 }
 
@@ -172,31 +180,39 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
     int rc = sync_tables(e, s);
     if (rc) return rc;
     const Dev& d = e->d;
-    {
-    Timed t(e, s, 2);
-    hipLaunchKernelGGL(k2_reduce_wgstat, dim3(1), dim3(256), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl);
-    if (d_union == nullptr) {
-        hipLaunchKernelGGL(k2_ob_collect, dim3(1), dim3(1024), 0, s, d, e->d_ob_list, e->ob_list_cap, e->d_ob_n);
-        hipLaunchKernelGGL(k2_ob_sort_unique, dim3(1), dim3(1024), 0, s, d, e->d_ob_list, e->d_ob_n, e->ob_list_cap);
+    if (d.variant == 0 && e->window_events_in > e->cfg.max_window_events) {
+        e->err = "more events ingested in this window than max_window_events"; /* slabs may have overflowed into the counted drop path */
+    }
+    if (d.variant == 0) {
+        // pass B of K1 belongs to the K1 timing group: K1 = k1a_partition (per batch) + k1b_merge (per window)
+        Timed tp(e, s, 2);
+        if (d_union == nullptr) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u);
+        else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap, 0u);
     } else {
-        hipLaunchKernelGGL(k2_ob_sort_unique, dim3(1), dim3(1024), 0, s, d, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap);
+        Timed tp(e, s, 2);
+        if (d_union == nullptr) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u);
+        else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap, 0u);
     }
-    const u32 ntiles = e->ecap / K2_TILE;
-    hipLaunchKernelGGL(k2_edge_count, dim3(ntiles), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k2_scan_tiles, dim3(1), dim3(1024), 0, s, d, ntiles);
-    hipLaunchKernelGGL(k2_edge_compact, dim3(ntiles), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k2_rowptr, dim3(1), dim3(1024), 0, s, d);
-    hipLaunchKernelGGL(k2_scatter, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k2_rowsort, dim3(grid_for(d.ncap, 1)), dim3(256), 0, s, d);
+    if (d.variant == 0) {
+        Timed t1(e, s, 7);                                   // group 7 = K1 pass B (k1b_merge)
+        hipLaunchKernelGGL(k1b_merge, dim3(d.np), dim3(K1B_THREADS), e->k1b_lds, s, d);
     }
-    HIP_TRY(e, hipGetLastError());
     {
-        Timed t3(e, s, 3);
-        hipLaunchKernelGGL(k3_gather, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(k3_out_stats, dim3(grid_for(d.ncap, 4)), dim3(256), 0, s, d);
+        Timed t(e, s, 2);
+        if (d.variant == 1) {
+            const u32 ntiles = e->ecap / K2_TILE;
+            hipLaunchKernelGGL(k2_edge_count, dim3(ntiles), dim3(256), 0, s, d);
+            hipLaunchKernelGGL(k2_scan_tiles, dim3(1), dim3(1024), 0, s, d, ntiles);
+            hipLaunchKernelGGL(k2_edge_compact, dim3(ntiles), dim3(256), 0, s, d);
+        }
+        hipLaunchKernelGGL(k2_rowptr, dim3(1), dim3(1024), 0, s, d);
+        if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.np), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k2_rowsort_gather, dim3(grid_for(d.ncap, 4)), dim3(256), 0, s, d);
     }
     HIP_TRY(e, hipGetLastError());
     e->closed = true;
+    e->window_events_in = 0;
     return SG_OK;
 }
 
@@ -204,7 +220,6 @@ int do_features(sg_engine* e, hipStream_t s) {
     const Dev& d = e->d;
     Timed t(e, s, 3);
     hipLaunchKernelGGL(k3_node_features, dim3(grid_for(d.ncap, 256)), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k3_edge_features, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
@@ -239,14 +254,7 @@ int do_score(sg_engine* e, hipStream_t s) {
 }
 
 int do_reset(sg_engine* e, hipStream_t s) {
-    const Dev& d = e->d;
-    const size_t nc = (size_t)d.ncap + 1;
-    HIP_TRY(e, hipMemsetAsync(d.deg, 0, nc * sizeof(u32), s));
-    HIP_TRY(e, hipMemsetAsync(d.cursor, 0, nc * sizeof(u32), s));
-    HIP_TRY(e, hipMemsetAsync(d.st_sum, 0, (size_t)d.ncap * SG_NODE_STAT_SUM_WORDS * sizeof(u64), s));
-    HIP_TRY(e, hipMemsetAsync(d.st_max, 0, (size_t)d.ncap * SG_NODE_STAT_MAX_WORDS * sizeof(u64), s));
-    HIP_TRY(e, hipMemsetAsync(d.obkeys, 0, (size_t)e->obcap * sizeof(u64), s));
-    hipLaunchKernelGGL(k3_reset_overflow, dim3(1024), dim3(256), 0, s, d);   // no-op unless max_edges overflowed
+    hipLaunchKernelGGL(k_reset_window, dim3(grid_for(std::max<u64>((u64)e->d.ncap * SG_NODE_STAT_SUM_WORDS, e->obcap), 256, 512)), dim3(256), 0, s, e->d);
     HIP_TRY(e, hipGetLastError());
     e->closed = false;
     return SG_OK;
@@ -268,7 +276,7 @@ int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n) {
     st.last_window_edges = E;
     st.last_window_nodes = e->h_ctr[C_N_NODES];
     st.events_dropped_src += e->h_ctr[C_DROPPED_SRC];
-    st.events_dropped_cap += e->h_ctr[C_DROPPED_CAP] + (e->h_ctr[C_EDGES_FOUND] > e->cfg.max_edges ? e->h_ctr[C_EDGES_FOUND] - e->cfg.max_edges : 0);
+    st.events_dropped_cap += e->h_ctr[C_DROPPED_CAP];
     if (e->h_ctr[C_N_EVENTS]) {
         // convertKernelTimeToUserspaceTime()/1e6 — aggregator/data.go:1740-1743, :1219 (u64 wrap arithmetic)
         st.last_window_tmin_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMIN_NS])) / 1000000ull);
@@ -332,8 +340,37 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CH(hipHostMalloc((void**)&e->h_iptab, (size_t)e->ipcap * sizeof(IpEnt)));
     CH(hipHostMalloc((void**)&e->h_kind, cfg->max_known_nodes));
     e->kind.assign(cfg->max_known_nodes, 0);
+    // K1 variant: 0 = partitioned LDS aggregation (fast; bounded edges per partition), 1 = global table + atomics
+    if (e->cfg.max_window_events == 0) e->cfg.max_window_events = e->cfg.max_batch;
+    d.variant = cfg->k1_variant == 1 ? 1u : 0u;
+    {
+        u64 np = next_pow2(std::max<u64>(ME / 160, 64));
+        if (cfg->k1_variant == 0 && np > 1024) d.variant = 1;           // beyond the partitioned path's range
+        d.np = (u32)std::min<u64>(np, 1024); d.nwg = 256; d.pcap = 768;
+        const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
+        d.ss = (u32)(2.0 * m + 6.0 * std::sqrt(m + 1.0) + 8.0);
+        d.sa = d.ss / 2 + 8;
+        d.ovf_cap = 1u << 16;
+    }
+    size_t eslots = ME;
+    if (d.variant == 0) {
+        eslots = std::max<size_t>(ME, (size_t)d.np * d.pcap);
+        CR(dev_alloc(e, &d.slab_s, (size_t)d.np * d.nwg * d.ss));
+        CR(dev_alloc(e, &d.slab_a, (size_t)d.np * d.nwg * d.sa * 5));
+        CR(dev_alloc(e, &d.fill_s, (size_t)d.np * d.nwg)); CR(dev_alloc(e, &d.fill_a, (size_t)d.np * d.nwg));
+        CR(dev_alloc(e, &d.ovf, (size_t)d.ovf_cap * 5));
+        CR(dev_alloc(e, &d.part_n, d.np));
+        CR(dev_alloc(e, &d.acc_src, (size_t)d.np * d.pcap * 4));
+        e->k1a_lds = (size_t)K1A_HT * 8 + (size_t)K1A_HT * 32 + (size_t)d.np * 8;
+        e->k1b_lds = (size_t)K1B_HT * (8 + 32 + 40 + 4 + 4);
+        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
+        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
+        e->ecap = K2_TILE;                                              // the global edge table is not used
+    }
     CR(dev_alloc(e, &d.ekeys, e->ecap, 0xFF));
     CR(dev_alloc(e, &d.eacc, (size_t)e->ecap * 4));
+    if (d.variant == 1) d.acc_src = d.eacc;
+    d.emask = e->ecap - 1;
     CR(dev_alloc(e, &d.obkeys, e->obcap));
     CR(dev_alloc(e, &d.wgstat, (size_t)SG_MAX_K1_WGS * WS_WORDS));
     CR(dev_alloc(e, &d.ctr, C_COUNT));
@@ -342,7 +379,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CR(dev_alloc(e, &e->d_ob_n, 4));
     CR(dev_alloc(e, &d.tile_cnt, e->ecap / K2_TILE));
     CR(dev_alloc(e, &d.tile_off, e->ecap / K2_TILE));
-    CR(dev_alloc(e, &d.e_slot, ME)); CR(dev_alloc(e, &d.e_from, ME)); CR(dev_alloc(e, &d.e_to, ME));
+    CR(dev_alloc(e, &d.e_slot, ME)); CR(dev_alloc(e, &d.e_from, eslots)); CR(dev_alloc(e, &d.e_to, eslots));
     CR(dev_alloc(e, &d.deg, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.rowptr, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.cursor, (size_t)d.ncap + 1));
     CR(dev_alloc(e, &d.col, ME)); CR(dev_alloc(e, &d.cslot, ME)); CR(dev_alloc(e, &d.csr_from, ME));
     CR(dev_alloc(e, &d.sort_k, 2 * ME)); CR(dev_alloc(e, &d.sort_v, 2 * ME));

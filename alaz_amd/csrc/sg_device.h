@@ -30,7 +30,7 @@ enum {
     C_TMAX_NS,
     C_N_NODES,        // NK + NL + NOB
     C_EDGES_FOUND,    // edges found in the table before clamping
-    C_HALO_N,
+    C_OVF_N,          // records in the partition overflow list (window)
     C_COUNT = 16
 };
 
@@ -57,6 +57,17 @@ struct Dev {
     u64* wgstat;                              // [SG_MAX_K1_WGS][WS_WORDS]
     u64* ctr;                                 // [C_COUNT]
     u64 max_edges;
+    // ---- partitioned K1 (variant 0): per-(partition, workgroup) record slabs ----
+    u32 variant;                              // 0 = partitioned (LDS aggregation), 1 = global edge table + atomics
+    u32 np, nwg;                              // partitions (power of two), pass-A workgroups
+    u32 ss, sa;                               // slab piece capacity: single / aggregate records
+    uint4* slab_s;                            // [np][nwg][ss]   {key.lo, key.hi, dur.lo, dur.hi | err<<31}
+    u64*   slab_a;                            // [np][nwg][sa][5] {key, cnt|err<<32, sum_ns, max_ns, sumsq_us}
+    u32*   fill_s; u32* fill_a;               // [np][nwg]
+    u64*   ovf;  u32 ovf_cap;                 // overflow records [ovf_cap][5] (pieces that ran full)
+    u32*   part_n;                            // [np] distinct edges per partition
+    u32 pcap;                                 // edge capacity per partition
+    u64*   acc_src;                           // accumulators by slot: eacc (variant 1) or partition output (variant 0)
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs
     u32* tile_cnt;  u32* tile_off;            // compaction scratch

@@ -73,166 +73,32 @@ __device__ __forceinline__ u32 is_error(u32 proto, u32 status) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1  resolve_aggregate: events -> (from, to) node refs -> edge slot -> integer accumulators.
-// Replaces extractAddressPair + setFromToV2 + ReverseDirection + the per-request PersistRequest
-// (aggregator/data.go:1760-1767, 827-870; datastore/dto.go:226-231; backend.go:819-847).
-// Algorithmic bytes: 32 per event read; accumulators (32 B/edge) are written when the window closes.
+// block-level primitives (single-workgroup kernels use 1024 threads = 16 waves)
 // ------------------------------------------------------------------------------------------------
-struct K1Local { u64 tmin, tmax; u32 maxlabel, dsrc, dcap, misr, acc; };
-
-__device__ __forceinline__ void k1_one(const Dev& d, const uint4 a, const uint4 b, K1Local& L) {
-    const u32 saddr = a.x, daddr = a.y, label = a.z;
-    const u32 status = a.w & 0xFFFFu, proto = (a.w >> 16) & 0xFFu, flags = a.w >> 24;
-    const u64 dur = (u64)b.x | ((u64)b.y << 32), wt = (u64)b.z | ((u64)b.w << 32);
-
-    u32 spod = SG_NONE, ssvc = SG_NONE;
-    const bool sf = ip_lookup(d.iptab, d.ipmask, saddr, spod, ssvc);
-    if (!sf || spod == SG_NONE) { L.dsrc++; return; }           // data.go:829-832: source must be a pod
-    u32 from = SG_MAKE_REF(SG_REF_KNOWN, spod);
-    u32 from_owner = owner_hash_ref(from);
-
-    u32 dpod = SG_NONE, dsvc = SG_NONE, to, to_owner;
-    const bool df = ip_lookup(d.iptab, d.ipmask, daddr, dpod, dsvc);
-    if (df && dsvc != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dsvc); to_owner = owner_hash_ref(to); }       // service first (:840-843)
-    else if (df && dpod != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dpod); to_owner = owner_hash_ref(to); }  // then pod (:845-849)
-    else if (label != 0) {                                       // outbound, Host header (:851-854)
-        if (label > d.max_labels) { L.dcap++; return; }
-        to = SG_MAKE_REF(SG_REF_LABEL, label - 1); to_owner = owner_hash_ref(to);
-        L.maxlabel = label > L.maxlabel ? label : L.maxlabel;
-    } else {                                                     // outbound, raw IP (:862-863)
-        u32 os;
-        if (!table_slot(d.obkeys, d.obmask, (u64)daddr | (1ull << 32), 0ull, sg_fmix32(daddr) & d.obmask, os)) { L.dcap++; return; }
-        to = SG_MAKE_REF(SG_REF_OBIP, os); to_owner = owner_hash_obip(daddr);
+// exclusive scan of one value per thread over the workgroup; *total = sum.  wsum: LDS [NT/64 + 1].
+template <int NT>
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* wsum, u32* total) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const u32 o = __shfl_up(incl, s, 64); if ((int)lane >= s) incl += o; }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const u32 x = lane < NT / 64 ? wsum[lane] : 0u;
+        u32 xi = x;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { const u32 o = __shfl_up(xi, s, 64); if ((int)lane >= s) xi += o; }
+        if (lane < NT / 64) wsum[lane] = xi - x;
+        if (lane == 63) wsum[NT / 64] = xi;
     }
-    if (flags & SG_EV_REVERSE) { u32 t = from; from = to; to = t; t = from_owner; from_owner = to_owner; to_owner = t; }  // dto.go:226-231
-    if (d.world > 1 && (from_owner % d.world) != d.rank) { L.misr++; return; }
-
-    const u64 key = ((u64)from << 32) | (u64)to;
-    u32 slot;
-    if (!table_slot(d.ekeys, d.emask, key, SG_EKEY_EMPTY, hash_key64(key) & d.emask, slot)) { L.dcap++; return; }
-    u64* acc = d.eacc + (size_t)slot * 4;
-    const u64 us = dur / 1000ull;
-    atomicAdd(&acc[0], 1ull | ((u64)is_error(proto, status) << 32));
-    atomicAdd(&acc[1], dur);
-    atomicMax(&acc[2], dur);
-    atomicAdd(&acc[3], us * us);
-    L.acc++;
-    L.tmin = wt < L.tmin ? wt : L.tmin;
-    L.tmax = wt > L.tmax ? wt : L.tmax;
+    __syncthreads();
+    *total = wsum[NT / 64];
+    return wsum[wave] + incl - v;
 }
 
-__global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_event* __restrict__ ev, u64 n) {
-    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
-    const uint4* __restrict__ p = reinterpret_cast<const uint4*>(ev);
-    const u64 stride = (u64)gridDim.x * 256;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const uint4 a = p[2 * i], b = p[2 * i + 1];
-        k1_one(d, a, b, L);
-    }
-    // per-workgroup statistics: wave reduce, then one update of this workgroup's private line
-    const u64 tmin = wave_min_u64(L.tmin), tmax = wave_max_u64(L.tmax);
-    const u32 ml = (u32)wave_max_u64(L.maxlabel);
-    const u32 ds = wave_sum_u32(L.dsrc), dc = wave_sum_u32(L.dcap), mr = wave_sum_u32(L.misr), ac = wave_sum_u32(L.acc);
-    if ((threadIdx.x & 63) == 0) {
-        u64* w = d.wgstat + (size_t)(blockIdx.x % SG_MAX_K1_WGS) * WS_WORDS;
-        if (ac) { atomicMin(&w[WS_TMIN], tmin); atomicMax(&w[WS_TMAX], tmax); atomicAdd(&w[WS_ACCEPTED], (u64)ac); }
-        if (ml) atomicMax(&w[WS_MAXLABEL], (u64)ml);
-        if (ds) atomicAdd(&w[WS_DROPPED_SRC], (u64)ds);
-        if (dc) atomicAdd(&w[WS_DROPPED_CAP], (u64)dc);
-        if (mr) atomicAdd(&w[WS_MISROUTED], (u64)mr);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2  csr_build: canonical node numbering, edge compaction, CSR with sorted rows.
-// ------------------------------------------------------------------------------------------------
-
-// one workgroup: fold the per-workgroup K1 statistics into the counters and re-arm the slots.
-__global__ __launch_bounds__(256) void k2_reduce_wgstat(Dev d, u64 n_known, u64 n_labels_decl) {
-    u64 tmin = ~0ull, tmax = 0, ml = 0, ds = 0, dc = 0, mr = 0, ac = 0;
-    for (u32 i = threadIdx.x; i < SG_MAX_K1_WGS; i += 256) {
-        u64* w = d.wgstat + (size_t)i * WS_WORDS;
-        tmin = w[WS_TMIN] < tmin ? w[WS_TMIN] : tmin; tmax = w[WS_TMAX] > tmax ? w[WS_TMAX] : tmax;
-        ml = w[WS_MAXLABEL] > ml ? w[WS_MAXLABEL] : ml;
-        ds += w[WS_DROPPED_SRC]; dc += w[WS_DROPPED_CAP]; mr += w[WS_MISROUTED]; ac += w[WS_ACCEPTED];
-        w[WS_TMIN] = ~0ull; w[WS_TMAX] = 0; w[WS_MAXLABEL] = 0; w[WS_DROPPED_SRC] = 0; w[WS_DROPPED_CAP] = 0; w[WS_MISROUTED] = 0; w[WS_ACCEPTED] = 0;
-    }
-    __shared__ u64 s[7][4];
-    tmin = wave_min_u64(tmin); tmax = wave_max_u64(tmax); ml = wave_max_u64(ml);
-    ds = wave_sum_u64(ds); dc = wave_sum_u64(dc); mr = wave_sum_u64(mr); ac = wave_sum_u64(ac);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s[0][w] = tmin; s[1][w] = tmax; s[2][w] = ml; s[3][w] = ds; s[4][w] = dc; s[5][w] = mr; s[6][w] = ac; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; k++) {
-            s[0][0] = s[0][k] < s[0][0] ? s[0][k] : s[0][0]; s[1][0] = s[1][k] > s[1][0] ? s[1][k] : s[1][0];
-            s[2][0] = s[2][k] > s[2][0] ? s[2][k] : s[2][0]; s[3][0] += s[3][k]; s[4][0] += s[4][k]; s[5][0] += s[5][k]; s[6][0] += s[6][k];
-        }
-        d.ctr[C_TMIN_NS] = s[0][0]; d.ctr[C_TMAX_NS] = s[1][0];
-        u64 nl = d.ctr[C_N_LABELS];                          // labels are cumulative across windows
-        nl = s[2][0] > nl ? s[2][0] : nl; nl = n_labels_decl > nl ? n_labels_decl : nl;
-        d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known;
-        d.ctr[C_DROPPED_SRC] = s[3][0]; d.ctr[C_DROPPED_CAP] = s[4][0]; d.ctr[C_MISROUTED] = s[5][0]; d.ctr[C_N_EVENTS] = s[6][0];
-    }
-}
-
-// one workgroup (1024 threads): collect the distinct raw outbound IPs of the window.
-__global__ __launch_bounds__(1024) void k2_ob_collect(Dev d, u32* list, u32 list_cap, u32* n_out) {
-    __shared__ u32 cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    for (u32 i = threadIdx.x; i <= d.obmask; i += 1024) {
-        const u64 k = d.obkeys[i];
-        if (k) { const u32 pos = atomicAdd(&cnt, 1u); if (pos < list_cap) list[pos] = (u32)k; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *n_out = cnt < list_cap ? cnt : list_cap;
-}
-
-// one workgroup (1024 threads): sort list[0..*n_in) ascending (bitonic, in global memory), drop
-// duplicates, write the result to d.ob_sorted and its length to ctr[C_N_OBIP]; finalise N.
-__global__ __launch_bounds__(1024) void k2_ob_sort_unique(Dev d, u32* list, const u32* n_in, u32 cap_pow2) {
-    const u32 n = *n_in;
-    u32 np = 1; while (np < n) np <<= 1;
-    if (np > cap_pow2) np = cap_pow2;
-    for (u32 i = n + threadIdx.x; i < np; i += 1024) list[i] = 0xFFFFFFFFu;
-    __syncthreads();
-    for (u32 k = 2; k <= np; k <<= 1)
-        for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 i = threadIdx.x; i < np; i += 1024) {
-                const u32 x = i ^ j;
-                if (x > i) {
-                    const u32 a = list[i], b = list[x];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { list[i] = b; list[x] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    // unique: count of distinct predecessors gives the output position (n is small: raw-IP outbound)
-    __shared__ u32 total;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    // sequential chunks keep the output ordered
-    __shared__ u32 chunk_cnt[1024];
-    const u32 per = (n + 1023) / 1024;
-    const u32 beg = threadIdx.x * per, end = (beg + per < n) ? beg + per : n;
-    u32 c = 0;
-    for (u32 i = beg; i < end; i++) c += (i == 0 || list[i] != list[i - 1]) ? 1u : 0u;
-    chunk_cnt[threadIdx.x] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { u32 run = 0; for (u32 t = 0; t < 1024; t++) { const u32 v = chunk_cnt[t]; chunk_cnt[t] = run; run += v; } total = run; }
-    __syncthreads();
-    u32 pos = chunk_cnt[threadIdx.x];
-    for (u32 i = beg; i < end; i++) if (i == 0 || list[i] != list[i - 1]) { if (pos < d.max_obip) d.ob_sorted[pos] = list[i]; pos++; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const u64 nob = total < d.max_obip ? total : d.max_obip;
-        d.ctr[C_N_OBIP] = nob;
-        d.ctr[C_N_NODES] = d.ctr[C_N_KNOWN] + d.ctr[C_N_LABELS] + nob;
-    }
-}
-
+// ---- canonical node numbering ---------------------------------------------------------------------
 __device__ __forceinline__ u32 lower_bound_u32(const u32* a, u32 n, u32 v) {
     u32 lo = 0, hi = n;
     while (lo < hi) { const u32 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
@@ -257,6 +123,388 @@ __device__ __forceinline__ u32 owner_of_dense(const Dev& d, u32 v, u32 nk, u32 n
     return owner_hash_obip(d.ob_sorted[v - nk - nl]) % d.world;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1  resolve_aggregate: events -> (from, to) node refs -> per-edge integer accumulators.
+// Replaces extractAddressPair + setFromToV2 + ReverseDirection + the per-request PersistRequest
+// (aggregator/data.go:1760-1767, 827-870; datastore/dto.go:226-231; backend.go:819-847).
+// Algorithmic bytes: 32 per event read + 32 per distinct edge written.
+// ------------------------------------------------------------------------------------------------
+struct K1Local { u64 tmin, tmax; u32 maxlabel, dsrc, dcap, misr, acc; };
+struct K1Ev { u64 key, dur, wt; u32 err; };
+
+// the join: one event -> edge key, or a counted drop.
+__device__ __forceinline__ bool k1_resolve(const Dev& d, const uint4 a, const uint4 b, K1Local& L, K1Ev& e) {
+    const u32 saddr = a.x, daddr = a.y, label = a.z;
+    const u32 status = a.w & 0xFFFFu, proto = (a.w >> 16) & 0xFFu, flags = a.w >> 24;
+    e.dur = (u64)b.x | ((u64)b.y << 32); e.wt = (u64)b.z | ((u64)b.w << 32);
+
+    u32 spod = SG_NONE, ssvc = SG_NONE;
+    const bool sf = ip_lookup(d.iptab, d.ipmask, saddr, spod, ssvc);
+    if (!sf || spod == SG_NONE) { L.dsrc++; return false; }     // data.go:829-832: source must be a pod
+    u32 from = SG_MAKE_REF(SG_REF_KNOWN, spod);
+    u32 from_owner = owner_hash_ref(from);
+
+    u32 dpod = SG_NONE, dsvc = SG_NONE, to, to_owner;
+    const bool df = ip_lookup(d.iptab, d.ipmask, daddr, dpod, dsvc);
+    if (df && dsvc != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dsvc); to_owner = owner_hash_ref(to); }       // service first (:840-843)
+    else if (df && dpod != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dpod); to_owner = owner_hash_ref(to); }  // then pod (:845-849)
+    else if (label != 0) {                                       // outbound, Host header (:851-854)
+        if (label > d.max_labels) { L.dcap++; return false; }
+        to = SG_MAKE_REF(SG_REF_LABEL, label - 1); to_owner = owner_hash_ref(to);
+        L.maxlabel = label > L.maxlabel ? label : L.maxlabel;
+    } else {                                                     // outbound, raw IP (:862-863)
+        u32 os;
+        if (!table_slot(d.obkeys, d.obmask, (u64)daddr | (1ull << 32), 0ull, sg_fmix32(daddr) & d.obmask, os)) { L.dcap++; return false; }
+        to = SG_MAKE_REF(SG_REF_OBIP, os); to_owner = owner_hash_obip(daddr);
+    }
+    if (flags & SG_EV_REVERSE) { u32 t = from; from = to; to = t; t = from_owner; from_owner = to_owner; to_owner = t; }  // dto.go:226-231
+    if (d.world > 1 && (from_owner % d.world) != d.rank) { L.misr++; return false; }
+    e.key = ((u64)from << 32) | (u64)to;
+    e.err = is_error(proto, status);
+    L.acc++;
+    L.tmin = e.wt < L.tmin ? e.wt : L.tmin;
+    L.tmax = e.wt > L.tmax ? e.wt : L.tmax;
+    return true;
+}
+
+// per-workgroup statistics: wave reduce, then one update of this workgroup's private 64-byte line.
+__device__ __forceinline__ void k1_publish_stats(const Dev& d, const K1Local& L) {
+    const u64 tmin = wave_min_u64(L.tmin), tmax = wave_max_u64(L.tmax);
+    const u32 ml = (u32)wave_max_u64(L.maxlabel);
+    const u32 ds = wave_sum_u32(L.dsrc), dc = wave_sum_u32(L.dcap), mr = wave_sum_u32(L.misr), ac = wave_sum_u32(L.acc);
+    if ((threadIdx.x & 63) == 0) {
+        u64* w = d.wgstat + (size_t)(blockIdx.x % SG_MAX_K1_WGS) * WS_WORDS;
+        if (ac) { atomicMin(&w[WS_TMIN], tmin); atomicMax(&w[WS_TMAX], tmax); atomicAdd(&w[WS_ACCEPTED], (u64)ac); }
+        if (ml) atomicMax(&w[WS_MAXLABEL], (u64)ml);
+        if (ds) atomicAdd(&w[WS_DROPPED_SRC], (u64)ds);
+        if (dc) atomicAdd(&w[WS_DROPPED_CAP], (u64)dc);
+        if (mr) atomicAdd(&w[WS_MISROUTED], (u64)mr);
+    }
+}
+
+// ---- variant 1: global open-addressing edge table + device-scope atomics.  General (any number
+// of edges, any degree) but bound by the chip's ~22 G atomics/s and 12 ns per same-sector atomic
+// (profiles/r01_atomic_probe.txt): kept for graphs the partitioned path cannot hold. ----------------
+__global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_event* __restrict__ ev, u64 n) {
+    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
+    const uint4* __restrict__ p = reinterpret_cast<const uint4*>(ev);
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint4 a = p[2 * i], b = p[2 * i + 1];
+        K1Ev e;
+        if (!k1_resolve(d, a, b, L, e)) continue;
+        u32 slot;
+        if (!table_slot(d.ekeys, d.emask, e.key, SG_EKEY_EMPTY, hash_key64(e.key) & d.emask, slot)) { L.dcap++; L.acc--; continue; }
+        u64* acc = d.eacc + (size_t)slot * 4;
+        const u64 us = e.dur / 1000ull;
+        atomicAdd(&acc[0], 1ull | ((u64)e.err << 32));
+        atomicAdd(&acc[1], e.dur);
+        atomicMax(&acc[2], e.dur);
+        atomicAdd(&acc[3], us * us);
+    }
+    k1_publish_stats(d, L);
+}
+
+// ---- variant 0: partitioned aggregation, no device-scope atomics on the data path. ---------------
+// Pass A (k1a_partition): each workgroup streams its contiguous share of the batch in chunks of
+// 1024 events, aggregates a chunk in an LDS hash table (LDS atomics), then sweeps the table and
+// appends one record per distinct edge to the slab piece [partition(edge)][this workgroup]:
+// 16 bytes if the edge was hit once in the chunk, 40 bytes otherwise.  Hot edges collapse here, so
+// partitions stay balanced; the long tail passes through as 16-byte singles.
+// Pass B (k1b_merge, at window close): workgroup p owns partition p exclusively, merges its pieces
+// in LDS and writes each distinct edge once with plain stores.
+#define K1A_THREADS 512
+#define K1A_CHUNK   1024
+#define K1A_HT      2048
+#define K1B_HT      1024
+#define K1B_THREADS 256
+
+__device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return (hash_key64(key) >> 7) & (d.np - 1); }
+
+__device__ __forceinline__ u32 lds_slot(volatile u64* hkey, u32 mask, u64 key) {
+    u32 h = hash_key64(key) & mask;
+    for (;;) {
+        u64 k = hkey[h];
+        if (k == SG_EKEY_EMPTY) {
+            k = atomicCAS((u64*)&hkey[h], SG_EKEY_EMPTY, key);
+            if (k == SG_EKEY_EMPTY) return h;
+        }
+        if (k == key) return h;
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
+    const u64 idx = atomicAdd(&d.ctr[C_OVF_N], 1ull);
+    if (idx < d.ovf_cap) { u64* o = d.ovf + idx * 5; o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; }
+    else { const u32 c = (u32)(a0 & 0xFFFFFFFFull); L.dcap += c; L.acc -= c; }
+}
+
+__global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_event* __restrict__ ev, u64 n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* hkey = reinterpret_cast<u64*>(smem);                       // [K1A_HT]
+    u64* hacc = hkey + K1A_HT;                                       // [K1A_HT][4]
+    u32* fS = reinterpret_cast<u32*>(hacc + K1A_HT * 4);             // [np]
+    u32* fA = fS + d.np;                                             // [np]
+    const u32 w = blockIdx.x, t = threadIdx.x;
+    for (u32 i = t; i < K1A_HT; i += K1A_THREADS) hkey[i] = SG_EKEY_EMPTY;
+    for (u32 i = t; i < K1A_HT * 4; i += K1A_THREADS) hacc[i] = 0;
+    for (u32 p = t; p < d.np; p += K1A_THREADS) { fS[p] = d.fill_s[(size_t)p * d.nwg + w]; fA[p] = d.fill_a[(size_t)p * d.nwg + w]; }
+    __syncthreads();
+
+    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
+    const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
+    u64 per = (n + d.nwg - 1) / d.nwg;
+    per = (per + K1A_CHUNK - 1) / K1A_CHUNK * K1A_CHUNK;
+    const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
+    for (u64 c0 = beg; c0 < end; c0 += K1A_CHUNK) {
+        const u64 i0 = c0 + t, i1 = c0 + K1A_THREADS + t;
+        uint4 a0, b0, a1, b1;
+        const bool v0 = i0 < end, v1 = i1 < end;
+        if (v0) { a0 = pe[2 * i0]; b0 = pe[2 * i0 + 1]; }
+        if (v1) { a1 = pe[2 * i1]; b1 = pe[2 * i1 + 1]; }
+        K1Ev e;
+        if (v0 && k1_resolve(d, a0, b0, L, e)) {
+            const u32 s = lds_slot(hkey, K1A_HT - 1, e.key); const u64 us = e.dur / 1000ull;
+            atomicAdd(&hacc[s * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&hacc[s * 4 + 1], e.dur);
+            atomicMax(&hacc[s * 4 + 2], e.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
+        }
+        if (v1 && k1_resolve(d, a1, b1, L, e)) {
+            const u32 s = lds_slot(hkey, K1A_HT - 1, e.key); const u64 us = e.dur / 1000ull;
+            atomicAdd(&hacc[s * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&hacc[s * 4 + 1], e.dur);
+            atomicMax(&hacc[s * 4 + 2], e.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
+        }
+        __syncthreads();
+        // sweep: one record per distinct edge of the chunk
+#pragma unroll
+        for (u32 q = 0; q < K1A_HT / K1A_THREADS; q++) {
+            const u32 s = q * K1A_THREADS + t;
+            const u64 k = hkey[s];
+            if (k == SG_EKEY_EMPTY) continue;
+            const u64 x0 = hacc[s * 4], x1 = hacc[s * 4 + 1], x2 = hacc[s * 4 + 2], x3 = hacc[s * 4 + 3];
+            hkey[s] = SG_EKEY_EMPTY; hacc[s * 4] = 0; hacc[s * 4 + 1] = 0; hacc[s * 4 + 2] = 0; hacc[s * 4 + 3] = 0;
+            const u32 p = part_of(d, k);
+            if ((x0 & 0xFFFFFFFFull) == 1ull) {
+                const u32 pos = atomicAdd(&fS[p], 1u);
+                if (pos < d.ss) d.slab_s[((size_t)p * d.nwg + w) * d.ss + pos] = make_uint4((u32)k, (u32)(k >> 32), (u32)x1, (u32)(x1 >> 32) | ((u32)(x0 >> 32) << 31));
+                else ovf_append(d, k, x0, x1, x2, x3, L);
+            } else {
+                const u32 pos = atomicAdd(&fA[p], 1u);
+                if (pos < d.sa) { u64* o = d.slab_a + (((size_t)p * d.nwg + w) * d.sa + pos) * 5; o[0] = k; o[1] = x0; o[2] = x1; o[3] = x2; o[4] = x3; }
+                else ovf_append(d, k, x0, x1, x2, x3, L);
+            }
+        }
+        __syncthreads();
+    }
+    for (u32 p = t; p < d.np; p += K1A_THREADS) {
+        d.fill_s[(size_t)p * d.nwg + w] = fS[p] < d.ss ? fS[p] : d.ss;
+        d.fill_a[(size_t)p * d.nwg + w] = fA[p] < d.sa ? fA[p] : d.sa;
+    }
+    k1_publish_stats(d, L);
+}
+
+// Pass B.  LDS: edge table [K1B_HT] (key + 4 words), in-statistics table [K1B_HT] keyed by dense
+// destination (6 words).  Outputs, all with plain stores except the statistics of shared nodes:
+//   e_from/e_to [p*pcap + i]  dense endpoints        acc_src [(p*pcap + i)*4]  accumulators
+//   deg[from] += 1 (atomic; a row's edges are spread over the partitions)
+//   st_sum[to] in-words / st_max[to][1]: one atomic per distinct destination of the partition
+__global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* hkey = reinterpret_cast<u64*>(smem);                       // [K1B_HT]
+    u64* hacc = hkey + K1B_HT;                                       // [K1B_HT][4]
+    u64* tacc = hacc + K1B_HT * 4;                                   // [K1B_HT][5]  cnt, err, sum, ssq, max
+    u32* tkey = reinterpret_cast<u32*>(tacc + K1B_HT * 5);           // [K1B_HT]
+    u32* tdeg = tkey + K1B_HT;                                       // [K1B_HT]
+    __shared__ u32 n_edges, n_drop;
+    const u32 p = blockIdx.x, t = threadIdx.x;
+    for (u32 i = t; i < K1B_HT; i += K1B_THREADS) { hkey[i] = SG_EKEY_EMPTY; tkey[i] = SG_NONE; tdeg[i] = 0; }
+    for (u32 i = t; i < K1B_HT * 4; i += K1B_THREADS) hacc[i] = 0;
+    for (u32 i = t; i < K1B_HT * 5; i += K1B_THREADS) tacc[i] = 0;
+    if (t == 0) { n_edges = 0; n_drop = 0; }
+    __syncthreads();
+
+    auto add = [&](u64 key, u64 a0, u64 a1, u64 a2, u64 a3) {
+        // bounded probe: a partition may hold at most K1B_HT - 1 distinct edges
+        u32 h = hash_key64(key) & (K1B_HT - 1); bool ok = false;
+        for (u32 it = 0; it < K1B_HT; it++) {
+            u64 k = ((volatile u64*)hkey)[h];
+            if (k == SG_EKEY_EMPTY && ((volatile u32*)&n_edges)[0] < d.pcap) {
+                k = atomicCAS(&hkey[h], SG_EKEY_EMPTY, key);
+                if (k == SG_EKEY_EMPTY) { atomicAdd(&n_edges, 1u); k = key; }
+            }
+            if (k == key) { ok = true; break; }
+            h = (h + 1) & (K1B_HT - 1);
+        }
+        if (!ok) { atomicAdd(&n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
+        atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
+    };
+    for (u32 w = t; w < d.nwg; w += K1B_THREADS) {
+        const size_t piece = (size_t)p * d.nwg + w;
+        const u32 fs = d.fill_s[piece], fa = d.fill_a[piece];
+        const uint4* __restrict__ ps = d.slab_s + piece * d.ss;
+        for (u32 r = 0; r < fs; r++) {
+            const uint4 x = ps[r];
+            const u64 key = (u64)x.x | ((u64)x.y << 32), dur = (u64)x.z | ((u64)(x.w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
+            add(key, 1ull | ((u64)(x.w >> 31) << 32), dur, dur, us * us);
+        }
+        const u64* __restrict__ pa = d.slab_a + piece * d.sa * 5;
+        for (u32 r = 0; r < fa; r++) add(pa[r * 5], pa[r * 5 + 1], pa[r * 5 + 2], pa[r * 5 + 3], pa[r * 5 + 4]);
+        d.fill_s[piece] = 0; d.fill_a[piece] = 0;                    // window reset of the slab
+    }
+    {
+        const u64 no = d.ctr[C_OVF_N] < d.ovf_cap ? d.ctr[C_OVF_N] : d.ovf_cap;
+        for (u64 i = t; i < no; i += K1B_THREADS) {
+            const u64* o = d.ovf + i * 5;
+            if (part_of(d, o[0]) == p) add(o[0], o[1], o[2], o[3], o[4]);
+        }
+    }
+    __syncthreads();
+
+    // compact the table into the partition's output slots (order within a partition is arbitrary;
+    // the CSR row sort makes the final order canonical)
+    const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
+    __shared__ u32 out_n;
+    if (t == 0) out_n = 0;
+    __syncthreads();
+#pragma unroll
+    for (u32 q = 0; q < K1B_HT / K1B_THREADS; q++) {
+        const u32 s = q * K1B_THREADS + t;
+        const u64 k = hkey[s];
+        if (k == SG_EKEY_EMPTY) continue;
+        const u32 i = atomicAdd(&out_n, 1u);
+        if (i >= d.pcap) { atomicAdd(&n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
+        const u32 f = dense_of(d, (u32)(k >> 32), nk, nl, nob), to = dense_of(d, (u32)k, nk, nl, nob);
+        const size_t slot = (size_t)p * d.pcap + i;
+        d.e_from[slot] = f; d.e_to[slot] = to;
+        const u64 a0 = hacc[s * 4], a1 = hacc[s * 4 + 1], a2 = hacc[s * 4 + 2], a3 = hacc[s * 4 + 3];
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
+        o[0] = make_ulonglong2(a0, a1); o[1] = make_ulonglong2(a2, a3);
+        atomicAdd(&d.deg[f], 1u);
+        // destination in-statistics, pre-aggregated per partition
+        u32 h = sg_fmix32(to) & (K1B_HT - 1);
+        for (;;) {
+            u32 kk = ((volatile u32*)tkey)[h];
+            if (kk == SG_NONE) { kk = atomicCAS(&tkey[h], SG_NONE, to); if (kk == SG_NONE) kk = to; }
+            if (kk == to) break;
+            h = (h + 1) & (K1B_HT - 1);
+        }
+        atomicAdd(&tdeg[h], 1u);
+        atomicAdd(&tacc[h * 5], a0 & 0xFFFFFFFFull); atomicAdd(&tacc[h * 5 + 1], a0 >> 32);
+        atomicAdd(&tacc[h * 5 + 2], a1); atomicAdd(&tacc[h * 5 + 3], a3); atomicMax(&tacc[h * 5 + 4], a2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 q = 0; q < K1B_HT / K1B_THREADS; q++) {
+        const u32 s = q * K1B_THREADS + t;
+        const u32 to = tkey[s];
+        if (to == SG_NONE) continue;
+        u64* g = d.st_sum + (size_t)to * SG_NODE_STAT_SUM_WORDS;
+        atomicAdd(&g[ST_IN_DEG], (u64)tdeg[s]); atomicAdd(&g[ST_IN_CNT], tacc[s * 5]); atomicAdd(&g[ST_IN_ERR], tacc[s * 5 + 1]);
+        atomicAdd(&g[ST_IN_SUM], tacc[s * 5 + 2]); atomicAdd(&g[ST_IN_SSQ], tacc[s * 5 + 3]);
+        atomicMax(&d.st_max[(size_t)to * 2 + 1], tacc[s * 5 + 4]);
+    }
+    __syncthreads();
+    if (t == 0) {
+        d.part_n[p] = out_n < d.pcap ? out_n : d.pcap;
+        if (n_drop) atomicAdd(&d.ctr[C_DROPPED_CAP], (u64)n_drop);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  csr_build: canonical node numbering, CSR with sorted rows.
+// ------------------------------------------------------------------------------------------------
+// one workgroup (1024 threads): window bookkeeping.
+//   (a) fold the per-workgroup K1 statistics into the counters and re-arm the slots;
+//   (b) collect the window's distinct raw outbound IPs (or take the sharded driver's union list),
+//       sort them (bitonic, global memory), drop duplicates -> ob_sorted, N_OBIP;
+//   (c) N = NK + NL + NOB.
+__global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_labels_decl, u32* list, const u32* n_in, u32 list_cap, u32 collect) {
+    __shared__ u64 red[7][16];
+    __shared__ u32 wsum[17];
+    __shared__ u32 cnt;
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // (a)
+    {
+        u64 tmin = ~0ull, tmax = 0, ml = 0, ds = 0, dc = 0, mr = 0, ac = 0;
+        for (u32 i = t; i < SG_MAX_K1_WGS; i += 1024) {
+            u64* w = d.wgstat + (size_t)i * WS_WORDS;
+            tmin = w[WS_TMIN] < tmin ? w[WS_TMIN] : tmin; tmax = w[WS_TMAX] > tmax ? w[WS_TMAX] : tmax;
+            ml = w[WS_MAXLABEL] > ml ? w[WS_MAXLABEL] : ml;
+            ds += w[WS_DROPPED_SRC]; dc += w[WS_DROPPED_CAP]; mr += w[WS_MISROUTED]; ac += w[WS_ACCEPTED];
+            w[WS_TMIN] = ~0ull; w[WS_TMAX] = 0; w[WS_MAXLABEL] = 0; w[WS_DROPPED_SRC] = 0; w[WS_DROPPED_CAP] = 0; w[WS_MISROUTED] = 0; w[WS_ACCEPTED] = 0;
+        }
+        tmin = wave_min_u64(tmin); tmax = wave_max_u64(tmax); ml = wave_max_u64(ml);
+        ds = wave_sum_u64(ds); dc = wave_sum_u64(dc); mr = wave_sum_u64(mr); ac = wave_sum_u64(ac);
+        if (lane == 0) { red[0][wave] = tmin; red[1][wave] = tmax; red[2][wave] = ml; red[3][wave] = ds; red[4][wave] = dc; red[5][wave] = mr; red[6][wave] = ac; }
+        if (t == 0) cnt = 0;
+        __syncthreads();
+        if (t == 0) {
+            for (int k = 1; k < 16; k++) {
+                red[0][0] = red[0][k] < red[0][0] ? red[0][k] : red[0][0]; red[1][0] = red[1][k] > red[1][0] ? red[1][k] : red[1][0];
+                red[2][0] = red[2][k] > red[2][0] ? red[2][k] : red[2][0];
+                red[3][0] += red[3][k]; red[4][0] += red[4][k]; red[5][0] += red[5][k]; red[6][0] += red[6][k];
+            }
+            d.ctr[C_TMIN_NS] = red[0][0]; d.ctr[C_TMAX_NS] = red[1][0];
+            u64 nl = d.ctr[C_N_LABELS];                              // labels are cumulative across windows
+            nl = red[2][0] > nl ? red[2][0] : nl; nl = n_labels_decl > nl ? n_labels_decl : nl;
+            d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known;
+            d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_DROPPED_CAP] += red[4][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
+        }
+    }
+    // (b)
+    u32 n;
+    if (collect) {
+        for (u32 i = t; i <= d.obmask; i += 1024) {
+            const u64 k = d.obkeys[i];
+            if (k) { const u32 pos = atomicAdd(&cnt, 1u); if (pos < list_cap) list[pos] = (u32)k; }
+        }
+        __syncthreads();
+        n = cnt < list_cap ? cnt : list_cap;
+    } else {
+        n = *n_in < list_cap ? *n_in : list_cap;
+    }
+    u32 np2 = 1; while (np2 < n) np2 <<= 1;
+    for (u32 i = n + t; i < np2; i += 1024) list[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 k = 2; k <= np2; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 i = t; i < np2; i += 1024) {
+                const u32 x = i ^ j;
+                if (x > i) {
+                    const u32 a = list[i], b = list[x];
+                    if ((a > b) == ((i & k) == 0)) { list[i] = b; list[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const u32 per = (n + 1023) / 1024;
+    const u32 beg = t * per < n ? t * per : n, end = (beg + per < n) ? beg + per : n;
+    u32 c = 0;
+    for (u32 i = beg; i < end; i++) c += (i == 0 || list[i] != list[i - 1]) ? 1u : 0u;
+    u32 total;
+    u32 pos = block_excl_scan<1024>(c, wsum, &total);
+    for (u32 i = beg; i < end; i++) if (i == 0 || list[i] != list[i - 1]) { if (pos < d.max_obip) d.ob_sorted[pos] = list[i]; pos++; }
+    if (t == 0) {
+        const u64 nob = total < d.max_obip ? total : d.max_obip;
+        d.ctr[C_N_OBIP] = nob;
+        d.ctr[C_N_NODES] = d.ctr[C_N_KNOWN] + d.ctr[C_N_LABELS] + nob;   // thread 0 wrote both above
+    }
+}
+
+// one workgroup: the window's distinct raw outbound IPs into a caller-owned list (sharded driver).
+__global__ __launch_bounds__(1024) void k2_ob_collect(Dev d, u32* list, u32 list_cap, u32* n_out) {
+    __shared__ u32 cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i <= d.obmask; i += 1024) {
+        const u64 k = d.obkeys[i];
+        if (k) { const u32 pos = atomicAdd(&cnt, 1u); if (pos < list_cap) list[pos] = (u32)k; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *n_out = cnt < list_cap ? cnt : list_cap;
+}
+
+// ---- variant 1 only: compaction of the global edge table in ascending slot order -------------------
 #define K2_TILE 2048   // table slots per workgroup (256 threads x 8)
 
 __global__ __launch_bounds__(256) void k2_edge_count(Dev d) {
@@ -272,27 +520,21 @@ __global__ __launch_bounds__(256) void k2_edge_count(Dev d) {
     if (threadIdx.x == 0) d.tile_cnt[tile] = s[0] + s[1] + s[2] + s[3];
 }
 
-// one workgroup: exclusive scan of the tile counts.
 __global__ __launch_bounds__(1024) void k2_scan_tiles(Dev d, u32 ntiles) {
-    __shared__ u32 part[1024];
+    __shared__ u32 wsum[17];
     const u32 per = (ntiles + 1023) / 1024;
-    const u32 beg = threadIdx.x * per, end = beg + per < ntiles ? beg + per : ntiles;
+    const u32 beg = threadIdx.x * per < ntiles ? threadIdx.x * per : ntiles, end = beg + per < ntiles ? beg + per : ntiles;
     u32 c = 0;
     for (u32 i = beg; i < end; i++) c += d.tile_cnt[i];
-    part[threadIdx.x] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 run = 0;
-        for (u32 t = 0; t < 1024; t++) { const u32 v = part[t]; part[t] = (u32)run; run += v; }
-        d.ctr[C_EDGES_FOUND] = run;
-        d.ctr[C_N_EDGES] = run < d.max_edges ? run : d.max_edges;
-    }
-    __syncthreads();
-    u32 run = part[threadIdx.x];
+    u32 total;
+    u32 run = block_excl_scan<1024>(c, wsum, &total);
     for (u32 i = beg; i < end; i++) { const u32 v = d.tile_cnt[i]; d.tile_off[i] = run; run += v; }
+    if (threadIdx.x == 0) {
+        d.ctr[C_EDGES_FOUND] = total;
+        if ((u64)total > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)total - d.max_edges;
+    }
 }
 
-// compaction in ascending slot order (deterministic), dense endpoints, out-degree histogram.
 __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
     const u32 tile = blockIdx.x;
     if (d.tile_cnt[tile] == 0) return;
@@ -301,7 +543,6 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
     u64 k[8]; u32 c = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) { k[j] = d.ekeys[(size_t)base_slot + j]; c += k[j] != SG_EKEY_EMPTY; }
-    // block exclusive scan of c
     __shared__ u32 wsum[4];
     u32 incl = c;
 #pragma unroll
@@ -322,134 +563,46 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
     }
 }
 
-// one workgroup: rowptr = exclusive scan of deg[0..N); rowptr[N] = E.
+// one workgroup: rowptr = exclusive scan of deg[0..N); rowptr[N] = E = edges of the window.
 __global__ __launch_bounds__(1024) void k2_rowptr(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES];
-    __shared__ u32 part[1024];
+    __shared__ u32 wsum[17];
     const u32 per = (N + 1023) / 1024;
-    const u32 beg = threadIdx.x * per, end = beg + per < N ? beg + per : N;
+    const u32 beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
     u32 c = 0;
     for (u32 i = beg; i < end; i++) c += d.deg[i];
-    part[threadIdx.x] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { u32 run = 0; for (u32 t = 0; t < 1024; t++) { const u32 v = part[t]; part[t] = run; run += v; } d.rowptr[N] = run; }
-    __syncthreads();
-    u32 run = part[threadIdx.x];
+    u32 total;
+    u32 run = block_excl_scan<1024>(c, wsum, &total);
     for (u32 i = beg; i < end; i++) { d.rowptr[i] = run; run += d.deg[i]; }
+    if (threadIdx.x == 0) {
+        d.rowptr[N] = total;
+        d.ctr[C_N_EDGES] = (u64)total < d.max_edges ? total : d.max_edges;
+        if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = total; if ((u64)total > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)total - d.max_edges; }
+    }
 }
 
-__global__ __launch_bounds__(256) void k2_scatter(Dev d) {
+// scatter into CSR rows (order inside a row is fixed afterwards by the row sort)
+__global__ __launch_bounds__(256) void k2_scatter_table(Dev d) {
     const u32 E = (u32)d.ctr[C_N_EDGES];
     for (u32 i = blockIdx.x * 256 + threadIdx.x; i < E; i += gridDim.x * 256) {
         const u32 f = d.e_from[i];
         const u32 pos = d.rowptr[f] + atomicAdd(&d.cursor[f], 1u);
-        d.col[pos] = d.e_to[i]; d.cslot[pos] = d.e_slot[i]; d.csr_from[pos] = f;
+        d.col[pos] = d.e_to[i]; d.cslot[pos] = d.e_slot[i];
+    }
+}
+__global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
+    const u32 p = blockIdx.x, n = d.part_n[p];
+    for (u32 i = threadIdx.x; i < n; i += 256) {
+        const u32 slot = p * d.pcap + i;
+        const u32 f = d.e_from[slot];
+        const u32 pos = d.rowptr[f] + atomicAdd(&d.cursor[f], 1u);
+        if (pos < d.max_edges) { d.col[pos] = d.e_to[slot]; d.cslot[pos] = slot; }
     }
 }
 
-#define K2_SORT_LDS 4096
-// one workgroup per row: sort the row by destination (keys are distinct), carrying the slot.
-__global__ __launch_bounds__(256) void k2_rowsort(Dev d) {
-    const u32 N = (u32)d.ctr[C_N_NODES];
-    __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
-    for (u32 r = blockIdx.x; r < N; r += gridDim.x) {
-        const u32 beg = d.rowptr[r], n = d.rowptr[r + 1] - beg;
-        if (n <= 1) continue;
-        u32* key = d.col + beg; u32* val = d.cslot + beg;
-        if (n <= 64) {
-            if (threadIdx.x < 64) {
-                const u32 l = threadIdx.x;
-                const u32 k = l < n ? key[l] : 0xFFFFFFFFu, v = l < n ? val[l] : 0;
-                u32 rank = 0;
-                for (u32 j = 0; j < n; j++) rank += __shfl(k, (int)j, 64) < k;
-                if (l < n) { key[rank] = k; val[rank] = v; }
-            }
-        } else if (n <= K2_SORT_LDS) {
-            u32 np = 1; while (np < n) np <<= 1;
-            for (u32 i = threadIdx.x; i < np; i += 256) { sk[i] = i < n ? key[i] : 0xFFFFFFFFu; sv[i] = i < n ? val[i] : 0; }
-            __syncthreads();
-            for (u32 k = 2; k <= np; k <<= 1)
-                for (u32 j = k >> 1; j > 0; j >>= 1) {
-                    for (u32 i = threadIdx.x; i < np; i += 256) {
-                        const u32 x = i ^ j;
-                        if (x > i) {
-                            const u32 a = sk[i], b = sk[x];
-                            if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[x] = a; const u32 t = sv[i]; sv[i] = sv[x]; sv[x] = t; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (u32 i = threadIdx.x; i < n; i += 256) { key[i] = sk[i]; val[i] = sv[i]; }
-        } else {
-            // very long row (> LDS capacity): bitonic sort in a private, power-of-two padded slice of
-            // the global scratch (offset 2*beg: slices of different rows never overlap).
-            u32 np = 1; while (np < n) np <<= 1;
-            u32* gk = d.sort_k + 2 * (size_t)beg; u32* gv = d.sort_v + 2 * (size_t)beg;
-            for (u32 i = threadIdx.x; i < np; i += 256) { gk[i] = i < n ? key[i] : 0xFFFFFFFFu; gv[i] = i < n ? val[i] : 0; }
-            __syncthreads();
-            for (u32 k = 2; k <= np; k <<= 1)
-                for (u32 j = k >> 1; j > 0; j >>= 1) {
-                    for (u32 i = threadIdx.x; i < np; i += 256) {
-                        const u32 x = i ^ j;
-                        if (x > i) {
-                            const u32 a = gk[i], b = gk[x];
-                            if ((a > b) == ((i & k) == 0)) { gk[i] = b; gk[x] = a; const u32 t = gv[i]; gv[i] = gv[x]; gv[x] = t; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (u32 i = threadIdx.x; i < n; i += 256) { key[i] = gk[i]; val[i] = gv[i]; }
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3  node_features: accumulators -> CSR order, integer node statistics, fp32 features.
-// ------------------------------------------------------------------------------------------------
-
-// thread per CSR position: move the accumulator into CSR order, clear the table slot (this is the
-// window reset of the edge table), and add the edge into its destination's in-statistics.
-__global__ __launch_bounds__(256) void k3_gather(Dev d) {
-    const u32 E = (u32)d.ctr[C_N_EDGES];
-    for (u32 pos = blockIdx.x * 256 + threadIdx.x; pos < E; pos += gridDim.x * 256) {
-        const u32 slot = d.cslot[pos];
-        ulonglong2* src = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)slot * 4);
-        const ulonglong2 a = src[0], b = src[1];
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)pos * 4);
-        dst[0] = a; dst[1] = b;
-        src[0] = make_ulonglong2(0, 0); src[1] = make_ulonglong2(0, 0);
-        d.ekeys[slot] = SG_EKEY_EMPTY;
-        const u64 cnt = a.x & 0xFFFFFFFFull, err = a.x >> 32;
-        u64* t = d.st_sum + (size_t)d.col[pos] * SG_NODE_STAT_SUM_WORDS;
-        atomicAdd(&t[ST_IN_DEG], 1ull); atomicAdd(&t[ST_IN_CNT], cnt); atomicAdd(&t[ST_IN_ERR], err);
-        atomicAdd(&t[ST_IN_SUM], a.y); atomicAdd(&t[ST_IN_SSQ], b.y);
-        atomicMax(&d.st_max[(size_t)d.col[pos] * 2 + 1], b.x);
-    }
-}
-
-// wave per row: out-statistics by a plain reduction over the row (no atomics; one wave owns a row).
-__global__ __launch_bounds__(256) void k3_out_stats(Dev d) {
-    const u32 N = (u32)d.ctr[C_N_NODES];
-    const u32 lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
-    for (u32 r = wave; r < N; r += nw) {
-        const u32 beg = d.rowptr[r], end = d.rowptr[r + 1];
-        if (beg == end) continue;
-        u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
-        for (u32 p = beg + lane; p < end; p += 64) {
-            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
-            const ulonglong2 x = a[0], y = a[1];
-            cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
-        }
-        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
-        if (lane == 0) {
-            u64* t = d.st_sum + (size_t)r * SG_NODE_STAT_SUM_WORDS;
-            t[ST_OUT_DEG] = end - beg; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
-            d.st_max[(size_t)r * 2] = mx;
-        }
-    }
-}
-
+// ---- row sort + gather: per row, sort by destination, move the accumulators into CSR order,
+// reduce the row's out-statistics (plain reduction: one owner per row) and compute e_uv, lat_z,
+// err_ratio of its edges.  Rows up to 64 edges are handled by one wave, 4 rows per workgroup at a time.
 __device__ __forceinline__ double mean_us(u64 sum_ns, u64 cnt) { return cnt ? ((double)sum_ns / 1000.0) / (double)cnt : 0.0; }
 __device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
     if (!cnt) return 0.0;
@@ -458,7 +611,120 @@ __device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
     return v > 0.0 ? sqrt(v) : 0.0;
 }
 
-// thread per node: x_v (DESIGN.md "node features"); fp64 intermediates, one rounding to fp32.
+// everything that is per edge once its row statistics are known
+__device__ __forceinline__ void edge_emit(const Dev& d, u32 pos, u32 row, u32 slot, u64 r_cnt, u64 r_sum, u64 r_ssq,
+                                          const ulonglong2 x, const ulonglong2 y) {
+    const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)pos * 4);
+    dst[0] = x; dst[1] = y;
+    d.csr_from[pos] = row;
+    const double m_e = mean_us(sum, cnt), s_e = std_us(sum, ssq, cnt);
+    const double mu = mean_us(r_sum, r_cnt), sd = std_us(r_sum, r_ssq, r_cnt);
+    const double z = (m_e - mu) / (sd > 1.0 ? sd : 1.0);
+    const float lat_z = (float)z;
+    const float err_ratio = cnt ? (float)((double)err / (double)cnt) : 0.0f;
+    const float zc = lat_z < -8.0f ? -8.0f : (lat_z > 8.0f ? 8.0f : lat_z);
+    float4* e = reinterpret_cast<float4*>(d.efeat + (size_t)pos * SG_F_EDGE);
+    e[0] = make_float4((float)log1p((double)cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
+    e[1] = make_float4(err_ratio, (float)log1p((double)err), zc * 0.125f, 1.0f);
+    d.latz[pos] = lat_z; d.errr[pos] = err_ratio;
+    if (d.variant == 1) {
+        // variant 1: this is also the window reset of the edge table, and the in-statistics (raw atomics)
+        ulonglong2* src = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)slot * 4);
+        src[0] = make_ulonglong2(0, 0); src[1] = make_ulonglong2(0, 0);
+        d.ekeys[slot] = SG_EKEY_EMPTY;
+        u64* t = d.st_sum + (size_t)d.col[pos] * SG_NODE_STAT_SUM_WORDS;
+        atomicAdd(&t[ST_IN_DEG], 1ull); atomicAdd(&t[ST_IN_CNT], cnt); atomicAdd(&t[ST_IN_ERR], err);
+        atomicAdd(&t[ST_IN_SUM], sum); atomicAdd(&t[ST_IN_SSQ], ssq);
+        atomicMax(&d.st_max[(size_t)d.col[pos] * 2 + 1], mx);
+    }
+}
+
+#define K2_SORT_LDS 4096
+__global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
+    __shared__ u64 red[5][4];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 r0 = blockIdx.x * 4; r0 < N; r0 += gridDim.x * 4) {
+        // ---- wave path: rows with <= 64 edges ----
+        const u32 r = r0 + wave;
+        u32 beg = 0, n = 0;
+        if (r < N) { beg = d.rowptr[r]; n = d.rowptr[r + 1] - beg; if ((u64)beg + n > d.max_edges) n = beg < d.max_edges ? (u32)(d.max_edges - beg) : 0; }
+        if (n > 0 && n <= 64) {
+            const u32 k = lane < n ? d.col[beg + lane] : 0xFFFFFFFFu, v = lane < n ? d.cslot[beg + lane] : 0;
+            u32 rank = 0;
+            for (u32 j = 0; j < n; j++) rank += __shfl(k, (int)j, 64) < k;
+            ulonglong2 x = make_ulonglong2(0, 0), y = make_ulonglong2(0, 0);
+            if (lane < n) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v * 4); x = a[0]; y = a[1]; }
+            const u64 cnt = wave_sum_u64(x.x & 0xFFFFFFFFull), err = wave_sum_u64(x.x >> 32), sum = wave_sum_u64(x.y), ssq = wave_sum_u64(y.y), mx = wave_max_u64(y.x);
+            if (lane < n) { d.col[beg + rank] = k; }
+            if (lane == 0) {
+                u64* t = d.st_sum + (size_t)r * SG_NODE_STAT_SUM_WORDS;
+                t[ST_OUT_DEG] = n; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+                d.st_max[(size_t)r * 2] = mx;
+            }
+            if (lane < n) edge_emit(d, beg + rank, r, v, cnt, sum, ssq, x, y);
+        }
+        __syncthreads();
+        // ---- workgroup path: the (rare) longer rows of this group of 4, one after the other ----
+        for (u32 q = 0; q < 4; q++) {
+            const u32 rr = r0 + q;
+            if (rr >= N) break;
+            const u32 b = d.rowptr[rr];
+            u32 m = d.rowptr[rr + 1] - b;
+            if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
+            if (m <= 64) continue;
+            u32* key = d.col + b; u32* val = d.cslot + b;
+            u32 np2 = 1; while (np2 < m) np2 <<= 1;
+            u32* gk = sk; u32* gv = sv;
+            if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
+            for (u32 i = threadIdx.x; i < np2; i += 256) { gk[i] = i < m ? key[i] : 0xFFFFFFFFu; gv[i] = i < m ? val[i] : 0; }
+            __syncthreads();
+            for (u32 k = 2; k <= np2; k <<= 1)
+                for (u32 j = k >> 1; j > 0; j >>= 1) {
+                    for (u32 i = threadIdx.x; i < np2; i += 256) {
+                        const u32 x = i ^ j;
+                        if (x > i) {
+                            const u32 a = gk[i], c = gk[x];
+                            if ((a > c) == ((i & k) == 0)) { gk[i] = c; gk[x] = a; const u32 tt = gv[i]; gv[i] = gv[x]; gv[x] = tt; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
+            for (u32 i = threadIdx.x; i < m; i += 256) {
+                const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
+                const ulonglong2 x = a[0], y = a[1];
+                cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
+            }
+            cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+            if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+            __syncthreads();
+            cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+            mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+            if (threadIdx.x == 0) {
+                u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
+                t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+                d.st_max[(size_t)rr * 2] = mx;
+            }
+            for (u32 i = threadIdx.x; i < m; i += 256) {
+                const u32 slot = gv[i];
+                key[i] = gk[i];
+                const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
+                const ulonglong2 x = a[0], y = a[1];
+                edge_emit(d, b + i, rr, slot, cnt, sum, ssq, x, y);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  node_features: fp32 x_v from the integer node statistics.
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN];
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < N; v += gridDim.x * 256) {
@@ -490,36 +756,24 @@ __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
     }
 }
 
-// thread per edge: e_uv, lat_z, err_ratio.
-__global__ __launch_bounds__(256) void k3_edge_features(Dev d) {
-    const u32 E = (u32)d.ctr[C_N_EDGES];
-    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < E; p += gridDim.x * 256) {
-        const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
-        const ulonglong2 x = a[0], y = a[1];
-        const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
-        const u64* su = d.st_sum + (size_t)d.csr_from[p] * SG_NODE_STAT_SUM_WORDS;
-        const double m_e = mean_us(sum, cnt), s_e = std_us(sum, ssq, cnt);
-        const double mu = mean_us(su[ST_OUT_SUM], su[ST_OUT_CNT]), sd = std_us(su[ST_OUT_SUM], su[ST_OUT_SSQ], su[ST_OUT_CNT]);
-        const double z = (m_e - mu) / (sd > 1.0 ? sd : 1.0);
-        const float lat_z = (float)z;
-        const float err_ratio = cnt ? (float)((double)err / (double)cnt) : 0.0f;
-        const float zc = lat_z < -8.0f ? -8.0f : (lat_z > 8.0f ? 8.0f : lat_z);
-        float4* e = reinterpret_cast<float4*>(d.efeat + (size_t)p * SG_F_EDGE);
-        e[0] = make_float4((float)log1p((double)cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
-        e[1] = make_float4(err_ratio, (float)log1p((double)err), zc * 0.125f, 1.0f);
-        d.latz[p] = lat_z; d.errr[p] = err_ratio;
+// window reset in one launch (replaces seven memsets): node arrays, outbound-ip table, window
+// counters; for variant 1 also the whole edge table if more edges were found than max_edges.
+__global__ __launch_bounds__(256) void k_reset_window(Dev d) {
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
+    const u64 nc = (u64)d.ncap + 1;
+    for (u64 i = tid; i < nc; i += nt) { d.deg[i] = 0; d.cursor[i] = 0; }
+    for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
+    for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
+    for (u64 i = tid; i <= d.obmask; i += nt) d.obkeys[i] = 0;
+    if (d.variant == 1 && d.ctr[C_EDGES_FOUND] > d.max_edges) {
+        for (u64 i = tid; i <= d.emask; i += nt) {
+            d.ekeys[i] = SG_EKEY_EMPTY;
+            ulonglong2* a = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)i * 4);
+            a[0] = make_ulonglong2(0, 0); a[1] = make_ulonglong2(0, 0);
+        }
     }
-}
-
-// Window reset of the edge table when more distinct edges were found than max_edges: the unlisted
-// slots were not cleared by k3_gather, so the whole table is wiped.  Exits at once otherwise.
-__global__ __launch_bounds__(256) void k3_reset_overflow(Dev d) {
-    if (d.ctr[C_EDGES_FOUND] <= d.max_edges) return;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i <= d.emask; i += (u64)gridDim.x * 256) {
-        d.ekeys[i] = SG_EKEY_EMPTY;
-        ulonglong2* a = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)i * 4);
-        a[0] = make_ulonglong2(0, 0); a[1] = make_ulonglong2(0, 0);
-    }
+    __syncthreads();
+    if (tid == 0) { d.ctr[C_OVF_N] = 0; d.ctr[C_DROPPED_CAP] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -143,7 +143,10 @@ typedef struct sg_config {
     uint32_t layers;            /* GraphSAGE layers L, 1..SG_MAX_LAYERS                         */
     uint32_t rank;              /* this shard                                                   */
     uint32_t world;             /* number of shards (1 = unsharded)                             */
-    uint32_t k1_variant;        /* 0 = default; others select tuning variants of K1             */
+    uint32_t k1_variant;        /* 0 = auto (partitioned LDS aggregation when the graph fits it),
+                                   1 = global edge table + device-scope atomics (any size)       */
+    uint64_t max_window_events; /* most events one window may carry (sizes the K1 record slabs;
+                                   0 = max_batch)                                               */
 } sg_config;
 
 #define SG_MAX_LAYERS 4u

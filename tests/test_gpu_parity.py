@@ -27,9 +27,10 @@ def _oracle(topo_ops, layers):
     return o
 
 
-def _run_both(topo, batches, labels, layers, *, max_edges=None, chunk=1 << 18):
+def _run_both(topo, batches, labels, layers, *, max_edges=None, chunk=1 << 18, variant=0):
     ops = topo.k8s_ops()
-    g = _engine(topo.n_nodes + 8, max_edges or 4 * len(topo.edge_src) + 1024, layers)
+    g = _engine(topo.n_nodes + 8, max_edges or 4 * len(topo.edge_src) + 1024, layers, k1_variant=variant,
+                max_window_events=max(len(b) for b in batches) + 1)
     shim = HostShim(); shim.apply(g, ops)
     o = _oracle(ops, layers)
     W = weights.make_weights(layers)
@@ -76,8 +77,9 @@ def test_config1_full_reference_path():
     assert st.events_dropped_src == o.dropped_src > 0 and st.events_in == len(ev)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("layers", [1, 2])
-def test_edge_cases_mixed_trace(layers):
+def test_edge_cases_mixed_trace(layers, variant):
     """raw-IP outbound, Host-header outbound, unknown sources, AMQP/Redis reversal, TLS, Kafka and
     Postgres status semantics, two windows, ragged batches."""
     topo = replay.make_topology(150, 1500, seed=31)
@@ -92,17 +94,19 @@ def test_edge_cases_mixed_trace(layers):
         remap[i + 1] = lab_all.index(s) + 1
     ev2 = ev2.copy(); ev2["host_label"] = remap[ev2["host_label"]]
     # oracle interns labels in first-use order: feed it the same cumulative table
-    _run_both(topo, [ev1, ev2], lab_all, layers, chunk=7777)
+    _run_both(topo, [ev1, ev2], lab_all, layers, chunk=7777, variant=variant)
 
 
-def test_empty_and_tiny_windows():
+@pytest.mark.parametrize("variant", [0, 1])
+def test_empty_and_tiny_windows(variant):
     topo = replay.make_topology(20, 40, seed=5)
     ev, labels = replay.make_events(topo, 3, seed=6)
-    g, o, _ = _run_both(topo, [ev[:0], ev[:1], ev, ev[:0]], labels, 1)
+    g, o, _ = _run_both(topo, [ev[:0], ev[:1], ev, ev[:0]], labels, 1, variant=variant)
     assert g.stats().windows == 4
 
 
-def test_table_updates_between_windows():
+@pytest.mark.parametrize("variant", [0, 1])
+def test_table_updates_between_windows(variant):
     """ADD / UPDATE / DELETE between windows (persist.go:55-71,114-130), incl. an IP that is both a
     pod and a service (service wins, data.go:840-849) and a deleted source (events dropped)."""
     from alaz_amd import engine
@@ -110,7 +114,7 @@ def test_table_updates_between_windows():
     topo = replay.make_topology(30, 120, seed=9)
     ev, labels = replay.make_events(topo, 20_000, seed=10)
     ops0 = topo.k8s_ops()
-    g = _engine(topo.n_nodes + 16, 4096, 1)
+    g = _engine(topo.n_nodes + 16, 4096, 1, k1_variant=variant)
     shim = HostShim(); shim.apply(g, ops0)
     o = pyoracle.Oracle(*CLOCK); o.apply_ops(ops0)
     W = weights.make_weights(1)
@@ -135,11 +139,12 @@ def test_table_updates_between_windows():
     assert g.stats().events_dropped_src == o.dropped_src
 
 
-def test_config2_full_size_bit_exact_and_deterministic():
+@pytest.mark.parametrize("variant", [0, 1])
+def test_config2_full_size_bit_exact_and_deterministic(variant):
     """BASELINE config 2 (1k pods / 50k edges / 1M events, L=1) against the oracle, run twice: the
     second run must reproduce the first bit for bit (integer atomics + canonical CSR order)."""
     topo, ev, labels, L = replay.make_config(2)
-    g, o, worst = _run_both(topo, [ev], labels, L, max_edges=1 << 17)
+    g, o, worst = _run_both(topo, [ev], labels, L, max_edges=1 << 16, variant=variant)
     rows_a = None
     for _ in range(2):
         for i in range(0, len(ev), 1 << 18):
@@ -211,7 +216,7 @@ def test_device_resident_ingest_and_staged_pipeline():
 def test_capacity_overflow_is_counted_not_silent():
     topo = replay.make_topology(60, 800, seed=61)
     ev, labels = replay.make_events(topo, 30_000, seed=62)
-    g = _engine(topo.n_nodes + 8, 256, 1)          # far fewer edge slots than edges
+    g = _engine(topo.n_nodes + 8, 256, 1, k1_variant=1)          # far fewer edge slots than edges
     HostShim().apply(g, topo.k8s_ops())
     assert g.ingest(ev) == 0
     rows = g.flush_window()
@@ -220,3 +225,23 @@ def test_capacity_overflow_is_counted_not_silent():
     # the next window starts clean
     assert g.ingest(ev[:10]) == 0
     assert len(g.flush_window()) <= 10
+
+
+def test_partitioned_k1_overflow_paths_are_exact_or_counted():
+    """Variant 0 with deliberately tiny slab pieces (max_window_events far below the real load):
+    records spill into the overflow list and the result must still be bit-exact; when even that
+    list is exhausted the loss must show up in events_dropped_cap, never silently."""
+    from oracle import pyoracle
+    topo = replay.make_topology(100, 2000, seed=71)
+    ev, labels = replay.make_events(topo, 200_000, seed=72)
+    g = _engine(topo.n_nodes + 8, 8192, 1, k1_variant=0, max_window_events=20_000)   # pieces sized for 10x fewer events
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    assert g.ingest(ev) == 0
+    g.set_label_count(len(labels))
+    rows = g.flush_window()
+    st = g.stats()
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(1), 1)
+    if st.events_dropped_cap == 0:
+        compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
+    else:
+        assert int(rows["count"].sum()) + st.events_dropped_cap == o.window_events
