@@ -60,7 +60,7 @@ struct sg_engine {
     bool closed = false;       // window_close has run; rows readable after score
     bool use_mfma = true;
     int k1_grid = 0;
-    size_t k1a_lds = 0, k1b_lds = 0;
+    size_t k1a_lds = 0, k1b_lds = 0, k3in_lds = 0;
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
@@ -209,6 +209,11 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.np), dim3(256), 0, s, d);
         hipLaunchKernelGGL(k2_rowsort_gather, dim3(grid_for(d.ncap, 4)), dim3(256), 0, s, d);
+    }
+    {
+        Timed t3(e, s, 3);
+        hipLaunchKernelGGL(k3_in_stats, dim3(d.in_groups), dim3(256), e->k3in_lds, s, d);
+        if (d.in_dense && !d.in_fused) hipLaunchKernelGGL(k3_in_reduce, dim3(grid_for(d.ncap, 256)), dim3(256), 0, s, d);
     }
     HIP_TRY(e, hipGetLastError());
     e->closed = true;
@@ -362,7 +367,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         CR(dev_alloc(e, &d.part_n, d.np));
         CR(dev_alloc(e, &d.acc_src, (size_t)d.np * d.pcap * 4));
         e->k1a_lds = (size_t)K1A_HT * 8 + (size_t)K1A_HT * 32 + (size_t)d.np * 8;
-        e->k1b_lds = (size_t)K1B_HT * (8 + 32 + 40 + 4 + 4);
+        e->k1b_lds = (size_t)K1B_HT * (8 + 32) + (size_t)(d.nwg + 1) * 8;
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
@@ -380,6 +385,13 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CR(dev_alloc(e, &d.tile_cnt, e->ecap / K2_TILE));
     CR(dev_alloc(e, &d.tile_off, e->ecap / K2_TILE));
     CR(dev_alloc(e, &d.e_slot, ME)); CR(dev_alloc(e, &d.e_from, eslots)); CR(dev_alloc(e, &d.e_to, eslots));
+    CR(dev_alloc(e, &d.longrows, (size_t)d.ncap + 1));
+    d.in_dense = d.ncap <= K3_IN_NODES ? 1u : 0u;
+    d.in_groups = 32; d.in_fused = cfg->world == 1 ? 1u : 0u;
+    CR(dev_alloc(e, &d.in_part, d.in_dense ? (size_t)d.in_groups * d.ncap * 6 : 1));
+    e->k3in_lds = d.in_dense ? (size_t)d.ncap * 48 : (size_t)K3_IN_HT * 52;
+    CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
+    { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
     CR(dev_alloc(e, &d.deg, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.rowptr, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.cursor, (size_t)d.ncap + 1));
     CR(dev_alloc(e, &d.col, ME)); CR(dev_alloc(e, &d.cslot, ME)); CR(dev_alloc(e, &d.csr_from, ME));
     CR(dev_alloc(e, &d.sort_k, 2 * ME)); CR(dev_alloc(e, &d.sort_v, 2 * ME));

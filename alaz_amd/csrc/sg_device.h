@@ -31,6 +31,7 @@ enum {
     C_N_NODES,        // NK + NL + NOB
     C_EDGES_FOUND,    // edges found in the table before clamping
     C_OVF_N,          // records in the partition overflow list (window)
+    C_N_LONG,         // rows longer than one wave (row sort work list)
     C_COUNT = 16
 };
 
@@ -68,6 +69,11 @@ struct Dev {
     u32*   part_n;                            // [np] distinct edges per partition
     u32 pcap;                                 // edge capacity per partition
     u64*   acc_src;                           // accumulators by slot: eacc (variant 1) or partition output (variant 0)
+    u32*   longrows;                          // [ncap] rows with more than 64 edges (work list of the row sort)
+    u64*   in_part;  u32 in_groups;           // [in_groups][ncap][6] per-workgroup partial in-statistics (dense mode)
+    u32 in_dense;                             // 1: node-indexed LDS accumulation (ncap small enough), 0: hashed + atomics
+    u32 in_fused;                             // 1: k3_node_features reduces the partials itself (unsharded)
+    u32 ablate;                               // tuning switches (SG_ABLATE), 0 in production
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs
     u32* tile_cnt;  u32* tile_off;            // compaction scratch

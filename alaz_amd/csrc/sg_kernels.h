@@ -263,16 +263,25 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
         const bool v0 = i0 < end, v1 = i1 < end;
         if (v0) { a0 = pe[2 * i0]; b0 = pe[2 * i0 + 1]; }
         if (v1) { a1 = pe[2 * i1]; b1 = pe[2 * i1 + 1]; }
-        K1Ev e;
-        if (v0 && k1_resolve(d, a0, b0, L, e)) {
-            const u32 s = lds_slot(hkey, K1A_HT - 1, e.key); const u64 us = e.dur / 1000ull;
-            atomicAdd(&hacc[s * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&hacc[s * 4 + 1], e.dur);
-            atomicMax(&hacc[s * 4 + 2], e.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
+        K1Ev e0, e1;
+        bool r0 = false, r1 = false;
+        if (d.ablate & 4u) {                                         // ablation: no join-table lookups
+            if (v0) { e0.key = ((u64)a0.x << 32) | a0.y; e0.dur = (u64)b0.x | ((u64)b0.y << 32); e0.err = 0; r0 = true; }
+            if (v1) { e1.key = ((u64)a1.x << 32) | a1.y; e1.dur = (u64)b1.x | ((u64)b1.y << 32); e1.err = 0; r1 = true; }
+        } else {
+            if (v0) r0 = k1_resolve(d, a0, b0, L, e0);
+            if (v1) r1 = k1_resolve(d, a1, b1, L, e1);
         }
-        if (v1 && k1_resolve(d, a1, b1, L, e)) {
-            const u32 s = lds_slot(hkey, K1A_HT - 1, e.key); const u64 us = e.dur / 1000ull;
-            atomicAdd(&hacc[s * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&hacc[s * 4 + 1], e.dur);
-            atomicMax(&hacc[s * 4 + 2], e.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
+        if (d.ablate & 1u) { if ((r0 && e0.key == 0x1234567ull) || (r1 && e1.key == 0x1234567ull)) L.dcap++; continue; }   // ablation: resolve only
+        if (r0) {
+            const u32 s = lds_slot(hkey, K1A_HT - 1, e0.key); const u64 us = e0.dur / 1000ull;
+            atomicAdd(&hacc[s * 4], 1ull | ((u64)e0.err << 32)); atomicAdd(&hacc[s * 4 + 1], e0.dur);
+            atomicMax(&hacc[s * 4 + 2], e0.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
+        }
+        if (r1) {
+            const u32 s = lds_slot(hkey, K1A_HT - 1, e1.key); const u64 us = e1.dur / 1000ull;
+            atomicAdd(&hacc[s * 4], 1ull | ((u64)e1.err << 32)); atomicAdd(&hacc[s * 4 + 1], e1.dur);
+            atomicMax(&hacc[s * 4 + 2], e1.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
         }
         __syncthreads();
         // sweep: one record per distinct edge of the chunk
@@ -284,6 +293,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
             const u64 x0 = hacc[s * 4], x1 = hacc[s * 4 + 1], x2 = hacc[s * 4 + 2], x3 = hacc[s * 4 + 3];
             hkey[s] = SG_EKEY_EMPTY; hacc[s * 4] = 0; hacc[s * 4 + 1] = 0; hacc[s * 4 + 2] = 0; hacc[s * 4 + 3] = 0;
             const u32 p = part_of(d, k);
+            if (d.ablate & 2u) { if (k == 0x1234567ull) fS[p]++; continue; }   // ablation: sweep without slab stores
             if ((x0 & 0xFFFFFFFFull) == 1ull) {
                 const u32 pos = atomicAdd(&fS[p], 1u);
                 if (pos < d.ss) d.slab_s[((size_t)p * d.nwg + w) * d.ss + pos] = make_uint4((u32)k, (u32)(k >> 32), (u32)x1, (u32)(x1 >> 32) | ((u32)(x0 >> 32) << 31));
@@ -303,30 +313,45 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     k1_publish_stats(d, L);
 }
 
-// Pass B.  LDS: edge table [K1B_HT] (key + 4 words), in-statistics table [K1B_HT] keyed by dense
-// destination (6 words).  Outputs, all with plain stores except the statistics of shared nodes:
+// Pass B.  LDS: edge table [K1B_HT] (key + 4 words) and the prefix sums of the piece fills.
+// The records of the partition are walked as one flat index space (piece found by binary search in
+// the LDS prefix array), so every thread has independent loads in flight.  Outputs, plain stores:
 //   e_from/e_to [p*pcap + i]  dense endpoints        acc_src [(p*pcap + i)*4]  accumulators
-//   deg[from] += 1 (atomic; a row's edges are spread over the partitions)
-//   st_sum[to] in-words / st_max[to][1]: one atomic per distinct destination of the partition
+//   deg[from] += 1 (atomic u32; a row's edges are spread over the partitions)
 __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* hkey = reinterpret_cast<u64*>(smem);                       // [K1B_HT]
     u64* hacc = hkey + K1B_HT;                                       // [K1B_HT][4]
-    u64* tacc = hacc + K1B_HT * 4;                                   // [K1B_HT][5]  cnt, err, sum, ssq, max
-    u32* tkey = reinterpret_cast<u32*>(tacc + K1B_HT * 5);           // [K1B_HT]
-    u32* tdeg = tkey + K1B_HT;                                       // [K1B_HT]
-    __shared__ u32 n_edges, n_drop;
+    u32* prefS = reinterpret_cast<u32*>(hacc + K1B_HT * 4);          // [nwg + 1]
+    u32* prefA = prefS + d.nwg + 1;                                  // [nwg + 1]
+    __shared__ u32 n_edges, n_drop, out_n;
+    __shared__ u32 wsum[K1B_THREADS / 64 + 1];
     const u32 p = blockIdx.x, t = threadIdx.x;
-    for (u32 i = t; i < K1B_HT; i += K1B_THREADS) { hkey[i] = SG_EKEY_EMPTY; tkey[i] = SG_NONE; tdeg[i] = 0; }
+    for (u32 i = t; i < K1B_HT; i += K1B_THREADS) hkey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < K1B_HT * 4; i += K1B_THREADS) hacc[i] = 0;
-    for (u32 i = t; i < K1B_HT * 5; i += K1B_THREADS) tacc[i] = 0;
-    if (t == 0) { n_edges = 0; n_drop = 0; }
+    if (t == 0) { n_edges = 0; n_drop = 0; out_n = 0; }
+
+    // prefix sums of the fills of this partition's pieces (nwg is a multiple of the block size or smaller)
+    u32 RS = 0, RA = 0;
+    for (u32 w0 = 0; w0 < d.nwg; w0 += K1B_THREADS) {
+        const u32 w = w0 + t;
+        const size_t piece = (size_t)p * d.nwg + w;
+        const u32 fs = w < d.nwg ? d.fill_s[piece] : 0u, fa = w < d.nwg ? d.fill_a[piece] : 0u;
+        if (w < d.nwg) { d.fill_s[piece] = 0; d.fill_a[piece] = 0; }  // window reset of the slab
+        u32 tot;
+        const u32 es = block_excl_scan<K1B_THREADS>(fs, wsum, &tot);
+        if (w < d.nwg) prefS[w] = RS + es;
+        RS += tot;
+        const u32 ea = block_excl_scan<K1B_THREADS>(fa, wsum, &tot);
+        if (w < d.nwg) prefA[w] = RA + ea;
+        RA += tot;
+    }
+    if (t == 0) { prefS[d.nwg] = RS; prefA[d.nwg] = RA; }
     __syncthreads();
 
     auto add = [&](u64 key, u64 a0, u64 a1, u64 a2, u64 a3) {
-        // bounded probe: a partition may hold at most K1B_HT - 1 distinct edges
         u32 h = hash_key64(key) & (K1B_HT - 1); bool ok = false;
-        for (u32 it = 0; it < K1B_HT; it++) {
+        for (u32 it = 0; it < K1B_HT; it++) {                        // bounded: at most pcap distinct edges per partition
             u64 k = ((volatile u64*)hkey)[h];
             if (k == SG_EKEY_EMPTY && ((volatile u32*)&n_edges)[0] < d.pcap) {
                 k = atomicCAS(&hkey[h], SG_EKEY_EMPTY, key);
@@ -338,18 +363,21 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         if (!ok) { atomicAdd(&n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
         atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
     };
-    for (u32 w = t; w < d.nwg; w += K1B_THREADS) {
-        const size_t piece = (size_t)p * d.nwg + w;
-        const u32 fs = d.fill_s[piece], fa = d.fill_a[piece];
-        const uint4* __restrict__ ps = d.slab_s + piece * d.ss;
-        for (u32 r = 0; r < fs; r++) {
-            const uint4 x = ps[r];
-            const u64 key = (u64)x.x | ((u64)x.y << 32), dur = (u64)x.z | ((u64)(x.w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
-            add(key, 1ull | ((u64)(x.w >> 31) << 32), dur, dur, us * us);
-        }
-        const u64* __restrict__ pa = d.slab_a + piece * d.sa * 5;
-        for (u32 r = 0; r < fa; r++) add(pa[r * 5], pa[r * 5 + 1], pa[r * 5 + 2], pa[r * 5 + 3], pa[r * 5 + 4]);
-        d.fill_s[piece] = 0; d.fill_a[piece] = 0;                    // window reset of the slab
+    auto piece_of = [&](const u32* pref, u32 r) {                    // largest w with pref[w] <= r
+        u32 lo = 0, hi = d.nwg;
+        while (hi - lo > 1) { const u32 m = (lo + hi) >> 1; if (pref[m] <= r) lo = m; else hi = m; }
+        return lo;
+    };
+    for (u32 r = t; r < RS; r += K1B_THREADS) {
+        const u32 w = piece_of(prefS, r);
+        const uint4 x = d.slab_s[((size_t)p * d.nwg + w) * d.ss + (r - prefS[w])];
+        const u64 key = (u64)x.x | ((u64)x.y << 32), dur = (u64)x.z | ((u64)(x.w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
+        add(key, 1ull | ((u64)(x.w >> 31) << 32), dur, dur, us * us);
+    }
+    for (u32 r = t; r < RA; r += K1B_THREADS) {
+        const u32 w = piece_of(prefA, r);
+        const u64* __restrict__ pa = d.slab_a + (((size_t)p * d.nwg + w) * d.sa + (r - prefA[w])) * 5;
+        add(pa[0], pa[1], pa[2], pa[3], pa[4]);
     }
     {
         const u64 no = d.ctr[C_OVF_N] < d.ovf_cap ? d.ctr[C_OVF_N] : d.ovf_cap;
@@ -363,9 +391,6 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     // compact the table into the partition's output slots (order within a partition is arbitrary;
     // the CSR row sort makes the final order canonical)
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
-    __shared__ u32 out_n;
-    if (t == 0) out_n = 0;
-    __syncthreads();
 #pragma unroll
     for (u32 q = 0; q < K1B_HT / K1B_THREADS; q++) {
         const u32 s = q * K1B_THREADS + t;
@@ -376,32 +401,9 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         const u32 f = dense_of(d, (u32)(k >> 32), nk, nl, nob), to = dense_of(d, (u32)k, nk, nl, nob);
         const size_t slot = (size_t)p * d.pcap + i;
         d.e_from[slot] = f; d.e_to[slot] = to;
-        const u64 a0 = hacc[s * 4], a1 = hacc[s * 4 + 1], a2 = hacc[s * 4 + 2], a3 = hacc[s * 4 + 3];
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
-        o[0] = make_ulonglong2(a0, a1); o[1] = make_ulonglong2(a2, a3);
+        o[0] = make_ulonglong2(hacc[s * 4], hacc[s * 4 + 1]); o[1] = make_ulonglong2(hacc[s * 4 + 2], hacc[s * 4 + 3]);
         atomicAdd(&d.deg[f], 1u);
-        // destination in-statistics, pre-aggregated per partition
-        u32 h = sg_fmix32(to) & (K1B_HT - 1);
-        for (;;) {
-            u32 kk = ((volatile u32*)tkey)[h];
-            if (kk == SG_NONE) { kk = atomicCAS(&tkey[h], SG_NONE, to); if (kk == SG_NONE) kk = to; }
-            if (kk == to) break;
-            h = (h + 1) & (K1B_HT - 1);
-        }
-        atomicAdd(&tdeg[h], 1u);
-        atomicAdd(&tacc[h * 5], a0 & 0xFFFFFFFFull); atomicAdd(&tacc[h * 5 + 1], a0 >> 32);
-        atomicAdd(&tacc[h * 5 + 2], a1); atomicAdd(&tacc[h * 5 + 3], a3); atomicMax(&tacc[h * 5 + 4], a2);
-    }
-    __syncthreads();
-#pragma unroll
-    for (u32 q = 0; q < K1B_HT / K1B_THREADS; q++) {
-        const u32 s = q * K1B_THREADS + t;
-        const u32 to = tkey[s];
-        if (to == SG_NONE) continue;
-        u64* g = d.st_sum + (size_t)to * SG_NODE_STAT_SUM_WORDS;
-        atomicAdd(&g[ST_IN_DEG], (u64)tdeg[s]); atomicAdd(&g[ST_IN_CNT], tacc[s * 5]); atomicAdd(&g[ST_IN_ERR], tacc[s * 5 + 1]);
-        atomicAdd(&g[ST_IN_SUM], tacc[s * 5 + 2]); atomicAdd(&g[ST_IN_SSQ], tacc[s * 5 + 3]);
-        atomicMax(&d.st_max[(size_t)to * 2 + 1], tacc[s * 5 + 4]);
     }
     __syncthreads();
     if (t == 0) {
@@ -567,14 +569,22 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
 __global__ __launch_bounds__(1024) void k2_rowptr(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES];
     __shared__ u32 wsum[17];
+    __shared__ u32 nlong;
+    if (threadIdx.x == 0) nlong = 0;
     const u32 per = (N + 1023) / 1024;
     const u32 beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
     u32 c = 0;
     for (u32 i = beg; i < end; i++) c += d.deg[i];
     u32 total;
     u32 run = block_excl_scan<1024>(c, wsum, &total);
-    for (u32 i = beg; i < end; i++) { d.rowptr[i] = run; run += d.deg[i]; }
+    for (u32 i = beg; i < end; i++) {
+        const u32 dg = d.deg[i];
+        d.rowptr[i] = run; run += dg;
+        if (dg > 64) d.longrows[atomicAdd(&nlong, 1u)] = i;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        d.ctr[C_N_LONG] = nlong;
         d.rowptr[N] = total;
         d.ctr[C_N_EDGES] = (u64)total < d.max_edges ? total : d.max_edges;
         if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = total; if ((u64)total > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)total - d.max_edges; }
@@ -628,97 +638,171 @@ __device__ __forceinline__ void edge_emit(const Dev& d, u32 pos, u32 row, u32 sl
     e[0] = make_float4((float)log1p((double)cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
     e[1] = make_float4(err_ratio, (float)log1p((double)err), zc * 0.125f, 1.0f);
     d.latz[pos] = lat_z; d.errr[pos] = err_ratio;
-    if (d.variant == 1) {
-        // variant 1: this is also the window reset of the edge table, and the in-statistics (raw atomics)
+    if (d.variant == 1) {                                            // variant 1: this is also the window reset of the edge table
         ulonglong2* src = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)slot * 4);
         src[0] = make_ulonglong2(0, 0); src[1] = make_ulonglong2(0, 0);
         d.ekeys[slot] = SG_EKEY_EMPTY;
-        u64* t = d.st_sum + (size_t)d.col[pos] * SG_NODE_STAT_SUM_WORDS;
-        atomicAdd(&t[ST_IN_DEG], 1ull); atomicAdd(&t[ST_IN_CNT], cnt); atomicAdd(&t[ST_IN_ERR], err);
-        atomicAdd(&t[ST_IN_SUM], sum); atomicAdd(&t[ST_IN_SSQ], ssq);
-        atomicMax(&d.st_max[(size_t)d.col[pos] * 2 + 1], mx);
     }
 }
 
 #define K2_SORT_LDS 4096
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
-    const u32 N = (u32)d.ctr[C_N_NODES];
+    const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
     __shared__ u64 red[5][4];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (u32 r0 = blockIdx.x * 4; r0 < N; r0 += gridDim.x * 4) {
-        // ---- wave path: rows with <= 64 edges ----
-        const u32 r = r0 + wave;
-        u32 beg = 0, n = 0;
-        if (r < N) { beg = d.rowptr[r]; n = d.rowptr[r + 1] - beg; if ((u64)beg + n > d.max_edges) n = beg < d.max_edges ? (u32)(d.max_edges - beg) : 0; }
-        if (n > 0 && n <= 64) {
-            const u32 k = lane < n ? d.col[beg + lane] : 0xFFFFFFFFu, v = lane < n ? d.cslot[beg + lane] : 0;
-            u32 rank = 0;
-            for (u32 j = 0; j < n; j++) rank += __shfl(k, (int)j, 64) < k;
-            ulonglong2 x = make_ulonglong2(0, 0), y = make_ulonglong2(0, 0);
-            if (lane < n) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v * 4); x = a[0]; y = a[1]; }
-            const u64 cnt = wave_sum_u64(x.x & 0xFFFFFFFFull), err = wave_sum_u64(x.x >> 32), sum = wave_sum_u64(x.y), ssq = wave_sum_u64(y.y), mx = wave_max_u64(y.x);
-            if (lane < n) { d.col[beg + rank] = k; }
-            if (lane == 0) {
-                u64* t = d.st_sum + (size_t)r * SG_NODE_STAT_SUM_WORDS;
-                t[ST_OUT_DEG] = n; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
-                d.st_max[(size_t)r * 2] = mx;
-            }
-            if (lane < n) edge_emit(d, beg + rank, r, v, cnt, sum, ssq, x, y);
-        }
+    // ---- long rows first (they are the critical path): one row per workgroup ----
+    for (u32 li = blockIdx.x; li < nlong; li += gridDim.x) {
+        const u32 rr = d.longrows[li];
+        const u32 b = d.rowptr[rr];
+        u32 m = d.rowptr[rr + 1] - b;
+        if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
+        if (m == 0) continue;
+        u32* key = d.col + b; u32* val = d.cslot + b;
+        u32 np2 = 1; while (np2 < m) np2 <<= 1;
+        u32* gk = sk; u32* gv = sv;
+        if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
+        for (u32 i = threadIdx.x; i < np2; i += 256) { gk[i] = i < m ? key[i] : 0xFFFFFFFFu; gv[i] = i < m ? val[i] : 0; }
         __syncthreads();
-        // ---- workgroup path: the (rare) longer rows of this group of 4, one after the other ----
-        for (u32 q = 0; q < 4; q++) {
-            const u32 rr = r0 + q;
-            if (rr >= N) break;
-            const u32 b = d.rowptr[rr];
-            u32 m = d.rowptr[rr + 1] - b;
-            if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
-            if (m <= 64) continue;
-            u32* key = d.col + b; u32* val = d.cslot + b;
-            u32 np2 = 1; while (np2 < m) np2 <<= 1;
-            u32* gk = sk; u32* gv = sv;
-            if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
-            for (u32 i = threadIdx.x; i < np2; i += 256) { gk[i] = i < m ? key[i] : 0xFFFFFFFFu; gv[i] = i < m ? val[i] : 0; }
-            __syncthreads();
-            for (u32 k = 2; k <= np2; k <<= 1)
-                for (u32 j = k >> 1; j > 0; j >>= 1) {
-                    for (u32 i = threadIdx.x; i < np2; i += 256) {
-                        const u32 x = i ^ j;
-                        if (x > i) {
-                            const u32 a = gk[i], c = gk[x];
-                            if ((a > c) == ((i & k) == 0)) { gk[i] = c; gk[x] = a; const u32 tt = gv[i]; gv[i] = gv[x]; gv[x] = tt; }
-                        }
+        for (u32 k = 2; k <= np2; k <<= 1)
+            for (u32 j = k >> 1; j > 0; j >>= 1) {
+                for (u32 i = threadIdx.x; i < np2; i += 256) {
+                    const u32 x = i ^ j;
+                    if (x > i) {
+                        const u32 a = gk[i], c = gk[x];
+                        if ((a > c) == ((i & k) == 0)) { gk[i] = c; gk[x] = a; const u32 tt = gv[i]; gv[i] = gv[x]; gv[x] = tt; }
                     }
-                    __syncthreads();
                 }
-            u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
-            for (u32 i = threadIdx.x; i < m; i += 256) {
-                const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
-                const ulonglong2 x = a[0], y = a[1];
-                cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
+                __syncthreads();
             }
-            cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
-            if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+        u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
+        for (u32 i = threadIdx.x; i < m; i += 256) {
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
+            const ulonglong2 x = a[0], y = a[1];
+            cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
+        }
+        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+        if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+        __syncthreads();
+        cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+        mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+        if (threadIdx.x == 0) {
+            u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
+            t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+            d.st_max[(size_t)rr * 2] = mx;
+        }
+        for (u32 i = threadIdx.x; i < m; i += 256) {
+            const u32 slot = gv[i];
+            key[i] = gk[i];
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
+            const ulonglong2 x = a[0], y = a[1];
+            edge_emit(d, b + i, rr, slot, cnt, sum, ssq, x, y);
+        }
+        __syncthreads();
+    }
+    // ---- rows of up to 64 edges: one wave per row ----
+    for (u32 r = blockIdx.x * 4 + wave; r < N; r += gridDim.x * 4) {
+        const u32 beg = d.rowptr[r];
+        u32 n = d.rowptr[r + 1] - beg;
+        if (n == 0 || n > 64) continue;
+        if ((u64)beg + n > d.max_edges) n = beg < d.max_edges ? (u32)(d.max_edges - beg) : 0;
+        if (n == 0) continue;
+        const u32 k = lane < n ? d.col[beg + lane] : 0xFFFFFFFFu, v = lane < n ? d.cslot[beg + lane] : 0;
+        u32 rank = 0;
+        for (u32 j = 0; j < n; j++) rank += __shfl(k, (int)j, 64) < k;
+        ulonglong2 x = make_ulonglong2(0, 0), y = make_ulonglong2(0, 0);
+        if (lane < n) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v * 4); x = a[0]; y = a[1]; }
+        const u64 cnt = wave_sum_u64(x.x & 0xFFFFFFFFull), err = wave_sum_u64(x.x >> 32), sum = wave_sum_u64(x.y), ssq = wave_sum_u64(y.y), mx = wave_max_u64(y.x);
+        if (lane < n) d.col[beg + rank] = k;
+        if (lane == 0) {
+            u64* t = d.st_sum + (size_t)r * SG_NODE_STAT_SUM_WORDS;
+            t[ST_OUT_DEG] = n; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+            d.st_max[(size_t)r * 2] = mx;
+        }
+        if (lane < n) edge_emit(d, beg + rank, r, v, cnt, sum, ssq, x, y);
+    }
+}
+
+// ---- in-statistics: per destination node, reduce over its in-edges --------------------------------
+// Dense mode (ncap <= K3_IN_NODES): each workgroup accumulates a contiguous range of CSR positions
+// into node-indexed LDS arrays (LDS atomics only) and writes its partial [ncap][6] with plain
+// stores; the partials are summed by k3_in_reduce / k3_node_features.  No device-scope atomics,
+// so popular services (thousands of in-edges) cost nothing extra.
+// Hashed mode (large graphs): LDS hash per workgroup, then device-scope atomics per distinct node.
+#define K3_IN_NODES 2560
+#define K3_IN_HT    2048
+__global__ __launch_bounds__(256) void k3_in_stats(Dev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 E = (u32)d.ctr[C_N_EDGES], N = (u32)d.ctr[C_N_NODES];
+    const u32 G = gridDim.x, g = blockIdx.x, t = threadIdx.x;
+    const u32 per = (E + G - 1) / G, p0 = g * per < E ? g * per : E, p1 = p0 + per < E ? p0 + per : E;
+    if (d.in_dense) {
+        u64* acc = reinterpret_cast<u64*>(smem);                     // [N][6]: deg, cnt, err, sum, ssq, max
+        for (u32 i = t; i < N * 6; i += 256) acc[i] = 0;
+        __syncthreads();
+        for (u32 p = p0 + t; p < p1; p += 256) {
+            const u32 to = d.col[p];
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
+            const ulonglong2 x = a[0], y = a[1];
+            u64* o = acc + (size_t)to * 6;
+            atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x.x & 0xFFFFFFFFull); atomicAdd(&o[2], x.x >> 32);
+            atomicAdd(&o[3], x.y); atomicAdd(&o[4], y.y); atomicMax(&o[5], y.x);
+        }
+        __syncthreads();
+        u64* out = d.in_part + (size_t)g * d.ncap * 6;
+        for (u32 i = t; i < N * 6; i += 256) out[i] = acc[i];
+    } else {
+        u64* tacc = reinterpret_cast<u64*>(smem);                    // [K3_IN_HT][6]
+        u32* tkey = reinterpret_cast<u32*>(tacc + K3_IN_HT * 6);     // [K3_IN_HT]
+        for (u32 c0 = p0; c0 < p1; c0 += K3_IN_HT / 2) {             // at most HT/2 edges (=> distinct nodes) per round
+            for (u32 i = t; i < K3_IN_HT; i += 256) tkey[i] = SG_NONE;
+            for (u32 i = t; i < K3_IN_HT * 6; i += 256) tacc[i] = 0;
             __syncthreads();
-            cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-            sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
-            mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-            if (threadIdx.x == 0) {
-                u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
-                t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
-                d.st_max[(size_t)rr * 2] = mx;
-            }
-            for (u32 i = threadIdx.x; i < m; i += 256) {
-                const u32 slot = gv[i];
-                key[i] = gk[i];
-                const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
+            const u32 c1 = c0 + K3_IN_HT / 2 < p1 ? c0 + K3_IN_HT / 2 : p1;
+            for (u32 p = c0 + t; p < c1; p += 256) {
+                const u32 to = d.col[p];
+                const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
                 const ulonglong2 x = a[0], y = a[1];
-                edge_emit(d, b + i, rr, slot, cnt, sum, ssq, x, y);
+                u32 h = sg_fmix32(to) & (K3_IN_HT - 1);
+                for (;;) {
+                    u32 kk = ((volatile u32*)tkey)[h];
+                    if (kk == SG_NONE) { kk = atomicCAS(&tkey[h], SG_NONE, to); if (kk == SG_NONE) kk = to; }
+                    if (kk == to) break;
+                    h = (h + 1) & (K3_IN_HT - 1);
+                }
+                u64* o = tacc + (size_t)h * 6;
+                atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x.x & 0xFFFFFFFFull); atomicAdd(&o[2], x.x >> 32);
+                atomicAdd(&o[3], x.y); atomicAdd(&o[4], y.y); atomicMax(&o[5], y.x);
+            }
+            __syncthreads();
+            for (u32 s = t; s < K3_IN_HT; s += 256) {
+                const u32 to = tkey[s];
+                if (to == SG_NONE) continue;
+                u64* gsum = d.st_sum + (size_t)to * SG_NODE_STAT_SUM_WORDS; const u64* o = tacc + (size_t)s * 6;
+                atomicAdd(&gsum[ST_IN_DEG], o[0]); atomicAdd(&gsum[ST_IN_CNT], o[1]); atomicAdd(&gsum[ST_IN_ERR], o[2]);
+                atomicAdd(&gsum[ST_IN_SUM], o[3]); atomicAdd(&gsum[ST_IN_SSQ], o[4]);
+                atomicMax(&d.st_max[(size_t)to * 2 + 1], o[5]);
             }
             __syncthreads();
         }
-        __syncthreads();
+    }
+}
+
+// dense mode, sharded driver: sum the partials into st_sum / st_max before the statistics exchange.
+__global__ __launch_bounds__(256) void k3_in_reduce(Dev d) {
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    for (u32 v = blockIdx.x * 256 + threadIdx.x; v < N; v += gridDim.x * 256) {
+        u64 a[6] = {0, 0, 0, 0, 0, 0};
+        for (u32 g = 0; g < d.in_groups; g++) {
+            const u64* o = d.in_part + ((size_t)g * d.ncap + v) * 6;
+#pragma unroll
+            for (int k = 0; k < 5; k++) a[k] += o[k];
+            a[5] = o[5] > a[5] ? o[5] : a[5];
+        }
+        u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
+        s[ST_IN_DEG] = a[0]; s[ST_IN_CNT] = a[1]; s[ST_IN_ERR] = a[2]; s[ST_IN_SUM] = a[3]; s[ST_IN_SSQ] = a[4];
+        d.st_max[(size_t)v * 2 + 1] = a[5];
     }
 }
 
@@ -728,7 +812,17 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN];
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < N; v += gridDim.x * 256) {
-        const u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS; const u64* mx = d.st_max + (size_t)v * 2;
+        u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS; u64* mx = d.st_max + (size_t)v * 2;
+        if (d.in_dense && d.in_fused) {
+            u64 a[6] = {0, 0, 0, 0, 0, 0};
+            for (u32 g = 0; g < d.in_groups; g++) {
+                const u64* o = d.in_part + ((size_t)g * d.ncap + v) * 6;
+#pragma unroll
+                for (int k = 0; k < 5; k++) a[k] += o[k];
+                a[5] = o[5] > a[5] ? o[5] : a[5];
+            }
+            s[ST_IN_DEG] = a[0]; s[ST_IN_CNT] = a[1]; s[ST_IN_ERR] = a[2]; s[ST_IN_SUM] = a[3]; s[ST_IN_SSQ] = a[4]; mx[1] = a[5];
+        }
         const u32 kind = v < nk ? d.kind[v] : 0u;
         const u64 oc = s[ST_OUT_CNT], ic = s[ST_IN_CNT];
         float x[SG_F_IN];
@@ -799,7 +893,9 @@ __device__ __forceinline__ f32x4 dense_tile_mfma(const float* A, int lda, const 
     return c;
 }
 
-// gather-mean of one node into dst[0..FI): executed by one wave.
+// gather-mean of one node into dst[0..FI): executed by one wave.  Neighbour ids are fetched 64 at a
+// time (one coalesced load) and broadcast by shuffle, so the 8 / 16 row loads of an unrolled step
+// are independent and in flight together.  Summation order is the canonical one (slot = i % 16).
 template <int FI>
 __device__ __forceinline__ void gather_mean(const Dev& d, const float* __restrict__ hin, u32 v, float* dst) {
     const u32 lane = threadIdx.x & 63;
@@ -810,11 +906,16 @@ __device__ __forceinline__ void gather_mean(const Dev& d, const float* __restric
         float acc[8];
 #pragma unroll
         for (int a = 0; a < 8; a++) acc[a] = 0.0f;
-        for (u32 i0 = 0; i0 < deg; i0 += 16) {
+        for (u32 base = 0; base < deg; base += 64) {
+            const u32 cnt = deg - base < 64 ? deg - base : 64;
+            const u32 my = lane < cnt ? nb[base + lane] : 0u;
+            for (u32 i0 = 0; i0 < cnt; i0 += 16) {
 #pragma unroll
-            for (int a = 0; a < 8; a++) {
-                const u32 i = i0 + 2 * a + g;                    // slot = i % 16 = 2a + g
-                if (i < deg) acc[a] = acc[a] + hin[(size_t)nb[i] * 32 + k];
+                for (int a = 0; a < 8; a++) {
+                    const u32 i = i0 + 2 * a + g;                    // slot = i % 16 = 2a + g  (base is a multiple of 16)
+                    const u32 id = __shfl(my, (int)(i & 63), 64);
+                    if (i < cnt) acc[a] = acc[a] + hin[(size_t)id * 32 + k];
+                }
             }
         }
         float t = 0.0f;
@@ -830,11 +931,16 @@ __device__ __forceinline__ void gather_mean(const Dev& d, const float* __restric
         float acc[16];
 #pragma unroll
         for (int a = 0; a < 16; a++) acc[a] = 0.0f;
-        for (u32 i0 = 0; i0 < deg; i0 += 16) {
+        for (u32 base = 0; base < deg; base += 64) {
+            const u32 cnt = deg - base < 64 ? deg - base : 64;
+            const u32 my = lane < cnt ? nb[base + lane] : 0u;
+            for (u32 i0 = 0; i0 < cnt; i0 += 16) {
 #pragma unroll
-            for (int a = 0; a < 16; a++) {
-                const u32 i = i0 + a;
-                if (i < deg) acc[a] = acc[a] + hin[(size_t)nb[i] * 64 + lane];
+                for (int a = 0; a < 16; a++) {
+                    const u32 i = i0 + a;
+                    const u32 id = __shfl(my, (int)i, 64);
+                    if (i < cnt) acc[a] = acc[a] + hin[(size_t)id * 64 + lane];
+                }
             }
         }
         float t = acc[0];
