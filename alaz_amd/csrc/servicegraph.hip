@@ -40,7 +40,8 @@ struct sg_engine {
     std::vector<uint8_t> kind;
     u32 n_known = 0;
     bool tab_dirty = true;
-    IpEnt* h_iptab = nullptr; IpEnt* d_iptab = nullptr; u32 ipcap = 0;
+    u64* h_iptab = nullptr; u64* d_iptab = nullptr; u32 ipcap = 0;       // main table, then the 'both maps' table (ip2cap entries)
+    u32 ip2cap = 0;
     uint8_t* h_kind = nullptr; uint8_t* d_kind = nullptr;
     hipEvent_t tab_ev = nullptr;
 
@@ -61,6 +62,7 @@ struct sg_engine {
     bool use_mfma = true;
     int k1_grid = 0;
     size_t k1a_lds = 0, k1b_lds = 0, k3in_lds = 0;
+    bool ip_lds = false;
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
@@ -109,21 +111,24 @@ struct Timed {
 int sync_tables(sg_engine* e, hipStream_t s) {
     if (!e->tab_dirty) return SG_OK;
     HIP_TRY(e, hipEventSynchronize(e->tab_ev));            // previous upload finished reading h_iptab
-    std::memset(e->h_iptab, 0, (size_t)e->ipcap * sizeof(IpEnt));
-    const u32 mask = e->ipcap - 1;
-    auto put = [&](u32 ip, u32 pod, u32 svc) {
+    const size_t tot = (size_t)e->ipcap + e->ip2cap;
+    std::memset(e->h_iptab, 0xFF, tot * sizeof(u64));
+    u64* t1 = e->h_iptab; u64* t2 = e->h_iptab + e->ipcap;
+    auto put = [](u64* tab, u32 mask, u32 ip, u32 val) {
         u32 h = sg_fmix32(ip) & mask;
-        for (;;) {
-            IpEnt& t = e->h_iptab[h];
-            if (!t.used) { t.ip = ip; t.pod = pod; t.svc = svc; t.used = 1; return; }
-            if (t.ip == ip) { if (pod != SG_NONE) t.pod = pod; if (svc != SG_NONE) t.svc = svc; return; }
-            h = (h + 1) & mask;
-        }
+        while (tab[h] != SG_IP_EMPTY && (u32)tab[h] != ip) h = (h + 1) & mask;
+        tab[h] = (u64)ip | ((u64)val << 32);
     };
-    for (auto& kv : e->pod_ip) put(kv.first, kv.second, SG_NONE);
-    for (auto& kv : e->svc_ip) put(kv.first, SG_NONE, kv.second);
+    size_t both = 0;
+    for (auto& kv : e->pod_ip) {
+        auto sv = e->svc_ip.find(kv.first);
+        if (sv == e->svc_ip.end()) put(t1, e->ipcap - 1, kv.first, (1u << 30) | kv.second);
+        else if (both < e->ip2cap / 2) { put(t1, e->ipcap - 1, kv.first, (3u << 30) | sv->second); put(t2, e->ip2cap - 1, kv.first, (1u << 30) | kv.second); both++; }
+        else put(t1, e->ipcap - 1, kv.first, (2u << 30) | sv->second);   // second table full: the service mapping wins as destination
+    }
+    for (auto& kv : e->svc_ip) if (e->pod_ip.find(kv.first) == e->pod_ip.end()) put(t1, e->ipcap - 1, kv.first, (2u << 30) | kv.second);
     std::memcpy(e->h_kind, e->kind.data(), e->kind.size());
-    HIP_TRY(e, hipMemcpyAsync(e->d_iptab, e->h_iptab, (size_t)e->ipcap * sizeof(IpEnt), hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(e->d_iptab, e->h_iptab, tot * sizeof(u64), hipMemcpyHostToDevice, s));
     HIP_TRY(e, hipMemcpyAsync(e->d_kind, e->h_kind, e->kind.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(e, hipEventRecord(e->tab_ev, s));
     e->tab_dirty = false;
@@ -137,7 +142,8 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     {
         Timed t(e, s, 1);
         if (e->d.variant == 0) {
-            hipLaunchKernelGGL(k1a_partition, dim3(e->d.nwg), dim3(K1A_THREADS), e->k1a_lds, s, e->d, d_ev, (u64)n);
+            if (e->ip_lds) hipLaunchKernelGGL(k1a_partition<true>, dim3(e->d.nwg), dim3(K1A_THREADS), e->k1a_lds, s, e->d, d_ev, (u64)n);
+            else hipLaunchKernelGGL(k1a_partition<false>, dim3(e->d.nwg), dim3(K1A_THREADS), e->k1a_lds, s, e->d, d_ev, (u64)n);
         } else {
             u64 want = (n + 255) / 256;
             int grid = (int)std::min<u64>(want, (u64)e->k1_grid);
@@ -208,7 +214,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         hipLaunchKernelGGL(k2_rowptr, dim3(1), dim3(1024), 0, s, d);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.np), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(k2_rowsort_gather, dim3(grid_for(d.ncap, 4)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, grid_for(d.ncap, 4))), dim3(256), 0, s, d);
     }
     {
         Timed t3(e, s, 3);
@@ -339,10 +345,11 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     d.ncap = cfg->max_known_nodes + cfg->max_labels + d.max_obip;
     d.emask = e->ecap - 1; d.obmask = e->obcap - 1; d.ipmask = e->ipcap - 1;
 
-    CR(dev_alloc(e, &e->d_iptab, e->ipcap));
+    e->ip2cap = 1024;
+    CR(dev_alloc(e, &e->d_iptab, (size_t)e->ipcap + e->ip2cap, 0xFF));
     CR(dev_alloc(e, &e->d_kind, cfg->max_known_nodes));
-    d.iptab = e->d_iptab; d.kind = e->d_kind;
-    CH(hipHostMalloc((void**)&e->h_iptab, (size_t)e->ipcap * sizeof(IpEnt)));
+    d.iptab = e->d_iptab; d.iptab2 = e->d_iptab + e->ipcap; d.ipmask2 = e->ip2cap - 1; d.kind = e->d_kind;
+    CH(hipHostMalloc((void**)&e->h_iptab, ((size_t)e->ipcap + e->ip2cap) * sizeof(u64)));
     CH(hipHostMalloc((void**)&e->h_kind, cfg->max_known_nodes));
     e->kind.assign(cfg->max_known_nodes, 0);
     // K1 variant: 0 = partitioned LDS aggregation (fast; bounded edges per partition), 1 = global table + atomics
@@ -351,7 +358,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     {
         u64 np = next_pow2(std::max<u64>(ME / 160, 64));
         if (cfg->k1_variant == 0 && np > 1024) d.variant = 1;           // beyond the partitioned path's range
-        d.np = (u32)std::min<u64>(np, 1024); d.nwg = 256; d.pcap = 768;
+        d.np = (u32)std::min<u64>(np, 1024); d.nwg = 512; d.pcap = 768;
+        if (const char* v = std::getenv("SG_NP")) d.np = (u32)std::strtoul(v, nullptr, 0);
+        if (const char* v = std::getenv("SG_NWG")) d.nwg = (u32)std::strtoul(v, nullptr, 0);
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
         d.ss = (u32)(2.0 * m + 6.0 * std::sqrt(m + 1.0) + 8.0);
         d.sa = d.ss / 2 + 8;
@@ -366,9 +375,11 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         CR(dev_alloc(e, &d.ovf, (size_t)d.ovf_cap * 5));
         CR(dev_alloc(e, &d.part_n, d.np));
         CR(dev_alloc(e, &d.acc_src, (size_t)d.np * d.pcap * 4));
-        e->k1a_lds = (size_t)K1A_HT * 8 + (size_t)K1A_HT * 32 + (size_t)d.np * 8;
+        e->ip_lds = e->ipcap <= SG_IP_LDS_MAX;
+        e->k1a_lds = (size_t)K1A_HT * 8 + (size_t)K1A_HT * 32 + (size_t)d.np * 8 + (e->ip_lds ? (size_t)e->ipcap * 8 : 0);
         e->k1b_lds = (size_t)K1B_HT * (8 + 32) + (size_t)(d.nwg + 1) * 8;
-        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
+        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
+        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }
@@ -387,7 +398,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CR(dev_alloc(e, &d.e_slot, ME)); CR(dev_alloc(e, &d.e_from, eslots)); CR(dev_alloc(e, &d.e_to, eslots));
     CR(dev_alloc(e, &d.longrows, (size_t)d.ncap + 1));
     d.in_dense = d.ncap <= K3_IN_NODES ? 1u : 0u;
-    d.in_groups = 32; d.in_fused = cfg->world == 1 ? 1u : 0u;
+    d.in_groups = 16; d.in_fused = cfg->world == 1 ? 1u : 0u;
     CR(dev_alloc(e, &d.in_part, d.in_dense ? (size_t)d.in_groups * d.ncap * 6 : 1));
     e->k3in_lds = d.in_dense ? (size_t)d.ncap * 48 : (size_t)K3_IN_HT * 52;
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));

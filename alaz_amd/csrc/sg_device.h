@@ -12,9 +12,12 @@ typedef uint32_t u32;
 #define SG_EKEY_EMPTY (~0ull)
 #define SG_WAVE       64
 
-// join-table entry: one 16-byte probe resolves an IP against BOTH reference maps
-// (PodIPToPodUid and ServiceIPToServiceUid, aggregator/cluster.go:13-17).
-struct IpEnt { u32 ip, pod, svc, used; };
+// join-table entry: one 8-byte probe resolves an IP against BOTH reference maps (PodIPToPodUid and
+// ServiceIPToServiceUid, aggregator/cluster.go:13-17):  low 32 bits = IP, high 32 bits =
+// kind << 30 | id with kind 1 = pod, 2 = service, 3 = the IP is in both maps (id = the service,
+// the pod id is in the small second table).  All ones = empty.
+#define SG_IP_EMPTY   (~0ull)
+#define SG_IP_LDS_MAX 4096      // entries (32 KiB): tables up to this size are staged in LDS by K1
 
 // device counters (u64 each)
 enum {
@@ -48,7 +51,8 @@ enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, 
 // Everything the kernels need, passed by value as one kernel argument.
 struct Dev {
     // ---- persistent across windows ----
-    const IpEnt* iptab; u32 ipmask;
+    const u64* iptab;  u32 ipmask;             // main join table (open addressing)
+    const u64* iptab2; u32 ipmask2;            // pod ids of IPs that are in both maps
     const uint8_t* kind;            // [max_known] SG_NODE_POD / SG_NODE_SERVICE
     u32 max_known, max_labels, max_obip;
     u32 rank, world;

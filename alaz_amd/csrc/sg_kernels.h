@@ -16,15 +16,24 @@ __device__ __forceinline__ u32 hash_key64(u64 k) { return sg_fmix32((u32)k ^ sg_
 __host__ __device__ __forceinline__ u32 owner_hash_ref(u32 ref) { return sg_fmix32(ref); }
 __host__ __device__ __forceinline__ u32 owner_hash_obip(u32 ip) { return sg_fmix32(ip ^ 0xA5A5F00Du); }
 
-__device__ __forceinline__ bool ip_lookup(const IpEnt* __restrict__ t, u32 mask, u32 ip, u32& pod, u32& svc) {
+__device__ __forceinline__ u64 ip_probe(const u64* t, u32 mask, u32 ip) {
     u32 h = sg_fmix32(ip) & mask;
     for (u32 p = 0; p <= mask; ++p) {
-        const uint4 e = reinterpret_cast<const uint4*>(t)[h];
-        if (!e.w) return false;
-        if (e.x == ip) { pod = e.y; svc = e.z; return true; }
+        const u64 e = t[h];
+        if (e == SG_IP_EMPTY || (u32)e == ip) return e;
         h = (h + 1) & mask;
     }
-    return false;
+    return SG_IP_EMPTY;
+}
+// t may point to LDS (staged copy) or global memory; t2 is always global (rare path).
+__device__ __forceinline__ bool ip_lookup(const u64* t, u32 mask, const u64* __restrict__ t2, u32 mask2, u32 ip, u32& pod, u32& svc) {
+    const u64 e = ip_probe(t, mask, ip);
+    if (e == SG_IP_EMPTY) return false;
+    const u32 v = (u32)(e >> 32), kind = v >> 30, id = v & 0x3FFFFFFFu;
+    if (kind == 1) pod = id;
+    else if (kind == 2) svc = id;
+    else { svc = id; const u64 e2 = ip_probe(t2, mask2, ip); if (e2 != SG_IP_EMPTY) pod = (u32)(e2 >> 32) & 0x3FFFFFFFu; }
+    return true;
 }
 
 // find-or-insert in an open-addressing u64 key table.  A plain load may return a stale EMPTY (the
@@ -133,19 +142,19 @@ struct K1Local { u64 tmin, tmax; u32 maxlabel, dsrc, dcap, misr, acc; };
 struct K1Ev { u64 key, dur, wt; u32 err; };
 
 // the join: one event -> edge key, or a counted drop.
-__device__ __forceinline__ bool k1_resolve(const Dev& d, const uint4 a, const uint4 b, K1Local& L, K1Ev& e) {
+__device__ __forceinline__ bool k1_resolve(const Dev& d, const u64* iptab, const uint4 a, const uint4 b, K1Local& L, K1Ev& e) {
     const u32 saddr = a.x, daddr = a.y, label = a.z;
     const u32 status = a.w & 0xFFFFu, proto = (a.w >> 16) & 0xFFu, flags = a.w >> 24;
     e.dur = (u64)b.x | ((u64)b.y << 32); e.wt = (u64)b.z | ((u64)b.w << 32);
 
     u32 spod = SG_NONE, ssvc = SG_NONE;
-    const bool sf = ip_lookup(d.iptab, d.ipmask, saddr, spod, ssvc);
+    const bool sf = ip_lookup(iptab, d.ipmask, d.iptab2, d.ipmask2, saddr, spod, ssvc);
     if (!sf || spod == SG_NONE) { L.dsrc++; return false; }     // data.go:829-832: source must be a pod
     u32 from = SG_MAKE_REF(SG_REF_KNOWN, spod);
     u32 from_owner = owner_hash_ref(from);
 
     u32 dpod = SG_NONE, dsvc = SG_NONE, to, to_owner;
-    const bool df = ip_lookup(d.iptab, d.ipmask, daddr, dpod, dsvc);
+    const bool df = ip_lookup(iptab, d.ipmask, d.iptab2, d.ipmask2, daddr, dpod, dsvc);
     if (df && dsvc != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dsvc); to_owner = owner_hash_ref(to); }       // service first (:840-843)
     else if (df && dpod != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dpod); to_owner = owner_hash_ref(to); }  // then pod (:845-849)
     else if (label != 0) {                                       // outbound, Host header (:851-854)
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const uint4 a = p[2 * i], b = p[2 * i + 1];
         K1Ev e;
-        if (!k1_resolve(d, a, b, L, e)) continue;
+        if (!k1_resolve(d, d.iptab, a, b, L, e)) continue;
         u32 slot;
         if (!table_slot(d.ekeys, d.emask, e.key, SG_EKEY_EMPTY, hash_key64(e.key) & d.emask, slot)) { L.dcap++; L.acc--; continue; }
         u64* acc = d.eacc + (size_t)slot * 4;
@@ -213,11 +222,12 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
 // partitions stay balanced; the long tail passes through as 16-byte singles.
 // Pass B (k1b_merge, at window close): workgroup p owns partition p exclusively, merges its pieces
 // in LDS and writes each distinct edge once with plain stores.
-#define K1A_THREADS 512
-#define K1A_CHUNK   1024
-#define K1A_HT      2048
+#define K1A_THREADS 256
+#define K1A_CHUNK   512
+#define K1A_HT      1024
 #define K1B_HT      1024
 #define K1B_THREADS 256
+#define K1B_U       4
 
 __device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return (hash_key64(key) >> 7) & (d.np - 1); }
 
@@ -240,16 +250,23 @@ __device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1
     else { const u32 c = (u32)(a0 & 0xFFFFFFFFull); L.dcap += c; L.acc -= c; }
 }
 
+// IPLDS: the join table is staged in LDS (tables of up to SG_IP_LDS_MAX entries): the two probes per
+// event then cost LDS reads instead of uncoalesced 8-byte global loads.
+// Two workgroups share a CU (<= 76 KiB LDS each): one streams / resolves while the other sweeps.
+template <bool IPLDS>
 __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_event* __restrict__ ev, u64 n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* hkey = reinterpret_cast<u64*>(smem);                       // [K1A_HT]
     u64* hacc = hkey + K1A_HT;                                       // [K1A_HT][4]
     u32* fS = reinterpret_cast<u32*>(hacc + K1A_HT * 4);             // [np]
     u32* fA = fS + d.np;                                             // [np]
+    u64* ipl = reinterpret_cast<u64*>(fA + d.np);                    // [ipmask + 1] when IPLDS
     const u32 w = blockIdx.x, t = threadIdx.x;
     for (u32 i = t; i < K1A_HT; i += K1A_THREADS) hkey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < K1A_HT * 4; i += K1A_THREADS) hacc[i] = 0;
     for (u32 p = t; p < d.np; p += K1A_THREADS) { fS[p] = d.fill_s[(size_t)p * d.nwg + w]; fA[p] = d.fill_a[(size_t)p * d.nwg + w]; }
+    if (IPLDS) for (u32 i = t; i <= d.ipmask; i += K1A_THREADS) ipl[i] = d.iptab[i];
+    const u64* iptab = IPLDS ? ipl : d.iptab;
     __syncthreads();
 
     K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
@@ -257,32 +274,43 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     u64 per = (n + d.nwg - 1) / d.nwg;
     per = (per + K1A_CHUNK - 1) / K1A_CHUNK * K1A_CHUNK;
     const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
-    for (u64 c0 = beg; c0 < end; c0 += K1A_CHUNK) {
-        const u64 i0 = c0 + t, i1 = c0 + K1A_THREADS + t;
-        uint4 a0, b0, a1, b1;
-        const bool v0 = i0 < end, v1 = i1 < end;
+    uint4 a0, b0, a1, b1;
+    bool v0 = false, v1 = false;
+    if (beg < end) {
+        const u64 i0 = beg + t, i1 = beg + K1A_THREADS + t;
+        v0 = i0 < end; v1 = i1 < end;
         if (v0) { a0 = pe[2 * i0]; b0 = pe[2 * i0 + 1]; }
         if (v1) { a1 = pe[2 * i1]; b1 = pe[2 * i1 + 1]; }
+    }
+    for (u64 c0 = beg; c0 < end; c0 += K1A_CHUNK) {
         K1Ev e0, e1;
         bool r0 = false, r1 = false;
         if (d.ablate & 4u) {                                         // ablation: no join-table lookups
             if (v0) { e0.key = ((u64)a0.x << 32) | a0.y; e0.dur = (u64)b0.x | ((u64)b0.y << 32); e0.err = 0; r0 = true; }
             if (v1) { e1.key = ((u64)a1.x << 32) | a1.y; e1.dur = (u64)b1.x | ((u64)b1.y << 32); e1.err = 0; r1 = true; }
         } else {
-            if (v0) r0 = k1_resolve(d, a0, b0, L, e0);
-            if (v1) r1 = k1_resolve(d, a1, b1, L, e1);
+            if (v0) r0 = k1_resolve(d, iptab, a0, b0, L, e0);
+            if (v1) r1 = k1_resolve(d, iptab, a1, b1, L, e1);
         }
-        if (d.ablate & 1u) { if ((r0 && e0.key == 0x1234567ull) || (r1 && e1.key == 0x1234567ull)) L.dcap++; continue; }   // ablation: resolve only
-        if (r0) {
-            const u32 s = lds_slot(hkey, K1A_HT - 1, e0.key); const u64 us = e0.dur / 1000ull;
-            atomicAdd(&hacc[s * 4], 1ull | ((u64)e0.err << 32)); atomicAdd(&hacc[s * 4 + 1], e0.dur);
-            atomicMax(&hacc[s * 4 + 2], e0.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
+        // prefetch the next chunk's events: they are in flight during the LDS phase and the sweep
+        {
+            const u64 n0 = c0 + K1A_CHUNK + t, n1 = n0 + K1A_THREADS;
+            v0 = n0 < end; v1 = n1 < end;
+            if (v0) { a0 = pe[2 * n0]; b0 = pe[2 * n0 + 1]; }
+            if (v1) { a1 = pe[2 * n1]; b1 = pe[2 * n1 + 1]; }
         }
-        if (r1) {
-            const u32 s = lds_slot(hkey, K1A_HT - 1, e1.key); const u64 us = e1.dur / 1000ull;
-            atomicAdd(&hacc[s * 4], 1ull | ((u64)e1.err << 32)); atomicAdd(&hacc[s * 4 + 1], e1.dur);
-            atomicMax(&hacc[s * 4 + 2], e1.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
-        }
+        if (!(d.ablate & 1u)) {
+            if (r0) {
+                const u32 s = lds_slot(hkey, K1A_HT - 1, e0.key); const u64 us = e0.dur / 1000ull;
+                atomicAdd(&hacc[s * 4], 1ull | ((u64)e0.err << 32)); atomicAdd(&hacc[s * 4 + 1], e0.dur);
+                atomicMax(&hacc[s * 4 + 2], e0.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
+            }
+            if (r1) {
+                const u32 s = lds_slot(hkey, K1A_HT - 1, e1.key); const u64 us = e1.dur / 1000ull;
+                atomicAdd(&hacc[s * 4], 1ull | ((u64)e1.err << 32)); atomicAdd(&hacc[s * 4 + 1], e1.dur);
+                atomicMax(&hacc[s * 4 + 2], e1.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
+            }
+        } else if ((r0 && e0.key == 0x1234567ull) || (r1 && e1.key == 0x1234567ull)) L.dcap++;
         __syncthreads();
         // sweep: one record per distinct edge of the chunk
 #pragma unroll
@@ -368,16 +396,36 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         while (hi - lo > 1) { const u32 m = (lo + hi) >> 1; if (pref[m] <= r) lo = m; else hi = m; }
         return lo;
     };
-    for (u32 r = t; r < RS; r += K1B_THREADS) {
-        const u32 w = piece_of(prefS, r);
-        const uint4 x = d.slab_s[((size_t)p * d.nwg + w) * d.ss + (r - prefS[w])];
-        const u64 key = (u64)x.x | ((u64)x.y << 32), dur = (u64)x.z | ((u64)(x.w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
-        add(key, 1ull | ((u64)(x.w >> 31) << 32), dur, dur, us * us);
+    // records are fetched K1B_U at a time per thread before any of them is merged: the loads are
+    // independent, so the hot partition pays a handful of memory latencies, not one per record
+    for (u32 r0 = t; r0 < RS; r0 += K1B_THREADS * K1B_U) {
+        uint4 x[K1B_U];
+#pragma unroll
+        for (int u = 0; u < K1B_U; u++) {
+            const u32 r = r0 + u * K1B_THREADS;
+            if (r < RS) { const u32 w = piece_of(prefS, r); x[u] = d.slab_s[((size_t)p * d.nwg + w) * d.ss + (r - prefS[w])]; }
+        }
+#pragma unroll
+        for (int u = 0; u < K1B_U; u++) {
+            if (r0 + u * K1B_THREADS < RS) {
+                const u64 key = (u64)x[u].x | ((u64)x[u].y << 32), dur = (u64)x[u].z | ((u64)(x[u].w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
+                add(key, 1ull | ((u64)(x[u].w >> 31) << 32), dur, dur, us * us);
+            }
+        }
     }
-    for (u32 r = t; r < RA; r += K1B_THREADS) {
-        const u32 w = piece_of(prefA, r);
-        const u64* __restrict__ pa = d.slab_a + (((size_t)p * d.nwg + w) * d.sa + (r - prefA[w])) * 5;
-        add(pa[0], pa[1], pa[2], pa[3], pa[4]);
+    for (u32 r0 = t; r0 < RA; r0 += K1B_THREADS * K1B_U) {
+        u64 y[K1B_U][5];
+#pragma unroll
+        for (int u = 0; u < K1B_U; u++) {
+            const u32 r = r0 + u * K1B_THREADS;
+            if (r < RA) {
+                const u32 w = piece_of(prefA, r);
+                const u64* __restrict__ pa = d.slab_a + (((size_t)p * d.nwg + w) * d.sa + (r - prefA[w])) * 5;
+                y[u][0] = pa[0]; y[u][1] = pa[1]; y[u][2] = pa[2]; y[u][3] = pa[3]; y[u][4] = pa[4];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_THREADS < RA) add(y[u][0], y[u][1], y[u][2], y[u][3], y[u][4]);
     }
     {
         const u64 no = d.ctr[C_OVF_N] < d.ovf_cap ? d.ctr[C_OVF_N] : d.ovf_cap;
@@ -428,7 +476,8 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
     // (a)
     {
         u64 tmin = ~0ull, tmax = 0, ml = 0, ds = 0, dc = 0, mr = 0, ac = 0;
-        for (u32 i = t; i < SG_MAX_K1_WGS; i += 1024) {
+        const u32 nslots = d.variant == 0 ? d.nwg : SG_MAX_K1_WGS;
+        for (u32 i = t; i < nslots; i += 1024) {
             u64* w = d.wgstat + (size_t)i * WS_WORDS;
             tmin = w[WS_TMIN] < tmin ? w[WS_TMIN] : tmin; tmax = w[WS_TMAX] > tmax ? w[WS_TMAX] : tmax;
             ml = w[WS_MAXLABEL] > ml ? w[WS_MAXLABEL] : ml;
@@ -646,63 +695,97 @@ __device__ __forceinline__ void edge_emit(const Dev& d, u32 pos, u32 row, u32 sl
 }
 
 #define K2_SORT_LDS 4096
+#define K2_LONG_WGS 160
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
     __shared__ u64 red[5][4];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // ---- long rows first (they are the critical path): one row per workgroup ----
-    for (u32 li = blockIdx.x; li < nlong; li += gridDim.x) {
-        const u32 rr = d.longrows[li];
-        const u32 b = d.rowptr[rr];
-        u32 m = d.rowptr[rr + 1] - b;
-        if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
-        if (m == 0) continue;
-        u32* key = d.col + b; u32* val = d.cslot + b;
-        u32 np2 = 1; while (np2 < m) np2 <<= 1;
-        u32* gk = sk; u32* gv = sv;
-        if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
-        for (u32 i = threadIdx.x; i < np2; i += 256) { gk[i] = i < m ? key[i] : 0xFFFFFFFFu; gv[i] = i < m ? val[i] : 0; }
-        __syncthreads();
-        for (u32 k = 2; k <= np2; k <<= 1)
-            for (u32 j = k >> 1; j > 0; j >>= 1) {
-                for (u32 i = threadIdx.x; i < np2; i += 256) {
-                    const u32 x = i ^ j;
-                    if (x > i) {
-                        const u32 a = gk[i], c = gk[x];
-                        if ((a > c) == ((i & k) == 0)) { gk[i] = c; gk[x] = a; const u32 tt = gv[i]; gv[i] = gv[x]; gv[x] = tt; }
-                    }
-                }
+    // ---- long rows: the first K2_LONG_WGS workgroups, one row at a time each ----
+    const u32 nlw = gridDim.x > 2 * K2_LONG_WGS ? K2_LONG_WGS : (gridDim.x / 2 ? gridDim.x / 2 : 1);   // host launches >= 2 workgroups
+    if (blockIdx.x < nlw) {
+        for (u32 li = blockIdx.x; li < nlong; li += nlw) {
+            const u32 rr = d.longrows[li];
+            const u32 b = d.rowptr[rr];
+            u32 m = d.rowptr[rr + 1] - b;
+            if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
+            if (m == 0) continue;
+            u32* key = d.col + b; u32* val = d.cslot + b;
+            u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
+            if (m <= 1024) {
+                // rank sort: keys in LDS, every thread counts the smaller keys of its (<= 4) elements
+                for (u32 i = threadIdx.x; i < m; i += 256) sk[i] = key[i];
                 __syncthreads();
+                u32 mk[4], mv[4], rk[4]; ulonglong2 ax[4], ay[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32 i = threadIdx.x + q * 256;
+                    mk[q] = i < m ? sk[i] : 0xFFFFFFFFu; mv[q] = i < m ? val[i] : 0u; rk[q] = 0;
+                    if (i < m) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q] * 4); ax[q] = a[0]; ay[q] = a[1]; }
+                    else { ax[q] = make_ulonglong2(0, 0); ay[q] = make_ulonglong2(0, 0); }
+                }
+                for (u32 j = 0; j < m; j++) {
+                    const u32 kj = sk[j];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) rk[q] += kj < mk[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) { cnt += ax[q].x & 0xFFFFFFFFull; err += ax[q].x >> 32; sum += ax[q].y; ssq += ay[q].y; mx = ay[q].x > mx ? ay[q].x : mx; }
+                cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+                if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+                __syncthreads();
+                cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+                sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+                mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) { key[rk[q]] = mk[q]; edge_emit(d, b + rk[q], rr, mv[q], cnt, sum, ssq, ax[q], ay[q]); }
+            } else {
+                u32 np2 = 1; while (np2 < m) np2 <<= 1;
+                u32* gk = sk; u32* gv = sv;
+                if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
+                for (u32 i = threadIdx.x; i < np2; i += 256) { gk[i] = i < m ? key[i] : 0xFFFFFFFFu; gv[i] = i < m ? val[i] : 0; }
+                __syncthreads();
+                for (u32 k = 2; k <= np2; k <<= 1)
+                    for (u32 j = k >> 1; j > 0; j >>= 1) {
+                        for (u32 i = threadIdx.x; i < np2; i += 256) {
+                            const u32 x = i ^ j;
+                            if (x > i) {
+                                const u32 a = gk[i], c = gk[x];
+                                if ((a > c) == ((i & k) == 0)) { gk[i] = c; gk[x] = a; const u32 tt = gv[i]; gv[i] = gv[x]; gv[x] = tt; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                for (u32 i = threadIdx.x; i < m; i += 256) {
+                    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
+                    const ulonglong2 x = a[0], y = a[1];
+                    cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
+                }
+                cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+                if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+                __syncthreads();
+                cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+                sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+                mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+                for (u32 i = threadIdx.x; i < m; i += 256) {
+                    const u32 slot = gv[i];
+                    key[i] = gk[i];
+                    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
+                    const ulonglong2 x = a[0], y = a[1];
+                    edge_emit(d, b + i, rr, slot, cnt, sum, ssq, x, y);
+                }
             }
-        u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
-        for (u32 i = threadIdx.x; i < m; i += 256) {
-            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
-            const ulonglong2 x = a[0], y = a[1];
-            cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
+            if (threadIdx.x == 0) {
+                u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
+                t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+                d.st_max[(size_t)rr * 2] = mx;
+            }
+            __syncthreads();
         }
-        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
-        if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
-        __syncthreads();
-        cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
-        mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-        if (threadIdx.x == 0) {
-            u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
-            t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
-            d.st_max[(size_t)rr * 2] = mx;
-        }
-        for (u32 i = threadIdx.x; i < m; i += 256) {
-            const u32 slot = gv[i];
-            key[i] = gk[i];
-            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
-            const ulonglong2 x = a[0], y = a[1];
-            edge_emit(d, b + i, rr, slot, cnt, sum, ssq, x, y);
-        }
-        __syncthreads();
+        return;
     }
     // ---- rows of up to 64 edges: one wave per row ----
-    for (u32 r = blockIdx.x * 4 + wave; r < N; r += gridDim.x * 4) {
+    for (u32 r = (blockIdx.x - nlw) * 4 + wave; r < N; r += (gridDim.x - nlw) * 4) {
         const u32 beg = d.rowptr[r];
         u32 n = d.rowptr[r + 1] - beg;
         if (n == 0 || n > 64) continue;
@@ -815,11 +898,12 @@ __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
         u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS; u64* mx = d.st_max + (size_t)v * 2;
         if (d.in_dense && d.in_fused) {
             u64 a[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 8
             for (u32 g = 0; g < d.in_groups; g++) {
-                const u64* o = d.in_part + ((size_t)g * d.ncap + v) * 6;
-#pragma unroll
-                for (int k = 0; k < 5; k++) a[k] += o[k];
-                a[5] = o[5] > a[5] ? o[5] : a[5];
+                const ulonglong2* o = reinterpret_cast<const ulonglong2*>(d.in_part + ((size_t)g * d.ncap + v) * 6);
+                const ulonglong2 p0 = o[0], p1 = o[1], p2 = o[2];
+                a[0] += p0.x; a[1] += p0.y; a[2] += p1.x; a[3] += p1.y; a[4] += p2.x;
+                a[5] = p2.y > a[5] ? p2.y : a[5];
             }
             s[ST_IN_DEG] = a[0]; s[ST_IN_CNT] = a[1]; s[ST_IN_ERR] = a[2]; s[ST_IN_SUM] = a[3]; s[ST_IN_SSQ] = a[4]; mx[1] = a[5];
         }
@@ -909,13 +993,18 @@ __device__ __forceinline__ void gather_mean(const Dev& d, const float* __restric
         for (u32 base = 0; base < deg; base += 64) {
             const u32 cnt = deg - base < 64 ? deg - base : 64;
             const u32 my = lane < cnt ? nb[base + lane] : 0u;
-            for (u32 i0 = 0; i0 < cnt; i0 += 16) {
+            for (u32 i0 = 0; i0 < cnt; i0 += 32) {                   // 16 row loads in flight per lane group
+                float tmp[16];
 #pragma unroll
-                for (int a = 0; a < 8; a++) {
-                    const u32 i = i0 + 2 * a + g;                    // slot = i % 16 = 2a + g  (base is a multiple of 16)
+                for (int a = 0; a < 16; a++) {
+                    const u32 i = i0 + 2 * a + g;                    // slot = i % 16 = (2a + g) % 16  (base, i0 multiples of 16)
                     const u32 id = __shfl(my, (int)(i & 63), 64);
-                    if (i < cnt) acc[a] = acc[a] + hin[(size_t)id * 32 + k];
+                    tmp[a] = i < cnt ? hin[(size_t)id * 32 + k] : 0.0f;
                 }
+#pragma unroll
+                for (int a = 0; a < 8; a++) if (i0 + 2 * a + g < cnt) acc[a] = acc[a] + tmp[a];
+#pragma unroll
+                for (int a = 0; a < 8; a++) if (i0 + 16 + 2 * a + g < cnt) acc[a] = acc[a] + tmp[8 + a];
             }
         }
         float t = 0.0f;
@@ -960,9 +1049,17 @@ __global__ __launch_bounds__(256) void k4_sage_layer(Dev d, const float* __restr
     for (u32 tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
         const u32 v0 = tile * 16;
         __shared__ u32 skip[16];
-        // phase 1: self row + gather-mean, 4 nodes per wave
-        for (u32 q = 0; q < 4; q++) {
-            const u32 r = wave * 4 + q, v = v0 + r;
+        __shared__ u32 next_row;
+        if (threadIdx.x == 0) next_row = 0;
+        __syncthreads();
+        // phase 1: self row + gather-mean; the 4 waves pull the tile's 16 nodes from a shared counter
+        // (row lengths follow a power law: static assignment leaves one wave with all the hubs)
+        for (;;) {
+            u32 r = 0;
+            if (lane == 0) r = atomicAdd(&next_row, 1u);
+            r = __shfl(r, 0, 64);
+            if (r >= 16) break;
+            const u32 v = v0 + r;
             float* row = A + r * LDA;
             bool sk = v >= N;
             if (!sk && d.world > 1) {
@@ -1052,7 +1149,9 @@ __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restri
     }
 }
 
-// wave per edge, lane = hidden unit j.
+// one wave scores K5_U edges at a time (lane = hidden unit j): the index loads, then the 2*K5_U row
+// gathers of a step are independent and in flight together.
+#define K5_U 4
 __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
     const u32 E = (u32)d.ctr[C_N_EDGES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const float* __restrict__ We = Wh + 2 * SG_F_HID * SG_F_HID;
@@ -1063,17 +1162,35 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
 #pragma unroll
     for (int k = 0; k < (int)SG_F_EDGE; k++) we[k] = We[k * SG_F_HID + lane];
     const float w2j = w2[lane];
-    for (u32 p = wave; p < E; p += nw) {
-        const u32 u = d.csr_from[p], v = d.col[p];
-        float t = d.P[(size_t)u * SG_F_HID + lane] + d.Q[(size_t)v * SG_F_HID + lane];
-        const float ev = lane < SG_F_EDGE ? d.efeat[(size_t)p * SG_F_EDGE + lane] : 0.0f;
+    for (u32 p0 = wave * K5_U; p0 < E; p0 += nw * K5_U) {
+        u32 uu[K5_U], vv[K5_U]; float t[K5_U], ev[K5_U];
 #pragma unroll
-        for (int k = 0; k < (int)SG_F_EDGE; k++) t = fmaf(__shfl(ev, k, 64), we[k], t);
-        t = t > 0.0f ? t : 0.0f;
-        float r = t * w2j;
+        for (int q = 0; q < K5_U; q++) { const u32 p = p0 + q < E ? p0 + q : E - 1; uu[q] = d.csr_from[p]; vv[q] = d.col[p]; }
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) r = r + __shfl_xor(r, s, 64);
-        if (lane == 0) {
+        for (int q = 0; q < K5_U; q++) {
+            const u32 p = p0 + q < E ? p0 + q : E - 1;
+            t[q] = d.P[(size_t)uu[q] * SG_F_HID + lane] + d.Q[(size_t)vv[q] * SG_F_HID + lane];
+            ev[q] = lane < SG_F_EDGE ? d.efeat[(size_t)p * SG_F_EDGE + lane] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < K5_U; q++) {
+            float x = t[q];
+#pragma unroll
+            for (int k = 0; k < (int)SG_F_EDGE; k++) x = fmaf(__shfl(ev[q], k, 64), we[k], x);
+            x = x > 0.0f ? x : 0.0f;
+            float r = x * w2j;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) r = r + __shfl_xor(r, s, 64);
+            t[q] = r;
+        }
+        if (lane < K5_U && p0 + lane < E) {
+            const u32 p = p0 + lane;
+            float r = t[0];
+#pragma unroll
+            for (int q = 1; q < K5_U; q++) r = lane == (u32)q ? t[q] : r;
+            u32 u = uu[0], v = vv[0];
+#pragma unroll
+            for (int q = 1; q < K5_U; q++) { u = lane == (u32)q ? uu[q] : u; v = lane == (u32)q ? vv[q] : v; }
             const float logit = r + b2;
             const float score = 1.0f / (1.0f + expf(-logit));
             const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
