@@ -339,7 +339,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     e->ecap = next_pow2(std::max<u64>(2 * ME, K2_TILE));
     e->obcap = next_pow2(std::max<u64>(2 * (u64)cfg->max_outbound_ips, 64));
     e->ob_list_cap = next_pow2(std::max<u64>((u64)cfg->max_outbound_ips * std::max<u32>(cfg->world, 1), 64));
-    e->ipcap = next_pow2(std::max<u64>(2 * (u64)e->cfg.max_ips, 64));
+    e->ipcap = next_pow2(std::max<u64>((u64)e->cfg.max_ips * 4 / 3 + 1, 64));
     d.max_known = cfg->max_known_nodes; d.max_labels = cfg->max_labels; d.max_obip = std::max<u32>(cfg->max_outbound_ips, 1);
     d.rank = cfg->rank; d.world = cfg->world; d.max_edges = ME; d.layers = cfg->layers;
     d.ncap = cfg->max_known_nodes + cfg->max_labels + d.max_obip;
@@ -358,25 +358,25 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     {
         u64 np = next_pow2(std::max<u64>(ME / 160, 64));
         if (cfg->k1_variant == 0 && np > 1024) d.variant = 1;           // beyond the partitioned path's range
-        d.np = (u32)std::min<u64>(np, 1024); d.nwg = 512; d.pcap = 768;
+        d.np = (u32)std::min<u64>(std::max<u64>(np / 2, 64), 1024); d.nwg = 256; d.pcap = 768;
         if (const char* v = std::getenv("SG_NP")) d.np = (u32)std::strtoul(v, nullptr, 0);
         if (const char* v = std::getenv("SG_NWG")) d.nwg = (u32)std::strtoul(v, nullptr, 0);
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
         d.ss = (u32)(2.0 * m + 6.0 * std::sqrt(m + 1.0) + 8.0);
-        d.sa = d.ss / 2 + 8;
+        d.ss = (d.ss + 1 + 7) / 8 * 8 - 1;                              // header + ss singles = whole 128-byte lines
+        d.sa = 16;
         d.ovf_cap = 1u << 16;
     }
     size_t eslots = ME;
     if (d.variant == 0) {
         eslots = std::max<size_t>(ME, (size_t)d.np * d.pcap);
-        CR(dev_alloc(e, &d.slab_s, (size_t)d.np * d.nwg * d.ss));
+        CR(dev_alloc(e, &d.slab_s, (size_t)d.np * d.nwg * (d.ss + 1)));
         CR(dev_alloc(e, &d.slab_a, (size_t)d.np * d.nwg * d.sa * 5));
-        CR(dev_alloc(e, &d.fill_s, (size_t)d.np * d.nwg)); CR(dev_alloc(e, &d.fill_a, (size_t)d.np * d.nwg));
         CR(dev_alloc(e, &d.ovf, (size_t)d.ovf_cap * 5));
         CR(dev_alloc(e, &d.part_n, d.np));
         CR(dev_alloc(e, &d.acc_src, (size_t)d.np * d.pcap * 4));
         e->ip_lds = e->ipcap <= SG_IP_LDS_MAX;
-        e->k1a_lds = (size_t)K1A_HT * 8 + (size_t)K1A_HT * 32 + (size_t)d.np * 8 + (e->ip_lds ? (size_t)e->ipcap * 8 : 0);
+        e->k1a_lds = (size_t)K1A_CT * 8 + (size_t)K1A_CT * 32 + (size_t)d.np * 8 + (e->ip_lds ? (size_t)e->ipcap * 8 : 0);
         e->k1b_lds = (size_t)K1B_HT * (8 + 32) + (size_t)(d.nwg + 1) * 8;
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));

@@ -222,27 +222,13 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
 // partitions stay balanced; the long tail passes through as 16-byte singles.
 // Pass B (k1b_merge, at window close): workgroup p owns partition p exclusively, merges its pieces
 // in LDS and writes each distinct edge once with plain stores.
-#define K1A_THREADS 256
-#define K1A_CHUNK   512
-#define K1A_HT      1024
+#define K1A_THREADS 1024
+#define K1A_CT      2048      // LDS cache slots per workgroup
 #define K1B_HT      1024
 #define K1B_THREADS 256
 #define K1B_U       4
 
-__device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return (hash_key64(key) >> 7) & (d.np - 1); }
-
-__device__ __forceinline__ u32 lds_slot(volatile u64* hkey, u32 mask, u64 key) {
-    u32 h = hash_key64(key) & mask;
-    for (;;) {
-        u64 k = hkey[h];
-        if (k == SG_EKEY_EMPTY) {
-            k = atomicCAS((u64*)&hkey[h], SG_EKEY_EMPTY, key);
-            if (k == SG_EKEY_EMPTY) return h;
-        }
-        if (k == key) return h;
-        h = (h + 1) & mask;
-    }
-}
+__device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return (hash_key64(key) >> 11) & (d.np - 1); }
 
 __device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
     const u64 idx = atomicAdd(&d.ctr[C_OVF_N], 1ull);
@@ -250,100 +236,97 @@ __device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1
     else { const u32 c = (u32)(a0 & 0xFFFFFFFFull); L.dcap += c; L.acc -= c; }
 }
 
-// IPLDS: the join table is staged in LDS (tables of up to SG_IP_LDS_MAX entries): the two probes per
-// event then cost LDS reads instead of uncoalesced 8-byte global loads.
-// Two workgroups share a CU (<= 76 KiB LDS each): one streams / resolves while the other sweeps.
+// Slab geometry: piece (p, w) = records workgroup w produced for partition p:
+//   slab_s[(p*nwg + w) * (ss + 1)]  : one 16-byte header {n_single, n_aggregate, 0, 0} followed by ss
+//                                     single records {key.lo, key.hi, dur.lo, dur.hi | err << 31}
+//   slab_a[(p*nwg + w) * sa * 5]    : sa aggregate records {key, cnt | err<<32, sum_ns, max_ns, sumsq_us}
+// A piece's header and its first 7 singles share one 128-byte line, so pass B usually needs one
+// line per piece.
+__device__ __forceinline__ void emit_single(const Dev& d, u32* fS, u32 w, u64 key, u64 dur, u32 err, K1Local& L) {
+    const u32 p = part_of(d, key);
+    const u32 pos = atomicAdd(&fS[p], 1u);
+    if (pos < d.ss) d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1) + 1 + pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31));
+    else { const u64 us = dur / 1000ull; ovf_append(d, key, 1ull | ((u64)err << 32), dur, dur, us * us, L); }
+}
+__device__ __forceinline__ void emit_agg(const Dev& d, u32* fA, u32 w, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
+    const u32 p = part_of(d, key);
+    const u32 pos = atomicAdd(&fA[p], 1u);
+    if (pos < d.sa) { u64* o = d.slab_a + (((size_t)p * d.nwg + w) * d.sa + pos) * 5; o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; }
+    else ovf_append(d, key, a0, a1, a2, a3, L);
+}
+
+// Pass A.  One fat workgroup per CU streams a contiguous share of the batch with no barrier in the
+// loop.  Each event is resolved (join table staged in LDS when IPLDS) and looked up in a
+// first-come LDS cache (2 probes): the first key to claim a slot owns it for the whole launch and
+// every later event of that key is folded in with LDS atomics; an event whose slots are taken by
+// other keys bypasses the cache as a 16-byte single record.  Hot edges appear early, claim their
+// slots and collapse to one aggregate record per workgroup; the long tail streams through.
 template <bool IPLDS>
 __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_event* __restrict__ ev, u64 n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* hkey = reinterpret_cast<u64*>(smem);                       // [K1A_HT]
-    u64* hacc = hkey + K1A_HT;                                       // [K1A_HT][4]
-    u32* fS = reinterpret_cast<u32*>(hacc + K1A_HT * 4);             // [np]
+    u64* ckey = reinterpret_cast<u64*>(smem);                       // [K1A_CT]
+    u64* cacc = ckey + K1A_CT;                                       // [K1A_CT][4]
+    u32* fS = reinterpret_cast<u32*>(cacc + K1A_CT * 4);             // [np]
     u32* fA = fS + d.np;                                             // [np]
     u64* ipl = reinterpret_cast<u64*>(fA + d.np);                    // [ipmask + 1] when IPLDS
     const u32 w = blockIdx.x, t = threadIdx.x;
-    for (u32 i = t; i < K1A_HT; i += K1A_THREADS) hkey[i] = SG_EKEY_EMPTY;
-    for (u32 i = t; i < K1A_HT * 4; i += K1A_THREADS) hacc[i] = 0;
-    for (u32 p = t; p < d.np; p += K1A_THREADS) { fS[p] = d.fill_s[(size_t)p * d.nwg + w]; fA[p] = d.fill_a[(size_t)p * d.nwg + w]; }
+    for (u32 i = t; i < K1A_CT; i += K1A_THREADS) ckey[i] = SG_EKEY_EMPTY;
+    for (u32 i = t; i < K1A_CT * 4; i += K1A_THREADS) cacc[i] = 0;
+    for (u32 p = t; p < d.np; p += K1A_THREADS) { const uint4 h = d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)]; fS[p] = h.x; fA[p] = h.y; }
     if (IPLDS) for (u32 i = t; i <= d.ipmask; i += K1A_THREADS) ipl[i] = d.iptab[i];
     const u64* iptab = IPLDS ? ipl : d.iptab;
     __syncthreads();
 
     K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
     const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
-    u64 per = (n + d.nwg - 1) / d.nwg;
-    per = (per + K1A_CHUNK - 1) / K1A_CHUNK * K1A_CHUNK;
+    const u64 per = (n + d.nwg - 1) / d.nwg;
     const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
-    uint4 a0, b0, a1, b1;
-    bool v0 = false, v1 = false;
-    if (beg < end) {
-        const u64 i0 = beg + t, i1 = beg + K1A_THREADS + t;
-        v0 = i0 < end; v1 = i1 < end;
-        if (v0) { a0 = pe[2 * i0]; b0 = pe[2 * i0 + 1]; }
-        if (v1) { a1 = pe[2 * i1]; b1 = pe[2 * i1 + 1]; }
-    }
-    for (u64 c0 = beg; c0 < end; c0 += K1A_CHUNK) {
-        K1Ev e0, e1;
-        bool r0 = false, r1 = false;
-        if (d.ablate & 4u) {                                         // ablation: no join-table lookups
-            if (v0) { e0.key = ((u64)a0.x << 32) | a0.y; e0.dur = (u64)b0.x | ((u64)b0.y << 32); e0.err = 0; r0 = true; }
-            if (v1) { e1.key = ((u64)a1.x << 32) | a1.y; e1.dur = (u64)b1.x | ((u64)b1.y << 32); e1.err = 0; r1 = true; }
-        } else {
-            if (v0) r0 = k1_resolve(d, iptab, a0, b0, L, e0);
-            if (v1) r1 = k1_resolve(d, iptab, a1, b1, L, e1);
-        }
-        // prefetch the next chunk's events: they are in flight during the LDS phase and the sweep
-        {
-            const u64 n0 = c0 + K1A_CHUNK + t, n1 = n0 + K1A_THREADS;
-            v0 = n0 < end; v1 = n1 < end;
-            if (v0) { a0 = pe[2 * n0]; b0 = pe[2 * n0 + 1]; }
-            if (v1) { a1 = pe[2 * n1]; b1 = pe[2 * n1 + 1]; }
-        }
-        if (!(d.ablate & 1u)) {
-            if (r0) {
-                const u32 s = lds_slot(hkey, K1A_HT - 1, e0.key); const u64 us = e0.dur / 1000ull;
-                atomicAdd(&hacc[s * 4], 1ull | ((u64)e0.err << 32)); atomicAdd(&hacc[s * 4 + 1], e0.dur);
-                atomicMax(&hacc[s * 4 + 2], e0.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
-            }
-            if (r1) {
-                const u32 s = lds_slot(hkey, K1A_HT - 1, e1.key); const u64 us = e1.dur / 1000ull;
-                atomicAdd(&hacc[s * 4], 1ull | ((u64)e1.err << 32)); atomicAdd(&hacc[s * 4 + 1], e1.dur);
-                atomicMax(&hacc[s * 4 + 2], e1.dur); atomicAdd(&hacc[s * 4 + 3], us * us);
-            }
-        } else if ((r0 && e0.key == 0x1234567ull) || (r1 && e1.key == 0x1234567ull)) L.dcap++;
-        __syncthreads();
-        // sweep: one record per distinct edge of the chunk
+    u64 i = beg + t;
+    uint4 a, b;
+    if (i < end) { a = pe[2 * i]; b = pe[2 * i + 1]; }
+    while (i < end) {
+        const uint4 ca = a, cb = b;
+        const u64 nx = i + K1A_THREADS;
+        if (nx < end) { a = pe[2 * nx]; b = pe[2 * nx + 1]; }        // next event in flight while this one is folded in
+        i = nx;
+        K1Ev e; bool ok;
+        if (d.ablate & 4u) { e.key = ((u64)ca.x << 32) | ca.y; e.dur = (u64)cb.x | ((u64)cb.y << 32); e.err = 0; ok = true; }
+        else ok = k1_resolve(d, iptab, ca, cb, L, e);
+        if (!ok) continue;
+        if (d.ablate & 1u) { if (e.key == 0x1234567ull) L.dcap++; continue; }
+        u32 h = hash_key64(e.key) & (K1A_CT - 1);
+        int slot = -1;
 #pragma unroll
-        for (u32 q = 0; q < K1A_HT / K1A_THREADS; q++) {
-            const u32 s = q * K1A_THREADS + t;
-            const u64 k = hkey[s];
-            if (k == SG_EKEY_EMPTY) continue;
-            const u64 x0 = hacc[s * 4], x1 = hacc[s * 4 + 1], x2 = hacc[s * 4 + 2], x3 = hacc[s * 4 + 3];
-            hkey[s] = SG_EKEY_EMPTY; hacc[s * 4] = 0; hacc[s * 4 + 1] = 0; hacc[s * 4 + 2] = 0; hacc[s * 4 + 3] = 0;
-            const u32 p = part_of(d, k);
-            if (d.ablate & 2u) { if (k == 0x1234567ull) fS[p]++; continue; }   // ablation: sweep without slab stores
-            if ((x0 & 0xFFFFFFFFull) == 1ull) {
-                const u32 pos = atomicAdd(&fS[p], 1u);
-                if (pos < d.ss) d.slab_s[((size_t)p * d.nwg + w) * d.ss + pos] = make_uint4((u32)k, (u32)(k >> 32), (u32)x1, (u32)(x1 >> 32) | ((u32)(x0 >> 32) << 31));
-                else ovf_append(d, k, x0, x1, x2, x3, L);
-            } else {
-                const u32 pos = atomicAdd(&fA[p], 1u);
-                if (pos < d.sa) { u64* o = d.slab_a + (((size_t)p * d.nwg + w) * d.sa + pos) * 5; o[0] = k; o[1] = x0; o[2] = x1; o[3] = x2; o[4] = x3; }
-                else ovf_append(d, k, x0, x1, x2, x3, L);
-            }
+        for (int pr = 0; pr < 2; pr++) {
+            u64 k = ((volatile u64*)ckey)[h];
+            if (k == SG_EKEY_EMPTY) { k = atomicCAS(&ckey[h], SG_EKEY_EMPTY, e.key); if (k == SG_EKEY_EMPTY) k = e.key; }
+            if (k == e.key) { slot = (int)h; break; }
+            h = (h + 1) & (K1A_CT - 1);
         }
-        __syncthreads();
+        if (slot >= 0) {
+            const u64 us = e.dur / 1000ull;
+            atomicAdd(&cacc[slot * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&cacc[slot * 4 + 1], e.dur);
+            atomicMax(&cacc[slot * 4 + 2], e.dur); atomicAdd(&cacc[slot * 4 + 3], us * us);
+        } else if (!(d.ablate & 2u)) emit_single(d, fS, w, e.key, e.dur, e.err, L);
     }
-    for (u32 p = t; p < d.np; p += K1A_THREADS) {
-        d.fill_s[(size_t)p * d.nwg + w] = fS[p] < d.ss ? fS[p] : d.ss;
-        d.fill_a[(size_t)p * d.nwg + w] = fA[p] < d.sa ? fA[p] : d.sa;
+    __syncthreads();
+    // flush the cache: one record per cached edge
+    for (u32 s = t; s < K1A_CT; s += K1A_THREADS) {
+        const u64 k = ckey[s];
+        if (k == SG_EKEY_EMPTY || (d.ablate & 2u)) continue;
+        const u64 x0 = cacc[s * 4], x1 = cacc[s * 4 + 1], x2 = cacc[s * 4 + 2], x3 = cacc[s * 4 + 3];
+        if ((x0 & 0xFFFFFFFFull) == 1ull) emit_single(d, fS, w, k, x1, (u32)(x0 >> 32), L);
+        else emit_agg(d, fA, w, k, x0, x1, x2, x3, L);
     }
+    __syncthreads();
+    for (u32 p = t; p < d.np; p += K1A_THREADS)
+        d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)] = make_uint4(fS[p] < d.ss ? fS[p] : d.ss, fA[p] < d.sa ? fA[p] : d.sa, 0u, 0u);
     k1_publish_stats(d, L);
 }
 
-// Pass B.  LDS: edge table [K1B_HT] (key + 4 words) and the prefix sums of the piece fills.
-// The records of the partition are walked as one flat index space (piece found by binary search in
-// the LDS prefix array), so every thread has independent loads in flight.  Outputs, plain stores:
+// Pass B.  Workgroup p owns partition p: it reads the headers of its nwg pieces, walks all their
+// records as one flat index space (K1B_U independent loads in flight per thread), merges them in
+// an LDS table and writes every distinct edge once with plain stores:
 //   e_from/e_to [p*pcap + i]  dense endpoints        acc_src [(p*pcap + i)*4]  accumulators
 //   deg[from] += 1 (atomic u32; a row's edges are spread over the partitions)
 __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
@@ -352,25 +335,24 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     u64* hacc = hkey + K1B_HT;                                       // [K1B_HT][4]
     u32* prefS = reinterpret_cast<u32*>(hacc + K1B_HT * 4);          // [nwg + 1]
     u32* prefA = prefS + d.nwg + 1;                                  // [nwg + 1]
-    __shared__ u32 n_edges, n_drop, out_n;
+    __shared__ u32 n_drop, out_n;
     __shared__ u32 wsum[K1B_THREADS / 64 + 1];
     const u32 p = blockIdx.x, t = threadIdx.x;
     for (u32 i = t; i < K1B_HT; i += K1B_THREADS) hkey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < K1B_HT * 4; i += K1B_THREADS) hacc[i] = 0;
-    if (t == 0) { n_edges = 0; n_drop = 0; out_n = 0; }
+    if (t == 0) { n_drop = 0; out_n = 0; }
 
-    // prefix sums of the fills of this partition's pieces (nwg is a multiple of the block size or smaller)
     u32 RS = 0, RA = 0;
     for (u32 w0 = 0; w0 < d.nwg; w0 += K1B_THREADS) {
         const u32 w = w0 + t;
-        const size_t piece = (size_t)p * d.nwg + w;
-        const u32 fs = w < d.nwg ? d.fill_s[piece] : 0u, fa = w < d.nwg ? d.fill_a[piece] : 0u;
-        if (w < d.nwg) { d.fill_s[piece] = 0; d.fill_a[piece] = 0; }  // window reset of the slab
+        uint4* hdr = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
+        uint4 h = make_uint4(0, 0, 0, 0);
+        if (w < d.nwg) { h = *hdr; if (h.x | h.y) *hdr = make_uint4(0, 0, 0, 0); }   // window reset of the piece
         u32 tot;
-        const u32 es = block_excl_scan<K1B_THREADS>(fs, wsum, &tot);
+        const u32 es = block_excl_scan<K1B_THREADS>(h.x, wsum, &tot);
         if (w < d.nwg) prefS[w] = RS + es;
         RS += tot;
-        const u32 ea = block_excl_scan<K1B_THREADS>(fa, wsum, &tot);
+        const u32 ea = block_excl_scan<K1B_THREADS>(h.y, wsum, &tot);
         if (w < d.nwg) prefA[w] = RA + ea;
         RA += tot;
     }
@@ -379,12 +361,9 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
 
     auto add = [&](u64 key, u64 a0, u64 a1, u64 a2, u64 a3) {
         u32 h = hash_key64(key) & (K1B_HT - 1); bool ok = false;
-        for (u32 it = 0; it < K1B_HT; it++) {                        // bounded: at most pcap distinct edges per partition
+        for (u32 it = 0; it < K1B_HT; it++) {                        // bounded: the table holds at most K1B_HT distinct edges
             u64 k = ((volatile u64*)hkey)[h];
-            if (k == SG_EKEY_EMPTY && ((volatile u32*)&n_edges)[0] < d.pcap) {
-                k = atomicCAS(&hkey[h], SG_EKEY_EMPTY, key);
-                if (k == SG_EKEY_EMPTY) { atomicAdd(&n_edges, 1u); k = key; }
-            }
+            if (k == SG_EKEY_EMPTY) { k = atomicCAS(&hkey[h], SG_EKEY_EMPTY, key); if (k == SG_EKEY_EMPTY) k = key; }
             if (k == key) { ok = true; break; }
             h = (h + 1) & (K1B_HT - 1);
         }
@@ -396,14 +375,12 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         while (hi - lo > 1) { const u32 m = (lo + hi) >> 1; if (pref[m] <= r) lo = m; else hi = m; }
         return lo;
     };
-    // records are fetched K1B_U at a time per thread before any of them is merged: the loads are
-    // independent, so the hot partition pays a handful of memory latencies, not one per record
     for (u32 r0 = t; r0 < RS; r0 += K1B_THREADS * K1B_U) {
         uint4 x[K1B_U];
 #pragma unroll
         for (int u = 0; u < K1B_U; u++) {
             const u32 r = r0 + u * K1B_THREADS;
-            if (r < RS) { const u32 w = piece_of(prefS, r); x[u] = d.slab_s[((size_t)p * d.nwg + w) * d.ss + (r - prefS[w])]; }
+            if (r < RS) { const u32 w = piece_of(prefS, r); x[u] = d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1) + 1 + (r - prefS[w])]; }
         }
 #pragma unroll
         for (int u = 0; u < K1B_U; u++) {
