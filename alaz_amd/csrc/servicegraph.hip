@@ -114,19 +114,32 @@ int sync_tables(sg_engine* e, hipStream_t s) {
     const size_t tot = (size_t)e->ipcap + e->ip2cap;
     std::memset(e->h_iptab, 0xFF, tot * sizeof(u64));
     u64* t1 = e->h_iptab; u64* t2 = e->h_iptab + e->ipcap;
-    auto put = [](u64* tab, u32 mask, u32 ip, u32 val) {
-        u32 h = sg_fmix32(ip) & mask;
-        while (tab[h] != SG_IP_EMPTY && (u32)tab[h] != ip) h = (h + 1) & mask;
-        tab[h] = (u64)ip | ((u64)val << 32);
+    // bucketized cuckoo insertion (2 hash functions x 2 entries per bucket), random-walk eviction
+    auto put = [](u64* tab, u32 mask, u32 ip, u32 val) -> bool {
+        const u32 bmask = mask >> 1;
+        u64 cur = (u64)ip | ((u64)val << 32);
+        u32 b = ip_h1((u32)cur, bmask);
+        for (int kick = 0; kick < 512; kick++) {
+            const u32 b1 = ip_h1((u32)cur, bmask), b2 = ip_h2((u32)cur, bmask);
+            for (u32 bb : {b1, b2}) for (int s2 = 0; s2 < 2; s2++) {
+                u64& slot = tab[2 * (size_t)bb + s2];
+                if (slot == SG_IP_EMPTY || (u32)slot == (u32)cur) { slot = cur; return true; }
+            }
+            b = (b == b1) ? b2 : b1;                                 // evict from the other bucket than last time
+            u64& victim = tab[2 * (size_t)b + (kick & 1)];
+            std::swap(cur, victim);
+        }
+        return false;
     };
-    size_t both = 0;
+    size_t both = 0; bool ok = true;
     for (auto& kv : e->pod_ip) {
         auto sv = e->svc_ip.find(kv.first);
-        if (sv == e->svc_ip.end()) put(t1, e->ipcap - 1, kv.first, (1u << 30) | kv.second);
-        else if (both < e->ip2cap / 2) { put(t1, e->ipcap - 1, kv.first, (3u << 30) | sv->second); put(t2, e->ip2cap - 1, kv.first, (1u << 30) | kv.second); both++; }
-        else put(t1, e->ipcap - 1, kv.first, (2u << 30) | sv->second);   // second table full: the service mapping wins as destination
+        if (sv == e->svc_ip.end()) ok &= put(t1, e->ipcap - 1, kv.first, (1u << 30) | kv.second);
+        else if (both < e->ip2cap / 2) { ok &= put(t1, e->ipcap - 1, kv.first, (3u << 30) | sv->second); ok &= put(t2, e->ip2cap - 1, kv.first, (1u << 30) | kv.second); both++; }
+        else ok &= put(t1, e->ipcap - 1, kv.first, (2u << 30) | sv->second);   // second table full: the service mapping wins as destination
     }
-    for (auto& kv : e->svc_ip) if (e->pod_ip.find(kv.first) == e->pod_ip.end()) put(t1, e->ipcap - 1, kv.first, (2u << 30) | kv.second);
+    for (auto& kv : e->svc_ip) if (e->pod_ip.find(kv.first) == e->pod_ip.end()) ok &= put(t1, e->ipcap - 1, kv.first, (2u << 30) | kv.second);
+    if (!ok) { e->err = "join table build failed (cuckoo cycle): raise max_ips"; return SG_ENOSPC; }
     std::memcpy(e->h_kind, e->kind.data(), e->kind.size());
     HIP_TRY(e, hipMemcpyAsync(e->d_iptab, e->h_iptab, tot * sizeof(u64), hipMemcpyHostToDevice, s));
     HIP_TRY(e, hipMemcpyAsync(e->d_kind, e->h_kind, e->kind.size(), hipMemcpyHostToDevice, s));
@@ -214,12 +227,11 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         hipLaunchKernelGGL(k2_rowptr, dim3(1), dim3(1024), 0, s, d);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.np), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, grid_for(d.ncap, 4))), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(2048, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 0, s, d);
     }
     {
         Timed t3(e, s, 3);
-        hipLaunchKernelGGL(k3_in_stats, dim3(d.in_groups), dim3(256), e->k3in_lds, s, d);
-        if (d.in_dense && !d.in_fused) hipLaunchKernelGGL(k3_in_reduce, dim3(grid_for(d.ncap, 256)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k3_in_stats, dim3(K3_IN_WGS), dim3(1024), e->k3in_lds, s, d);
     }
     HIP_TRY(e, hipGetLastError());
     e->closed = true;
@@ -339,7 +351,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     e->ecap = next_pow2(std::max<u64>(2 * ME, K2_TILE));
     e->obcap = next_pow2(std::max<u64>(2 * (u64)cfg->max_outbound_ips, 64));
     e->ob_list_cap = next_pow2(std::max<u64>((u64)cfg->max_outbound_ips * std::max<u32>(cfg->world, 1), 64));
-    e->ipcap = next_pow2(std::max<u64>((u64)e->cfg.max_ips * 4 / 3 + 1, 64));
+    e->ipcap = next_pow2(std::max<u64>((u64)e->cfg.max_ips * 5 / 4 + 1, 64));       // cuckoo 2x2: load factor <= 0.8
     d.max_known = cfg->max_known_nodes; d.max_labels = cfg->max_labels; d.max_obip = std::max<u32>(cfg->max_outbound_ips, 1);
     d.rank = cfg->rank; d.world = cfg->world; d.max_edges = ME; d.layers = cfg->layers;
     d.ncap = cfg->max_known_nodes + cfg->max_labels + d.max_obip;
@@ -375,9 +387,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         CR(dev_alloc(e, &d.ovf, (size_t)d.ovf_cap * 5));
         CR(dev_alloc(e, &d.part_n, d.np));
         CR(dev_alloc(e, &d.acc_src, (size_t)d.np * d.pcap * 4));
+        CR(dev_alloc(e, &d.e_rank, (size_t)d.np * d.pcap));
         e->ip_lds = e->ipcap <= SG_IP_LDS_MAX;
         e->k1a_lds = (size_t)K1A_CT * 8 + (size_t)K1A_CT * 32 + (size_t)d.np * 8 + (e->ip_lds ? (size_t)e->ipcap * 8 : 0);
-        e->k1b_lds = (size_t)K1B_HT * (8 + 32) + (size_t)(d.nwg + 1) * 8;
+        e->k1b_lds = (size_t)K1B_HT * (8 + 32);
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
@@ -398,8 +411,6 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CR(dev_alloc(e, &d.e_slot, ME)); CR(dev_alloc(e, &d.e_from, eslots)); CR(dev_alloc(e, &d.e_to, eslots));
     CR(dev_alloc(e, &d.longrows, (size_t)d.ncap + 1));
     d.in_dense = d.ncap <= K3_IN_NODES ? 1u : 0u;
-    d.in_groups = 16; d.in_fused = cfg->world == 1 ? 1u : 0u;
-    CR(dev_alloc(e, &d.in_part, d.in_dense ? (size_t)d.in_groups * d.ncap * 6 : 1));
     e->k3in_lds = d.in_dense ? (size_t)d.ncap * 48 : (size_t)K3_IN_HT * 52;
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }

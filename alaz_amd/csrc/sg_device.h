@@ -12,10 +12,12 @@ typedef uint32_t u32;
 #define SG_EKEY_EMPTY (~0ull)
 #define SG_WAVE       64
 
-// join-table entry: one 8-byte probe resolves an IP against BOTH reference maps (PodIPToPodUid and
-// ServiceIPToServiceUid, aggregator/cluster.go:13-17):  low 32 bits = IP, high 32 bits =
-// kind << 30 | id with kind 1 = pod, 2 = service, 3 = the IP is in both maps (id = the service,
-// the pod id is in the small second table).  All ones = empty.
+// Join table: bucketized cuckoo hash over BOTH reference maps (PodIPToPodUid and
+// ServiceIPToServiceUid, aggregator/cluster.go:13-17).  A bucket is two 8-byte entries (one 16-byte
+// load); an IP lives in bucket h1(ip) or bucket h2(ip), so a lookup is two independent loads and
+// four compares — no probe loop, no divergence between the lanes of a wave.
+// entry: low 32 bits = IP, high 32 bits = kind << 30 | id; kind 1 = pod, 2 = service, 3 = the IP
+// is in both maps (id = the service; the pod id is in the small second table).  All ones = empty.
 #define SG_IP_EMPTY   (~0ull)
 #define SG_IP_LDS_MAX 4096      // entries (32 KiB): tables up to this size are staged in LDS by K1
 
@@ -51,7 +53,7 @@ enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, 
 // Everything the kernels need, passed by value as one kernel argument.
 struct Dev {
     // ---- persistent across windows ----
-    const u64* iptab;  u32 ipmask;             // main join table (open addressing)
+    const u64* iptab;  u32 ipmask;             // main join table: ipmask + 1 entries = (ipmask + 1) / 2 buckets
     const u64* iptab2; u32 ipmask2;            // pod ids of IPs that are in both maps
     const uint8_t* kind;            // [max_known] SG_NODE_POD / SG_NODE_SERVICE
     u32 max_known, max_labels, max_obip;
@@ -73,9 +75,8 @@ struct Dev {
     u32 pcap;                                 // edge capacity per partition
     u64*   acc_src;                           // accumulators by slot: eacc (variant 1) or partition output (variant 0)
     u32*   longrows;                          // [ncap] rows with more than 64 edges (work list of the row sort)
-    u64*   in_part;  u32 in_groups;           // [in_groups][ncap][6] per-workgroup partial in-statistics (dense mode)
-    u32 in_dense;                             // 1: node-indexed LDS accumulation (ncap small enough), 0: hashed + atomics
-    u32 in_fused;                             // 1: k3_node_features reduces the partials itself (unsharded)
+    u32*   e_rank;                            // [np*pcap] position of the edge inside its row (arrival order)
+    u32 in_dense;                             // 1: node-indexed LDS accumulation (ncap small enough), 0: hashed
     u32 ablate;                               // tuning switches (SG_ABLATE), 0 in production
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs

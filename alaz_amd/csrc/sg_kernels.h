@@ -16,16 +16,21 @@ __device__ __forceinline__ u32 hash_key64(u64 k) { return sg_fmix32((u32)k ^ sg_
 __host__ __device__ __forceinline__ u32 owner_hash_ref(u32 ref) { return sg_fmix32(ref); }
 __host__ __device__ __forceinline__ u32 owner_hash_obip(u32 ip) { return sg_fmix32(ip ^ 0xA5A5F00Du); }
 
+__host__ __device__ __forceinline__ u32 ip_h1(u32 ip, u32 bmask) { return sg_fmix32(ip) & bmask; }
+__host__ __device__ __forceinline__ u32 ip_h2(u32 ip, u32 bmask) { return sg_fmix32(ip ^ 0x7F4A7C15u) & bmask; }
+
+// two independent bucket reads; t may point to LDS (staged copy) or to global memory
 __device__ __forceinline__ u64 ip_probe(const u64* t, u32 mask, u32 ip) {
-    u32 h = sg_fmix32(ip) & mask;
-    for (u32 p = 0; p <= mask; ++p) {
-        const u64 e = t[h];
-        if (e == SG_IP_EMPTY || (u32)e == ip) return e;
-        h = (h + 1) & mask;
-    }
-    return SG_IP_EMPTY;
+    const u32 bmask = mask >> 1;
+    const ulonglong2 a = reinterpret_cast<const ulonglong2*>(t)[ip_h1(ip, bmask)];
+    const ulonglong2 b = reinterpret_cast<const ulonglong2*>(t)[ip_h2(ip, bmask)];
+    u64 e = SG_IP_EMPTY;
+    e = ((u32)a.x == ip && a.x != SG_IP_EMPTY) ? a.x : e;
+    e = ((u32)a.y == ip && a.y != SG_IP_EMPTY) ? a.y : e;
+    e = ((u32)b.x == ip && b.x != SG_IP_EMPTY) ? b.x : e;
+    e = ((u32)b.y == ip && b.y != SG_IP_EMPTY) ? b.y : e;
+    return e;
 }
-// t may point to LDS (staged copy) or global memory; t2 is always global (rare path).
 __device__ __forceinline__ bool ip_lookup(const u64* t, u32 mask, const u64* __restrict__ t2, u32 mask2, u32 ip, u32& pod, u32& svc) {
     const u64 e = ip_probe(t, mask, ip);
     if (e == SG_IP_EMPTY) return false;
@@ -333,30 +338,11 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* hkey = reinterpret_cast<u64*>(smem);                       // [K1B_HT]
     u64* hacc = hkey + K1B_HT;                                       // [K1B_HT][4]
-    u32* prefS = reinterpret_cast<u32*>(hacc + K1B_HT * 4);          // [nwg + 1]
-    u32* prefA = prefS + d.nwg + 1;                                  // [nwg + 1]
     __shared__ u32 n_drop, out_n;
-    __shared__ u32 wsum[K1B_THREADS / 64 + 1];
     const u32 p = blockIdx.x, t = threadIdx.x;
     for (u32 i = t; i < K1B_HT; i += K1B_THREADS) hkey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < K1B_HT * 4; i += K1B_THREADS) hacc[i] = 0;
     if (t == 0) { n_drop = 0; out_n = 0; }
-
-    u32 RS = 0, RA = 0;
-    for (u32 w0 = 0; w0 < d.nwg; w0 += K1B_THREADS) {
-        const u32 w = w0 + t;
-        uint4* hdr = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
-        uint4 h = make_uint4(0, 0, 0, 0);
-        if (w < d.nwg) { h = *hdr; if (h.x | h.y) *hdr = make_uint4(0, 0, 0, 0); }   // window reset of the piece
-        u32 tot;
-        const u32 es = block_excl_scan<K1B_THREADS>(h.x, wsum, &tot);
-        if (w < d.nwg) prefS[w] = RS + es;
-        RS += tot;
-        const u32 ea = block_excl_scan<K1B_THREADS>(h.y, wsum, &tot);
-        if (w < d.nwg) prefA[w] = RA + ea;
-        RA += tot;
-    }
-    if (t == 0) { prefS[d.nwg] = RS; prefA[d.nwg] = RA; }
     __syncthreads();
 
     auto add = [&](u64 key, u64 a0, u64 a1, u64 a2, u64 a3) {
@@ -370,39 +356,32 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         if (!ok) { atomicAdd(&n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
         atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
     };
-    auto piece_of = [&](const u32* pref, u32 r) {                    // largest w with pref[w] <= r
-        u32 lo = 0, hi = d.nwg;
-        while (hi - lo > 1) { const u32 m = (lo + hi) >> 1; if (pref[m] <= r) lo = m; else hi = m; }
-        return lo;
-    };
-    for (u32 r0 = t; r0 < RS; r0 += K1B_THREADS * K1B_U) {
-        uint4 x[K1B_U];
+    // one thread walks one piece: its records are contiguous (header + first singles share a line),
+    // and K1B_U records are fetched before any is merged, so the loads of a step are independent.
+    for (u32 w = t; w < d.nwg; w += K1B_THREADS) {
+        uint4* piece = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
+        const uint4 h = piece[0];
+        if (!(h.x | h.y)) continue;
+        piece[0] = make_uint4(0, 0, 0, 0);                           // window reset of the piece
+        const u32 ns = h.x < d.ss ? h.x : d.ss, na = h.y < d.sa ? h.y : d.sa;
+        for (u32 r0 = 0; r0 < ns; r0 += K1B_U) {
+            uint4 x[K1B_U];
 #pragma unroll
-        for (int u = 0; u < K1B_U; u++) {
-            const u32 r = r0 + u * K1B_THREADS;
-            if (r < RS) { const u32 w = piece_of(prefS, r); x[u] = d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1) + 1 + (r - prefS[w])]; }
-        }
+            for (int u = 0; u < K1B_U; u++) if (r0 + u < ns) x[u] = piece[1 + r0 + u];
 #pragma unroll
-        for (int u = 0; u < K1B_U; u++) {
-            if (r0 + u * K1B_THREADS < RS) {
+            for (int u = 0; u < K1B_U; u++) if (r0 + u < ns) {
                 const u64 key = (u64)x[u].x | ((u64)x[u].y << 32), dur = (u64)x[u].z | ((u64)(x[u].w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
                 add(key, 1ull | ((u64)(x[u].w >> 31) << 32), dur, dur, us * us);
             }
         }
-    }
-    for (u32 r0 = t; r0 < RA; r0 += K1B_THREADS * K1B_U) {
-        u64 y[K1B_U][5];
+        const u64* __restrict__ pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
+        for (u32 r0 = 0; r0 < na; r0 += 2) {
+            u64 y[2][5];
 #pragma unroll
-        for (int u = 0; u < K1B_U; u++) {
-            const u32 r = r0 + u * K1B_THREADS;
-            if (r < RA) {
-                const u32 w = piece_of(prefA, r);
-                const u64* __restrict__ pa = d.slab_a + (((size_t)p * d.nwg + w) * d.sa + (r - prefA[w])) * 5;
-                y[u][0] = pa[0]; y[u][1] = pa[1]; y[u][2] = pa[2]; y[u][3] = pa[3]; y[u][4] = pa[4];
-            }
+            for (int u = 0; u < 2; u++) if (r0 + u < na) { const u64* q = pa + (size_t)(r0 + u) * 5; y[u][0] = q[0]; y[u][1] = q[1]; y[u][2] = q[2]; y[u][3] = q[3]; y[u][4] = q[4]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) if (r0 + u < na) add(y[u][0], y[u][1], y[u][2], y[u][3], y[u][4]);
         }
-#pragma unroll
-        for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_THREADS < RA) add(y[u][0], y[u][1], y[u][2], y[u][3], y[u][4]);
     }
     {
         const u64 no = d.ctr[C_OVF_N] < d.ovf_cap ? d.ctr[C_OVF_N] : d.ovf_cap;
@@ -428,7 +407,7 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         d.e_from[slot] = f; d.e_to[slot] = to;
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
         o[0] = make_ulonglong2(hacc[s * 4], hacc[s * 4 + 1]); o[1] = make_ulonglong2(hacc[s * 4 + 2], hacc[s * 4 + 3]);
-        atomicAdd(&d.deg[f], 1u);
+        d.e_rank[slot] = atomicAdd(&d.deg[f], 1u);                  // arrival order inside the row: the scatter position
     }
     __syncthreads();
     if (t == 0) {
@@ -630,8 +609,7 @@ __global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
     const u32 p = blockIdx.x, n = d.part_n[p];
     for (u32 i = threadIdx.x; i < n; i += 256) {
         const u32 slot = p * d.pcap + i;
-        const u32 f = d.e_from[slot];
-        const u32 pos = d.rowptr[f] + atomicAdd(&d.cursor[f], 1u);
+        const u64 pos = (u64)d.rowptr[d.e_from[slot]] + d.e_rank[slot];
         if (pos < d.max_edges) { d.col[pos] = d.e_to[slot]; d.cslot[pos] = slot; }
     }
 }
@@ -672,7 +650,7 @@ __device__ __forceinline__ void edge_emit(const Dev& d, u32 pos, u32 row, u32 sl
 }
 
 #define K2_SORT_LDS 4096
-#define K2_LONG_WGS 160
+#define K2_LONG_WGS 256
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
@@ -785,23 +763,29 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 }
 
 // ---- in-statistics: per destination node, reduce over its in-edges --------------------------------
-// Dense mode (ncap <= K3_IN_NODES): each workgroup accumulates a contiguous range of CSR positions
-// into node-indexed LDS arrays (LDS atomics only) and writes its partial [ncap][6] with plain
-// stores; the partials are summed by k3_in_reduce / k3_node_features.  No device-scope atomics,
-// so popular services (thousands of in-edges) cost nothing extra.
-// Hashed mode (large graphs): LDS hash per workgroup, then device-scope atomics per distinct node.
+// A handful of workgroups each accumulate a contiguous range of CSR positions in LDS (node-indexed
+// arrays when ncap <= K3_IN_NODES, else a hash table refilled per round) with LDS atomics, then
+// flush the touched nodes with device-scope atomics: a popular service with thousands of in-edges
+// receives one atomic per word per workgroup instead of one per edge.
 #define K3_IN_NODES 2560
 #define K3_IN_HT    2048
-__global__ __launch_bounds__(256) void k3_in_stats(Dev d) {
+#define K3_IN_WGS   8
+__device__ __forceinline__ void in_flush(const Dev& d, u32 to, const u64* o) {
+    u64* gsum = d.st_sum + (size_t)to * SG_NODE_STAT_SUM_WORDS;
+    atomicAdd(&gsum[ST_IN_DEG], o[0]); atomicAdd(&gsum[ST_IN_CNT], o[1]); atomicAdd(&gsum[ST_IN_ERR], o[2]);
+    atomicAdd(&gsum[ST_IN_SUM], o[3]); atomicAdd(&gsum[ST_IN_SSQ], o[4]);
+    atomicMax(&d.st_max[(size_t)to * 2 + 1], o[5]);
+}
+__global__ __launch_bounds__(1024) void k3_in_stats(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 E = (u32)d.ctr[C_N_EDGES], N = (u32)d.ctr[C_N_NODES];
     const u32 G = gridDim.x, g = blockIdx.x, t = threadIdx.x;
     const u32 per = (E + G - 1) / G, p0 = g * per < E ? g * per : E, p1 = p0 + per < E ? p0 + per : E;
     if (d.in_dense) {
         u64* acc = reinterpret_cast<u64*>(smem);                     // [N][6]: deg, cnt, err, sum, ssq, max
-        for (u32 i = t; i < N * 6; i += 256) acc[i] = 0;
+        for (u32 i = t; i < N * 6; i += 1024) acc[i] = 0;
         __syncthreads();
-        for (u32 p = p0 + t; p < p1; p += 256) {
+        for (u32 p = p0 + t; p < p1; p += 1024) {
             const u32 to = d.col[p];
             const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
             const ulonglong2 x = a[0], y = a[1];
@@ -810,17 +794,16 @@ __global__ __launch_bounds__(256) void k3_in_stats(Dev d) {
             atomicAdd(&o[3], x.y); atomicAdd(&o[4], y.y); atomicMax(&o[5], y.x);
         }
         __syncthreads();
-        u64* out = d.in_part + (size_t)g * d.ncap * 6;
-        for (u32 i = t; i < N * 6; i += 256) out[i] = acc[i];
+        for (u32 v = t; v < N; v += 1024) if (acc[(size_t)v * 6]) in_flush(d, v, acc + (size_t)v * 6);
     } else {
         u64* tacc = reinterpret_cast<u64*>(smem);                    // [K3_IN_HT][6]
         u32* tkey = reinterpret_cast<u32*>(tacc + K3_IN_HT * 6);     // [K3_IN_HT]
         for (u32 c0 = p0; c0 < p1; c0 += K3_IN_HT / 2) {             // at most HT/2 edges (=> distinct nodes) per round
-            for (u32 i = t; i < K3_IN_HT; i += 256) tkey[i] = SG_NONE;
-            for (u32 i = t; i < K3_IN_HT * 6; i += 256) tacc[i] = 0;
+            for (u32 i = t; i < K3_IN_HT; i += 1024) tkey[i] = SG_NONE;
+            for (u32 i = t; i < K3_IN_HT * 6; i += 1024) tacc[i] = 0;
             __syncthreads();
             const u32 c1 = c0 + K3_IN_HT / 2 < p1 ? c0 + K3_IN_HT / 2 : p1;
-            for (u32 p = c0 + t; p < c1; p += 256) {
+            for (u32 p = c0 + t; p < c1; p += 1024) {
                 const u32 to = d.col[p];
                 const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
                 const ulonglong2 x = a[0], y = a[1];
@@ -836,33 +819,9 @@ __global__ __launch_bounds__(256) void k3_in_stats(Dev d) {
                 atomicAdd(&o[3], x.y); atomicAdd(&o[4], y.y); atomicMax(&o[5], y.x);
             }
             __syncthreads();
-            for (u32 s = t; s < K3_IN_HT; s += 256) {
-                const u32 to = tkey[s];
-                if (to == SG_NONE) continue;
-                u64* gsum = d.st_sum + (size_t)to * SG_NODE_STAT_SUM_WORDS; const u64* o = tacc + (size_t)s * 6;
-                atomicAdd(&gsum[ST_IN_DEG], o[0]); atomicAdd(&gsum[ST_IN_CNT], o[1]); atomicAdd(&gsum[ST_IN_ERR], o[2]);
-                atomicAdd(&gsum[ST_IN_SUM], o[3]); atomicAdd(&gsum[ST_IN_SSQ], o[4]);
-                atomicMax(&d.st_max[(size_t)to * 2 + 1], o[5]);
-            }
+            for (u32 s = t; s < K3_IN_HT; s += 1024) if (tkey[s] != SG_NONE) in_flush(d, tkey[s], tacc + (size_t)s * 6);
             __syncthreads();
         }
-    }
-}
-
-// dense mode, sharded driver: sum the partials into st_sum / st_max before the statistics exchange.
-__global__ __launch_bounds__(256) void k3_in_reduce(Dev d) {
-    const u32 N = (u32)d.ctr[C_N_NODES];
-    for (u32 v = blockIdx.x * 256 + threadIdx.x; v < N; v += gridDim.x * 256) {
-        u64 a[6] = {0, 0, 0, 0, 0, 0};
-        for (u32 g = 0; g < d.in_groups; g++) {
-            const u64* o = d.in_part + ((size_t)g * d.ncap + v) * 6;
-#pragma unroll
-            for (int k = 0; k < 5; k++) a[k] += o[k];
-            a[5] = o[5] > a[5] ? o[5] : a[5];
-        }
-        u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
-        s[ST_IN_DEG] = a[0]; s[ST_IN_CNT] = a[1]; s[ST_IN_ERR] = a[2]; s[ST_IN_SUM] = a[3]; s[ST_IN_SSQ] = a[4];
-        d.st_max[(size_t)v * 2 + 1] = a[5];
     }
 }
 
@@ -872,18 +831,7 @@ __global__ __launch_bounds__(256) void k3_in_reduce(Dev d) {
 __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN];
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < N; v += gridDim.x * 256) {
-        u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS; u64* mx = d.st_max + (size_t)v * 2;
-        if (d.in_dense && d.in_fused) {
-            u64 a[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll 8
-            for (u32 g = 0; g < d.in_groups; g++) {
-                const ulonglong2* o = reinterpret_cast<const ulonglong2*>(d.in_part + ((size_t)g * d.ncap + v) * 6);
-                const ulonglong2 p0 = o[0], p1 = o[1], p2 = o[2];
-                a[0] += p0.x; a[1] += p0.y; a[2] += p1.x; a[3] += p1.y; a[4] += p2.x;
-                a[5] = p2.y > a[5] ? p2.y : a[5];
-            }
-            s[ST_IN_DEG] = a[0]; s[ST_IN_CNT] = a[1]; s[ST_IN_ERR] = a[2]; s[ST_IN_SUM] = a[3]; s[ST_IN_SSQ] = a[4]; mx[1] = a[5];
-        }
+        const u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS; const u64* mx = d.st_max + (size_t)v * 2;
         const u32 kind = v < nk ? d.kind[v] : 0u;
         const u64 oc = s[ST_OUT_CNT], ic = s[ST_IN_CNT];
         float x[SG_F_IN];
