@@ -247,31 +247,38 @@ int do_features(sg_engine* e, hipStream_t s) {
     return SG_OK;
 }
 
-int do_layer(sg_engine* e, u32 l, hipStream_t s) {
+// fuse_proj: the last layer also writes the score head's P and Q (unsharded pipelines only)
+int do_layer(sg_engine* e, u32 l, hipStream_t s, bool fuse_proj) {
     const Dev& d = e->d;
     if (!e->have_w) { e->err = "sg_load_weights not called"; return SG_ESTATE; }
     const float* Wl = e->d_W + layer_offset(l);
+    const float* Wh = e->d_W + layer_offset(e->cfg.layers);
     const int grid = grid_for(d.ncap, 16);
+    const bool pj = fuse_proj && l + 1 == e->cfg.layers && d.world == 1;
     Timed t(e, s, 4);
+#define K4_LAUNCH(FI, MF, PJ, HIN, HOUT) hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ>), dim3(grid), dim3(1024), 0, s, d, HIN, HOUT, Wl, Wh)
     if (l == 0) {
-        if (e->use_mfma) hipLaunchKernelGGL((k4_sage_layer<32, true>), dim3(grid), dim3(256), 0, s, d, d.x0, d.h[1], Wl);
-        else hipLaunchKernelGGL((k4_sage_layer<32, false>), dim3(grid), dim3(256), 0, s, d, d.x0, d.h[1], Wl);
+        if (e->use_mfma) { if (pj) K4_LAUNCH(32, true, true, d.x0, d.h[1]); else K4_LAUNCH(32, true, false, d.x0, d.h[1]); }
+        else { if (pj) K4_LAUNCH(32, false, true, d.x0, d.h[1]); else K4_LAUNCH(32, false, false, d.x0, d.h[1]); }
     } else {
-        if (e->use_mfma) hipLaunchKernelGGL((k4_sage_layer<64, true>), dim3(grid), dim3(256), 0, s, d, d.h[l], d.h[l + 1], Wl);
-        else hipLaunchKernelGGL((k4_sage_layer<64, false>), dim3(grid), dim3(256), 0, s, d, d.h[l], d.h[l + 1], Wl);
+        if (e->use_mfma) { if (pj) K4_LAUNCH(64, true, true, d.h[l], d.h[l + 1]); else K4_LAUNCH(64, true, false, d.h[l], d.h[l + 1]); }
+        else { if (pj) K4_LAUNCH(64, false, true, d.h[l], d.h[l + 1]); else K4_LAUNCH(64, false, false, d.h[l], d.h[l + 1]); }
     }
+#undef K4_LAUNCH
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
 
-int do_score(sg_engine* e, hipStream_t s) {
+int do_score(sg_engine* e, hipStream_t s, bool proj_done) {
     const Dev& d = e->d;
     if (!e->have_w) { e->err = "sg_load_weights not called"; return SG_ESTATE; }
     const float* Wh = e->d_W + layer_offset(e->cfg.layers);
     Timed t(e, s, 5);
-    if (e->use_mfma) hipLaunchKernelGGL((k5_node_proj<true>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
-    else hipLaunchKernelGGL((k5_node_proj<false>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
-    hipLaunchKernelGGL(k5_edge_score, dim3(grid_for(e->cfg.max_edges, 4)), dim3(256), 0, s, d, Wh);
+    if (!(proj_done && d.world == 1)) {
+        if (e->use_mfma) hipLaunchKernelGGL((k5_node_proj<true>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
+        else hipLaunchKernelGGL((k5_node_proj<false>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
+    }
+    hipLaunchKernelGGL(k5_edge_score, dim3(grid_for(e->cfg.max_edges, 16)), dim3(256), 0, s, d, Wh);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
@@ -573,13 +580,13 @@ int sg_window_layer(sg_handle e, uint32_t l, void* stream) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (!e->closed || l >= e->cfg.layers) { e->err = "sg_window_layer: bad phase or layer"; return SG_ESTATE; }
-    return do_layer(e, l, pick(e, stream));
+    return do_layer(e, l, pick(e, stream), false);
 }
 int sg_window_score(sg_handle e, void* stream) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (!e->closed) { e->err = "sg_window_score before sg_window_close"; return SG_ESTATE; }
-    return do_score(e, pick(e, stream));
+    return do_score(e, pick(e, stream), false);
 }
 int sg_window_read(sg_handle e, sg_edge_out* out, size_t cap, size_t* n) {
     if (!e) return SG_EINVAL;
@@ -601,8 +608,8 @@ int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_
     int rc;
     if ((rc = do_close(e, s, nullptr, nullptr))) return rc;
     if ((rc = do_features(e, s))) return rc;
-    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s))) return rc;
-    if ((rc = do_score(e, s))) return rc;
+    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
+    if ((rc = do_score(e, s, true))) return rc;
     if ((rc = do_read(e, out, cap, n))) return rc;
     return do_reset(e, s);
 }
@@ -615,8 +622,8 @@ int sg_window_run(sg_handle e, void* stream) {
     int rc;
     if ((rc = do_close(e, s, nullptr, nullptr))) return rc;
     if ((rc = do_features(e, s))) return rc;
-    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s))) return rc;
-    if ((rc = do_score(e, s))) return rc;
+    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
+    if ((rc = do_score(e, s, true))) return rc;
     return do_reset(e, s);
 }
 

@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
 #define K1A_THREADS 1024
 #define K1A_CT      2048      // LDS cache slots per workgroup
 #define K1B_HT      1024
-#define K1B_THREADS 256
+#define K1B_THREADS 1024
+#define K1B_LPP     4        // lanes per piece
 #define K1B_U       4
 
 __device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return (hash_key64(key) >> 11) & (d.np - 1); }
@@ -275,6 +276,12 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     u32* fA = fS + d.np;                                             // [np]
     u64* ipl = reinterpret_cast<u64*>(fA + d.np);                    // [ipmask + 1] when IPLDS
     const u32 w = blockIdx.x, t = threadIdx.x;
+    const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
+    const u64 per = (n + d.nwg - 1) / d.nwg;
+    const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
+    u64 i = beg + t;
+    uint4 a, b;
+    if (i < end) { a = pe[2 * i]; b = pe[2 * i + 1]; }               // first events in flight during the LDS set-up
     for (u32 i = t; i < K1A_CT; i += K1A_THREADS) ckey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < K1A_CT * 4; i += K1A_THREADS) cacc[i] = 0;
     for (u32 p = t; p < d.np; p += K1A_THREADS) { const uint4 h = d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)]; fS[p] = h.x; fA[p] = h.y; }
@@ -283,12 +290,6 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     __syncthreads();
 
     K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
-    const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
-    const u64 per = (n + d.nwg - 1) / d.nwg;
-    const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
-    u64 i = beg + t;
-    uint4 a, b;
-    if (i < end) { a = pe[2 * i]; b = pe[2 * i + 1]; }
     while (i < end) {
         const uint4 ca = a, cb = b;
         const u64 nx = i + K1A_THREADS;
@@ -356,33 +357,35 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         if (!ok) { atomicAdd(&n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
         atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
     };
-    // one thread walks one piece: its records are contiguous (header + first singles share a line),
-    // and K1B_U records are fetched before any is merged, so the loads of a step are independent.
-    for (u32 w = t; w < d.nwg; w += K1B_THREADS) {
+    // K1B_LPP lanes walk one piece (record r belongs to lane r % K1B_LPP); each lane fetches up to
+    // K1B_U records before merging any, so a piece of <= 16 singles costs one round of loads.
+    for (u32 w = t / K1B_LPP; w < d.nwg; w += K1B_THREADS / K1B_LPP) {
+        const u32 sub = t % K1B_LPP;
         uint4* piece = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
         const uint4 h = piece[0];
         if (!(h.x | h.y)) continue;
-        piece[0] = make_uint4(0, 0, 0, 0);                           // window reset of the piece
         const u32 ns = h.x < d.ss ? h.x : d.ss, na = h.y < d.sa ? h.y : d.sa;
-        for (u32 r0 = 0; r0 < ns; r0 += K1B_U) {
+        for (u32 r0 = sub; r0 < ns; r0 += K1B_LPP * K1B_U) {
             uint4 x[K1B_U];
 #pragma unroll
-            for (int u = 0; u < K1B_U; u++) if (r0 + u < ns) x[u] = piece[1 + r0 + u];
+            for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) x[u] = piece[1 + r0 + u * K1B_LPP];
 #pragma unroll
-            for (int u = 0; u < K1B_U; u++) if (r0 + u < ns) {
+            for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) {
                 const u64 key = (u64)x[u].x | ((u64)x[u].y << 32), dur = (u64)x[u].z | ((u64)(x[u].w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
                 add(key, 1ull | ((u64)(x[u].w >> 31) << 32), dur, dur, us * us);
             }
         }
         const u64* __restrict__ pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
-        for (u32 r0 = 0; r0 < na; r0 += 2) {
+        for (u32 r0 = sub; r0 < na; r0 += K1B_LPP * 2) {
             u64 y[2][5];
 #pragma unroll
-            for (int u = 0; u < 2; u++) if (r0 + u < na) { const u64* q = pa + (size_t)(r0 + u) * 5; y[u][0] = q[0]; y[u][1] = q[1]; y[u][2] = q[2]; y[u][3] = q[3]; y[u][4] = q[4]; }
+            for (int u = 0; u < 2; u++) if (r0 + u * K1B_LPP < na) { const u64* q = pa + (size_t)(r0 + u * K1B_LPP) * 5; y[u][0] = q[0]; y[u][1] = q[1]; y[u][2] = q[2]; y[u][3] = q[3]; y[u][4] = q[4]; }
 #pragma unroll
-            for (int u = 0; u < 2; u++) if (r0 + u < na) add(y[u][0], y[u][1], y[u][2], y[u][3], y[u][4]);
+            for (int u = 0; u < 2; u++) if (r0 + u * K1B_LPP < na) add(y[u][0], y[u][1], y[u][2], y[u][3], y[u][4]);
         }
     }
+    __syncthreads();
+    for (u32 w = t; w < d.nwg; w += K1B_THREADS) d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)] = make_uint4(0, 0, 0, 0);   // window reset of the pieces
     {
         const u64 no = d.ctr[C_OVF_N] < d.ovf_cap ? d.ctr[C_OVF_N] : d.ovf_cap;
         for (u64 i = t; i < no; i += K1B_THREADS) {
@@ -964,27 +967,24 @@ __device__ __forceinline__ void gather_mean(const Dev& d, const float* __restric
     }
 }
 
-template <int FI, bool USE_MFMA>
-__global__ __launch_bounds__(256) void k4_sage_layer(Dev d, const float* __restrict__ hin, float* __restrict__ hout, const float* __restrict__ Wl) {
+// 16-node tiles, 1024 threads: in the gather phase every wave owns one node of the tile (the rows
+// follow a power law, so per-node parallelism is what bounds this kernel); the dense phase runs on
+// the first 4 waves.  With PROJ the tile's fresh h rows are immediately projected to the score
+// head's P = b1 + h Wu and Q = h Wv (last layer, unsharded), saving a launch.
+template <int FI, bool USE_MFMA, bool PROJ>
+__global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __restrict__ hin, float* __restrict__ hout, const float* __restrict__ Wl, const float* __restrict__ Wh) {
     constexpr int LDA = 2 * FI + 2;                               // +2 floats: conflict-free A-fragment reads
+    constexpr int LDH = SG_F_HID + 2;
     __shared__ float A[16 * LDA];
+    __shared__ float H[PROJ ? 16 * LDH : 1];
+    __shared__ u32 skip[16];
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* __restrict__ bias = Wl + 2 * FI * SG_F_HID;
     for (u32 tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
         const u32 v0 = tile * 16;
-        __shared__ u32 skip[16];
-        __shared__ u32 next_row;
-        if (threadIdx.x == 0) next_row = 0;
-        __syncthreads();
-        // phase 1: self row + gather-mean; the 4 waves pull the tile's 16 nodes from a shared counter
-        // (row lengths follow a power law: static assignment leaves one wave with all the hubs)
-        for (;;) {
-            u32 r = 0;
-            if (lane == 0) r = atomicAdd(&next_row, 1u);
-            r = __shfl(r, 0, 64);
-            if (r >= 16) break;
-            const u32 v = v0 + r;
+        {   // phase 1: self row + gather-mean, wave w <-> node v0 + w
+            const u32 r = wave, v = v0 + r;
             float* row = A + r * LDA;
             bool sk = v >= N;
             if (!sk && d.world > 1) {
@@ -992,35 +992,77 @@ __global__ __launch_bounds__(256) void k4_sage_layer(Dev d, const float* __restr
                 sk = has_out && owner_of_dense(d, v, nk, nl) != d.rank;   // computed by its owner, arrives by halo exchange
             }
             if (lane == 0) skip[r] = sk ? 1u : 0u;
-            if (sk) { for (u32 k = lane; k < 2 * FI; k += 64) row[k] = 0.0f; continue; }
-            for (u32 k = lane; k < FI; k += 64) row[k] = hin[(size_t)v * FI + k];
-            gather_mean<FI>(d, hin, v, row + FI);
+            if (sk) { for (u32 k = lane; k < 2 * FI; k += 64) row[k] = 0.0f; }
+            else {
+                for (u32 k = lane; k < FI; k += 64) row[k] = hin[(size_t)v * FI + k];
+                gather_mean<FI>(d, hin, v, row + FI);
+            }
         }
         __syncthreads();
-        // phase 2: dense 16 x 64, wave w -> columns 16w..16w+15
-        if (USE_MFMA) {
-            const int jb = wave * 16, i = lane & 15;
-            const float bj = bias[jb + i];
-            f32x4 c = { bj, bj, bj, bj };
-            c = dense_tile_mfma<2 * FI>(A, LDA, Wl, jb, c);
+        // phase 2: dense 16 x 64 on waves 0..3, wave w -> columns 16w..16w+15
+        if (wave < 4) {
+            if (USE_MFMA) {
+                const int jb = wave * 16, i = lane & 15;
+                const float bj = bias[jb + i];
+                f32x4 c = { bj, bj, bj, bj };
+                c = dense_tile_mfma<2 * FI>(A, LDA, Wl, jb, c);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const u32 row = (lane >> 4) * 4 + r;
-                if (!skip[row]) hout[(size_t)(v0 + row) * SG_F_HID + jb + i] = c[r] > 0.0f ? c[r] : 0.0f;
+                for (int r = 0; r < 4; r++) {
+                    const u32 row = (lane >> 4) * 4 + r;
+                    const float hv = c[r] > 0.0f ? c[r] : 0.0f;
+                    if (!skip[row]) hout[(size_t)(v0 + row) * SG_F_HID + jb + i] = hv;
+                    if (PROJ) H[row * LDH + jb + i] = hv;
+                }
+            } else {
+                const u32 row = (threadIdx.x & 255) >> 4, jq = (threadIdx.x & 15) * 4;
+                float acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c] = bias[jq + c];
+                for (int k = 0; k < 2 * FI; k++) {
+                    const float a = A[row * LDA + k];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[c] = fmaf(a, Wl[(size_t)k * SG_F_HID + jq + c], acc[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float hv = acc[c] > 0.0f ? acc[c] : 0.0f;
+                    if (!skip[row]) hout[(size_t)(v0 + row) * SG_F_HID + jq + c] = hv;
+                    if (PROJ) H[row * LDH + jq + c] = hv;
+                }
             }
-        } else {
-            const u32 row = threadIdx.x >> 4, jq = (threadIdx.x & 15) * 4;
-            float acc[4];
+        }
+        if (PROJ) {
+            __syncthreads();
+            // waves 0..3 -> P columns, waves 4..7 -> Q columns
+            const float* __restrict__ Wu = Wh; const float* __restrict__ Wv = Wh + SG_F_HID * SG_F_HID;
+            const float* __restrict__ b1 = Wv + SG_F_HID * SG_F_HID + SG_F_EDGE * SG_F_HID;
+            if (wave < 8) {
+                const bool isq = wave >= 4;
+                const int jb = (wave & 3) * 16, i = lane & 15;
+                float* dst = isq ? d.Q : d.P;
+                const float* __restrict__ Wm = isq ? Wv : Wu;
+                if (USE_MFMA) {
+                    const float bj = isq ? 0.0f : b1[jb + i];
+                    f32x4 c = { bj, bj, bj, bj };
+                    c = dense_tile_mfma<SG_F_HID>(H, LDH, Wm, jb, c);
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[c] = bias[jq + c];
-            for (int k = 0; k < 2 * FI; k++) {
-                const float a = A[row * LDA + k];
+                    for (int r = 0; r < 4; r++) { const u32 row = (lane >> 4) * 4 + r; if (v0 + row < N) dst[(size_t)(v0 + row) * SG_F_HID + jb + i] = c[r]; }
+                } else {
+                    // VALU twin: lane -> (row = lane >> 2, 4 columns)
+                    const u32 row = lane >> 2, jq = jb + (lane & 3) * 4;
+                    float acc[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) acc[c] = fmaf(a, Wl[(size_t)k * SG_F_HID + jq + c], acc[c]);
+                    for (int c = 0; c < 4; c++) acc[c] = isq ? 0.0f : b1[jq + c];
+                    for (int k = 0; k < (int)SG_F_HID; k++) {
+                        const float a = H[row * LDH + k];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[c] = fmaf(a, Wm[(size_t)k * SG_F_HID + jq + c], acc[c]);
+                    }
+                    if (v0 + row < N)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) dst[(size_t)(v0 + row) * SG_F_HID + jq + c] = acc[c];
+                }
             }
-            if (!skip[row])
-#pragma unroll
-                for (int c = 0; c < 4; c++) hout[(size_t)(v0 + row) * SG_F_HID + jq + c] = acc[c] > 0.0f ? acc[c] : 0.0f;
         }
         __syncthreads();
     }
