@@ -361,27 +361,32 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     // K1B_U records before merging any, so a piece of <= 16 singles costs one round of loads.
     for (u32 w = t / K1B_LPP; w < d.nwg; w += K1B_THREADS / K1B_LPP) {
         const u32 sub = t % K1B_LPP;
-        uint4* piece = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
+        const uint4* piece = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
+        const u64* __restrict__ pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
+        // header, the lane's first K1B_U singles and its first aggregate are fetched together (the
+        // slab memory is always mapped, stale contents are ignored): one round of latency for a
+        // typical piece instead of three dependent ones.
         const uint4 h = piece[0];
+        uint4 x[K1B_U]; u64 y[5];
+#pragma unroll
+        for (int u = 0; u < K1B_U; u++) x[u] = piece[1 + ((sub + u * K1B_LPP) < d.ss ? (sub + u * K1B_LPP) : 0)];
+        { const u64* q = pa + (size_t)sub * 5; y[0] = q[0]; y[1] = q[1]; y[2] = q[2]; y[3] = q[3]; y[4] = q[4]; }
         if (!(h.x | h.y)) continue;
         const u32 ns = h.x < d.ss ? h.x : d.ss, na = h.y < d.sa ? h.y : d.sa;
         for (u32 r0 = sub; r0 < ns; r0 += K1B_LPP * K1B_U) {
-            uint4 x[K1B_U];
+            if (r0 != sub) {
 #pragma unroll
-            for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) x[u] = piece[1 + r0 + u * K1B_LPP];
+                for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) x[u] = piece[1 + r0 + u * K1B_LPP];
+            }
 #pragma unroll
             for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) {
                 const u64 key = (u64)x[u].x | ((u64)x[u].y << 32), dur = (u64)x[u].z | ((u64)(x[u].w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
                 add(key, 1ull | ((u64)(x[u].w >> 31) << 32), dur, dur, us * us);
             }
         }
-        const u64* __restrict__ pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
-        for (u32 r0 = sub; r0 < na; r0 += K1B_LPP * 2) {
-            u64 y[2][5];
-#pragma unroll
-            for (int u = 0; u < 2; u++) if (r0 + u * K1B_LPP < na) { const u64* q = pa + (size_t)(r0 + u * K1B_LPP) * 5; y[u][0] = q[0]; y[u][1] = q[1]; y[u][2] = q[2]; y[u][3] = q[3]; y[u][4] = q[4]; }
-#pragma unroll
-            for (int u = 0; u < 2; u++) if (r0 + u * K1B_LPP < na) add(y[u][0], y[u][1], y[u][2], y[u][3], y[u][4]);
+        for (u32 r0 = sub; r0 < na; r0 += K1B_LPP) {
+            if (r0 != sub) { const u64* q = pa + (size_t)r0 * 5; y[0] = q[0]; y[1] = q[1]; y[2] = q[2]; y[3] = q[3]; y[4] = q[4]; }
+            add(y[0], y[1], y[2], y[3], y[4]);
         }
     }
     __syncthreads();
