@@ -421,7 +421,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     e->k3in_lds = d.in_dense ? (size_t)d.ncap * 48 : (size_t)K3_IN_HT * 52;
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
-    CR(dev_alloc(e, &d.deg, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.rowptr, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.cursor, (size_t)d.ncap + 1));
+    CR(dev_alloc(e, &d.deg, ((size_t)d.ncap + 1) * SG_DEG_STRIDE)); CR(dev_alloc(e, &d.rowptr, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.cursor, (size_t)d.ncap + 1));
     CR(dev_alloc(e, &d.col, ME)); CR(dev_alloc(e, &d.cslot, ME)); CR(dev_alloc(e, &d.csr_from, ME));
     CR(dev_alloc(e, &d.sort_k, 2 * ME)); CR(dev_alloc(e, &d.sort_v, 2 * ME));
     CR(dev_alloc(e, &d.acc_csr, ME * 4));

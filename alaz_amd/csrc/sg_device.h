@@ -49,6 +49,9 @@ enum { WS_TMIN = 0, WS_TMAX, WS_MAXLABEL, WS_DROPPED_SRC, WS_DROPPED_CAP, WS_MIS
 enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, ST_OUT_SUM, ST_IN_SUM, ST_OUT_SSQ, ST_IN_SSQ };
 
 #define SG_MEAN_SLOTS 16
+// One out-degree counter per 32-byte sector: device-scope atomics serialise per sector (~12 ns each,
+// profiles/r01_atomic_probe.txt), so neighbouring nodes must not share one.
+#define SG_DEG_STRIDE 8
 
 // Everything the kernels need, passed by value as one kernel argument.
 struct Dev {

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         d.e_from[slot] = f; d.e_to[slot] = to;
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
         o[0] = make_ulonglong2(hacc[s * 4], hacc[s * 4 + 1]); o[1] = make_ulonglong2(hacc[s * 4 + 2], hacc[s * 4 + 3]);
-        d.e_rank[slot] = atomicAdd(&d.deg[f], 1u);                  // arrival order inside the row: the scatter position
+        d.e_rank[slot] = atomicAdd(&d.deg[(size_t)f * SG_DEG_STRIDE], 1u);                  // arrival order inside the row: the scatter position
     }
     __syncthreads();
     if (t == 0) {
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
         if (pos < d.max_edges) {
             const u32 f = dense_of(d, (u32)(k[j] >> 32), nk, nl, nob), t = dense_of(d, (u32)k[j], nk, nl, nob);
             d.e_slot[pos] = base_slot + j; d.e_from[pos] = f; d.e_to[pos] = t;
-            atomicAdd(&d.deg[f], 1u);
+            atomicAdd(&d.deg[(size_t)f * SG_DEG_STRIDE], 1u);
         }
         pos++;
     }
@@ -587,11 +587,11 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d) {
     const u32 per = (N + 1023) / 1024;
     const u32 beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
     u32 c = 0;
-    for (u32 i = beg; i < end; i++) c += d.deg[i];
+    for (u32 i = beg; i < end; i++) c += d.deg[(size_t)i * SG_DEG_STRIDE];
     u32 total;
     u32 run = block_excl_scan<1024>(c, wsum, &total);
     for (u32 i = beg; i < end; i++) {
-        const u32 dg = d.deg[i];
+        const u32 dg = d.deg[(size_t)i * SG_DEG_STRIDE];
         d.rowptr[i] = run; run += dg;
         if (dg > 64) d.longrows[atomicAdd(&nlong, 1u)] = i;
     }
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
 __global__ __launch_bounds__(256) void k_reset_window(Dev d) {
     const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
     const u64 nc = (u64)d.ncap + 1;
-    for (u64 i = tid; i < nc; i += nt) { d.deg[i] = 0; d.cursor[i] = 0; }
+    for (u64 i = tid; i < nc; i += nt) { d.deg[i * SG_DEG_STRIDE] = 0; d.cursor[i] = 0; }
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
     for (u64 i = tid; i <= d.obmask; i += nt) d.obkeys[i] = 0;
