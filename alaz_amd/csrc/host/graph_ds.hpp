@@ -1,0 +1,107 @@
+// graph_ds.hpp — GraphDS: a datastore.DataStore decorator that feeds the MI355X ServiceGraph engine.
+//
+// It is what INTEGRATION.md's Go `GraphDS` is, written in C++ because no Go toolchain exists in the
+// build environment: it wraps an inner DataStore (the reference's BackendDS), forwards the eight k8s
+// resource calls unchanged, mirrors pod / service IP changes into the engine's join tables
+// (sg_upsert_* / sg_delete_*, the analogue of aggregator/persist.go:55-71,114-130), turns the per-request
+// calls into packed events (sg_ingest) and, once per window, reads back one scored row per edge
+// (sg_flush_window) and hands them to an EdgeSink.
+//
+// Two taps exist, as in SURVEY.md §8b:
+//   * PersistRequest / PersistKafkaEvent — the datastore boundary itself (the reference aggregator has
+//     already run setFromToV2; the engine repeats the join on the GPU from FromIP / ToIP);
+//   * IngestL7 — one step earlier, straight from l7_req.L7Event, so that the reference's CPU join is
+//     not needed at all (the L7Packer does the payload-dependent part on the host).
+#pragma once
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/servicegraph.h"
+#include "datastore.hpp"
+#include "l7_event.hpp"
+#include "packer.hpp"
+
+namespace alaz {
+
+// the C ABI as a table of function pointers: the real library (dlsym) in production, a recording
+// stand-in in the host-logic tests.
+struct SgApi {
+    int (*create)(const sg_config*, sg_handle*) = nullptr;
+    int (*destroy)(sg_handle) = nullptr;
+    int (*upsert_pod)(sg_handle, uint32_t, uint32_t) = nullptr;
+    int (*delete_pod)(sg_handle, uint32_t) = nullptr;
+    int (*upsert_service)(sg_handle, uint32_t, uint32_t) = nullptr;
+    int (*delete_service)(sg_handle, uint32_t) = nullptr;
+    int (*set_label_count)(sg_handle, uint32_t) = nullptr;
+    int (*ingest)(sg_handle, const sg_event*, size_t) = nullptr;
+    int (*flush_window)(sg_handle, uint64_t, sg_edge_out*, size_t, size_t*) = nullptr;
+    int (*window_outbound_ips)(sg_handle, uint32_t*, size_t, size_t*) = nullptr;
+    const char* (*last_error)(sg_handle) = nullptr;
+    static bool FromLibrary(void* dl_handle, SgApi* out);      // dlsym of every entry; false if one is missing
+};
+
+struct EdgeRow {                       // one edge of a closed window, in the reference's vocabulary
+    std::string FromType, FromUID, ToType, ToUID;
+    uint32_t Count = 0, ErrCount = 0;
+    uint64_t SumNs = 0, MaxNs = 0, SumSqUs = 0;
+    float Score = 0, LatZ = 0, ErrRatio = 0;
+};
+
+class EdgeSink {
+public:
+    virtual ~EdgeSink() = default;
+    virtual int PersistEdges(int64_t window_end_ms, const std::vector<EdgeRow>& rows) = 0;
+};
+
+bool ParseIPv4(const std::string& s, uint32_t* out);     // "a.b.c.d" -> a<<24|b<<16|c<<8|d
+std::string FormatIPv4(uint32_t ip);                      // IntToIPv4().String(), aggregator/data.go:1751-1758
+
+class GraphDS : public datastore::DataStore {
+public:
+    GraphDS(datastore::DataStore* inner, const SgApi& api, sg_handle h, EdgeSink* sink, size_t max_edges, size_t batch = 4096);
+    ~GraphDS() override;
+
+    int PersistPod(const datastore::Pod& pod, const std::string& eventType) override;
+    int PersistService(const datastore::Service& service, const std::string& eventType) override;
+    int PersistReplicaSet(const datastore::ReplicaSet& rs, const std::string& et) override { return inner_->PersistReplicaSet(rs, et); }
+    int PersistDeployment(const datastore::Deployment& d, const std::string& et) override { return inner_->PersistDeployment(d, et); }
+    int PersistEndpoints(const datastore::Endpoints& e, const std::string& et) override { return inner_->PersistEndpoints(e, et); }
+    int PersistContainer(const datastore::Container& c, const std::string& et) override { return inner_->PersistContainer(c, et); }
+    int PersistDaemonSet(const datastore::DaemonSet& ds, const std::string& et) override { return inner_->PersistDaemonSet(ds, et); }
+    int PersistStatefulSet(const datastore::StatefulSet& ss, const std::string& et) override { return inner_->PersistStatefulSet(ss, et); }
+    int PersistRequest(const datastore::Request* request) override;
+    int PersistKafkaEvent(const datastore::KafkaEvent* request) override;
+    int PersistAliveConnection(const datastore::AliveConnection* conn) override { return inner_->PersistAliveConnection(conn); }
+
+    // earlier tap: the raw L7 event (what processL7 receives, aggregator/data.go:1364-1383)
+    int IngestL7(const l7_req::L7Event& e, uint32_t kafka_msgs = 1);
+
+    // close the window: pending batch -> engine, K2..K5, rows -> sink.  Returns the number of edges or < 0.
+    long FlushWindow(int64_t window_end_ms);
+
+    uint64_t EventsOffered() const { return offered_; }
+    uint64_t BatchesDropped() const { return batches_dropped_; }
+    const std::vector<std::string>& Labels() const { return packer_.Labels(); }
+    const L7Packer& Packer() const { return packer_; }
+
+private:
+    uint32_t Intern(const std::string& uid, uint8_t kind);
+    int Append(const sg_event& ev);                    // under mu_
+    int FlushBatchLocked();
+
+    datastore::DataStore* inner_;
+    SgApi api_; sg_handle h_; EdgeSink* sink_;
+    size_t max_edges_, batch_cap_;
+    std::mutex mu_;
+    std::vector<sg_event> batch_;
+    std::unordered_map<std::string, uint32_t> ids_;    // UID -> node id, arrival order
+    std::vector<std::string> uid_of_; std::vector<uint8_t> kind_of_;
+    L7Packer packer_;
+    std::unordered_map<std::string, uint32_t> dto_labels_;   // labels seen through the PersistRequest tap share the packer's id space
+    uint64_t offered_ = 0, batches_dropped_ = 0;
+};
+
+}  // namespace alaz

@@ -1,0 +1,58 @@
+// packer.hpp — host side of the hot path: one l7_req.L7Event -> packed sg_event(s).
+//
+// Everything that needs the 1 KiB payload stays here, exactly where the reference does it:
+//   processHttpEvent   aggregator/data.go:1208-1249  (parseHttpPayload :508-531 -> Host header)
+//   processPostgres..  :1323-1362 (parsePostgresCommand :1474-1556: drop on parse error; statement cache)
+//   processMySQLEvent  :1287-1321 (parseMySQLCommand :1431-1472)
+//   processMongoEvent  :1251-1285 (parseMongoEvent :1561-1617; recover() => keep the event)
+//   processRedisEvent  :1120-1160, processAmqpEvent :1081-1118 (ReverseDirection for PUSHED_EVENT / DELIVER)
+//   processKafkaEvent  :1035-1079 (one event per decoded message; the decoder itself is out of scope)
+// The join (setFromToV2) is NOT done here: it is K1 on the GPU.  The packer only decides whether
+// an event reaches the join at all and which outbound label it would carry.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../../include/servicegraph.h"
+#include "l7_event.hpp"
+
+namespace alaz {
+
+// parseHttpPayload — aggregator/data.go:508-531 (strings.Split semantics)
+void ParseHttpPayload(const char* req, size_t len, std::string* method, std::string* path, std::string* version, std::string* host);
+// containsSQLKeywords — data.go:1624-1626 over the keyword list of :123
+bool ContainsSQLKeywords(const uint8_t* s, size_t n);
+
+class L7Packer {
+public:
+    // IPs currently present in the join tables (pods + services): the Host header is interned only
+    // when the destination is not one of them, i.e. exactly when setFromToV2 would use it (:851-854).
+    void AddKnownIP(uint32_t ip) { known_[ip]++; }
+    void RemoveKnownIP(uint32_t ip) { auto it = known_.find(ip); if (it != known_.end() && --it->second == 0) known_.erase(it); }
+    bool IsKnownIP(uint32_t ip) const { return known_.count(ip) != 0; }
+
+    // Appends 0..n packed events for `e` to `out`.  kafka_msgs = number of messages the Kafka decoder
+    // produced for this event (ignored for other protocols).  Returns the number appended.
+    size_t Pack(const l7_req::L7Event& e, uint32_t kafka_msgs, std::vector<sg_event>* out);
+
+    const std::vector<std::string>& Labels() const { return labels_; }
+    uint64_t DroppedParse() const { return dropped_parse_; }
+    uint64_t SkippedHttp2() const { return skipped_http2_; }
+
+private:
+    uint32_t InternLabel(const std::string& host);
+    int ParsePostgres(const l7_req::L7Event& e, std::string* out);
+    int ParseMySQL(const l7_req::L7Event& e, std::string* out);
+    static int ParseMongo(const l7_req::L7Event& e, std::string* out);
+
+    std::unordered_map<uint32_t, uint32_t> known_;
+    std::unordered_map<std::string, uint32_t> label_ids_;
+    std::vector<std::string> labels_;
+    std::unordered_map<std::string, std::string> pg_stmts_, mysql_stmts_;   // data.go pgStmts / mySqlStmts
+    uint64_t dropped_parse_ = 0, skipped_http2_ = 0;
+};
+
+}  // namespace alaz

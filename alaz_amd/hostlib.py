@@ -1,0 +1,181 @@
+"""ctypes binding of libsgdatastore.so — the C++ host side (DataStore mirror, L7 packer, GraphDS).
+Plumbing only; see alaz_amd/csrc/host/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .engine import LIB_PATH as ENGINE_LIB, SgConfig
+from .replay import EVENT_DTYPE, L7_WIRE_SIZE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB = os.path.join(_HERE, "lib", "libsgdatastore.so")
+
+
+class EdgeRowC(C.Structure):
+    _fields_ = [("from_type", C.c_char * 12), ("to_type", C.c_char * 12), ("from_uid", C.c_char * 160), ("to_uid", C.c_char * 160),
+                ("count", C.c_uint32), ("err_count", C.c_uint32), ("sum_ns", C.c_uint64), ("max_ns", C.c_uint64), ("sumsq_us", C.c_uint64),
+                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError(f"{HOST_LIB} is missing: build it with `python -m alaz_amd.build`")
+        lib = C.CDLL(HOST_LIB)
+        P, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+        sig = {
+            "sgh_packer_create": (P, []), "sgh_packer_destroy": (None, [P]), "sgh_packer_known_ip": (None, [P, u32, C.c_int]),
+            "sgh_packer_pack_wire": (sz, [P, P, sz, P, P, sz]), "sgh_packer_labels": (sz, [P, C.c_char_p, sz]),
+            "sgh_packer_dropped_parse": (u64, [P]),
+            "sgh_parse_http": (None, [C.c_char_p, sz, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz]),
+            "sgh_graphds_create": (P, [C.c_char_p, C.POINTER(SgConfig), sz]), "sgh_graphds_destroy": (None, [P]),
+            "sgh_graphds_persist_pod": (C.c_int, [P, C.c_char_p, C.c_char_p, C.c_char_p]),
+            "sgh_graphds_persist_service": (C.c_int, [P, C.c_char_p, C.c_char_p, C.c_char_p]),
+            "sgh_graphds_ingest_wire": (C.c_int, [P, P, sz, P]),
+            "sgh_graphds_persist_request": (C.c_int, [P, C.c_int64, u64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                                      C.c_char_p, u32, C.c_char_p, C.c_int]),
+            "sgh_graphds_flush": (C.c_long, [P, C.c_int64, C.POINTER(EdgeRowC), sz]),
+            "sgh_graphds_labels": (sz, [P, C.c_char_p, sz]), "sgh_graphds_dropped_parse": (u64, [P]), "sgh_graphds_engine": (P, [P]),
+            "sgh_mock_events": (sz, [P, P, sz]), "sgh_mock_table_ops": (sz, [P, P, sz]), "sgh_mock_label_count": (u32, [P]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(lib, name); f.restype = res; f.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _labels(fn, h) -> List[str]:
+    buf = C.create_string_buffer(1 << 16)
+    n = fn(h, buf, len(buf))
+    return buf.value.decode().split("\n") if n else []
+
+
+def parse_http(req: bytes):
+    m, p, v, h = (C.create_string_buffer(1200) for _ in range(4))
+    load().sgh_parse_http(req, len(req), m, p, v, h, 1200)
+    return tuple(x.value.decode("latin-1") for x in (m, p, v, h))
+
+
+class Packer:
+    def __init__(self):
+        self._l = load(); self._p = self._l.sgh_packer_create()
+
+    def __del__(self):
+        try:
+            self._l.sgh_packer_destroy(self._p)
+        except Exception:
+            pass
+
+    def known_ip(self, ip: int, add: bool = True): self._l.sgh_packer_known_ip(self._p, ip, int(add))
+
+    def pack_wire(self, wire: bytes, kafka_msgs: Optional[np.ndarray] = None) -> np.ndarray:
+        n = len(wire) // L7_WIRE_SIZE
+        km = None
+        if kafka_msgs is not None:
+            kafka_msgs = np.ascontiguousarray(kafka_msgs, dtype=np.uint32); km = kafka_msgs.ctypes.data
+            cap = int(kafka_msgs.sum()) + n
+        else:
+            cap = n
+        out = np.zeros(max(cap, 1), dtype=EVENT_DTYPE)
+        buf = (C.c_char * len(wire)).from_buffer_copy(wire)
+        k = self._l.sgh_packer_pack_wire(self._p, C.addressof(buf), n, km, out.ctypes.data, cap)
+        return out[:k]
+
+    @property
+    def labels(self): return _labels(self._l.sgh_packer_labels, self._p)
+    @property
+    def dropped_parse(self): return self._l.sgh_packer_dropped_parse(self._p)
+
+
+class GraphDS:
+    """C++ GraphDS over the real engine (engine_lib = path of libservicegraph.so) or over a recording
+    stand-in (engine_lib=None; host-logic tests)."""
+
+    def __init__(self, cfg: SgConfig, engine_lib: Optional[str] = ENGINE_LIB, batch: int = 4096):
+        self._l = load()
+        self._g = self._l.sgh_graphds_create(engine_lib.encode() if engine_lib else None, C.byref(cfg), batch)
+        if not self._g:
+            raise RuntimeError("GraphDS: engine could not be created (no usable gfx950 device or library missing); no CPU fallback")
+        self.max_edges = int(cfg.max_edges)
+
+    def close(self):
+        if self._g:
+            self._l.sgh_graphds_destroy(self._g); self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def PersistPod(self, uid: str, ip: str, event_type: str = "ADD"): return self._l.sgh_graphds_persist_pod(self._g, event_type.encode(), uid.encode(), ip.encode())
+    def PersistService(self, uid: str, ip: str, event_type: str = "ADD"): return self._l.sgh_graphds_persist_service(self._g, event_type.encode(), uid.encode(), ip.encode())
+
+    def apply_ops(self, ops):
+        for kind, et, uid, ip in ops:
+            (self.PersistPod if kind == "pod" else self.PersistService)(uid, ip, et)
+
+    def ingest_wire(self, wire: bytes, kafka_msgs: Optional[np.ndarray] = None) -> int:
+        n = len(wire) // L7_WIRE_SIZE
+        km = None
+        if kafka_msgs is not None:
+            kafka_msgs = np.ascontiguousarray(kafka_msgs, dtype=np.uint32); km = kafka_msgs.ctypes.data
+        buf = (C.c_char * len(wire)).from_buffer_copy(wire)
+        return self._l.sgh_graphds_ingest_wire(self._g, C.addressof(buf), n, km)
+
+    def PersistRequest(self, r: Sequence) -> int:
+        """r: the 16 ReqInfo slots (datastore/backend.go:824-839)."""
+        e = lambda s: s.encode("latin-1")
+        return self._l.sgh_graphds_persist_request(self._g, r[0], r[1], e(r[2]), e(r[3]), e(r[4]), e(r[6]), e(r[7]), e(r[8]), e(r[10]), r[11], e(r[13]), int(r[15]))
+
+    def FlushWindow(self, window_end_ms: int = 0):
+        out = (EdgeRowC * self.max_edges)()
+        n = self._l.sgh_graphds_flush(self._g, window_end_ms, out, self.max_edges)
+        if n < 0:
+            raise RuntimeError(f"FlushWindow rc={n}")
+        d = {}
+        for i in range(min(n, self.max_edges)):
+            r = out[i]
+            d[(r.from_type.decode(), r.from_uid.decode(), r.to_type.decode(), r.to_uid.decode())] = (
+                r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio)
+        return d
+
+    @property
+    def labels(self): return _labels(self._l.sgh_graphds_labels, self._g)
+    @property
+    def dropped_parse(self): return self._l.sgh_graphds_dropped_parse(self._g)
+    @property
+    def engine_handle(self): return self._l.sgh_graphds_engine(self._g)
+
+    # engine settings that are not part of the DataStore surface go straight to the C ABI
+    def set_clock(self, first_kernel_ns: int, first_user_ns: int):
+        from . import engine
+        assert engine.load_library().sg_set_clock(self.engine_handle, first_kernel_ns, first_user_ns) == 0
+
+    def load_weights(self, w: np.ndarray):
+        from . import engine
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        assert engine.load_library().sg_load_weights(self.engine_handle, w.ctypes.data, len(w)) == 0
+
+    def mock_events(self) -> np.ndarray:
+        n = self._l.sgh_mock_events(self._g, None, 0)
+        out = np.zeros(max(n, 1), dtype=EVENT_DTYPE)
+        self._l.sgh_mock_events(self._g, out.ctypes.data, n)
+        return out[:n]
+
+    def mock_table_ops(self) -> np.ndarray:
+        n = self._l.sgh_mock_table_ops(self._g, None, 0)
+        out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        self._l.sgh_mock_table_ops(self._g, out.ctypes.data, n)
+        return out[:n]
+
+    @property
+    def mock_label_count(self): return self._l.sgh_mock_label_count(self._g)

@@ -245,3 +245,33 @@ def test_partitioned_k1_overflow_paths_are_exact_or_counted():
         compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
     else:
         assert int(rows["count"].sum()) + st.events_dropped_cap == o.window_events
+
+
+def test_cpp_graphds_end_to_end_from_wire_records():
+    """The product path end to end: 1096-byte l7_event records -> C++ GraphDS (L7 packer, id interning,
+    batching) -> C ABI -> HIP kernels -> EdgeSink rows, against the oracle's full reference path on the
+    same records (payload parse, string tables, setFromToV2), incl. SQL drops, Kafka fan-out, reversal."""
+    from alaz_amd import engine, hostlib
+    from oracle import pyoracle
+    topo = replay.make_topology(60, 400, seed=11)
+    ev, labels = replay.make_events(topo, 20_000, seed=12, mixed=True, with_raw_outbound=True, with_reverse=True)
+    wire = bytearray(replay.to_wire(ev, labels))
+    pg = np.flatnonzero(ev["protocol"] == replay.PROTO_POSTGRES)[:50]
+    for j, i in enumerate(pg):
+        off = int(i) * replay.L7_WIRE_SIZE
+        if j % 2:
+            wire[off + 36 + 5: off + 36 + 11] = b"xxxxxx"
+        else:
+            wire[off + 1060: off + 1064] = (3).to_bytes(4, "little")
+    kafka = np.where(ev["protocol"] == replay.PROTO_KAFKA, 1 + (np.arange(len(ev)) % 3), 1).astype(np.uint32)
+    wire = bytes(wire)
+    W = weights.make_weights(2)
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.l7_wire(wire, kafka); o.window_close(W, 2)
+    cfg = engine.SgConfig(1, 0, topo.n_nodes + 8, 256, 256, topo.n_nodes + 8, 4096, 1 << 16, 2, 0, 1, 0, 1 << 16)
+    g = hostlib.GraphDS(cfg, batch=1000)
+    g.set_clock(*CLOCK); g.load_weights(W)
+    g.apply_ops(topo.k8s_ops())
+    assert g.ingest_wire(wire, kafka) == 0
+    got = g.FlushWindow(123)
+    compare_edge_dicts(got, o.edge_dict())
+    assert g.dropped_parse == o.dropped_parse > 0 and g.labels == o.labels

@@ -1,0 +1,117 @@
+"""CPU tests of the C++ host side (alaz_amd/csrc/host): the L7 packer and the GraphDS decorator,
+against the oracle's restatement of the same reference code and against a recording engine."""
+import numpy as np
+import pytest
+
+from alaz_amd import build, engine, hostlib, replay, weights
+from oracle import pyoracle
+from tests.test_oracle_golden import _wire
+
+CLOCK = (1_000_000_000, 1_700_000_000_000_000_000)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    build.build_all()
+
+
+def _cfg(nodes=256, edges=4096):
+    return engine.SgConfig(1, 0, nodes, 256, 64, nodes, edges, 1 << 16, 1, 0, 1, 0, 0)
+
+
+@pytest.mark.parametrize("req", [b"GET /user HTTP1.1", b"GET /a HTTP/1.1\r\nHost: example.com\r\nX: y\r\n\r\n",
+                                 b"POST /x?y=1 HTTP/1.1\nHost: h:8080\n", b"GET / HTTP/1.1\r\nHost:nospace\r\nHost: second\r\n",
+                                 b"GET / HTTP/1.1\r\nHost:  two-spaces\r\n", b"BROKEN", b"", b"A B C D\nHost: x y\n"])
+def test_parse_http_matches_oracle(req):
+    """C++ ParseHttpPayload == the oracle's restatement of aggregator/data.go:508-531."""
+    assert hostlib.parse_http(req) == pyoracle.parse_http_payload(req)
+
+
+def test_packer_reproduces_generator_events_and_label_order():
+    """BASELINE config 1 as 1096-byte records through the C++ packer: the packed events are the
+    generator's, and labels are interned in first-use order (what the oracle does on the wire path)."""
+    topo, ev, labels, _ = replay.make_config(1)
+    pk = hostlib.Packer()
+    for ip in list(topo.pod_ips) + list(topo.svc_ips):
+        pk.known_ip(int(ip))
+    got = pk.pack_wire(replay.to_wire(ev, labels))
+    assert pk.labels == labels and pk.dropped_parse == 0
+    for f in ("saddr", "daddr", "host_label", "status", "protocol", "flags", "duration_ns", "write_time_ns"):
+        assert np.array_equal(got[f], ev[f]), f
+
+
+def test_packer_plus_packed_oracle_equals_wire_oracle_mixed_protocols():
+    """Payload-dependent decisions (Host interning, SQL keyword filter, Kafka fan-out, reversal) made by
+    the C++ packer lead to the same edges as the oracle's full reference path on the same records."""
+    topo = replay.make_topology(60, 400, seed=11)
+    ev, labels = replay.make_events(topo, 20_000, seed=12, mixed=True, with_raw_outbound=True, with_reverse=True)
+    wire = bytearray(replay.to_wire(ev, labels))
+    # corrupt some Postgres payloads so that parsePostgresCommand rejects them (no SQL keyword / too short)
+    pg = np.flatnonzero(ev["protocol"] == replay.PROTO_POSTGRES)[:50]
+    for j, i in enumerate(pg):
+        off = int(i) * replay.L7_WIRE_SIZE
+        if j % 2:
+            wire[off + 36 + 5: off + 36 + 11] = b"xxxxxx"            # "SELECT" -> garbage
+        else:
+            wire[off + 1060: off + 1064] = (3).to_bytes(4, "little")   # payload_size 3 < 5
+    kafka = np.where(ev["protocol"] == replay.PROTO_KAFKA, 1 + (np.arange(len(ev)) % 3), 1).astype(np.uint32)
+    wire = bytes(wire)
+    W = weights.make_weights(1)
+    o_wire = pyoracle.Oracle(*CLOCK); o_wire.apply_ops(topo.k8s_ops())
+    o_wire.l7_wire(wire, kafka)
+    o_wire.window_close(W, 1)
+
+    pk = hostlib.Packer()
+    for ip in list(topo.pod_ips) + list(topo.svc_ips):
+        pk.known_ip(int(ip))
+    packed = pk.pack_wire(wire, kafka)
+    assert pk.dropped_parse == o_wire.dropped_parse > 0
+    o_pk = pyoracle.Oracle(*CLOCK); o_pk.apply_ops(topo.k8s_ops())
+    o_pk.packed(packed, pk.labels)
+    o_pk.window_close(W, 1)
+    assert o_pk.edge_dict() == o_wire.edge_dict()
+    assert o_pk.labels == o_wire.labels == pk.labels
+
+
+def test_graphds_table_maintenance_and_id_interning():
+    """PersistPod / PersistService mirror aggregator/persist.go:55-71,114-130 into sg_upsert_* / sg_delete_*
+    with arrival-order node ids; pods without IP are ignored (persist.go:37-40)."""
+    g = hostlib.GraphDS(_cfg(), engine_lib=None)
+    g.PersistPod("p1", "10.0.0.1"); g.PersistService("s1", "10.96.0.1"); g.PersistPod("p2", "10.0.0.2")
+    g.PersistPod("p1", "10.0.0.9", "UPDATE"); g.PersistPod("noip", ""); g.PersistPod("p2", "10.0.0.2", "DELETE")
+    g.PersistService("s1", "10.96.0.1", "DELETE")
+    ip = engine.ip_u32
+    assert g.mock_table_ops().tolist() == [[1, ip("10.0.0.1"), 0], [3, ip("10.96.0.1"), 1], [1, ip("10.0.0.2"), 2],
+                                           [1, ip("10.0.0.9"), 0], [2, ip("10.0.0.2"), 0], [4, ip("10.96.0.1"), 0]]
+
+
+def test_graphds_l7_tap_and_datastore_tap_produce_the_same_events():
+    """IngestL7 (raw event, packer) and PersistRequest (the DTO the reference aggregator would have
+    built, here taken from the oracle's ReqInfo rows) must hand the engine the same packed events,
+    including the un-reversal of AMQP DELIVER / Redis PUSHED_EVENT and the shared label ids."""
+    o = pyoracle.Oracle(0, 0, log_limit=100)       # clock (0,0): StartTime == write_time_ns / 1e6
+    ops = [("pod", "ADD", "p1", "10.0.0.1"), ("pod", "ADD", "p2", "10.0.0.2"), ("svc", "ADD", "s1", "10.96.0.1")]
+    o.apply_ops(ops)
+    A, B, S, X = 0x0A000001, 0x0A000002, 0x0A600001, 0x08080808
+    ms = 1_000_000
+    recs = b"".join([
+        _wire(A, S, wt=5 * ms), _wire(A, X, wt=6 * ms, payload=b"GET / HTTP/1.1\r\nHost: ext.example\r\n"),
+        _wire(A, X, wt=7 * ms, payload=b"GET / HTTP/1.1\r\n"), _wire(A, S, wt=8 * ms, tls=1),
+        _wire(A, S, wt=9 * ms, proto=2, method=2, status=1, payload=b""),            # AMQP DELIVER: reversed
+        _wire(B, S, wt=10 * ms, proto=5, method=2, status=2, payload=b"x"),           # Redis PUSHED_EVENT: reversed
+        _wire(A, B, wt=11 * ms, proto=3, method=2, status=2, payload=b"Q\x00\x00\x00\x0dselect 1"),
+    ])
+    assert o.l7_wire(recs) == 7
+    g1 = hostlib.GraphDS(_cfg(), engine_lib=None, batch=2); g1.apply_ops(ops)
+    g1.ingest_wire(recs); g1.FlushWindow()
+    g2 = hostlib.GraphDS(_cfg(), engine_lib=None, batch=3); g2.apply_ops(ops)
+    for r in o.reqinfos():
+        g2.PersistRequest(r)
+    g2.FlushWindow()
+    e1, e2 = g1.mock_events(), g2.mock_events()
+    assert len(e1) == len(e2) == 7
+    for f in ("saddr", "daddr", "host_label", "status", "protocol", "flags", "duration_ns"):
+        assert np.array_equal(e1[f], e2[f]), f
+    assert np.array_equal(e1["write_time_ns"] // ms, e2["write_time_ns"] // ms)
+    assert (e1["flags"] & 2).tolist() == [0, 0, 0, 0, 2, 2, 0] and (e1["flags"] & 1).tolist() == [0, 0, 0, 1, 0, 0, 0]
+    assert g1.labels == g2.labels == ["ext.example"] and g1.mock_label_count == 1
