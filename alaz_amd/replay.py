@@ -223,11 +223,12 @@ EXTERNAL_HOSTS = [f"api{k}.example-{k % 7}.com" for k in range(64)]
 
 def make_events(topo: Topology, n_events: int, seed: int, *, mixed: bool = False, stream_base: int = 100,
                 t0_ns: int = 1_000_000_000, with_raw_outbound: bool = False,
-                with_reverse: bool = False) -> Tuple[np.ndarray, List[str]]:
+                with_reverse: bool = False, fixed_labels: bool = False) -> Tuple[np.ndarray, List[str]]:
     """Packed events for ``topo`` (SURVEY.md §8d "Events").  Returns (events, labels) where
     labels[i] is the Host header of host_label i+1.
 
     mixed=False : HTTP only (configs 1-4).  mixed=True: 70 % HTTP / 15 % KAFKA / 15 % POSTGRES (config 5).
+    fixed_labels: label ids are the indices of EXTERNAL_HOSTS (+1) instead of first-use order.
     with_raw_outbound / with_reverse add the edge cases the parity tests exercise (raw-IP outbound
     destinations; AMQP DELIVER / Redis PUSHED_EVENT direction reversal)."""
     E = len(topo.edge_src)
@@ -281,8 +282,11 @@ def make_events(topo: Topology, n_events: int, seed: int, *, mixed: bool = False
     if outb.any():
         # label ids in first-use order, as the host packer interns them
         use = np.flatnonzero(outb & http)
-        _, first = np.unique(k[use], return_index=True)
-        order = k[use][np.sort(first)]
+        if fixed_labels:      # one global label table (sharded feeders must agree on the ids)
+            order = np.arange(len(EXTERNAL_HOSTS))
+        else:
+            _, first = np.unique(k[use], return_index=True)
+            order = k[use][np.sort(first)]
         lab_of = np.zeros(len(EXTERNAL_HOSTS), dtype=np.uint32)
         lab_of[order] = np.arange(1, len(order) + 1, dtype=np.uint32)
         labels = [EXTERNAL_HOSTS[int(x)] for x in order]

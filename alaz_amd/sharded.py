@@ -79,8 +79,65 @@ def route_events(ev: np.ndarray, world: int, pod_ip_to_id: dict, svc_ip_to_id: d
 
 
 # ------------------------------------------------------------------------------------------------
-# collectives helpers
+# communicators
 # ------------------------------------------------------------------------------------------------
+class DistComm:
+    """torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_gather(self, t: torch.Tensor) -> List[torch.Tensor]:
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return out
+
+    def all_to_all_v(self, out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int]) -> None:
+        _all_to_all_v(out, inp, out_splits, in_splits, self.group)
+
+
+class ThreadComm:
+    """All shards in one process, one thread per shard (validation of G logical shards on one device,
+    SURVEY.md §8e): the same collectives through shared memory and a barrier."""
+
+    class Shared:
+        def __init__(self, world: int):
+            import threading
+            self.world = world
+            self.slots = [None] * world
+            self.barrier = threading.Barrier(world)
+
+    def __init__(self, shared: "ThreadComm.Shared", rank: int):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+
+    def _exchange(self, obj):
+        self.sh.slots[self.rank] = obj
+        self.sh.barrier.wait()
+        got = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return got
+
+    def all_gather(self, t: torch.Tensor) -> List[torch.Tensor]:
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        return [x.clone() for x in self._exchange(t)]
+
+    def all_to_all_v(self, out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int]) -> None:
+        if inp.is_cuda:
+            torch.cuda.synchronize(inp.device)
+        got = self._exchange((inp, list(in_splits)))
+        off = 0
+        for r, c in enumerate(out_splits):
+            src, splits = got[r]
+            so = sum(splits[: self.rank])
+            out[off:off + c] = src[so:so + c]; off += c
+        if out.is_cuda:
+            torch.cuda.synchronize(out.device)
+        self.sh.barrier.wait()
+
+
 def _all_to_all_v(out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int], group) -> None:
     """all_to_all_single with uneven splits; falls back to an all_gather emulation where the
     backend has no alltoall (older gloo builds)."""
@@ -105,10 +162,17 @@ def _all_to_all_v(out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int
         out[off:off + c] = got[r][me, :c]; off += c
 
 
-def run_window(be, group=None) -> None:
-    """One window close on every shard (all ranks call it together)."""
-    world = dist.get_world_size(group)
-    me = dist.get_rank(group)
+def run_window(be, comm=None) -> None:
+    """One window close on every shard (all shards call it together).  On a GPU backend every torch op
+    below runs on the backend's stream, the same one its kernels are enqueued on."""
+    import contextlib
+    stream = getattr(be, "stream", None)
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        _run_window(be, comm if comm is not None else DistComm())
+
+
+def _run_window(be, comm) -> None:
+    world, me = comm.world, comm.rank
     dev = be.device
 
     # 1. outbound-IP union -> same OBIP numbering on every shard
@@ -116,16 +180,13 @@ def run_window(be, group=None) -> None:
     mine = be.obip_list()                                    # int64 [n_local] (distinct raw IPs seen here)
     buf = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
     buf[0] = len(mine); buf[1:1 + len(mine)] = mine
-    got = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(got, buf, group=group)
+    got = comm.all_gather(buf)
     union = torch.cat([g[1:1 + int(g[0].item())] for g in got]) if world > 1 else mine
     be.close(union)
 
     # 2. node statistics: all_gather, then SUM / MAX locally (integers: exact, order-free)
     flat = be.stats_flat                                     # int64 [ncap*10 | ncap*2], engine writes in place
-    got = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(got, flat, group=group)
-    st = torch.stack(got)
+    st = torch.stack(comm.all_gather(flat))
     ns = be.ncap * STAT_SUM_WORDS
     flat[:ns] = st[:, :ns].sum(dim=0)
     flat[ns:] = st[:, ns:].max(dim=0).values
@@ -133,19 +194,17 @@ def run_window(be, group=None) -> None:
 
     # 3. halo requests (ids grouped by owner) -> everyone learns what it must serve
     counts, ids = be.halo_requests()                         # List[int] * world, int64 [sum(counts)]
-    cmat = torch.tensor(counts, dtype=torch.int64, device=dev)
-    call = [torch.empty_like(cmat) for _ in range(world)]
-    dist.all_gather(call, cmat, group=group)
-    want_from_me = [int(call[r][me].item()) for r in range(world)]          # rows rank r asks of me
+    call = comm.all_gather(torch.tensor(counts, dtype=torch.int64, device=dev))
+    want_from_me = [int(call[r][me].item()) for r in range(world)]          # rows shard r asks of me
     serve_ids = torch.empty(sum(want_from_me), dtype=torch.int64, device=dev)
-    _all_to_all_v(serve_ids, ids, want_from_me, counts, group)
+    comm.all_to_all_v(serve_ids, ids, want_from_me, counts)
 
     # 4. layers with halo exchange of the produced rows
     for l in range(be.layers):
         be.layer(l)
         rows_out = be.pack(l + 1, serve_ids)                 # float32 [n_serve, 64]
         rows_in = torch.empty((sum(counts), 64), dtype=torch.float32, device=dev)
-        _all_to_all_v(rows_in, rows_out, counts, want_from_me, group)
+        comm.all_to_all_v(rows_in, rows_out, counts, want_from_me)
         be.unpack(l + 1, ids, rows_in)
     be.score()
 

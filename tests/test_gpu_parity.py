@@ -275,3 +275,52 @@ def test_cpp_graphds_end_to_end_from_wire_records():
     got = g.FlushWindow(123)
     compare_edge_dicts(got, o.edge_dict())
     assert g.dropped_parse == o.dropped_parse > 0 and g.labels == o.labels
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_logical_shards_on_one_device_equal_the_unsharded_engine(layers):
+    """SURVEY.md §8e validation: G = 2 and G = 4 shard engines on ONE device (one thread per shard,
+    the real HipBackend + exchange logic, collectives through ThreadComm) must reproduce the unsharded
+    engine bit for bit: integer statistics are exact and halo rows are copied, never reduced."""
+    import threading
+    import torch
+    from alaz_amd import engine, sharded
+    topo = replay.make_topology(120, 1500, seed=91)
+    ev, labels = replay.make_events(topo, 60_000, seed=92, mixed=True, with_raw_outbound=True, with_reverse=True, fixed_labels=True)
+    W = weights.make_weights(layers)
+    ref = _engine(topo.n_nodes + 8, 8192, layers, max_labels=128, max_outbound_ips=128)
+    shim = HostShim(); shim.apply(ref, topo.k8s_ops())
+    assert ref.ingest(ev) == 0
+    ref.set_label_count(len(labels))
+    want = ref.flush_window()
+    for world in (2, 4):
+        shard = ref.route(ev, world)
+        pod = {int(ip): i for i, ip in enumerate(topo.pod_ips)}; svc = {int(ip): topo.n_pods + j for j, ip in enumerate(topo.svc_ips)}
+        assert np.array_equal(shard, sharded.route_events(ev, world, pod, svc))     # host twin == sg_route
+        shared = sharded.ThreadComm.Shared(world)
+        dev = torch.device("cuda", 0)
+        ncap = topo.n_nodes + 8 + 128 + 128
+        engs, bes, outs = [], [], [None] * world
+        for r in range(world):
+            g = engine.ServiceGraph(max_known_nodes=topo.n_nodes + 8, max_edges=8192, layers=layers, max_labels=128, max_outbound_ips=128,
+                                    rank=r, world=world, max_window_events=len(ev))
+            g.set_clock(*CLOCK); g.load_weights(W); HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
+            assert g.ingest(ev[shard == r]) == 0
+            engs.append(g)
+            bes.append(sharded.HipBackend(g, ncap=ncap, layers=layers, world=world, rank=r, device=dev, max_obip=128, stream=torch.cuda.Stream(dev)))
+
+        def run(r):
+            sharded.run_window(bes[r], sharded.ThreadComm(shared, r))
+            outs[r] = engs[r].window_read().copy()
+            engs[r].window_reset(bes[r].s)
+        ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ths: t.start()
+        for t in ths: t.join(timeout=300)
+        assert all(o is not None for o in outs)
+        assert sum(e.stats().events_dropped_cap for e in engs) == 0
+        got = np.concatenate(outs)
+        key = lambda a: np.lexsort((a["to_ref"], a["from_ref"]))
+        got = got[key(got)]; exp = want[key(want)]
+        assert len(got) == len(exp) and min(len(o) for o in outs) > 0
+        assert got.tobytes() == exp.tobytes()
+        for g in engs: g.close()

@@ -1,0 +1,134 @@
+"""CPU tests of the multi-GPU path: 2 processes, gloo, the real exchange logic of
+alaz_amd.sharded.run_window driven by a numpy stand-in backend (tests/np_backend.py), checked
+against the unsharded oracle.  Also the host-side routing rule."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from alaz_amd import replay, sharded, weights
+from oracle import pyoracle
+
+CLOCK = (1_000_000_000, 1_700_000_000_000_000_000)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _trace(layers):
+    topo = replay.make_topology(40, 300, seed=201)
+    ev, labels = replay.make_events(topo, 6000, seed=202, mixed=True, with_raw_outbound=True, with_reverse=True, fixed_labels=True)
+    return topo, ev, labels
+
+
+def _worker(rank, world, port, layers, q):
+    from tests.np_backend import NumpyBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        topo, ev, labels = _trace(layers)
+        pod = {int(ip): i for i, ip in enumerate(topo.pod_ips)}
+        svc = {int(ip): topo.n_pods + j for j, ip in enumerate(topo.svc_ips)}
+        kind = [1] * topo.n_pods + [2] * topo.n_svcs
+        shard = sharded.route_events(ev, world, pod, svc)
+        be = NumpyBackend(pod_ip_to_id=pod, svc_ip_to_id=svc, kind=kind, n_labels=len(labels), weights=weights.make_weights(layers),
+                          layers=layers, rank=rank, world=world, ncap=topo.n_nodes + len(labels) + 64)
+        be.ingest(ev[shard == rank])
+        sharded.run_window(be)
+        q.put((rank, be.rows, be.misrouted, be.N, [int(x) for x in be.ob]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_two_shards_equal_unsharded_oracle(layers):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, layers, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    topo, ev, labels = _trace(layers)
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(layers), layers)
+    want = o.edge_rows()
+    NK, NL = o.n_known, len(labels)
+
+    def dense(ref):
+        t, v = ref >> 30, ref & 0x3FFFFFFF
+        return int(v if t == 0 else (NK + v if t == 1 else NK + NL + v))
+    ref_rows = {(dense(int(r["from_ref"])), dense(int(r["to_ref"]))): r for r in want}
+    rows = [r for g in got for r in g[1]]
+    assert sum(g[2] for g in got) == 0                       # nothing misrouted by route_events
+    assert all(g[3] == o.n_nodes for g in got)               # same node numbering on every shard
+    assert all(g[4] == [int(x) for x in o.outbound_ips()] for g in got)
+    assert len(rows) == len(ref_rows) and len({(r[0], r[1]) for r in rows}) == len(rows)   # every edge on exactly one shard
+    for f, t, acc, score, z, er in rows:
+        w = ref_rows[(f, t)]
+        assert acc == (int(w["count"]), int(w["err_count"]), int(w["sum_ns"]), int(w["max_ns"]), int(w["sumsq_us"]))
+        assert abs(score - float(w["score"])) <= 1e-5 and abs(z - float(w["lat_z"])) <= 1e-5 * max(1.0, abs(float(w["lat_z"])))
+        assert er == float(w["err_ratio"])
+    # both shards actually own edges, and some edges need halo rows
+    assert all(len(g[1]) > 0 for g in got)
+
+
+def test_route_events_matches_the_ownership_rule():
+    topo, ev, labels = _trace(1)
+    pod = {int(ip): i for i, ip in enumerate(topo.pod_ips)}
+    svc = {int(ip): topo.n_pods + j for j, ip in enumerate(topo.svc_ips)}
+    for world in (2, 4, 8):
+        sh = sharded.route_events(ev, world, pod, svc)
+        plain = (ev["flags"] & replay.EV_REVERSE) == 0
+        known = np.isin(ev["saddr"], topo.pod_ips)
+        ids = (ev["saddr"][plain & known] - replay.POD_IP_BASE).astype(np.uint32)
+        assert np.array_equal(sh[plain & known], replay.hash32(ids) % np.uint32(world))
+        assert sh.max() < world
+        # balance: no shard is starved
+        assert np.bincount(sh, minlength=world).min() > len(ev) / world / 3
+
+
+def test_all_to_all_v_fallback_path():
+    """_all_to_all_v on a 1-process group: identity."""
+    port = _free_port()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        x = torch.arange(12, dtype=torch.float32).reshape(3, 4); y = torch.empty_like(x)
+        sharded.DistComm().all_to_all_v(y, x, [3], [3])
+        assert torch.equal(x, y)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_thread_comm_runs_the_same_pipeline_without_processes():
+    """ThreadComm (all shards in one process) gives the same result as the 2-process gloo run."""
+    import threading
+    from tests.np_backend import NumpyBackend
+    world, layers = 2, 1
+    topo, ev, labels = _trace(layers)
+    pod = {int(ip): i for i, ip in enumerate(topo.pod_ips)}
+    svc = {int(ip): topo.n_pods + j for j, ip in enumerate(topo.svc_ips)}
+    shard = sharded.route_events(ev, world, pod, svc)
+    shared = sharded.ThreadComm.Shared(world)
+    bes = [NumpyBackend(pod_ip_to_id=pod, svc_ip_to_id=svc, kind=[1] * topo.n_pods + [2] * topo.n_svcs, n_labels=len(labels),
+                        weights=weights.make_weights(layers), layers=layers, rank=r, world=world, ncap=topo.n_nodes + len(labels) + 64) for r in range(world)]
+    for r in range(world):
+        bes[r].ingest(ev[shard == r])
+    ths = [threading.Thread(target=sharded.run_window, args=(bes[r], sharded.ThreadComm(shared, r))) for r in range(world)]
+    for t in ths: t.start()
+    for t in ths: t.join(timeout=120)
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(layers), layers)
+    rows = [r for b in bes for r in b.rows]
+    assert len(rows) == len(o.edge_rows())
+    assert sorted(r[2] for r in rows) == sorted((int(w["count"]), int(w["err_count"]), int(w["sum_ns"]), int(w["max_ns"]), int(w["sumsq_us"])) for w in o.edge_rows())
