@@ -78,17 +78,18 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local)
-    if world > 1:
+    force_sharded = os.environ.get("SG_FORCE_SHARDED") == "1"      # exercise the multi-GPU code path at world = 1
+    if world > 1 or force_sharded:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    if world > 1:
+    if world > 1 or force_sharded:
         from alaz_amd import sharded
         res = sharded.bench(a, rank, world, local)
     else:
         res = bench_single(a, local)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_sharded:
         dist.barrier()
         dist.destroy_process_group()
 
