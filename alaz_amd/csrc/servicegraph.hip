@@ -307,6 +307,7 @@ int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n) {
     st.last_window_nodes = e->h_ctr[C_N_NODES];
     st.events_dropped_src += e->h_ctr[C_DROPPED_SRC];
     st.events_dropped_cap += e->h_ctr[C_DROPPED_CAP];
+    st.events_misrouted += e->h_ctr[C_MISROUTED];
     if (e->h_ctr[C_N_EVENTS]) {
         // convertKernelTimeToUserspaceTime()/1e6 — aggregator/data.go:1740-1743, :1219 (u64 wrap arithmetic)
         st.last_window_tmin_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMIN_NS])) / 1000000ull);

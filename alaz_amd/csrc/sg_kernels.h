@@ -125,7 +125,8 @@ __device__ __forceinline__ u32 dense_of(const Dev& d, u32 ref, u32 nk, u32 nl, u
     if (t == SG_REF_KNOWN) return v;
     if (t == SG_REF_LABEL) return nk + v;
     const u32 ip = (u32)d.obkeys[v];
-    return nk + nl + lower_bound_u32(d.ob_sorted, nob, ip);
+    const u32 r = lower_bound_u32(d.ob_sorted, nob, ip);
+    return (r < nob && d.ob_sorted[r] == ip) ? nk + nl + r : SG_NONE;   // not listed: more raw outbound IPs than max_outbound_ips
 }
 __device__ __forceinline__ u32 ref_of_dense(u32 v, u32 nk, u32 nl) {
     if (v < nk) return SG_MAKE_REF(SG_REF_KNOWN, v);
@@ -408,9 +409,10 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         const u32 s = q * K1B_THREADS + t;
         const u64 k = hkey[s];
         if (k == SG_EKEY_EMPTY) continue;
+        const u32 f = dense_of(d, (u32)(k >> 32), nk, nl, nob), to = dense_of(d, (u32)k, nk, nl, nob);
+        if (f == SG_NONE || to == SG_NONE) { atomicAdd(&n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
         const u32 i = atomicAdd(&out_n, 1u);
         if (i >= d.pcap) { atomicAdd(&n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
-        const u32 f = dense_of(d, (u32)(k >> 32), nk, nl, nob), to = dense_of(d, (u32)k, nk, nl, nob);
         const size_t slot = (size_t)p * d.pcap + i;
         d.e_from[slot] = f; d.e_to[slot] = to;
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
@@ -572,7 +574,8 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
         if (pos < d.max_edges) {
             const u32 f = dense_of(d, (u32)(k[j] >> 32), nk, nl, nob), t = dense_of(d, (u32)k[j], nk, nl, nob);
             d.e_slot[pos] = base_slot + j; d.e_from[pos] = f; d.e_to[pos] = t;
-            atomicAdd(&d.deg[(size_t)f * SG_DEG_STRIDE], 1u);
+            if (f != SG_NONE && t != SG_NONE) atomicAdd(&d.deg[(size_t)f * SG_DEG_STRIDE], 1u);
+            else atomicAdd(&d.ctr[C_DROPPED_CAP], d.eacc[(size_t)(base_slot + j) * 4] & 0xFFFFFFFFull);
         }
         pos++;
     }
@@ -606,9 +609,15 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d) {
 
 // scatter into CSR rows (order inside a row is fixed afterwards by the row sort)
 __global__ __launch_bounds__(256) void k2_scatter_table(Dev d) {
-    const u32 E = (u32)d.ctr[C_N_EDGES];
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < E; i += gridDim.x * 256) {
+    const u64 found = d.ctr[C_EDGES_FOUND] < d.max_edges ? d.ctr[C_EDGES_FOUND] : d.max_edges;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < found; i += gridDim.x * 256) {
         const u32 f = d.e_from[i];
+        if (f == SG_NONE || d.e_to[i] == SG_NONE) {                    // endpoint beyond max_outbound_ips: dropped; clear its table slot
+            const u32 sl = d.e_slot[i];
+            d.ekeys[sl] = SG_EKEY_EMPTY;
+            ulonglong2* a = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)sl * 4); a[0] = make_ulonglong2(0, 0); a[1] = make_ulonglong2(0, 0);
+            continue;
+        }
         const u32 pos = d.rowptr[f] + atomicAdd(&d.cursor[f], 1u);
         d.col[pos] = d.e_to[i]; d.cslot[pos] = d.e_slot[i];
     }

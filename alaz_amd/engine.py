@@ -47,7 +47,8 @@ class SgStats(C.Structure):
     _fields_ = [("events_in", C.c_uint64), ("events_dropped_src", C.c_uint64), ("events_dropped_ring", C.c_uint64),
                 ("events_dropped_cap", C.c_uint64), ("windows", C.c_uint64), ("last_window_events", C.c_uint64),
                 ("last_window_edges", C.c_uint64), ("last_window_nodes", C.c_uint64),
-                ("last_window_tmin_ms", C.c_int64), ("last_window_tmax_ms", C.c_int64), ("h2d_bytes", C.c_uint64)]
+                ("last_window_tmin_ms", C.c_int64), ("last_window_tmax_ms", C.c_int64), ("h2d_bytes", C.c_uint64),
+                ("events_misrouted", C.c_uint64)]
 
 
 class ServiceGraphError(RuntimeError):

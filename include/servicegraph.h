@@ -168,6 +168,7 @@ typedef struct sg_stats {
     int64_t  last_window_tmin_ms;  /* min/max Request.StartTime in the window (data.go:1219)    */
     int64_t  last_window_tmax_ms;
     uint64_t h2d_bytes;
+    uint64_t events_misrouted;     /* world > 1: events fed to the wrong shard (see sg_route)    */
 } sg_stats;
 
 typedef struct sg_engine* sg_handle;

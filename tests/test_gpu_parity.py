@@ -288,7 +288,7 @@ def test_logical_shards_on_one_device_equal_the_unsharded_engine(layers):
     topo = replay.make_topology(120, 1500, seed=91)
     ev, labels = replay.make_events(topo, 60_000, seed=92, mixed=True, with_raw_outbound=True, with_reverse=True, fixed_labels=True)
     W = weights.make_weights(layers)
-    ref = _engine(topo.n_nodes + 8, 8192, layers, max_labels=128, max_outbound_ips=128)
+    ref = _engine(topo.n_nodes + 8, 8192, layers, max_labels=128, max_outbound_ips=512)
     shim = HostShim(); shim.apply(ref, topo.k8s_ops())
     assert ref.ingest(ev) == 0
     ref.set_label_count(len(labels))
@@ -299,15 +299,15 @@ def test_logical_shards_on_one_device_equal_the_unsharded_engine(layers):
         assert np.array_equal(shard, sharded.route_events(ev, world, pod, svc))     # host twin == sg_route
         shared = sharded.ThreadComm.Shared(world)
         dev = torch.device("cuda", 0)
-        ncap = topo.n_nodes + 8 + 128 + 128
+        ncap = topo.n_nodes + 8 + 128 + 512
         engs, bes, outs = [], [], [None] * world
         for r in range(world):
-            g = engine.ServiceGraph(max_known_nodes=topo.n_nodes + 8, max_edges=8192, layers=layers, max_labels=128, max_outbound_ips=128,
+            g = engine.ServiceGraph(max_known_nodes=topo.n_nodes + 8, max_edges=8192, layers=layers, max_labels=128, max_outbound_ips=512,
                                     rank=r, world=world, max_window_events=len(ev))
             g.set_clock(*CLOCK); g.load_weights(W); HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
             assert g.ingest(ev[shard == r]) == 0
             engs.append(g)
-            bes.append(sharded.HipBackend(g, ncap=ncap, layers=layers, world=world, rank=r, device=dev, max_obip=128, stream=torch.cuda.Stream(dev)))
+            bes.append(sharded.HipBackend(g, ncap=ncap, layers=layers, world=world, rank=r, device=dev, max_obip=512, stream=torch.cuda.Stream(dev)))
 
         def run(r):
             sharded.run_window(bes[r], sharded.ThreadComm(shared, r))
@@ -317,10 +317,31 @@ def test_logical_shards_on_one_device_equal_the_unsharded_engine(layers):
         for t in ths: t.start()
         for t in ths: t.join(timeout=300)
         assert all(o is not None for o in outs)
-        assert sum(e.stats().events_dropped_cap for e in engs) == 0
+        assert sum(e.stats().events_dropped_cap + e.stats().events_misrouted for e in engs) == 0
         got = np.concatenate(outs)
         key = lambda a: np.lexsort((a["to_ref"], a["from_ref"]))
         got = got[key(got)]; exp = want[key(want)]
         assert len(got) == len(exp) and min(len(o) for o in outs) > 0
         assert got.tobytes() == exp.tobytes()
         for g in engs: g.close()
+
+
+def test_outbound_ip_capacity_overflow_is_counted():
+    """More distinct raw outbound IPs than max_outbound_ips: the unlisted ones are dropped and counted,
+    the listed ones keep exact results (no aliasing of node ids)."""
+    from oracle import pyoracle
+    topo = replay.make_topology(40, 200, seed=81)
+    ev, labels = replay.make_events(topo, 20_000, seed=82, with_raw_outbound=True)
+    for variant in (0, 1):
+        g = _engine(topo.n_nodes + 8, 4096, 1, max_outbound_ips=16, k1_variant=variant)
+        shim = HostShim(); shim.apply(g, topo.k8s_ops())
+        assert g.ingest(ev) == 0
+        g.set_label_count(len(labels))
+        rows = g.flush_window()
+        st = g.stats()
+        o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(1), 1)
+        assert len(g.outbound_ips()) == 16 and len(o.outbound_ips()) > 16 and st.events_dropped_cap > 0
+        assert int(rows["count"].sum()) + st.events_dropped_cap == o.window_events
+        want = o.edge_dict()
+        got = engine_edge_dict(rows, shim, labels, g.outbound_ips())
+        assert set(got) <= set(want) and all(got[k][:5] == want[k][:5] for k in got)
