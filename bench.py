@@ -105,7 +105,7 @@ def bench_single(a, device):
     topo = replay.make_topology(c["pods"], c["edges"], seed)
     ev_all, labels = replay.make_events(topo, Ev * nb, seed)
     g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.25) + 4096, layers=L,
-                            max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=Ev,
+                            max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=1 << 18,
                             max_window_events=Ev)
     g.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
     g.load_weights(weights.make_weights(L))
@@ -167,6 +167,20 @@ def bench_single(a, device):
                      "k1a_partition_us": k1a[0], "k1b_merge_us": k1b[0], "launches": k1a[1]},
         "kernel_group_us": {"K1a": round(k1a[0], 2), "K1b": round(k1b[0], 2), **{f"K{k}": round(v[0], 2) for k, v in k_us.items() if k > 1}},
     }
+    # diagnostic (never `value`): the same windows fed from host memory through sg_ingest
+    # (pinned staging ring + H2D over PCIe), DESIGN.md "PCIe-inclusive rate"
+    hs = min(10, a.steps)
+    chunk = 1 << 18
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(hs):
+        b = ev_all[(i % nb) * Ev:((i % nb) + 1) * Ev]
+        for j in range(0, Ev, chunk):
+            while g.ingest(b[j:j + chunk]) != 0:
+                pass
+        g.window_run()
+    torch.cuda.synchronize()
+    res["host_fed_events_per_s"] = Ev * hs / (time.perf_counter() - t0)
     if not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(topo, ev_all[:Ev], labels, L, a.cpu_seconds)
     g.close()
