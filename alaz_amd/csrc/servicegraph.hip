@@ -269,7 +269,9 @@ int do_layer(sg_engine* e, u32 l, hipStream_t s, bool fuse_proj) {
     return SG_OK;
 }
 
-int do_score(sg_engine* e, hipStream_t s, bool proj_done) {
+// proj_done: the last SAGE layer already wrote P and Q.  fuse_reset: fold the window reset into the
+// score kernel (unsharded variant-0 pipelines; saves a launch) — returns true through *did_reset.
+int do_score(sg_engine* e, hipStream_t s, bool proj_done, bool fuse_reset, bool* did_reset) {
     const Dev& d = e->d;
     if (!e->have_w) { e->err = "sg_load_weights not called"; return SG_ESTATE; }
     const float* Wh = e->d_W + layer_offset(e->cfg.layers);
@@ -278,7 +280,10 @@ int do_score(sg_engine* e, hipStream_t s, bool proj_done) {
         if (e->use_mfma) hipLaunchKernelGGL((k5_node_proj<true>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
         else hipLaunchKernelGGL((k5_node_proj<false>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
     }
-    hipLaunchKernelGGL(k5_edge_score, dim3(grid_for(e->cfg.max_edges, 16)), dim3(256), 0, s, d, Wh);
+    const bool fr = fuse_reset && d.variant == 0 && d.world == 1;
+    if (fr) hipLaunchKernelGGL(k5_edge_score<true>, dim3(grid_for(e->cfg.max_edges, 16)), dim3(256), 0, s, d, Wh);
+    else hipLaunchKernelGGL(k5_edge_score<false>, dim3(grid_for(e->cfg.max_edges, 16)), dim3(256), 0, s, d, Wh);
+    if (did_reset) *did_reset = fr;
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
@@ -377,8 +382,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     d.variant = cfg->k1_variant == 1 ? 1u : 0u;
     {
         u64 np = next_pow2(std::max<u64>(ME / 160, 64));
-        if (cfg->k1_variant == 0 && np > 1024) d.variant = 1;           // beyond the partitioned path's range
-        d.np = (u32)std::min<u64>(std::max<u64>(np / 2, 64), 1024); d.nwg = 256; d.pcap = 768;
+        if (cfg->k1_variant == 0 && np / 2 > 4096) d.variant = 1;       // beyond the partitioned path's range
+        d.np = (u32)std::min<u64>(std::max<u64>(np / 2, 64), 4096); d.nwg = 256; d.pcap = 768;
         if (const char* v = std::getenv("SG_NP")) d.np = (u32)std::strtoul(v, nullptr, 0);
         if (const char* v = std::getenv("SG_NWG")) d.nwg = (u32)std::strtoul(v, nullptr, 0);
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
@@ -587,7 +592,7 @@ int sg_window_score(sg_handle e, void* stream) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
     if (!e->closed) { e->err = "sg_window_score before sg_window_close"; return SG_ESTATE; }
-    return do_score(e, pick(e, stream), false);
+    return do_score(e, pick(e, stream), false, false, nullptr);
 }
 int sg_window_read(sg_handle e, sg_edge_out* out, size_t cap, size_t* n) {
     if (!e) return SG_EINVAL;
@@ -610,8 +615,10 @@ int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_
     if ((rc = do_close(e, s, nullptr, nullptr))) return rc;
     if ((rc = do_features(e, s))) return rc;
     for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
-    if ((rc = do_score(e, s, true))) return rc;
+    bool did = false;
+    if ((rc = do_score(e, s, true, true, &did))) return rc;
     if ((rc = do_read(e, out, cap, n))) return rc;
+    if (did) { e->closed = false; return SG_OK; }
     return do_reset(e, s);
 }
 
@@ -624,7 +631,9 @@ int sg_window_run(sg_handle e, void* stream) {
     if ((rc = do_close(e, s, nullptr, nullptr))) return rc;
     if ((rc = do_features(e, s))) return rc;
     for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
-    if ((rc = do_score(e, s, true))) return rc;
+    bool did = false;
+    if ((rc = do_score(e, s, true, true, &did))) return rc;
+    if (did) { e->closed = false; return SG_OK; }
     return do_reset(e, s);
 }
 

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
 // in LDS and writes each distinct edge once with plain stores.
 #define K1A_THREADS 1024
 #define K1A_CT      2048      // LDS cache slots per workgroup
+#define K1A_G       4         // events per thread per step
 #define K1B_HT      1024
 #define K1B_THREADS 1024
 #define K1B_LPP     4        // lanes per piece
@@ -280,9 +281,12 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
     const u64 per = (n + d.nwg - 1) / d.nwg;
     const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
+    // K1A_G events per thread are fetched together (8 x 16 B in flight per lane): the first group is
+    // issued before the LDS set-up, each next group before the current one is folded in
     u64 i = beg + t;
-    uint4 a, b;
-    if (i < end) { a = pe[2 * i]; b = pe[2 * i + 1]; }               // first events in flight during the LDS set-up
+    uint4 a[K1A_G], b[K1A_G];
+#pragma unroll
+    for (int q = 0; q < K1A_G; q++) { const u64 j = i + (u64)q * K1A_THREADS; if (j < end) { a[q] = pe[2 * j]; b[q] = pe[2 * j + 1]; } }
     for (u32 i = t; i < K1A_CT; i += K1A_THREADS) ckey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < K1A_CT * 4; i += K1A_THREADS) cacc[i] = 0;
     for (u32 p = t; p < d.np; p += K1A_THREADS) { const uint4 h = d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)]; fS[p] = h.x; fA[p] = h.y; }
@@ -292,29 +296,36 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
 
     K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
     while (i < end) {
-        const uint4 ca = a, cb = b;
-        const u64 nx = i + K1A_THREADS;
-        if (nx < end) { a = pe[2 * nx]; b = pe[2 * nx + 1]; }        // next event in flight while this one is folded in
-        i = nx;
-        K1Ev e; bool ok;
-        if (d.ablate & 4u) { e.key = ((u64)ca.x << 32) | ca.y; e.dur = (u64)cb.x | ((u64)cb.y << 32); e.err = 0; ok = true; }
-        else ok = k1_resolve(d, iptab, ca, cb, L, e);
-        if (!ok) continue;
-        if (d.ablate & 1u) { if (e.key == 0x1234567ull) L.dcap++; continue; }
-        u32 h = hash_key64(e.key) & (K1A_CT - 1);
-        int slot = -1;
+        uint4 ca[K1A_G], cb[K1A_G];
 #pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-            u64 k = ((volatile u64*)ckey)[h];
-            if (k == SG_EKEY_EMPTY) { k = atomicCAS(&ckey[h], SG_EKEY_EMPTY, e.key); if (k == SG_EKEY_EMPTY) k = e.key; }
-            if (k == e.key) { slot = (int)h; break; }
-            h = (h + 1) & (K1A_CT - 1);
+        for (int q = 0; q < K1A_G; q++) { ca[q] = a[q]; cb[q] = b[q]; }
+        const u64 cur = i;
+        i += (u64)K1A_G * K1A_THREADS;
+#pragma unroll
+        for (int q = 0; q < K1A_G; q++) { const u64 j = i + (u64)q * K1A_THREADS; if (j < end) { a[q] = pe[2 * j]; b[q] = pe[2 * j + 1]; } }
+#pragma unroll
+        for (int q = 0; q < K1A_G; q++) {
+            if (cur + (u64)q * K1A_THREADS >= end) break;
+            K1Ev e; bool ok;
+            if (d.ablate & 4u) { e.key = ((u64)ca[q].x << 32) | ca[q].y; e.dur = (u64)cb[q].x | ((u64)cb[q].y << 32); e.err = 0; ok = true; }
+            else ok = k1_resolve(d, iptab, ca[q], cb[q], L, e);
+            if (!ok) continue;
+            if (d.ablate & 1u) { if (e.key == 0x1234567ull) L.dcap++; continue; }
+            u32 h = hash_key64(e.key) & (K1A_CT - 1);
+            int slot = -1;
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++) {
+                u64 k = ((volatile u64*)ckey)[h];
+                if (k == SG_EKEY_EMPTY) { k = atomicCAS(&ckey[h], SG_EKEY_EMPTY, e.key); if (k == SG_EKEY_EMPTY) k = e.key; }
+                if (k == e.key) { slot = (int)h; break; }
+                h = (h + 1) & (K1A_CT - 1);
+            }
+            if (slot >= 0) {
+                const u64 us = e.dur / 1000ull;
+                atomicAdd(&cacc[slot * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&cacc[slot * 4 + 1], e.dur);
+                atomicMax(&cacc[slot * 4 + 2], e.dur); atomicAdd(&cacc[slot * 4 + 3], us * us);
+            } else if (!(d.ablate & 2u)) emit_single(d, fS, w, e.key, e.dur, e.err, L);
         }
-        if (slot >= 0) {
-            const u64 us = e.dur / 1000ull;
-            atomicAdd(&cacc[slot * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&cacc[slot * 4 + 1], e.dur);
-            atomicMax(&cacc[slot * 4 + 2], e.dur); atomicAdd(&cacc[slot * 4 + 3], us * us);
-        } else if (!(d.ablate & 2u)) emit_single(d, fS, w, e.key, e.dur, e.err, L);
     }
     __syncthreads();
     // flush the cache: one record per cached edge
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
             u64 nl = d.ctr[C_N_LABELS];                              // labels are cumulative across windows
             nl = red[2][0] > nl ? red[2][0] : nl; nl = n_labels_decl > nl ? n_labels_decl : nl;
             d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known;
-            d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_DROPPED_CAP] += red[4][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
+            d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_DROPPED_CAP] = red[4][0];   // K1b / K2 add their own drops afterwards d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
         }
     }
     // (b)
@@ -601,6 +612,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d) {
     __syncthreads();
     if (threadIdx.x == 0) {
         d.ctr[C_N_LONG] = nlong;
+        d.ctr[C_OVF_N] = 0;                                            // K1b has consumed the overflow list
         d.rowptr[N] = total;
         d.ctr[C_N_EDGES] = (u64)total < d.max_edges ? total : d.max_edges;
         if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = total; if ((u64)total > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)total - d.max_edges; }
@@ -802,13 +814,19 @@ __global__ __launch_bounds__(1024) void k3_in_stats(Dev d) {
         u64* acc = reinterpret_cast<u64*>(smem);                     // [N][6]: deg, cnt, err, sum, ssq, max
         for (u32 i = t; i < N * 6; i += 1024) acc[i] = 0;
         __syncthreads();
-        for (u32 p = p0 + t; p < p1; p += 1024) {
-            const u32 to = d.col[p];
-            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
-            const ulonglong2 x = a[0], y = a[1];
-            u64* o = acc + (size_t)to * 6;
-            atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x.x & 0xFFFFFFFFull); atomicAdd(&o[2], x.x >> 32);
-            atomicAdd(&o[3], x.y); atomicAdd(&o[4], y.y); atomicMax(&o[5], y.x);
+        for (u32 pb = p0 + t; pb < p1; pb += 1024 * 4) {          // 4 edges per thread in flight
+            u32 to[4]; ulonglong2 x[4], y[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 p = pb + q * 1024;
+                if (p < p1) { to[q] = d.col[p]; const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4); x[q] = a[0]; y[q] = a[1]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (pb + q * 1024 < p1) {
+                u64* o = acc + (size_t)to[q] * 6;
+                atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x[q].x & 0xFFFFFFFFull); atomicAdd(&o[2], x[q].x >> 32);
+                atomicAdd(&o[3], x[q].y); atomicAdd(&o[4], y[q].y); atomicMax(&o[5], y[q].x);
+            }
         }
         __syncthreads();
         for (u32 v = t; v < N; v += 1024) if (acc[(size_t)v * 6]) in_flush(d, v, acc + (size_t)v * 6);
@@ -881,6 +899,8 @@ __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
 __global__ __launch_bounds__(256) void k_reset_window(Dev d) {
     const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
     const u64 nc = (u64)d.ncap + 1;
+    // (obkeys must be cleared here, not in K5: k5's rows reference OBIP ranks only, but a K1a of the next
+    // window may already be enqueued behind this kernel — same stream, so ordering is by launch order)
     for (u64 i = tid; i < nc; i += nt) { d.deg[i * SG_DEG_STRIDE] = 0; d.cursor[i] = 0; }
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
@@ -892,8 +912,6 @@ __global__ __launch_bounds__(256) void k_reset_window(Dev d) {
             a[0] = make_ulonglong2(0, 0); a[1] = make_ulonglong2(0, 0);
         }
     }
-    __syncthreads();
-    if (tid == 0) { d.ctr[C_OVF_N] = 0; d.ctr[C_DROPPED_CAP] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1133,6 +1151,7 @@ __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restri
 // one wave scores K5_U edges at a time (lane = hidden unit j): the index loads, then the 2*K5_U row
 // gathers of a step are independent and in flight together.
 #define K5_U 4
+template <bool RESET>
 __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
     const u32 E = (u32)d.ctr[C_N_EDGES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const float* __restrict__ We = Wh + 2 * SG_F_HID * SG_F_HID;
@@ -1183,6 +1202,16 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
             o.score = score; o.lat_z = d.latz[p]; o.err_ratio = d.errr[p]; o._pad = 0;
             d.rows[p] = o;
         }
+    }
+    if (RESET) {
+        // Window reset folded into the last kernel of the pipeline (nothing after it reads these arrays;
+        // the counters stay: sg_window_read / the next kc_prepare consume them).
+        const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
+        const u64 nc = (u64)d.ncap + 1;
+        for (u64 i = tid; i < nc; i += nt) { d.deg[i * SG_DEG_STRIDE] = 0; d.cursor[i] = 0; }
+        for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
+        for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
+        for (u64 i = tid; i <= d.obmask; i += nt) d.obkeys[i] = 0;
     }
 }
 
