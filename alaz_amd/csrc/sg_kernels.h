@@ -476,7 +476,8 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
             u64 nl = d.ctr[C_N_LABELS];                              // labels are cumulative across windows
             nl = red[2][0] > nl ? red[2][0] : nl; nl = n_labels_decl > nl ? n_labels_decl : nl;
             d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known;
-            d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_DROPPED_CAP] = red[4][0];   // K1b / K2 add their own drops afterwards d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
+            d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
+            d.ctr[C_DROPPED_CAP] = red[4][0];                        // K1b / K2 add their own drops afterwards
         }
     }
     // (b)
