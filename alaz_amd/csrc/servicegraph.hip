@@ -195,22 +195,17 @@ int grid_for(u64 items, int per_block, int cap = 2048) {
     return (int)std::max<u64>(1, std::min<u64>(g, (u64)cap));
 }
 
-int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union_n) {
+// ob_mode 1: collect this engine's own raw outbound IPs; 0: caller's union list (d_union, *d_union_n);
+// 2: all-gathered per-shard lists (d_union = [world][stride], element 0 of a row = count)
+int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union_n, u32 ob_mode = 1, u32 stride = 0, u32 gworld = 0) {
     int rc = sync_tables(e, s);
     if (rc) return rc;
     const Dev& d = e->d;
-    if (d.variant == 0 && e->window_events_in > e->cfg.max_window_events) {
-        e->err = "more events ingested in this window than max_window_events"; /* slabs may have overflowed into the counted drop path */
-    }
-    if (d.variant == 0) {
-        // pass B of K1 belongs to the K1 timing group: K1 = k1a_partition (per batch) + k1b_merge (per window)
+    {
         Timed tp(e, s, 2);
-        if (d_union == nullptr) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u);
-        else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap, 0u);
-    } else {
-        Timed tp(e, s, 2);
-        if (d_union == nullptr) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u);
-        else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap, 0u);
+        if (ob_mode == 1) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u, (const u32*)nullptr, 0u, 0u);
+        else if (ob_mode == 0) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap, 0u, (const u32*)nullptr, 0u, 0u);
+        else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 2u, d_union, stride, gworld);
     }
     if (d.variant == 0) {
         Timed t1(e, s, 7);                                   // group 7 = K1 pass B (k1b_merge)
@@ -313,6 +308,7 @@ int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n) {
     st.events_dropped_src += e->h_ctr[C_DROPPED_SRC];
     st.events_dropped_cap += e->h_ctr[C_DROPPED_CAP];
     st.events_misrouted += e->h_ctr[C_MISROUTED];
+    st.halo_overflow += e->h_ctr[C_HALO_OVF];
     if (e->h_ctr[C_N_EVENTS]) {
         // convertKernelTimeToUserspaceTime()/1e6 — aggregator/data.go:1740-1743, :1219 (u64 wrap arithmetic)
         st.last_window_tmin_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMIN_NS])) / 1000000ull);
@@ -547,7 +543,7 @@ int sg_ingest_device(sg_handle e, const sg_event* d_events, size_t n, void* stre
 int sg_window_close(sg_handle e, void* stream) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    return do_close(e, pick(e, stream), nullptr, nullptr);
+    return do_close(e, pick(e, stream), nullptr, nullptr, 1u);
 }
 
 int sg_window_obip_list(sg_handle e, uint32_t* d_list, uint32_t cap, uint32_t* d_n, void* stream) {
@@ -573,7 +569,48 @@ int sg_bind_buffers(sg_handle e, void* stats_sum, void* stats_max, void* const* 
 int sg_window_close_sharded(sg_handle e, const uint32_t* d_union_ips, const uint32_t* d_union_n, void* stream) {
     if (!e || !d_union_ips || !d_union_n) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    return do_close(e, pick(e, stream), d_union_ips, d_union_n);
+    return do_close(e, pick(e, stream), d_union_ips, d_union_n, 0u);
+}
+
+// Sharded close without a host round trip: d_gathered = the all-gather of every shard's
+// [count, ip, ip, ...] buffer (stride u32 per shard), straight from the collective.
+int sg_window_close_gathered(sg_handle e, const uint32_t* d_gathered, uint32_t stride, uint32_t world, void* stream) {
+    if (!e || !d_gathered || stride < 2 || world == 0 || world > 8) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if ((u64)(stride - 1) * world > e->ob_list_cap) { e->err = "gathered outbound-ip lists exceed the engine's list capacity"; return SG_ENOSPC; }
+    return do_close(e, pick(e, stream), d_gathered, nullptr, 2u, stride, world);
+}
+
+// Padded halo exchange (fixed-size all-to-all, no host synchronisation).  Lists are [world][capp + 1]
+// u32 with element 0 = count.  build: what this shard needs from each owner; pack: rows of layer l for
+// the lists the other shards sent (d_serve); unpack: received rows into the feature buffer (d_req).
+int sg_halo_build_padded(sg_handle e, uint32_t* d_req, uint32_t capp, void* stream) {
+    if (!e || !d_req || capp == 0 || e->cfg.world > 8) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = pick(e, stream);
+    Timed t(e, s, 6);
+    hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
+    hipLaunchKernelGGL(k6_halo_build_padded, dim3(1), dim3(256), 0, s, e->d, d_req, capp);
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
+}
+int sg_halo_pack_padded(sg_handle e, uint32_t l, const uint32_t* d_serve, uint32_t capp, float* d_rows, void* stream) {
+    if (!e || l < 1 || l > e->cfg.layers || !d_serve || !d_rows) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = pick(e, stream);
+    Timed t(e, s, 6);
+    hipLaunchKernelGGL(k6_pack_padded, dim3(grid_for((u64)e->cfg.world * capp * 16, 256)), dim3(256), 0, s, e->d.h[l], d_serve, capp, e->cfg.world, d_rows);
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
+}
+int sg_halo_unpack_padded(sg_handle e, uint32_t l, const uint32_t* d_req, uint32_t capp, const float* d_rows, void* stream) {
+    if (!e || l < 1 || l > e->cfg.layers || !d_req || !d_rows) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    hipStream_t s = pick(e, stream);
+    Timed t(e, s, 6);
+    hipLaunchKernelGGL(k6_unpack_padded, dim3(grid_for((u64)e->cfg.world * capp * 16, 256)), dim3(256), 0, s, e->d.h[l], d_req, capp, e->cfg.world, d_rows);
+    HIP_TRY(e, hipGetLastError());
+    return SG_OK;
 }
 
 int sg_window_features(sg_handle e, void* stream) {
@@ -612,7 +649,7 @@ int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_
     std::lock_guard<std::mutex> g(e->mu);
     hipStream_t s = e->stream;
     int rc;
-    if ((rc = do_close(e, s, nullptr, nullptr))) return rc;
+    if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
     if ((rc = do_features(e, s))) return rc;
     for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
     bool did = false;
@@ -628,7 +665,7 @@ int sg_window_run(sg_handle e, void* stream) {
     std::lock_guard<std::mutex> g(e->mu);
     hipStream_t s = pick(e, stream);
     int rc;
-    if ((rc = do_close(e, s, nullptr, nullptr))) return rc;
+    if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
     if ((rc = do_features(e, s))) return rc;
     for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
     bool did = false;

@@ -37,6 +37,7 @@ enum {
     C_EDGES_FOUND,    // edges found in the table before clamping
     C_OVF_N,          // records in the partition overflow list (window)
     C_N_LONG,         // rows longer than one wave (row sort work list)
+    C_HALO_OVF,       // halo requests that did not fit the per-pair capacity (must stay 0)
     C_COUNT = 16
 };
 

@@ -445,7 +445,8 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
 //   (b) collect the window's distinct raw outbound IPs (or take the sharded driver's union list),
 //       sort them (bitonic, global memory), drop duplicates -> ob_sorted, N_OBIP;
 //   (c) N = NK + NL + NOB.
-__global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_labels_decl, u32* list, const u32* n_in, u32 list_cap, u32 collect) {
+__global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_labels_decl, u32* list, const u32* n_in, u32 list_cap, u32 collect,
+                                                   const u32* seg, u32 seg_stride, u32 seg_world) {
     __shared__ u64 red[7][16];
     __shared__ u32 wsum[17];
     __shared__ u32 cnt;
@@ -489,6 +490,17 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
         }
         __syncthreads();
         n = cnt < list_cap ? cnt : list_cap;
+    } else if (collect == 2) {
+        // all-gathered per-shard lists: seg[r * seg_stride] = count, entries follow (sharded driver, no host sync)
+        u32 off = 0;
+        for (u32 r = 0; r < seg_world; r++) {
+            const u32* sr = seg + (size_t)r * seg_stride;
+            const u32 c = sr[0] < seg_stride - 1 ? sr[0] : seg_stride - 1;
+            for (u32 i = t; i < c; i += 1024) if (off + i < list_cap) list[off + i] = sr[1 + i];
+            off += c;
+        }
+        __syncthreads();
+        n = off < list_cap ? off : list_cap;
     } else {
         n = *n_in < list_cap ? *n_in : list_cap;
     }
@@ -1277,5 +1289,60 @@ __global__ __launch_bounds__(256) void k6_unpack(float* __restrict__ feat, const
     for (u32 t = blockIdx.x * 256 + threadIdx.x; t < n * 16; t += gridDim.x * 256) {
         const u32 i = t >> 4, q = t & 15;
         reinterpret_cast<float4*>(feat)[(size_t)ids[i] * 16 + q] = reinterpret_cast<const float4*>(rows)[(size_t)i * 16 + q];
+    }
+}
+
+// ---- padded halo exchange (no host synchronisation: fixed-size all-to-all) ----------------------------
+// req / serve layout: [world][capp + 1] u32, element 0 = count, ids follow.
+__global__ __launch_bounds__(256) void k6_halo_build_padded(Dev d, u32* req, u32 capp) {
+    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    __shared__ u32 part[8][256];
+    const u32 W = d.world < 8 ? d.world : 8;
+    const u32 per = (N + 255) / 256, beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
+    u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (u32 v = beg; v < end; v++) {
+        if (d.cursor[v] != 0xFFFFFFFFu || d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0) continue;
+        const u32 o = owner_of_dense(d, v, nk, nl);
+        if (o == d.rank) continue;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] += (o == (u32)k);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) part[k][threadIdx.x] = c[k];
+    __syncthreads();
+    if (threadIdx.x < W) {
+        const u32 k = threadIdx.x; u32 tot = 0;
+        for (int t = 0; t < 256; t++) { const u32 x = part[k][t]; part[k][t] = tot; tot += x; }
+        if (tot > capp) { atomicAdd(&d.ctr[C_HALO_OVF], (u64)(tot - capp)); tot = capp; }
+        req[(size_t)k * (capp + 1)] = tot;
+    }
+    __syncthreads();
+    u32 pos[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) pos[k] = part[k][threadIdx.x];
+    for (u32 v = beg; v < end; v++) {
+        if (d.cursor[v] != 0xFFFFFFFFu || d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0) continue;
+        const u32 o = owner_of_dense(d, v, nk, nl);
+        if (o == d.rank) continue;
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (o == (u32)k) { if (pos[k] < capp) req[(size_t)k * (capp + 1) + 1 + pos[k]] = v; pos[k]++; }
+    }
+}
+// rows[r][i][:] = feat[lists[r][1 + i]][:] for i < lists[r][0]   (pack: lists = what shard r asked of me)
+__global__ __launch_bounds__(256) void k6_pack_padded(const float* __restrict__ feat, const u32* __restrict__ lists, u32 capp, u32 world, float* __restrict__ rows) {
+    const u64 total = (u64)world * capp * 16;
+    for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < total; t += (u64)gridDim.x * 256) {
+        const u32 q = (u32)(t & 15); const u64 ri = t >> 4; const u32 r = (u32)(ri / capp), i = (u32)(ri % capp);
+        const u32* l = lists + (size_t)r * (capp + 1);
+        if (i < l[0]) reinterpret_cast<float4*>(rows)[ri * 16 + q] = reinterpret_cast<const float4*>(feat)[(size_t)l[1 + i] * 16 + q];
+    }
+}
+// feat[lists[r][1 + i]][:] = rows[r][i][:]   (unpack: lists = what I asked of shard r)
+__global__ __launch_bounds__(256) void k6_unpack_padded(float* __restrict__ feat, const u32* __restrict__ lists, u32 capp, u32 world, const float* __restrict__ rows) {
+    const u64 total = (u64)world * capp * 16;
+    for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < total; t += (u64)gridDim.x * 256) {
+        const u32 q = (u32)(t & 15); const u64 ri = t >> 4; const u32 r = (u32)(ri / capp), i = (u32)(ri % capp);
+        const u32* l = lists + (size_t)r * (capp + 1);
+        if (i < l[0]) reinterpret_cast<float4*>(feat)[(size_t)l[1 + i] * 16 + q] = reinterpret_cast<const float4*>(rows)[ri * 16 + q];
     }
 }

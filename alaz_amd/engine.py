@@ -30,7 +30,8 @@ EXPORTS = [
     "sg_window_run", "sg_window_rows_buffer", "sg_window_close", "sg_window_obip_list",
     "sg_window_close_sharded", "sg_bind_buffers", "sg_window_features", "sg_window_layer", "sg_window_score",
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
-    "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_outbound_ips", "sg_stats_get",
+    "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
+    "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
     "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_route",
 ]
 
@@ -48,7 +49,7 @@ class SgStats(C.Structure):
                 ("events_dropped_cap", C.c_uint64), ("windows", C.c_uint64), ("last_window_events", C.c_uint64),
                 ("last_window_edges", C.c_uint64), ("last_window_nodes", C.c_uint64),
                 ("last_window_tmin_ms", C.c_int64), ("last_window_tmax_ms", C.c_int64), ("h2d_bytes", C.c_uint64),
-                ("events_misrouted", C.c_uint64)]
+                ("events_misrouted", C.c_uint64), ("halo_overflow", C.c_uint64)]
 
 
 class ServiceGraphError(RuntimeError):
@@ -99,6 +100,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_window_feat_buffer": (C.c_int, [H, u32, C.POINTER(P), C.POINTER(sz)]),
         "sg_halo_build": (C.c_int, [H, P, u32, P, P]), "sg_halo_pack": (C.c_int, [H, u32, P, u32, P, P]),
         "sg_halo_unpack": (C.c_int, [H, u32, P, u32, P, P]),
+        "sg_window_close_gathered": (C.c_int, [H, P, u32, u32, P]),
+        "sg_halo_build_padded": (C.c_int, [H, P, u32, P]), "sg_halo_pack_padded": (C.c_int, [H, u32, P, u32, P, P]),
+        "sg_halo_unpack_padded": (C.c_int, [H, u32, P, u32, P, P]),
         "sg_window_outbound_ips": (C.c_int, [H, P, sz, C.POINTER(sz)]),
         "sg_stats_get": (C.c_int, [H, C.POINTER(SgStats)]),
         "sg_timing_enable": (C.c_int, [H, C.c_int]), "sg_timing_reset": (C.c_int, [H]),
@@ -223,6 +227,13 @@ class ServiceGraph:
     def halo_build(self, d_ids: int, cap: int, d_counts: int, stream: int = 0): self._ck(self._l.sg_halo_build(self._h, d_ids, cap, d_counts, stream or None))
     def halo_pack(self, l: int, d_ids: int, n: int, d_rows: int, stream: int = 0): self._ck(self._l.sg_halo_pack(self._h, l, d_ids, n, d_rows, stream or None))
     def halo_unpack(self, l: int, d_ids: int, n: int, d_rows: int, stream: int = 0): self._ck(self._l.sg_halo_unpack(self._h, l, d_ids, n, d_rows, stream or None))
+
+    def window_close_gathered(self, d_gathered: int, stride: int, world: int, stream: int = 0):
+        self._ck(self._l.sg_window_close_gathered(self._h, d_gathered, stride, world, stream or None))
+
+    def halo_build_padded(self, d_req: int, capp: int, stream: int = 0): self._ck(self._l.sg_halo_build_padded(self._h, d_req, capp, stream or None))
+    def halo_pack_padded(self, l: int, d_serve: int, capp: int, d_rows: int, stream: int = 0): self._ck(self._l.sg_halo_pack_padded(self._h, l, d_serve, capp, d_rows, stream or None))
+    def halo_unpack_padded(self, l: int, d_req: int, capp: int, d_rows: int, stream: int = 0): self._ck(self._l.sg_halo_unpack_padded(self._h, l, d_req, capp, d_rows, stream or None))
 
     def outbound_ips(self) -> np.ndarray:
         n = C.c_size_t(0)

@@ -169,6 +169,7 @@ typedef struct sg_stats {
     int64_t  last_window_tmax_ms;
     uint64_t h2d_bytes;
     uint64_t events_misrouted;     /* world > 1: events fed to the wrong shard (see sg_route)    */
+    uint64_t halo_overflow;        /* halo requests beyond the per-pair capacity (must be 0)     */
 } sg_stats;
 
 typedef struct sg_engine* sg_handle;
@@ -231,6 +232,10 @@ int sg_window_close(sg_handle h, void* stream);      /* K2: canonical ids, CSR; 
  * allowed) and passes the total count in *d_union_n (device).                                   */
 int sg_window_obip_list(sg_handle h, uint32_t* d_list, uint32_t cap, uint32_t* d_n, void* stream);
 int sg_window_close_sharded(sg_handle h, const uint32_t* d_union_ips, const uint32_t* d_union_n, void* stream);
+/* Sharded close with no host round trip: d_gathered is the all-gather of every shard's
+ * [count, ip, ip, ...] u32 buffer (sg_window_obip_list with d_list = buf + 1, d_n = buf), `stride` u32
+ * per shard.                                                                                     */
+int sg_window_close_gathered(sg_handle h, const uint32_t* d_gathered, uint32_t stride, uint32_t world, void* stream);
 int sg_window_features(sg_handle h, void* stream);   /* K3b: node + edge features from reduced stats    */
 int sg_window_layer(sg_handle h, uint32_t l, void* stream);  /* K4: rows with out-edges owned here + all rows without out-edges */
 int sg_window_score(sg_handle h, void* stream);      /* K5 */
@@ -258,6 +263,11 @@ int sg_bind_buffers(sg_handle h, void* stats_sum, void* stats_max, void* const* 
  * of ids owned by shard k.  pack/unpack move rows of layer l between the feature buffer and a
  * contiguous exchange buffer.  Call after the node statistics have been reduced.                */
 int sg_halo_build(sg_handle h, uint32_t* d_ids, uint32_t cap, uint32_t* d_counts, void* stream);
+/* Padded variants for a fixed-size all-to-all (no host synchronisation): lists are [world][capp + 1]
+ * u32, element 0 = count.  Requests beyond capp are dropped and counted in sg_stats.halo_overflow.   */
+int sg_halo_build_padded(sg_handle h, uint32_t* d_req, uint32_t capp, void* stream);
+int sg_halo_pack_padded(sg_handle h, uint32_t l, const uint32_t* d_serve, uint32_t capp, float* d_rows, void* stream);
+int sg_halo_unpack_padded(sg_handle h, uint32_t l, const uint32_t* d_req, uint32_t capp, const float* d_rows, void* stream);
 int sg_halo_pack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, float* d_rows, void* stream);
 int sg_halo_unpack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, const float* d_rows, void* stream);
 

@@ -30,6 +30,11 @@ class NumpyBackend:
         self.W, self.layers, self.rank, self.world, self.ncap, self.max_obip = weights.astype(np.float32), layers, rank, world, ncap, max_obip
         self.device = torch.device("cpu")
         self.stats_flat = torch.zeros(ncap * 12, dtype=torch.int64)
+        self.stats_sum = self.stats_flat[: ncap * 10]; self.stats_max = self.stats_flat[ncap * 10:]
+        self.capp = ncap
+        self.ob_all = torch.zeros((world, max_obip + 1), dtype=torch.int64)
+        self.serve = torch.zeros((world, self.capp + 1), dtype=torch.int64)
+        self.rows_in = torch.zeros((world, self.capp, F_HID), dtype=torch.float32)
         self.misrouted = 0
         self.edges = {}
 
@@ -63,9 +68,11 @@ class NumpyBackend:
         return int(replay.hash32(ref)[0] % self.world)
 
     # ---- backend interface of sharded.run_window ----
-    def obip_list(self):
+    def ob_local(self):
         ips = sorted({n[2] for k in self.edges for n in k if n[0] == OBIP})
-        return torch.tensor(ips, dtype=torch.int64)
+        buf = torch.zeros(self.max_obip + 1, dtype=torch.int64)
+        buf[0] = len(ips); buf[1:1 + len(ips)] = torch.tensor(ips, dtype=torch.int64)
+        return buf
 
     def _dense(self, node):
         t, v, ip = node
@@ -77,8 +84,9 @@ class NumpyBackend:
             return int(replay.hash32(np.array([ref], dtype=np.uint32))[0] % self.world)
         return int(sharded.owner_of_obip(np.array([self.ob[v - self.nk - self.nl]], dtype=np.uint32), self.world)[0])
 
-    def close(self, union):
-        self.ob = np.unique(union.numpy().astype(np.int64))
+    def close_gathered(self):
+        g = self.ob_all.numpy()
+        self.ob = np.unique(np.concatenate([g[r, 1:1 + int(g[r, 0])] for r in range(self.world)]).astype(np.int64))
         self.N = self.nk + self.nl + len(self.ob)
         rows = sorted((self._dense(f), self._dense(t), a) for (f, t), a in self.edges.items())
         self.frm = np.array([r[0] for r in rows], dtype=np.int64); self.to = np.array([r[1] for r in rows], dtype=np.int64)
@@ -111,8 +119,11 @@ class NumpyBackend:
 
     def halo_requests(self):
         need = sorted({int(v) for v in self.to if self.out_deg[v] > 0 and self.owner_of_dense(int(v)) != self.rank})
-        groups = [[v for v in need if self.owner_of_dense(v) == k] for k in range(self.world)]
-        return [len(g) for g in groups], torch.tensor([v for g in groups for v in g], dtype=torch.int64)
+        self.req = torch.zeros((self.world, self.capp + 1), dtype=torch.int64)
+        for k in range(self.world):
+            g = [v for v in need if self.owner_of_dense(v) == k]
+            self.req[k, 0] = len(g); self.req[k, 1:1 + len(g)] = torch.tensor(g, dtype=torch.int64)
+        return self.req
 
     def _layer_weights(self, l):
         off = 0
@@ -136,14 +147,20 @@ class NumpyBackend:
             assert not np.isnan(mean).any(), "a neighbour row was neither computed here nor received"
             hout[v] = np.maximum(hin[v].astype(np.float64) @ Ws.astype(np.float64) + mean @ Wn.astype(np.float64) + b, 0.0)
 
-    def pack(self, l, ids):
-        rows = self.h[l][ids.numpy()]
-        assert not np.isnan(rows).any(), "asked for a row this shard does not own"
-        return torch.from_numpy(np.ascontiguousarray(rows))
+    def pack(self, l):
+        out = torch.zeros((self.world, self.capp, F_HID), dtype=torch.float32)
+        for r in range(self.world):
+            n = int(self.serve[r, 0]); ids = self.serve[r, 1:1 + n].numpy()
+            rows = self.h[l][ids]
+            assert not np.isnan(rows).any(), "asked for a row this shard does not own"
+            out[r, :n] = torch.from_numpy(np.ascontiguousarray(rows))
+        return out
 
-    def unpack(self, l, ids, rows):
-        if len(ids):
-            self.h[l][ids.numpy()] = rows.numpy()
+    def unpack(self, l):
+        for r in range(self.world):
+            n = int(self.req[r, 0])
+            if n:
+                self.h[l][self.req[r, 1:1 + n].numpy()] = self.rows_in[r, :n].numpy()
 
     def score(self):
         off = sum(2 * (F_IN if k == 0 else F_HID) * F_HID + F_HID for k in range(self.layers))

@@ -98,15 +98,18 @@ def test_route_events_matches_the_ownership_rule():
         assert np.bincount(sh, minlength=world).min() > len(ev) / world / 3
 
 
-def test_all_to_all_v_fallback_path():
-    """_all_to_all_v on a 1-process group: identity."""
+def test_collectives_on_a_single_process_group():
+    """The three collectives of the window on a 1-process group: identity."""
     port = _free_port()
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
-        x = torch.arange(12, dtype=torch.float32).reshape(3, 4); y = torch.empty_like(x)
-        sharded.DistComm().all_to_all_v(y, x, [3], [3])
+        c = sharded.DistComm()
+        x = torch.arange(12, dtype=torch.float32).reshape(1, 3, 4); y = torch.empty_like(x)
+        c.all_to_all_equal(y, x)
         assert torch.equal(x, y)
+        g = torch.empty(1, 5, dtype=torch.int64); c.all_gather_into(g, torch.arange(5)); assert g[0].tolist() == [0, 1, 2, 3, 4]
+        t = torch.tensor([3, 4]); c.all_reduce_(t, "max"); assert t.tolist() == [3, 4]
     finally:
         dist.destroy_process_group()
 
