@@ -483,7 +483,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
     }
     // (b)
     u32 n;
-    if (collect) {
+    if (collect == 1) {
         for (u32 i = t; i <= d.obmask; i += 1024) {
             const u64 k = d.obkeys[i];
             if (k) { const u32 pos = atomicAdd(&cnt, 1u); if (pos < list_cap) list[pos] = (u32)k; }
