@@ -345,3 +345,63 @@ def test_outbound_ip_capacity_overflow_is_counted():
         want = o.edge_dict()
         got = engine_edge_dict(rows, shim, labels, g.outbound_ips())
         assert set(got) <= set(want) and all(got[k][:5] == want[k][:5] for k in got)
+
+
+def _feed(g, ev, chunk=1 << 18):
+    for i in range(0, len(ev), chunk):
+        while g.ingest(ev[i:i + chunk]) != 0:
+            pass
+
+
+def test_config3_graph_two_layers_against_the_oracle():
+    """BASELINE config 3's graph (10k pods / 5k services / 1M edges, power-law out-degree up to 3750) with 2M
+    events and 2 SAGE layers, on the partitioned K1 (4096 partitions): row-for-row against the oracle
+    (~590k edges; rows come out in the same canonical order, so arrays are compared directly)."""
+    from oracle import pyoracle
+    topo = replay.make_topology(10_000, 1_000_000, replay.SEED_BASE + 3)
+    ev, labels = replay.make_events(topo, 2_000_000, replay.SEED_BASE + 3)
+    g = _engine(topo.n_nodes, 1_250_000, 2, max_labels=128, max_outbound_ips=128, max_window_events=len(ev))
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    _feed(g, ev)
+    g.set_label_count(len(labels))
+    rows = g.flush_window()
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(2), 2)
+    want = o.edge_rows()
+    st = g.stats()
+    assert st.events_dropped_cap == 0 and st.last_window_events == o.window_events and len(rows) == len(want) > 500_000
+    for f in ("from_ref", "to_ref", "count", "err_count", "sum_ns", "max_ns", "sumsq_us", "err_ratio"):
+        assert np.array_equal(rows[f], want[f]), f
+    assert np.abs(rows["score"] - want["score"]).max() <= 1e-5
+    assert (np.abs(rows["lat_z"] - want["lat_z"]) <= 1e-5 * np.maximum(1.0, np.abs(want["lat_z"]))).all()
+
+
+def test_config3_full_size_invariants():
+    """BASELINE config 3 at full size (10M events, 1M edges, L=2): size-independent properties — event
+    conservation, checksums of the integer accumulators against numpy, canonical strictly increasing
+    row order, scores inside (0, 1)."""
+    topo = replay.make_topology(10_000, 1_000_000, replay.SEED_BASE + 3)
+    ev, labels = replay.make_events(topo, 10_000_000, replay.SEED_BASE + 3)
+    g = _engine(topo.n_nodes, 1_250_000, 2, max_labels=128, max_outbound_ips=128, max_window_events=len(ev))
+    HostShim().apply(g, topo.k8s_ops())
+    _feed(g, ev)
+    g.set_label_count(len(labels))
+    rows = g.flush_window()
+    st = g.stats()
+    acc = np.isin(ev["saddr"], topo.pod_ips)
+    assert st.events_dropped_cap == 0 and st.events_dropped_src == int((~acc).sum())
+    assert int(rows["count"].astype(np.uint64).sum()) == int(acc.sum()) == st.last_window_events
+    assert int(rows["sum_ns"].sum()) == int(ev["duration_ns"][acc].sum())
+    us = ev["duration_ns"][acc] // np.uint64(1000)
+    assert int(rows["sumsq_us"].sum()) == int((us * us).sum())
+    assert int(rows["max_ns"].max()) == int(ev["duration_ns"][acc].max())
+    assert int(rows["err_count"].sum()) == int((ev["status"][acc] >= 500).sum())
+    NK, NL = topo.n_nodes, len(labels)
+
+    def dense(ref):
+        t, v = ref >> 30, (ref & 0x3FFFFFFF).astype(np.int64)
+        return np.where(t == 0, v, np.where(t == 1, NK + v, NK + NL + v))
+    key = dense(rows["from_ref"]) * (1 << 20) + dense(rows["to_ref"])
+    assert (np.diff(key) > 0).all()
+    assert ((rows["score"] > 0) & (rows["score"] < 1)).all() and np.isfinite(rows["lat_z"]).all()
+    key_ev = np.unique((ev["saddr"][acc].astype(np.uint64) << np.uint64(32)) | ev["daddr"][acc].astype(np.uint64))
+    assert len(rows) == len(key_ev)                 # HTTP-only trace: one edge per distinct (saddr, daddr) of accepted events
