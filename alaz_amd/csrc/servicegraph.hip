@@ -66,6 +66,13 @@ struct sg_engine {
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
+
+    // windows in flight: every slot has its own window buffers and stream; the members above (d, stream,
+    // d_ob_list, d_ob_n, closed, window_events_in) are the working copy of slot `cur`
+    struct WinSlot { Dev d; hipStream_t stream; u32* ob_list; u32* ob_n; bool closed; u64 events_in; };
+    std::vector<WinSlot> slots;
+    int cur = 0;
+    sg_edge_out* last_rows = nullptr;
     std::vector<TimingRec> trecs;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -111,6 +118,7 @@ struct Timed {
 int sync_tables(sg_engine* e, hipStream_t s) {
     if (!e->tab_dirty) return SG_OK;
     HIP_TRY(e, hipEventSynchronize(e->tab_ev));            // previous upload finished reading h_iptab
+    if (e->slots.size() > 1) HIP_TRY(e, hipDeviceSynchronize());   // other windows in flight still read the old table
     const size_t tot = (size_t)e->ipcap + e->ip2cap;
     std::memset(e->h_iptab, 0xFF, tot * sizeof(u64));
     u64* t1 = e->h_iptab; u64* t2 = e->h_iptab + e->ipcap;
@@ -146,6 +154,16 @@ int sync_tables(sg_engine* e, hipStream_t s) {
     HIP_TRY(e, hipEventRecord(e->tab_ev, s));
     e->tab_dirty = false;
     return SG_OK;
+}
+
+// make slot (cur + 1) % NW the working window; the closed window keeps running on its own stream
+void rotate_window(sg_engine* e) {
+    if (e->slots.size() < 2) return;
+    sg_engine::WinSlot& a = e->slots[e->cur];
+    a.d = e->d; a.stream = e->stream; a.ob_list = e->d_ob_list; a.ob_n = e->d_ob_n; a.closed = e->closed; a.events_in = e->window_events_in;
+    e->cur = (e->cur + 1) % (int)e->slots.size();
+    const sg_engine::WinSlot& b = e->slots[e->cur];
+    e->d = b.d; e->stream = b.stream; e->d_ob_list = b.ob_list; e->d_ob_n = b.ob_n; e->closed = b.closed; e->window_events_in = b.events_in;
 }
 
 int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
@@ -388,15 +406,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         d.sa = 16;
         d.ovf_cap = 1u << 16;
     }
-    size_t eslots = ME;
     if (d.variant == 0) {
-        eslots = std::max<size_t>(ME, (size_t)d.np * d.pcap);
-        CR(dev_alloc(e, &d.slab_s, (size_t)d.np * d.nwg * (d.ss + 1)));
-        CR(dev_alloc(e, &d.slab_a, (size_t)d.np * d.nwg * d.sa * 5));
-        CR(dev_alloc(e, &d.ovf, (size_t)d.ovf_cap * 5));
-        CR(dev_alloc(e, &d.part_n, d.np));
-        CR(dev_alloc(e, &d.acc_src, (size_t)d.np * d.pcap * 4));
-        CR(dev_alloc(e, &d.e_rank, (size_t)d.np * d.pcap));
         e->ip_lds = e->ipcap <= SG_IP_LDS_MAX;
         e->k1a_lds = (size_t)K1A_CT * 8 + (size_t)K1A_CT * 32 + (size_t)d.np * 8 + (e->ip_lds ? (size_t)e->ipcap * 8 : 0);
         e->k1b_lds = (size_t)K1B_HT * (8 + 32);
@@ -405,34 +415,56 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }
-    CR(dev_alloc(e, &d.ekeys, e->ecap, 0xFF));
-    CR(dev_alloc(e, &d.eacc, (size_t)e->ecap * 4));
-    if (d.variant == 1) d.acc_src = d.eacc;
     d.emask = e->ecap - 1;
-    CR(dev_alloc(e, &d.obkeys, e->obcap));
-    CR(dev_alloc(e, &d.wgstat, (size_t)SG_MAX_K1_WGS * WS_WORDS));
-    CR(dev_alloc(e, &d.ctr, C_COUNT));
-    CR(dev_alloc(e, &d.ob_sorted, d.max_obip));
-    CR(dev_alloc(e, &e->d_ob_list, e->ob_list_cap));
-    CR(dev_alloc(e, &e->d_ob_n, 4));
-    CR(dev_alloc(e, &d.tile_cnt, e->ecap / K2_TILE));
-    CR(dev_alloc(e, &d.tile_off, e->ecap / K2_TILE));
-    CR(dev_alloc(e, &d.e_slot, ME)); CR(dev_alloc(e, &d.e_from, eslots)); CR(dev_alloc(e, &d.e_to, eslots));
-    CR(dev_alloc(e, &d.longrows, (size_t)d.ncap + 1));
     d.in_dense = d.ncap <= K3_IN_NODES ? 1u : 0u;
     e->k3in_lds = d.in_dense ? (size_t)d.ncap * 48 : (size_t)K3_IN_HT * 52;
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
-    CR(dev_alloc(e, &d.deg, ((size_t)d.ncap + 1) * SG_DEG_STRIDE)); CR(dev_alloc(e, &d.rowptr, (size_t)d.ncap + 1)); CR(dev_alloc(e, &d.cursor, (size_t)d.ncap + 1));
-    CR(dev_alloc(e, &d.col, ME)); CR(dev_alloc(e, &d.cslot, ME)); CR(dev_alloc(e, &d.csr_from, ME));
-    CR(dev_alloc(e, &d.sort_k, 2 * ME)); CR(dev_alloc(e, &d.sort_v, 2 * ME));
-    CR(dev_alloc(e, &d.acc_csr, ME * 4));
-    CR(dev_alloc(e, &d.st_sum, (size_t)d.ncap * SG_NODE_STAT_SUM_WORDS)); CR(dev_alloc(e, &d.st_max, (size_t)d.ncap * SG_NODE_STAT_MAX_WORDS));
-    CR(dev_alloc(e, &d.x0, (size_t)d.ncap * SG_F_IN));
-    for (u32 l = 1; l <= cfg->layers; l++) CR(dev_alloc(e, &d.h[l], (size_t)d.ncap * SG_F_HID));
-    CR(dev_alloc(e, &d.P, (size_t)d.ncap * SG_F_HID)); CR(dev_alloc(e, &d.Q, (size_t)d.ncap * SG_F_HID));
-    CR(dev_alloc(e, &d.efeat, ME * SG_F_EDGE)); CR(dev_alloc(e, &d.latz, ME)); CR(dev_alloc(e, &d.errr, ME));
-    CR(dev_alloc(e, &d.rows, ME));
+    // everything a window owns; allocated once per slot
+    auto alloc_window = [&](Dev& w, u32*& ob_list, u32*& ob_n) -> int {
+#define LR(call) do { int _rc = (call); if (_rc) return _rc; } while (0)
+        size_t eslots = ME;
+        if (w.variant == 0) {
+            eslots = std::max<size_t>(ME, (size_t)w.np * w.pcap);
+            LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * (w.ss + 1)));
+            LR(dev_alloc(e, &w.slab_a, (size_t)w.np * w.nwg * w.sa * 5));
+            LR(dev_alloc(e, &w.ovf, (size_t)w.ovf_cap * 5));
+            LR(dev_alloc(e, &w.part_n, w.np));
+            LR(dev_alloc(e, &w.acc_src, (size_t)w.np * w.pcap * 4));
+            LR(dev_alloc(e, &w.e_rank, (size_t)w.np * w.pcap));
+        }
+        LR(dev_alloc(e, &w.ekeys, e->ecap, 0xFF));
+        LR(dev_alloc(e, &w.eacc, (size_t)e->ecap * 4));
+        if (w.variant == 1) w.acc_src = w.eacc;
+        LR(dev_alloc(e, &w.obkeys, e->obcap));
+        LR(dev_alloc(e, &w.wgstat, (size_t)SG_MAX_K1_WGS * WS_WORDS));
+        LR(dev_alloc(e, &w.ctr, C_COUNT));
+        LR(dev_alloc(e, &w.ob_sorted, w.max_obip));
+        LR(dev_alloc(e, &ob_list, e->ob_list_cap));
+        LR(dev_alloc(e, &ob_n, 4));
+        LR(dev_alloc(e, &w.tile_cnt, e->ecap / K2_TILE));
+        LR(dev_alloc(e, &w.tile_off, e->ecap / K2_TILE));
+        LR(dev_alloc(e, &w.e_slot, ME)); LR(dev_alloc(e, &w.e_from, eslots)); LR(dev_alloc(e, &w.e_to, eslots));
+        LR(dev_alloc(e, &w.longrows, (size_t)w.ncap + 1));
+        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
+        LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cslot, ME)); LR(dev_alloc(e, &w.csr_from, ME));
+        LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
+        LR(dev_alloc(e, &w.acc_csr, ME * 4));
+        LR(dev_alloc(e, &w.st_sum, (size_t)w.ncap * SG_NODE_STAT_SUM_WORDS)); LR(dev_alloc(e, &w.st_max, (size_t)w.ncap * SG_NODE_STAT_MAX_WORDS));
+        LR(dev_alloc(e, &w.x0, (size_t)w.ncap * SG_F_IN));
+        for (u32 l = 1; l <= cfg->layers; l++) LR(dev_alloc(e, &w.h[l], (size_t)w.ncap * SG_F_HID));
+        LR(dev_alloc(e, &w.P, (size_t)w.ncap * SG_F_HID)); LR(dev_alloc(e, &w.Q, (size_t)w.ncap * SG_F_HID));
+        LR(dev_alloc(e, &w.efeat, ME * SG_F_EDGE)); LR(dev_alloc(e, &w.latz, ME)); LR(dev_alloc(e, &w.errr, ME));
+        LR(dev_alloc(e, &w.rows, ME));
+        // arm the per-workgroup statistic slots (tmin = ~0)
+        std::vector<u64> init((size_t)SG_MAX_K1_WGS * WS_WORDS, 0);
+        for (int i = 0; i < SG_MAX_K1_WGS; i++) init[(size_t)i * WS_WORDS + WS_TMIN] = ~0ull;
+        HIP_TRY(e, hipMemcpy(w.wgstat, init.data(), init.size() * sizeof(u64), hipMemcpyHostToDevice));
+#undef LR
+        return SG_OK;
+    };
+    CH(hipStreamSynchronize(e->stream));
+    CR(alloc_window(d, e->d_ob_list, e->d_ob_n));
     CR(dev_alloc(e, &e->d_W, weights_count(cfg->layers)));
     d.W = e->d_W;
     for (int i = 0; i < kStageSlots; i++) {
@@ -440,12 +472,19 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         CR(dev_alloc(e, &e->d_stage[i], e->cfg.max_batch));
         CH(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
     }
-    // arm the per-workgroup statistic slots (tmin = ~0)
+    CH(hipStreamSynchronize(e->stream));
+    // further windows in flight: same tables and weights, own window buffers and stream
     {
-        std::vector<u64> init((size_t)SG_MAX_K1_WGS * WS_WORDS, 0);
-        for (int i = 0; i < SG_MAX_K1_WGS; i++) init[(size_t)i * WS_WORDS + WS_TMIN] = ~0ull;
-        CH(hipMemcpyAsync(d.wgstat, init.data(), init.size() * sizeof(u64), hipMemcpyHostToDevice, e->stream));
-        CH(hipStreamSynchronize(e->stream));
+        const u32 nw = std::min<u32>(std::max<u32>(cfg->windows_in_flight, 1), 8);
+        e->slots.resize(nw);
+        e->slots[0] = sg_engine::WinSlot{e->d, e->stream, e->d_ob_list, e->d_ob_n, false, 0};
+        for (u32 k = 1; k < nw; k++) {
+            sg_engine::WinSlot& w = e->slots[k];
+            w.d = e->d; w.closed = false; w.events_in = 0; w.ob_list = nullptr; w.ob_n = nullptr; w.stream = nullptr;
+            CH(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+            CR(alloc_window(w.d, w.ob_list, w.ob_n));
+        }
+        CH(hipDeviceSynchronize());
     }
 #undef CR
 #undef CH
@@ -455,7 +494,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
 
 int sg_destroy(sg_handle e) {
     if (!e) return SG_EINVAL;
-    if (e->stream) hipStreamSynchronize(e->stream);
+    hipDeviceSynchronize();
+    for (size_t k = 0; k < e->slots.size(); k++) if ((int)k != e->cur && e->slots[k].stream) hipStreamDestroy(e->slots[k].stream);
     for (void* p : e->allocs) hipFree(p);
     if (e->h_iptab) hipHostFree(e->h_iptab);
     if (e->h_kind) hipHostFree(e->h_kind);
@@ -670,8 +710,10 @@ int sg_window_run(sg_handle e, void* stream) {
     for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
     bool did = false;
     if ((rc = do_score(e, s, true, true, &did))) return rc;
-    if (did) { e->closed = false; return SG_OK; }
-    return do_reset(e, s);
+    if (did) e->closed = false; else if ((rc = do_reset(e, s))) return rc;
+    e->last_rows = e->d.rows;
+    rotate_window(e);                                    // the next sg_ingest* goes to the next slot (if any)
+    return SG_OK;
 }
 
 int sg_window_buffers(sg_handle e, void** stats_sum, void** stats_max, void** counters, size_t* n_nodes_cap) {
@@ -690,7 +732,7 @@ int sg_window_feat_buffer(sg_handle e, uint32_t l, void** rows, size_t* row_floa
 }
 int sg_window_rows_buffer(sg_handle e, void** rows) {
     if (!e || !rows) return SG_EINVAL;
-    *rows = e->d.rows;
+    *rows = e->last_rows ? e->last_rows : e->d.rows;
     return SG_OK;
 }
 

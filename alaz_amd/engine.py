@@ -41,7 +41,7 @@ class SgConfig(C.Structure):
                 ("max_labels", C.c_uint32), ("max_outbound_ips", C.c_uint32), ("max_ips", C.c_uint32),
                 ("max_edges", C.c_uint64), ("max_batch", C.c_uint32), ("layers", C.c_uint32),
                 ("rank", C.c_uint32), ("world", C.c_uint32), ("k1_variant", C.c_uint32),
-                ("max_window_events", C.c_uint64)]
+                ("max_window_events", C.c_uint64), ("windows_in_flight", C.c_uint32), ("_reserved", C.c_uint32)]
 
 
 class SgStats(C.Structure):
@@ -126,11 +126,11 @@ class ServiceGraph:
 
     def __init__(self, *, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 1024,
                  max_outbound_ips: int = 1024, max_ips: int = 0, max_batch: int = 1 << 20, device: int = 0,
-                 rank: int = 0, world: int = 1, k1_variant: int = 0, max_window_events: int = 0):
+                 rank: int = 0, world: int = 1, k1_variant: int = 0, max_window_events: int = 0, windows_in_flight: int = 1):
         self._l = load_library()
         cfg = SgConfig(self._l.sg_abi_version(), device, max_known_nodes, max_labels, max_outbound_ips,
                        max_ips or max_known_nodes, max_edges, max_batch, layers, rank, world, k1_variant,
-                       max_window_events)
+                       max_window_events, windows_in_flight, 0)
         h = C.c_void_p()
         rc = self._l.sg_create(C.byref(cfg), C.byref(h))
         if rc != SG_OK:

@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--batches", type=int, default=0, help="distinct event batches in the HBM ring (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--windows", type=int, default=4, help="window slots in flight inside the engine (sg_config.windows_in_flight)")
     return ap.parse_args()
 
 
@@ -106,7 +107,7 @@ def bench_single(a, device):
     ev_all, labels = replay.make_events(topo, Ev * nb, seed)
     g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.25) + 4096, layers=L,
                             max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=1 << 18,
-                            max_window_events=Ev)
+                            max_window_events=Ev, windows_in_flight=a.windows)
     g.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
     g.load_weights(weights.make_weights(L))
     for i in range(topo.n_pods):
@@ -115,8 +116,7 @@ def bench_single(a, device):
         g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
     g.set_label_count(len(labels))
 
-    stream = torch.cuda.Stream()
-    s = stream.cuda_stream
+    s = 0          # NULL stream argument: the engine enqueues every window on its own slot's stream
     dev = [torch.from_numpy(ev_all[i * Ev:(i + 1) * Ev].view(np.uint8).reshape(-1)).cuda() for i in range(nb)]
     torch.cuda.synchronize()
 
@@ -160,7 +160,7 @@ def bench_single(a, device):
         "config": {"workload": f"C{a.config}: {c['pods']} pods / {topo.n_svcs} services / {c['edges']} edges, "
                                f"{Ev} HTTP l7 events per window, {L}-layer SAGE + MLP score; {nb}-batch HBM ring",
                    "events_per_window": Ev, "edges_per_window": E, "nodes": int(st.last_window_nodes), "layers": L,
-                   "parallelism": "1 GPU"},
+                   "windows_in_flight": a.windows, "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = k1a_partition + k1b_merge", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": k1_us,

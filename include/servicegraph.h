@@ -147,6 +147,11 @@ typedef struct sg_config {
                                    1 = global edge table + device-scope atomics (any size)       */
     uint64_t max_window_events; /* most events one window may carry (sizes the K1 record slabs;
                                    0 = max_batch)                                               */
+    uint32_t windows_in_flight; /* 1..8 window slots, each with its own buffers and HIP stream:
+                                   sg_window_run() closes the current window on its slot's stream
+                                   and moves on to the next slot, so the (latency-bound) close of
+                                   window w overlaps the ingest of window w+1.  0 = 1.              */
+    uint32_t _reserved;
 } sg_config;
 
 #define SG_MAX_LAYERS 4u
@@ -219,7 +224,8 @@ int sg_flush_window(sg_handle h, uint64_t window_end_ms, sg_edge_out* out, size_
 /* Enqueue-only form of the same pipeline (K2..K5 + reset, no copy-out, no host sync) for
  * callers that keep results on the device (sg_window_rows_buffer) or time the pipeline.         */
 int sg_window_run(sg_handle h, void* stream);
-int sg_window_rows_buffer(sg_handle h, void** d_rows);   /* device sg_edge_out[max_edges]        */
+int sg_window_rows_buffer(sg_handle h, void** d_rows);   /* device sg_edge_out[max_edges] of the window
+                                                             sg_window_run closed last (valid until its slot is reused) */
 
 /* The same pipeline in stages, so that a sharded driver can run its exchanges in between.
  * Order: close -> [allreduce node stats] -> features -> for l in 0..L-1 { layer(l) ->
