@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--batches", type=int, default=0, help="distinct event batches in the HBM ring (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--windows", type=int, default=4, help="window slots in flight inside the engine (sg_config.windows_in_flight)")
+    ap.add_argument("--windows", type=int, default=1, help="window slots in flight for the timed region (sg_config.windows_in_flight); "
+                                                            "1 keeps the per-kernel timings uncontended")
+    ap.add_argument("--overlap-windows", type=int, default=4, help="extra diagnostic pass with this many windows in flight (0 = skip)")
     return ap.parse_args()
 
 
@@ -167,6 +169,30 @@ def bench_single(a, device):
                      "k1a_partition_us": k1a[0], "k1b_merge_us": k1b[0], "launches": k1a[1]},
         "kernel_group_us": {"K1a": round(k1a[0], 2), "K1b": round(k1b[0], 2), **{f"K{k}": round(v[0], 2) for k, v in k_us.items() if k > 1}},
     }
+    # diagnostic (never `value`): the same steps with several windows in flight inside one engine — the
+    # latency-bound close of window w overlaps the ingest of window w+1 (per-kernel durations stretch,
+    # throughput rises); no timing events in this pass
+    if a.overlap_windows > 1:
+        g2 = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.25) + 4096, layers=L,
+                                 max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=1 << 18,
+                                 max_window_events=Ev, windows_in_flight=a.overlap_windows)
+        g2.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
+        g2.load_weights(weights.make_weights(L))
+        for i in range(topo.n_pods):
+            g2.upsert_pod(int(topo.pod_ips[i]), i)
+        for j in range(topo.n_svcs):
+            g2.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
+        g2.set_label_count(len(labels))
+        for i in range(a.warmup):
+            g2.ingest_device(dev[i % nb].data_ptr(), Ev, 0); g2.window_run(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(a.steps):
+            g2.ingest_device(dev[(a.warmup + i) % nb].data_ptr(), Ev, 0); g2.window_run(0)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        res["overlapped"] = {"windows_in_flight": a.overlap_windows, "events_per_s": Ev * a.steps / dt2, "ms_per_step": dt2 / a.steps * 1e3}
+        g2.close()
     # diagnostic (never `value`): the same windows fed from host memory through sg_ingest
     # (pinned staging ring + H2D over PCIe), DESIGN.md "PCIe-inclusive rate"
     hs = min(10, a.steps)
