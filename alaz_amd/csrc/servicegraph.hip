@@ -5,6 +5,7 @@
 // stream.  All kernels live in sg_kernels.h.  There is no CPU compute path in this file: every
 // entry point that produces results launches HIP kernels, and sg_create() fails without a device.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -170,16 +171,19 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     if (n == 0) return SG_OK;
     int rc = sync_tables(e, s);
     if (rc) return rc;
-    {
+    if (e->d.variant == 0) {
+        // single-kernel groups are timed by the dispatch's own begin/end stamps (hipExtLaunchKernel start/stop
+        // events): the kernel's duration as rocprofv3 reports it, without the event-record round trip
+        const bool tk = (e->timing >> 1) & 1u;
+        hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
+        if (e->ip_lds) hipExtLaunchKernelGGL(k1a_partition<true>, dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, e->d, d_ev, (u64)n);
+        else hipExtLaunchKernelGGL(k1a_partition<false>, dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, e->d, d_ev, (u64)n);
+        if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 1; e->trecs.push_back(r); }
+    } else {
         Timed t(e, s, 1);
-        if (e->d.variant == 0) {
-            if (e->ip_lds) hipLaunchKernelGGL(k1a_partition<true>, dim3(e->d.nwg), dim3(K1A_THREADS), e->k1a_lds, s, e->d, d_ev, (u64)n);
-            else hipLaunchKernelGGL(k1a_partition<false>, dim3(e->d.nwg), dim3(K1A_THREADS), e->k1a_lds, s, e->d, d_ev, (u64)n);
-        } else {
-            u64 want = (n + 255) / 256;
-            int grid = (int)std::min<u64>(want, (u64)e->k1_grid);
-            hipLaunchKernelGGL(k1_resolve_aggregate, dim3(grid), dim3(256), 0, s, e->d, d_ev, (u64)n);
-        }
+        u64 want = (n + 255) / 256;
+        int grid = (int)std::min<u64>(want, (u64)e->k1_grid);
+        hipLaunchKernelGGL(k1_resolve_aggregate, dim3(grid), dim3(256), 0, s, e->d, d_ev, (u64)n);
     }
     HIP_TRY(e, hipGetLastError());
     e->st.events_in += n;
@@ -225,9 +229,11 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         else if (ob_mode == 0) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap, 0u, (const u32*)nullptr, 0u, 0u);
         else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 2u, d_union, stride, gworld);
     }
-    if (d.variant == 0) {
-        Timed t1(e, s, 7);                                   // group 7 = K1 pass B (k1b_merge)
-        hipLaunchKernelGGL(k1b_merge, dim3(d.np), dim3(K1B_THREADS), e->k1b_lds, s, d);
+    if (d.variant == 0) {                                    // group 7 = K1 pass B (k1b_merge), kernel-exact timing as for pass A
+        const bool tk = (e->timing >> 7) & 1u;
+        hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
+        hipExtLaunchKernelGGL(k1b_merge, dim3(d.np), dim3(K1B_THREADS), (uint32_t)e->k1b_lds, s, ta, tb, 0u, d);
+        if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
     }
     {
         Timed t(e, s, 2);
@@ -255,7 +261,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
 int do_features(sg_engine* e, hipStream_t s) {
     const Dev& d = e->d;
     Timed t(e, s, 3);
-    hipLaunchKernelGGL(k3_node_features, dim3(grid_for(d.ncap, 256)), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k3_node_features, dim3(grid_for(d.ncap, 128)), dim3(256), 0, s, d);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
@@ -408,7 +414,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     }
     if (d.variant == 0) {
         e->ip_lds = e->ipcap <= SG_IP_LDS_MAX;
-        e->k1a_lds = (size_t)K1A_CT * 8 + (size_t)K1A_CT * 32 + (size_t)d.np * 8 + (e->ip_lds ? (size_t)e->ipcap * 8 : 0);
+        e->k1a_lds = (size_t)K1A_CT * 8 + (size_t)K1A_CT * 32 + (size_t)d.np * 8 + 64 + (e->ip_lds ? (size_t)e->ipcap * 8 : 0);
         e->k1b_lds = (size_t)K1B_HT * (8 + 32);
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
@@ -420,6 +426,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     e->k3in_lds = d.in_dense ? (size_t)d.ncap * 48 : (size_t)K3_IN_HT * 52;
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
+    CR(dev_alloc(e, &d.dbg, (size_t)4 * 4096 * 8));
     // everything a window owns; allocated once per slot
     auto alloc_window = [&](Dev& w, u32*& ob_list, u32*& ob_n) -> int {
 #define LR(call) do { int _rc = (call); if (_rc) return _rc; } while (0)
@@ -794,6 +801,13 @@ int sg_timing_reset(sg_handle e) {
     std::lock_guard<std::mutex> g(e->mu);
     for (auto& r : e->trecs) { e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b); }
     e->trecs.clear();
+    return SG_OK;
+}
+int sg_debug_stamps(sg_handle e, uint64_t* out, size_t n) {
+    if (!e || !out) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpy(out, e->d.dbg, std::min<size_t>(n, (size_t)4 * 4096 * 8) * sizeof(u64), hipMemcpyDeviceToHost));
     return SG_OK;
 }
 int sg_timing_get(sg_handle e, int kernel, double* avg_us, uint64_t* launches) {

@@ -53,6 +53,11 @@ enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, 
 // One out-degree counter per 32-byte sector: device-scope atomics serialise per sector (~12 ns each,
 // profiles/r01_atomic_probe.txt), so neighbouring nodes must not share one.
 #define SG_DEG_STRIDE 8
+// (Replicating a hub row's counter 8x was tried, r01k: k1b_merge -2 us, but the single-workgroup
+// k2_rowptr then reads 8 sectors per row: +18 us.)
+
+// phase stamps for kernel tuning (off unless SG_ABLATE & 0x100): 100 MHz wall clock, thread 0 of a workgroup
+#define SG_STAMP(d, kid, k) do { if (((d).ablate & 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096) (d).dbg[((size_t)(kid) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
 
 // Everything the kernels need, passed by value as one kernel argument.
 struct Dev {
@@ -82,6 +87,7 @@ struct Dev {
     u32*   e_rank;                            // [np*pcap] position of the edge inside its row (arrival order)
     u32 in_dense;                             // 1: node-indexed LDS accumulation (ncap small enough), 0: hashed
     u32 ablate;                               // tuning switches (SG_ABLATE), 0 in production
+    u64* dbg;                                 // phase time stamps (SG_ABLATE & 0x100): [kernel 0..3][4096 workgroups][8]
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs
     u32* tile_cnt;  u32* tile_off;            // compaction scratch

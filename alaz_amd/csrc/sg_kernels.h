@@ -57,26 +57,28 @@ __device__ __forceinline__ bool table_slot(u64* keys, u32 mask, u64 key, u64 emp
     return false;
 }
 
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { u64 o = __shfl_xor(v, s, 64); v = o < v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { u64 o = __shfl_xor(v, s, 64); v = o > v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-    return v;
-}
-__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-    return v;
-}
+// Wave-wide reductions without LDS traffic: an xor butterfly inside each row of 16 lanes with DPP
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row results
+// are combined through v_readlane.  All 64 lanes must be active; every lane gets the result.
+// (A __shfl_xor chain is six dependent ds_bpermute round trips per value: seven values per wave at
+// the end of k1a_partition cost ~1.5 us that way.)
+template <int CTRL> __device__ __forceinline__ u32 dpp32(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ u64 dpp64(u64 v) { return (u64)dpp32<CTRL>((u32)v) | ((u64)dpp32<CTRL>((u32)(v >> 32)) << 32); }
+__device__ __forceinline__ u32 rdlane32(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ u64 rdlane64(u64 v, int l) { return (u64)rdlane32((u32)v, l) | ((u64)rdlane32((u32)(v >> 32), l) << 32); }
+#define SG_WAVE_REDUCE(T, DPP, RD, OP)                                                                   \
+    { T o;                                                                                                \
+      o = DPP<0xB1>(v); v = OP(v, o); o = DPP<0x4E>(v); v = OP(v, o);                                     \
+      o = DPP<0x141>(v); v = OP(v, o); o = DPP<0x140>(v); v = OP(v, o);                                   \
+      const T r0 = RD(v, 0), r1 = RD(v, 16), r2 = RD(v, 32), r3 = RD(v, 48);                              \
+      return OP(OP(r0, r1), OP(r2, r3)); }
+#define SG_OP_MIN(a, b) ((b) < (a) ? (b) : (a))
+#define SG_OP_MAX(a, b) ((b) > (a) ? (b) : (a))
+#define SG_OP_ADD(a, b) ((a) + (b))
+__device__ __forceinline__ u64 wave_min_u64(u64 v) SG_WAVE_REDUCE(u64, dpp64, rdlane64, SG_OP_MIN)
+__device__ __forceinline__ u64 wave_max_u64(u64 v) SG_WAVE_REDUCE(u64, dpp64, rdlane64, SG_OP_MAX)
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) SG_WAVE_REDUCE(u64, dpp64, rdlane64, SG_OP_ADD)
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) SG_WAVE_REDUCE(u32, dpp32, rdlane32, SG_OP_ADD)
 
 // "error" classification: HTTP/HTTP2 >= 500; POSTGRES/REDIS/MYSQL == 2 (ebpf/c/postgres.c:91,
 // redis.c:10, mysql.c:36).
@@ -157,12 +159,13 @@ __device__ __forceinline__ bool k1_resolve(const Dev& d, const u64* iptab, const
     const bool sf = ip_lookup(iptab, d.ipmask, d.iptab2, d.ipmask2, saddr, spod, ssvc);
     if (!sf || spod == SG_NONE) { L.dsrc++; return false; }     // data.go:829-832: source must be a pod
     u32 from = SG_MAKE_REF(SG_REF_KNOWN, spod);
-    u32 from_owner = owner_hash_ref(from);
+    const bool sharded = d.world > 1;
+    u32 from_owner = sharded ? owner_hash_ref(from) : 0u;
 
     u32 dpod = SG_NONE, dsvc = SG_NONE, to, to_owner;
     const bool df = ip_lookup(iptab, d.ipmask, d.iptab2, d.ipmask2, daddr, dpod, dsvc);
-    if (df && dsvc != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dsvc); to_owner = owner_hash_ref(to); }       // service first (:840-843)
-    else if (df && dpod != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dpod); to_owner = owner_hash_ref(to); }  // then pod (:845-849)
+    if (df && dsvc != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dsvc); to_owner = sharded ? owner_hash_ref(to) : 0u; }       // service first (:840-843)
+    else if (df && dpod != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dpod); to_owner = sharded ? owner_hash_ref(to) : 0u; }  // then pod (:845-849)
     else if (label != 0) {                                       // outbound, Host header (:851-854)
         if (label > d.max_labels) { L.dcap++; return false; }
         to = SG_MAKE_REF(SG_REF_LABEL, label - 1); to_owner = owner_hash_ref(to);
@@ -173,7 +176,7 @@ __device__ __forceinline__ bool k1_resolve(const Dev& d, const u64* iptab, const
         to = SG_MAKE_REF(SG_REF_OBIP, os); to_owner = owner_hash_obip(daddr);
     }
     if (flags & SG_EV_REVERSE) { u32 t = from; from = to; to = t; t = from_owner; from_owner = to_owner; to_owner = t; }  // dto.go:226-231
-    if (d.world > 1 && (from_owner % d.world) != d.rank) { L.misr++; return false; }
+    if (sharded && (from_owner % d.world) != d.rank) { L.misr++; return false; }
     e.key = ((u64)from << 32) | (u64)to;
     e.err = is_error(proto, status);
     L.acc++;
@@ -236,7 +239,20 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
 #define K1B_LPP     4        // lanes per piece
 #define K1B_U       4
 
-__device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return (hash_key64(key) >> 11) & (d.np - 1); }
+// Issue a global load NOW and leave it in flight; a later s_waitcnt (inline asm that names the
+// destination registers as in/out operands) is the matching wait.  Written as inline asm because the
+// compiler sinks a speculative load below the branch that makes its use conditional (k1b_merge:
+// header -> test -> records became two dependent round trips) and puts waits between conditional
+// loads.  vmcnt is in-order for loads, so the compiler's own (unaware) waits can only become
+// stronger, never too weak.  Rule: no loop-carried value and no branch merge between an issue and
+// its wait (a compiler-inserted register copy there would read a register that is still being loaded).
+typedef u32 v4u_t __attribute__((ext_vector_type(4)));
+typedef u32 v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gload16_issue(v4u_t& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gload8_issue(v2u_t& dst, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory"); }
+
+__device__ __forceinline__ u32 part_of_hash(const Dev& d, u32 hk) { return (hk >> 11) & (d.np - 1); }
+__device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return part_of_hash(d, hash_key64(key)); }
 
 __device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
     const u64 idx = atomicAdd(&d.ctr[C_OVF_N], 1ull);
@@ -250,8 +266,8 @@ __device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1
 //   slab_a[(p*nwg + w) * sa * 5]    : sa aggregate records {key, cnt | err<<32, sum_ns, max_ns, sumsq_us}
 // A piece's header and its first 7 singles share one 128-byte line, so pass B usually needs one
 // line per piece.
-__device__ __forceinline__ void emit_single(const Dev& d, u32* fS, u32 w, u64 key, u64 dur, u32 err, K1Local& L) {
-    const u32 p = part_of(d, key);
+__device__ __forceinline__ void emit_single(const Dev& d, u32* fS, u32 w, u32 hk, u64 key, u64 dur, u32 err, K1Local& L) {
+    const u32 p = part_of_hash(d, hk);
     const u32 pos = atomicAdd(&fS[p], 1u);
     if (pos < d.ss) d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1) + 1 + pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31));
     else { const u64 us = dur / 1000ull; ovf_append(d, key, 1ull | ((u64)err << 32), dur, dur, us * us, L); }
@@ -276,83 +292,176 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     u64* cacc = ckey + K1A_CT;                                       // [K1A_CT][4]
     u32* fS = reinterpret_cast<u32*>(cacc + K1A_CT * 4);             // [np]
     u32* fA = fS + d.np;                                             // [np]
-    u64* ipl = reinterpret_cast<u64*>(fA + d.np);                    // [ipmask + 1] when IPLDS
+    u64* red = reinterpret_cast<u64*>(fA + d.np);                    // [8] workgroup statistics (WS_* order)
+    u64* ipl = red + 8;                                              // [ipmask + 1] when IPLDS
     const u32 w = blockIdx.x, t = threadIdx.x;
     const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
     const u64 per = (n + d.nwg - 1) / d.nwg;
     const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
-    // K1A_G events per thread are fetched together (8 x 16 B in flight per lane): the first group is
-    // issued before the LDS set-up, each next group before the current one is folded in
+    if (beg >= end) return;                                          // no share of this batch: pieces and statistics stay as they are
+    const u64 last = end - 1;
+    SG_STAMP(d, 0, 0);
+    // K1A_G events per thread are fetched together (8 x 16 B in flight per lane).  Loads return in issue
+    // order, so the small set-up loads (join table, this workgroup's piece headers) go out first, the
+    // first event group right behind them; the LDS set-up then waits for the set-up loads only
+    // (vmcnt(8): the eight event loads stay in flight).  Out-of-range lanes re-read the share's last
+    // event and ignore it, so there is no branch between the loads.
+    static_assert(K1A_G == 4 && SG_IP_LDS_MAX / K1A_THREADS == 4, "written out for 4 event pairs and 4 table words per lane");
     u64 i = beg + t;
-    uint4 a[K1A_G], b[K1A_G];
-#pragma unroll
-    for (int q = 0; q < K1A_G; q++) { const u64 j = i + (u64)q * K1A_THREADS; if (j < end) { a[q] = pe[2 * j]; b[q] = pe[2 * j + 1]; } }
-    for (u32 i = t; i < K1A_CT; i += K1A_THREADS) ckey[i] = SG_EKEY_EMPTY;
-    for (u32 i = t; i < K1A_CT * 4; i += K1A_THREADS) cacc[i] = 0;
-    for (u32 p = t; p < d.np; p += K1A_THREADS) { const uint4 h = d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)]; fS[p] = h.x; fA[p] = h.y; }
-    if (IPLDS) for (u32 i = t; i <= d.ipmask; i += K1A_THREADS) ipl[i] = d.iptab[i];
-    const u64* iptab = IPLDS ? ipl : d.iptab;
-    __syncthreads();
-
+#define K1A_ISSUE(base)                                                                                           \
+        { const u64 j0 = (base), j1 = j0 + K1A_THREADS, j2 = j1 + K1A_THREADS, j3 = j2 + K1A_THREADS;               \
+          const uint4* q0 = pe + 2 * (j0 < end ? j0 : last); const uint4* q1 = pe + 2 * (j1 < end ? j1 : last);     \
+          const uint4* q2 = pe + 2 * (j2 < end ? j2 : last); const uint4* q3 = pe + 2 * (j3 < end ? j3 : last);     \
+          gload16_issue(ea0, q0); gload16_issue(eb0, q0 + 1); gload16_issue(ea1, q1); gload16_issue(eb1, q1 + 1);   \
+          gload16_issue(ea2, q2); gload16_issue(eb2, q2 + 1); gload16_issue(ea3, q3); gload16_issue(eb3, q3 + 1); }
     K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
-    while (i < end) {
-        uint4 ca[K1A_G], cb[K1A_G];
+    const u64* iptab = IPLDS ? ipl : d.iptab;
+    auto resolve = [&](const u64 idx, const v4u_t va, const v4u_t vb, K1Ev& e) -> bool {
+        if (idx >= end) return false;
+        const uint4 ca = make_uint4(va.x, va.y, va.z, va.w), cb = make_uint4(vb.x, vb.y, vb.z, vb.w);
+        if (d.ablate & 4u) { e.key = ((u64)ca.x << 32) | ca.y; e.dur = (u64)cb.x | ((u64)cb.y << 32); e.err = 0; return true; }
+        return k1_resolve(d, iptab, ca, cb, L, e);
+    };
+    auto insert = [&](const K1Ev& e) {
+        if (d.ablate & 1u) { if (e.key == 0x1234567ull) L.dcap++; return; }
+        const u32 hk = hash_key64(e.key);
+        u32 h = hk & (K1A_CT - 1);
+        int slot = -1;
 #pragma unroll
-        for (int q = 0; q < K1A_G; q++) { ca[q] = a[q]; cb[q] = b[q]; }
-        const u64 cur = i;
-        i += (u64)K1A_G * K1A_THREADS;
-#pragma unroll
-        for (int q = 0; q < K1A_G; q++) { const u64 j = i + (u64)q * K1A_THREADS; if (j < end) { a[q] = pe[2 * j]; b[q] = pe[2 * j + 1]; } }
-#pragma unroll
-        for (int q = 0; q < K1A_G; q++) {
-            if (cur + (u64)q * K1A_THREADS >= end) break;
-            K1Ev e; bool ok;
-            if (d.ablate & 4u) { e.key = ((u64)ca[q].x << 32) | ca[q].y; e.dur = (u64)cb[q].x | ((u64)cb[q].y << 32); e.err = 0; ok = true; }
-            else ok = k1_resolve(d, iptab, ca[q], cb[q], L, e);
-            if (!ok) continue;
-            if (d.ablate & 1u) { if (e.key == 0x1234567ull) L.dcap++; continue; }
-            u32 h = hash_key64(e.key) & (K1A_CT - 1);
-            int slot = -1;
-#pragma unroll
-            for (int pr = 0; pr < 2; pr++) {
-                u64 k = ((volatile u64*)ckey)[h];
-                if (k == SG_EKEY_EMPTY) { k = atomicCAS(&ckey[h], SG_EKEY_EMPTY, e.key); if (k == SG_EKEY_EMPTY) k = e.key; }
-                if (k == e.key) { slot = (int)h; break; }
-                h = (h + 1) & (K1A_CT - 1);
-            }
-            if (slot >= 0) {
-                const u64 us = e.dur / 1000ull;
-                atomicAdd(&cacc[slot * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&cacc[slot * 4 + 1], e.dur);
-                atomicMax(&cacc[slot * 4 + 2], e.dur); atomicAdd(&cacc[slot * 4 + 3], us * us);
-            } else if (!(d.ablate & 2u)) emit_single(d, fS, w, e.key, e.dur, e.err, L);
+        for (int pr = 0; pr < 2; pr++) {
+            u64 k = ((volatile u64*)ckey)[h];
+            if (k == SG_EKEY_EMPTY) { k = atomicCAS(&ckey[h], SG_EKEY_EMPTY, e.key); if (k == SG_EKEY_EMPTY) k = e.key; }
+            if (k == e.key) { slot = (int)h; break; }
+            h = (h + 1) & (K1A_CT - 1);
         }
+        if (slot >= 0) {
+            const u64 us = e.dur / 1000ull;
+            atomicAdd(&cacc[slot * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&cacc[slot * 4 + 1], e.dur);
+            atomicMax(&cacc[slot * 4 + 2], e.dur); atomicAdd(&cacc[slot * 4 + 3], us * us);
+        } else if (!(d.ablate & 2u)) emit_single(d, fS, w, hk, e.key, e.dur, e.err, L);
+    };
+    // One copy of the per-event code, run four times (not unrolled): the kernel body is executed once
+    // per workgroup, so every instruction is an instruction-cache miss the first time through, and
+    // four inlined copies of the join cost more in fetch stalls than the loop does in selects.
+#define K1A_FOLD(base)                                                                                            \
+        { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(eb0), "+v"(ea1), "+v"(eb1), "+v"(ea2), "+v"(eb2), "+v"(ea3), "+v"(eb3) : : "memory"); \
+          _Pragma("unroll 1")                                                                                       \
+          for (u32 q = 0; q < K1A_G; q++) {                                                                         \
+              const v4u_t va = q == 0 ? ea0 : q == 1 ? ea1 : q == 2 ? ea2 : ea3;                                    \
+              const v4u_t vb = q == 0 ? eb0 : q == 1 ? eb1 : q == 2 ? eb2 : eb3;                                    \
+              K1Ev e;                                                                                               \
+              if (resolve((base) + (u64)q * K1A_THREADS, va, vb, e)) insert(e);                                     \
+          } }
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory")   /* LDS-only: does not drain the global stores */
+    {
+        v2u_t ip0, ip1, ip2, ip3; v4u_t hdr;
+        v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
+        if (IPLDS) {
+            gload8_issue(ip0, d.iptab + (t & d.ipmask)); gload8_issue(ip1, d.iptab + ((t + K1A_THREADS) & d.ipmask));
+            gload8_issue(ip2, d.iptab + ((t + 2 * K1A_THREADS) & d.ipmask)); gload8_issue(ip3, d.iptab + ((t + 3 * K1A_THREADS) & d.ipmask));
+        }
+        gload16_issue(hdr, d.slab_s + ((size_t)(t < d.np ? t : 0) * d.nwg + w) * (d.ss + 1));
+        K1A_ISSUE(i);
+        for (u32 k = t; k < K1A_CT; k += K1A_THREADS) ckey[k] = SG_EKEY_EMPTY;
+        for (u32 k = t; k < K1A_CT * 4; k += K1A_THREADS) cacc[k] = 0;
+        if (IPLDS) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ip0), "+v"(ip1), "+v"(ip2), "+v"(ip3), "+v"(hdr) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(hdr) : : "memory");
+        if (t < d.np) { fS[t] = hdr.x; fA[t] = hdr.y; }
+        if (IPLDS) {
+            if (t <= d.ipmask) ipl[t] = (u64)ip0.x | ((u64)ip0.y << 32);
+            if (t + K1A_THREADS <= d.ipmask) ipl[t + K1A_THREADS] = (u64)ip1.x | ((u64)ip1.y << 32);
+            if (t + 2 * K1A_THREADS <= d.ipmask) ipl[t + 2 * K1A_THREADS] = (u64)ip2.x | ((u64)ip2.y << 32);
+            if (t + 3 * K1A_THREADS <= d.ipmask) ipl[t + 3 * K1A_THREADS] = (u64)ip3.x | ((u64)ip3.y << 32);
+        }
+        if (t < 8) red[t] = t == WS_TMIN ? ~0ull : 0ull;
+        if (d.np > K1A_THREADS) {                                    // more partitions than threads: the remaining headers (waits for everything)
+            for (u32 p = t + K1A_THREADS; p < d.np; p += K1A_THREADS) { const uint4 h = d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)]; fS[p] = h.x; fA[p] = h.y; }
+        }
+        LDS_BARRIER();
+        SG_STAMP(d, 0, 1);
+        K1A_FOLD(i);
+        SG_STAMP(d, 0, 3);
     }
-    __syncthreads();
+    for (i += (u64)K1A_G * K1A_THREADS; i < end; i += (u64)K1A_G * K1A_THREADS) {
+        v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
+        K1A_ISSUE(i);
+        K1A_FOLD(i);
+    }
+#undef K1A_ISSUE
+#undef K1A_FOLD
+    LDS_BARRIER();
+    SG_STAMP(d, 0, 4);
     // flush the cache: one record per cached edge
     for (u32 s = t; s < K1A_CT; s += K1A_THREADS) {
         const u64 k = ckey[s];
         if (k == SG_EKEY_EMPTY || (d.ablate & 2u)) continue;
         const u64 x0 = cacc[s * 4], x1 = cacc[s * 4 + 1], x2 = cacc[s * 4 + 2], x3 = cacc[s * 4 + 3];
-        if ((x0 & 0xFFFFFFFFull) == 1ull) emit_single(d, fS, w, k, x1, (u32)(x0 >> 32), L);
+        if ((x0 & 0xFFFFFFFFull) == 1ull) emit_single(d, fS, w, hash_key64(k), k, x1, (u32)(x0 >> 32), L);
         else emit_agg(d, fA, w, k, x0, x1, x2, x3, L);
     }
-    __syncthreads();
+    // workgroup statistics: wave reduce -> LDS -> one thread updates this workgroup's private line
+    {
+        const u64 tmin = wave_min_u64(L.tmin), tmax = wave_max_u64(L.tmax);
+        const u32 ml = (u32)wave_max_u64(L.maxlabel);
+        const u32 ds = wave_sum_u32(L.dsrc), dc = wave_sum_u32(L.dcap), mr = wave_sum_u32(L.misr), ac = wave_sum_u32(L.acc);
+        if ((t & 63) == 0) {
+            if (ac) { atomicMin(&red[WS_TMIN], tmin); atomicMax(&red[WS_TMAX], tmax); atomicAdd(&red[WS_ACCEPTED], (u64)ac); }
+            if (ml) atomicMax(&red[WS_MAXLABEL], (u64)ml);
+            if (ds) atomicAdd(&red[WS_DROPPED_SRC], (u64)ds);
+            if (dc) atomicAdd(&red[WS_DROPPED_CAP], (u64)dc);
+            if (mr) atomicAdd(&red[WS_MISROUTED], (u64)mr);
+        }
+    }
+    LDS_BARRIER();
     for (u32 p = t; p < d.np; p += K1A_THREADS)
         d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)] = make_uint4(fS[p] < d.ss ? fS[p] : d.ss, fA[p] < d.sa ? fA[p] : d.sa, 0u, 0u);
-    k1_publish_stats(d, L);
+    SG_STAMP(d, 0, 5);
+    if (t == 0) {
+        u64* g = d.wgstat + (size_t)(blockIdx.x % SG_MAX_K1_WGS) * WS_WORDS;
+        if (red[WS_ACCEPTED]) { atomicMin(&g[WS_TMIN], red[WS_TMIN]); atomicMax(&g[WS_TMAX], red[WS_TMAX]); atomicAdd(&g[WS_ACCEPTED], red[WS_ACCEPTED]); }
+        if (red[WS_MAXLABEL]) atomicMax(&g[WS_MAXLABEL], red[WS_MAXLABEL]);
+        if (red[WS_DROPPED_SRC]) atomicAdd(&g[WS_DROPPED_SRC], red[WS_DROPPED_SRC]);
+        if (red[WS_DROPPED_CAP]) atomicAdd(&g[WS_DROPPED_CAP], red[WS_DROPPED_CAP]);
+        if (red[WS_MISROUTED]) atomicAdd(&g[WS_MISROUTED], red[WS_MISROUTED]);
+    }
+    SG_STAMP(d, 0, 6);
+#undef LDS_BARRIER
 }
 
-// Pass B.  Workgroup p owns partition p: it reads the headers of its nwg pieces, walks all their
-// records as one flat index space (K1B_U independent loads in flight per thread), merges them in
-// an LDS table and writes every distinct edge once with plain stores:
+// Pass B.  Workgroup p owns partition p: it reads its nwg pieces, merges them in an LDS table and
+// writes every distinct edge once with plain stores:
 //   e_from/e_to [p*pcap + i]  dense endpoints        acc_src [(p*pcap + i)*4]  accumulators
-//   deg[from] += 1 (atomic u32; a row's edges are spread over the partitions)
+//   deg[from] += 1 (atomic u32; a row's edges are spread over the partitions; the returned value is the
+//   edge's position inside its CSR row)
 __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* hkey = reinterpret_cast<u64*>(smem);                       // [K1B_HT]
     u64* hacc = hkey + K1B_HT;                                       // [K1B_HT][4]
     __shared__ u32 n_drop, out_n;
     const u32 p = blockIdx.x, t = threadIdx.x;
+    SG_STAMP(d, 1, 0);
+    // counters the tail needs: fetched now so their latency hides behind the merge
+    const u64 ovf_n = d.ctr[C_OVF_N];
+    const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
+    static_assert(K1B_U == 4, "the speculative first round is written out for 4 singles per lane");
+    const u32 sub = t % K1B_LPP;
+    // K1B_LPP lanes walk one piece (record r belongs to lane r % K1B_LPP).  A piece's header, the lane's
+    // first K1B_U singles and its first aggregate are fetched together (the slab memory is always
+    // mapped, stale contents are ignored): one round of latency for a typical piece (<= 16 singles)
+    // instead of three dependent ones.  The first round is in flight during the LDS set-up.
+#define K1B_SIDX(u) (1 + ((sub + (u) * K1B_LPP) < d.ss ? (sub + (u) * K1B_LPP) : 0))
+#define K1B_ISSUE(piece, pa)                                                                              \
+        gload16_issue(hv, (piece));                                                                        \
+        gload16_issue(xv0, (piece) + K1B_SIDX(0)); gload16_issue(xv1, (piece) + K1B_SIDX(1));              \
+        gload16_issue(xv2, (piece) + K1B_SIDX(2)); gload16_issue(xv3, (piece) + K1B_SIDX(3));              \
+        gload16_issue(y01, (pa) + (size_t)sub * 5); gload16_issue(y23, (pa) + (size_t)sub * 5 + 2);        \
+        gload8_issue(y4, (pa) + (size_t)sub * 5 + 4)
+#define K1B_WAIT() asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv), "+v"(xv0), "+v"(xv1), "+v"(xv2), "+v"(xv3), "+v"(y01), "+v"(y23), "+v"(y4) : : "memory")
+    const u32 w0 = t / K1B_LPP, wc = w0 < d.nwg ? w0 : 0;
+    const uint4* piece0 = d.slab_s + ((size_t)p * d.nwg + wc) * (d.ss + 1);
+    const u64* pa0 = d.slab_a + ((size_t)p * d.nwg + wc) * d.sa * 5;
+    v4u_t hv, xv0, xv1, xv2, xv3, y01, y23; v2u_t y4;
+    K1B_ISSUE(piece0, pa0);
     for (u32 i = t; i < K1B_HT; i += K1B_THREADS) hkey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < K1B_HT * 4; i += K1B_THREADS) hacc[i] = 0;
     if (t == 0) { n_drop = 0; out_n = 0; }
@@ -369,21 +478,13 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         if (!ok) { atomicAdd(&n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
         atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
     };
-    // K1B_LPP lanes walk one piece (record r belongs to lane r % K1B_LPP); each lane fetches up to
-    // K1B_U records before merging any, so a piece of <= 16 singles costs one round of loads.
-    for (u32 w = t / K1B_LPP; w < d.nwg; w += K1B_THREADS / K1B_LPP) {
-        const u32 sub = t % K1B_LPP;
-        const uint4* piece = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
-        const u64* __restrict__ pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
-        // header, the lane's first K1B_U singles and its first aggregate are fetched together (the
-        // slab memory is always mapped, stale contents are ignored): one round of latency for a
-        // typical piece instead of three dependent ones.
-        const uint4 h = piece[0];
-        uint4 x[K1B_U]; u64 y[5];
-#pragma unroll
-        for (int u = 0; u < K1B_U; u++) x[u] = piece[1 + ((sub + u * K1B_LPP) < d.ss ? (sub + u * K1B_LPP) : 0)];
-        { const u64* q = pa + (size_t)sub * 5; y[0] = q[0]; y[1] = q[1]; y[2] = q[2]; y[3] = q[3]; y[4] = q[4]; }
-        if (!(h.x | h.y)) continue;
+    auto merge_piece = [&](const uint4* piece, const u64* pa, const v4u_t h, const v4u_t q0, const v4u_t q1, const v4u_t q2, const v4u_t q3,
+                           const v4u_t z01, const v4u_t z23, const v2u_t z4) {
+        if (!(h.x | h.y)) return;
+        uint4 x[K1B_U] = {make_uint4(q0.x, q0.y, q0.z, q0.w), make_uint4(q1.x, q1.y, q1.z, q1.w),
+                          make_uint4(q2.x, q2.y, q2.z, q2.w), make_uint4(q3.x, q3.y, q3.z, q3.w)};
+        u64 y[5] = {(u64)z01.x | ((u64)z01.y << 32), (u64)z01.z | ((u64)z01.w << 32), (u64)z23.x | ((u64)z23.y << 32),
+                    (u64)z23.z | ((u64)z23.w << 32), (u64)z4.x | ((u64)z4.y << 32)};
         const u32 ns = h.x < d.ss ? h.x : d.ss, na = h.y < d.sa ? h.y : d.sa;
         for (u32 r0 = sub; r0 < ns; r0 += K1B_LPP * K1B_U) {
             if (r0 != sub) {
@@ -400,21 +501,37 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
             if (r0 != sub) { const u64* q = pa + (size_t)r0 * 5; y[0] = q[0]; y[1] = q[1]; y[2] = q[2]; y[3] = q[3]; y[4] = q[4]; }
             add(y[0], y[1], y[2], y[3], y[4]);
         }
+    };
+    SG_STAMP(d, 1, 1);
+    K1B_WAIT();
+    SG_STAMP(d, 1, 2);
+    if (w0 < d.nwg) merge_piece(piece0, pa0, hv, xv0, xv1, xv2, xv3, y01, y23, y4);
+    for (u32 w = w0 + K1B_THREADS / K1B_LPP; w < d.nwg; w += K1B_THREADS / K1B_LPP) {    // only when nwg > 256
+        const uint4* piece = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
+        const u64* pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
+        v4u_t hv, xv0, xv1, xv2, xv3, y01, y23; v2u_t y4;
+        K1B_ISSUE(piece, pa);
+        K1B_WAIT();
+        merge_piece(piece, pa, hv, xv0, xv1, xv2, xv3, y01, y23, y4);
     }
+#undef K1B_ISSUE
+#undef K1B_WAIT
+#undef K1B_SIDX
     __syncthreads();
+    SG_STAMP(d, 1, 3);
     for (u32 w = t; w < d.nwg; w += K1B_THREADS) d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)] = make_uint4(0, 0, 0, 0);   // window reset of the pieces
     {
-        const u64 no = d.ctr[C_OVF_N] < d.ovf_cap ? d.ctr[C_OVF_N] : d.ovf_cap;
+        const u64 no = ovf_n < d.ovf_cap ? ovf_n : d.ovf_cap;
         for (u64 i = t; i < no; i += K1B_THREADS) {
             const u64* o = d.ovf + i * 5;
             if (part_of(d, o[0]) == p) add(o[0], o[1], o[2], o[3], o[4]);
         }
     }
     __syncthreads();
+    SG_STAMP(d, 1, 4);
 
     // compact the table into the partition's output slots (order within a partition is arbitrary;
     // the CSR row sort makes the final order canonical)
-    const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
 #pragma unroll
     for (u32 q = 0; q < K1B_HT / K1B_THREADS; q++) {
         const u32 s = q * K1B_THREADS + t;
@@ -431,6 +548,7 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         d.e_rank[slot] = atomicAdd(&d.deg[(size_t)f * SG_DEG_STRIDE], 1u);                  // arrival order inside the row: the scatter position
     }
     __syncthreads();
+    SG_STAMP(d, 1, 5);
     if (t == 0) {
         d.part_n[p] = out_n < d.pcap ? out_n : d.pcap;
         if (n_drop) atomicAdd(&d.ctr[C_DROPPED_CAP], (u64)n_drop);
@@ -876,34 +994,41 @@ __global__ __launch_bounds__(1024) void k3_in_stats(Dev d) {
 // ------------------------------------------------------------------------------------------------
 // K3  node_features: fp32 x_v from the integer node statistics.
 // ------------------------------------------------------------------------------------------------
+// Two lanes per node: lane 0 of the pair turns the out-side statistics into features, lane 1 the
+// in-side ones (the fp64 log1p / sqrt chains are the whole cost of this kernel), then they swap.
 __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN];
-    for (u32 v = blockIdx.x * 256 + threadIdx.x; v < N; v += gridDim.x * 256) {
-        const u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS; const u64* mx = d.st_max + (size_t)v * 2;
-        const u32 kind = v < nk ? d.kind[v] : 0u;
-        const u64 oc = s[ST_OUT_CNT], ic = s[ST_IN_CNT];
-        float x[SG_F_IN];
+    const u32 side = threadIdx.x & 1u;
+    for (u32 v0 = blockIdx.x * 128; v0 < N; v0 += gridDim.x * 128) {
+        const u32 v = v0 + (threadIdx.x >> 1);
+        const bool live = v < N;
+        float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (live) {
+            const u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
+            const u64 dg = s[ST_OUT_DEG + side], c = s[ST_OUT_CNT + side], er = s[ST_OUT_ERR + side], sm = s[ST_OUT_SUM + side], sq = s[ST_OUT_SSQ + side];
+            const u64 mx = d.st_max[(size_t)v * 2 + side];
+            a[0] = (float)log1p((double)dg);
+            a[1] = (float)log1p((double)c);
+            a[2] = (float)log1p(mean_us(sm, c) / 1000.0);
+            a[3] = c ? (float)((double)er / (double)c) : 0.0f;
+            a[4] = (float)log1p((double)mx / 1e6);
+            a[5] = (float)log1p(std_us(sm, sq, c) / 1000.0);
+        }
+        float b[6];
 #pragma unroll
-        for (int k = 0; k < (int)SG_F_IN; k++) x[k] = 0.0f;
-        x[0] = (float)log1p((double)s[ST_OUT_DEG]);
-        x[1] = (float)log1p((double)s[ST_IN_DEG]);
-        x[2] = (float)log1p((double)oc);
-        x[3] = (float)log1p((double)ic);
-        x[4] = (float)log1p(mean_us(s[ST_OUT_SUM], oc) / 1000.0);
-        x[5] = (float)log1p(mean_us(s[ST_IN_SUM], ic) / 1000.0);
-        x[6] = oc ? (float)((double)s[ST_OUT_ERR] / (double)oc) : 0.0f;
-        x[7] = ic ? (float)((double)s[ST_IN_ERR] / (double)ic) : 0.0f;
-        x[8] = (float)log1p((double)mx[0] / 1e6);
-        x[9] = (float)log1p((double)mx[1] / 1e6);
-        x[10] = kind == SG_NODE_POD ? 1.0f : 0.0f;
-        x[11] = kind == SG_NODE_SERVICE ? 1.0f : 0.0f;
-        x[12] = kind == 0 ? 1.0f : 0.0f;
-        x[13] = (float)log1p(std_us(s[ST_OUT_SUM], s[ST_OUT_SSQ], oc) / 1000.0);
-        x[14] = (float)log1p(std_us(s[ST_IN_SUM], s[ST_IN_SSQ], ic) / 1000.0);
-        x[15] = 1.0f;
+        for (int k = 0; k < 6; k++) b[k] = __shfl_xor(a[k], 1, 64);
+        if (!live) continue;
         float4* o = reinterpret_cast<float4*>(d.x0 + (size_t)v * SG_F_IN);
+        if (side == 0) {                                             // a = out side, b = in side
+            const u32 kind = v < nk ? d.kind[v] : 0u;
+            o[0] = make_float4(a[0], b[0], a[1], b[1]);
+            o[1] = make_float4(a[2], b[2], a[3], b[3]);
+            o[2] = make_float4(a[4], b[4], kind == SG_NODE_POD ? 1.0f : 0.0f, kind == SG_NODE_SERVICE ? 1.0f : 0.0f);
+            o[3] = make_float4(kind == 0 ? 1.0f : 0.0f, a[5], b[5], 1.0f);
+        } else {
 #pragma unroll
-        for (int q = 0; q < (int)SG_F_IN / 4; q++) o[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+            for (int q = 4; q < (int)SG_F_IN / 4; q++) o[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
     }
 }
 

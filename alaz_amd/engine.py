@@ -15,7 +15,7 @@ import numpy as np
 from .replay import EDGE_OUT_DTYPE, EVENT_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libservicegraph.so")
+LIB_PATH = os.environ.get("SG_LIB_PATH") or os.path.join(_HERE, "lib", "libservicegraph.so")   # SG_LIB_PATH: A/B runs of two builds on one box
 
 SG_OK, SG_EINVAL, SG_ENOMEM, SG_ENODEV, SG_ENOSPC, SG_EAGAIN, SG_ESTATE = 0, -22, -12, -19, -28, -11, -71
 F_IN, F_HID, F_EDGE = 32, 64, 8
@@ -32,7 +32,7 @@ EXPORTS = [
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
-    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_route",
+    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_stats_get": (C.c_int, [H, C.POINTER(SgStats)]),
         "sg_timing_enable": (C.c_int, [H, C.c_int]), "sg_timing_reset": (C.c_int, [H]),
         "sg_timing_get": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "sg_debug_stamps": (C.c_int, [H, P, sz]),
         "sg_route": (C.c_int, [H, P, sz, u32, P]),
     }
     for name, (res, args) in sig.items():
@@ -255,6 +256,12 @@ class ServiceGraph:
         us, n = C.c_double(), C.c_uint64()
         self._ck(self._l.sg_timing_get(self._h, kernel, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def debug_stamps(self) -> np.ndarray:
+        """[kernel 0..3][workgroup][8] phase stamps (100 MHz ticks); zeros unless SG_ABLATE & 0x100."""
+        out = np.zeros((4, 4096, 8), dtype=np.uint64)
+        self._ck(self._l.sg_debug_stamps(self._h, out.ctypes.data, out.size))
+        return out
 
     def route(self, events: np.ndarray, world: int) -> np.ndarray:
         ev = np.ascontiguousarray(events)

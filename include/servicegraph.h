@@ -288,6 +288,10 @@ int sg_stats_get(sg_handle h, sg_stats* out);
 int sg_timing_enable(sg_handle h, int on);   /* 0 = off, 1 = every group, else bitmask: bit k = group Kk */
 int sg_timing_reset(sg_handle h);
 int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
+/* Tuning aid: with SG_ABLATE & 0x100 in the environment at sg_create, the K1 kernels record 100 MHz
+ * wall-clock stamps at their phase boundaries, [kernel 0..3][4096 workgroups][8 stamps] u64; this
+ * copies the first n words out.  All zero otherwise.                                                */
+int sg_debug_stamps(sg_handle h, uint64_t* out, size_t n);
 
 /* Owner shard of a node / routing shard of an event: murmur3 fmix32(ip) % world.
  * The feeder routes an event by the IP of its from-endpoint: daddr if SG_EV_REVERSE else saddr. */

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Phase timeline of the K1 kernels from the SG_STAMP buffer (run with SG_ABLATE=0x100).
+Prints, per kernel, for every stamp: min / mean / max over workgroups, in us since the earliest
+workgroup start of that launch."""
+import os, sys
+os.environ["SG_ABLATE"] = os.environ.get("SG_ABLATE", "0x100")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from alaz_amd import engine, replay, weights
+
+cfgno = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+c = replay.CONFIGS[cfgno]; seed = replay.SEED_BASE + cfgno
+topo = replay.make_topology(c["pods"], c["edges"], seed)
+Ev = c["events"]
+ev, labels = replay.make_events(topo, Ev * 3, seed)
+g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.25) + 4096, layers=c["layers"],
+                        max_labels=max(64, len(labels)), max_outbound_ips=64, max_batch=1 << 18, max_window_events=Ev)
+g.set_clock(1_000_000_000, 1_700_000_000_000_000_000); g.load_weights(weights.make_weights(c["layers"]))
+for i in range(topo.n_pods): g.upsert_pod(int(topo.pod_ips[i]), i)
+for j in range(topo.n_svcs): g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
+g.set_label_count(len(labels))
+dev = [torch.from_numpy(ev[i * Ev:(i + 1) * Ev].view(np.uint8).reshape(-1)).cuda() for i in range(3)]
+for i in range(6):
+    g.ingest_device(dev[i % 3].data_ptr(), Ev, 0); g.window_run(0)
+torch.cuda.synchronize()
+st = g.debug_stamps()
+names = {0: ["start", "setup+barrier", "events landed", "folded", "barrier", "flushed", "stats"],
+         1: ["start", "setup+barrier", "loads landed", "merged+barrier", "reset/ovf+barrier", "compacted+barrier"]}
+for kid, kname in ((0, "k1a_partition"), (1, "k1b_merge")):
+    a = st[kid].astype(np.int64)
+    live = a[:, 0] != 0
+    a = a[live]
+    if not len(a):
+        print(kname, "no stamps"); continue
+    t0 = a[:, 0].min()
+    print(f"{kname}: {len(a)} workgroups; 100 MHz ticks -> us")
+    for k, nm in enumerate(names[kid]):
+        col = (a[:, k] - t0) / 100.0
+        print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
+g.close()
