@@ -785,9 +785,13 @@ __device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
     return v > 0.0 ? sqrt(v) : 0.0;
 }
 
-// everything that is per edge once its row statistics are known
-__device__ __forceinline__ void edge_emit(const Dev& d, u32 pos, u32 row, u32 slot, u64 r_cnt, u64 r_sum, u64 r_ssq,
-                                          const ulonglong2 x, const ulonglong2 y) {
+// everything that is per edge once its row statistics are known.  NOT inlined: five fp64 log1p, two
+// sqrt and four divisions are ~1000 instructions, and k2_rowsort_gather has three call sites (one of
+// them unrolled 4x) — inlined, the kernel was 6.9 k instructions of mostly cold instruction-cache
+// misses.  The arguments are passed by value (a reference to Dev would spill the whole struct to scratch).
+struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; float* efeat; float* latz; float* errr; u64* eacc; u64* ekeys; u32 variant; };
+__device__ __attribute__((noinline)) void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row, u32 slot, u64 r_cnt, u64 r_sum, u64 r_ssq,
+                                                    const ulonglong2 x, const ulonglong2 y) {
     const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)pos * 4);
     dst[0] = x; dst[1] = y;
@@ -813,6 +817,7 @@ __device__ __forceinline__ void edge_emit(const Dev& d, u32 pos, u32 row, u32 sl
 #define K2_LONG_WGS 256
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
+    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.efeat, d.latz, d.errr, d.eacc, d.ekeys, d.variant};
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
     __shared__ u64 red[5][4];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -853,7 +858,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                 sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
                 mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
 #pragma unroll
-                for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) { key[rk[q]] = mk[q]; edge_emit(d, b + rk[q], rr, mv[q], cnt, sum, ssq, ax[q], ay[q]); }
+                for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) { key[rk[q]] = mk[q]; edge_emit(ea, b + rk[q], rr, mv[q], cnt, sum, ssq, ax[q], ay[q]); }
             } else {
                 u32 np2 = 1; while (np2 < m) np2 <<= 1;
                 u32* gk = sk; u32* gv = sv;
@@ -887,7 +892,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                     key[i] = gk[i];
                     const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
                     const ulonglong2 x = a[0], y = a[1];
-                    edge_emit(d, b + i, rr, slot, cnt, sum, ssq, x, y);
+                    edge_emit(ea, b + i, rr, slot, cnt, sum, ssq, x, y);
                 }
             }
             if (threadIdx.x == 0) {
@@ -908,7 +913,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
         if (n == 0) continue;
         const u32 k = lane < n ? d.col[beg + lane] : 0xFFFFFFFFu, v = lane < n ? d.cslot[beg + lane] : 0;
         u32 rank = 0;
-        for (u32 j = 0; j < n; j++) rank += __shfl(k, (int)j, 64) < k;
+        for (u32 j = 0; j < n; j++) rank += rdlane32(k, (int)j) < k;   // j uniform: v_readlane
         ulonglong2 x = make_ulonglong2(0, 0), y = make_ulonglong2(0, 0);
         if (lane < n) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v * 4); x = a[0]; y = a[1]; }
         const u64 cnt = wave_sum_u64(x.x & 0xFFFFFFFFull), err = wave_sum_u64(x.x >> 32), sum = wave_sum_u64(x.y), ssq = wave_sum_u64(y.y), mx = wave_max_u64(y.x);
@@ -918,7 +923,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
             t[ST_OUT_DEG] = n; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
             d.st_max[(size_t)r * 2] = mx;
         }
-        if (lane < n) edge_emit(d, beg + rank, r, v, cnt, sum, ssq, x, y);
+        if (lane < n) edge_emit(ea, beg + rank, r, v, cnt, sum, ssq, x, y);
     }
 }
 
@@ -1096,7 +1101,7 @@ __device__ __forceinline__ void gather_mean(const Dev& d, const float* __restric
 #pragma unroll
                 for (int a = 0; a < 16; a++) {
                     const u32 i = i0 + 2 * a + g;                    // slot = i % 16 = (2a + g) % 16  (base, i0 multiples of 16)
-                    const u32 id = __shfl(my, (int)(i & 63), 64);
+                    const u32 id = __shfl(my, (int)(i & 63), 64);    // (two v_readlane + select measured slower here, r01r)
                     tmp[a] = i < cnt ? hin[(size_t)id * 32 + k] : 0.0f;
                 }
 #pragma unroll
@@ -1314,7 +1319,7 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
         for (int q = 0; q < K5_U; q++) {
             float x = t[q];
 #pragma unroll
-            for (int k = 0; k < (int)SG_F_EDGE; k++) x = fmaf(__shfl(ev[q], k, 64), we[k], x);
+            for (int k = 0; k < (int)SG_F_EDGE; k++) x = fmaf(__uint_as_float(rdlane32(__float_as_uint(ev[q]), k)), we[k], x);
             x = x > 0.0f ? x : 0.0f;
             float r = x * w2j;
 #pragma unroll
