@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("SG_LIB_PATH") or os.path.join(_HERE, "lib", "libservi
 
 SG_OK, SG_EINVAL, SG_ENOMEM, SG_ENODEV, SG_ENOSPC, SG_EAGAIN, SG_ESTATE = 0, -22, -12, -19, -28, -11, -71
 F_IN, F_HID, F_EDGE = 32, 64, 8
-STAT_SUM_WORDS, STAT_MAX_WORDS = 10, 2
+STAT_SUM_WORDS, STAT_MAX_WORDS = 12, 2
 REF_KNOWN, REF_LABEL, REF_OBIP = 0, 1, 2
 
 #: every symbol include/servicegraph.h declares (checked by tests/test_abi.py)

@@ -27,12 +27,12 @@ assert EVENT_DTYPE.itemsize == 32
 EDGE_OUT_DTYPE = np.dtype([
     ("sum_ns", "<u8"), ("max_ns", "<u8"), ("sumsq_us", "<u8"), ("from_ref", "<u4"), ("to_ref", "<u4"),
     ("count", "<u4"), ("err_count", "<u4"), ("score", "<f4"), ("lat_z", "<f4"), ("err_ratio", "<f4"),
-    ("_pad", "<u4"),
+    ("alive", "<u4"),
 ])
 assert EDGE_OUT_DTYPE.itemsize == 56
 
 PROTO_HTTP, PROTO_AMQP, PROTO_POSTGRES, PROTO_HTTP2, PROTO_REDIS, PROTO_KAFKA, PROTO_MYSQL, PROTO_MONGO = 1, 2, 3, 4, 5, 6, 7, 8
-EV_TLS, EV_REVERSE, EV_CONSUME = 1, 2, 4
+EV_TLS, EV_REVERSE, EV_CONSUME, EV_ALIVE = 1, 2, 4, 8
 L7_WIRE_SIZE = 1096
 
 POD_IP_BASE = 0x0A000000 + 1      # 10.0.0.1 + i

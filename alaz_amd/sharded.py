@@ -30,7 +30,7 @@ import torch.distributed as dist
 
 from . import replay
 
-STAT_SUM_WORDS, STAT_MAX_WORDS = 10, 2
+STAT_SUM_WORDS, STAT_MAX_WORDS = 12, 2
 
 
 # ------------------------------------------------------------------------------------------------

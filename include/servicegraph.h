@@ -56,6 +56,12 @@ extern "C" {
 #define SG_EV_REVERSE  0x02u /* AMQP DELIVER / Redis PUSHED_EVENT: ReverseDirection() after
                                 the join            aggregator/data.go:1110-1112,1151-1153  */
 #define SG_EV_CONSUME  0x04u /* Kafka CONSUME record (informational) data.go:1043-1076       */
+#define SG_EV_ALIVE    0x08u /* not a request: one open TCP connection saddr -> daddr, as
+                                sendOpenConnection() reports it  aggregator/data.go:1628-1679.
+                                Joined like a request but without a Host header (ToUID of an
+                                unknown daddr is the IP, :1671-1672); creates / keeps the edge
+                                and adds 1 to its `alive` count; status, duration and
+                                write_time_ns are ignored and no request is counted.           */
 
 /*
  * One L7 request, packed.  32 bytes, little-endian, naturally aligned.
@@ -128,7 +134,7 @@ typedef struct sg_edge_out {
     float    score;
     float    lat_z;
     float    err_ratio;
-    uint32_t _pad;
+    uint32_t alive;             /* open connections reported on this edge in the window (SG_EV_ALIVE) */
 } sg_edge_out;
 
 typedef struct sg_config {
@@ -151,14 +157,14 @@ typedef struct sg_config {
                                    sg_window_run() closes the current window on its slot's stream
                                    and moves on to the next slot, so the (latency-bound) close of
                                    window w overlaps the ingest of window w+1.  0 = 1.              */
-    uint32_t _reserved;
+    uint32_t max_alive;         /* most SG_EV_ALIVE records one window may carry (0 = 65536)        */
 } sg_config;
 
 #define SG_MAX_LAYERS 4u
 #define SG_F_IN    32u   /* node feature width                                                  */
 #define SG_F_HID   64u   /* hidden width of every SAGE layer and of the score head               */
 #define SG_F_EDGE   8u   /* edge feature width                                                  */
-#define SG_NODE_STAT_SUM_WORDS 10u /* u64 words per node in the SUM-reduced stats block           */
+#define SG_NODE_STAT_SUM_WORDS 12u /* u64 words per node in the SUM-reduced stats block           */
 #define SG_NODE_STAT_MAX_WORDS  2u /* u64 words per node in the MAX-reduced stats block           */
 
 typedef struct sg_stats {
@@ -175,6 +181,8 @@ typedef struct sg_stats {
     uint64_t h2d_bytes;
     uint64_t events_misrouted;     /* world > 1: events fed to the wrong shard (see sg_route)    */
     uint64_t halo_overflow;        /* halo requests beyond the per-pair capacity (must be 0)     */
+    uint64_t alive_in;             /* SG_EV_ALIVE records handed to K1 since create               */
+    uint64_t alive_dropped;        /* ... of which beyond max_alive, or with an endpoint that was dropped */
 } sg_stats;
 
 typedef struct sg_engine* sg_handle;

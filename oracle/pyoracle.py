@@ -16,7 +16,7 @@ L7_WIRE_SIZE = 1096
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("sg_oracle.c", "sg_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("sg_oracle.c", "sockline.c", "sg_oracle.h")] + [os.path.join(_HERE, "..", "include", "servicegraph.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
     return LIB_PATH
@@ -25,7 +25,7 @@ def build(force: bool = False) -> str:
 class EdgeOut(C.Structure):
     _fields_ = [("sum_ns", C.c_uint64), ("max_ns", C.c_uint64), ("sumsq_us", C.c_uint64),
                 ("from_ref", C.c_uint32), ("to_ref", C.c_uint32), ("count", C.c_uint32), ("err_count", C.c_uint32),
-                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float), ("_pad", C.c_uint32)]
+                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float), ("alive", C.c_uint32)]
 
 
 class OrEdge(C.Structure):
@@ -46,6 +46,29 @@ class ReqInfo(C.Structure):
         return (self.start_time, self.latency, d(self.from_ip), d(self.from_type), d(self.from_uid), self.from_port,
                 d(self.to_ip), d(self.to_type), d(self.to_uid), self.to_port, d(self.protocol), self.status_code,
                 d(self.fail_reason), d(self.method), d(self.path), bool(self.tls))
+
+
+class SockInfo(C.Structure):
+    """SockInfo, aggregator/socket.go:20-27"""
+    _fields_ = [("pid", C.c_uint32), ("fd", C.c_uint64), ("saddr", C.c_char * 16), ("sport", C.c_uint16),
+                ("daddr", C.c_char * 16), ("dport", C.c_uint16)]
+
+
+class Alive(C.Structure):
+    """datastore.AliveConnection, datastore/dto.go:96-106"""
+    _fields_ = [("check_time", C.c_int64),
+                ("from_ip", C.c_char * 16), ("from_type", C.c_char * 10), ("from_uid", C.c_char * OR_UID_MAX), ("from_port", C.c_uint16),
+                ("to_ip", C.c_char * 16), ("to_type", C.c_char * 10), ("to_uid", C.c_char * OR_UID_MAX), ("to_port", C.c_uint16)]
+
+    def as_tuple(self):
+        d = lambda b: b.decode("latin-1")
+        return (self.check_time, d(self.from_ip), d(self.from_type), d(self.from_uid), self.from_port,
+                d(self.to_ip), d(self.to_type), d(self.to_uid), self.to_port)
+
+
+SL_ERRORS = {1: "sock line is empty", 2: "closed socket on last entry", 3: "no smaller value found", 4: "closed socket"}
+TCP_WIRE_SIZE = 64
+TCP_ESTABLISHED, TCP_CLOSED = 1, 5
 
 
 def _load():
@@ -73,6 +96,16 @@ def _load():
         "or_parse_postgres": (C.c_int, [P, C.c_uint32, C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
         "or_int_to_ipv4": (None, [C.c_uint32, C.c_char_p]),
         "or_weights_count": (C.c_size_t, [C.c_uint32]), "or_hash32": (C.c_uint32, [C.c_uint32]),
+        "or_sl_create": (P, [C.c_uint32, C.c_uint64]), "or_sl_destroy": (None, [P]),
+        "or_sl_add": (None, [P, C.c_uint64, C.POINTER(SockInfo)]),
+        "or_sl_get": (C.c_int, [P, C.c_uint64, C.c_uint64, C.POINTER(SockInfo)]),
+        "or_sl_delete_unused": (None, [P]), "or_sl_len": (C.c_size_t, [P]),
+        "or_sl_at": (C.c_int, [P, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(SockInfo)]),
+        "or_process_tcp": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint16, C.c_char_p, C.c_uint16]),
+        "or_process_tcp_wire": (C.c_size_t, [P, C.c_void_p, C.c_size_t]),
+        "or_sockline_of": (P, [P, C.c_uint32, C.c_uint64]), "or_sockline_count": (C.c_size_t, [P]),
+        "or_sweep_socket_lines": (C.c_size_t, [P, C.c_int64, C.c_int]),
+        "or_alive_count": (C.c_size_t, [P]), "or_alive_at": (C.POINTER(Alive), [P, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name); f.restype = res; f.argtypes = args
@@ -87,6 +120,47 @@ def lib():
     if _lib is None:
         _lib = _load()
     return _lib
+
+
+def sockinfo(saddr="", sport=0, daddr="", dport=0, pid=0, fd=0) -> SockInfo:
+    return SockInfo(pid, fd, saddr.encode(), sport, daddr.encode(), dport)
+
+
+class SockLine:
+    """SocketLine (aggregator/sock_num_line.go).  Owns its C object unless wrapped around a borrowed pointer."""
+    def __init__(self, pid: int = 0, fd: int = 0, _borrowed=None):
+        self._l = lib()
+        self._own = _borrowed is None
+        self._s = self._l.or_sl_create(pid, fd) if self._own else _borrowed
+
+    def __del__(self):
+        try:
+            if self._own and self._s:
+                self._l.or_sl_destroy(self._s); self._s = None
+        except Exception:
+            pass
+
+    def add(self, ts: int, si: Optional[SockInfo]):
+        self._l.or_sl_add(self._s, ts, C.byref(si) if si is not None else None)
+
+    def get(self, ts: int, now_ns: int = 1):
+        """-> (SockInfo, None) or (None, error string), as GetValue returns (value, error)."""
+        out = SockInfo()
+        rc = self._l.or_sl_get(self._s, ts, now_ns, C.byref(out))
+        return (out, None) if rc == 0 else (None, SL_ERRORS[rc])
+
+    def delete_unused(self): self._l.or_sl_delete_unused(self._s)
+
+    def __len__(self): return self._l.or_sl_len(self._s)
+
+    def values(self):
+        """[(timestamp, last_match, (saddr, sport, daddr, dport) or None)]"""
+        out = []
+        for i in range(len(self)):
+            ts, lm, si = C.c_uint64(), C.c_uint64(), SockInfo()
+            o = self._l.or_sl_at(self._s, i, C.byref(ts), C.byref(lm), C.byref(si))
+            out.append((ts.value, lm.value, (si.saddr.decode(), si.sport, si.daddr.decode(), si.dport) if o == 1 else None))
+        return out
 
 
 class Oracle:
@@ -132,6 +206,33 @@ class Oracle:
         return self._l.or_process_packed(self._o, ev.ctypes.data, len(ev), arr, len(labels))
 
     # --- results ---
+    # ---- f-2: TCP connect events -> socket lines -> alive connections ----
+    def tcp(self, type_: int, pid: int, fd: int, ts: int, saddr: str, sport: int, daddr: str, dport: int) -> int:
+        return self._l.or_process_tcp(self._o, type_, pid, fd, ts, saddr.encode(), sport, daddr.encode(), dport)
+
+    def tcp_wire(self, recs: bytes) -> int:
+        assert len(recs) % TCP_WIRE_SIZE == 0
+        return self._l.or_process_tcp_wire(self._o, recs, len(recs) // TCP_WIRE_SIZE)
+
+    def sockline(self, pid: int, fd: int) -> Optional[SockLine]:
+        p = self._l.or_sockline_of(self._o, pid, fd)
+        return SockLine(_borrowed=p) if p else None
+
+    def sockline_count(self) -> int: return self._l.or_sockline_count(self._o)
+
+    def sweep(self, now_ms: int, send_alive: bool = True) -> int:
+        return self._l.or_sweep_socket_lines(self._o, now_ms, int(send_alive))
+
+    def alive_count(self) -> int: return self._l.or_alive_count(self._o)
+
+    def alive_rows(self):
+        out, i = [], 0
+        while True:
+            p = self._l.or_alive_at(self._o, i)
+            if not p:
+                return out
+            out.append(p.contents.as_tuple()); i += 1
+
     def window_close(self, weights: np.ndarray, layers: int) -> int:
         w = np.ascontiguousarray(weights, dtype=np.float32)
         assert len(w) == self._l.or_weights_count(layers)
@@ -152,12 +253,12 @@ class Oracle:
         return out
 
     def edge_dict(self):
-        """{(from_type, from_uid, to_type, to_uid): (count, err, sum, max, sumsq, score, lat_z, err_ratio)}"""
+        """{(from_type, from_uid, to_type, to_uid): (count, err, sum, max, sumsq, score, lat_z, err_ratio, alive)}"""
         d = {}
         for e in self.edges():
             k = (e.from_type.decode(), e.from_uid.decode(), e.to_type.decode(), e.to_uid.decode())
             r = e.row
-            d[k] = (r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio)
+            d[k] = (r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio, r.alive)
         return d
 
     def reqinfos(self):

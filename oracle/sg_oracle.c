@@ -78,6 +78,7 @@ typedef struct {             /* one (FromType,FromUID,ToType,ToUID) edge of the 
     uint32_t from_obip, to_obip; /* raw IP when the endpoint is an OBIP node */
     uint32_t count, err;
     uint64_t sum_ns, max_ns, sumsq_us;
+    uint32_t alive;              /* alive connections reported on this edge (f-2) */
 } w_edge;
 
 struct oracle {
@@ -93,6 +94,10 @@ struct oracle {
     /* ReqInfo log */
     or_reqinfo* log; size_t log_n, log_cap, log_limit; size_t persisted;
     uint64_t dropped_src, dropped_parse;
+
+    /* f-2: clusterInfo.SocketMaps (pid -> fd -> SocketLine), flattened to "pid:fd" -> index */
+    strmap sock_index; or_sockline** socklines; size_t n_socklines, cap_socklines;
+    or_alive* alive_log; size_t alive_n, alive_cap; size_t alive_persisted;
 
     /* open window */
     strmap edge_index;       /* "ft\x1fuid\x1ftt\x1fuid" -> index into wedges */
@@ -111,7 +116,7 @@ struct oracle {
 oracle_t* or_create(void) {
     oracle_t* o = calloc(1, sizeof(*o));
     sm_init(&o->pod_ip_to_uid); sm_init(&o->svc_ip_to_uid); sm_init(&o->uid_to_id);
-    sm_init(&o->label_to_id); sm_init(&o->pg_stmts); sm_init(&o->mysql_stmts); sm_init(&o->edge_index);
+    sm_init(&o->label_to_id); sm_init(&o->pg_stmts); sm_init(&o->mysql_stmts); sm_init(&o->edge_index); sm_init(&o->sock_index);
     o->tmin = INT64_MAX; o->tmax = INT64_MIN;
     return o;
 }
@@ -132,6 +137,9 @@ void or_destroy(oracle_t* o) {
     free(o->id_to_uid); free(o->id_kind);
     for (size_t i = 0; i < o->n_labels; i++) free(o->labels[i]);
     free(o->labels); free(o->log); free(o->wedges);
+    sm_free(&o->sock_index);
+    for (size_t i = 0; i < o->n_socklines; i++) or_sl_destroy(o->socklines[i]);
+    free(o->socklines); free(o->alive_log);
     free_closed(o);
     free(o);
 }
@@ -545,6 +553,96 @@ static int resolve_and_persist(oracle_t* o, uint32_t saddr, uint16_t sport, uint
     return 1;
 }
 
+/* sendOpenConnection's join + PersistAliveConnection — aggregator/data.go:1641-1677: the source
+ * must be a pod (else the connection is ignored, not counted); destination service first, then pod,
+ * else ("outbound", Daddr).  No Host header, no reverse DNS, no direction reversal.
+ * Part 2 hook: the edge is created if needed and its alive count grows by one. */
+static int persist_alive(oracle_t* o, uint32_t saddr, uint16_t sport, uint32_t daddr, uint16_t dport, int64_t check_ms) {
+    char sip[16], dip[16];
+    or_int_to_ipv4(saddr, sip); or_int_to_ipv4(daddr, dip);
+    endpoint from, to;
+    if (set_from_to_v2(o, sip, dip, daddr, "", &from, &to) != 0) return 0;
+    if (o->alive_n < o->log_limit) {
+        if (o->alive_n == o->alive_cap) { o->alive_cap = o->alive_cap ? o->alive_cap * 2 : 64; o->alive_log = realloc(o->alive_log, o->alive_cap * sizeof(or_alive)); }
+        or_alive* a = &o->alive_log[o->alive_n++];
+        memset(a, 0, sizeof *a);
+        a->check_time = check_ms;
+        strcpy(a->from_ip, sip); strcpy(a->from_type, "pod"); strcpy(a->from_uid, from.uid); a->from_port = sport;
+        strcpy(a->to_ip, dip); strcpy(a->to_type, to.type); strcpy(a->to_uid, to.uid); a->to_port = dport;
+    }
+    o->alive_persisted++;
+    window_edge(o, &from, &to)->alive += 1;
+    return 1;
+}
+
+static uint32_t ipv4_to_int(const char* s) {
+    unsigned a = 0, b = 0, c = 0, d = 0;
+    if (sscanf(s, "%u.%u.%u.%u", &a, &b, &c, &d) != 4) return 0;
+    return (a << 24) | (b << 16) | (c << 8) | d;
+}
+
+or_sockline* or_sockline_of(oracle_t* o, uint32_t pid, uint64_t fd) {
+    char key[48]; snprintf(key, sizeof key, "%u:%llu", pid, (unsigned long long)fd);
+    sm_ent* e = sm_find(&o->sock_index, key);
+    return e ? o->socklines[e->uval] : NULL;
+}
+size_t or_sockline_count(const oracle_t* o) { return o->n_socklines; }
+
+/* processTcpConnect — aggregator/data.go:404-506 */
+int or_process_tcp(oracle_t* o, uint32_t type, uint32_t pid, uint64_t fd, uint64_t ts,
+                   const char* saddr, uint16_t sport, const char* daddr, uint16_t dport) {
+    if (type != OR_TCP_ESTABLISHED && type != OR_TCP_CLOSED) return 0;
+    if (strcmp(saddr, "127.0.0.1") == 0 || strcmp(daddr, "127.0.0.1") == 0) return 0;   /* :409-411, :456-458 */
+    or_sockline* sl = or_sockline_of(o, pid, fd);
+    if (type == OR_TCP_ESTABLISHED) {
+        if (!sl) {                                   /* :416-438: signalled for creation, event re-queued until it exists */
+            if (o->n_socklines == o->cap_socklines) { o->cap_socklines = o->cap_socklines ? o->cap_socklines * 2 : 64; o->socklines = realloc(o->socklines, o->cap_socklines * sizeof(or_sockline*)); }
+            sl = or_sl_create(pid, fd);
+            char key[48]; snprintf(key, sizeof key, "%u:%llu", pid, (unsigned long long)fd);
+            sm_put(&o->sock_index, key, NULL, (uint32_t)o->n_socklines);
+            o->socklines[o->n_socklines++] = sl;
+        }
+        or_sockinfo si; memset(&si, 0, sizeof si);
+        si.pid = pid; si.fd = fd; si.sport = sport; si.dport = dport;
+        copy_trunc(si.saddr, sizeof si.saddr, saddr, strlen(saddr)); copy_trunc(si.daddr, sizeof si.daddr, daddr, strlen(daddr));
+        or_sl_add(sl, ts, &si);                      /* :440-450 */
+        return 1;
+    }
+    if (!sl) return 0;                               /* CLOSED without a line: dropped (:472-477) */
+    or_sl_add(sl, ts, NULL);                         /* :480-483; h2 parser / pgStmts clean-up (:485-503) is off this path */
+    return 1;
+}
+
+size_t or_process_tcp_wire(oracle_t* o, const uint8_t* recs, size_t n) {
+    size_t added = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* r = recs + i * OR_TCP_WIRE_SIZE;
+        char s[16], d[16];
+        snprintf(s, sizeof s, "%u.%u.%u.%u", r[28], r[29], r[30], r[31]);    /* tcp.go:241-242 */
+        snprintf(d, sizeof d, "%u.%u.%u.%u", r[44], r[45], r[46], r[47]);
+        added += (size_t)or_process_tcp(o, rd32(r + 16), rd32(r + 20), rd64(r), rd64(r + 8), s, rd16(r + 24), d, rd16(r + 26));
+    }
+    return added;
+}
+
+/* clearSocketLines, one tick — aggregator/data.go:1681-1716 (sendOpenConnection :1628-1679) */
+size_t or_sweep_socket_lines(oracle_t* o, int64_t now_ms, int send_alive) {
+    size_t sent = 0;
+    for (size_t i = 0; i < o->n_socklines; i++) {
+        or_sockline* sl = o->socklines[i];
+        size_t len = or_sl_len(sl);
+        if (send_alive && len > 0) {
+            or_sockinfo si; uint64_t ts, lm;
+            if (or_sl_at(sl, len - 1, &ts, &lm, &si) == 1)           /* last value is an open socket */
+                sent += (size_t)persist_alive(o, ipv4_to_int(si.saddr), si.sport, ipv4_to_int(si.daddr), si.dport, now_ms);
+        }
+        or_sl_delete_unused(sl);
+    }
+    return sent;
+}
+size_t or_alive_count(const oracle_t* o) { return o->alive_persisted; }
+const or_alive* or_alive_at(const oracle_t* o, size_t i) { return i < o->alive_n ? &o->alive_log[i] : NULL; }
+
 /* processL7 — aggregator/data.go:1364-1383 — and the per-protocol handlers it dispatches to. */
 static size_t process_one(oracle_t* o, const l7ev* d, uint32_t kafka_msgs) {
     const char* protocol = proto_str(d->protocol);
@@ -615,6 +713,7 @@ size_t or_process_packed(oracle_t* o, const sg_event* ev, size_t n, const char* 
     }
     for (size_t i = 0; i < n; i++) {
         const sg_event* e = &ev[i];
+        if (e->flags & SG_EV_ALIVE) { persist_alive(o, e->saddr, 0, e->daddr, 0, 0); continue; }
         const char* host = "";
         if (e->host_label != 0 && e->host_label <= n_labels) host = labels[e->host_label - 1];
         const char* method = e->protocol == SG_PROTO_KAFKA ? ((e->flags & SG_EV_CONSUME) ? "CONSUME" : "PUBLISH") : "";
@@ -674,6 +773,8 @@ static size_t lower_bound_u32(const uint32_t* a, size_t n, uint32_t v) {
 #define ST_IN_SUM 7
 #define ST_OUT_SSQ 8
 #define ST_IN_SSQ 9
+#define ST_OUT_ALIVE 10
+#define ST_IN_ALIVE 11
 
 static double mean_us(uint64_t sum_ns, uint64_t cnt) { return cnt ? ((double)sum_ns / 1000.0) / (double)cnt : 0.0; }
 static double std_us(uint64_t sum_ns, uint64_t ssq_us, uint64_t cnt) {
@@ -703,6 +804,8 @@ static void node_features(const uint64_t* s, const uint64_t* mx, uint8_t kind, f
     x[13] = (float)log1p(std_us(s[ST_OUT_SUM], s[ST_OUT_SSQ], oc) / 1000.0);
     x[14] = (float)log1p(std_us(s[ST_IN_SUM], s[ST_IN_SSQ], ic) / 1000.0);
     x[15] = 1.0f;
+    x[16] = (float)log1p((double)s[ST_OUT_ALIVE]);              /* open connections from / to the node (f-2) */
+    x[17] = (float)log1p((double)s[ST_IN_ALIVE]);
 }
 
 #define SG_MEAN_SLOTS 16
@@ -750,6 +853,7 @@ size_t or_window_close(oracle_t* o, const float* W, uint32_t L) {
         a[ST_OUT_ERR] += w->err; b[ST_IN_ERR] += w->err;
         a[ST_OUT_SUM] += w->sum_ns; b[ST_IN_SUM] += w->sum_ns;
         a[ST_OUT_SSQ] += w->sumsq_us; b[ST_IN_SSQ] += w->sumsq_us;
+        a[ST_OUT_ALIVE] += w->alive; b[ST_IN_ALIVE] += w->alive;
         uint64_t* ma = sm + (size_t)se[i].from * 2; uint64_t* mb = sm + (size_t)se[i].to * 2;
         if (w->max_ns > ma[0]) ma[0] = w->max_ns;
         if (w->max_ns > mb[1]) mb[1] = w->max_ns;
@@ -829,6 +933,7 @@ size_t or_window_close(oracle_t* o, const float* W, uint32_t L) {
         oe->row.from_ref = fr; oe->row.to_ref = tr;
         oe->row.count = w->count; oe->row.err_count = w->err;
         oe->row.sum_ns = w->sum_ns; oe->row.max_ns = w->max_ns; oe->row.sumsq_us = w->sumsq_us;
+        oe->row.alive = w->alive;
 
         /* edge features */
         const uint64_t* su = ss + (size_t)uu * SG_NODE_STAT_SUM_WORDS;

@@ -106,7 +106,7 @@ size_t or_node_count(const oracle_t* o);
 /* debug/inspection of the last closed window */
 const float*    or_node_features(const oracle_t* o);           /* [N][SG_F_IN]           */
 const float*    or_layer_output(const oracle_t* o, uint32_t l);/* [N][SG_F_HID], l=1..L  */
-const uint64_t* or_node_stats_sum(const oracle_t* o);          /* [N][10]                */
+const uint64_t* or_node_stats_sum(const oracle_t* o);          /* [N][SG_NODE_STAT_SUM_WORDS] */
 const uint64_t* or_node_stats_max(const oracle_t* o);          /* [N][2]                 */
 const uint32_t* or_outbound_ips(const oracle_t* o, size_t* n);
 int64_t or_window_tmin(const oracle_t* o);
@@ -116,6 +116,51 @@ uint64_t or_window_events(const oracle_t* o);
 /* stand-alone pieces exposed for the known-answer tests */
 #define OR_HTTP_TOK_CAP  64
 #define OR_HTTP_PATH_CAP 1100
+/* ---- f-2: TCP connect events, socket lines, alive connections --------------------------------- *
+ * SockInfo (aggregator/socket.go:20-27) with the address strings the reference keeps.            */
+typedef struct or_sockinfo {
+    uint32_t pid; uint64_t fd;
+    char saddr[16]; uint16_t sport;
+    char daddr[16]; uint16_t dport;
+} or_sockinfo;
+typedef struct or_sockline or_sockline;
+enum { OR_SL_OK = 0, OR_SL_EMPTY = 1, OR_SL_CLOSED_LAST = 2, OR_SL_NO_SMALLER = 3, OR_SL_CLOSED = 4 };
+/* SocketLine (aggregator/sock_num_line.go:29-208); si == NULL is a close; now_ns stands for time.Now() */
+or_sockline* or_sl_create(uint32_t pid, uint64_t fd);
+void   or_sl_destroy(or_sockline* s);
+void   or_sl_add(or_sockline* s, uint64_t ts, const or_sockinfo* si);
+int    or_sl_get(or_sockline* s, uint64_t ts, uint64_t now_ns, or_sockinfo* out);
+void   or_sl_delete_unused(or_sockline* s);
+size_t or_sl_len(const or_sockline* s);
+int    or_sl_at(const or_sockline* s, size_t i, uint64_t* ts, uint64_t* last_match, or_sockinfo* si); /* 1 open, 0 close, -1 out of range */
+
+/* BpfTcpEvent (ebpf/tcp_state/tcp.go:63-72): fd u64@0, timestamp u64@8, type u32@16, pid u32@20,
+ * sport u16@24, dport u16@26, saddr[16]@28, daddr[16]@44 (first 4 bytes = a.b.c.d), padded to 64. */
+#define OR_TCP_WIRE_SIZE 64
+enum { OR_TCP_ESTABLISHED = 1, OR_TCP_CONNECT_FAILED = 2, OR_TCP_LISTEN = 3, OR_TCP_LISTEN_CLOSED = 4, OR_TCP_CLOSED = 5 };
+/* processTcpConnect (aggregator/data.go:404-506).  The reference re-queues an event until the
+ * process' socket map / the fd's socket line exists (created asynchronously, optionally from /proc);
+ * here the line is created on demand and starts empty.  Returns 1 if a value was added. */
+int    or_process_tcp(oracle_t* o, uint32_t type, uint32_t pid, uint64_t fd, uint64_t ts,
+                      const char* saddr, uint16_t sport, const char* daddr, uint16_t dport);
+size_t or_process_tcp_wire(oracle_t* o, const uint8_t* recs, size_t n);
+or_sockline* or_sockline_of(oracle_t* o, uint32_t pid, uint64_t fd);     /* NULL if none */
+size_t or_sockline_count(const oracle_t* o);
+
+/* datastore.AliveConnection (datastore/dto.go:96-106) */
+typedef struct or_alive {
+    int64_t  check_time;
+    char     from_ip[16], from_type[10], from_uid[OR_UID_MAX]; uint16_t from_port;
+    char     to_ip[16], to_type[10], to_uid[OR_UID_MAX];       uint16_t to_port;
+} or_alive;
+/* One tick of clearSocketLines (data.go:1681-1716) over every socket line: sendOpenConnection
+ * (:1628-1679, only when send_alive) -> PersistAliveConnection, then DeleteUnused.  Each persisted
+ * alive connection also adds 1 to its edge's `alive` count in the open window.  Returns how many
+ * were persisted by this call. */
+size_t or_sweep_socket_lines(oracle_t* o, int64_t now_ms, int send_alive);
+size_t or_alive_count(const oracle_t* o);                 /* persisted since create */
+const or_alive* or_alive_at(const oracle_t* o, size_t i); /* kept up to the log limit */
+
 /* method[OR_HTTP_TOK_CAP], path[OR_HTTP_PATH_CAP], version[OR_HTTP_TOK_CAP], host[OR_UID_MAX] */
 void   or_parse_http_payload(const char* req, size_t len, char* method, char* path, char* version,
                              char* host);                             /* data.go:508-531  */

@@ -55,7 +55,7 @@ def engine_edge_dict(rows: np.ndarray, shim: HostShim, labels: Sequence[str], ob
         ft, fu = shim.ref_identity(int(r["from_ref"]), labels, obips)
         tt, tu = shim.ref_identity(int(r["to_ref"]), labels, obips)
         d[(ft, fu, tt, tu)] = (int(r["count"]), int(r["err_count"]), int(r["sum_ns"]), int(r["max_ns"]), int(r["sumsq_us"]),
-                               float(r["score"]), float(r["lat_z"]), float(r["err_ratio"]))
+                               float(r["score"]), float(r["lat_z"]), float(r["err_ratio"]), int(r["alive"]))
     return d
 
 
@@ -71,5 +71,7 @@ def compare_edge_dicts(got: dict, want: dict, score_tol: float = 1e-5):
         assert abs(g[5] - w[5]) <= score_tol, f"score differs on {k}: {g[5]} vs {w[5]}"
         assert abs(g[6] - w[6]) <= 1e-5 * max(1.0, abs(w[6])), f"lat_z differs on {k}: {g[6]} vs {w[6]}"
         assert g[7] == w[7], f"err_ratio differs on {k}: {g[7]} vs {w[7]}"
+        if len(g) > 8 and len(w) > 8:
+            assert g[8] == w[8], f"alive count differs on {k}: {g[8]} vs {w[8]}"
         worst = max(worst, abs(g[5] - w[5]))
     return worst

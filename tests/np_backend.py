@@ -30,13 +30,14 @@ class NumpyBackend:
         self.W, self.layers, self.rank, self.world, self.ncap, self.max_obip = weights.astype(np.float32), layers, rank, world, ncap, max_obip
         self.device = torch.device("cpu")
         self.stats_flat = torch.zeros(ncap * 12, dtype=torch.int64)
-        self.stats_sum = self.stats_flat[: ncap * 10]; self.stats_max = self.stats_flat[ncap * 10:]
+        self.stats_sum = self.stats_flat[: ncap * 12]; self.stats_max = self.stats_flat[ncap * 12:]
         self.capp = ncap
         self.ob_all = torch.zeros((world, max_obip + 1), dtype=torch.int64)
         self.serve = torch.zeros((world, self.capp + 1), dtype=torch.int64)
         self.rows_in = torch.zeros((world, self.capp, F_HID), dtype=torch.float32)
         self.misrouted = 0
         self.edges = {}
+        self.alive = {}
 
     # ---- K1 ----
     def ingest(self, ev):
@@ -48,8 +49,15 @@ class NumpyBackend:
             d = int(e["daddr"])
             if d in self.svc: to = (KNOWN, self.svc[d], 0)
             elif d in self.pod: to = (KNOWN, self.pod[d], 0)
-            elif int(e["host_label"]): to = (LABEL, int(e["host_label"]) - 1, 0)
+            elif int(e["host_label"]) and not (int(e["flags"]) & replay.EV_ALIVE): to = (LABEL, int(e["host_label"]) - 1, 0)
             else: to = (OBIP, 0, d)
+            if int(e["flags"]) & replay.EV_ALIVE:                    # open connection: creates the edge, counts no request
+                if self._owner_ref(frm) != self.rank:
+                    self.misrouted += 1
+                    continue
+                self.edges.setdefault((frm, to), [0, 0, 0, 0, 0])
+                self.alive[(frm, to)] = self.alive.get((frm, to), 0) + 1
+                continue
             if int(e["flags"]) & replay.EV_REVERSE:
                 frm, to = to, frm
             if self._owner_ref(frm) != self.rank:
@@ -88,22 +96,23 @@ class NumpyBackend:
         g = self.ob_all.numpy()
         self.ob = np.unique(np.concatenate([g[r, 1:1 + int(g[r, 0])] for r in range(self.world)]).astype(np.int64))
         self.N = self.nk + self.nl + len(self.ob)
-        rows = sorted((self._dense(f), self._dense(t), a) for (f, t), a in self.edges.items())
+        rows = sorted((self._dense(f), self._dense(t), a, self.alive.get((f, t), 0)) for (f, t), a in self.edges.items())
+        self.alive_csr = np.array([r[3] for r in rows], dtype=np.int64)
         self.frm = np.array([r[0] for r in rows], dtype=np.int64); self.to = np.array([r[1] for r in rows], dtype=np.int64)
         self.acc = np.array([r[2] for r in rows], dtype=np.int64).reshape(-1, 5)
-        s = np.zeros((self.ncap, 10), dtype=np.int64); m = np.zeros((self.ncap, 2), dtype=np.int64)
+        s = np.zeros((self.ncap, 12), dtype=np.int64); m = np.zeros((self.ncap, 2), dtype=np.int64)
         cnt, err, sm, mx, sq = (self.acc[:, i] if len(self.acc) else np.zeros(0, np.int64) for i in range(5))
-        for col_out, col_in, val in ((0, 1, np.ones(len(self.frm), np.int64)), (2, 3, cnt), (4, 5, err), (6, 7, sm), (8, 9, sq)):
+        for col_out, col_in, val in ((0, 1, np.ones(len(self.frm), np.int64)), (2, 3, cnt), (4, 5, err), (6, 7, sm), (8, 9, sq), (10, 11, self.alive_csr)):
             np.add.at(s[:, col_out], self.frm, val); np.add.at(s[:, col_in], self.to, val)
         np.maximum.at(m[:, 0], self.frm, mx); np.maximum.at(m[:, 1], self.to, mx)
-        self.stats_flat[: self.ncap * 10] = torch.from_numpy(s.reshape(-1))
-        self.stats_flat[self.ncap * 10:] = torch.from_numpy(m.reshape(-1))
+        self.stats_flat[: self.ncap * 12] = torch.from_numpy(s.reshape(-1))
+        self.stats_flat[self.ncap * 12:] = torch.from_numpy(m.reshape(-1))
 
     def features(self):
         N = self.N
-        s = self.stats_flat[: self.ncap * 10].numpy().reshape(self.ncap, 10)[:N].astype(np.float64)
-        si = self.stats_flat[: self.ncap * 10].numpy().reshape(self.ncap, 10)[:N]
-        m = self.stats_flat[self.ncap * 10:].numpy().reshape(self.ncap, 2)[:N].astype(np.float64)
+        s = self.stats_flat[: self.ncap * 12].numpy().reshape(self.ncap, 12)[:N].astype(np.float64)
+        si = self.stats_flat[: self.ncap * 12].numpy().reshape(self.ncap, 12)[:N]
+        m = self.stats_flat[self.ncap * 12:].numpy().reshape(self.ncap, 2)[:N].astype(np.float64)
         self.out_deg = si[:, 0].copy()
         self.out_stats = si[:, [2, 6, 8]].copy()
         kind = np.zeros(N, dtype=np.int64); kind[: self.nk] = self.kind
@@ -115,6 +124,7 @@ class NumpyBackend:
         x[:, 10] = kind == 1; x[:, 11] = kind == 2; x[:, 12] = kind == 0
         x[:, 13] = np.log1p(_std_us(si[:, 6], si[:, 8], s[:, 2]) / 1000.0); x[:, 14] = np.log1p(_std_us(si[:, 7], si[:, 9], s[:, 3]) / 1000.0)
         x[:, 15] = 1.0
+        x[:, 16] = np.log1p(s[:, 10]); x[:, 17] = np.log1p(s[:, 11])
         self.h = [x] + [np.full((N, F_HID), np.nan, dtype=np.float32) for _ in range(self.layers)]   # NaN = "not valid here"
 
     def halo_requests(self):

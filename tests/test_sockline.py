@@ -1,0 +1,134 @@
+"""f-2: the socket-line state machine and the alive-connection source.
+
+The oracle's restatement (oracle/sockline.c) is pinned by the reference's own known-answer tests,
+re-encoded here: aggregator/sock_line_test.go TestSocketLine (:10-347), TestXxx2 (:443-476),
+TestAlreadyEstablishCanBeFound (:478-501) and the retention loop of TestXxx (:349-441).  The C++ host
+implementation (alaz_amd/csrc/host/sockline.*) is then checked against the oracle on random traces.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from oracle.pyoracle import SockLine, sockinfo
+
+
+def test_kat_second_open_is_found_after_its_timestamp():
+    """sock_line_test.go:443-476 (TestXxx2): AddValue(0, yy); AddValue(247453008321477, xx); GetValue(247453008321499) -> xx"""
+    nl = SockLine(1, 0)
+    nl.add(0, sockinfo(saddr="yy"))
+    nl.add(247453008321477, sockinfo(saddr="xx"))
+    s, err = nl.get(247453008321499)
+    assert err is None and s.saddr == b"xx"
+
+
+def test_kat_already_established_can_be_found():
+    """sock_line_test.go:478-501: a single open at timestamp 0 answers GetValue(0)"""
+    nl = SockLine(1, 0)
+    nl.add(0, sockinfo(saddr="yy"))
+    s, err = nl.get(0)
+    assert err is None and s.saddr == b"yy"
+
+
+def test_kat_identical_consecutive_opens_collapse_and_answer_later_queries():
+    """sock_line_test.go:10-347 (TestSocketLine): hundreds of AddValue calls with an identical (empty) SockInfo
+    keep only the first entry (last-equal de-duplication, sock_num_line.go:71-78); GetValue after the last
+    timestamp returns it without error.  (First / last stamps and the queried stamp are the reference's; the
+    ones in between are regenerated — they never reach the line.)"""
+    nl = SockLine(0, 0)
+    first, last, query = 33805065332163, 33815077484050, 33835107729129
+    rng = np.random.default_rng(7)
+    stamps = [first] + sorted(int(x) for x in rng.integers(first + 1, last, size=300)) + [last]
+    for ts in stamps:
+        nl.add(ts, sockinfo())
+    assert len(nl) == 1 and nl.values()[0][0] == first
+    s, err = nl.get(query)
+    assert err is None and s is not None
+
+
+def test_kat_retention_loop_of_the_reference_test():
+    """sock_line_test.go:349-441 (TestXxx): opens at 10/30/50, closes at 20/40/60; GetValue(52) and
+    GetValue(33) match the opens at 50 and 30.  DeleteUnused (sock_num_line.go:159-208) first drops the
+    trailing close (its pairing loop never appends the last element), then removes (open, close) pairs whose
+    open was last matched more than 5 minutes before the newest match."""
+    nl = SockLine(1, 0)
+    for ts, si in ((10, sockinfo()), (20, None), (30, sockinfo(saddr="b")), (40, None), (50, sockinfo(saddr="c")), (60, None)):
+        nl.add(ts, si)
+    assert [v[0] for v in nl.values()] == [10, 20, 30, 40, 50, 60]
+    t_old, t_new = 1_000, 1_000 + 6 * 60 * 1_000_000_000
+    s, err = nl.get(33, now_ns=t_old); assert err is None and s.saddr == b"b"
+    s, err = nl.get(52, now_ns=t_new); assert err is None and s.saddr == b"c"
+    nl.delete_unused()
+    # pass 1 keeps [10, 20, 30, 40, 50] (60 dropped); pass 2: (30, 40) was matched 6 min before the newest match
+    # -> removed; (10, 20) was never matched (LastMatch 0) -> removed as well
+    assert [v[0] for v in nl.values()] == [50]
+
+
+def test_getvalue_special_cases():
+    """sock_num_line.go:83-157 branch by branch."""
+    nl = SockLine(1, 3)
+    assert nl.get(5) == (None, "sock line is empty")
+    a = sockinfo("10.0.0.1", 1000, "10.0.0.2", 80); b = sockinfo("10.0.0.1", 1001, "10.0.0.2", 80); c = sockinfo("10.0.0.1", 1002, "10.0.0.9", 80)
+    nl.add(100, None)
+    assert nl.get(50) == (None, "no smaller value found")                  # index 0 is a close
+    nl = SockLine(1, 3)
+    nl.add(100, a); nl.add(200, None)
+    s, err = nl.get(150); assert err is None and s.sport == 1000            # closest previous open
+    s, err = nl.get(100); assert err is None and s.sport == 1000            # equal stamp: index 0 -> first value
+    s, err = nl.get(200 + 59_000_000_000); assert err is None and s.sport == 1000   # after a closing last entry, < 1 minute after the open
+    assert nl.get(100 + 60_000_000_000 + 1) == (None, "closed socket on last entry")
+    nl.add(1000, b)                                                         # [100 open a, 200 close, 1000 open b], same daddr:dport
+    s, err = nl.get(240); assert err is None and s.sport == 1000            # on the close: 240-100 < 1000-240 -> the previous open
+    s, err = nl.get(600); assert err is None and s.sport == 1001            # 600-100 >= 1000-600 -> the next open
+    nl = SockLine(1, 3)
+    nl.add(100, a); nl.add(200, None); nl.add(300, c)
+    assert nl.get(250) == (None, "closed socket")                           # neighbours go to different destinations
+    # equal timestamps are inserted BEFORE the existing entry (lower bound, sock_num_line.go:311-322)
+    nl = SockLine(1, 3)
+    nl.add(100, a); nl.add(100, None)
+    assert [v[2] is None for v in nl.values()] == [True, False]
+
+
+def _tcp_wire(recs):
+    """BpfTcpEvent records (ebpf/tcp_state/tcp.go:63-72)."""
+    buf = np.zeros((len(recs), pyoracle.TCP_WIRE_SIZE), dtype=np.uint8)
+    for i, (typ, pid, fd, ts, saddr, sport, daddr, dport) in enumerate(recs):
+        r = buf[i]
+        r[0:8] = np.frombuffer(np.uint64(fd).tobytes(), np.uint8); r[8:16] = np.frombuffer(np.uint64(ts).tobytes(), np.uint8)
+        r[16:20] = np.frombuffer(np.uint32(typ).tobytes(), np.uint8); r[20:24] = np.frombuffer(np.uint32(pid).tobytes(), np.uint8)
+        r[24:26] = np.frombuffer(np.uint16(sport).tobytes(), np.uint8); r[26:28] = np.frombuffer(np.uint16(dport).tobytes(), np.uint8)
+        r[28:32] = [int(x) for x in saddr.split(".")]; r[44:48] = [int(x) for x in daddr.split(".")]
+    return buf.tobytes()
+
+
+def test_tcp_events_to_alive_connections():
+    """processTcpConnect (data.go:404-506) + one clearSocketLines tick (:1628-1716): localhost filtered, a close
+    without a line dropped, only lines whose last value is an open socket report, the source must be a pod,
+    destination service-first / pod / ("outbound", ip)."""
+    o = pyoracle.Oracle(0, 0, log_limit=100)
+    o.pod("ADD", "pod-a", "10.0.0.1"); o.pod("ADD", "pod-b", "10.0.0.2"); o.svc("ADD", "svc-x", "10.96.0.5")
+    E, Cl = pyoracle.TCP_ESTABLISHED, pyoracle.TCP_CLOSED
+    wire = _tcp_wire([
+        (E, 10, 3, 1000, "10.0.0.1", 40000, "10.96.0.5", 80),      # pod-a -> svc-x, stays open
+        (E, 10, 4, 1100, "10.0.0.1", 40001, "10.0.0.2", 8080),     # pod-a -> pod-b, closed below
+        (Cl, 10, 4, 1200, "10.0.0.1", 40001, "10.0.0.2", 8080),
+        (E, 10, 5, 1300, "10.0.0.1", 40002, "93.184.216.34", 443), # pod-a -> outbound
+        (E, 11, 3, 1400, "172.16.0.9", 40003, "10.0.0.2", 80),     # source is not a pod: ignored at sweep
+        (E, 12, 3, 1500, "127.0.0.1", 40004, "10.0.0.2", 80),      # localhost: filtered
+        (Cl, 13, 9, 1600, "10.0.0.2", 40005, "10.0.0.1", 80),      # close without a line: dropped
+        (3, 14, 3, 1700, "10.0.0.2", 0, "0.0.0.0", 0),             # LISTEN: not handled by processTcpConnect
+    ])
+    assert o.tcp_wire(wire) == 5 and o.sockline_count() == 4
+    assert o.sweep(now_ms=1_700_000_000_000) == 2
+    rows = sorted(o.alive_rows(), key=lambda r: r[4])
+    assert rows == [
+        (1_700_000_000_000, "10.0.0.1", "pod", "pod-a", 40000, "10.96.0.5", "service", "svc-x", 80),
+        (1_700_000_000_000, "10.0.0.1", "pod", "pod-a", 40002, "93.184.216.34", "outbound", "93.184.216.34", 443),
+    ]
+    # part 2: the alive connections are count-only edges of the open window
+    from alaz_amd import weights
+    o.window_close(weights.make_weights(1), 1)
+    d = o.edge_dict()
+    assert d[("pod", "pod-a", "service", "svc-x")][:5] == (0, 0, 0, 0, 0) and d[("pod", "pod-a", "service", "svc-x")][8] == 1
+    assert d[("pod", "pod-a", "outbound", "93.184.216.34")][8] == 1 and len(d) == 2
+    # DeleteUnused ran on every line: the (open, close) line lost its trailing close
+    assert len(o.sockline(10, 4)) == 1
