@@ -333,6 +333,8 @@ int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n) {
     st.events_dropped_cap += e->h_ctr[C_DROPPED_CAP];
     st.events_misrouted += e->h_ctr[C_MISROUTED];
     st.halo_overflow += e->h_ctr[C_HALO_OVF];
+    st.alive_in += e->h_ctr[C_ALIVE_SEEN];
+    st.alive_dropped += e->h_ctr[C_ALIVE_DROPPED];
     if (e->h_ctr[C_N_EVENTS]) {
         // convertKernelTimeToUserspaceTime()/1e6 — aggregator/data.go:1740-1743, :1219 (u64 wrap arithmetic)
         st.last_window_tmin_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMIN_NS])) / 1000000ull);
@@ -423,6 +425,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     }
     d.emask = e->ecap - 1;
     d.in_dense = d.ncap <= K3_IN_NODES ? 1u : 0u;
+    d.alive_cap = cfg->max_alive ? cfg->max_alive : 65536u;
     e->k3in_lds = d.in_dense ? (size_t)d.ncap * 48 : (size_t)K3_IN_HT * 52;
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
@@ -463,6 +466,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.P, (size_t)w.ncap * SG_F_HID)); LR(dev_alloc(e, &w.Q, (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.efeat, ME * SG_F_EDGE)); LR(dev_alloc(e, &w.latz, ME)); LR(dev_alloc(e, &w.errr, ME));
         LR(dev_alloc(e, &w.rows, ME));
+        LR(dev_alloc(e, &w.alive_keys, w.alive_cap)); LR(dev_alloc(e, &w.alive_csr, ME));
         // arm the per-workgroup statistic slots (tmin = ~0)
         std::vector<u64> init((size_t)SG_MAX_K1_WGS * WS_WORDS, 0);
         for (int i = 0; i < SG_MAX_K1_WGS; i++) init[(size_t)i * WS_WORDS + WS_TMIN] = ~0ull;

@@ -38,7 +38,11 @@ enum {
     C_OVF_N,          // records in the partition overflow list (window)
     C_N_LONG,         // rows longer than one wave (row sort work list)
     C_HALO_OVF,       // halo requests that did not fit the per-pair capacity (must stay 0)
-    C_COUNT = 16
+    C_ALIVE_N,        // SG_EV_ALIVE records accepted by K1 in the open window (list length, may exceed the capacity)
+    C_ALIVE_DROP,     // ... whose endpoint was not listed at close (working counter)
+    C_ALIVE_SEEN,     // closed window: records accepted
+    C_ALIVE_DROPPED,  // closed window: records not marked (capacity / unlisted endpoint)
+    C_COUNT = 24
 };
 
 // per-workgroup statistics slots written by K1 (one 64-byte line per workgroup: no cross-WG
@@ -47,7 +51,7 @@ enum { WS_TMIN = 0, WS_TMAX, WS_MAXLABEL, WS_DROPPED_SRC, WS_DROPPED_CAP, WS_MIS
 #define SG_MAX_K1_WGS 2048
 
 // node statistics words (SUM block), see include/servicegraph.h SG_NODE_STAT_SUM_WORDS
-enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, ST_OUT_SUM, ST_IN_SUM, ST_OUT_SSQ, ST_IN_SSQ };
+enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, ST_OUT_SUM, ST_IN_SUM, ST_OUT_SSQ, ST_IN_SSQ, ST_OUT_ALIVE, ST_IN_ALIVE };
 
 #define SG_MEAN_SLOTS 16
 // One out-degree counter per 32-byte sector: device-scope atomics serialise per sector (~12 ns each,
@@ -88,6 +92,8 @@ struct Dev {
     u32 in_dense;                             // 1: node-indexed LDS accumulation (ncap small enough), 0: hashed
     u32 ablate;                               // tuning switches (SG_ABLATE), 0 in production
     u64* dbg;                                 // phase time stamps (SG_ABLATE & 0x100): [kernel 0..3][4096 workgroups][8]
+    u64* alive_keys; u32 alive_cap;           // edge keys of the window's SG_EV_ALIVE records (marked onto the CSR at close)
+    u32* alive_csr;                           // [max_edges] CSR order: open connections per edge
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs
     u32* tile_cnt;  u32* tile_off;            // compaction scratch
@@ -97,7 +103,7 @@ struct Dev {
     u32* csr_from;                            // [max_edges] CSR order: source (row id per edge)
     u32* sort_k;    u32* sort_v;              // [2*max_edges] scratch for rows longer than the LDS sort
     u64* acc_csr;                             // [max_edges][4]
-    u64* st_sum;    u64* st_max;              // [ncap][10], [ncap][2]
+    u64* st_sum;    u64* st_max;              // [ncap][SG_NODE_STAT_SUM_WORDS], [ncap][2]
     float* x0;                                // [ncap][32]
     float* h[SG_MAX_LAYERS + 1];              // h[l] = output of layer l (l>=1): [ncap][64]
     float* P; float* Q;                       // [ncap][64]

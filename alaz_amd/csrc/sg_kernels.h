@@ -147,17 +147,22 @@ __device__ __forceinline__ u32 owner_of_dense(const Dev& d, u32 v, u32 nk, u32 n
 // Algorithmic bytes: 32 per event read + 32 per distinct edge written.
 // ------------------------------------------------------------------------------------------------
 struct K1Local { u64 tmin, tmax; u32 maxlabel, dsrc, dcap, misr, acc; };
-struct K1Ev { u64 key, dur, wt; u32 err; };
+struct K1Ev { u64 key, dur, wt; u32 err; u32 alive; };
+#define SG_DUR_MAX ((1ull << 62) - 1)      // durations saturate here: bits 62/63 of a single record carry flags
 
 // the join: one event -> edge key, or a counted drop.
 __device__ __forceinline__ bool k1_resolve(const Dev& d, const u64* iptab, const uint4 a, const uint4 b, K1Local& L, K1Ev& e) {
-    const u32 saddr = a.x, daddr = a.y, label = a.z;
+    const u32 saddr = a.x, daddr = a.y;
     const u32 status = a.w & 0xFFFFu, proto = (a.w >> 16) & 0xFFu, flags = a.w >> 24;
+    const bool alive = (flags & SG_EV_ALIVE) != 0;                // an open connection, not a request (data.go:1628-1679)
+    const u32 label = alive ? 0u : a.z;                          // ... joined without a Host header
     e.dur = (u64)b.x | ((u64)b.y << 32); e.wt = (u64)b.z | ((u64)b.w << 32);
+    e.dur = e.dur > SG_DUR_MAX ? SG_DUR_MAX : e.dur;
+    e.alive = alive ? 1u : 0u;
 
     u32 spod = SG_NONE, ssvc = SG_NONE;
     const bool sf = ip_lookup(iptab, d.ipmask, d.iptab2, d.ipmask2, saddr, spod, ssvc);
-    if (!sf || spod == SG_NONE) { L.dsrc++; return false; }     // data.go:829-832: source must be a pod
+    if (!sf || spod == SG_NONE) { if (!alive) L.dsrc++; return false; }   // data.go:829-832: source must be a pod (:1643-1647 ignores silently)
     u32 from = SG_MAKE_REF(SG_REF_KNOWN, spod);
     const bool sharded = d.world > 1;
     u32 from_owner = sharded ? owner_hash_ref(from) : 0u;
@@ -175,9 +180,15 @@ __device__ __forceinline__ bool k1_resolve(const Dev& d, const u64* iptab, const
         if (!table_slot(d.obkeys, d.obmask, (u64)daddr | (1ull << 32), 0ull, sg_fmix32(daddr) & d.obmask, os)) { L.dcap++; return false; }
         to = SG_MAKE_REF(SG_REF_OBIP, os); to_owner = owner_hash_obip(daddr);
     }
-    if (flags & SG_EV_REVERSE) { u32 t = from; from = to; to = t; t = from_owner; from_owner = to_owner; to_owner = t; }  // dto.go:226-231
+    if ((flags & SG_EV_REVERSE) && !alive) { u32 t = from; from = to; to = t; t = from_owner; from_owner = to_owner; to_owner = t; }  // dto.go:226-231
     if (sharded && (from_owner % d.world) != d.rank) { L.misr++; return false; }
     e.key = ((u64)from << 32) | (u64)to;
+    if (alive) {                                                 // no request is counted; the key goes on the window's alive list
+        e.err = 0; e.dur = 0;
+        const u64 idx = atomicAdd(&d.ctr[C_ALIVE_N], 1ull);
+        if (idx < d.alive_cap) d.alive_keys[idx] = e.key;
+        return true;
+    }
     e.err = is_error(proto, status);
     L.acc++;
     L.tmin = e.wt < L.tmin ? e.wt : L.tmin;
@@ -212,7 +223,8 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
         K1Ev e;
         if (!k1_resolve(d, d.iptab, a, b, L, e)) continue;
         u32 slot;
-        if (!table_slot(d.ekeys, d.emask, e.key, SG_EKEY_EMPTY, hash_key64(e.key) & d.emask, slot)) { L.dcap++; L.acc--; continue; }
+        if (!table_slot(d.ekeys, d.emask, e.key, SG_EKEY_EMPTY, hash_key64(e.key) & d.emask, slot)) { if (!e.alive) { L.dcap++; L.acc--; } continue; }
+        if (e.alive) continue;                                       // the slot exists now (count 0): that is all an open connection adds here
         u64* acc = d.eacc + (size_t)slot * 4;
         const u64 us = e.dur / 1000ull;
         atomicAdd(&acc[0], 1ull | ((u64)e.err << 32));
@@ -266,10 +278,12 @@ __device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1
 //   slab_a[(p*nwg + w) * sa * 5]    : sa aggregate records {key, cnt | err<<32, sum_ns, max_ns, sumsq_us}
 // A piece's header and its first 7 singles share one 128-byte line, so pass B usually needs one
 // line per piece.
-__device__ __forceinline__ void emit_single(const Dev& d, u32* fS, u32 w, u32 hk, u64 key, u64 dur, u32 err, K1Local& L) {
+// zero = 1: a record that only creates the edge (SG_EV_ALIVE): count 0, all accumulators 0
+__device__ __forceinline__ void emit_single(const Dev& d, u32* fS, u32 w, u32 hk, u64 key, u64 dur, u32 err, K1Local& L, u32 zero = 0) {
     const u32 p = part_of_hash(d, hk);
     const u32 pos = atomicAdd(&fS[p], 1u);
-    if (pos < d.ss) d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1) + 1 + pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31));
+    if (pos < d.ss) d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1) + 1 + pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31) | (zero << 30));
+    else if (zero) ovf_append(d, key, 0ull, 0ull, 0ull, 0ull, L);
     else { const u64 us = dur / 1000ull; ovf_append(d, key, 1ull | ((u64)err << 32), dur, dur, us * us, L); }
 }
 __device__ __forceinline__ void emit_agg(const Dev& d, u32* fA, u32 w, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
@@ -325,6 +339,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     auto insert = [&](const K1Ev& e) {
         if (d.ablate & 1u) { if (e.key == 0x1234567ull) L.dcap++; return; }
         const u32 hk = hash_key64(e.key);
+        if (e.alive) { emit_single(d, fS, w, hk, e.key, 0ull, 0u, L, 1u); return; }
         u32 h = hk & (K1A_CT - 1);
         int slot = -1;
 #pragma unroll
@@ -493,8 +508,9 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
             }
 #pragma unroll
             for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) {
-                const u64 key = (u64)x[u].x | ((u64)x[u].y << 32), dur = (u64)x[u].z | ((u64)(x[u].w & 0x7FFFFFFFu) << 32), us = dur / 1000ull;
-                add(key, 1ull | ((u64)(x[u].w >> 31) << 32), dur, dur, us * us);
+                const u64 key = (u64)x[u].x | ((u64)x[u].y << 32), dur = (u64)x[u].z | ((u64)(x[u].w & 0x3FFFFFFFu) << 32), us = dur / 1000ull;
+                const u64 one = ((x[u].w >> 30) & 1u) ? 0ull : 1ull;             // bit 62: edge-only record (SG_EV_ALIVE)
+                add(key, one | ((u64)(x[u].w >> 31) << 32), dur, dur, us * us);
             }
         }
         for (u32 r0 = sub; r0 < na; r0 += K1B_LPP) {
@@ -789,7 +805,7 @@ __device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
 // sqrt and four divisions are ~1000 instructions, and k2_rowsort_gather has three call sites (one of
 // them unrolled 4x) — inlined, the kernel was 6.9 k instructions of mostly cold instruction-cache
 // misses.  The arguments are passed by value (a reference to Dev would spill the whole struct to scratch).
-struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; float* efeat; float* latz; float* errr; u64* eacc; u64* ekeys; u32 variant; };
+struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; float* efeat; float* latz; float* errr; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; };
 __device__ __attribute__((noinline)) void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row, u32 slot, u64 r_cnt, u64 r_sum, u64 r_ssq,
                                                     const ulonglong2 x, const ulonglong2 y) {
     const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
@@ -806,6 +822,7 @@ __device__ __attribute__((noinline)) void edge_emit(const EdgeEmitArgs d, u32 po
     e[0] = make_float4((float)log1p((double)cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
     e[1] = make_float4(err_ratio, (float)log1p((double)err), zc * 0.125f, 1.0f);
     d.latz[pos] = lat_z; d.errr[pos] = err_ratio;
+    d.alive_csr[pos] = 0;                                            // k3_in_stats adds the window's open connections
     if (d.variant == 1) {                                            // variant 1: this is also the window reset of the edge table
         ulonglong2* src = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)slot * 4);
         src[0] = make_ulonglong2(0, 0); src[1] = make_ulonglong2(0, 0);
@@ -817,7 +834,7 @@ __device__ __attribute__((noinline)) void edge_emit(const EdgeEmitArgs d, u32 po
 #define K2_LONG_WGS 256
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
-    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.efeat, d.latz, d.errr, d.eacc, d.ekeys, d.variant};
+    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.efeat, d.latz, d.errr, d.eacc, d.ekeys, d.alive_csr, d.variant};
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
     __shared__ u64 red[5][4];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -941,10 +958,39 @@ __device__ __forceinline__ void in_flush(const Dev& d, u32 to, const u64* o) {
     atomicAdd(&gsum[ST_IN_SUM], o[3]); atomicAdd(&gsum[ST_IN_SSQ], o[4]);
     atomicMax(&d.st_max[(size_t)to * 2 + 1], o[5]);
 }
+// The window's open connections (SG_EV_ALIVE, f-2) are marked here too: every record's edge exists in
+// the CSR (K1 created it with count 0 if it carried no request); a binary search in the sorted row
+// finds it.  Costs one scalar load when the window has none.
+__device__ __forceinline__ void alive_mark(const Dev& d, u32 g, u32 G, u32 t) {
+    const u64 n_all = d.ctr[C_ALIVE_N];
+    if (n_all == 0) return;
+    const u32 n = (u32)(n_all < d.alive_cap ? n_all : d.alive_cap);
+    const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
+    for (u32 i = g * 1024 + t; i < n; i += G * 1024) {
+        const u64 key = d.alive_keys[i];
+        const u32 f = dense_of(d, (u32)(key >> 32), nk, nl, nob), to = dense_of(d, (u32)key, nk, nl, nob);
+        bool ok = f != SG_NONE && to != SG_NONE;
+        if (ok) {
+            u32 lo = d.rowptr[f], hi = d.rowptr[f + 1];
+            if ((u64)hi > d.max_edges) hi = (u32)d.max_edges;
+            const u32 end = hi;
+            while (lo < hi) { const u32 m = (lo + hi) >> 1; if (d.col[m] < to) lo = m + 1; else hi = m; }
+            ok = lo < end && d.col[lo] == to;
+            if (ok) {
+                atomicAdd(&d.alive_csr[lo], 1u);
+                atomicAdd(&d.st_sum[(size_t)f * SG_NODE_STAT_SUM_WORDS + ST_OUT_ALIVE], 1ull);
+                atomicAdd(&d.st_sum[(size_t)to * SG_NODE_STAT_SUM_WORDS + ST_IN_ALIVE], 1ull);
+            }
+        }
+        if (!ok) atomicAdd(&d.ctr[C_ALIVE_DROP], 1ull);
+    }
+}
+
 __global__ __launch_bounds__(1024) void k3_in_stats(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 E = (u32)d.ctr[C_N_EDGES], N = (u32)d.ctr[C_N_NODES];
     const u32 G = gridDim.x, g = blockIdx.x, t = threadIdx.x;
+    alive_mark(d, g, G, t);
     const u32 per = (E + G - 1) / G, p0 = g * per < E ? g * per : E, p1 = p0 + per < E ? p0 + per : E;
     if (d.in_dense) {
         u64* acc = reinterpret_cast<u64*>(smem);                     // [N][6]: deg, cnt, err, sum, ssq, max
@@ -1007,7 +1053,7 @@ __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
     for (u32 v0 = blockIdx.x * 128; v0 < N; v0 += gridDim.x * 128) {
         const u32 v = v0 + (threadIdx.x >> 1);
         const bool live = v < N;
-        float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        float a[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (live) {
             const u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
             const u64 dg = s[ST_OUT_DEG + side], c = s[ST_OUT_CNT + side], er = s[ST_OUT_ERR + side], sm = s[ST_OUT_SUM + side], sq = s[ST_OUT_SSQ + side];
@@ -1018,10 +1064,11 @@ __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
             a[3] = c ? (float)((double)er / (double)c) : 0.0f;
             a[4] = (float)log1p((double)mx / 1e6);
             a[5] = (float)log1p(std_us(sm, sq, c) / 1000.0);
+            a[6] = (float)log1p((double)s[ST_OUT_ALIVE + side]);
         }
-        float b[6];
+        float b[7];
 #pragma unroll
-        for (int k = 0; k < 6; k++) b[k] = __shfl_xor(a[k], 1, 64);
+        for (int k = 0; k < 7; k++) b[k] = __shfl_xor(a[k], 1, 64);
         if (!live) continue;
         float4* o = reinterpret_cast<float4*>(d.x0 + (size_t)v * SG_F_IN);
         if (side == 0) {                                             // a = out side, b = in side
@@ -1030,10 +1077,17 @@ __global__ __launch_bounds__(256) void k3_node_features(Dev d) {
             o[1] = make_float4(a[2], b[2], a[3], b[3]);
             o[2] = make_float4(a[4], b[4], kind == SG_NODE_POD ? 1.0f : 0.0f, kind == SG_NODE_SERVICE ? 1.0f : 0.0f);
             o[3] = make_float4(kind == 0 ? 1.0f : 0.0f, a[5], b[5], 1.0f);
-        } else {
+        } else {                                                     // a = in side, b = out side
+            o[4] = make_float4(b[6], a[6], 0.0f, 0.0f);
 #pragma unroll
-            for (int q = 4; q < (int)SG_F_IN / 4; q++) o[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int q = 5; q < (int)SG_F_IN / 4; q++) o[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                       // the alive list is consumed (k3_in_stats): report and re-arm
+        const u64 n = d.ctr[C_ALIVE_N];
+        d.ctr[C_ALIVE_SEEN] = n;
+        d.ctr[C_ALIVE_DROPPED] = d.ctr[C_ALIVE_DROP] + (n > d.alive_cap ? n - d.alive_cap : 0);
+        d.ctr[C_ALIVE_N] = 0; d.ctr[C_ALIVE_DROP] = 0;
     }
 }
 
@@ -1342,7 +1396,7 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
             o.sum_ns = x.y; o.max_ns = y.x; o.sumsq_us = y.y;
             o.from_ref = ref_of_dense(u, nk, nl); o.to_ref = ref_of_dense(v, nk, nl);
             o.count = (u32)(x.x & 0xFFFFFFFFull); o.err_count = (u32)(x.x >> 32);
-            o.score = score; o.lat_z = d.latz[p]; o.err_ratio = d.errr[p]; o._pad = 0;
+            o.score = score; o.lat_z = d.latz[p]; o.err_ratio = d.errr[p]; o.alive = d.alive_csr[p];
             d.rows[p] = o;
         }
     }

@@ -41,7 +41,7 @@ class SgConfig(C.Structure):
                 ("max_labels", C.c_uint32), ("max_outbound_ips", C.c_uint32), ("max_ips", C.c_uint32),
                 ("max_edges", C.c_uint64), ("max_batch", C.c_uint32), ("layers", C.c_uint32),
                 ("rank", C.c_uint32), ("world", C.c_uint32), ("k1_variant", C.c_uint32),
-                ("max_window_events", C.c_uint64), ("windows_in_flight", C.c_uint32), ("_reserved", C.c_uint32)]
+                ("max_window_events", C.c_uint64), ("windows_in_flight", C.c_uint32), ("max_alive", C.c_uint32)]
 
 
 class SgStats(C.Structure):
@@ -49,7 +49,8 @@ class SgStats(C.Structure):
                 ("events_dropped_cap", C.c_uint64), ("windows", C.c_uint64), ("last_window_events", C.c_uint64),
                 ("last_window_edges", C.c_uint64), ("last_window_nodes", C.c_uint64),
                 ("last_window_tmin_ms", C.c_int64), ("last_window_tmax_ms", C.c_int64), ("h2d_bytes", C.c_uint64),
-                ("events_misrouted", C.c_uint64), ("halo_overflow", C.c_uint64)]
+                ("events_misrouted", C.c_uint64), ("halo_overflow", C.c_uint64),
+                ("alive_in", C.c_uint64), ("alive_dropped", C.c_uint64)]
 
 
 class ServiceGraphError(RuntimeError):

@@ -29,7 +29,7 @@ class NumpyBackend:
         self.nk, self.nl = len(kind), n_labels
         self.W, self.layers, self.rank, self.world, self.ncap, self.max_obip = weights.astype(np.float32), layers, rank, world, ncap, max_obip
         self.device = torch.device("cpu")
-        self.stats_flat = torch.zeros(ncap * 12, dtype=torch.int64)
+        self.stats_flat = torch.zeros(ncap * 14, dtype=torch.int64)
         self.stats_sum = self.stats_flat[: ncap * 12]; self.stats_max = self.stats_flat[ncap * 12:]
         self.capp = ncap
         self.ob_all = torch.zeros((world, max_obip + 1), dtype=torch.int64)

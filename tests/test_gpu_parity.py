@@ -443,3 +443,55 @@ def test_windows_in_flight_give_the_same_rows_as_one_window_at_a_time():
     # and the synchronous API keeps working on the current slot
     assert g.ingest(wins[0]) == 0
     assert g.flush_window().tobytes() == want[0].tobytes()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_alive_connections_are_count_only_edges(variant):
+    """f-2: SG_EV_ALIVE records (open TCP connections, data.go:1628-1679) go through the same join — no Host
+    header, no reversal, a non-pod source is ignored silently — create their edge if the window has no request
+    on it, and only add to `alive`.  Edges, accumulators, alive counts, scores (node features 16/17 feed the
+    SAGE layers) and the canonical row order must equal the oracle's; two windows, the second without alive
+    records, to show the list is re-armed."""
+    topo = replay.make_topology(60, 400, seed=91)
+    ev, labels = replay.make_events(topo, 30_000, seed=92, with_raw_outbound=True)
+    rng = np.random.default_rng(93)
+    n_alive = 3000
+    al = np.zeros(n_alive, dtype=replay.EVENT_DTYPE)
+    al["flags"] = replay.EV_ALIVE
+    src = rng.integers(0, topo.n_pods, n_alive)
+    al["saddr"] = topo.pod_ips[src]
+    kind = rng.random(n_alive)
+    on_edge = rng.integers(0, len(ev), n_alive)
+    al["daddr"] = np.where(kind < 0.4, ev["daddr"][on_edge],                                      # where requests also flow
+                  np.where(kind < 0.7, topo.svc_ips[rng.integers(0, topo.n_svcs, n_alive)],          # idle service edges
+                  np.where(kind < 0.85, topo.pod_ips[rng.integers(0, topo.n_pods, n_alive)],         # pod to pod
+                           0x5DB8D800 + rng.integers(0, 40, n_alive)))).astype(np.uint32)            # raw outbound IPs
+    al["saddr"][kind < 0.4] = ev["saddr"][on_edge][kind < 0.4]
+    al["saddr"][-50:] = 0xC0A80001                                                                   # not a pod: ignored, not counted as dropped
+    al["host_label"][::7] = 1                                                                         # must be ignored for alive records
+    al["flags"][::11] |= replay.EV_REVERSE                                                            # so must this
+    al["duration_ns"] = 12345; al["status"] = 503                                                     # and these
+    both = np.concatenate([ev[:15_000], al[:1500], ev[15_000:], al[1500:]])
+    ops = topo.k8s_ops()
+    g = _engine(topo.n_nodes + 8, 8192, 2, k1_variant=variant, max_window_events=len(both) + 1)
+    shim = HostShim(); shim.apply(g, ops)
+    o = _oracle(ops, 2)
+    W = weights.make_weights(2)
+    seen = 0
+    for batch, has_alive in ((both, True), (ev[:5000], False)):
+        for i in range(0, len(batch), 7001):
+            assert g.ingest(batch[i:i + 7001]) == 0
+        g.set_label_count(len(labels))
+        rows = g.flush_window()
+        o.packed(batch, labels); o.window_close(W, 2)
+        want = o.edge_dict()
+        compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), want)
+        n_al = sum(v[8] for v in want.values())
+        assert int(rows["alive"].sum()) == n_al and (n_al > 2500) == has_alive and (n_al == 0) == (not has_alive)
+        seen += n_al
+        if has_alive:
+            assert sum(1 for v in want.values() if v[0] == 0 and v[8] > 0) > 1000                     # idle edges exist only through alive records
+        assert np.array_equal(rows["from_ref"], o.edge_rows()["from_ref"]) and np.array_equal(rows["to_ref"], o.edge_rows()["to_ref"])
+        st = g.stats()
+        assert st.last_window_events == o.window_events and st.last_window_nodes == o.n_nodes
+    assert st.alive_in == seen and st.alive_dropped == 0 and st.events_dropped_src == o.dropped_src
