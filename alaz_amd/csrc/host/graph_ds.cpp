@@ -91,6 +91,17 @@ static uint8_t ProtocolId(const std::string& p, bool* tls) {
 }
 
 // The datastore-boundary tap.  The DTO is only read during the call (cgo rule; backend.go:824-839).
+int GraphDS::PersistAliveConnection(const datastore::AliveConnection* c) {
+    if (!c) return SG_EINVAL;
+    sg_event ev; std::memset(&ev, 0, sizeof ev);
+    if (ParseIPv4(c->FromIP, &ev.saddr) && ParseIPv4(c->ToIP, &ev.daddr)) {
+        ev.flags = SG_EV_ALIVE;
+        std::lock_guard<std::mutex> g(mu_);
+        Append(ev);
+    }
+    return inner_->PersistAliveConnection(c);
+}
+
 int GraphDS::PersistRequest(const datastore::Request* r) {
     if (!r) return SG_EINVAL;
     sg_event ev; std::memset(&ev, 0, sizeof ev);
@@ -174,7 +185,7 @@ long GraphDS::FlushWindow(int64_t window_end_ms) {
             const sg_edge_out& r = rows[i]; EdgeRow& o = out[i];
             name(r.from_ref, &o.FromType, &o.FromUID); name(r.to_ref, &o.ToType, &o.ToUID);
             o.Count = r.count; o.ErrCount = r.err_count; o.SumNs = r.sum_ns; o.MaxNs = r.max_ns; o.SumSqUs = r.sumsq_us;
-            o.Score = r.score; o.LatZ = r.lat_z; o.ErrRatio = r.err_ratio;
+            o.Score = r.score; o.LatZ = r.lat_z; o.ErrRatio = r.err_ratio; o.Alive = r.alive;
         }
     }
     if (sink_) { const int rc = sink_->PersistEdges(window_end_ms, out); if (rc != 0) return rc; }

@@ -48,6 +48,7 @@ struct EdgeRow {                       // one edge of a closed window, in the re
     uint32_t Count = 0, ErrCount = 0;
     uint64_t SumNs = 0, MaxNs = 0, SumSqUs = 0;
     float Score = 0, LatZ = 0, ErrRatio = 0;
+    uint32_t Alive = 0;                // open connections reported on the edge in the window
 };
 
 class EdgeSink {
@@ -74,7 +75,9 @@ public:
     int PersistStatefulSet(const datastore::StatefulSet& ss, const std::string& et) override { return inner_->PersistStatefulSet(ss, et); }
     int PersistRequest(const datastore::Request* request) override;
     int PersistKafkaEvent(const datastore::KafkaEvent* request) override;
-    int PersistAliveConnection(const datastore::AliveConnection* conn) override { return inner_->PersistAliveConnection(conn); }
+    // an open TCP connection (sendOpenConnection, data.go:1628-1679): forwarded, and fed to the engine as an
+    // SG_EV_ALIVE record — the join (source must be a pod, service before pod, else the IP) runs on the GPU
+    int PersistAliveConnection(const datastore::AliveConnection* conn) override;
 
     // earlier tap: the raw L7 event (what processL7 receives, aggregator/data.go:1364-1383)
     int IngestL7(const l7_req::L7Event& e, uint32_t kafka_msgs = 1);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "graph_ds.hpp"
+#include "sockline.hpp"
 
 using namespace alaz;
 
@@ -43,6 +44,7 @@ struct HostCtx {
     void* dl = nullptr; SgApi api; sg_handle h = nullptr; bool mock = false;
     datastore::NullDataStore inner; CollectSink sink;
     std::unique_ptr<GraphDS> ds;
+    ConnTracker conns;                 // f-2: TCP connect events -> socket lines -> alive connections
 };
 
 }  // namespace
@@ -51,7 +53,7 @@ extern "C" {
 
 struct sgh_edge_row {
     char from_type[12], to_type[12], from_uid[160], to_uid[160];
-    uint32_t count, err_count; uint64_t sum_ns, max_ns, sumsq_us; float score, lat_z, err_ratio;
+    uint32_t count, err_count; uint64_t sum_ns, max_ns, sumsq_us; float score, lat_z, err_ratio; uint32_t alive;
 };
 
 void* sgh_packer_create(void) { return new L7Packer(); }
@@ -121,10 +123,46 @@ long sgh_graphds_flush(void* g, int64_t window_end_ms, sgh_edge_row* out, size_t
         std::strncpy(o.from_type, r.FromType.c_str(), sizeof o.from_type - 1); std::strncpy(o.to_type, r.ToType.c_str(), sizeof o.to_type - 1);
         std::strncpy(o.from_uid, r.FromUID.c_str(), sizeof o.from_uid - 1); std::strncpy(o.to_uid, r.ToUID.c_str(), sizeof o.to_uid - 1);
         o.count = r.Count; o.err_count = r.ErrCount; o.sum_ns = r.SumNs; o.max_ns = r.MaxNs; o.sumsq_us = r.SumSqUs;
-        o.score = r.Score; o.lat_z = r.LatZ; o.err_ratio = r.ErrRatio;
+        o.score = r.Score; o.lat_z = r.LatZ; o.err_ratio = r.ErrRatio; o.alive = r.Alive;
     }
     return n;
 }
+// ---- f-2: socket lines ----
+struct sgh_sockinfo { uint32_t pid; uint64_t fd; uint32_t saddr; uint16_t sport; uint32_t daddr; uint16_t dport; };
+void* sgh_sockline_create(uint32_t pid, uint64_t fd) { return new SocketLine(pid, fd); }
+void sgh_sockline_destroy(void* l) { delete static_cast<SocketLine*>(l); }
+void sgh_sockline_add(void* l, uint64_t ts, const sgh_sockinfo* si) {
+    if (!si) { static_cast<SocketLine*>(l)->AddValue(ts, nullptr); return; }
+    SockInfo s; s.Pid = si->pid; s.Fd = si->fd; s.Saddr = si->saddr; s.Sport = si->sport; s.Daddr = si->daddr; s.Dport = si->dport;
+    static_cast<SocketLine*>(l)->AddValue(ts, &s);
+}
+int sgh_sockline_get(void* l, uint64_t ts, uint64_t now_ns, sgh_sockinfo* out) {
+    SockInfo s; const SockErr e = static_cast<SocketLine*>(l)->GetValue(ts, now_ns, &s);
+    if (e == SockErr::Ok && out) { out->pid = s.Pid; out->fd = s.Fd; out->saddr = s.Saddr; out->sport = s.Sport; out->daddr = s.Daddr; out->dport = s.Dport; }
+    return (int)e;
+}
+void sgh_sockline_delete_unused(void* l) { static_cast<SocketLine*>(l)->DeleteUnused(); }
+size_t sgh_sockline_len(void* l) { return static_cast<SocketLine*>(l)->Size(); }
+int sgh_sockline_at(void* l, size_t i, uint64_t* ts, uint64_t* last_match, sgh_sockinfo* out) {
+    auto* sl = static_cast<SocketLine*>(l);
+    if (i >= sl->Size()) return -1;
+    const TimestampedSocket v = sl->At(i);
+    if (ts) *ts = v.Timestamp;
+    if (last_match) *last_match = v.LastMatch;
+    if (out && v.Open) { out->pid = v.Info.Pid; out->fd = v.Info.Fd; out->saddr = v.Info.Saddr; out->sport = v.Info.Sport; out->daddr = v.Info.Daddr; out->dport = v.Info.Dport; }
+    return v.Open ? 1 : 0;
+}
+// TCP connect records (BpfTcpEvent, 64 bytes each) through processTcpConnect; returns values added
+size_t sgh_graphds_tcp_wire(void* g, const uint8_t* recs, size_t n) {
+    auto* c = static_cast<HostCtx*>(g); size_t added = 0;
+    for (size_t i = 0; i < n; i++) added += c->conns.ProcessTcpConnect(tcp_state::DecodeWire(recs + i * tcp_state::kWireSize)) ? 1 : 0;
+    return added;
+}
+size_t sgh_graphds_socklines(void* g) { return static_cast<HostCtx*>(g)->conns.Lines(); }
+void* sgh_graphds_sockline(void* g, uint32_t pid, uint64_t fd) { return static_cast<HostCtx*>(g)->conns.Line(pid, fd); }
+// one clearSocketLines tick: open connections -> GraphDS::PersistAliveConnection (-> SG_EV_ALIVE records)
+size_t sgh_graphds_sweep(void* g, int64_t now_ms, int send_alive) { auto* c = static_cast<HostCtx*>(g); return c->conns.Sweep(now_ms, send_alive != 0, c->ds.get()); }
+
 size_t sgh_graphds_labels(void* g, char* buf, size_t cap) { return join_labels(static_cast<HostCtx*>(g)->ds->Labels(), buf, cap); }
 uint64_t sgh_graphds_dropped_parse(void* g) { return static_cast<HostCtx*>(g)->ds->Packer().DroppedParse(); }
 void* sgh_graphds_engine(void* g) { return static_cast<HostCtx*>(g)->h; }

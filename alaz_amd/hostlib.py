@@ -18,7 +18,11 @@ HOST_LIB = os.path.join(_HERE, "lib", "libsgdatastore.so")
 class EdgeRowC(C.Structure):
     _fields_ = [("from_type", C.c_char * 12), ("to_type", C.c_char * 12), ("from_uid", C.c_char * 160), ("to_uid", C.c_char * 160),
                 ("count", C.c_uint32), ("err_count", C.c_uint32), ("sum_ns", C.c_uint64), ("max_ns", C.c_uint64), ("sumsq_us", C.c_uint64),
-                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float)]
+                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float), ("alive", C.c_uint32)]
+
+
+class SockInfoC(C.Structure):
+    _fields_ = [("pid", C.c_uint32), ("fd", C.c_uint64), ("saddr", C.c_uint32), ("sport", C.c_uint16), ("daddr", C.c_uint32), ("dport", C.c_uint16)]
 
 
 _lib = None
@@ -43,6 +47,12 @@ def load() -> C.CDLL:
             "sgh_graphds_persist_request": (C.c_int, [P, C.c_int64, u64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                                       C.c_char_p, u32, C.c_char_p, C.c_int]),
             "sgh_graphds_flush": (C.c_long, [P, C.c_int64, C.POINTER(EdgeRowC), sz]),
+            "sgh_sockline_create": (P, [u32, u64]), "sgh_sockline_destroy": (None, [P]),
+            "sgh_sockline_add": (None, [P, u64, C.POINTER(SockInfoC)]), "sgh_sockline_get": (C.c_int, [P, u64, u64, C.POINTER(SockInfoC)]),
+            "sgh_sockline_delete_unused": (None, [P]), "sgh_sockline_len": (sz, [P]),
+            "sgh_sockline_at": (C.c_int, [P, sz, C.POINTER(u64), C.POINTER(u64), C.POINTER(SockInfoC)]),
+            "sgh_graphds_tcp_wire": (sz, [P, P, sz]), "sgh_graphds_socklines": (sz, [P]), "sgh_graphds_sockline": (P, [P, u32, u64]),
+            "sgh_graphds_sweep": (sz, [P, C.c_int64, C.c_int]),
             "sgh_graphds_labels": (sz, [P, C.c_char_p, sz]), "sgh_graphds_dropped_parse": (u64, [P]), "sgh_graphds_engine": (P, [P]),
             "sgh_mock_events": (sz, [P, P, sz]), "sgh_mock_table_ops": (sz, [P, P, sz]), "sgh_mock_label_count": (u32, [P]),
         }
@@ -62,6 +72,47 @@ def parse_http(req: bytes):
     m, p, v, h = (C.create_string_buffer(1200) for _ in range(4))
     load().sgh_parse_http(req, len(req), m, p, v, h, 1200)
     return tuple(x.value.decode("latin-1") for x in (m, p, v, h))
+
+
+SL_ERRORS = {1: "sock line is empty", 2: "closed socket on last entry", 3: "no smaller value found", 4: "closed socket"}
+
+
+class SocketLine:
+    """alaz::SocketLine (csrc/host/sockline.hpp); addresses are numeric IPv4."""
+    def __init__(self, pid: int = 0, fd: int = 0, _borrowed=None):
+        self._l = load(); self._own = _borrowed is None
+        self._p = self._l.sgh_sockline_create(pid, fd) if self._own else _borrowed
+
+    def __del__(self):
+        try:
+            if self._own and self._p:
+                self._l.sgh_sockline_destroy(self._p); self._p = None
+        except Exception:
+            pass
+
+    def add(self, ts: int, si):
+        """si = (saddr, sport, daddr, dport) or None for a close"""
+        if si is None:
+            self._l.sgh_sockline_add(self._p, ts, None)
+        else:
+            c = SockInfoC(0, 0, si[0], si[1], si[2], si[3]); self._l.sgh_sockline_add(self._p, ts, C.byref(c))
+
+    def get(self, ts: int, now_ns: int = 1):
+        out = SockInfoC()
+        rc = self._l.sgh_sockline_get(self._p, ts, now_ns, C.byref(out))
+        return ((out.saddr, out.sport, out.daddr, out.dport), None) if rc == 0 else (None, SL_ERRORS[rc])
+
+    def delete_unused(self): self._l.sgh_sockline_delete_unused(self._p)
+
+    def __len__(self): return self._l.sgh_sockline_len(self._p)
+
+    def values(self):
+        out = []
+        for i in range(len(self)):
+            ts, lm, si = C.c_uint64(), C.c_uint64(), SockInfoC()
+            o = self._l.sgh_sockline_at(self._p, i, C.byref(ts), C.byref(lm), C.byref(si))
+            out.append((ts.value, lm.value, (si.saddr, si.sport, si.daddr, si.dport) if o == 1 else None))
+        return out
 
 
 class Packer:
@@ -145,8 +196,22 @@ class GraphDS:
         for i in range(min(n, self.max_edges)):
             r = out[i]
             d[(r.from_type.decode(), r.from_uid.decode(), r.to_type.decode(), r.to_uid.decode())] = (
-                r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio)
+                r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio, r.alive)
         return d
+
+    # ---- f-2: TCP connect events -> socket lines -> alive connections ----
+    def tcp_wire(self, recs: bytes) -> int:
+        assert len(recs) % 64 == 0
+        buf = (C.c_uint8 * len(recs)).from_buffer_copy(recs)
+        return self._l.sgh_graphds_tcp_wire(self._g, C.addressof(buf), len(recs) // 64)
+
+    def sockline_count(self) -> int: return self._l.sgh_graphds_socklines(self._g)
+
+    def sockline(self, pid: int, fd: int):
+        p = self._l.sgh_graphds_sockline(self._g, pid, fd)
+        return SocketLine(_borrowed=p) if p else None
+
+    def sweep(self, now_ms: int, send_alive: bool = True) -> int: return self._l.sgh_graphds_sweep(self._g, now_ms, int(send_alive))
 
     @property
     def labels(self): return _labels(self._l.sgh_graphds_labels, self._g)

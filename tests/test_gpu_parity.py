@@ -275,6 +275,23 @@ def test_cpp_graphds_end_to_end_from_wire_records():
     got = g.FlushWindow(123)
     compare_edge_dicts(got, o.edge_dict())
     assert g.dropped_parse == o.dropped_parse > 0 and g.labels == o.labels
+    # f-2, second window: TCP connect records -> socket lines -> sweep -> alive connections beside the requests
+    from tests.test_sockline import _tcp_wire
+    rng = np.random.default_rng(5)
+    ips = [replay.ip_str(int(x)) for x in topo.pod_ips[:20]] + [replay.ip_str(int(x)) for x in topo.svc_ips[:10]] + ["93.184.216.34", "172.16.5.5"]
+    recs = []
+    for k in range(400):
+        recs.append((1 if rng.random() < 0.7 else 5, int(rng.integers(1, 9)), int(rng.integers(3, 20)), 1000 + 7 * k,
+                     ips[int(rng.integers(0, 20))] if rng.random() < 0.9 else ips[-1], 40000 + k, ips[int(rng.integers(0, len(ips)))], 443))
+    tw = _tcp_wire(recs)
+    assert g.tcp_wire(tw) == o.tcp_wire(tw)
+    assert g.ingest_wire(wire[: 5000 * replay.L7_WIRE_SIZE], kafka[:5000]) == 0
+    o.l7_wire(wire[: 5000 * replay.L7_WIRE_SIZE], kafka[:5000])
+    g.sweep(99); o.sweep(99)
+    o.window_close(W, 2)
+    got = g.FlushWindow(124)
+    compare_edge_dicts(got, o.edge_dict())
+    assert sum(v[8] for v in got.values()) == o.alive_count() > 0
 
 
 @pytest.mark.parametrize("layers", [1, 2])

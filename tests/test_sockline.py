@@ -132,3 +132,88 @@ def test_tcp_events_to_alive_connections():
     assert d[("pod", "pod-a", "outbound", "93.184.216.34")][8] == 1 and len(d) == 2
     # DeleteUnused ran on every line: the (open, close) line lost its trailing close
     assert len(o.sockline(10, 4)) == 1
+
+
+# ---- the C++ host implementation against the oracle ---------------------------------------------
+def _ip(s):
+    a, b, c, d = (int(x) for x in s.split("."))
+    return (a << 24) | (b << 16) | (c << 8) | d
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_cpp_socket_line_equals_the_oracle_on_random_traces(seed):
+    """AddValue / GetValue / DeleteUnused in random order, a handful of address pairs (so de-duplication,
+    equal time stamps, closes between opens to the same destination and the 1-minute / 5-minute rules all
+    occur): the C++ SocketLine (alaz_amd/csrc/host/sockline.cpp) must agree with the oracle after every step."""
+    from alaz_amd import build, hostlib
+    build.build_all()
+    rng = np.random.default_rng(seed)
+    cpp, orc = hostlib.SocketLine(7, 9), SockLine(7, 9)
+    pairs = [("10.0.0.1", 1000 + k % 3, "10.0.0.%d" % (2 + k % 2), 80) for k in range(4)]
+    now = 10**12
+    for step in range(400):
+        r = rng.random()
+        ts = int(rng.integers(0, 50)) * 10**9 * (40 if rng.random() < 0.1 else 1)       # coarse stamps: ties happen
+        if r < 0.45:
+            p = pairs[int(rng.integers(0, len(pairs)))] if rng.random() < 0.7 else None
+            cpp.add(ts, None if p is None else (_ip(p[0]), p[1], _ip(p[2]), p[3]))
+            orc.add(ts, None if p is None else sockinfo(*p))
+        elif r < 0.9:
+            now += int(rng.integers(1, 200)) * 10**9
+            a, ea = cpp.get(ts, now)
+            b, eb = orc.get(ts, now)
+            assert ea == eb, (step, ea, eb)
+            if ea is None:
+                assert a == (_ip(b.saddr.decode()), b.sport, _ip(b.daddr.decode()), b.dport)
+        else:
+            cpp.delete_unused(); orc.delete_unused()
+        va = cpp.values()
+        vb = [(t, lm, None if si is None else (_ip(si[0]), si[1], _ip(si[2]), si[3])) for t, lm, si in orc.values()]
+        assert va == vb, step
+
+
+def test_cpp_tracker_feeds_alive_records_to_the_engine_boundary():
+    """BpfTcpEvent records -> ConnTracker::ProcessTcpConnect -> Sweep -> GraphDS::PersistAliveConnection ->
+    SG_EV_ALIVE events at the C ABI (recording engine): same lines, same reported connections as the oracle."""
+    from alaz_amd import build, engine, hostlib, replay
+    build.build_all()
+    E, Cl = pyoracle.TCP_ESTABLISHED, pyoracle.TCP_CLOSED
+    rng = np.random.default_rng(11)
+    recs = []
+    for k in range(300):
+        pid, fd = int(rng.integers(1, 6)), int(rng.integers(3, 12))
+        s = "10.0.0.%d" % rng.integers(1, 5) if rng.random() < 0.9 else ("127.0.0.1" if rng.random() < 0.5 else "172.16.0.3")
+        d = ("10.96.0.%d" % rng.integers(1, 4)) if rng.random() < 0.6 else ("10.0.0.%d" % rng.integers(1, 5) if rng.random() < 0.6 else "93.184.216.%d" % rng.integers(1, 5))
+        recs.append((E if rng.random() < 0.6 else (Cl if rng.random() < 0.9 else 3), pid, fd, 1000 + 10 * k, s, 30000 + k, d, 80))
+    wire = _tcp_wire(recs)
+    o = pyoracle.Oracle(0, 0, log_limit=10_000)
+    cfg = engine.SgConfig(1, 0, 64, 64, 64, 64, 1024, 1 << 16, 1, 0, 1, 0, 0, 1, 0)
+    g = hostlib.GraphDS(cfg, engine_lib=None, batch=1)
+    for i in range(1, 5):
+        o.pod("ADD", f"pod-{i}", f"10.0.0.{i}"); g.PersistPod(f"pod-{i}", f"10.0.0.{i}")
+    for i in range(1, 4):
+        o.svc("ADD", f"svc-{i}", f"10.96.0.{i}"); g.PersistService(f"svc-{i}", f"10.96.0.{i}")
+    assert g.tcp_wire(wire) == o.tcp_wire(wire)
+    assert g.sockline_count() == o.sockline_count()
+    for pid in range(1, 6):
+        for fd in range(3, 12):
+            a, b = g.sockline(pid, fd), o.sockline(pid, fd)
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert [(t, s is None) for t, _, s in a.values()] == [(t, s is None) for t, _, s in b.values()]
+    n_lines_open = g.sweep(1234)
+    o.sweep(1234)
+    ev = g.mock_events()
+    al = ev[(ev["flags"] & replay.EV_ALIVE) != 0]
+    # the host reports every line whose last value is open; the join (source must be a pod ...) is the engine's
+    assert len(al) == n_lines_open >= o.alive_count() > 0
+    pod_ips = {_ip(f"10.0.0.{i}") for i in range(1, 5)}
+    got = sorted((int(e["saddr"]), int(e["daddr"])) for e in al if int(e["saddr"]) in pod_ips)
+    want = sorted((_ip(r[1]), _ip(r[5])) for r in o.alive_rows())
+    assert got == want
+    # DeleteUnused ran on both sides
+    for pid in range(1, 6):
+        for fd in range(3, 12):
+            a, b = g.sockline(pid, fd), o.sockline(pid, fd)
+            if a is not None:
+                assert [(t, s is None) for t, _, s in a.values()] == [(t, s is None) for t, _, s in b.values()]
