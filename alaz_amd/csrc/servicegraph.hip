@@ -123,20 +123,24 @@ int sync_tables(sg_engine* e, hipStream_t s) {
     const size_t tot = (size_t)e->ipcap + e->ip2cap;
     std::memset(e->h_iptab, 0xFF, tot * sizeof(u64));
     u64* t1 = e->h_iptab; u64* t2 = e->h_iptab + e->ipcap;
-    // bucketized cuckoo insertion (2 hash functions x 2 entries per bucket), random-walk eviction
+    // bucketized cuckoo insertion (2 hash functions x 2 entries per bucket), random-walk eviction: a key that
+    // finds both its buckets full takes a random slot of the bucket it was NOT just evicted from, and the
+    // evicted key continues.  (2,2)-cuckoo tables fill to ~0.89; the capacity keeps the load <= 0.8.
     auto put = [](u64* tab, u32 mask, u32 ip, u32 val) -> bool {
         const u32 bmask = mask >> 1;
         u64 cur = (u64)ip | ((u64)val << 32);
-        u32 b = ip_h1((u32)cur, bmask);
-        for (int kick = 0; kick < 512; kick++) {
+        u32 avoid = 0xFFFFFFFFu;                                       // bucket `cur` was just evicted from
+        u32 rng = sg_fmix32(ip) | 1u;
+        for (int kick = 0; kick < 8192; kick++) {
             const u32 b1 = ip_h1((u32)cur, bmask), b2 = ip_h2((u32)cur, bmask);
             for (u32 bb : {b1, b2}) for (int s2 = 0; s2 < 2; s2++) {
                 u64& slot = tab[2 * (size_t)bb + s2];
                 if (slot == SG_IP_EMPTY || (u32)slot == (u32)cur) { slot = cur; return true; }
             }
-            b = (b == b1) ? b2 : b1;                                 // evict from the other bucket than last time
-            u64& victim = tab[2 * (size_t)b + (kick & 1)];
-            std::swap(cur, victim);
+            rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;       // xorshift32
+            const u32 b = (b1 == avoid) ? b2 : (b2 == avoid ? b1 : ((rng & 2u) ? b2 : b1));
+            std::swap(cur, tab[2 * (size_t)b + (rng & 1u)]);
+            avoid = b;
         }
         return false;
     };
@@ -250,7 +254,10 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
     }
     {
         Timed t3(e, s, 3);
-        hipLaunchKernelGGL(k3_in_stats, dim3(K3_IN_WGS), dim3(1024), e->k3in_lds, s, d);
+        // dense-LDS case: few workgroups (every one flushes every node it saw); hashed case (too many nodes for
+        // LDS): a workgroup aggregates HT/2 edges per round, so more of them, bounded by the flush atomics
+        const int g3 = d.in_dense ? K3_IN_WGS : (int)std::min<u64>(64, std::max<u64>(K3_IN_WGS, (e->cfg.max_edges + 2047) / 2048));
+        hipLaunchKernelGGL(k3_in_stats, dim3(g3), dim3(1024), e->k3in_lds, s, d);
     }
     HIP_TRY(e, hipGetLastError());
     e->closed = true;
@@ -467,6 +474,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.efeat, ME * SG_F_EDGE)); LR(dev_alloc(e, &w.latz, ME)); LR(dev_alloc(e, &w.errr, ME));
         LR(dev_alloc(e, &w.rows, ME));
         LR(dev_alloc(e, &w.alive_keys, w.alive_cap)); LR(dev_alloc(e, &w.alive_csr, ME));
+        LR(dev_alloc(e, &w.act_l, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.act_p, (size_t)w.ncap + 1));
         // arm the per-workgroup statistic slots (tmin = ~0)
         std::vector<u64> init((size_t)SG_MAX_K1_WGS * WS_WORDS, 0);
         for (int i = 0; i < SG_MAX_K1_WGS; i++) init[(size_t)i * WS_WORDS + WS_TMIN] = ~0ull;
@@ -641,7 +649,7 @@ int sg_halo_build_padded(sg_handle e, uint32_t* d_req, uint32_t capp, void* stre
     hipStream_t s = pick(e, stream);
     Timed t(e, s, 6);
     hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
-    hipLaunchKernelGGL(k6_halo_build_padded, dim3(1), dim3(256), 0, s, e->d, d_req, capp);
+    hipLaunchKernelGGL(k6_halo_build_padded, dim3(1), dim3(1024), 0, s, e->d, d_req, capp);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
@@ -754,6 +762,7 @@ int sg_halo_build(sg_handle e, uint32_t* d_ids, uint32_t cap, uint32_t* d_counts
     hipStream_t s = pick(e, stream);
     Timed t(e, s, 6);
     hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
+    hipLaunchKernelGGL(k6_active_lists, dim3(1), dim3(1024), 0, s, e->d);
     hipLaunchKernelGGL(k6_halo_build, dim3(1), dim3(256), 0, s, e->d, d_ids, cap, d_counts);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;

@@ -42,6 +42,8 @@ enum {
     C_ALIVE_DROP,     // ... whose endpoint was not listed at close (working counter)
     C_ALIVE_SEEN,     // closed window: records accepted
     C_ALIVE_DROPPED,  // closed window: records not marked (capacity / unlisted endpoint)
+    C_ACT_L,          // world > 1: nodes whose layer output this shard computes (local sources + local leaf destinations)
+    C_ACT_P,          // world > 1: nodes whose score projections this shard needs (local sources + local destinations)
     C_COUNT = 24
 };
 
@@ -54,6 +56,7 @@ enum { WS_TMIN = 0, WS_TMAX, WS_MAXLABEL, WS_DROPPED_SRC, WS_DROPPED_CAP, WS_MIS
 enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, ST_OUT_SUM, ST_IN_SUM, ST_OUT_SSQ, ST_IN_SSQ, ST_OUT_ALIVE, ST_IN_ALIVE };
 
 #define SG_MEAN_SLOTS 16
+#define SG_ACT_NONE 0xFFFFFFFFull          // ctr[C_ACT_L]: the window has no active node lists (yet)
 // One out-degree counter per 32-byte sector: device-scope atomics serialise per sector (~12 ns each,
 // profiles/r01_atomic_probe.txt), so neighbouring nodes must not share one.
 #define SG_DEG_STRIDE 8
@@ -94,6 +97,7 @@ struct Dev {
     u64* dbg;                                 // phase time stamps (SG_ABLATE & 0x100): [kernel 0..3][4096 workgroups][8]
     u64* alive_keys; u32 alive_cap;           // edge keys of the window's SG_EV_ALIVE records (marked onto the CSR at close)
     u32* alive_csr;                           // [max_edges] CSR order: open connections per edge
+    u32* act_l; u32* act_p;                   // [ncap] world > 1: active node lists (ascending), built with the halo requests
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs
     u32* tile_cnt;  u32* tile_off;            // compaction scratch

@@ -760,6 +760,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d) {
     if (threadIdx.x == 0) {
         d.ctr[C_N_LONG] = nlong;
         d.ctr[C_OVF_N] = 0;                                            // K1b has consumed the overflow list
+        d.ctr[C_ACT_L] = SG_ACT_NONE; d.ctr[C_ACT_P] = 0;              // no active lists yet for this window (see k6_active_lists)
         d.rowptr[N] = total;
         d.ctr[C_N_EDGES] = (u64)total < d.max_edges ? total : d.max_edges;
         if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = total; if ((u64)total > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)total - d.max_edges; }
@@ -837,6 +838,8 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.efeat, d.latz, d.errr, d.eacc, d.ekeys, d.alive_csr, d.variant};
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
     __shared__ u64 red[5][4];
+    __shared__ u32 bsum[5];
+    const u32 BW = (N + 31) >> 5;                                    // words of a node bitmap
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- long rows: the first K2_LONG_WGS workgroups, one row at a time each ----
     const u32 nlw = gridDim.x > 2 * K2_LONG_WGS ? K2_LONG_WGS : (gridDim.x / 2 ? gridDim.x / 2 : 1);   // host launches >= 2 workgroups
@@ -849,7 +852,50 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
             if (m == 0) continue;
             u32* key = d.col + b; u32* val = d.cslot + b;
             u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
-            if (m <= 1024) {
+            if (BW <= K2_SORT_LDS) {
+                // Bitmap rank: the destinations of one row are distinct node ids < N, so setting bit `to` in an
+                // N-bit LDS bitmap and counting the bits below it IS the sorted position — O(m + N/32) per row
+                // instead of a comparison sort (a 3000-edge hub row cost ~100 us in the bitonic network).
+                for (u32 w = threadIdx.x; w < BW; w += 256) sk[w] = 0;
+                __syncthreads();
+                for (u32 i = threadIdx.x; i < m; i += 256) { const u32 k = key[i]; atomicOr(&sk[k >> 5], 1u << (k & 31)); }
+                __syncthreads();
+                {   // sv[w] = number of set bits in words [0, w)
+                    const u32 per = (BW + 255) / 256, w0 = threadIdx.x * per < BW ? threadIdx.x * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
+                    u32 c = 0;
+                    for (u32 w = w0; w < w1; w++) c += __popc(sk[w]);
+                    u32 tot;
+                    u32 run = block_excl_scan<256>(c, bsum, &tot);
+                    for (u32 w = w0; w < w1; w++) { sv[w] = run; run += __popc(sk[w]); }
+                }
+                __syncthreads();
+                u32* gk = d.sort_k + 2 * (size_t)b; u32* gv = d.sort_v + 2 * (size_t)b;     // the row's private slice of the scratch
+                for (u32 i = threadIdx.x; i < m; i += 256) {
+                    const u32 k = key[i], v = val[i];
+                    const u32 r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
+                    gk[r] = k; gv[r] = v;
+                }
+                __threadfence_block();
+                __syncthreads();
+                for (u32 i = threadIdx.x; i < m; i += 256) {
+                    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
+                    const ulonglong2 x = a[0], y = a[1];
+                    cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
+                }
+                cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+                if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+                __syncthreads();
+                cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+                sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+                mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+                for (u32 i = threadIdx.x; i < m; i += 256) {
+                    const u32 slot = gv[i];
+                    key[i] = gk[i];
+                    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
+                    const ulonglong2 x = a[0], y = a[1];
+                    edge_emit(ea, b + i, rr, slot, cnt, sum, ssq, x, y);
+                }
+            } else if (m <= 1024) {
                 // rank sort: keys in LDS, every thread counts the smaller keys of its (<= 4) elements
                 for (u32 i = threadIdx.x; i < m; i += 256) sk[i] = key[i];
                 __syncthreads();
@@ -1207,20 +1253,26 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
     __shared__ float A[16 * LDA];
     __shared__ float H[PROJ ? 16 * LDH : 1];
     __shared__ u32 skip[16];
-    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    __shared__ u32 vid[16];
+    // world > 1: walk the shard's active list (local sources + local leaf destinations; the rows of remote
+    // sources arrive by halo exchange); unsharded: every node
+    const bool listed = !PROJ && d.world > 1 && d.ctr[C_ACT_L] != SG_ACT_NONE;   // lists are built with the halo requests
+    const u32 N = listed ? (u32)d.ctr[C_ACT_L] : (u32)d.ctr[C_N_NODES];
+    const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* __restrict__ bias = Wl + 2 * FI * SG_F_HID;
     for (u32 tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
         const u32 v0 = tile * 16;
-        {   // phase 1: self row + gather-mean, wave w <-> node v0 + w
-            const u32 r = wave, v = v0 + r;
-            float* row = A + r * LDA;
-            bool sk = v >= N;
-            if (!sk && d.world > 1) {
+        {   // phase 1: self row + gather-mean, wave w <-> tile row w
+            const u32 r = wave;
+            bool sk = v0 + r >= N;
+            const u32 v = sk ? 0u : (listed ? d.act_l[v0 + r] : v0 + r);
+            if (!sk && !listed && d.world > 1) {                     // no list this window: walk all nodes, skip what an owner computes
                 const bool has_out = d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0;
-                sk = has_out && owner_of_dense(d, v, nk, nl) != d.rank;   // computed by its owner, arrives by halo exchange
+                sk = has_out && owner_of_dense(d, v, nk, nl) != d.rank;
             }
-            if (lane == 0) skip[r] = sk ? 1u : 0u;
+            float* row = A + r * LDA;
+            if (lane == 0) { skip[r] = sk ? 1u : 0u; vid[r] = v; }
             if (sk) { for (u32 k = lane; k < 2 * FI; k += 64) row[k] = 0.0f; }
             else {
                 for (u32 k = lane; k < FI; k += 64) row[k] = hin[(size_t)v * FI + k];
@@ -1239,7 +1291,7 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
                 for (int r = 0; r < 4; r++) {
                     const u32 row = (lane >> 4) * 4 + r;
                     const float hv = c[r] > 0.0f ? c[r] : 0.0f;
-                    if (!skip[row]) hout[(size_t)(v0 + row) * SG_F_HID + jb + i] = hv;
+                    if (!skip[row]) hout[(size_t)vid[row] * SG_F_HID + jb + i] = hv;
                     if (PROJ) H[row * LDH + jb + i] = hv;
                 }
             } else {
@@ -1255,7 +1307,7 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const float hv = acc[c] > 0.0f ? acc[c] : 0.0f;
-                    if (!skip[row]) hout[(size_t)(v0 + row) * SG_F_HID + jq + c] = hv;
+                    if (!skip[row]) hout[(size_t)vid[row] * SG_F_HID + jq + c] = hv;
                     if (PROJ) H[row * LDH + jq + c] = hv;
                 }
             }
@@ -1305,15 +1357,19 @@ template <bool USE_MFMA>
 __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restrict__ hL, const float* __restrict__ Wh) {
     constexpr int LDA = SG_F_HID + 2;
     __shared__ float A[16 * LDA];
-    const u32 N = (u32)d.ctr[C_N_NODES];
+    __shared__ u32 vid[16];
+    const bool listed = d.world > 1 && d.ctr[C_ACT_L] != SG_ACT_NONE;   // only the endpoints of this shard's edges
+    const u32 N = listed ? (u32)d.ctr[C_ACT_P] : (u32)d.ctr[C_N_NODES];
     const float* __restrict__ Wu = Wh; const float* __restrict__ Wv = Wh + SG_F_HID * SG_F_HID;
     const float* __restrict__ b1 = Wv + SG_F_HID * SG_F_HID + SG_F_EDGE * SG_F_HID;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (u32 tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
         const u32 v0 = tile * 16;
+        if (threadIdx.x < 16) vid[threadIdx.x] = v0 + threadIdx.x < N ? (listed ? d.act_p[v0 + threadIdx.x] : v0 + threadIdx.x) : 0u;
+        __syncthreads();
         for (u32 idx = threadIdx.x; idx < 16 * SG_F_HID; idx += 256) {
             const u32 r = idx >> 6, k = idx & 63;
-            A[r * LDA + k] = (v0 + r < N) ? hL[(size_t)(v0 + r) * SG_F_HID + k] : 0.0f;
+            A[r * LDA + k] = (v0 + r < N) ? hL[(size_t)vid[r] * SG_F_HID + k] : 0.0f;
         }
         __syncthreads();
         if (USE_MFMA) {
@@ -1325,7 +1381,7 @@ __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restri
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const u32 row = (lane >> 4) * 4 + r;
-                if (v0 + row < N) { d.P[(size_t)(v0 + row) * SG_F_HID + jb + i] = p[r]; d.Q[(size_t)(v0 + row) * SG_F_HID + jb + i] = q[r]; }
+                if (v0 + row < N) { d.P[(size_t)vid[row] * SG_F_HID + jb + i] = p[r]; d.Q[(size_t)vid[row] * SG_F_HID + jb + i] = q[r]; }
             }
         } else {
             const u32 row = threadIdx.x >> 4, jq = (threadIdx.x & 15) * 4;
@@ -1339,7 +1395,7 @@ __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restri
             }
             if (v0 + row < N)
 #pragma unroll
-                for (int c = 0; c < 4; c++) { d.P[(size_t)(v0 + row) * SG_F_HID + jq + c] = p[c]; d.Q[(size_t)(v0 + row) * SG_F_HID + jq + c] = q[c]; }
+                for (int c = 0; c < 4; c++) { d.P[(size_t)vid[row] * SG_F_HID + jq + c] = p[c]; d.Q[(size_t)vid[row] * SG_F_HID + jq + c] = q[c]; }
         }
         __syncthreads();
     }
@@ -1478,11 +1534,43 @@ __global__ __launch_bounds__(256) void k6_unpack(float* __restrict__ feat, const
 
 // ---- padded halo exchange (no host synchronisation: fixed-size all-to-all) ----------------------------
 // req / serve layout: [world][capp + 1] u32, element 0 = count, ids follow.
-__global__ __launch_bounds__(256) void k6_halo_build_padded(Dev d, u32* req, u32 capp) {
+// The shard's active node lists (world > 1), for a 1024-thread workgroup whose thread t sweeps nodes
+// [beg, end): with N nodes in the map and only ~N/world of them touched here, the layer and projection
+// kernels must not walk all N (that would undo weak scaling).
+//   act_l: nodes whose layer output is computed here = local sources + local destinations without out-edges anywhere
+//   act_p: nodes whose score projections are needed here = the endpoints of the local edges
+__device__ __forceinline__ void build_active_lists(const Dev& d, u32 N, u32 beg, u32 end, u32* wsum) {
+    u32 cl = 0, cp = 0;
+    for (u32 v = beg; v < end; v++) {
+        const bool dst = d.cursor[v] == 0xFFFFFFFFu, src = d.rowptr[v + 1] != d.rowptr[v];
+        cl += (src || (dst && d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0)) ? 1u : 0u;
+        cp += (src || dst) ? 1u : 0u;
+    }
+    u32 tl, tp;
+    u32 pl = block_excl_scan<1024>(cl, wsum, &tl);
+    __syncthreads();
+    u32 pp = block_excl_scan<1024>(cp, wsum, &tp);
+    __syncthreads();
+    if (threadIdx.x == 0) { d.ctr[C_ACT_L] = tl; d.ctr[C_ACT_P] = tp; }
+    for (u32 v = beg; v < end; v++) {
+        const bool dst = d.cursor[v] == 0xFFFFFFFFu, src = d.rowptr[v + 1] != d.rowptr[v];
+        if (src || (dst && d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0)) d.act_l[pl++] = v;
+        if (src || dst) d.act_p[pp++] = v;
+    }
+}
+__global__ __launch_bounds__(1024) void k6_active_lists(Dev d) {       // for the unpadded halo API
+    __shared__ u32 wsum[17];
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    const u32 per = (N + 1023) / 1024, beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
+    build_active_lists(d, N, beg, end, wsum);
+}
+
+__global__ __launch_bounds__(1024) void k6_halo_build_padded(Dev d, u32* req, u32 capp) {
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
-    __shared__ u32 part[8][256];
+    __shared__ u32 wsum[17];
     const u32 W = d.world < 8 ? d.world : 8;
-    const u32 per = (N + 255) / 256, beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
+    // contiguous chunk of nodes per thread: thread order = ascending dense id, so every shard builds the same lists
+    const u32 per = (N + 1023) / 1024, beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
     u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (u32 v = beg; v < end; v++) {
         if (d.cursor[v] != 0xFFFFFFFFu || d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0) continue;
@@ -1491,19 +1579,21 @@ __global__ __launch_bounds__(256) void k6_halo_build_padded(Dev d, u32* req, u32
 #pragma unroll
         for (int k = 0; k < 8; k++) c[k] += (o == (u32)k);
     }
-#pragma unroll
-    for (int k = 0; k < 8; k++) part[k][threadIdx.x] = c[k];
-    __syncthreads();
-    if (threadIdx.x < W) {
-        const u32 k = threadIdx.x; u32 tot = 0;
-        for (int t = 0; t < 256; t++) { const u32 x = part[k][t]; part[k][t] = tot; tot += x; }
-        if (tot > capp) { atomicAdd(&d.ctr[C_HALO_OVF], (u64)(tot - capp)); tot = capp; }
-        req[(size_t)k * (capp + 1)] = tot;
-    }
-    __syncthreads();
+    build_active_lists(d, N, beg, end, wsum);
     u32 pos[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) pos[k] = part[k][threadIdx.x];
+    for (int k = 0; k < 8; k++) {
+        pos[k] = 0;
+        if ((u32)k < W) {                                            // uniform
+            u32 tot;
+            pos[k] = block_excl_scan<1024>(c[k], wsum, &tot);
+            if (threadIdx.x == 0) {
+                if (tot > capp) { atomicAdd(&d.ctr[C_HALO_OVF], (u64)(tot - capp)); tot = capp; }
+                req[(size_t)k * (capp + 1)] = tot;
+            }
+            __syncthreads();
+        }
+    }
     for (u32 v = beg; v < end; v++) {
         if (d.cursor[v] != 0xFFFFFFFFu || d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0) continue;
         const u32 o = owner_of_dense(d, v, nk, nl);

@@ -512,3 +512,25 @@ def test_alive_connections_are_count_only_edges(variant):
         st = g.stats()
         assert st.last_window_events == o.window_events and st.last_window_nodes == o.n_nodes
     assert st.alive_in == seen and st.alive_dropped == 0 and st.events_dropped_src == o.dropped_src
+
+
+@pytest.mark.parametrize("pods", [2000, 8000, 8738])
+def test_join_table_builds_and_resolves_at_full_load(pods):
+    """The host-built cuckoo join table at its design load (<= 0.8, e.g. 13107 IPs in 16384 slots) and at the
+    sizes the 8-GPU weak-scaling bench uses (12000 IPs): every pod and service IP must resolve — one event per
+    (pod, service) pair, and the edge set must be exactly those pairs."""
+    from oracle import pyoracle
+    topo = replay.make_topology(pods, pods * 2, seed=17)
+    n = topo.n_nodes
+    ev = np.zeros(n, dtype=replay.EVENT_DTYPE)
+    ev["saddr"] = topo.pod_ips[np.arange(n) % topo.n_pods]
+    ev["daddr"] = np.concatenate([topo.svc_ips, topo.pod_ips])[np.arange(n) % n]
+    ev["protocol"] = replay.PROTO_HTTP; ev["status"] = 200; ev["duration_ns"] = 1000 + np.arange(n); ev["write_time_ns"] = 10**9 + np.arange(n)
+    g = _engine(n, n + 1024, 1, max_window_events=n, max_ips=n)
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    assert g.ingest(ev) == 0
+    rows = g.flush_window()
+    st = g.stats()
+    assert st.events_dropped_src == 0 and st.last_window_events == n and int(rows["count"].sum()) == n
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, []); o.window_close(weights.make_weights(1), 1)
+    compare_edge_dicts(engine_edge_dict(rows, shim, [], g.outbound_ips()), o.edge_dict())
