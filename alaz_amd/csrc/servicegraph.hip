@@ -250,7 +250,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         hipLaunchKernelGGL(k2_rowptr, dim3(1), dim3(1024), 0, s, d);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.np), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(2048, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 0, s, d);
     }
     {
         Timed t3(e, s, 3);

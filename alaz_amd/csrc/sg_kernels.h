@@ -832,7 +832,7 @@ __device__ __attribute__((noinline)) void edge_emit(const EdgeEmitArgs d, u32 po
 }
 
 #define K2_SORT_LDS 4096
-#define K2_LONG_WGS 256
+#define K2_LONG_WGS 1024
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
     const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.efeat, d.latz, d.errr, d.eacc, d.ekeys, d.alive_csr, d.variant};
@@ -1183,18 +1183,21 @@ __device__ __forceinline__ f32x4 dense_tile_mfma(const float* A, int lda, const 
 // gather-mean of one node into dst[0..FI): executed by one wave.  Neighbour ids are fetched 64 at a
 // time (one coalesced load) and broadcast by shuffle, so the 8 / 16 row loads of an unrolled step
 // are independent and in flight together.  Summation order is the canonical one (slot = i % 16).
+// Sum of the feature rows of neighbours [i_beg, i_end) of one node, one wave.  i_beg is a multiple of
+// SG_MEAN_BLOCK and the range at most one block, so this is the block sum of the canonical mean:
+// 16 interleaved slot sums (neighbour i -> slot i % 16, ascending i) combined in slot order.
+// FI == 32: lanes 0..31 return the sum for feature k = lane (lane group g = lane >> 5 takes the even /
+// odd slots); FI == 64: every lane returns feature k = lane.
 template <int FI>
-__device__ __forceinline__ void gather_mean(const Dev& d, const float* __restrict__ hin, u32 v, float* dst) {
+__device__ __forceinline__ float gather_block_sum(const float* __restrict__ hin, const u32* __restrict__ nb, u32 i_beg, u32 i_end) {
     const u32 lane = threadIdx.x & 63;
-    const u32 beg = d.rowptr[v], deg = d.rowptr[v + 1] - beg;
-    const u32* __restrict__ nb = d.col + beg;
     if (FI == 32) {
         const u32 g = lane >> 5, k = lane & 31;
         float acc[8];
 #pragma unroll
         for (int a = 0; a < 8; a++) acc[a] = 0.0f;
-        for (u32 base = 0; base < deg; base += 64) {
-            const u32 cnt = deg - base < 64 ? deg - base : 64;
+        for (u32 base = i_beg; base < i_end; base += 64) {
+            const u32 cnt = i_end - base < 64 ? i_end - base : 64;
             const u32 my = lane < cnt ? nb[base + lane] : 0u;
             for (u32 i0 = 0; i0 < cnt; i0 += 32) {                   // 16 row loads in flight per lane group
                 float tmp[16];
@@ -1218,13 +1221,13 @@ __device__ __forceinline__ void gather_mean(const Dev& d, const float* __restric
             t = a == 0 ? even : t + even;
             t = t + odd;
         }
-        if (g == 0) dst[k] = deg ? t / (float)deg : 0.0f;
+        return t;
     } else {
         float acc[16];
 #pragma unroll
         for (int a = 0; a < 16; a++) acc[a] = 0.0f;
-        for (u32 base = 0; base < deg; base += 64) {
-            const u32 cnt = deg - base < 64 ? deg - base : 64;
+        for (u32 base = i_beg; base < i_end; base += 64) {
+            const u32 cnt = i_end - base < 64 ? i_end - base : 64;
             const u32 my = lane < cnt ? nb[base + lane] : 0u;
             for (u32 i0 = 0; i0 < cnt; i0 += 16) {
 #pragma unroll
@@ -1238,14 +1241,16 @@ __device__ __forceinline__ void gather_mean(const Dev& d, const float* __restric
         float t = acc[0];
 #pragma unroll
         for (int a = 1; a < 16; a++) t = t + acc[a];
-        dst[lane] = deg ? t / (float)deg : 0.0f;
+        return t;
     }
 }
+#define SG_MEAN_BLOCK 512        // neighbours per block of the canonical mean: block sums are added in block order
 
 // 16-node tiles, 1024 threads: in the gather phase every wave owns one node of the tile (the rows
 // follow a power law, so per-node parallelism is what bounds this kernel); the dense phase runs on
 // the first 4 waves.  With PROJ the tile's fresh h rows are immediately projected to the score
 // head's P = b1 + h Wu and Q = h Wv (last layer, unsharded), saving a launch.
+#define K4_HUB_BLOCKS 32         // block sums of a hub row kept in LDS per round
 template <int FI, bool USE_MFMA, bool PROJ>
 __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __restrict__ hin, float* __restrict__ hout, const float* __restrict__ Wl, const float* __restrict__ Wh) {
     constexpr int LDA = 2 * FI + 2;                               // +2 floats: conflict-free A-fragment reads
@@ -1253,7 +1258,8 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
     __shared__ float A[16 * LDA];
     __shared__ float H[PROJ ? 16 * LDH : 1];
     __shared__ u32 skip[16];
-    __shared__ u32 vid[16];
+    __shared__ u32 vid[16], tdeg[16];
+    __shared__ float hub[K4_HUB_BLOCKS * FI];
     // world > 1: walk the shard's active list (local sources + local leaf destinations; the rows of remote
     // sources arrive by halo exchange); unsharded: every node
     const bool listed = !PROJ && d.world > 1 && d.ctr[C_ACT_L] != SG_ACT_NONE;   // lists are built with the halo requests
@@ -1272,12 +1278,38 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
                 sk = has_out && owner_of_dense(d, v, nk, nl) != d.rank;
             }
             float* row = A + r * LDA;
-            if (lane == 0) { skip[r] = sk ? 1u : 0u; vid[r] = v; }
+            u32 deg = 0;
             if (sk) { for (u32 k = lane; k < 2 * FI; k += 64) row[k] = 0.0f; }
             else {
                 for (u32 k = lane; k < FI; k += 64) row[k] = hin[(size_t)v * FI + k];
-                gather_mean<FI>(d, hin, v, row + FI);
+                const u32 beg = d.rowptr[v];
+                deg = d.rowptr[v + 1] - beg;
+                // block 0 here (one wave per row, all rows at once); the further blocks of a hub row below
+                const float t = deg ? gather_block_sum<FI>(hin, d.col + beg, 0, deg < SG_MEAN_BLOCK ? deg : SG_MEAN_BLOCK) : 0.0f;
+                if (lane < FI) row[FI + lane] = deg > SG_MEAN_BLOCK ? t : (deg ? t / (float)deg : 0.0f);
             }
+            if (lane == 0) { skip[r] = sk ? 1u : 0u; vid[r] = v; tdeg[r] = deg; }
+        }
+        __syncthreads();
+        // hub rows (more than one block): the blocks of a row are spread over the 16 waves, the block sums are
+        // then added in block order by one wave — a 3000-neighbour row no longer serialises on a single wave
+        for (u32 r = 0; r < 16; r++) {
+            const u32 deg = tdeg[r];
+            if (deg <= SG_MEAN_BLOCK) continue;                      // uniform
+            const u32 v = vid[r], beg = d.rowptr[v], nblk = (deg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
+            float total = (wave == 0 && lane < FI) ? A[r * LDA + FI + lane] : 0.0f;   // block 0, from above (wave 0, lanes < FI)
+            for (u32 b0 = 1; b0 < nblk; b0 += K4_HUB_BLOCKS) {
+                const u32 bn = nblk - b0 < K4_HUB_BLOCKS ? nblk - b0 : K4_HUB_BLOCKS;
+                for (u32 j = wave; j < bn; j += 16) {
+                    const u32 i0 = (b0 + j) * SG_MEAN_BLOCK, i1 = i0 + SG_MEAN_BLOCK < deg ? i0 + SG_MEAN_BLOCK : deg;
+                    const float t = gather_block_sum<FI>(hin, d.col + beg, i0, i1);
+                    if (lane < FI) hub[j * FI + lane] = t;
+                }
+                __syncthreads();
+                if (wave == 0 && lane < FI) for (u32 j = 0; j < bn; j++) total = total + hub[j * FI + lane];
+                __syncthreads();
+            }
+            if (wave == 0 && lane < FI) A[r * LDA + FI + lane] = total / (float)deg;
         }
         __syncthreads();
         // phase 2: dense 16 x 64 on waves 0..3, wave w -> columns 16w..16w+15
@@ -1532,19 +1564,43 @@ __global__ __launch_bounds__(256) void k6_unpack(float* __restrict__ feat, const
     }
 }
 
-// ---- padded halo exchange (no host synchronisation: fixed-size all-to-all) ----------------------------
-// req / serve layout: [world][capp + 1] u32, element 0 = count, ids follow.
-// The shard's active node lists (world > 1), for a 1024-thread workgroup whose thread t sweeps nodes
-// [beg, end): with N nodes in the map and only ~N/world of them touched here, the layer and projection
-// kernels must not walk all N (that would undo weak scaling).
+// Per-node flags of the halo / active-list sweep: bit 0 = destination of a local edge, bit 1 = source of one,
+// bit 2 = has out-edges somewhere (global out-degree, after the statistics all-reduce), bits 3.. = owner + 1
+// when the node is a halo node (remote owner, out-edges, local destination), else 0.
+__device__ __forceinline__ u32 node_flags(const Dev& d, u32 v, u32 nk, u32 nl) {
+    const bool dst = d.cursor[v] == 0xFFFFFFFFu, src = d.rowptr[v + 1] != d.rowptr[v];
+    const bool has_out = d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0;
+    u32 f = (dst ? 1u : 0u) | (src ? 2u : 0u) | (has_out ? 4u : 0u);
+    if (dst && has_out) { const u32 o = owner_of_dense(d, v, nk, nl); if (o != d.rank) f |= (o + 1) << 3; }
+    return f;
+}
+#define K6_FLAGS_LDS 49152       // nodes whose flags fit the LDS staging of the list builder
+
+// The halo request lists and the shard's active node lists (world > 1) in one sweep over the nodes by a
+// 1024-thread workgroup.  With N nodes in the map and only ~N/world of them touched here, the layer and
+// projection kernels must not walk all N (that would undo weak scaling):
 //   act_l: nodes whose layer output is computed here = local sources + local destinations without out-edges anywhere
 //   act_p: nodes whose score projections are needed here = the endpoints of the local edges
-__device__ __forceinline__ void build_active_lists(const Dev& d, u32 N, u32 beg, u32 end, u32* wsum) {
-    u32 cl = 0, cp = 0;
+//   req[k]: halo nodes owned by shard k (k < 8), ascending — every shard builds the same lists
+// Flags are first staged in LDS with coalesced loads (thread t, nodes t, t + 1024, ...); the ordered passes
+// then give thread t the contiguous chunk [beg, end) so that thread order is ascending node order.
+__device__ __forceinline__ void build_lists(const Dev& d, u32* req, u32 capp, bool want_req, unsigned char* fl, u32* wsum) {
+    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    const u32 W = d.world < 8 ? d.world : 8;
+    const bool staged = N <= K6_FLAGS_LDS;
+    if (staged) {
+        for (u32 v = threadIdx.x; v < N; v += 1024) fl[v] = (unsigned char)node_flags(d, v, nk, nl);
+        __syncthreads();
+    }
+    const u32 per = (N + 1023) / 1024, beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
+    u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cl = 0, cp = 0;
     for (u32 v = beg; v < end; v++) {
-        const bool dst = d.cursor[v] == 0xFFFFFFFFu, src = d.rowptr[v + 1] != d.rowptr[v];
-        cl += (src || (dst && d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0)) ? 1u : 0u;
-        cp += (src || dst) ? 1u : 0u;
+        const u32 f = staged ? fl[v] : node_flags(d, v, nk, nl);
+        cl += ((f & 2u) || ((f & 1u) && !(f & 4u))) ? 1u : 0u;
+        cp += (f & 3u) ? 1u : 0u;
+        const u32 o = f >> 3;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] += (o == (u32)k + 1);
     }
     u32 tl, tp;
     u32 pl = block_excl_scan<1024>(cl, wsum, &tl);
@@ -1552,39 +1608,11 @@ __device__ __forceinline__ void build_active_lists(const Dev& d, u32 N, u32 beg,
     u32 pp = block_excl_scan<1024>(cp, wsum, &tp);
     __syncthreads();
     if (threadIdx.x == 0) { d.ctr[C_ACT_L] = tl; d.ctr[C_ACT_P] = tp; }
-    for (u32 v = beg; v < end; v++) {
-        const bool dst = d.cursor[v] == 0xFFFFFFFFu, src = d.rowptr[v + 1] != d.rowptr[v];
-        if (src || (dst && d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0)) d.act_l[pl++] = v;
-        if (src || dst) d.act_p[pp++] = v;
-    }
-}
-__global__ __launch_bounds__(1024) void k6_active_lists(Dev d) {       // for the unpadded halo API
-    __shared__ u32 wsum[17];
-    const u32 N = (u32)d.ctr[C_N_NODES];
-    const u32 per = (N + 1023) / 1024, beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
-    build_active_lists(d, N, beg, end, wsum);
-}
-
-__global__ __launch_bounds__(1024) void k6_halo_build_padded(Dev d, u32* req, u32 capp) {
-    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
-    __shared__ u32 wsum[17];
-    const u32 W = d.world < 8 ? d.world : 8;
-    // contiguous chunk of nodes per thread: thread order = ascending dense id, so every shard builds the same lists
-    const u32 per = (N + 1023) / 1024, beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
-    u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (u32 v = beg; v < end; v++) {
-        if (d.cursor[v] != 0xFFFFFFFFu || d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0) continue;
-        const u32 o = owner_of_dense(d, v, nk, nl);
-        if (o == d.rank) continue;
-#pragma unroll
-        for (int k = 0; k < 8; k++) c[k] += (o == (u32)k);
-    }
-    build_active_lists(d, N, beg, end, wsum);
     u32 pos[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         pos[k] = 0;
-        if ((u32)k < W) {                                            // uniform
+        if (want_req && (u32)k < W) {                                // uniform
             u32 tot;
             pos[k] = block_excl_scan<1024>(c[k], wsum, &tot);
             if (threadIdx.x == 0) {
@@ -1595,12 +1623,28 @@ __global__ __launch_bounds__(1024) void k6_halo_build_padded(Dev d, u32* req, u3
         }
     }
     for (u32 v = beg; v < end; v++) {
-        if (d.cursor[v] != 0xFFFFFFFFu || d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] == 0) continue;
-        const u32 o = owner_of_dense(d, v, nk, nl);
-        if (o == d.rank) continue;
+        const u32 f = staged ? fl[v] : node_flags(d, v, nk, nl);
+        if ((f & 2u) || ((f & 1u) && !(f & 4u))) d.act_l[pl++] = v;
+        if (f & 3u) d.act_p[pp++] = v;
+        const u32 o = f >> 3;
+        if (want_req && o) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) if (o == (u32)k) { if (pos[k] < capp) req[(size_t)k * (capp + 1) + 1 + pos[k]] = v; pos[k]++; }
+            for (int k = 0; k < 8; k++) if (o == (u32)k + 1) { if (pos[k] < capp) req[(size_t)k * (capp + 1) + 1 + pos[k]] = v; pos[k]++; }
+        }
     }
+}
+__global__ __launch_bounds__(1024) void k6_active_lists(Dev d) {       // for the unpadded halo API
+    __shared__ u32 wsum[17];
+    __shared__ unsigned char fl[K6_FLAGS_LDS];
+    build_lists(d, nullptr, 0, false, fl, wsum);
+}
+
+// ---- padded halo exchange (no host synchronisation: fixed-size all-to-all) ----------------------------
+// req / serve layout: [world][capp + 1] u32, element 0 = count, ids follow.
+__global__ __launch_bounds__(1024) void k6_halo_build_padded(Dev d, u32* req, u32 capp) {
+    __shared__ u32 wsum[17];
+    __shared__ unsigned char fl[K6_FLAGS_LDS];
+    build_lists(d, req, capp, true, fl, wsum);
 }
 // rows[r][i][:] = feat[lists[r][1 + i]][:] for i < lists[r][0]   (pack: lists = what shard r asked of me)
 __global__ __launch_bounds__(256) void k6_pack_padded(const float* __restrict__ feat, const u32* __restrict__ lists, u32 capp, u32 world, float* __restrict__ rows) {

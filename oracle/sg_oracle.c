@@ -809,6 +809,7 @@ static void node_features(const uint64_t* s, const uint64_t* mx, uint8_t kind, f
 }
 
 #define SG_MEAN_SLOTS 16
+#define SG_MEAN_BLOCK 512   /* neighbours per block of the canonical mean (a multiple of SG_MEAN_SLOTS) */
 
 size_t or_window_close(oracle_t* o, const float* W, uint32_t L) {
     free_closed(o);
@@ -883,17 +884,24 @@ size_t or_window_close(oracle_t* o, const float* W, uint32_t L) {
             uint32_t beg = rowptr[v], end = rowptr[v + 1], deg = end - beg;
             for (size_t k = 0; k < Fi; k++) mean[k] = 0.0f;
             if (deg) {
-                for (int s = 0; s < SG_MEAN_SLOTS; s++) for (size_t k = 0; k < Fi; k++) part[s][k] = 0.0f;
-                for (uint32_t i = 0; i < deg; i++) {
-                    const float* hu = hin + (size_t)se[beg + i].to * Fi;
-                    float* p = part[i % SG_MEAN_SLOTS];
-                    for (size_t k = 0; k < Fi; k++) p[k] = p[k] + hu[k];
+                /* blocks of SG_MEAN_BLOCK neighbours: inside a block 16 interleaved slot sums (neighbour i -> slot
+                 * i % 16, ascending i), combined in slot order; block sums added in block order */
+                float total[SG_F_HID];
+                for (uint32_t b0 = 0; b0 < deg; b0 += SG_MEAN_BLOCK) {
+                    uint32_t b1 = b0 + SG_MEAN_BLOCK < deg ? b0 + SG_MEAN_BLOCK : deg;
+                    for (int s = 0; s < SG_MEAN_SLOTS; s++) for (size_t k = 0; k < Fi; k++) part[s][k] = 0.0f;
+                    for (uint32_t i = b0; i < b1; i++) {
+                        const float* hu = hin + (size_t)se[beg + i].to * Fi;
+                        float* p = part[i % SG_MEAN_SLOTS];
+                        for (size_t k = 0; k < Fi; k++) p[k] = p[k] + hu[k];
+                    }
+                    for (size_t k = 0; k < Fi; k++) {
+                        float t = part[0][k];
+                        for (int s = 1; s < SG_MEAN_SLOTS; s++) t = t + part[s][k];
+                        total[k] = b0 == 0 ? t : total[k] + t;
+                    }
                 }
-                for (size_t k = 0; k < Fi; k++) {
-                    float t = part[0][k];
-                    for (int s = 1; s < SG_MEAN_SLOTS; s++) t = t + part[s][k];
-                    mean[k] = t / (float)deg;
-                }
+                for (size_t k = 0; k < Fi; k++) mean[k] = total[k] / (float)deg;
             }
             const float* hv = hin + v * Fi;
             for (size_t j = 0; j < SG_F_HID; j++) {
