@@ -268,7 +268,8 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
 int do_features(sg_engine* e, hipStream_t s) {
     const Dev& d = e->d;
     Timed t(e, s, 3);
-    hipLaunchKernelGGL(k3_node_features, dim3(grid_for(d.ncap, 128)), dim3(256), 0, s, d);
+    const int nbn = grid_for(d.ncap, 128), nbe = grid_for(e->cfg.max_edges, 256, 4096);
+    hipLaunchKernelGGL(k3_node_features, dim3(nbn + nbe), dim3(256), 0, s, d, (u32)nbn);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }

@@ -802,17 +802,29 @@ __device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
     return v > 0.0 ? sqrt(v) : 0.0;
 }
 
-// everything that is per edge once its row statistics are known.  NOT inlined: five fp64 log1p, two
-// sqrt and four divisions are ~1000 instructions, and k2_rowsort_gather has three call sites (one of
-// them unrolled 4x) — inlined, the kernel was 6.9 k instructions of mostly cold instruction-cache
-// misses.  The arguments are passed by value (a reference to Dev would spill the whole struct to scratch).
-struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; float* efeat; float* latz; float* errr; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; };
-__device__ __attribute__((noinline)) void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row, u32 slot, u64 r_cnt, u64 r_sum, u64 r_ssq,
-                                                    const ulonglong2 x, const ulonglong2 y) {
-    const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
+// What the row sort does per edge: move the accumulators into CSR order and (variant 1) free the table slot.
+// The fp32 edge features, lat_z and err_ratio are computed afterwards, one thread per edge, by the edge
+// workgroups of k3_node_features: inside the row sort they were ~1000 fp64-heavy instructions per edge run
+// by the few threads that own a long row (a 3000-edge hub row kept one 256-thread workgroup busy for tens of us).
+struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; };
+__device__ __forceinline__ void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row, u32 slot, u64, u64, u64, const ulonglong2 x, const ulonglong2 y) {
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)pos * 4);
     dst[0] = x; dst[1] = y;
     d.csr_from[pos] = row;
+    d.alive_csr[pos] = 0;                                            // k3_in_stats adds the window's open connections
+    if (d.variant == 1) {                                            // variant 1: this is also the window reset of the edge table
+        ulonglong2* src = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)slot * 4);
+        src[0] = make_ulonglong2(0, 0); src[1] = make_ulonglong2(0, 0);
+        d.ekeys[slot] = SG_EKEY_EMPTY;
+    }
+}
+// e_uv, lat_z, err_ratio of edge `pos` from its accumulators and its row's out-statistics
+__device__ __forceinline__ void edge_features(const Dev& d, u32 pos) {
+    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)pos * 4);
+    const ulonglong2 x = a[0], y = a[1];
+    const u64* rs = d.st_sum + (size_t)d.csr_from[pos] * SG_NODE_STAT_SUM_WORDS;
+    const u64 r_cnt = rs[ST_OUT_CNT], r_sum = rs[ST_OUT_SUM], r_ssq = rs[ST_OUT_SSQ];
+    const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
     const double m_e = mean_us(sum, cnt), s_e = std_us(sum, ssq, cnt);
     const double mu = mean_us(r_sum, r_cnt), sd = std_us(r_sum, r_ssq, r_cnt);
     const double z = (m_e - mu) / (sd > 1.0 ? sd : 1.0);
@@ -823,19 +835,13 @@ __device__ __attribute__((noinline)) void edge_emit(const EdgeEmitArgs d, u32 po
     e[0] = make_float4((float)log1p((double)cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
     e[1] = make_float4(err_ratio, (float)log1p((double)err), zc * 0.125f, 1.0f);
     d.latz[pos] = lat_z; d.errr[pos] = err_ratio;
-    d.alive_csr[pos] = 0;                                            // k3_in_stats adds the window's open connections
-    if (d.variant == 1) {                                            // variant 1: this is also the window reset of the edge table
-        ulonglong2* src = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)slot * 4);
-        src[0] = make_ulonglong2(0, 0); src[1] = make_ulonglong2(0, 0);
-        d.ekeys[slot] = SG_EKEY_EMPTY;
-    }
 }
 
 #define K2_SORT_LDS 4096
 #define K2_LONG_WGS 1024
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
-    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.efeat, d.latz, d.errr, d.eacc, d.ekeys, d.alive_csr, d.variant};
+    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant};
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
     __shared__ u64 red[5][4];
     __shared__ u32 bsum[5];
@@ -1093,10 +1099,16 @@ __global__ __launch_bounds__(1024) void k3_in_stats(Dev d) {
 // ------------------------------------------------------------------------------------------------
 // Two lanes per node: lane 0 of the pair turns the out-side statistics into features, lane 1 the
 // in-side ones (the fp64 log1p / sqrt chains are the whole cost of this kernel), then they swap.
-__global__ __launch_bounds__(256) void k3_node_features(Dev d) {
+// Workgroups [0, nb_nodes) do the nodes; the rest do the edge features (one thread per edge, edge_features()).
+__global__ __launch_bounds__(256) void k3_node_features(Dev d, u32 nb_nodes) {
+    if (blockIdx.x >= nb_nodes) {
+        const u32 E = (u32)d.ctr[C_N_EDGES];
+        for (u32 p = (blockIdx.x - nb_nodes) * 256 + threadIdx.x; p < E; p += (gridDim.x - nb_nodes) * 256) edge_features(d, p);
+        return;
+    }
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN];
     const u32 side = threadIdx.x & 1u;
-    for (u32 v0 = blockIdx.x * 128; v0 < N; v0 += gridDim.x * 128) {
+    for (u32 v0 = blockIdx.x * 128; v0 < N; v0 += nb_nodes * 128) {
         const u32 v = v0 + (threadIdx.x >> 1);
         const bool live = v < N;
         float a[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
