@@ -67,6 +67,7 @@ struct sg_engine {
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
+    u32 rp_epoch = 0;          // k2_rowptr launch counter (tags the per-workgroup totals, so they need no reset)
 
     // windows in flight: every slot has its own window buffers and stream; the members above (d, stream,
     // d_ob_list, d_ob_n, closed, window_events_in) are the working copy of slot `cur`
@@ -247,7 +248,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
             hipLaunchKernelGGL(k2_scan_tiles, dim3(1), dim3(1024), 0, s, d, ntiles);
             hipLaunchKernelGGL(k2_edge_compact, dim3(ntiles), dim3(256), 0, s, d);
         }
-        hipLaunchKernelGGL(k2_rowptr, dim3(1), dim3(1024), 0, s, d);
+        hipLaunchKernelGGL(k2_rowptr, dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, d, ++e->rp_epoch);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.np), dim3(256), 0, s, d);
         hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 0, s, d);
@@ -464,7 +465,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.tile_off, e->ecap / K2_TILE));
         LR(dev_alloc(e, &w.e_slot, ME)); LR(dev_alloc(e, &w.e_from, eslots)); LR(dev_alloc(e, &w.e_to, eslots));
         LR(dev_alloc(e, &w.longrows, (size_t)w.ncap + 1));
-        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
+        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS) / K2_RP_ROWS + 1)); LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cslot, ME)); LR(dev_alloc(e, &w.csr_from, ME));
         LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));

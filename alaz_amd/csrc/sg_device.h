@@ -60,8 +60,13 @@ enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, 
 // One out-degree counter per 32-byte sector: device-scope atomics serialise per sector (~12 ns each,
 // profiles/r01_atomic_probe.txt), so neighbouring nodes must not share one.
 #define SG_DEG_STRIDE 8
-// (Replicating a hub row's counter 8x was tried, r01k: k1b_merge -2 us, but the single-workgroup
-// k2_rowptr then reads 8 sectors per row: +18 us.)
+// ... and every row has SG_DEG_REP counters (replica = partition & (REP - 1)), one sector each: the edges of
+// a hub row arrive from hundreds of partitions at once and would serialise on one counter (a 3000-edge row:
+// ~36 us at the tail of k1b_merge).  k2_rowptr (multi-workgroup) sums the replicas of a row and turns them
+// into offsets inside the row.
+#define SG_DEG_REP 8
+#define SG_DEG_IDX(f, r) (((size_t)(f) * SG_DEG_REP + (r)) * SG_DEG_STRIDE)
+#define K2_RP_ROWS 1024          // rows per workgroup of k2_rowptr
 
 // phase stamps for kernel tuning (off unless SG_ABLATE & 0x100): 100 MHz wall clock, thread 0 of a workgroup
 #define SG_STAMP(d, kid, k) do { if (((d).ablate & 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096) (d).dbg[((size_t)(kid) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
@@ -98,6 +103,7 @@ struct Dev {
     u64* alive_keys; u32 alive_cap;           // edge keys of the window's SG_EV_ALIVE records (marked onto the CSR at close)
     u32* alive_csr;                           // [max_edges] CSR order: open connections per edge
     u32* act_l; u32* act_p;                   // [ncap] world > 1: active node lists (ascending), built with the halo requests
+    u64* rp_tot;                              // [ceil((ncap+1)/K2_RP_ROWS)] k2_rowptr: (epoch << 32 | rows' edge total) per workgroup
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs
     u32* tile_cnt;  u32* tile_off;            // compaction scratch

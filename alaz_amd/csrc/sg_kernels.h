@@ -561,7 +561,7 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         d.e_from[slot] = f; d.e_to[slot] = to;
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
         o[0] = make_ulonglong2(hacc[s * 4], hacc[s * 4 + 1]); o[1] = make_ulonglong2(hacc[s * 4 + 2], hacc[s * 4 + 3]);
-        d.e_rank[slot] = atomicAdd(&d.deg[(size_t)f * SG_DEG_STRIDE], 1u);                  // arrival order inside the row: the scatter position
+        d.e_rank[slot] = atomicAdd(&d.deg[SG_DEG_IDX(f, p & (SG_DEG_REP - 1))], 1u);        // arrival order inside the row's replica
     }
     __syncthreads();
     SG_STAMP(d, 1, 5);
@@ -613,6 +613,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
             d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known;
             d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
             d.ctr[C_DROPPED_CAP] = red[4][0];                        // K1b / K2 add their own drops afterwards
+            d.ctr[C_N_LONG] = 0;                                     // k2_rowptr's workgroups append to the long-row list
         }
     }
     // (b)
@@ -732,38 +733,84 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
         if (pos < d.max_edges) {
             const u32 f = dense_of(d, (u32)(k[j] >> 32), nk, nl, nob), t = dense_of(d, (u32)k[j], nk, nl, nob);
             d.e_slot[pos] = base_slot + j; d.e_from[pos] = f; d.e_to[pos] = t;
-            if (f != SG_NONE && t != SG_NONE) atomicAdd(&d.deg[(size_t)f * SG_DEG_STRIDE], 1u);
+            if (f != SG_NONE && t != SG_NONE) atomicAdd(&d.deg[SG_DEG_IDX(f, tile & (SG_DEG_REP - 1))], 1u);
             else atomicAdd(&d.ctr[C_DROPPED_CAP], d.eacc[(size_t)(base_slot + j) * 4] & 0xFFFFFFFFull);
         }
         pos++;
     }
 }
 
-// one workgroup: rowptr = exclusive scan of deg[0..N); rowptr[N] = E = edges of the window.
-__global__ __launch_bounds__(1024) void k2_rowptr(Dev d) {
+// rowptr = exclusive scan of the row degrees; rowptr[N] = E = edges of the window.  Multi-workgroup, single
+// pass: workgroup b owns rows [b*1024, (b+1)*1024): eight lanes per row read its SG_DEG_REP replica counters
+// (one sector each, consecutive lanes -> consecutive sectors), turn them into offsets inside the row and
+// give the row's degree; a block scan makes local row offsets; the sum of the preceding workgroups' totals
+// comes from rp_tot[] (each workgroup publishes (epoch, total) as soon as it knows it and the later ones
+// wait for it — all workgroups are resident, at most one per CU, so the wait cannot deadlock).
+__global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     const u32 N = (u32)d.ctr[C_N_NODES];
     __shared__ u32 wsum[17];
-    __shared__ u32 nlong;
-    if (threadIdx.x == 0) nlong = 0;
-    const u32 per = (N + 1023) / 1024;
-    const u32 beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
-    u32 c = 0;
-    for (u32 i = beg; i < end; i++) c += d.deg[(size_t)i * SG_DEG_STRIDE];
-    u32 total;
-    u32 run = block_excl_scan<1024>(c, wsum, &total);
-    for (u32 i = beg; i < end; i++) {
-        const u32 dg = d.deg[(size_t)i * SG_DEG_STRIDE];
-        d.rowptr[i] = run; run += dg;
-        if (dg > 64) d.longrows[atomicAdd(&nlong, 1u)] = i;
+    __shared__ u32 rdeg[K2_RP_ROWS];
+    __shared__ u32 nlong, lbase, pre;
+    const u32 b = blockIdx.x, t = threadIdx.x, r0 = b * K2_RP_ROWS;
+    if (r0 >= N && b != 0) return;                                   // beyond the last row (grid sized for ncap)
+    if (t == 0) nlong = 0;
+    // 1. replicas -> in-row offsets, row degrees
+    for (u32 pass = 0; pass < K2_RP_ROWS / 128; pass++) {
+        const u32 rl = pass * 128 + (t >> 3), row = r0 + rl, rep = t & 7;
+        u32 v = row < N ? d.deg[SG_DEG_IDX(row, rep)] : 0u;
+        u32 incl = v;                                                // inclusive prefix over the 8 lanes of the row
+#pragma unroll
+        for (int s2 = 1; s2 < 8; s2 <<= 1) { const u32 o = __shfl_up(incl, s2, 8); if ((int)rep >= s2) incl += o; }
+        if (row < N) d.deg[SG_DEG_IDX(row, rep)] = incl - v;
+        if (rep == 7) rdeg[rl] = incl;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        d.ctr[C_N_LONG] = nlong;
-        d.ctr[C_OVF_N] = 0;                                            // K1b has consumed the overflow list
-        d.ctr[C_ACT_L] = SG_ACT_NONE; d.ctr[C_ACT_P] = 0;              // no active lists yet for this window (see k6_active_lists)
-        d.rowptr[N] = total;
-        d.ctr[C_N_EDGES] = (u64)total < d.max_edges ? total : d.max_edges;
-        if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = total; if ((u64)total > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)total - d.max_edges; }
+    // 2. local scan
+    const u32 dg = rdeg[t];
+    u32 total;
+    const u32 run = block_excl_scan<1024>(dg, wsum, &total);
+    // 3. totals of the preceding workgroups
+    if (t == 0) {
+        __atomic_store_n(&d.rp_tot[b], ((u64)epoch << 32) | total, __ATOMIC_RELEASE);
+        pre = 0;
+    }
+    __syncthreads();
+    {
+        u32 mine = 0;
+        for (u32 j = t; j < b; j += 1024) {
+            u64 x;
+            do { x = __atomic_load_n(&d.rp_tot[j], __ATOMIC_ACQUIRE); } while ((u32)(x >> 32) != epoch);
+            mine += (u32)x;
+        }
+        if (b) { mine = wave_sum_u32(mine); if ((t & 63) == 0 && mine) atomicAdd(&pre, mine); }
+    }
+    __syncthreads();
+    const u32 base = pre;
+    // 4. publish
+    if (r0 + t < N) {
+        d.rowptr[r0 + t] = base + run;
+        if (dg > 64) atomicAdd(&nlong, 1u);
+    }
+    __syncthreads();
+    if (t == 0) lbase = nlong ? (u32)atomicAdd(&d.ctr[C_N_LONG], (u64)nlong) : 0u;   // C_N_LONG is zeroed by kc_prepare
+    __syncthreads();
+    {   // positions inside this workgroup's slice of the long-row list
+        __shared__ u32 lpos;
+        if (t == 0) lpos = 0;
+        __syncthreads();
+        if (r0 + t < N && dg > 64) d.longrows[lbase + atomicAdd(&lpos, 1u)] = r0 + t;
+    }
+    if (t == 0) {
+        if (b == 0) {
+            d.ctr[C_OVF_N] = 0;                                        // K1b has consumed the overflow list
+            d.ctr[C_ACT_L] = SG_ACT_NONE; d.ctr[C_ACT_P] = 0;          // no active lists yet for this window (see k6_active_lists)
+        }
+        if (r0 + K2_RP_ROWS >= N) {                                    // the workgroup of the last row knows E
+            const u32 E = base + total;
+            d.rowptr[N] = E;
+            d.ctr[C_N_EDGES] = (u64)E < d.max_edges ? E : d.max_edges;
+            if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = E; if ((u64)E > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)E - d.max_edges; }
+        }
     }
 }
 
@@ -786,7 +833,8 @@ __global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
     const u32 p = blockIdx.x, n = d.part_n[p];
     for (u32 i = threadIdx.x; i < n; i += 256) {
         const u32 slot = p * d.pcap + i;
-        const u64 pos = (u64)d.rowptr[d.e_from[slot]] + d.e_rank[slot];
+        const u32 f = d.e_from[slot];
+        const u64 pos = (u64)d.rowptr[f] + d.deg[SG_DEG_IDX(f, p & (SG_DEG_REP - 1))] + d.e_rank[slot];   // row + replica offset + arrival order
         if (pos < d.max_edges) { d.col[pos] = d.e_to[slot]; d.cslot[pos] = slot; }
     }
 }
@@ -1156,7 +1204,8 @@ __global__ __launch_bounds__(256) void k_reset_window(Dev d) {
     const u64 nc = (u64)d.ncap + 1;
     // (obkeys must be cleared here, not in K5: k5's rows reference OBIP ranks only, but a K1a of the next
     // window may already be enqueued behind this kernel — same stream, so ordering is by launch order)
-    for (u64 i = tid; i < nc; i += nt) { d.deg[i * SG_DEG_STRIDE] = 0; d.cursor[i] = 0; }
+    for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) d.deg[i * SG_DEG_STRIDE] = 0;
+        for (u64 i = tid; i < nc; i += nt) d.cursor[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
     for (u64 i = tid; i <= d.obmask; i += nt) d.obkeys[i] = 0;
@@ -1208,9 +1257,11 @@ __device__ __forceinline__ float gather_block_sum(const float* __restrict__ hin,
         float acc[8];
 #pragma unroll
         for (int a = 0; a < 8; a++) acc[a] = 0.0f;
+        u32 nxt = i_beg + lane < i_end ? nb[i_beg + lane] : 0u;     // ids of the next batch are fetched one batch ahead
         for (u32 base = i_beg; base < i_end; base += 64) {
             const u32 cnt = i_end - base < 64 ? i_end - base : 64;
-            const u32 my = lane < cnt ? nb[base + lane] : 0u;
+            const u32 my = nxt;
+            nxt = base + 64 + lane < i_end ? nb[base + 64 + lane] : 0u;
             for (u32 i0 = 0; i0 < cnt; i0 += 32) {                   // 16 row loads in flight per lane group
                 float tmp[16];
 #pragma unroll
@@ -1238,9 +1289,11 @@ __device__ __forceinline__ float gather_block_sum(const float* __restrict__ hin,
         float acc[16];
 #pragma unroll
         for (int a = 0; a < 16; a++) acc[a] = 0.0f;
+        u32 nxt = i_beg + lane < i_end ? nb[i_beg + lane] : 0u;
         for (u32 base = i_beg; base < i_end; base += 64) {
             const u32 cnt = i_end - base < 64 ? i_end - base : 64;
-            const u32 my = lane < cnt ? nb[base + lane] : 0u;
+            const u32 my = nxt;
+            nxt = base + 64 + lane < i_end ? nb[base + 64 + lane] : 0u;
             for (u32 i0 = 0; i0 < cnt; i0 += 16) {
 #pragma unroll
                 for (int a = 0; a < 16; a++) {
@@ -1505,7 +1558,8 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
         // the counters stay: sg_window_read / the next kc_prepare consume them).
         const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
         const u64 nc = (u64)d.ncap + 1;
-        for (u64 i = tid; i < nc; i += nt) { d.deg[i * SG_DEG_STRIDE] = 0; d.cursor[i] = 0; }
+        for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) d.deg[i * SG_DEG_STRIDE] = 0;
+        for (u64 i = tid; i < nc; i += nt) d.cursor[i] = 0;
         for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
         for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
         for (u64 i = tid; i <= d.obmask; i += nt) d.obkeys[i] = 0;
@@ -1601,7 +1655,13 @@ __device__ __forceinline__ void build_lists(const Dev& d, u32* req, u32 capp, bo
     const u32 W = d.world < 8 ? d.world : 8;
     const bool staged = N <= K6_FLAGS_LDS;
     if (staged) {
-        for (u32 v = threadIdx.x; v < N; v += 1024) fl[v] = (unsigned char)node_flags(d, v, nk, nl);
+        for (u32 v0 = threadIdx.x; v0 < N; v0 += 4096) {             // four nodes per thread in flight
+            u32 f[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const u32 v = v0 + q * 1024; f[q] = node_flags(d, v < N ? v : N - 1, nk, nl); }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const u32 v = v0 + q * 1024; if (v < N) fl[v] = (unsigned char)f[q]; }
+        }
         __syncthreads();
     }
     const u32 per = (N + 1023) / 1024, beg = threadIdx.x * per < N ? threadIdx.x * per : N, end = beg + per < N ? beg + per : N;
