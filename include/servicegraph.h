@@ -267,7 +267,7 @@ int sg_window_buffers(sg_handle h, void** stats_sum, void** stats_max, void** co
 int sg_window_feat_buffer(sg_handle h, uint32_t l, void** rows, size_t* row_floats);
 
 /* Caller-owned device memory for the buffers a sharded driver reduces / exchanges in place
- * (stats_sum [ncap][10] u64, stats_max [ncap][2] u64, feat_rows[l] = layer l+1 rows [ncap][64] f32).
+ * (stats_sum [ncap][SG_NODE_STAT_SUM_WORDS] u64, stats_max [ncap][2] u64, feat_rows[l] = layer l+1 rows [ncap][64] f32).
  * NULL entries keep the engine's own buffer.                                                    */
 int sg_bind_buffers(sg_handle h, void* stats_sum, void* stats_max, void* const* feat_rows, uint32_t n_feat);
 

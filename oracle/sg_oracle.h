@@ -12,6 +12,8 @@
  *       pinned by source reading plus the adjacent known-answer tests that do exist
  *       (aggregator/pg_test.go Parse/Bind strings; the simulator constants of
  *       main_benchmark_test.go:562,585-598) — see tests/golden/.
+ *   socket lines (AddValue / GetValue / DeleteUnused, sockline.c): pinned by the reference's own
+ *       exact known-answer tests (aggregator/sock_line_test.go), re-encoded in tests/test_sockline.py.
  *   scores (GraphSAGE + MLP):  PARITY UNPINNED — the reference has no scoring code at all;
  *       this file *defines* the model and tests/ cross-check it against an
  *       independent numpy implementation (oracle/score_np.py).
