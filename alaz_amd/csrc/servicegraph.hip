@@ -415,6 +415,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         u64 np = next_pow2(std::max<u64>(ME / 160, 64));
         if (cfg->k1_variant == 0 && np / 2 > 4096) d.variant = 1;       // beyond the partitioned path's range
         d.np = (u32)std::min<u64>(std::max<u64>(np / 2, 64), 4096); d.nwg = 256; d.pcap = 768;
+        // few edges but many events (a small shard of a busy map): the merge pass must still fill the chip, ~16
+        // records per piece; 256 partitions hold every event count up to the 1 M-per-window class
+        d.np = (u32)std::max<u64>(d.np, std::min<u64>(256, next_pow2(e->cfg.max_window_events / ((u64)d.nwg * 16) + 1) / 2));
         if (const char* v = std::getenv("SG_NP")) d.np = (u32)std::strtoul(v, nullptr, 0);
         if (const char* v = std::getenv("SG_NWG")) d.nwg = (u32)std::strtoul(v, nullptr, 0);
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);

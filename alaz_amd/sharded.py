@@ -238,13 +238,17 @@ def shard_view(topo: replay.Topology, rank: int, world: int) -> replay.Topology:
 
 
 def bench(a, rank: int, world: int, local: int) -> dict:
-    """Weak scaling: world x the C2 graph, 1 M events per GPU per window.  Two engine instances per GPU
-    alternate windows on two streams, so the exchanges of window w overlap the kernels of window w+1."""
+    """Weak scaling in the event volume: 1 M events per GPU per window.  --graph fixed (default): the
+    configuration's own graph, hash-sharded by source pod over the GPUs — BASELINE's multi-GPU configurations
+    shard one given graph the same way; --graph scaled: the graph grows with the GPU count too (world x pods,
+    world x edges).  Two engine instances per GPU alternate windows on two streams, so the exchanges of
+    window w overlap the kernels of window w+1."""
     from . import engine, weights
     c = replay.CONFIGS[a.config]
     seed = replay.SEED_BASE + a.config
     Ev, L = c["events"], c["layers"]                       # per GPU and window: weak scaling
-    P, E = c["pods"] * world, c["edges"] * world
+    gs = world if getattr(a, "graph", "fixed") == "scaled" else 1
+    P, E = c["pods"] * gs, c["edges"] * gs
     device = torch.device("cuda", local)
     nb = a.batches or max(2, -(-(320 << 20) // (Ev * 32)))
     topo = replay.make_topology(P, E, seed)
@@ -307,7 +311,8 @@ def bench(a, rank: int, world: int, local: int) -> dict:
         "metric": "L7 edge-events/s ingested->scored service-map", "value": Ev * world * a.steps / dt, "unit": "events/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"C{a.config} x {world}: {P} pods / {topo.n_svcs} services / {E} edges hash-sharded by source pod, "
+        "config": {"workload": f"C{a.config}{' x ' + str(world) + ' (graph scaled)' if gs > 1 else ''}: {P} pods / {topo.n_svcs} services / {E} edges "
+                               f"hash-sharded by source pod over {world} GPU(s), "
                                f"{Ev} HTTP l7 events per GPU per window, {L}-layer SAGE + MLP score",
                    "events_per_window": Ev * world, "edges_per_window": int(agg[0].item()), "layers": L,
                    "dropped_or_misrouted": int(agg[1].item()),

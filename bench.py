@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--windows", type=int, default=1, help="window slots in flight for the timed region (sg_config.windows_in_flight); "
                                                             "1 keeps the per-kernel timings uncontended")
     ap.add_argument("--overlap-windows", type=int, default=4, help="extra diagnostic pass with this many windows in flight (0 = skip)")
+    ap.add_argument("--graph", choices=["fixed", "scaled"], default="fixed",
+                    help="N > 1: 'fixed' shards the configuration's own graph over the N GPUs (what BASELINE's multi-GPU configurations "
+                         "do with theirs) and scales the event volume, 1 M events per GPU per window; 'scaled' also grows the graph N-fold")
     ap.add_argument("--profile-mode", action="store_true", help="only warm-up + the timed steps (no diagnostic passes, no CPU baseline): "
                                                                   "the run rocprofv3 wraps, so its per-kernel averages are those of the timed region")
     return ap.parse_args()

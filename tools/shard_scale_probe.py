@@ -2,7 +2,7 @@
 """Per-shard kernel cost of the multi-GPU weak-scaling workload, measured on ONE GPU: WORLD logical shards
 (one engine each, ThreadComm exchanges through device memory) run the workload of sharded.bench(); the
 per-group HIP-event timings of shard 0's engine are what one GPU of a WORLD-GPU node spends in kernels
-per window (exchanges excluded: those need the real fabric).  usage: shard_scale_probe.py [WORLD] [STEPS]"""
+per window (exchanges excluded: those need the real fabric).  usage: shard_scale_probe.py [WORLD] [STEPS] [fixed|scaled]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,9 +10,10 @@ from alaz_amd import engine, sharded, replay, weights
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+gs = world if (len(sys.argv) > 3 and sys.argv[3] == "scaled") else 1      # graph: fixed (default) or scaled with world
 c = replay.CONFIGS[2]; seed = replay.SEED_BASE + 2
 Ev, L = c["events"], c["layers"]
-topo = replay.make_topology(c["pods"] * world, c["edges"] * world, seed)
+topo = replay.make_topology(c["pods"] * gs, c["edges"] * gs, seed)
 dev = torch.device("cuda", 0)
 shared = sharded.ThreadComm.Shared(world)
 engs, bes, evs = [], [], []
