@@ -308,7 +308,7 @@ int do_score(sg_engine* e, hipStream_t s, bool proj_done, bool fuse_reset, bool*
         if (e->use_mfma) hipLaunchKernelGGL((k5_node_proj<true>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
         else hipLaunchKernelGGL((k5_node_proj<false>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
     }
-    const bool fr = fuse_reset && d.variant == 0 && d.world == 1;
+    const bool fr = fuse_reset && d.variant == 0;
     if (fr) hipLaunchKernelGGL(k5_edge_score<true>, dim3(grid_for(e->cfg.max_edges, 16)), dim3(256), 0, s, d, Wh);
     else hipLaunchKernelGGL(k5_edge_score<false>, dim3(grid_for(e->cfg.max_edges, 16)), dim3(256), 0, s, d, Wh);
     if (did_reset) *did_reset = fr;
@@ -694,6 +694,16 @@ int sg_window_score(sg_handle e, void* stream) {
     std::lock_guard<std::mutex> g(e->mu);
     if (!e->closed) { e->err = "sg_window_score before sg_window_close"; return SG_ESTATE; }
     return do_score(e, pick(e, stream), false, false, nullptr);
+}
+int sg_window_score_reset(sg_handle e, void* stream) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->closed) { e->err = "sg_window_score_reset before sg_window_close"; return SG_ESTATE; }
+    bool did = false;
+    int rc = do_score(e, pick(e, stream), false, true, &did);
+    if (rc) return rc;
+    if (did) { e->closed = false; return SG_OK; }
+    return do_reset(e, pick(e, stream));
 }
 int sg_window_read(sg_handle e, sg_edge_out* out, size_t cap, size_t* n) {
     if (!e) return SG_EINVAL;

@@ -98,7 +98,7 @@ struct Dev {
     u32*   longrows;                          // [ncap] rows with more than 64 edges (work list of the row sort)
     u32*   e_rank;                            // [np*pcap] position of the edge inside its row (arrival order)
     u32 in_dense;                             // 1: node-indexed LDS accumulation (ncap small enough), 0: hashed
-    u32 ablate;                               // tuning switches (SG_ABLATE), 0 in production
+    u32 ablate;                               // SG_ABLATE: 0x100 = record phase stamps (SG_STAMP); 0 in production
     u64* dbg;                                 // phase time stamps (SG_ABLATE & 0x100): [kernel 0..3][4096 workgroups][8]
     u64* alive_keys; u32 alive_cap;           // edge keys of the window's SG_EV_ALIVE records (marked onto the CSR at close)
     u32* alive_csr;                           // [max_edges] CSR order: open connections per edge

@@ -333,11 +333,9 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     auto resolve = [&](const u64 idx, const v4u_t va, const v4u_t vb, K1Ev& e) -> bool {
         if (idx >= end) return false;
         const uint4 ca = make_uint4(va.x, va.y, va.z, va.w), cb = make_uint4(vb.x, vb.y, vb.z, vb.w);
-        if (d.ablate & 4u) { e.key = ((u64)ca.x << 32) | ca.y; e.dur = (u64)cb.x | ((u64)cb.y << 32); e.err = 0; return true; }
         return k1_resolve(d, iptab, ca, cb, L, e);
     };
     auto insert = [&](const K1Ev& e) {
-        if (d.ablate & 1u) { if (e.key == 0x1234567ull) L.dcap++; return; }
         const u32 hk = hash_key64(e.key);
         if (e.alive) { emit_single(d, fS, w, hk, e.key, 0ull, 0u, L, 1u); return; }
         u32 h = hk & (K1A_CT - 1);
@@ -353,7 +351,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
             const u64 us = e.dur / 1000ull;
             atomicAdd(&cacc[slot * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&cacc[slot * 4 + 1], e.dur);
             atomicMax(&cacc[slot * 4 + 2], e.dur); atomicAdd(&cacc[slot * 4 + 3], us * us);
-        } else if (!(d.ablate & 2u)) emit_single(d, fS, w, hk, e.key, e.dur, e.err, L);
+        } else emit_single(d, fS, w, hk, e.key, e.dur, e.err, L);
     };
     // One copy of the per-event code, run four times (not unrolled): the kernel body is executed once
     // per workgroup, so every instruction is an instruction-cache miss the first time through, and
@@ -409,7 +407,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     // flush the cache: one record per cached edge
     for (u32 s = t; s < K1A_CT; s += K1A_THREADS) {
         const u64 k = ckey[s];
-        if (k == SG_EKEY_EMPTY || (d.ablate & 2u)) continue;
+        if (k == SG_EKEY_EMPTY) continue;
         const u64 x0 = cacc[s * 4], x1 = cacc[s * 4 + 1], x2 = cacc[s * 4 + 2], x3 = cacc[s * 4 + 3];
         if ((x0 & 0xFFFFFFFFull) == 1ull) emit_single(d, fS, w, hash_key64(k), k, x1, (u32)(x0 >> 32), L);
         else emit_agg(d, fA, w, k, x0, x1, x2, x3, L);

@@ -28,7 +28,7 @@ EXPORTS = [
     "sg_upsert_pod", "sg_delete_pod", "sg_upsert_service", "sg_delete_service", "sg_set_clock",
     "sg_set_label_count", "sg_load_weights", "sg_ingest", "sg_ingest_device", "sg_flush_window",
     "sg_window_run", "sg_window_rows_buffer", "sg_window_close", "sg_window_obip_list",
-    "sg_window_close_sharded", "sg_bind_buffers", "sg_window_features", "sg_window_layer", "sg_window_score",
+    "sg_window_close_sharded", "sg_bind_buffers", "sg_window_features", "sg_window_layer", "sg_window_score", "sg_window_score_reset",
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
@@ -95,7 +95,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_bind_buffers": (C.c_int, [H, P, P, C.POINTER(P), u32]),
         "sg_window_close_sharded": (C.c_int, [H, P, P, P]),
         "sg_window_features": (C.c_int, [H, P]), "sg_window_layer": (C.c_int, [H, u32, P]),
-        "sg_window_score": (C.c_int, [H, P]), "sg_window_read": (C.c_int, [H, P, sz, C.POINTER(sz)]),
+        "sg_window_score": (C.c_int, [H, P]), "sg_window_score_reset": (C.c_int, [H, P]), "sg_window_read": (C.c_int, [H, P, sz, C.POINTER(sz)]),
         "sg_window_reset": (C.c_int, [H, P]),
         "sg_window_buffers": (C.c_int, [H, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(sz)]),
         "sg_window_feat_buffer": (C.c_int, [H, u32, C.POINTER(P), C.POINTER(sz)]),
@@ -192,6 +192,8 @@ class ServiceGraph:
     def window_features(self, stream: int = 0): self._ck(self._l.sg_window_features(self._h, stream or None))
     def window_layer(self, l: int, stream: int = 0): self._ck(self._l.sg_window_layer(self._h, l, stream or None))
     def window_score(self, stream: int = 0): self._ck(self._l.sg_window_score(self._h, stream or None))
+
+    def window_score_reset(self, stream: int = 0): self._ck(self._l.sg_window_score_reset(self._h, stream or None))
     def window_reset(self, stream: int = 0): self._ck(self._l.sg_window_reset(self._h, stream or None))
 
     def window_close_sharded(self, d_union_ips: int, d_union_n: int, stream: int = 0):

@@ -148,17 +148,17 @@ class ThreadComm:
             out[r] = got[r][self.rank]
 
 
-def run_window(be, comm=None) -> None:
+def run_window(be, comm=None, fused_reset: bool = False) -> None:
     """One window close on every shard (all shards call it together).  Nothing in here waits for the
     device: every exchange has a fixed size, so the host only enqueues and windows can pipeline.
     On a GPU backend every torch op runs on the backend's stream, the one its kernels are enqueued on."""
     import contextlib
     stream = getattr(be, "stream", None)
     with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-        _run_window(be, comm if comm is not None else DistComm())
+        _run_window(be, comm if comm is not None else DistComm(), fused_reset)
 
 
-def _run_window(be, comm) -> None:
+def _run_window(be, comm, fused_reset: bool = False) -> None:
     # 1. raw outbound IPs of every shard -> identical OBIP numbering everywhere
     comm.all_gather_into(be.ob_all, be.ob_local())
     be.close_gathered()
@@ -173,7 +173,10 @@ def _run_window(be, comm) -> None:
         be.layer(l)
         comm.all_to_all_equal(be.rows_in, be.pack(l + 1))
         be.unpack(l + 1)
-    be.score()
+    if fused_reset:
+        be.score_reset()          # K5 + window reset in one launch; rows stay in sg_window_rows_buffer()
+    else:
+        be.score()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -227,6 +230,9 @@ class HipBackend:
     def score(self) -> None:
         self.g.window_score(self.s)
 
+    def score_reset(self) -> None:
+        self.g.window_score_reset(self.s)
+
 
 # ------------------------------------------------------------------------------------------------
 # weak-scaling bench (called by bench.py under torch.distributed.run)
@@ -277,8 +283,7 @@ def bench(a, rank: int, world: int, local: int) -> dict:
     def step(i):
         k = i & 1
         engs[k].ingest_device(dev[i % nb].data_ptr(), Ev, bes[k].s)
-        run_window(bes[k], comm)
-        engs[k].window_reset(bes[k].s)
+        run_window(bes[k], comm, fused_reset=True)
 
     for i in range(a.warmup):
         step(i)

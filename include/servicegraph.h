@@ -253,6 +253,9 @@ int sg_window_close_gathered(sg_handle h, const uint32_t* d_gathered, uint32_t s
 int sg_window_features(sg_handle h, void* stream);   /* K3b: node + edge features from reduced stats    */
 int sg_window_layer(sg_handle h, uint32_t l, void* stream);  /* K4: rows with out-edges owned here + all rows without out-edges */
 int sg_window_score(sg_handle h, void* stream);      /* K5 */
+int sg_window_score_reset(sg_handle h, void* stream);/* K5 with the window reset folded in (one launch less): for drivers
+                                                        that read the rows through sg_window_rows_buffer(), not
+                                                        sg_window_read(); the window is open again afterwards      */
 int sg_window_read(sg_handle h, sg_edge_out* out, size_t cap, size_t* n); /* device-syncs, copies out */
 int sg_window_reset(sg_handle h, void* stream);      /* clears the window state                  */
 

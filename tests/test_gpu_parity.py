@@ -211,6 +211,19 @@ def test_device_resident_ingest_and_staged_pipeline():
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     assert hip.hipMemcpy(ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(g.rows_buffer()), len(a) * 56, 3) == 0
     assert rows.cpu().numpy().tobytes() == a.tobytes()
+    # staged calls with the reset folded into the score kernel (what the sharded driver's steady state uses):
+    # same rows on the device, and the window is open and clean afterwards
+    g.ingest_device(t.data_ptr(), len(ev), s)
+    g.window_close(s); g.window_features(s)
+    for l in range(2):
+        g.window_layer(l, s)
+    g.window_score_reset(s)
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(g.rows_buffer()), len(a) * 56, 3) == 0
+    assert rows.cpu().numpy().tobytes() == a.tobytes()
+    assert g.ingest(ev[:1000]) == 0
+    c = g.flush_window()
+    assert int(c["count"].sum()) + int((np.isin(ev[:1000]["saddr"], topo.pod_ips) == False).sum()) == 1000
 
 
 def test_capacity_overflow_is_counted_not_silent():
