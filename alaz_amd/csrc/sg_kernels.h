@@ -72,6 +72,29 @@ __device__ __forceinline__ u64 rdlane64(u64 v, int l) { return (u64)rdlane32((u3
       o = DPP<0x141>(v); v = OP(v, o); o = DPP<0x140>(v); v = OP(v, o);                                   \
       const T r0 = RD(v, 0), r1 = RD(v, 16), r2 = RD(v, 32), r3 = RD(v, 48);                              \
       return OP(OP(r0, r1), OP(r2, r3)); }
+// xor-butterfly partner of a lane without LDS: strides 1, 2 = quad_perm; 4 = row_half_mirror then a quad reverse
+// ((i ^ 7) ^ 3 = i ^ 4); 8 = row_ror:8; 16 / 32 = the gfx950 v_permlane16_swap / v_permlane32_swap (both operands
+// hold v: afterwards one result holds the lower member of every pair in both places, the other the upper one).
+__device__ __forceinline__ float xor_partner_f32(float x, int stride) {
+    const u32 v = __float_as_uint(x);
+    u32 o;
+    switch (stride) {
+        case 1:  o = dpp32<0xB1>(v); break;
+        case 2:  o = dpp32<0x4E>(v); break;
+        case 4:  o = dpp32<0x1B>(dpp32<0x141>(v)); break;
+        case 8:  o = dpp32<0x128>(v); break;
+        case 16: { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); o = (threadIdx.x & 16u) ? r[0] : r[1]; break; }
+        default: { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); o = (threadIdx.x & 32u) ? r[0] : r[1]; break; }
+    }
+    return __uint_as_float(o);
+}
+// r_l <- sum over the wave in the canonical butterfly order (strides 32, 16, 8, 4, 2, 1): what the oracle defines
+// for the score head (sg_oracle.c, "butterfly tree over the 64 lanes"); every lane ends with the same bits
+__device__ __forceinline__ float wave_butterfly_sum_f32(float r) {
+    r = r + xor_partner_f32(r, 32); r = r + xor_partner_f32(r, 16); r = r + xor_partner_f32(r, 8);
+    r = r + xor_partner_f32(r, 4);  r = r + xor_partner_f32(r, 2);  r = r + xor_partner_f32(r, 1);
+    return r;
+}
 #define SG_OP_MIN(a, b) ((b) < (a) ? (b) : (a))
 #define SG_OP_MAX(a, b) ((b) > (a) ? (b) : (a))
 #define SG_OP_ADD(a, b) ((a) + (b))
@@ -1514,6 +1537,11 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
         u32 uu[K5_U], vv[K5_U]; float t[K5_U], ev[K5_U];
 #pragma unroll
         for (int q = 0; q < K5_U; q++) { const u32 p = p0 + q < E ? p0 + q : E - 1; uu[q] = d.csr_from[p]; vv[q] = d.col[p]; }
+        // what the row writer (lane q -> edge p0 + q) needs is fetched now, beside the index loads, not after the sums
+        const u32 pw = p0 + (lane < K5_U ? lane : 0) < E ? p0 + (lane < K5_U ? lane : 0) : E - 1;
+        const ulonglong2* __restrict__ aw = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)pw * 4);
+        const ulonglong2 wx = aw[0], wy = aw[1];
+        const float w_latz = d.latz[pw], w_errr = d.errr[pw]; const u32 w_alive = d.alive_csr[pw];
 #pragma unroll
         for (int q = 0; q < K5_U; q++) {
             const u32 p = p0 + q < E ? p0 + q : E - 1;
@@ -1527,9 +1555,7 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
             for (int k = 0; k < (int)SG_F_EDGE; k++) x = fmaf(__uint_as_float(rdlane32(__float_as_uint(ev[q]), k)), we[k], x);
             x = x > 0.0f ? x : 0.0f;
             float r = x * w2j;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) r = r + __shfl_xor(r, s, 64);
-            t[q] = r;
+            t[q] = wave_butterfly_sum_f32(r);
         }
         if (lane < K5_U && p0 + lane < E) {
             const u32 p = p0 + lane;
@@ -1541,13 +1567,11 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
             for (int q = 1; q < K5_U; q++) { u = lane == (u32)q ? uu[q] : u; v = lane == (u32)q ? vv[q] : v; }
             const float logit = r + b2;
             const float score = 1.0f / (1.0f + expf(-logit));
-            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
-            const ulonglong2 x = a[0], y = a[1];
             sg_edge_out o;
-            o.sum_ns = x.y; o.max_ns = y.x; o.sumsq_us = y.y;
+            o.sum_ns = wx.y; o.max_ns = wy.x; o.sumsq_us = wy.y;
             o.from_ref = ref_of_dense(u, nk, nl); o.to_ref = ref_of_dense(v, nk, nl);
-            o.count = (u32)(x.x & 0xFFFFFFFFull); o.err_count = (u32)(x.x >> 32);
-            o.score = score; o.lat_z = d.latz[p]; o.err_ratio = d.errr[p]; o.alive = d.alive_csr[p];
+            o.count = (u32)(wx.x & 0xFFFFFFFFull); o.err_count = (u32)(wx.x >> 32);
+            o.score = score; o.lat_z = w_latz; o.err_ratio = w_errr; o.alive = w_alive;
             d.rows[p] = o;
         }
     }
