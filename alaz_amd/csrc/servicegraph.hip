@@ -422,7 +422,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         if (const char* v = std::getenv("SG_NWG")) d.nwg = (u32)std::strtoul(v, nullptr, 0);
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
         d.ss = (u32)(2.0 * m + 6.0 * std::sqrt(m + 1.0) + 8.0);
-        d.ss = (d.ss + 1 + 7) / 8 * 8 - 1;                              // header + ss singles = whole 128-byte lines
+        d.ss = (d.ss + SG_PIECE_HDR + 7) / 8 * 8 - SG_PIECE_HDR;        // header + first aggregate + ss singles = whole 128-byte lines
         d.sa = 16;
         d.ovf_cap = 1u << 16;
     }
@@ -448,7 +448,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         size_t eslots = ME;
         if (w.variant == 0) {
             eslots = std::max<size_t>(ME, (size_t)w.np * w.pcap);
-            LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * (w.ss + 1)));
+            LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * SG_PIECE_SLOTS(w)));
             LR(dev_alloc(e, &w.slab_a, (size_t)w.np * w.nwg * w.sa * 5));
             LR(dev_alloc(e, &w.ovf, (size_t)w.ovf_cap * 5));
             LR(dev_alloc(e, &w.part_n, w.np));

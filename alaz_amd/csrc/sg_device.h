@@ -89,8 +89,8 @@ struct Dev {
     u32 variant;                              // 0 = partitioned (LDS aggregation), 1 = global edge table + atomics
     u32 np, nwg;                              // partitions (power of two), pass-A workgroups
     u32 ss, sa;                               // slab piece capacity: single / aggregate records
-    uint4* slab_s;                            // [np][nwg][1 + ss]  header {n_single, n_agg, 0, 0} + singles {key.lo, key.hi, dur.lo, dur.hi | err<<31}
-    u64*   slab_a;                            // [np][nwg][sa][5] {key, cnt|err<<32, sum_ns, max_ns, sumsq_us}
+    uint4* slab_s;                            // [np][nwg][4 + ss]  header {n_single, n_agg, 0, 0}, first aggregate (3 slots), singles {key.lo, key.hi, dur.lo, dur.hi | err<<31 | edge-only<<30}
+    u64*   slab_a;                            // [np][nwg][sa][5] the aggregates after a piece's first: {key, cnt|err<<32, sum_ns, max_ns, sumsq_us}
     u64*   ovf;  u32 ovf_cap;                 // overflow records [ovf_cap][5] (pieces that ran full)
     u32*   part_n;                            // [np] distinct edges per partition
     u32 pcap;                                 // edge capacity per partition

@@ -89,7 +89,7 @@ __device__ __forceinline__ float xor_partner_f32(float x, int stride) {
     return __uint_as_float(o);
 }
 // r_l <- sum over the wave in the canonical butterfly order (strides 32, 16, 8, 4, 2, 1): what the oracle defines
-// for the score head (sg_oracle.c, "butterfly tree over the 64 lanes"); every lane ends with the same bits
+// for the score head ("xor-butterfly sum"); every lane ends with the same bits
 __device__ __forceinline__ float wave_butterfly_sum_f32(float r) {
     r = r + xor_partner_f32(r, 32); r = r + xor_partner_f32(r, 16); r = r + xor_partner_f32(r, 8);
     r = r + xor_partner_f32(r, 4);  r = r + xor_partner_f32(r, 2);  r = r + xor_partner_f32(r, 1);
@@ -295,24 +295,31 @@ __device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1
     else { const u32 c = (u32)(a0 & 0xFFFFFFFFull); L.dcap += c; L.acc -= c; }
 }
 
-// Slab geometry: piece (p, w) = records workgroup w produced for partition p:
-//   slab_s[(p*nwg + w) * (ss + 1)]  : one 16-byte header {n_single, n_aggregate, 0, 0} followed by ss
-//                                     single records {key.lo, key.hi, dur.lo, dur.hi | err << 31}
-//   slab_a[(p*nwg + w) * sa * 5]    : sa aggregate records {key, cnt | err<<32, sum_ns, max_ns, sumsq_us}
-// A piece's header and its first 7 singles share one 128-byte line, so pass B usually needs one
-// line per piece.
+// Slab geometry: piece (p, w) = records workgroup w produced for partition p, SG_PIECE_SLOTS 16-byte slots:
+//   slot 0      header {n_single, n_aggregate, 0, 0}
+//   slots 1..3  the piece's FIRST aggregate record {key, cnt | err<<32, sum_ns, max_ns, sumsq_us} (40 of 48 bytes)
+//   slots 4..   ss single records {key.lo, key.hi, dur.lo, dur.hi | err << 31 | edge-only << 30}
+//   slab_a[(p*nwg + w) * sa + r - 1] : the piece's aggregates r >= 1 (rare)
+// Header, first aggregate and the first four singles share one 128-byte line; pass B reads a piece's header, first
+// aggregate and first 16 singles in one round without touching slab_a.
+#define SG_PIECE_HDR 4u
+#define SG_PIECE_SLOTS(d) ((d).ss + SG_PIECE_HDR)
+__device__ __forceinline__ uint4* piece_of(const Dev& d, u32 p, u32 w) { return d.slab_s + ((size_t)p * d.nwg + w) * SG_PIECE_SLOTS(d); }
 // zero = 1: a record that only creates the edge (SG_EV_ALIVE): count 0, all accumulators 0
 __device__ __forceinline__ void emit_single(const Dev& d, u32* fS, u32 w, u32 hk, u64 key, u64 dur, u32 err, K1Local& L, u32 zero = 0) {
     const u32 p = part_of_hash(d, hk);
     const u32 pos = atomicAdd(&fS[p], 1u);
-    if (pos < d.ss) d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1) + 1 + pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31) | (zero << 30));
+    if (pos < d.ss) piece_of(d, p, w)[SG_PIECE_HDR + pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31) | (zero << 30));
     else if (zero) ovf_append(d, key, 0ull, 0ull, 0ull, 0ull, L);
     else { const u64 us = dur / 1000ull; ovf_append(d, key, 1ull | ((u64)err << 32), dur, dur, us * us, L); }
 }
 __device__ __forceinline__ void emit_agg(const Dev& d, u32* fA, u32 w, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
     const u32 p = part_of(d, key);
     const u32 pos = atomicAdd(&fA[p], 1u);
-    if (pos < d.sa) { u64* o = d.slab_a + (((size_t)p * d.nwg + w) * d.sa + pos) * 5; o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; }
+    if (pos < d.sa) {
+        u64* o = pos == 0 ? reinterpret_cast<u64*>(piece_of(d, p, w) + 1) : d.slab_a + (((size_t)p * d.nwg + w) * d.sa + pos - 1) * 5;
+        o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3;
+    }
     else ovf_append(d, key, a0, a1, a2, a3, L);
 }
 
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
             gload8_issue(ip0, d.iptab + (t & d.ipmask)); gload8_issue(ip1, d.iptab + ((t + K1A_THREADS) & d.ipmask));
             gload8_issue(ip2, d.iptab + ((t + 2 * K1A_THREADS) & d.ipmask)); gload8_issue(ip3, d.iptab + ((t + 3 * K1A_THREADS) & d.ipmask));
         }
-        gload16_issue(hdr, d.slab_s + ((size_t)(t < d.np ? t : 0) * d.nwg + w) * (d.ss + 1));
+        gload16_issue(hdr, piece_of(d, t < d.np ? t : 0, w));
         K1A_ISSUE(i);
         for (u32 k = t; k < K1A_CT; k += K1A_THREADS) ckey[k] = SG_EKEY_EMPTY;
         for (u32 k = t; k < K1A_CT * 4; k += K1A_THREADS) cacc[k] = 0;
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
         }
         if (t < 8) red[t] = t == WS_TMIN ? ~0ull : 0ull;
         if (d.np > K1A_THREADS) {                                    // more partitions than threads: the remaining headers (waits for everything)
-            for (u32 p = t + K1A_THREADS; p < d.np; p += K1A_THREADS) { const uint4 h = d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)]; fS[p] = h.x; fA[p] = h.y; }
+            for (u32 p = t + K1A_THREADS; p < d.np; p += K1A_THREADS) { const uint4 h = *piece_of(d, p, w); fS[p] = h.x; fA[p] = h.y; }
         }
         LDS_BARRIER();
         SG_STAMP(d, 0, 1);
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     }
     LDS_BARRIER();
     for (u32 p = t; p < d.np; p += K1A_THREADS)
-        d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)] = make_uint4(fS[p] < d.ss ? fS[p] : d.ss, fA[p] < d.sa ? fA[p] : d.sa, 0u, 0u);
+        *piece_of(d, p, w) = make_uint4(fS[p] < d.ss ? fS[p] : d.ss, fA[p] < d.sa ? fA[p] : d.sa, 0u, 0u);
     SG_STAMP(d, 0, 5);
     if (t == 0) {
         u64* g = d.wgstat + (size_t)(blockIdx.x % SG_MAX_K1_WGS) * WS_WORDS;
@@ -485,19 +492,18 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     // first K1B_U singles and its first aggregate are fetched together (the slab memory is always
     // mapped, stale contents are ignored): one round of latency for a typical piece (<= 16 singles)
     // instead of three dependent ones.  The first round is in flight during the LDS set-up.
-#define K1B_SIDX(u) (1 + ((sub + (u) * K1B_LPP) < d.ss ? (sub + (u) * K1B_LPP) : 0))
-#define K1B_ISSUE(piece, pa)                                                                              \
+#define K1B_SIDX(u) (SG_PIECE_HDR + ((sub + (u) * K1B_LPP) < d.ss ? (sub + (u) * K1B_LPP) : 0))
+#define K1B_ISSUE(piece)                                                                                  \
         gload16_issue(hv, (piece));                                                                        \
         gload16_issue(xv0, (piece) + K1B_SIDX(0)); gload16_issue(xv1, (piece) + K1B_SIDX(1));              \
         gload16_issue(xv2, (piece) + K1B_SIDX(2)); gload16_issue(xv3, (piece) + K1B_SIDX(3));              \
-        gload16_issue(y01, (pa) + (size_t)sub * 5); gload16_issue(y23, (pa) + (size_t)sub * 5 + 2);        \
-        gload8_issue(y4, (pa) + (size_t)sub * 5 + 4)
+        gload16_issue(y01, (piece) + 1); gload16_issue(y23, (piece) + 2); gload8_issue(y4, (piece) + 3)
 #define K1B_WAIT() asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv), "+v"(xv0), "+v"(xv1), "+v"(xv2), "+v"(xv3), "+v"(y01), "+v"(y23), "+v"(y4) : : "memory")
     const u32 w0 = t / K1B_LPP, wc = w0 < d.nwg ? w0 : 0;
-    const uint4* piece0 = d.slab_s + ((size_t)p * d.nwg + wc) * (d.ss + 1);
+    const uint4* piece0 = piece_of(d, p, wc);
     const u64* pa0 = d.slab_a + ((size_t)p * d.nwg + wc) * d.sa * 5;
     v4u_t hv, xv0, xv1, xv2, xv3, y01, y23; v2u_t y4;
-    K1B_ISSUE(piece0, pa0);
+    K1B_ISSUE(piece0);
     for (u32 i = t; i < K1B_HT; i += K1B_THREADS) hkey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < K1B_HT * 4; i += K1B_THREADS) hacc[i] = 0;
     if (t == 0) { n_drop = 0; out_n = 0; }
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
         for (u32 r0 = sub; r0 < ns; r0 += K1B_LPP * K1B_U) {
             if (r0 != sub) {
 #pragma unroll
-                for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) x[u] = piece[1 + r0 + u * K1B_LPP];
+                for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) x[u] = piece[SG_PIECE_HDR + r0 + u * K1B_LPP];
             }
 #pragma unroll
             for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) {
@@ -534,8 +540,8 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
                 add(key, one | ((u64)(x[u].w >> 31) << 32), dur, dur, us * us);
             }
         }
-        for (u32 r0 = sub; r0 < na; r0 += K1B_LPP) {
-            if (r0 != sub) { const u64* q = pa + (size_t)r0 * 5; y[0] = q[0]; y[1] = q[1]; y[2] = q[2]; y[3] = q[3]; y[4] = q[4]; }
+        for (u32 r0 = sub; r0 < na; r0 += K1B_LPP) {                 // aggregate 0 came with the piece; the others (rare) from slab_a
+            if (r0 != 0) { const u64* q = pa + (size_t)(r0 - 1) * 5; y[0] = q[0]; y[1] = q[1]; y[2] = q[2]; y[3] = q[3]; y[4] = q[4]; }
             add(y[0], y[1], y[2], y[3], y[4]);
         }
     };
@@ -544,10 +550,10 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     SG_STAMP(d, 1, 2);
     if (w0 < d.nwg) merge_piece(piece0, pa0, hv, xv0, xv1, xv2, xv3, y01, y23, y4);
     for (u32 w = w0 + K1B_THREADS / K1B_LPP; w < d.nwg; w += K1B_THREADS / K1B_LPP) {    // only when nwg > 256
-        const uint4* piece = d.slab_s + ((size_t)p * d.nwg + w) * (d.ss + 1);
+        const uint4* piece = piece_of(d, p, w);
         const u64* pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
         v4u_t hv, xv0, xv1, xv2, xv3, y01, y23; v2u_t y4;
-        K1B_ISSUE(piece, pa);
+        K1B_ISSUE(piece);
         K1B_WAIT();
         merge_piece(piece, pa, hv, xv0, xv1, xv2, xv3, y01, y23, y4);
     }
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
 #undef K1B_SIDX
     __syncthreads();
     SG_STAMP(d, 1, 3);
-    for (u32 w = t; w < d.nwg; w += K1B_THREADS) d.slab_s[((size_t)p * d.nwg + w) * (d.ss + 1)] = make_uint4(0, 0, 0, 0);   // window reset of the pieces
+    for (u32 w = t; w < d.nwg; w += K1B_THREADS) *piece_of(d, p, w) = make_uint4(0, 0, 0, 0);   // window reset of the pieces
     {
         const u64 no = ovf_n < d.ovf_cap ? ovf_n : d.ovf_cap;
         for (u64 i = t; i < no; i += K1B_THREADS) {
