@@ -181,8 +181,9 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
         // events): the kernel's duration as rocprofv3 reports it, without the event-record round trip
         const bool tk = (e->timing >> 1) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
-        if (e->ip_lds) hipExtLaunchKernelGGL(k1a_partition<true>, dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, e->d, d_ev, (u64)n);
-        else hipExtLaunchKernelGGL(k1a_partition<false>, dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, e->d, d_ev, (u64)n);
+        Dev da = e->d; da.batch_state = e->window_events_in == 0 ? 1u : 0u;     // first batch of this window?
+        if (e->ip_lds) hipExtLaunchKernelGGL(k1a_partition<true>, dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n);
+        else hipExtLaunchKernelGGL(k1a_partition<false>, dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n);
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 1; e->trecs.push_back(r); }
     } else {
         Timed t(e, s, 1);
@@ -237,7 +238,8 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
     if (d.variant == 0) {                                    // group 7 = K1 pass B (k1b_merge), kernel-exact timing as for pass A
         const bool tk = (e->timing >> 7) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
-        hipExtLaunchKernelGGL(k1b_merge, dim3(d.np), dim3(K1B_THREADS), (uint32_t)e->k1b_lds, s, ta, tb, 0u, d);
+        Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
+        hipExtLaunchKernelGGL(k1b_merge, dim3(d.np), dim3(K1B_THREADS), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
     }
     {

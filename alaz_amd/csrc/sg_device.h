@@ -98,6 +98,9 @@ struct Dev {
     u32*   longrows;                          // [ncap] rows with more than 64 edges (work list of the row sort)
     u32*   e_rank;                            // [np*pcap] position of the edge inside its row (arrival order)
     u32 in_dense;                             // 1: node-indexed LDS accumulation (ncap small enough), 0: hashed
+    u32 batch_state;                          // per launch: k1a_partition 1 = first batch of the window (piece headers are
+                                              // not read, every workgroup rewrites all of its headers); k1b_merge 2 = the
+                                              // window had no batch (pieces hold the previous window: ignore them)
     u32 ablate;                               // SG_ABLATE: 0x100 = record phase stamps (SG_STAMP); 0 in production
     u64* dbg;                                 // phase time stamps (SG_ABLATE & 0x100): [kernel 0..3][4096 workgroups][8]
     u64* alive_keys; u32 alive_cap;           // edge keys of the window's SG_EV_ALIVE records (marked onto the CSR at close)

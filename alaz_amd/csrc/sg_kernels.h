@@ -342,7 +342,11 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
     const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
     const u64 per = (n + d.nwg - 1) / d.nwg;
     const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
-    if (beg >= end) return;                                          // no share of this batch: pieces and statistics stay as they are
+    const bool first = d.batch_state == 1u;                          // first batch of the window: headers are zero by definition
+    if (beg >= end) {                                                // no share of this batch: pieces and statistics stay as they are,
+        if (first) for (u32 p = t; p < d.np; p += K1A_THREADS) *piece_of(d, p, w) = make_uint4(0, 0, 0, 0);   // but stale headers must go
+        return;
+    }
     const u64 last = end - 1;
     SG_STAMP(d, 0, 0);
     // K1A_G events per thread are fetched together (8 x 16 B in flight per lane).  Loads return in issue
@@ -397,19 +401,21 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
           } }
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory")   /* LDS-only: does not drain the global stores */
     {
-        v2u_t ip0, ip1, ip2, ip3; v4u_t hdr;
+        // piece headers: zero by definition in the first batch of a window (no loads: 65 k scattered sectors per launch
+        // saved); a later batch reads them with ordinary loads BEFORE anything is issued by hand — a hand-issued load
+        // behind a branch would put a register merge between its issue and its wait (the compiler then copies the
+        // still-loading register: seen in r02c, the LDS join table came out as garbage)
+        for (u32 p = t; p < d.np; p += K1A_THREADS) { const uint4 h = first ? make_uint4(0, 0, 0, 0) : *piece_of(d, p, w); fS[p] = h.x; fA[p] = h.y; }
+        v2u_t ip0, ip1, ip2, ip3;
         v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
         if (IPLDS) {
             gload8_issue(ip0, d.iptab + (t & d.ipmask)); gload8_issue(ip1, d.iptab + ((t + K1A_THREADS) & d.ipmask));
             gload8_issue(ip2, d.iptab + ((t + 2 * K1A_THREADS) & d.ipmask)); gload8_issue(ip3, d.iptab + ((t + 3 * K1A_THREADS) & d.ipmask));
         }
-        gload16_issue(hdr, piece_of(d, t < d.np ? t : 0, w));
         K1A_ISSUE(i);
         for (u32 k = t; k < K1A_CT; k += K1A_THREADS) ckey[k] = SG_EKEY_EMPTY;
         for (u32 k = t; k < K1A_CT * 4; k += K1A_THREADS) cacc[k] = 0;
-        if (IPLDS) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ip0), "+v"(ip1), "+v"(ip2), "+v"(ip3), "+v"(hdr) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(hdr) : : "memory");
-        if (t < d.np) { fS[t] = hdr.x; fA[t] = hdr.y; }
+        if (IPLDS) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ip0), "+v"(ip1), "+v"(ip2), "+v"(ip3) : : "memory");
         if (IPLDS) {
             if (t <= d.ipmask) ipl[t] = (u64)ip0.x | ((u64)ip0.y << 32);
             if (t + K1A_THREADS <= d.ipmask) ipl[t + K1A_THREADS] = (u64)ip1.x | ((u64)ip1.y << 32);
@@ -417,9 +423,6 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
             if (t + 3 * K1A_THREADS <= d.ipmask) ipl[t + 3 * K1A_THREADS] = (u64)ip3.x | ((u64)ip3.y << 32);
         }
         if (t < 8) red[t] = t == WS_TMIN ? ~0ull : 0ull;
-        if (d.np > K1A_THREADS) {                                    // more partitions than threads: the remaining headers (waits for everything)
-            for (u32 p = t + K1A_THREADS; p < d.np; p += K1A_THREADS) { const uint4 h = *piece_of(d, p, w); fS[p] = h.x; fA[p] = h.y; }
-        }
         LDS_BARRIER();
         SG_STAMP(d, 0, 1);
         K1A_FOLD(i);
@@ -548,8 +551,9 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     SG_STAMP(d, 1, 1);
     K1B_WAIT();
     SG_STAMP(d, 1, 2);
-    if (w0 < d.nwg) merge_piece(piece0, pa0, hv, xv0, xv1, xv2, xv3, y01, y23, y4);
-    for (u32 w = w0 + K1B_THREADS / K1B_LPP; w < d.nwg; w += K1B_THREADS / K1B_LPP) {    // only when nwg > 256
+    const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
+    if (w0 < d.nwg && !empty) merge_piece(piece0, pa0, hv, xv0, xv1, xv2, xv3, y01, y23, y4);
+    for (u32 w = w0 + K1B_THREADS / K1B_LPP; w < d.nwg && !empty; w += K1B_THREADS / K1B_LPP) {    // only when nwg > 256
         const uint4* piece = piece_of(d, p, w);
         const u64* pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
         v4u_t hv, xv0, xv1, xv2, xv3, y01, y23; v2u_t y4;
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
 #undef K1B_SIDX
     __syncthreads();
     SG_STAMP(d, 1, 3);
-    for (u32 w = t; w < d.nwg; w += K1B_THREADS) *piece_of(d, p, w) = make_uint4(0, 0, 0, 0);   // window reset of the pieces
+    // (no reset of the piece headers: the first batch of the next window rewrites every one of them)
     {
         const u64 no = ovf_n < d.ovf_cap ? ovf_n : d.ovf_cap;
         for (u64 i = t; i < no; i += K1B_THREADS) {
