@@ -79,3 +79,12 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"pyoracle|sg_oracle|libsgoracle|from oracle|import oracle", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_hand_issued_loads_are_never_touched_before_their_wait():
+    """tools/check_asm_loads.py on the gfx950 assembly of the engine: no instruction reads or writes a VGPR that
+    is the destination of an inline-asm global load before an inline-asm s_waitcnt has covered it (a compiler
+    copy there reads stale data; it happened once and only showed up as wrong joins on the GPU)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
