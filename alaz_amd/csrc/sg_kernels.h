@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 // receives one atomic per word per workgroup instead of one per edge.
 #define K3_IN_NODES 2560
 #define K3_IN_HT    2048
-#define K3_IN_WGS   8
+#define K3_IN_WGS   16
 __device__ __forceinline__ void in_flush(const Dev& d, u32 to, const u64* o) {
     u64* gsum = d.st_sum + (size_t)to * SG_NODE_STAT_SUM_WORDS;
     atomicAdd(&gsum[ST_IN_DEG], o[0]); atomicAdd(&gsum[ST_IN_CNT], o[1]); atomicAdd(&gsum[ST_IN_ERR], o[2]);
