@@ -66,7 +66,7 @@ enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, 
 // into offsets inside the row.
 #define SG_DEG_REP 8
 #define SG_DEG_IDX(f, r) (((size_t)(f) * SG_DEG_REP + (r)) * SG_DEG_STRIDE)
-#define K2_RP_ROWS 1024          // rows per workgroup of k2_rowptr
+#define K2_RP_ROWS 256           // rows per workgroup of k2_rowptr (a multiple of 128; 1024 threads: 8 lanes per row, 2 passes)
 
 // phase stamps for kernel tuning (off unless SG_ABLATE & 0x100): 100 MHz wall clock, thread 0 of a workgroup
 #define SG_STAMP(d, kid, k) do { if (((d).ablate & 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096) (d).dbg[((size_t)(kid) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)

@@ -797,7 +797,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     }
     __syncthreads();
     // 2. local scan
-    const u32 dg = rdeg[t];
+    const u32 dg = t < K2_RP_ROWS ? rdeg[t] : 0u;
     u32 total;
     const u32 run = block_excl_scan<1024>(dg, wsum, &total);
     // 3. totals of the preceding workgroups
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     __syncthreads();
     const u32 base = pre;
     // 4. publish
-    if (r0 + t < N) {
+    if (t < K2_RP_ROWS && r0 + t < N) {
         d.rowptr[r0 + t] = base + run;
         if (dg > 64) atomicAdd(&nlong, 1u);
     }
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
         __shared__ u32 lpos;
         if (t == 0) lpos = 0;
         __syncthreads();
-        if (r0 + t < N && dg > 64) d.longrows[lbase + atomicAdd(&lpos, 1u)] = r0 + t;
+        if (t < K2_RP_ROWS && r0 + t < N && dg > 64) d.longrows[lbase + atomicAdd(&lpos, 1u)] = r0 + t;
     }
     if (t == 0) {
         if (b == 0) {
