@@ -259,7 +259,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         Timed t3(e, s, 3);
         // dense-LDS case: few workgroups (every one flushes every node it saw); hashed case (too many nodes for
         // LDS): a workgroup aggregates HT/2 edges per round, so more of them, bounded by the flush atomics
-        const int g3 = d.in_dense ? K3_IN_WGS : (int)std::min<u64>(64, std::max<u64>(K3_IN_WGS, (e->cfg.max_edges + 2047) / 2048));
+        const int g3 = d.in_dense ? K3_IN_WGS : (int)std::min<u64>(128, std::max<u64>(K3_IN_WGS, (e->cfg.max_edges + K3_IN_ROUND - 1) / K3_IN_ROUND));
         hipLaunchKernelGGL(k3_in_stats, dim3(g3), dim3(1024), e->k3in_lds, s, d);
     }
     HIP_TRY(e, hipGetLastError());

@@ -1082,6 +1082,8 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 // receives one atomic per word per workgroup instead of one per edge.
 #define K3_IN_NODES 2560
 #define K3_IN_HT    2048
+#define K3_IN_ROUND 8192      // edges per round of the hashed path
+#define K3_IN_PROBES 32
 #define K3_IN_WGS   16
 __device__ __forceinline__ void in_flush(const Dev& d, u32 to, const u64* o) {
     u64* gsum = d.st_sum + (size_t)to * SG_NODE_STAT_SUM_WORDS;
@@ -1146,25 +1148,40 @@ __global__ __launch_bounds__(1024) void k3_in_stats(Dev d) {
     } else {
         u64* tacc = reinterpret_cast<u64*>(smem);                    // [K3_IN_HT][6]
         u32* tkey = reinterpret_cast<u32*>(tacc + K3_IN_HT * 6);     // [K3_IN_HT]
-        for (u32 c0 = p0; c0 < p1; c0 += K3_IN_HT / 2) {             // at most HT/2 edges (=> distinct nodes) per round
+        // Rounds of K3_IN_ROUND edges (8 per thread, loads of a thread's edges in flight together).  The table holds
+        // K3_IN_HT distinct destinations; a destination that finds no slot within K3_IN_PROBES probes (a round with
+        // too many distinct destinations) is added with device-scope atomics directly — rare, and exact either way.
+        for (u32 c0 = p0; c0 < p1; c0 += K3_IN_ROUND) {
             for (u32 i = t; i < K3_IN_HT; i += 1024) tkey[i] = SG_NONE;
             for (u32 i = t; i < K3_IN_HT * 6; i += 1024) tacc[i] = 0;
             __syncthreads();
-            const u32 c1 = c0 + K3_IN_HT / 2 < p1 ? c0 + K3_IN_HT / 2 : p1;
-            for (u32 p = c0 + t; p < c1; p += 1024) {
-                const u32 to = d.col[p];
-                const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
-                const ulonglong2 x = a[0], y = a[1];
-                u32 h = sg_fmix32(to) & (K3_IN_HT - 1);
-                for (;;) {
-                    u32 kk = ((volatile u32*)tkey)[h];
-                    if (kk == SG_NONE) { kk = atomicCAS(&tkey[h], SG_NONE, to); if (kk == SG_NONE) kk = to; }
-                    if (kk == to) break;
-                    h = (h + 1) & (K3_IN_HT - 1);
+            const u32 c1 = c0 + K3_IN_ROUND < p1 ? c0 + K3_IN_ROUND : p1;
+            for (u32 pb = c0 + t; pb < c1; pb += 1024 * 4) {
+                u32 to[4]; ulonglong2 x[4], y[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32 p = pb + q * 1024;
+                    if (p < c1) { to[q] = d.col[p]; const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4); x[q] = a[0]; y[q] = a[1]; }
                 }
-                u64* o = tacc + (size_t)h * 6;
-                atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x.x & 0xFFFFFFFFull); atomicAdd(&o[2], x.x >> 32);
-                atomicAdd(&o[3], x.y); atomicAdd(&o[4], y.y); atomicMax(&o[5], y.x);
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (pb + q * 1024 < c1) {
+                    u32 h = sg_fmix32(to[q]) & (K3_IN_HT - 1);
+                    bool found = false;
+                    for (u32 pr = 0; pr < K3_IN_PROBES; pr++) {
+                        u32 kk = ((volatile u32*)tkey)[h];
+                        if (kk == SG_NONE) { kk = atomicCAS(&tkey[h], SG_NONE, to[q]); if (kk == SG_NONE) kk = to[q]; }
+                        if (kk == to[q]) { found = true; break; }
+                        h = (h + 1) & (K3_IN_HT - 1);
+                    }
+                    if (found) {
+                        u64* o = tacc + (size_t)h * 6;
+                        atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x[q].x & 0xFFFFFFFFull); atomicAdd(&o[2], x[q].x >> 32);
+                        atomicAdd(&o[3], x[q].y); atomicAdd(&o[4], y[q].y); atomicMax(&o[5], y[q].x);
+                    } else {
+                        const u64 one[6] = {1ull, x[q].x & 0xFFFFFFFFull, x[q].x >> 32, x[q].y, y[q].y, y[q].x};
+                        in_flush(d, to[q], one);
+                    }
+                }
             }
             __syncthreads();
             for (u32 s = t; s < K3_IN_HT; s += 1024) if (tkey[s] != SG_NONE) in_flush(d, tkey[s], tacc + (size_t)s * 6);
