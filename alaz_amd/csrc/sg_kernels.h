@@ -1292,48 +1292,20 @@ __device__ __forceinline__ f32x4 dense_tile_mfma(const float* A, int lda, const 
 // gather-mean of one node into dst[0..FI): executed by one wave.  Neighbour ids are fetched 64 at a
 // time (one coalesced load) and broadcast by shuffle, so the 8 / 16 row loads of an unrolled step
 // are independent and in flight together.  Summation order is the canonical one (slot = i % 16).
-// Sum of the feature rows of neighbours [i_beg, i_end) of one node, one wave.  i_beg is a multiple of
-// SG_MEAN_BLOCK and the range at most one block, so this is the block sum of the canonical mean:
-// 16 interleaved slot sums (neighbour i -> slot i % 16, ascending i) combined in slot order.
-// FI == 32: lanes 0..31 return the sum for feature k = lane (lane group g = lane >> 5 takes the even /
-// odd slots); FI == 64: every lane returns feature k = lane.
+// Sum of the feature rows of neighbours [i_beg, i_end) of one node, one wave, written to dst[0..FI) (LDS).
+// i_beg is a multiple of SG_MEAN_BLOCK and the range at most one block, so this is the block sum of the canonical
+// mean: 16 interleaved slot sums (neighbour i -> slot i % 16, ascending i) combined in slot order.
+// Lane layout: a lane loads four consecutive features (one 16-byte load) of one neighbour: c = lane % (FI/4) picks
+// the features 4c..4c+3, g = lane / (FI/4) the neighbour inside a group of G = 256/FI; one load instruction fetches G
+// whole rows and the 64/G loads of a 64-neighbour batch are all in flight together (one round trip per batch; the
+// scalar-per-lane layout before needed two for FI = 32 and four for FI = 64).
+// Neighbour i = G*a + g of a batch goes to slot i % 16 = G*(a % (16/G)) + g, i.e. accumulator a % (16/G) of group g.
 template <int FI>
-__device__ __forceinline__ float gather_block_sum(const float* __restrict__ hin, const u32* __restrict__ nb, u32 i_beg, u32 i_end) {
-    const u32 lane = threadIdx.x & 63;
-    if (FI == 32) {
-        const u32 g = lane >> 5, k = lane & 31;
-        float acc[8];
-#pragma unroll
-        for (int a = 0; a < 8; a++) acc[a] = 0.0f;
-        u32 nxt = i_beg + lane < i_end ? nb[i_beg + lane] : 0u;     // ids of the next batch are fetched one batch ahead
-        for (u32 base = i_beg; base < i_end; base += 64) {
-            const u32 cnt = i_end - base < 64 ? i_end - base : 64;
-            const u32 my = nxt;
-            nxt = base + 64 + lane < i_end ? nb[base + 64 + lane] : 0u;
-            for (u32 i0 = 0; i0 < cnt; i0 += 32) {                   // 16 row loads in flight per lane group
-                float tmp[16];
-#pragma unroll
-                for (int a = 0; a < 16; a++) {
-                    const u32 i = i0 + 2 * a + g;                    // slot = i % 16 = (2a + g) % 16  (base, i0 multiples of 16)
-                    const u32 id = __shfl(my, (int)(i & 63), 64);    // (two v_readlane + select measured slower here, r01r)
-                    tmp[a] = i < cnt ? hin[(size_t)id * 32 + k] : 0.0f;
-                }
-#pragma unroll
-                for (int a = 0; a < 8; a++) if (i0 + 2 * a + g < cnt) acc[a] = acc[a] + tmp[a];
-#pragma unroll
-                for (int a = 0; a < 8; a++) if (i0 + 16 + 2 * a + g < cnt) acc[a] = acc[a] + tmp[8 + a];
-            }
-        }
-        float t = 0.0f;
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-            const float o = __shfl_xor(acc[a], 32, 64);
-            const float even = g == 0 ? acc[a] : o, odd = g == 0 ? o : acc[a];
-            t = a == 0 ? even : t + even;
-            t = t + odd;
-        }
-        return t;
-    } else {
+__device__ __forceinline__ void gather_block_sum(const float* __restrict__ hin, const u32* __restrict__ nb, u32 i_beg, u32 i_end, float* dst) {
+    if (FI == 64) {
+        // one feature per lane, 16 row loads in flight (the 16-byte layout below needs more registers than a
+        // 1024-thread workgroup has for FI = 64: it spilled)
+        const u32 lane = threadIdx.x & 63;
         float acc[16];
 #pragma unroll
         for (int a = 0; a < 16; a++) acc[a] = 0.0f;
@@ -1354,8 +1326,50 @@ __device__ __forceinline__ float gather_block_sum(const float* __restrict__ hin,
         float t = acc[0];
 #pragma unroll
         for (int a = 1; a < 16; a++) t = t + acc[a];
-        return t;
+        dst[lane] = t;
+        return;
     }
+    constexpr int C = FI / 4, G = 64 / C, NL = 64 / G, NA = 16 / G, NLC = NL < 8 ? NL : 8;   // FI=32: 8 lanes per row, 8 groups, 8 loads, 2 accumulators
+    const u32 lane = threadIdx.x & 63, c = lane % C, g = lane / C;
+    const float4* __restrict__ h4 = reinterpret_cast<const float4*>(hin);
+    float4 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) acc[a] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    u32 nxt = i_beg + lane < i_end ? nb[i_beg + lane] : 0u;             // ids of the next batch are fetched one batch ahead
+    for (u32 base = i_beg; base < i_end; base += 64) {
+        const u32 cnt = i_end - base < 64 ? i_end - base : 64;
+        const u32 my = nxt;
+        nxt = base + 64 + lane < i_end ? nb[base + 64 + lane] : 0u;
+#pragma unroll
+        for (int a0 = 0; a0 < NL; a0 += NLC) {                           // NLC loads in flight (register budget: 128 VGPRs at 1024 threads)
+            float4 tmp[NLC];
+#pragma unroll
+            for (int a = 0; a < NLC; a++) {
+                const u32 i = (u32)(G * (a0 + a)) + g;
+                const u32 id = __shfl(my, (int)i, 64);
+                tmp[a] = i < cnt ? h4[id * (u32)C + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int a = 0; a < NLC; a++) if ((u32)(G * (a0 + a)) + g < cnt) {   // ascending neighbour index inside every slot
+                float4& o = acc[(a0 + a) % NA];
+                o.x = o.x + tmp[a].x; o.y = o.y + tmp[a].y; o.z = o.z + tmp[a].z; o.w = o.w + tmp[a].w;
+            }
+        }
+    }
+    // slots combined in slot order 0..15: slot s lives in group s % G, accumulator s / G (not unrolled: 64 shuffles
+    // unrolled cost more registers than the kernel has)
+    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 1
+    for (int sl = 0; sl < 16; sl++) {
+        const int src = (int)c + C * (sl % G);
+        float4 v = acc[0];
+#pragma unroll
+        for (int a = 1; a < NA; a++) if (sl / G == a) v = acc[a];
+        const float x = __shfl(v.x, src, 64), y = __shfl(v.y, src, 64), z = __shfl(v.z, src, 64), w = __shfl(v.w, src, 64);
+        if (sl == 0) t = make_float4(x, y, z, w);
+        else { t.x = t.x + x; t.y = t.y + y; t.z = t.z + z; t.w = t.w + w; }
+    }
+    if (g == 0) { dst[4 * c] = t.x; dst[4 * c + 1] = t.y; dst[4 * c + 2] = t.z; dst[4 * c + 3] = t.w; }   // (dst is only 8-byte aligned in the tile)
 }
 #define SG_MEAN_BLOCK 512        // neighbours per block of the canonical mean: block sums are added in block order
 
@@ -1398,8 +1412,11 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
                 const u32 beg = d.rowptr[v];
                 deg = d.rowptr[v + 1] - beg;
                 // block 0 here (one wave per row, all rows at once); the further blocks of a hub row below
-                const float t = deg ? gather_block_sum<FI>(hin, d.col + beg, 0, deg < SG_MEAN_BLOCK ? deg : SG_MEAN_BLOCK) : 0.0f;
-                if (lane < FI) row[FI + lane] = deg > SG_MEAN_BLOCK ? t : (deg ? t / (float)deg : 0.0f);
+                if (deg) gather_block_sum<FI>(hin, d.col + beg, 0, deg < SG_MEAN_BLOCK ? deg : SG_MEAN_BLOCK, row + FI);
+                if (lane < FI) {                                     // (same wave wrote row[FI..): ordered by the LDS counter)
+                    const float t = deg ? row[FI + lane] : 0.0f;
+                    row[FI + lane] = deg > SG_MEAN_BLOCK ? t : (deg ? t / (float)deg : 0.0f);
+                }
             }
             if (lane == 0) { skip[r] = sk ? 1u : 0u; vid[r] = v; tdeg[r] = deg; }
         }
@@ -1415,8 +1432,7 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
                 const u32 bn = nblk - b0 < K4_HUB_BLOCKS ? nblk - b0 : K4_HUB_BLOCKS;
                 for (u32 j = wave; j < bn; j += 16) {
                     const u32 i0 = (b0 + j) * SG_MEAN_BLOCK, i1 = i0 + SG_MEAN_BLOCK < deg ? i0 + SG_MEAN_BLOCK : deg;
-                    const float t = gather_block_sum<FI>(hin, d.col + beg, i0, i1);
-                    if (lane < FI) hub[j * FI + lane] = t;
+                    gather_block_sum<FI>(hin, d.col + beg, i0, i1, hub + j * FI);
                 }
                 __syncthreads();
                 if (wave == 0 && lane < FI) for (u32 j = 0; j < bn; j++) total = total + hub[j * FI + lane];

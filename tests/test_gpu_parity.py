@@ -510,7 +510,8 @@ def test_alive_connections_are_count_only_edges(variant):
     seen = 0
     for batch, has_alive in ((both, True), (ev[:5000], False)):
         for i in range(0, len(batch), 7001):
-            assert g.ingest(batch[i:i + 7001]) == 0
+            while g.ingest(batch[i:i + 7001]) != 0:          # SG_EAGAIN: staging ring momentarily full -> the test retries
+                pass
         g.set_label_count(len(labels))
         rows = g.flush_window()
         o.packed(batch, labels); o.window_close(W, 2)
