@@ -8,7 +8,7 @@
 //   processTcpConnect                  aggregator/data.go:404-506
 //   sendOpenConnection / sweep         aggregator/data.go:1628-1716
 // Addresses are numeric IPv4 here (a<<24|b<<16|c<<8|d, like L7Event.Saddr); the reference keeps dotted
-// strings, the oracle (oracle/sockline.c) does too, and tests/test_host.py compares the two.
+// strings, the oracle (oracle/sockline.c) does too, and tests/test_sockline.py compares the two.
 // Differences by design: the reference creates a process' socket map and an fd's socket line
 // asynchronously (and may seed the line from /proc/<pid>/net/tcp) and re-queues the event meanwhile;
 // here the line is created on demand and starts empty.  time.Now() is a parameter.
