@@ -865,7 +865,7 @@ int sg_route(sg_handle e, const sg_event* ev, size_t n, uint32_t world, uint32_t
         auto sp = e->pod_ip.find(x.saddr);
         if (sp == e->pod_ip.end()) { shard_out[i] = sg_fmix32(x.saddr) % world; continue; }   // will be dropped wherever it lands
         owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, sp->second));
-        if (x.flags & SG_EV_REVERSE) {
+        if ((x.flags & SG_EV_REVERSE) && !(x.flags & SG_EV_ALIVE)) {    // (K1 never reverses an alive record)
             auto ds = e->svc_ip.find(x.daddr);
             if (ds != e->svc_ip.end()) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, ds->second));
             else {

@@ -66,7 +66,7 @@ def route_events(ev: np.ndarray, world: int, pod_ip_to_id: dict, svc_ip_to_id: d
         return hit, vals[i]
     sp_hit, sp = lookup(pod_keys, pod_vals, ev["saddr"])
     shard = np.where(sp_hit, owner_of_known(sp, world), replay.hash32(ev["saddr"]) % np.uint32(world))
-    rev = (ev["flags"] & replay.EV_REVERSE) != 0
+    rev = ((ev["flags"] & replay.EV_REVERSE) != 0) & ((ev["flags"] & replay.EV_ALIVE) == 0)   # alive records are never reversed
     if rev.any():
         ds_hit, ds = lookup(svc_keys, svc_vals, ev["daddr"])
         dp_hit, dp = lookup(pod_keys, pod_vals, ev["daddr"])

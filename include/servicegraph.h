@@ -305,7 +305,7 @@ int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
 int sg_debug_stamps(sg_handle h, uint64_t* out, size_t n);
 
 /* Owner shard of a node / routing shard of an event: murmur3 fmix32(ip) % world.
- * The feeder routes an event by the IP of its from-endpoint: daddr if SG_EV_REVERSE else saddr. */
+ * The feeder routes an event by the IP of its from-endpoint: daddr if SG_EV_REVERSE (and not SG_EV_ALIVE) else saddr. */
 uint32_t sg_hash32(uint32_t x);
 /* Shard each event must be fed to when world > 1: owner of its from-endpoint after the join and
  * the optional direction reversal — the same rule K1 enforces (misrouted events are dropped and

@@ -317,6 +317,16 @@ def test_logical_shards_on_one_device_equal_the_unsharded_engine(layers):
     from alaz_amd import engine, sharded
     topo = replay.make_topology(120, 1500, seed=91)
     ev, labels = replay.make_events(topo, 60_000, seed=92, mixed=True, with_raw_outbound=True, with_reverse=True, fixed_labels=True)
+    # f-2: open connections too — on busy edges, on idle pairs, to raw outbound IPs; a stray REVERSE flag must not
+    # change where they are routed (K1 never reverses an alive record)
+    rng = np.random.default_rng(94)
+    al = np.zeros(4000, dtype=replay.EVENT_DTYPE)
+    al["flags"] = replay.EV_ALIVE; al["flags"][::5] |= replay.EV_REVERSE
+    al["saddr"] = topo.pod_ips[rng.integers(0, topo.n_pods, len(al))]
+    pick = rng.random(len(al))
+    al["daddr"] = np.where(pick < 0.5, topo.svc_ips[rng.integers(0, topo.n_svcs, len(al))],
+                  np.where(pick < 0.8, topo.pod_ips[rng.integers(0, topo.n_pods, len(al))], 0x5DB8D800 + rng.integers(0, 30, len(al)))).astype(np.uint32)
+    ev = np.concatenate([ev[:30_000], al[:2000], ev[30_000:], al[2000:]])
     W = weights.make_weights(layers)
     ref = _engine(topo.n_nodes + 8, 8192, layers, max_labels=128, max_outbound_ips=512)
     shim = HostShim(); shim.apply(ref, topo.k8s_ops())
@@ -353,6 +363,7 @@ def test_logical_shards_on_one_device_equal_the_unsharded_engine(layers):
         got = got[key(got)]; exp = want[key(want)]
         assert len(got) == len(exp) and min(len(o) for o in outs) > 0
         assert got.tobytes() == exp.tobytes()
+        assert int(got["alive"].sum()) == len(al) and sum(e.stats().alive_in for e in engs) == len(al)
         for g in engs: g.close()
 
 
