@@ -25,6 +25,13 @@ def _free_port():
 def _trace(layers):
     topo = replay.make_topology(40, 300, seed=201)
     ev, labels = replay.make_events(topo, 6000, seed=202, mixed=True, with_raw_outbound=True, with_reverse=True, fixed_labels=True)
+    # f-2: alive-connection records ride the same shards (some with a stray REVERSE flag, which must be ignored)
+    rng = np.random.default_rng(203)
+    al = np.zeros(400, dtype=replay.EVENT_DTYPE)
+    al["flags"] = replay.EV_ALIVE; al["flags"][::3] |= replay.EV_REVERSE
+    al["saddr"] = topo.pod_ips[rng.integers(0, topo.n_pods, len(al))]
+    al["daddr"] = np.where(rng.random(len(al)) < 0.7, topo.svc_ips[rng.integers(0, topo.n_svcs, len(al))], 0x5DB8D800 + rng.integers(0, 10, len(al))).astype(np.uint32)
+    ev = np.concatenate([ev[:3000], al, ev[3000:]])
     return topo, ev, labels
 
 
@@ -42,7 +49,7 @@ def _worker(rank, world, port, layers, q):
                           layers=layers, rank=rank, world=world, ncap=topo.n_nodes + len(labels) + 64)
         be.ingest(ev[shard == rank])
         sharded.run_window(be)
-        q.put((rank, be.rows, be.misrouted, be.N, [int(x) for x in be.ob]))
+        q.put((rank, be.rows, be.misrouted, be.N, [int(x) for x in be.ob], [int(x) for x in be.alive_csr]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -81,6 +88,11 @@ def test_two_shards_equal_unsharded_oracle(layers):
         assert er == float(w["err_ratio"])
     # both shards actually own edges, and some edges need halo rows
     assert all(len(g[1]) > 0 for g in got)
+    # alive counts: per edge as in the oracle (rows and alive_csr are both in the shard's CSR order)
+    for g in got:
+        for (f, t, *_), a in zip(g[1], g[5]):
+            assert a == int(ref_rows[(f, t)]["alive"])
+    assert sum(sum(g[5]) for g in got) == int(want["alive"].sum()) == 400
 
 
 def test_route_events_matches_the_ownership_rule():
@@ -89,7 +101,7 @@ def test_route_events_matches_the_ownership_rule():
     svc = {int(ip): topo.n_pods + j for j, ip in enumerate(topo.svc_ips)}
     for world in (2, 4, 8):
         sh = sharded.route_events(ev, world, pod, svc)
-        plain = (ev["flags"] & replay.EV_REVERSE) == 0
+        plain = ((ev["flags"] & replay.EV_REVERSE) == 0) | ((ev["flags"] & replay.EV_ALIVE) != 0)
         known = np.isin(ev["saddr"], topo.pod_ips)
         ids = (ev["saddr"][plain & known] - replay.POD_IP_BASE).astype(np.uint32)
         assert np.array_equal(sh[plain & known], replay.hash32(ids) % np.uint32(world))
