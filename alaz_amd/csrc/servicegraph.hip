@@ -286,7 +286,7 @@ int do_layer(sg_engine* e, u32 l, hipStream_t s, bool fuse_proj) {
     const int grid = grid_for(d.ncap, 16);
     const bool pj = fuse_proj && l + 1 == e->cfg.layers && d.world == 1;
     Timed t(e, s, 4);
-#define K4_LAUNCH(FI, MF, PJ, HIN, HOUT) hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ>), dim3(grid), dim3(1024), 0, s, d, HIN, HOUT, Wl, Wh)
+#define K4_LAUNCH(FI, MF, PJ, HIN, HOUT) hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ, (FI == 32 ? 1024 : 512)>), dim3(grid), dim3(FI == 32 ? 1024 : 512), 0, s, d, HIN, HOUT, Wl, Wh)
     if (l == 0) {
         if (e->use_mfma) { if (pj) K4_LAUNCH(32, true, true, d.x0, d.h[1]); else K4_LAUNCH(32, true, false, d.x0, d.h[1]); }
         else { if (pj) K4_LAUNCH(32, false, true, d.x0, d.h[1]); else K4_LAUNCH(32, false, false, d.x0, d.h[1]); }

@@ -1300,11 +1300,12 @@ __device__ __forceinline__ f32x4 dense_tile_mfma(const float* A, int lda, const 
 // whole rows and the 64/G loads of a 64-neighbour batch are all in flight together (one round trip per batch; the
 // scalar-per-lane layout before needed two for FI = 32 and four for FI = 64).
 // Neighbour i = G*a + g of a batch goes to slot i % 16 = G*(a % (16/G)) + g, i.e. accumulator a % (16/G) of group g.
-template <int FI>
+// WIDE = loads in flight per 64-neighbour batch in the 16-byte layout (0: the one-feature-per-lane layout)
+template <int FI, int WIDE>
 __device__ __forceinline__ void gather_block_sum(const float* __restrict__ hin, const u32* __restrict__ nb, u32 i_beg, u32 i_end, float* dst) {
-    if (FI == 64) {
-        // one feature per lane, 16 row loads in flight (the 16-byte layout below needs more registers than a
-        // 1024-thread workgroup has for FI = 64: it spilled)
+    if (WIDE == 0) {
+        // one feature per lane (FI = 64), 16 row loads in flight: for the 1024-thread kernel, where the 16-byte
+        // layout below needs more registers than there are (it spilled)
         const u32 lane = threadIdx.x & 63;
         float acc[16];
 #pragma unroll
@@ -1329,7 +1330,7 @@ __device__ __forceinline__ void gather_block_sum(const float* __restrict__ hin, 
         dst[lane] = t;
         return;
     }
-    constexpr int C = FI / 4, G = 64 / C, NL = 64 / G, NA = 16 / G, NLC = NL < 8 ? NL : 8;   // FI=32: 8 lanes per row, 8 groups, 8 loads, 2 accumulators
+    constexpr int C = FI / 4, G = 64 / C, NL = 64 / G, NA = 16 / G, NLC = NL < WIDE ? NL : WIDE;   // FI=32: 8 lanes per row, 8 groups, 8 loads, 2 accumulators
     const u32 lane = threadIdx.x & 63, c = lane % C, g = lane / C;
     const float4* __restrict__ h4 = reinterpret_cast<const float4*>(hin);
     float4 acc[NA];
@@ -1378,8 +1379,11 @@ __device__ __forceinline__ void gather_block_sum(const float* __restrict__ hin, 
 // the first 4 waves.  With PROJ the tile's fresh h rows are immediately projected to the score
 // head's P = b1 + h Wu and Q = h Wv (last layer, unsharded), saving a launch.
 #define K4_HUB_BLOCKS 32         // block sums of a hub row kept in LDS per round
-template <int FI, bool USE_MFMA, bool PROJ>
-__global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __restrict__ hin, float* __restrict__ hout, const float* __restrict__ Wl, const float* __restrict__ Wh) {
+// NT = 1024 (one wave per tile row) for the 32-feature first layer; NT = 512 (a wave takes two rows) for the
+// 64-feature hidden layers: twice the registers per lane, so all 16 loads of a batch in the 16-byte layout are in
+// flight (a quarter of the round trips on hub rows; C3 layer 2: 369 us before).
+template <int FI, bool USE_MFMA, bool PROJ, int NT>
+__global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restrict__ hin, float* __restrict__ hout, const float* __restrict__ Wl, const float* __restrict__ Wh) {
     constexpr int LDA = 2 * FI + 2;                               // +2 floats: conflict-free A-fragment reads
     constexpr int LDH = SG_F_HID + 2;
     __shared__ float A[16 * LDA];
@@ -1392,12 +1396,13 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
     const bool listed = !PROJ && d.world > 1 && d.ctr[C_ACT_L] != SG_ACT_NONE;   // lists are built with the halo requests
     const u32 N = listed ? (u32)d.ctr[C_ACT_L] : (u32)d.ctr[C_N_NODES];
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    constexpr u32 NW = NT / 64;
+    constexpr int WIDE = FI == 32 ? 8 : (NT <= 512 ? 16 : 0);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* __restrict__ bias = Wl + 2 * FI * SG_F_HID;
     for (u32 tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
         const u32 v0 = tile * 16;
-        {   // phase 1: self row + gather-mean, wave w <-> tile row w
-            const u32 r = wave;
+        for (u32 r = wave; r < 16; r += NW) {   // phase 1: self row + gather-mean, one wave per tile row
             bool sk = v0 + r >= N;
             const u32 v = sk ? 0u : (listed ? d.act_l[v0 + r] : v0 + r);
             if (!sk && !listed && d.world > 1) {                     // no list this window: walk all nodes, skip what an owner computes
@@ -1412,7 +1417,7 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
                 const u32 beg = d.rowptr[v];
                 deg = d.rowptr[v + 1] - beg;
                 // block 0 here (one wave per row, all rows at once); the further blocks of a hub row below
-                if (deg) gather_block_sum<FI>(hin, d.col + beg, 0, deg < SG_MEAN_BLOCK ? deg : SG_MEAN_BLOCK, row + FI);
+                if (deg) gather_block_sum<FI, WIDE>(hin, d.col + beg, 0, deg < SG_MEAN_BLOCK ? deg : SG_MEAN_BLOCK, row + FI);
                 if (lane < FI) {                                     // (same wave wrote row[FI..): ordered by the LDS counter)
                     const float t = deg ? row[FI + lane] : 0.0f;
                     row[FI + lane] = deg > SG_MEAN_BLOCK ? t : (deg ? t / (float)deg : 0.0f);
@@ -1430,9 +1435,9 @@ __global__ __launch_bounds__(1024) void k4_sage_layer(Dev d, const float* __rest
             float total = (wave == 0 && lane < FI) ? A[r * LDA + FI + lane] : 0.0f;   // block 0, from above (wave 0, lanes < FI)
             for (u32 b0 = 1; b0 < nblk; b0 += K4_HUB_BLOCKS) {
                 const u32 bn = nblk - b0 < K4_HUB_BLOCKS ? nblk - b0 : K4_HUB_BLOCKS;
-                for (u32 j = wave; j < bn; j += 16) {
+                for (u32 j = wave; j < bn; j += NW) {
                     const u32 i0 = (b0 + j) * SG_MEAN_BLOCK, i1 = i0 + SG_MEAN_BLOCK < deg ? i0 + SG_MEAN_BLOCK : deg;
-                    gather_block_sum<FI>(hin, d.col + beg, i0, i1, hub + j * FI);
+                    gather_block_sum<FI, WIDE>(hin, d.col + beg, i0, i1, hub + j * FI);
                 }
                 __syncthreads();
                 if (wave == 0 && lane < FI) for (u32 j = 0; j < bn; j++) total = total + hub[j * FI + lane];
