@@ -82,6 +82,13 @@ public:
     // earlier tap: the raw L7 event (what processL7 receives, aggregator/data.go:1364-1383)
     int IngestL7(const l7_req::L7Event& e, uint32_t kafka_msgs = 1);
 
+    // process / connection lifecycle as far as the HTTP/2 assembler needs it (aggregator/data.go:354-377, :484-494,
+    // :553-567): only events of live pids are assembled; a closed connection or an exited process drops its HPACK state
+    void ProcExec(uint32_t pid) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ProcExec(pid); }
+    void ProcExit(uint32_t pid) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ProcExit(pid); }
+    void ConnClosed(uint32_t pid, uint64_t fd) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ConnClosed(pid, fd); }
+    void SweepHttp2() { std::lock_guard<std::mutex> g(mu_); packer_.Http2().Sweep(); }
+
     // close the window: pending batch -> engine, K2..K5, rows -> sink.  Returns the number of edges or < 0.
     long FlushWindow(int64_t window_end_ms);
 

@@ -155,9 +155,90 @@ int sgh_sockline_at(void* l, size_t i, uint64_t* ts, uint64_t* last_match, sgh_s
 // TCP connect records (BpfTcpEvent, 64 bytes each) through processTcpConnect; returns values added
 size_t sgh_graphds_tcp_wire(void* g, const uint8_t* recs, size_t n) {
     auto* c = static_cast<HostCtx*>(g); size_t added = 0;
-    for (size_t i = 0; i < n; i++) added += c->conns.ProcessTcpConnect(tcp_state::DecodeWire(recs + i * tcp_state::kWireSize)) ? 1 : 0;
+    for (size_t i = 0; i < n; i++) {
+        const tcp_state::TcpConnectEvent e = tcp_state::DecodeWire(recs + i * tcp_state::kWireSize);
+        const bool ok = c->conns.ProcessTcpConnect(e);
+        if (ok && e.Type == tcp_state::kClosed) c->ds->ConnClosed(e.Pid, e.Fd);     // data.go:484-494
+        added += ok ? 1 : 0;
+    }
     return added;
 }
+// process exec / exit (proc events, data.go:354-377) and the HTTP/2 minute sweep (:553-567)
+void sgh_graphds_proc_exec(void* g, uint32_t pid) { static_cast<HostCtx*>(g)->ds->ProcExec(pid); }
+void sgh_graphds_proc_exit(void* g, uint32_t pid) { static_cast<HostCtx*>(g)->ds->ProcExit(pid); }
+void sgh_graphds_sweep_http2(void* g) { static_cast<HostCtx*>(g)->ds->SweepHttp2(); }
+// counters of the assembler: [0] streams pending, [1] parsers, [2] dropped: pid not live, [3] dropped: method/path unparsed, [4] dropped: time
+void sgh_graphds_http2_stats(void* g, uint64_t out[5]) {
+    const Http2Assembler& a = static_cast<HostCtx*>(g)->ds->Packer().Http2();
+    out[0] = a.Pending(); out[1] = a.Parsers(); out[2] = a.DroppedNotLive(); out[3] = a.DroppedUnparsed(); out[4] = a.DroppedTime();
+}
+
+// ---- stand-alone HPACK decoder / HTTP/2 assembler (known-answer and differential tests) ----
+void* sgh_hpack_create(uint32_t max_table) { return new hpack::Decoder(max_table); }
+void sgh_hpack_destroy(void* d) { delete static_cast<hpack::Decoder*>(d); }
+// decodes `block`; the emitted fields are appended to buf as name\0value\0 (lengths in lens[2*i], lens[2*i+1]).
+// returns the number of fields, or -(1 + fields emitted before the error) on a decoding error
+long sgh_hpack_write(void* d, const uint8_t* block, size_t n, char* buf, size_t cap, uint32_t* lens, size_t max_fields) {
+    auto* dec = static_cast<hpack::Decoder*>(d);
+    size_t used = 0, nf = 0;
+    dec->SetEmitFunc([&](const hpack::HeaderField& f) {
+        if (nf < max_fields && used + f.Name.size() + f.Value.size() <= cap) {
+            std::memcpy(buf + used, f.Name.data(), f.Name.size()); used += f.Name.size();
+            std::memcpy(buf + used, f.Value.data(), f.Value.size()); used += f.Value.size();
+            lens[2 * nf] = (uint32_t)f.Name.size(); lens[2 * nf + 1] = (uint32_t)f.Value.size();
+        }
+        nf++;
+    });
+    const bool ok = dec->Write(block, n);
+    dec->SetEmitFunc(nullptr);
+    return ok ? (long)nf : -(long)(1 + nf);
+}
+size_t sgh_hpack_table_len(void* d) { return static_cast<hpack::Decoder*>(d)->DynamicTableLen(); }
+uint32_t sgh_hpack_table_size(void* d) { return static_cast<hpack::Decoder*>(d)->DynamicTableSize(); }
+size_t sgh_hpack_table_at(void* d, size_t i, char* buf, size_t cap, uint32_t lens[2]) {
+    const hpack::HeaderField& f = static_cast<hpack::Decoder*>(d)->DynamicTableAt(i);
+    lens[0] = (uint32_t)f.Name.size(); lens[1] = (uint32_t)f.Value.size();
+    if (f.Name.size() + f.Value.size() > cap) return 0;
+    std::memcpy(buf, f.Name.data(), f.Name.size()); std::memcpy(buf + f.Name.size(), f.Value.data(), f.Value.size());
+    return f.Name.size() + f.Value.size();
+}
+long sgh_huffman_decode(const uint8_t* p, size_t n, char* out, size_t cap) {
+    std::string s; if (!hpack::HuffmanDecode(p, n, &s)) return -1;
+    if (s.size() > cap) return -2;
+    std::memcpy(out, s.data(), s.size()); return (long)s.size();
+}
+long sgh_huffman_encode(const char* p, size_t n, char* out, size_t cap) {
+    std::string s; hpack::HuffmanEncode(std::string(p, n), &s);
+    if (s.size() > cap) return -2;
+    std::memcpy(out, s.data(), s.size()); return (long)s.size();
+}
+uint32_t sgh_go_atoi_u32(const char* p, size_t n) { return GoAtoiU32(std::string(p, n)); }
+
+struct sgh_h2_out { char method[64]; char path[1100]; char authority[160]; char protocol[8]; uint32_t status_code; uint64_t latency; };
+void* sgh_h2_create(void) { return new Http2Assembler(); }
+void sgh_h2_destroy(void* a) { delete static_cast<Http2Assembler*>(a); }
+int sgh_h2_event(void* a, uint32_t pid, uint64_t fd, int method_id, const uint8_t* payload, uint32_t size, uint64_t write_ns, int tls, sgh_h2_out* out) {
+    l7_req::L7Event e; e.Pid = pid; e.Fd = fd; e.ProtocolId = l7_req::BPF_L7_PROTOCOL_HTTP2; e.MethodId = (uint8_t)method_id;
+    e.PayloadSize = size > l7_req::kMaxPayload ? (uint32_t)l7_req::kMaxPayload : size; std::memcpy(e.Payload, payload, e.PayloadSize);
+    e.WriteTimeNs = write_ns; e.Tls = tls != 0;
+    Http2Request r;
+    if (!static_cast<Http2Assembler*>(a)->OnEvent(e, &r)) return 0;
+    auto put = [](char* dst, size_t cap, const std::string& s) { const size_t n = s.size() < cap - 1 ? s.size() : cap - 1; std::memcpy(dst, s.data(), n); dst[n] = 0; };
+    std::memset(out, 0, sizeof *out);
+    put(out->method, sizeof out->method, r.Method); put(out->path, sizeof out->path, r.Path); put(out->authority, sizeof out->authority, r.Authority);
+    put(out->protocol, sizeof out->protocol, r.Protocol); out->status_code = r.StatusCode; out->latency = r.Latency;
+    return 1;
+}
+void sgh_h2_proc_exec(void* a, uint32_t pid) { static_cast<Http2Assembler*>(a)->ProcExec(pid); }
+void sgh_h2_proc_exit(void* a, uint32_t pid) { static_cast<Http2Assembler*>(a)->ProcExit(pid); }
+void sgh_h2_conn_closed(void* a, uint32_t pid, uint64_t fd) { static_cast<Http2Assembler*>(a)->ConnClosed(pid, fd); }
+void sgh_h2_sweep(void* a) { static_cast<Http2Assembler*>(a)->Sweep(); }
+size_t sgh_h2_pending(void* a) { return static_cast<Http2Assembler*>(a)->Pending(); }
+size_t sgh_h2_parsers(void* a) { return static_cast<Http2Assembler*>(a)->Parsers(); }
+// the stand-alone packer's assembler
+void sgh_packer_proc_exec(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Http2().ProcExec(pid); }
+void sgh_packer_proc_exit(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Http2().ProcExit(pid); }
+void sgh_packer_conn_closed(void* p, uint32_t pid, uint64_t fd) { static_cast<L7Packer*>(p)->Http2().ConnClosed(pid, fd); }
 size_t sgh_graphds_socklines(void* g) { return static_cast<HostCtx*>(g)->conns.Lines(); }
 void* sgh_graphds_sockline(void* g, uint32_t pid, uint64_t fd) { return static_cast<HostCtx*>(g)->conns.Line(pid, fd); }
 // one clearSocketLines tick: open connections -> GraphDS::PersistAliveConnection (-> SG_EV_ALIVE records)

@@ -206,9 +206,14 @@ size_t L7Packer::Pack(const l7_req::L7Event& e, uint32_t kafka_msgs, std::vector
         if (e.MethodId == 2) ev.flags |= SG_EV_CONSUME;
         for (uint32_t k = 0; k < kafka_msgs; k++) out->push_back(ev);    // one KafkaEvent per decoded message
         return kafka_msgs;
-    case BPF_L7_PROTOCOL_HTTP2:
-        skipped_http2_++;                                               // frame assembly (data.go:544-810) is out of scope
-        return 0;
+    case BPF_L7_PROTOCOL_HTTP2: {
+        Http2Request r;
+        if (!h2_.OnEvent(e, &r)) return 0;                              // not (yet) a complete request, or dropped
+        ev.duration_ns = r.Latency;
+        ev.status = (uint16_t)(r.StatusCode > 0xFFFFu ? 0xFFFFu : r.StatusCode);
+        if (!IsKnownIP(e.Daddr) && !r.Authority.empty()) ev.host_label = InternLabel(r.Authority);
+        out->push_back(ev); return 1;
+    }
     default:
         return 0;
     }

@@ -7,6 +7,9 @@
 //   processMongoEvent  :1251-1285 (parseMongoEvent :1561-1617; recover() => keep the event)
 //   processRedisEvent  :1120-1160, processAmqpEvent :1081-1118 (ReverseDirection for PUSHED_EVENT / DELIVER)
 //   processKafkaEvent  :1035-1079 (one event per decoded message; the decoder itself is out of scope)
+//   processHttp2Event  :1019-1033 -> processHttp2Frames :544-810 (Http2Assembler, http2.hpp): an event is
+//                      emitted when the second HEADERS frame of a stream arrives; latency = the distance of
+//                      the two write times, status = :status or grpc-status, host label = :authority
 // The join (setFromToV2) is NOT done here: it is K1 on the GPU.  The packer only decides whether
 // an event reaches the join at all and which outbound label it would carry.
 #pragma once
@@ -17,6 +20,7 @@
 #include <vector>
 
 #include "../../../include/servicegraph.h"
+#include "http2.hpp"
 #include "l7_event.hpp"
 
 namespace alaz {
@@ -40,7 +44,8 @@ public:
 
     const std::vector<std::string>& Labels() const { return labels_; }
     uint64_t DroppedParse() const { return dropped_parse_; }
-    uint64_t SkippedHttp2() const { return skipped_http2_; }
+    Http2Assembler& Http2() { return h2_; }
+    const Http2Assembler& Http2() const { return h2_; }
 
 private:
     uint32_t InternLabel(const std::string& host);
@@ -52,7 +57,8 @@ private:
     std::unordered_map<std::string, uint32_t> label_ids_;
     std::vector<std::string> labels_;
     std::unordered_map<std::string, std::string> pg_stmts_, mysql_stmts_;   // data.go pgStmts / mySqlStmts
-    uint64_t dropped_parse_ = 0, skipped_http2_ = 0;
+    Http2Assembler h2_;
+    uint64_t dropped_parse_ = 0;
 };
 
 }  // namespace alaz

@@ -28,6 +28,14 @@ class SockInfoC(C.Structure):
 _lib = None
 
 
+class H2OutC(C.Structure):
+    _fields_ = [("method", C.c_char * 64), ("path", C.c_char * 1100), ("authority", C.c_char * 160), ("protocol", C.c_char * 8),
+                ("status_code", C.c_uint32), ("latency", C.c_uint64)]
+
+    def as_tuple(self):
+        return (self.method, self.path, self.authority, self.protocol, self.status_code, self.latency)
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -54,6 +62,19 @@ def load() -> C.CDLL:
             "sgh_graphds_tcp_wire": (sz, [P, P, sz]), "sgh_graphds_socklines": (sz, [P]), "sgh_graphds_sockline": (P, [P, u32, u64]),
             "sgh_graphds_sweep": (sz, [P, C.c_int64, C.c_int]),
             "sgh_graphds_labels": (sz, [P, C.c_char_p, sz]), "sgh_graphds_dropped_parse": (u64, [P]), "sgh_graphds_engine": (P, [P]),
+            "sgh_graphds_proc_exec": (None, [P, u32]), "sgh_graphds_proc_exit": (None, [P, u32]), "sgh_graphds_sweep_http2": (None, [P]),
+            "sgh_graphds_http2_stats": (None, [P, C.POINTER(u64)]),
+            "sgh_hpack_create": (P, [u32]), "sgh_hpack_destroy": (None, [P]),
+            "sgh_hpack_write": (C.c_long, [P, C.c_char_p, sz, C.c_char_p, sz, C.POINTER(u32), sz]),
+            "sgh_hpack_table_len": (sz, [P]), "sgh_hpack_table_size": (u32, [P]),
+            "sgh_hpack_table_at": (sz, [P, sz, C.c_char_p, sz, C.POINTER(u32)]),
+            "sgh_huffman_decode": (C.c_long, [C.c_char_p, sz, C.c_char_p, sz]), "sgh_huffman_encode": (C.c_long, [C.c_char_p, sz, C.c_char_p, sz]),
+            "sgh_go_atoi_u32": (u32, [C.c_char_p, sz]),
+            "sgh_h2_create": (P, []), "sgh_h2_destroy": (None, [P]),
+            "sgh_h2_event": (C.c_int, [P, u32, u64, C.c_int, C.c_char_p, u32, u64, C.c_int, C.POINTER(H2OutC)]),
+            "sgh_h2_proc_exec": (None, [P, u32]), "sgh_h2_proc_exit": (None, [P, u32]), "sgh_h2_conn_closed": (None, [P, u32, u64]),
+            "sgh_h2_sweep": (None, [P]), "sgh_h2_pending": (sz, [P]), "sgh_h2_parsers": (sz, [P]),
+            "sgh_packer_proc_exec": (None, [P, u32]), "sgh_packer_proc_exit": (None, [P, u32]), "sgh_packer_conn_closed": (None, [P, u32, u64]),
             "sgh_mock_events": (sz, [P, P, sz]), "sgh_mock_table_ops": (sz, [P, P, sz]), "sgh_mock_label_count": (u32, [P]),
         }
         for name, (res, args) in sig.items():
@@ -115,6 +136,74 @@ class SocketLine:
         return out
 
 
+class Hpack:
+    """hpack::Decoder (csrc/host/http2.hpp)."""
+
+    def __init__(self, max_table_size: int = 4096):
+        self._l = load(); self._d = self._l.sgh_hpack_create(max_table_size)
+
+    def __del__(self):
+        try: self._l.sgh_hpack_destroy(self._d)
+        except Exception: pass
+
+    def write(self, block: bytes):
+        """-> (rc, fields): rc 0 ok / -1 decoding error; fields emitted by this call"""
+        cap = 8 * len(block) + 4096; buf = C.create_string_buffer(cap); lens = (C.c_uint32 * 512)()
+        r = self._l.sgh_hpack_write(self._d, block, len(block), buf, cap, lens, 256)
+        nf = r if r >= 0 else -r - 1
+        out = []; off = 0
+        for i in range(nf):
+            nl, vl = lens[2 * i], lens[2 * i + 1]
+            out.append((buf.raw[off:off + nl], buf.raw[off + nl:off + nl + vl])); off += nl + vl
+        return (0 if r >= 0 else -1), out
+
+    def table(self):
+        out = []
+        for i in range(self._l.sgh_hpack_table_len(self._d)):
+            buf = C.create_string_buffer(8192); lens = (C.c_uint32 * 2)()
+            self._l.sgh_hpack_table_at(self._d, i, buf, 8192, lens)
+            out.append((buf.raw[:lens[0]], buf.raw[lens[0]:lens[0] + lens[1]]))
+        return out
+
+    def table_size(self) -> int: return self._l.sgh_hpack_table_size(self._d)
+
+
+def huffman_decode(b: bytes):
+    out = C.create_string_buffer(2 * len(b) + 8)
+    r = load().sgh_huffman_decode(b, len(b), out, 2 * len(b) + 8)
+    return None if r < 0 else out.raw[:r]
+
+
+def huffman_encode(b: bytes) -> bytes:
+    out = C.create_string_buffer(4 * len(b) + 8)
+    r = load().sgh_huffman_encode(b, len(b), out, 4 * len(b) + 8)
+    return out.raw[:r]
+
+
+def go_atoi_u32(b: bytes) -> int: return load().sgh_go_atoi_u32(b, len(b))
+
+
+class Http2Assembler:
+    def __init__(self):
+        self._l = load(); self._a = self._l.sgh_h2_create()
+
+    def __del__(self):
+        try: self._l.sgh_h2_destroy(self._a)
+        except Exception: pass
+
+    def event(self, pid, fd, method_id, payload: bytes, write_ns, tls=False):
+        out = H2OutC()
+        r = self._l.sgh_h2_event(self._a, pid, fd, method_id, payload, len(payload), write_ns, int(tls), C.byref(out))
+        return out.as_tuple() if r else None
+
+    def proc_exec(self, pid): self._l.sgh_h2_proc_exec(self._a, pid)
+    def proc_exit(self, pid): self._l.sgh_h2_proc_exit(self._a, pid)
+    def conn_closed(self, pid, fd): self._l.sgh_h2_conn_closed(self._a, pid, fd)
+    def sweep(self): self._l.sgh_h2_sweep(self._a)
+    def pending(self): return self._l.sgh_h2_pending(self._a)
+    def parsers(self): return self._l.sgh_h2_parsers(self._a)
+
+
 class Packer:
     def __init__(self):
         self._l = load(); self._p = self._l.sgh_packer_create()
@@ -144,6 +233,10 @@ class Packer:
     def labels(self): return _labels(self._l.sgh_packer_labels, self._p)
     @property
     def dropped_parse(self): return self._l.sgh_packer_dropped_parse(self._p)
+
+    def proc_exec(self, pid): self._l.sgh_packer_proc_exec(self._p, pid)
+    def proc_exit(self, pid): self._l.sgh_packer_proc_exit(self._p, pid)
+    def conn_closed(self, pid, fd): self._l.sgh_packer_conn_closed(self._p, pid, fd)
 
 
 class GraphDS:
@@ -212,6 +305,14 @@ class GraphDS:
         return SocketLine(_borrowed=p) if p else None
 
     def sweep(self, now_ms: int, send_alive: bool = True) -> int: return self._l.sgh_graphds_sweep(self._g, now_ms, int(send_alive))
+
+    def proc_exec(self, pid: int): self._l.sgh_graphds_proc_exec(self._g, pid)
+    def proc_exit(self, pid: int): self._l.sgh_graphds_proc_exit(self._g, pid)
+    def sweep_http2(self): self._l.sgh_graphds_sweep_http2(self._g)
+
+    def http2_stats(self):
+        out = (C.c_uint64 * 5)(); self._l.sgh_graphds_http2_stats(self._g, out)
+        return dict(zip(("pending", "parsers", "dropped_not_live", "dropped_unparsed", "dropped_time"), list(out)))
 
     @property
     def labels(self): return _labels(self._l.sgh_graphds_labels, self._g)

@@ -502,8 +502,8 @@ static int persist_req(or_h2* h, const frame_arrival* f, uint64_t write_ns, int 
 int or_h2_event(or_h2* h, uint32_t pid, uint64_t fd, int method_id, const uint8_t* payload, uint32_t size,
                 uint64_t write_ns, int tls, or_h2_out* out) {
     if (!is_live(h, pid)) { h->dropped_not_live++; return 0; }       /* processHttp2Event :1023-1029 */
-    if (method_id != 1 && method_id != 2) return 0;                  /* "unknown http2 frame type" :802-805 */
     h2_parser* ps = parser_of(h, pid, fd);                           /* created before the direction test, :646-657 */
+    if (method_id != 1 && method_id != 2) return 0;                  /* "unknown http2 frame type" :802-805 */
     const uint8_t* buf = payload; const long len = (long)size;
     uint32_t offset = 0;
     for (;;) {

@@ -16,7 +16,7 @@ L7_WIRE_SIZE = 1096
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("sg_oracle.c", "sockline.c", "sg_oracle.h")] + [os.path.join(_HERE, "..", "include", "servicegraph.h")]
+    src = [os.path.join(_HERE, f) for f in ("sg_oracle.c", "sockline.c", "http2.c", "sg_oracle.h")] + [os.path.join(_HERE, "..", "include", "servicegraph.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
     return LIB_PATH
@@ -71,6 +71,17 @@ TCP_WIRE_SIZE = 64
 TCP_ESTABLISHED, TCP_CLOSED = 1, 5
 
 
+HPACK_EMIT = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+
+
+class H2Out(C.Structure):
+    _fields_ = [("method", C.c_char * 64), ("path", C.c_char * 1100), ("authority", C.c_char * OR_UID_MAX),
+                ("protocol", C.c_char * 8), ("status_code", C.c_uint32), ("latency", C.c_uint64)]
+
+    def as_tuple(self):
+        return (self.method, self.path, self.authority, self.protocol, self.status_code, self.latency)
+
+
 def _load():
     lib = C.CDLL(build())
     P = C.c_void_p
@@ -106,6 +117,21 @@ def _load():
         "or_sockline_of": (P, [P, C.c_uint32, C.c_uint64]), "or_sockline_count": (C.c_size_t, [P]),
         "or_sweep_socket_lines": (C.c_size_t, [P, C.c_int64, C.c_int]),
         "or_alive_count": (C.c_size_t, [P]), "or_alive_at": (C.POINTER(Alive), [P, C.c_size_t]),
+        "or_hpack_create": (P, [C.c_uint32]), "or_hpack_destroy": (None, [P]),
+        "or_hpack_set_emit": (None, [P, HPACK_EMIT, C.c_void_p]),
+        "or_hpack_write": (C.c_int, [P, C.c_char_p, C.c_size_t]),
+        "or_hpack_dyn_len": (C.c_size_t, [P]), "or_hpack_dyn_size": (C.c_uint32, [P]),
+        "or_hpack_dyn_at": (C.c_int, [P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+        "or_hpack_selfcheck": (C.c_int, []), "or_hpack_huff_code": (C.c_uint32, [C.c_int, C.POINTER(C.c_uint8)]),
+        "or_hpack_huff_decode": (C.c_long, [C.c_char_p, C.c_size_t, C.c_char_p]),
+        "or_go_atoi_u32": (C.c_uint32, [C.c_char_p, C.c_size_t]),
+        "or_h2_create": (P, []), "or_h2_destroy": (None, [P]),
+        "or_h2_event": (C.c_int, [P, C.c_uint32, C.c_uint64, C.c_int, C.c_char_p, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(H2Out)]),
+        "or_h2_proc_exec": (None, [P, C.c_uint32]), "or_h2_proc_exit": (None, [P, C.c_uint32]),
+        "or_h2_conn_closed": (None, [P, C.c_uint32, C.c_uint64]), "or_h2_sweep": (None, [P]),
+        "or_h2_pending": (C.c_size_t, [P]), "or_h2_parsers": (C.c_size_t, [P]),
+        "or_h2_dropped_not_live": (C.c_uint64, [P]), "or_h2_dropped_unparsed": (C.c_uint64, [P]),
+        "or_h2_of": (P, [P]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name); f.restype = res; f.argtypes = args
@@ -161,6 +187,85 @@ class SockLine:
             o = self._l.or_sl_at(self._s, i, C.byref(ts), C.byref(lm), C.byref(si))
             out.append((ts.value, lm.value, (si.saddr.decode(), si.sport, si.daddr.decode(), si.dport) if o == 1 else None))
         return out
+
+
+class Hpack:
+    """hpack.Decoder of golang.org/x/net as oracle/http2.c restates it."""
+
+    def __init__(self, max_table_size: int = 4096):
+        self._l = lib(); self._d = self._l.or_hpack_create(max_table_size)
+        self.fields: List[tuple] = []
+        self._cb = HPACK_EMIT(lambda ctx, n, nl, v, vl: self.fields.append((C.string_at(n, nl), C.string_at(v, vl))))
+        self._l.or_hpack_set_emit(self._d, self._cb, None)
+
+    def __del__(self):
+        try: self._l.or_hpack_destroy(self._d)
+        except Exception: pass
+
+    def write(self, block: bytes):
+        """-> (rc, fields emitted by this call)"""
+        self.fields = []
+        rc = self._l.or_hpack_write(self._d, block, len(block))
+        return rc, list(self.fields)
+
+    def table(self):
+        out = []
+        for i in range(self._l.or_hpack_dyn_len(self._d)):
+            n = C.c_void_p(); v = C.c_void_p(); nl = C.c_size_t(); vl = C.c_size_t()
+            self._l.or_hpack_dyn_at(self._d, i, C.byref(n), C.byref(nl), C.byref(v), C.byref(vl))
+            out.append((C.string_at(n, nl.value), C.string_at(v, vl.value)))
+        return out
+
+    def table_size(self) -> int: return self._l.or_hpack_dyn_size(self._d)
+
+
+def huff_code(sym: int):
+    ln = C.c_uint8(); code = lib().or_hpack_huff_code(sym, C.byref(ln)); return code, ln.value
+
+
+def huff_encode(s: bytes) -> bytes:
+    acc = 0; nb = 0
+    for ch in s:
+        code, ln = huff_code(ch); acc = (acc << ln) | code; nb += ln
+    pad = (-nb) % 8
+    acc = (acc << pad) | ((1 << pad) - 1); nb += pad
+    return acc.to_bytes(nb // 8, "big") if nb else b""
+
+
+def huff_decode(b: bytes):
+    out = C.create_string_buffer(2 * len(b) + 1)
+    r = lib().or_hpack_huff_decode(b, len(b), out)
+    return None if r < 0 else out.raw[:r]
+
+
+def go_atoi_u32(b: bytes) -> int: return lib().or_go_atoi_u32(b, len(b))
+
+
+class H2Assembler:
+    """processHttp2Frames as oracle/http2.c restates it (stand-alone or the Oracle's own)."""
+
+    def __init__(self, _borrowed=None):
+        self._l = lib(); self._own = _borrowed is None
+        self._h = self._l.or_h2_create() if self._own else _borrowed
+
+    def __del__(self):
+        try:
+            if self._own: self._l.or_h2_destroy(self._h)
+        except Exception: pass
+
+    def event(self, pid, fd, method_id, payload: bytes, write_ns, tls=False):
+        out = H2Out()
+        r = self._l.or_h2_event(self._h, pid, fd, method_id, payload, len(payload), write_ns, int(tls), C.byref(out))
+        return out.as_tuple() if r else None
+
+    def proc_exec(self, pid): self._l.or_h2_proc_exec(self._h, pid)
+    def proc_exit(self, pid): self._l.or_h2_proc_exit(self._h, pid)
+    def conn_closed(self, pid, fd): self._l.or_h2_conn_closed(self._h, pid, fd)
+    def sweep(self): self._l.or_h2_sweep(self._h)
+    def pending(self): return self._l.or_h2_pending(self._h)
+    def parsers(self): return self._l.or_h2_parsers(self._h)
+    def dropped_not_live(self): return self._l.or_h2_dropped_not_live(self._h)
+    def dropped_unparsed(self): return self._l.or_h2_dropped_unparsed(self._h)
 
 
 class Oracle:
@@ -219,6 +324,8 @@ class Oracle:
         return SockLine(_borrowed=p) if p else None
 
     def sockline_count(self) -> int: return self._l.or_sockline_count(self._o)
+
+    def h2(self) -> H2Assembler: return H2Assembler(_borrowed=self._l.or_h2_of(self._o))
 
     def sweep(self, now_ms: int, send_alive: bool = True) -> int:
         return self._l.or_sweep_socket_lines(self._o, now_ms, int(send_alive))

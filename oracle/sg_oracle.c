@@ -98,6 +98,7 @@ struct oracle {
     /* f-2: clusterInfo.SocketMaps (pid -> fd -> SocketLine), flattened to "pid:fd" -> index */
     strmap sock_index; or_sockline** socklines; size_t n_socklines, cap_socklines;
     or_alive* alive_log; size_t alive_n, alive_cap; size_t alive_persisted;
+    or_h2* h2;                /* f-4: HTTP/2 request assembly (http2.c) */
 
     /* open window */
     strmap edge_index;       /* "ft\x1fuid\x1ftt\x1fuid" -> index into wedges */
@@ -118,8 +119,10 @@ oracle_t* or_create(void) {
     sm_init(&o->pod_ip_to_uid); sm_init(&o->svc_ip_to_uid); sm_init(&o->uid_to_id);
     sm_init(&o->label_to_id); sm_init(&o->pg_stmts); sm_init(&o->mysql_stmts); sm_init(&o->edge_index); sm_init(&o->sock_index);
     o->tmin = INT64_MAX; o->tmax = INT64_MIN;
+    o->h2 = or_h2_create();
     return o;
 }
+or_h2* or_h2_of(oracle_t* o) { return o->h2; }
 
 static void free_closed(oracle_t* o) {
     free(o->edges); o->edges = NULL; o->n_edges = 0;
@@ -140,6 +143,7 @@ void or_destroy(oracle_t* o) {
     sm_free(&o->sock_index);
     for (size_t i = 0; i < o->n_socklines; i++) or_sl_destroy(o->socklines[i]);
     free(o->socklines); free(o->alive_log);
+    or_h2_destroy(o->h2);
     free_closed(o);
     free(o);
 }
@@ -609,7 +613,8 @@ int or_process_tcp(oracle_t* o, uint32_t type, uint32_t pid, uint64_t fd, uint64
         return 1;
     }
     if (!sl) return 0;                               /* CLOSED without a line: dropped (:472-477) */
-    or_sl_add(sl, ts, NULL);                         /* :480-483; h2 parser / pgStmts clean-up (:485-503) is off this path */
+    or_sl_add(sl, ts, NULL);                         /* :480-483 */
+    or_h2_conn_closed(o->h2, pid, fd);               /* :485-494 (pgStmts clean-up :496-503 is keyed the same way; not restated) */
     return 1;
 }
 
@@ -689,7 +694,13 @@ static size_t process_one(oracle_t* o, const l7ev* d, uint32_t kafka_msgs) {
         }
         return done;
     }
-    default:   /* HTTP2 goes to the frame-assembly queue (:1019-1033), out of scope; UNKNOWN ignored */
+    case SG_PROTO_HTTP2: {                                       /* processHttp2Event :1019-1033 -> processHttp2Frames :544-810 */
+        or_h2_out r;
+        if (!or_h2_event(o->h2, d->pid, d->fd, d->method, d->payload, d->payload_size, d->write_time_ns, d->tls, &r)) return 0;
+        return (size_t)resolve_and_persist(o, d->saddr, d->sport, d->daddr, d->dport, d->protocol, r.protocol, r.method, d->tls,
+                                           r.status_code, r.latency, d->write_time_ns, r.authority, r.path, 0, 0);
+    }
+    default:   /* UNKNOWN ignored */
         return 0;
     }
 }

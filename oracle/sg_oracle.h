@@ -163,6 +163,44 @@ size_t or_sweep_socket_lines(oracle_t* o, int64_t now_ms, int send_alive);
 size_t or_alive_count(const oracle_t* o);                 /* persisted since create */
 const or_alive* or_alive_at(const oracle_t* o, size_t i); /* kept up to the log limit */
 
+/* ---- f-4 (first half): HTTP/2 request assembly — oracle/http2.c ---------------------------------- *
+ * HPACK decoder with the semantics of golang.org/x/net v0.20.0 http2/hpack (see http2.c header).   */
+typedef struct or_hpack or_hpack;
+typedef void (*or_hpack_emit_fn)(void* ctx, const uint8_t* name, size_t nlen, const uint8_t* value, size_t vlen);
+or_hpack* or_hpack_create(uint32_t max_table_size);
+void      or_hpack_destroy(or_hpack* d);
+void      or_hpack_set_emit(or_hpack* d, or_hpack_emit_fn fn, void* ctx);
+int       or_hpack_write(or_hpack* d, const uint8_t* p, size_t n);     /* 0, or -1 on a decoding error */
+size_t    or_hpack_dyn_len(const or_hpack* d);
+uint32_t  or_hpack_dyn_size(const or_hpack* d);
+int       or_hpack_dyn_at(const or_hpack* d, size_t i, const uint8_t** name, size_t* nlen, const uint8_t** value, size_t* vlen);
+int       or_hpack_selfcheck(void);
+uint32_t  or_hpack_huff_code(int sym, uint8_t* len_out);
+long      or_hpack_huff_decode(const uint8_t* v, size_t n, uint8_t* out);   /* out: 2n bytes; -1 = invalid */
+uint32_t  or_go_atoi_u32(const uint8_t* v, size_t n);
+
+/* what persistReq (data.go:576-616) hands to the join: strings are copies truncated to the caps */
+typedef struct or_h2_out {
+    char method[64]; char path[OR_HTTP_PATH_CAP]; char authority[OR_UID_MAX];
+    char protocol[8];              /* "HTTP2" | "HTTPS" | "gRPC" */
+    uint32_t status_code; uint64_t latency;
+} or_h2_out;
+typedef struct or_h2 or_h2;
+or_h2* or_h2_create(void);
+void   or_h2_destroy(or_h2* h);
+int    or_h2_event(or_h2* h, uint32_t pid, uint64_t fd, int method_id, const uint8_t* payload, uint32_t size,
+                   uint64_t write_ns, int tls, or_h2_out* out);
+void   or_h2_proc_exec(or_h2* h, uint32_t pid);
+void   or_h2_proc_exit(or_h2* h, uint32_t pid);
+void   or_h2_conn_closed(or_h2* h, uint32_t pid, uint64_t fd);
+void   or_h2_sweep(or_h2* h);
+size_t or_h2_pending(const or_h2* h);
+size_t or_h2_parsers(const or_h2* h);
+uint64_t or_h2_dropped_not_live(const or_h2* h);
+uint64_t or_h2_dropped_unparsed(const or_h2* h);
+/* the oracle's own assembler (HTTP2 records of or_process_l7_wire go through it) */
+or_h2* or_h2_of(oracle_t* o);
+
 /* method[OR_HTTP_TOK_CAP], path[OR_HTTP_PATH_CAP], version[OR_HTTP_TOK_CAP], host[OR_UID_MAX] */
 void   or_parse_http_payload(const char* req, size_t len, char* method, char* path, char* version,
                              char* host);                             /* data.go:508-531  */
