@@ -47,7 +47,7 @@ def build_host(force: bool = False) -> str | None:
     if srcs and (force or _stale(HOST_LIB, deps)):
         os.makedirs(os.path.dirname(HOST_LIB), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-pthread",
-                               "-I", os.path.join(ROOT, "include"), "-o", HOST_LIB] + srcs + ["-ldl"])
+                               "-I", os.path.join(ROOT, "include"), "-o", HOST_LIB] + srcs + ["-ldl", "-lz"])
     return HOST_LIB if srcs else None
 
 

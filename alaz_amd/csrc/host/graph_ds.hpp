@@ -87,6 +87,7 @@ public:
     void ProcExec(uint32_t pid) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ProcExec(pid); }
     void ProcExit(uint32_t pid) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ProcExit(pid); }
     void ConnClosed(uint32_t pid, uint64_t fd) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ConnClosed(pid, fd); }
+    void SetKafkaDecode(bool on) { std::lock_guard<std::mutex> g(mu_); packer_.SetKafkaDecode(on); }
     void SweepHttp2() { std::lock_guard<std::mutex> g(mu_); packer_.Http2().Sweep(); }
 
     // close the window: pending batch -> engine, K2..K5, rows -> sink.  Returns the number of edges or < 0.

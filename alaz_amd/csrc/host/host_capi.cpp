@@ -235,6 +235,36 @@ void sgh_h2_conn_closed(void* a, uint32_t pid, uint64_t fd) { static_cast<Http2A
 void sgh_h2_sweep(void* a) { static_cast<Http2Assembler*>(a)->Sweep(); }
 size_t sgh_h2_pending(void* a) { return static_cast<Http2Assembler*>(a)->Pending(); }
 size_t sgh_h2_parsers(void* a) { return static_cast<Http2Assembler*>(a)->Parsers(); }
+// ---- Kafka payload decode (kafka.hpp) ----
+void sgh_packer_kafka_decode(void* p, int on) { static_cast<L7Packer*>(p)->SetKafkaDecode(on != 0); }
+void sgh_graphds_kafka_decode(void* g, int on) { static_cast<HostCtx*>(g)->ds->SetKafkaDecode(on != 0); }
+// decodes one payload; messages are serialised into buf as [u32 topic_n][i32 partition][u32 key_n][u32 value_n] topic key value ...
+// returns the message count (also when buf is too small: then nothing is written), *status = kafka::Status
+long sgh_kafka_decode(const uint8_t* payload, size_t size, int method_id, int api_version, int* status, uint8_t* buf, size_t cap) {
+    std::vector<kafka::Message> msgs;
+    const kafka::Status st = kafka::DecodePayload(payload, size, method_id, (int16_t)api_version, &msgs);
+    if (status) *status = (int)st;
+    size_t need = 0;
+    for (const auto& m : msgs) need += 16 + m.Topic.size() + m.Key.size() + m.Value.size();
+    if (need <= cap) {
+        uint8_t* w = buf;
+        for (const auto& m : msgs) {
+            const uint32_t h[4] = {(uint32_t)m.Topic.size(), (uint32_t)m.Partition, (uint32_t)m.Key.size(), (uint32_t)m.Value.size()};
+            std::memcpy(w, h, 16); w += 16;
+            std::memcpy(w, m.Topic.data(), m.Topic.size()); w += m.Topic.size();
+            std::memcpy(w, m.Key.data(), m.Key.size()); w += m.Key.size();
+            std::memcpy(w, m.Value.data(), m.Value.size()); w += m.Value.size();
+        }
+    }
+    return (long)msgs.size();
+}
+long sgh_kafka_decompress(int codec, const uint8_t* src, size_t n, uint8_t* out, size_t cap) {
+    std::string s; if (!kafka::Decompress(codec, src, n, &s)) return -1;
+    if (s.size() > cap) return -2;
+    std::memcpy(out, s.data(), s.size()); return (long)s.size();
+}
+uint32_t sgh_crc32(int castagnoli, const uint8_t* p, size_t n) { return kafka::Crc32(p, n, castagnoli != 0); }
+uint32_t sgh_xxh32(const uint8_t* p, size_t n, uint32_t seed) { return kafka::XXH32(p, n, seed); }
 // the stand-alone packer's assembler
 void sgh_packer_proc_exec(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Http2().ProcExec(pid); }
 void sgh_packer_proc_exit(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Http2().ProcExit(pid); }

@@ -1,0 +1,520 @@
+// kafka.cpp — see kafka.hpp.
+#include "kafka.hpp"
+
+#include <dlfcn.h>
+#include <zlib.h>
+
+#include <array>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace alaz {
+namespace kafka {
+namespace {
+
+// ----------------------------------------------------------------------------------------------- checksums
+struct CrcTables {
+    std::array<uint32_t, 256> ieee, castagnoli;
+    CrcTables() {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t a = i, b = i;
+            for (int k = 0; k < 8; k++) { a = (a >> 1) ^ (0xEDB88320u & (0u - (a & 1))); b = (b >> 1) ^ (0x82F63B78u & (0u - (b & 1))); }
+            ieee[i] = a; castagnoli[i] = b;
+        }
+    }
+};
+const CrcTables& Tables() { static const CrcTables t; return t; }
+
+inline uint32_t Le32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }      // host is little endian (x86-64)
+inline uint32_t Be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+inline uint32_t Rol(uint32_t x, unsigned r) { return (x << r) | (x >> (32 - r)); }
+
+// ----------------------------------------------------------------------------------------------- decompressors
+constexpr size_t kMaxInflated = size_t(1) << 30;      // bound against hostile length fields
+
+bool Gunzip(const uint8_t* src, size_t n, std::string* out) {
+    z_stream z{};
+    if (inflateInit2(&z, 16 + MAX_WBITS) != Z_OK) return false;
+    z.next_in = const_cast<Bytef*>(src); z.avail_in = (uInt)n;
+    bool ok = true; int members = 0; uint8_t chunk[16384];
+    while (ok) {
+        z.next_out = chunk; z.avail_out = sizeof chunk;
+        const int r = inflate(&z, Z_NO_FLUSH);
+        out->append((const char*)chunk, sizeof chunk - z.avail_out);
+        if (out->size() > kMaxInflated) ok = false;
+        else if (r == Z_STREAM_END) { members++; if (z.avail_in == 0) break; ok = inflateReset(&z) == Z_OK; }
+        else if (r != Z_OK) ok = false;
+        else if (z.avail_in == 0 && z.avail_out != 0) ok = false;     // member cut short
+    }
+    inflateEnd(&z);
+    return ok && members > 0;
+}
+
+// one raw snappy block appended to *out
+bool SnappyBlock(const uint8_t* p, const uint8_t* end, std::string* out) {
+    uint64_t want = 0;
+    for (unsigned shift = 0;; shift += 7) {
+        if (p == end || shift > 63) return false;
+        const uint8_t b = *p++;
+        want |= uint64_t(b & 0x7F) << shift;
+        if (b < 0x80) break;
+    }
+    if (want > 0xFFFFFFFFull) return false;
+    const size_t start = out->size();
+    out->reserve(start + (size_t)want);
+    auto produced = [&] { return out->size() - start; };
+    while (p < end) {
+        const unsigned tag = *p++, kind = tag & 3;
+        size_t len, dist = 0;
+        if (kind == 0) {
+            len = tag >> 2;
+            if (len >= 60) {
+                const size_t nb = len - 59;
+                if ((size_t)(end - p) < nb) return false;
+                len = 0; for (size_t k = 0; k < nb; k++) len |= size_t(p[k]) << (8 * k);
+                p += nb;
+            }
+            len += 1;
+            if (len > (size_t)(end - p) || len > want - produced()) return false;
+            out->append((const char*)p, len); p += len;
+            continue;
+        }
+        if (kind == 1) { if (end - p < 1) return false; len = 4 + ((tag >> 2) & 7); dist = size_t(tag >> 5) << 8 | p[0]; p += 1; }
+        else if (kind == 2) { if (end - p < 2) return false; len = (tag >> 2) + 1; dist = size_t(p[0]) | size_t(p[1]) << 8; p += 2; }
+        else { if (end - p < 4) return false; len = (tag >> 2) + 1; dist = Le32(p); p += 4; }
+        if (dist == 0 || dist > produced() || len > want - produced()) return false;
+        for (size_t k = 0; k < len; k++) out->push_back((*out)[out->size() - dist]);
+    }
+    return produced() == want;
+}
+
+// xerial framing ("\x82SNAPPY\0" + 8 bytes of versions + [len32 block]*) or a bare block
+bool Unsnappy(const uint8_t* src, size_t n, std::string* out, bool* nil_slice) {
+    static const uint8_t kMagic[8] = {0x82, 'S', 'N', 'A', 'P', 'P', 'Y', 0};
+    if (n < 8) return false;
+    if (std::memcmp(src, kMagic, 8) != 0) {
+        if (!SnappyBlock(src, src + n, out)) return false;
+        if (nil_slice) *nil_slice = out->empty();        // snappy.Decode(nil, <empty block>) hands back nil
+        return true;
+    }
+    if (n < 20) return false;
+    for (size_t at = 16; at + 4 <= n;) {
+        const size_t len = Be32(src + at); at += 4;
+        if (len > n - at) return false;
+        if (!SnappyBlock(src + at, src + at + len, out)) return false;
+        at += len;
+    }
+    return true;
+}
+
+bool Lz4Block(const uint8_t* p, const uint8_t* end, std::string* out, size_t history_start) {
+    auto extend = [&](size_t* v) { for (;;) { if (p == end) return false; const uint8_t b = *p++; *v += b; if (b != 255) return true; } };
+    while (p < end) {
+        const unsigned token = *p++;
+        size_t lit = token >> 4;
+        if (lit == 15 && !extend(&lit)) return false;
+        if (lit > (size_t)(end - p)) return false;
+        out->append((const char*)p, lit); p += lit;
+        if (p == end) return true;                           // a block ends with literals
+        if (end - p < 2) return false;
+        const size_t dist = size_t(p[0]) | size_t(p[1]) << 8; p += 2;
+        size_t len = token & 15;
+        if (len == 15 && !extend(&len)) return false;
+        len += 4;
+        if (dist == 0 || dist > out->size() - history_start) return false;
+        if (out->size() + len > kMaxInflated) return false;
+        for (size_t k = 0; k < len; k++) out->push_back((*out)[out->size() - dist]);
+    }
+    return true;
+}
+
+bool Unlz4(const uint8_t* src, size_t n, std::string* out) {
+    const uint8_t* p = src; const uint8_t* const end = src + n;
+    auto left = [&] { return (size_t)(end - p); };
+    while (p < end) {
+        if (left() < 4) return false;
+        const uint32_t magic = Le32(p); p += 4;
+        if ((magic >> 4) == (0x184D2A50u >> 4)) {              // skippable frame
+            if (left() < 4) return false;
+            const uint32_t skip = Le32(p); p += 4;
+            if (skip > left()) return false;
+            p += skip; continue;
+        }
+        if (magic != 0x184D2204u || left() < 3) return false;
+        const uint8_t* const descriptor = p;
+        const uint8_t flg = p[0], bd = p[1]; p += 2;
+        if ((flg & 0xC0) != 0x40) return false;
+        const bool independent = flg & 0x20, block_checksum = flg & 0x10, sized = flg & 0x08, content_checksum = flg & 0x04, dict = flg & 0x01;
+        const unsigned size_code = (bd >> 4) & 7;
+        if (size_code < 4) return false;
+        const size_t block_max = size_t(1) << (8 + 2 * size_code);
+        uint64_t declared = 0;
+        if (sized) { if (left() < 8) return false; declared = uint64_t(Le32(p)) | uint64_t(Le32(p + 4)) << 32; p += 8; }
+        if (dict) { if (left() < 4) return false; p += 4; }
+        if (left() < 1 || *p != uint8_t(XXH32(descriptor, (size_t)(p - descriptor), 0) >> 8)) return false;
+        p++;
+        const size_t frame_start = out->size();
+        for (;;) {
+            if (left() < 4) return false;
+            uint32_t sz = Le32(p); p += 4;
+            if (sz == 0) break;
+            const bool stored = sz >> 31; sz &= 0x7FFFFFFFu;
+            if (sz > block_max || sz > left()) return false;
+            const size_t before = out->size();
+            if (stored) out->append((const char*)p, sz);
+            else if (!Lz4Block(p, p + sz, out, independent ? before : frame_start) || out->size() - before > block_max) return false;
+            if (block_checksum) { if (left() < sz + 4 || Le32(p + sz) != XXH32(p, sz, 0)) return false; p += 4; }
+            p += sz;
+        }
+        if (content_checksum) {
+            if (left() < 4 || Le32(p) != XXH32((const uint8_t*)out->data() + frame_start, out->size() - frame_start, 0)) return false;
+            p += 4;
+        }
+        if (sized && declared != out->size() - frame_start) return false;
+    }
+    return true;
+}
+
+// zstd: the system library's streaming interface (stable since libzstd 1.3), loaded on first use
+struct ZIn { const void* src; size_t size, pos; };
+struct ZOut { void* dst; size_t size, pos; };
+struct ZstdApi {
+    void* (*create)() = nullptr; size_t (*destroy)(void*) = nullptr; size_t (*run)(void*, ZOut*, ZIn*) = nullptr; unsigned (*is_error)(size_t) = nullptr;
+    ZstdApi() {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW);
+        if (!h) return;
+        create = (void* (*)())dlsym(h, "ZSTD_createDStream"); destroy = (size_t (*)(void*))dlsym(h, "ZSTD_freeDStream");
+        run = (size_t (*)(void*, ZOut*, ZIn*))dlsym(h, "ZSTD_decompressStream"); is_error = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+    }
+    bool ok() const { return create && destroy && run && is_error; }
+};
+bool Unzstd(const uint8_t* src, size_t n, std::string* out) {
+    static const ZstdApi api;
+    if (!api.ok()) return false;
+    void* ds = api.create();
+    if (!ds) return false;
+    ZIn in{src, n, 0}; bool ok = true; size_t hint = 0; char chunk[65536];
+    while (ok && in.pos < in.size) {
+        ZOut o{chunk, sizeof chunk, 0};
+        hint = api.run(ds, &o, &in);
+        out->append(chunk, o.pos);
+        ok = !api.is_error(hint) && out->size() <= kMaxInflated;
+    }
+    api.destroy(ds);
+    return ok && hint == 0;
+}
+
+// ----------------------------------------------------------------------------------------------- realDecoder
+class Reader {
+public:
+    Reader(const uint8_t* p, size_t n) : p_(p), n_((long)n) {}
+    long Remaining() const { return n_ - at_; }
+    long Offset() const { return at_; }
+    const uint8_t* Base() const { return p_; }
+    int PeekI8(long ahead) const { return Remaining() < ahead + 1 ? -1000 : (int)(int8_t)p_[at_ + ahead]; }
+
+    Status I8(int8_t* v) { if (!Have(1)) return Short(); *v = (int8_t)p_[at_]; at_ += 1; return Status::kOk; }
+    Status I16(int16_t* v) { if (!Have(2)) return Short(); *v = (int16_t)(uint16_t(p_[at_]) << 8 | p_[at_ + 1]); at_ += 2; return Status::kOk; }
+    Status I32(int32_t* v) { if (!Have(4)) return Short(); *v = (int32_t)Be32(p_ + at_); at_ += 4; return Status::kOk; }
+    Status I64(int64_t* v) { if (!Have(8)) return Short(); *v = (int64_t)(uint64_t(Be32(p_ + at_)) << 32 | Be32(p_ + at_ + 4)); at_ += 8; return Status::kOk; }
+    Status Skip(long n) { if (!Have(n)) return Short(); at_ += n; return Status::kOk; }
+    // encoding/binary.Uvarint: at most 10 bytes, the 10th at most 1
+    Status UVarint(uint64_t* v) {
+        uint64_t acc = 0;
+        for (long i = 0; at_ + i < n_; i++) {
+            const uint8_t b = p_[at_ + i];
+            if (i == 10 || (i == 9 && b > 1 && b < 0x80)) { at_ += i + 1; return Status::kError; }
+            if (b < 0x80) { *v = acc | uint64_t(b) << (7 * i); at_ += i + 1; return Status::kOk; }
+            acc |= uint64_t(b & 0x7F) << (7 * i);
+        }
+        return Short();
+    }
+    Status Varint(int64_t* v) { uint64_t u; const Status s = UVarint(&u); if (s == Status::kOk) *v = (int64_t)(u >> 1) ^ -(int64_t)(u & 1); return s; }
+    // getArrayLength: a count larger than what is left is "insufficient", larger than 2*65535 an error; negative passes
+    Status ArrayLen(long* n) {
+        int32_t v; if (!Have(4)) return Short(); I32(&v);
+        if (v > Remaining()) return Short();
+        if (v > 2 * 65535) return Status::kError;
+        *n = v; return Status::kOk;
+    }
+    Status Raw(long n, const uint8_t** out) {
+        if (n < 0) return Status::kError;
+        if (!Have(n)) return Short();
+        *out = p_ + at_; at_ += n; return Status::kOk;
+    }
+    Status String(std::string* s) {          // getString / getNullableString: -1 reads as empty
+        int16_t n; const Status st = I16(&n); if (st != Status::kOk) return st;
+        if (n < -1) return Status::kError;
+        if (n > Remaining()) return Short();
+        s->clear(); if (n > 0) { s->assign((const char*)p_ + at_, (size_t)n); at_ += n; }
+        return Status::kOk;
+    }
+    Status Bytes32(const uint8_t** out, long* n, bool* is_nil) {
+        int32_t len; const Status st = I32(&len); if (st != Status::kOk) return st;
+        *is_nil = len == -1; *n = 0; *out = nullptr;
+        if (len == -1) return Status::kOk;
+        *n = len; return Raw(len, out);
+    }
+    Status VarintBytes(std::string* s) {
+        int64_t len; const Status st = Varint(&len); if (st != Status::kOk) return st;
+        s->clear();
+        if (len == -1) return Status::kOk;
+        if (len < 0) return Status::kError;
+        if (len > Remaining()) return Short();
+        s->assign((const char*)p_ + at_, (size_t)len); at_ += (long)len; return Status::kOk;
+    }
+
+private:
+    bool Have(long n) const { return n_ - at_ >= n; }
+    Status Short() { at_ = n_; return Status::kInsufficientData; }
+    const uint8_t* p_; long n_; long at_ = 0;
+};
+
+#define KTRY(expr) do { const Status st_ = (expr); if (st_ != Status::kOk) return st_; } while (0)
+
+int ZigZagLen(int64_t v) { uint64_t u = (uint64_t(v) << 1) ^ uint64_t(v >> 63); int n = 1; while (u > 0x7F) { u >>= 7; n++; } return n; }
+
+struct PartitionRecords {
+    std::vector<std::pair<std::string, std::string>> recs;
+    bool legacy = false;           // a MessageSet sits where the reference expects a RecordBatch
+    bool nil_entries = false;      // Records holds nil *Record entries (decode of a nil buffer)
+};
+using TopicMap = std::map<std::string, std::map<int32_t, PartitionRecords>>;
+
+struct RecordsInfo { size_t count = 0; bool partial = false, overflow = false, legacy = false, nil_entries = false; };
+
+// record.go:41-87
+Status DecodeRecord(Reader* r, std::vector<std::pair<std::string, std::string>>* out) {
+    const long start = r->Offset();
+    int64_t length, ts, off, headers; int8_t attr; std::string key, value, scratch;
+    KTRY(r->Varint(&length)); KTRY(r->I8(&attr)); KTRY(r->Varint(&ts)); KTRY(r->Varint(&off));
+    KTRY(r->VarintBytes(&key)); KTRY(r->VarintBytes(&value)); KTRY(r->Varint(&headers));
+    if (headers > (int64_t(1) << 45)) return Status::kPanic;          // make([]*RecordHeader, n) refuses
+    for (int64_t i = 0; i < headers; i++) { KTRY(r->VarintBytes(&scratch)); KTRY(r->VarintBytes(&scratch)); }
+    if (r->Offset() - start - ZigZagLen(length) != length) return Status::kError;
+    out->emplace_back(std::move(key), std::move(value));
+    return Status::kOk;
+}
+
+// record_batch.go:51-139
+Status DecodeRecordBatch(Reader* r, std::vector<std::pair<std::string, std::string>>* out, RecordsInfo* info) {
+    int64_t i64; int32_t batch_len, i32; int16_t attributes, i16; int8_t magic;
+    KTRY(r->I64(&i64)); KTRY(r->I32(&batch_len)); KTRY(r->I32(&i32)); KTRY(r->I8(&magic));
+    const long crc_at = r->Offset();
+    KTRY(r->Skip(4));
+    KTRY(r->I16(&attributes)); KTRY(r->I32(&i32)); KTRY(r->I64(&i64)); KTRY(r->I64(&i64)); KTRY(r->I64(&i64)); KTRY(r->I16(&i16)); KTRY(r->I32(&i32));
+    long declared; KTRY(r->ArrayLen(&declared));
+    const uint8_t* body; const long body_len = (long)batch_len - 49;
+    const Status got = r->Raw(body_len, &body);
+    if (got == Status::kInsufficientData) { info->partial = true; return Status::kOk; }
+    if (got != Status::kOk) return got;
+    if (Crc32(r->Base() + crc_at + 4, (size_t)(r->Offset() - crc_at - 4), true) != Be32(r->Base() + crc_at)) return Status::kError;
+    std::string plain; bool nil_slice = false;
+    if (!Decompress((int8_t)attributes & 7, body, (size_t)body_len, &plain, &nil_slice)) return Status::kError;
+    if (nil_slice) { if (declared > 0) { info->nil_entries = true; info->count = (size_t)declared; } return Status::kOk; }
+    Reader inner((const uint8_t*)plain.data(), plain.size());
+    std::vector<std::pair<std::string, std::string>> recs;
+    Status st = Status::kOk;
+    for (long i = 0; i < declared && st == Status::kOk; i++) st = DecodeRecord(&inner, &recs);
+    if (st == Status::kOk && inner.Remaining() != 0) st = Status::kError;
+    if (st == Status::kInsufficientData) { info->partial = true; return Status::kOk; }
+    if (st != Status::kOk) return st;
+    info->count = recs.size();
+    for (auto& kv : recs) out->push_back(std::move(kv));
+    return Status::kOk;
+}
+
+Status DecodeMessageSet(Reader* r, RecordsInfo* info, int depth);
+
+// message_set.go:14-41 + message.go:64-140
+Status DecodeMessageBlock(Reader* r, int64_t* offset, int depth) {
+    KTRY(r->I64(offset));
+    const long length_at = r->Offset();
+    int32_t length; KTRY(r->I32(&length));
+    if (length > (int32_t)r->Remaining()) return Status::kInsufficientData;
+    const long crc_at = r->Offset();
+    KTRY(r->Skip(4));
+    int8_t magic, attributes; int64_t ts;
+    KTRY(r->I8(&magic));
+    if (magic > 1) return Status::kError;
+    KTRY(r->I8(&attributes));
+    if (magic == 1) KTRY(r->I64(&ts));
+    const uint8_t *key, *value; long key_n, value_n; bool key_nil, value_nil;
+    KTRY(r->Bytes32(&key, &key_n, &key_nil)); KTRY(r->Bytes32(&value, &value_n, &value_nil));
+    if (!value_nil && (attributes & 7) != 0) {
+        std::string plain;
+        if (depth > 8 || !Decompress(attributes & 7, value, (size_t)value_n, &plain)) return Status::kError;
+        Reader inner((const uint8_t*)plain.data(), plain.size()); RecordsInfo nested;
+        KTRY(DecodeMessageSet(&inner, &nested, depth + 1));
+    }
+    if (Crc32(r->Base() + crc_at + 4, (size_t)(r->Offset() - crc_at - 4), false) != Be32(r->Base() + crc_at)) return Status::kError;
+    if ((int32_t)(r->Offset() - length_at - 4) != length) return Status::kError;
+    return Status::kOk;
+}
+
+// message_set.go:49-86
+Status DecodeMessageSet(Reader* r, RecordsInfo* info, int depth) {
+    while (r->Remaining() > 0) {
+        const int magic = r->PeekI8(16);
+        if (magic == -1000) { info->partial = true; return Status::kOk; }
+        if (magic > 1) return Status::kOk;
+        int64_t offset = 0;
+        const Status st = DecodeMessageBlock(r, &offset, depth);
+        if (st == Status::kOk) { info->count++; continue; }
+        if (st != Status::kInsufficientData) return st;
+        if (offset == -1) info->overflow = true; else info->partial = true;
+        return Status::kOk;
+    }
+    return Status::kOk;
+}
+
+// records.go:46-71
+Status DecodeRecords(Reader* r, std::vector<std::pair<std::string, std::string>>* out, RecordsInfo* info) {
+    const int magic = r->PeekI8(16);
+    if (magic == -1000) return Status::kInsufficientData;
+    if (magic < 2) { info->legacy = true; return DecodeMessageSet(r, info, 0); }
+    return DecodeRecordBatch(r, out, info);
+}
+
+Status DecodeProduce(const uint8_t* payload, size_t size, TopicMap* topics) {
+    if (size < 4) return Status::kError;
+    const int32_t length = (int32_t)Be32(payload);
+    if (length <= 4 || length > 100 * 1024 * 1024 || (size_t)length > size - 4) return Status::kError;
+    Reader r(payload + 4, (size_t)length);
+    int16_t api_key, version, acks; int32_t correlation, timeout; std::string client_id, txn_id, topic;
+    KTRY(r.I16(&api_key)); KTRY(r.I16(&version)); KTRY(r.I32(&correlation)); KTRY(r.String(&client_id));
+    if (api_key != 0) return Status::kError;
+    if (version >= 3) KTRY(r.String(&txn_id));
+    KTRY(r.I16(&acks)); KTRY(r.I32(&timeout));
+    long n_topics; KTRY(r.ArrayLen(&n_topics));
+    for (long i = 0; i < n_topics; i++) {
+        KTRY(r.String(&topic));
+        long n_parts; KTRY(r.ArrayLen(&n_parts));
+        auto& parts = (*topics)[topic]; parts.clear();
+        for (long j = 0; j < n_parts; j++) {
+            int32_t id, bytes; const uint8_t* sub;
+            KTRY(r.I32(&id)); KTRY(r.I32(&bytes)); KTRY(r.Raw(bytes, &sub));
+            Reader rr(sub, (size_t)bytes); PartitionRecords pr; RecordsInfo info;
+            KTRY(DecodeRecords(&rr, &pr.recs, &info));
+            pr.legacy = info.legacy; pr.nil_entries = info.nil_entries;
+            parts[id] = std::move(pr);
+        }
+    }
+    return r.Remaining() == 0 ? Status::kOk : Status::kError;
+}
+
+Status DecodeFetch(const uint8_t* payload, size_t size, int16_t version, TopicMap* topics) {
+    Reader h(payload, size);
+    int32_t length, correlation;
+    KTRY(h.I32(&length));
+    if (length <= 4 || length > 100 * 1024 * 1024) return Status::kError;
+    const Status corr = h.I32(&correlation);
+    if (version >= 12) {                                            // response header v1: tagged fields
+        uint64_t tags, x; const uint8_t* skip;
+        KTRY(h.UVarint(&tags));
+        for (uint64_t i = 0; i < tags; i++) { KTRY(h.UVarint(&x)); KTRY(h.UVarint(&x)); if (x > 0x7FFFFFFFull) return Status::kError; KTRY(h.Raw((long)x, &skip)); }
+    }
+    if (corr != Status::kOk) return corr;
+    Reader r(payload + h.Offset(), size - (size_t)h.Offset());
+    int32_t i32; int16_t i16; int64_t i64; std::string topic;
+    if (version >= 1) KTRY(r.I32(&i32));
+    if (version >= 7) { KTRY(r.I16(&i16)); KTRY(r.I32(&i32)); }
+    long n_topics; KTRY(r.ArrayLen(&n_topics));
+    for (long i = 0; i < n_topics; i++) {
+        KTRY(r.String(&topic));
+        long n_blocks; KTRY(r.ArrayLen(&n_blocks));
+        auto& parts = (*topics)[topic]; parts.clear();
+        for (long j = 0; j < n_blocks; j++) {
+            int32_t id; KTRY(r.I32(&id));
+            KTRY(r.I16(&i16)); KTRY(r.I64(&i64));
+            if (version >= 4) {
+                KTRY(r.I64(&i64));
+                if (version >= 5) KTRY(r.I64(&i64));
+                long aborted; KTRY(r.ArrayLen(&aborted));
+                for (long k = 0; k < aborted; k++) { KTRY(r.I64(&i64)); KTRY(r.I64(&i64)); }
+            }
+            if (version >= 11) KTRY(r.I32(&i32));
+            int32_t bytes; const uint8_t* sub;
+            KTRY(r.I32(&bytes)); KTRY(r.Raw(bytes, &sub));
+            Reader rr(sub, (size_t)bytes); PartitionRecords block; int sets = 0;
+            while (rr.Remaining() > 0) {
+                std::vector<std::pair<std::string, std::string>> recs; RecordsInfo info;
+                const Status st = DecodeRecords(&rr, &recs, &info);
+                if (st == Status::kInsufficientData) break;
+                if (st != Status::kOk) return st;
+                if (info.count > 0 || (info.partial && sets == 0)) {          // joins RecordsSet
+                    sets++;
+                    block.legacy |= info.legacy; block.nil_entries |= info.nil_entries;
+                    for (auto& kv : recs) block.recs.push_back(std::move(kv));
+                }
+                if (info.partial || info.overflow) break;
+            }
+            parts[id] = std::move(block);
+        }
+    }
+    return Status::kOk;
+}
+
+}  // namespace
+
+uint32_t Crc32(const uint8_t* p, size_t n, bool castagnoli) {
+    const auto& t = castagnoli ? Tables().castagnoli : Tables().ieee;
+    uint32_t c = ~0u;
+    while (n--) c = t[(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
+
+uint32_t XXH32(const uint8_t* p, size_t n, uint32_t seed) {
+    constexpr uint32_t A = 0x9E3779B1u, B = 0x85EBCA77u, C = 0xC2B2AE3Du, D = 0x27D4EB2Fu, E = 0x165667B1u;
+    const uint8_t* const end = p + n;
+    uint32_t h;
+    if (n >= 16) {
+        uint32_t lane[4] = {seed + A + B, seed + B, seed, seed - A};
+        for (; end - p >= 16; p += 16)
+            for (int k = 0; k < 4; k++) lane[k] = Rol(lane[k] + Le32(p + 4 * k) * B, 13) * A;
+        h = Rol(lane[0], 1) + Rol(lane[1], 7) + Rol(lane[2], 12) + Rol(lane[3], 18);
+    } else {
+        h = seed + E;
+    }
+    h += (uint32_t)n;
+    for (; end - p >= 4; p += 4) h = Rol(h + Le32(p) * C, 17) * D;
+    for (; p < end; p++) h = Rol(h + *p * E, 11) * A;
+    h ^= h >> 15; h *= B; h ^= h >> 13; h *= C; h ^= h >> 16;
+    return h;
+}
+
+bool Decompress(int codec, const uint8_t* src, size_t n, std::string* out, bool* nil_slice) {
+    if (nil_slice) *nil_slice = false;
+    switch (codec) {
+    case 0: out->append((const char*)src, n); return true;
+    case 1: return Gunzip(src, n, out);
+    case 2: return Unsnappy(src, n, out, nil_slice);
+    case 3: return Unlz4(src, n, out);
+    case 4: return Unzstd(src, n, out);
+    default: return false;
+    }
+}
+
+Status DecodePayload(const uint8_t* payload, size_t size, int method_id, int16_t api_version, std::vector<Message>* out) {
+    out->clear();
+    TopicMap topics; Status st;
+    if (method_id == 1) st = DecodeProduce(payload, size, &topics);
+    else if (method_id == 2) st = DecodeFetch(payload, size, api_version, &topics);
+    else return Status::kOk;
+    if (st != Status::kOk) return st;
+    for (const auto& t : topics)
+        for (const auto& p : t.second)
+            if (p.second.legacy || p.second.nil_entries) return Status::kPanic;   // nil RecordBatch / nil *Record dereferenced
+    for (auto& t : topics)
+        for (auto& p : t.second)
+            for (auto& kv : p.second.recs) {
+                Message m; m.Topic = t.first; m.Partition = p.first; m.Key = std::move(kv.first); m.Value = std::move(kv.second);
+                out->push_back(std::move(m));
+            }
+    return Status::kOk;
+}
+
+}  // namespace kafka
+}  // namespace alaz

@@ -204,6 +204,12 @@ size_t L7Packer::Pack(const l7_req::L7Event& e, uint32_t kafka_msgs, std::vector
         out->push_back(ev); return 1;
     case BPF_L7_PROTOCOL_KAFKA:
         if (e.MethodId == 2) ev.flags |= SG_EV_CONSUME;
+        if (kafka_decode_) {                                            // decodeKafkaPayload, data.go:929-1017
+            std::vector<kafka::Message> msgs;
+            if (kafka::DecodePayload(e.Payload, e.PayloadSize, e.MethodId, e.KafkaApiVersion, &msgs) != kafka::Status::kOk) msgs.clear();
+            if (msgs.empty()) { dropped_parse_++; return 0; }
+            kafka_msgs = (uint32_t)msgs.size();
+        }
         for (uint32_t k = 0; k < kafka_msgs; k++) out->push_back(ev);    // one KafkaEvent per decoded message
         return kafka_msgs;
     case BPF_L7_PROTOCOL_HTTP2: {

@@ -21,6 +21,7 @@
 
 #include "../../../include/servicegraph.h"
 #include "http2.hpp"
+#include "kafka.hpp"
 #include "l7_event.hpp"
 
 namespace alaz {
@@ -38,12 +39,14 @@ public:
     void RemoveKnownIP(uint32_t ip) { auto it = known_.find(ip); if (it != known_.end() && --it->second == 0) known_.erase(it); }
     bool IsKnownIP(uint32_t ip) const { return known_.count(ip) != 0; }
 
-    // Appends 0..n packed events for `e` to `out`.  kafka_msgs = number of messages the Kafka decoder
-    // produced for this event (ignored for other protocols).  Returns the number appended.
+    // Appends 0..n packed events for `e` to `out`.  kafka_msgs = number of messages a Kafka decoder on the
+    // caller's side produced for this event (ignored for other protocols, and ignored when SetKafkaDecode(true):
+    // then the payload is decoded here, kafka.hpp).  Returns the number appended.
     size_t Pack(const l7_req::L7Event& e, uint32_t kafka_msgs, std::vector<sg_event>* out);
 
     const std::vector<std::string>& Labels() const { return labels_; }
     uint64_t DroppedParse() const { return dropped_parse_; }
+    void SetKafkaDecode(bool on) { kafka_decode_ = on; }
     Http2Assembler& Http2() { return h2_; }
     const Http2Assembler& Http2() const { return h2_; }
 
@@ -58,6 +61,7 @@ private:
     std::vector<std::string> labels_;
     std::unordered_map<std::string, std::string> pg_stmts_, mysql_stmts_;   // data.go pgStmts / mySqlStmts
     Http2Assembler h2_;
+    bool kafka_decode_ = false;
     uint64_t dropped_parse_ = 0;
 };
 

@@ -75,6 +75,10 @@ def load() -> C.CDLL:
             "sgh_h2_proc_exec": (None, [P, u32]), "sgh_h2_proc_exit": (None, [P, u32]), "sgh_h2_conn_closed": (None, [P, u32, u64]),
             "sgh_h2_sweep": (None, [P]), "sgh_h2_pending": (sz, [P]), "sgh_h2_parsers": (sz, [P]),
             "sgh_packer_proc_exec": (None, [P, u32]), "sgh_packer_proc_exit": (None, [P, u32]), "sgh_packer_conn_closed": (None, [P, u32, u64]),
+            "sgh_packer_kafka_decode": (None, [P, C.c_int]), "sgh_graphds_kafka_decode": (None, [P, C.c_int]),
+            "sgh_kafka_decode": (C.c_long, [C.c_char_p, sz, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p, sz]),
+            "sgh_kafka_decompress": (C.c_long, [C.c_int, C.c_char_p, sz, C.c_char_p, sz]),
+            "sgh_crc32": (u32, [C.c_int, C.c_char_p, sz]), "sgh_xxh32": (u32, [C.c_char_p, sz, u32]),
             "sgh_mock_events": (sz, [P, P, sz]), "sgh_mock_table_ops": (sz, [P, P, sz]), "sgh_mock_label_count": (u32, [P]),
         }
         for name, (res, args) in sig.items():
@@ -204,6 +208,31 @@ class Http2Assembler:
     def parsers(self): return self._l.sgh_h2_parsers(self._a)
 
 
+KAFKA_STATUS = {0: "ok", 1: "insufficient", 2: "error", 3: "panic"}
+
+
+def kafka_decode(payload: bytes, method_id: int, api_version: int = 0):
+    """kafka::DecodePayload -> (status, [(topic, partition, key, value), ...])"""
+    import struct
+    st = C.c_int(); cap = 1 << 20; buf = C.create_string_buffer(cap)
+    n = load().sgh_kafka_decode(payload, len(payload), method_id, api_version, C.byref(st), buf, cap)
+    out = []; off = 0; raw = buf.raw
+    for _ in range(n):
+        tn, part, kn, vn = struct.unpack_from("<IiII", raw, off); off += 16
+        out.append((raw[off:off + tn], part, raw[off + tn:off + tn + kn], raw[off + tn + kn:off + tn + kn + vn])); off += tn + kn + vn
+    return KAFKA_STATUS[st.value], out
+
+
+def kafka_decompress(codec: int, data: bytes):
+    cap = 1 << 22; out = C.create_string_buffer(cap)
+    r = load().sgh_kafka_decompress(codec, data, len(data), out, cap)
+    return None if r < 0 else out.raw[:r]
+
+
+def crc32(data: bytes, castagnoli: bool = False) -> int: return load().sgh_crc32(int(castagnoli), data, len(data))
+def xxh32(data: bytes, seed: int = 0) -> int: return load().sgh_xxh32(data, len(data), seed)
+
+
 class Packer:
     def __init__(self):
         self._l = load(); self._p = self._l.sgh_packer_create()
@@ -223,7 +252,7 @@ class Packer:
             kafka_msgs = np.ascontiguousarray(kafka_msgs, dtype=np.uint32); km = kafka_msgs.ctypes.data
             cap = int(kafka_msgs.sum()) + n
         else:
-            cap = n
+            cap = n * 160 if getattr(self, "_kafka", False) else n      # a 1 KiB payload holds < 160 minimal records
         out = np.zeros(max(cap, 1), dtype=EVENT_DTYPE)
         buf = (C.c_char * len(wire)).from_buffer_copy(wire)
         k = self._l.sgh_packer_pack_wire(self._p, C.addressof(buf), n, km, out.ctypes.data, cap)
@@ -234,6 +263,7 @@ class Packer:
     @property
     def dropped_parse(self): return self._l.sgh_packer_dropped_parse(self._p)
 
+    def kafka_decode(self, on: bool = True): self._kafka = on; self._l.sgh_packer_kafka_decode(self._p, int(on))
     def proc_exec(self, pid): self._l.sgh_packer_proc_exec(self._p, pid)
     def proc_exit(self, pid): self._l.sgh_packer_proc_exit(self._p, pid)
     def conn_closed(self, pid, fd): self._l.sgh_packer_conn_closed(self._p, pid, fd)
@@ -306,6 +336,7 @@ class GraphDS:
 
     def sweep(self, now_ms: int, send_alive: bool = True) -> int: return self._l.sgh_graphds_sweep(self._g, now_ms, int(send_alive))
 
+    def kafka_decode(self, on: bool = True): self._l.sgh_graphds_kafka_decode(self._g, int(on))
     def proc_exec(self, pid: int): self._l.sgh_graphds_proc_exec(self._g, pid)
     def proc_exit(self, pid: int): self._l.sgh_graphds_proc_exit(self._g, pid)
     def sweep_http2(self): self._l.sgh_graphds_sweep_http2(self._g)

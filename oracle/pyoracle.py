@@ -16,7 +16,7 @@ L7_WIRE_SIZE = 1096
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("sg_oracle.c", "sockline.c", "http2.c", "sg_oracle.h")] + [os.path.join(_HERE, "..", "include", "servicegraph.h")]
+    src = [os.path.join(_HERE, f) for f in ("sg_oracle.c", "sockline.c", "http2.c", "kafka.c", "sg_oracle.h")] + [os.path.join(_HERE, "..", "include", "servicegraph.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
     return LIB_PATH
@@ -132,6 +132,14 @@ def _load():
         "or_h2_pending": (C.c_size_t, [P]), "or_h2_parsers": (C.c_size_t, [P]),
         "or_h2_dropped_not_live": (C.c_uint64, [P]), "or_h2_dropped_unparsed": (C.c_uint64, [P]),
         "or_h2_of": (P, [P]),
+        "or_set_kafka_decode": (None, [P, C.c_int]),
+        "or_kafka_decode": (P, [C.c_char_p, C.c_size_t, C.c_int, C.c_int16]), "or_kafka_result_free": (None, [P]),
+        "or_kafka_count": (C.c_size_t, [P]), "or_kafka_status": (C.c_int, [P]),
+        "or_kafka_msg": (C.c_int, [P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+        "or_kafka_decompress": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+        "or_kafka_free": (None, [P]),
+        "or_crc32": (C.c_uint32, [C.c_int, C.c_char_p, C.c_size_t]), "or_xxh32": (C.c_uint32, [C.c_char_p, C.c_size_t, C.c_uint32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name); f.restype = res; f.argtypes = args
@@ -268,6 +276,37 @@ class H2Assembler:
     def dropped_unparsed(self): return self._l.or_h2_dropped_unparsed(self._h)
 
 
+KAFKA_STATUS = {0: "ok", 1: "insufficient", 2: "error", 3: "panic"}
+
+
+def kafka_decode(payload: bytes, method_id: int, api_version: int = 0):
+    """decodeKafkaPayload as oracle/kafka.c restates it -> (status, [(topic, partition, key, value), ...])."""
+    l = lib(); r = l.or_kafka_decode(payload, len(payload), method_id, api_version)
+    try:
+        out = []
+        for i in range(l.or_kafka_count(r)):
+            t = C.c_void_p(); k = C.c_void_p(); v = C.c_void_p(); tn = C.c_size_t(); kn = C.c_size_t(); vn = C.c_size_t(); part = C.c_int32()
+            l.or_kafka_msg(r, i, C.byref(t), C.byref(tn), C.byref(part), C.byref(k), C.byref(kn), C.byref(v), C.byref(vn))
+            out.append((C.string_at(t, tn.value), part.value, C.string_at(k, kn.value), C.string_at(v, vn.value)))
+        return KAFKA_STATUS[l.or_kafka_status(r)], out
+    finally:
+        l.or_kafka_result_free(r)
+
+
+def kafka_decompress(codec: int, data: bytes):
+    l = lib(); out = C.c_void_p(); n = C.c_size_t()
+    if l.or_kafka_decompress(codec, data, len(data), C.byref(out), C.byref(n)) != 0:
+        return None
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        l.or_kafka_free(out)
+
+
+def crc32(data: bytes, castagnoli: bool = False) -> int: return lib().or_crc32(int(castagnoli), data, len(data))
+def xxh32(data: bytes, seed: int = 0) -> int: return lib().or_xxh32(data, len(data), seed)
+
+
 class Oracle:
     def __init__(self, first_kernel_ns: int = 0, first_user_ns: int = 0, log_limit: int = 0):
         self._l = lib()
@@ -324,6 +363,8 @@ class Oracle:
         return SockLine(_borrowed=p) if p else None
 
     def sockline_count(self) -> int: return self._l.or_sockline_count(self._o)
+
+    def set_kafka_decode(self, on: bool = True): self._l.or_set_kafka_decode(self._o, int(on))
 
     def h2(self) -> H2Assembler: return H2Assembler(_borrowed=self._l.or_h2_of(self._o))
 

@@ -99,6 +99,7 @@ struct oracle {
     strmap sock_index; or_sockline** socklines; size_t n_socklines, cap_socklines;
     or_alive* alive_log; size_t alive_n, alive_cap; size_t alive_persisted;
     or_h2* h2;                /* f-4: HTTP/2 request assembly (http2.c) */
+    int kafka_decode;         /* f-4: decode Kafka payloads (kafka.c) instead of taking the message count as a side input */
 
     /* open window */
     strmap edge_index;       /* "ft\x1fuid\x1ftt\x1fuid" -> index into wedges */
@@ -123,6 +124,7 @@ oracle_t* or_create(void) {
     return o;
 }
 or_h2* or_h2_of(oracle_t* o) { return o->h2; }
+void or_set_kafka_decode(oracle_t* o, int on) { o->kafka_decode = on; }
 
 static void free_closed(oracle_t* o) {
     free(o->edges); o->edges = NULL; o->n_edges = 0;
@@ -432,7 +434,7 @@ static const char* method_str(uint8_t proto, uint8_t m) {
 typedef struct {
     uint64_t fd, duration, write_time_ns; uint32_t pid, status, payload_size, prep_stmt_id;
     uint8_t protocol, method, tls; const uint8_t* payload;
-    uint32_t saddr, daddr; uint16_t sport, dport;
+    uint32_t saddr, daddr; uint16_t sport, dport; int16_t kafka_api_version;
 } l7ev;
 
 /* bpfL7Event layout — ebpf/l7_req/l7.go:345-369 (= struct l7_event, ebpf/c/l7.c:19-47):
@@ -446,7 +448,7 @@ static void decode_wire(const uint8_t* r, l7ev* e) {
     e->fd = rd64(r + 0); e->write_time_ns = rd64(r + 8); e->pid = rd32(r + 16); e->status = rd32(r + 20);
     e->duration = rd64(r + 24); e->protocol = r[32]; e->method = r[33]; e->payload = r + 36;
     e->payload_size = rd32(r + 1060); if (e->payload_size > 1024) e->payload_size = 1024;
-    e->tls = r[1066] != 0; e->prep_stmt_id = rd32(r + 1072);
+    e->tls = r[1066] != 0; e->prep_stmt_id = rd32(r + 1072); e->kafka_api_version = (int16_t)(r[1068] | r[1069] << 8);
     e->saddr = rd32(r + 1076); e->sport = rd16(r + 1080); e->daddr = rd32(r + 1084); e->dport = rd16(r + 1088);
 }
 
@@ -685,6 +687,21 @@ static size_t process_one(oracle_t* o, const l7ev* d, uint32_t kafka_msgs) {
          * 0 messages => event dropped (:1037-1039); one KafkaEvent per message; the first failing
          * setFromToV2 returns from the whole handler (:1065-1068). */
         size_t done = 0;
+        if (o->kafka_decode) {                                   /* decodeKafkaPayload :929-1017 */
+            or_kafka_result* kr = or_kafka_decode(d->payload, d->payload_size, d->method, d->kafka_api_version);
+            const size_t n = or_kafka_status(kr) == 0 ? or_kafka_count(kr) : 0;
+            if (n == 0) o->dropped_parse++;                      /* err != nil || len(kafkaMessages) == 0 (:1037-1039) */
+            for (size_t k = 0; k < n; k++) {
+                const uint8_t *t, *kk, *vv; size_t tn, kn, vn; int32_t part; char topic[OR_HTTP_PATH_CAP];
+                or_kafka_msg(kr, k, &t, &tn, &part, &kk, &kn, &vv, &vn);
+                copy_trunc(topic, sizeof topic, t, tn);
+                if (!resolve_and_persist(o, d->saddr, d->sport, d->daddr, d->dport, d->protocol, protocol, d->method == 2 ? "CONSUME" : "PUBLISH",
+                                         d->tls, d->status, d->duration, d->write_time_ns, "", topic, 0, 1)) break;
+                done++;
+            }
+            or_kafka_result_free(kr);
+            return done;
+        }
         for (uint32_t k = 0; k < kafka_msgs; k++) {
             int ok = resolve_and_persist(o, d->saddr, d->sport, d->daddr, d->dport, d->protocol, protocol,
                                          d->method == 2 ? "CONSUME" : "PUBLISH", d->tls, d->status, d->duration,

@@ -201,6 +201,22 @@ uint64_t or_h2_dropped_unparsed(const or_h2* h);
 /* the oracle's own assembler (HTTP2 records of or_process_l7_wire go through it) */
 or_h2* or_h2_of(oracle_t* o);
 
+/* ---- f-4 (second half): Kafka payload decode — oracle/kafka.c ------------------------------------- */
+/* when on, KAFKA records of or_process_l7_wire are decoded (kafka_msgs is ignored): one row per message, path = topic */
+void or_set_kafka_decode(oracle_t* o, int on);
+typedef struct or_kafka_result or_kafka_result;
+/* decodeKafkaPayload (data.go:929-1017): method_id 1 = PRODUCE_REQUEST, 2 = FETCH_RESPONSE */
+or_kafka_result* or_kafka_decode(const uint8_t* payload, size_t size, int method_id, int16_t api_version);
+void   or_kafka_result_free(or_kafka_result* r);
+size_t or_kafka_count(const or_kafka_result* r);
+int    or_kafka_status(const or_kafka_result* r);      /* 0 ok, 1 insufficient data, 2 error, 3 panic (recovered) */
+int    or_kafka_msg(const or_kafka_result* r, size_t i, const uint8_t** topic, size_t* topic_n, int32_t* partition,
+                    const uint8_t** key, size_t* key_n, const uint8_t** value, size_t* value_n);
+int    or_kafka_decompress(int codec, const uint8_t* src, size_t n, uint8_t** out, size_t* out_n);   /* 0 / -1; free with or_kafka_free */
+void   or_kafka_free(void* p);
+uint32_t or_crc32(int castagnoli, const uint8_t* p, size_t n);
+uint32_t or_xxh32(const uint8_t* p, size_t n, uint32_t seed);
+
 /* method[OR_HTTP_TOK_CAP], path[OR_HTTP_PATH_CAP], version[OR_HTTP_TOK_CAP], host[OR_UID_MAX] */
 void   or_parse_http_payload(const char* req, size_t len, char* method, char* path, char* version,
                              char* host);                             /* data.go:508-531  */
