@@ -152,6 +152,18 @@ int GraphDS::IngestL7(const l7_req::L7Event& e, uint32_t kafka_msgs) {
     return rc;
 }
 
+int GraphDS::IngestWire(const uint8_t* recs, size_t n, const uint32_t* kafka_msgs) {
+    std::lock_guard<std::mutex> g(mu_);
+    std::vector<sg_event> tmp;
+    int rc = SG_OK;
+    for (size_t i = 0; i < n; i++) {
+        tmp.clear();
+        packer_.PackWire(recs + i * l7_req::kWireSize, kafka_msgs ? kafka_msgs[i] : 1u, &tmp);
+        for (const sg_event& ev : tmp) { const int r2 = Append(ev); if (r2 != SG_OK) rc = r2; }
+    }
+    return rc;
+}
+
 long GraphDS::FlushWindow(int64_t window_end_ms) {
     std::vector<sg_edge_out> rows(max_edges_);
     std::vector<uint32_t> obips;

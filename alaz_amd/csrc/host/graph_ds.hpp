@@ -81,6 +81,8 @@ public:
 
     // earlier tap: the raw L7 event (what processL7 receives, aggregator/data.go:1364-1383)
     int IngestL7(const l7_req::L7Event& e, uint32_t kafka_msgs = 1);
+    // n perf records of l7_req::kWireSize bytes each, through L7Packer::PackWire (f-1: no 1 KiB copy per event)
+    int IngestWire(const uint8_t* recs, size_t n, const uint32_t* kafka_msgs = nullptr);
 
     // process / connection lifecycle as far as the HTTP/2 assembler needs it (aggregator/data.go:354-377, :484-494,
     // :553-567): only events of live pids are assembled; a closed connection or an exited process drops its HPACK state

@@ -61,8 +61,8 @@ void sgh_packer_destroy(void* p) { delete static_cast<L7Packer*>(p); }
 void sgh_packer_known_ip(void* p, uint32_t ip, int add) { if (add) static_cast<L7Packer*>(p)->AddKnownIP(ip); else static_cast<L7Packer*>(p)->RemoveKnownIP(ip); }
 size_t sgh_packer_pack_wire(void* p, const uint8_t* recs, size_t n, const uint32_t* kafka_msgs, sg_event* out, size_t cap) {
     auto* pk = static_cast<L7Packer*>(p);
-    std::vector<sg_event> v; l7_req::L7Event e;
-    for (size_t i = 0; i < n; i++) { l7_req::DecodeWire(recs + i * l7_req::kWireSize, &e); pk->Pack(e, kafka_msgs ? kafka_msgs[i] : 1u, &v); }
+    std::vector<sg_event> v; v.reserve(n);
+    for (size_t i = 0; i < n; i++) pk->PackWire(recs + i * l7_req::kWireSize, kafka_msgs ? kafka_msgs[i] : 1u, &v);
     const size_t m = std::min(cap, v.size());
     if (m) std::memcpy(out, v.data(), m * sizeof(sg_event));
     return v.size();
@@ -101,9 +101,7 @@ void sgh_graphds_destroy(void* g) { auto* c = static_cast<HostCtx*>(g); if (!c) 
 int sgh_graphds_persist_pod(void* g, const char* et, const char* uid, const char* ip) { datastore::Pod p; p.UID = uid; p.IP = ip; return static_cast<HostCtx*>(g)->ds->PersistPod(p, et); }
 int sgh_graphds_persist_service(void* g, const char* et, const char* uid, const char* ip) { datastore::Service s; s.UID = uid; if (ip && *ip) s.ClusterIPs.push_back(ip); return static_cast<HostCtx*>(g)->ds->PersistService(s, et); }
 int sgh_graphds_ingest_wire(void* g, const uint8_t* recs, size_t n, const uint32_t* kafka_msgs) {
-    auto* c = static_cast<HostCtx*>(g); l7_req::L7Event e; int rc = 0;
-    for (size_t i = 0; i < n; i++) { l7_req::DecodeWire(recs + i * l7_req::kWireSize, &e); const int r = c->ds->IngestL7(e, kafka_msgs ? kafka_msgs[i] : 1u); if (r) rc = r; }
-    return rc;
+    return static_cast<HostCtx*>(g)->ds->IngestWire(recs, n, kafka_msgs);
 }
 int sgh_graphds_persist_request(void* g, int64_t start_ms, uint64_t latency, const char* from_ip, const char* from_type, const char* from_uid,
                                 const char* to_ip, const char* to_type, const char* to_uid, const char* protocol, uint32_t status,
@@ -241,8 +239,10 @@ void sgh_graphds_kafka_decode(void* g, int on) { static_cast<HostCtx*>(g)->ds->S
 // decodes one payload; messages are serialised into buf as [u32 topic_n][i32 partition][u32 key_n][u32 value_n] topic key value ...
 // returns the message count (also when buf is too small: then nothing is written), *status = kafka::Status
 long sgh_kafka_decode(const uint8_t* payload, size_t size, int method_id, int api_version, int* status, uint8_t* buf, size_t cap) {
-    std::vector<kafka::Message> msgs;
-    const kafka::Status st = kafka::DecodePayload(payload, size, method_id, (int16_t)api_version, &msgs);
+    std::vector<kafka::Message> msgs; size_t counted = 0, counted_only = 0;
+    const kafka::Status st = kafka::DecodePayload(payload, size, method_id, (int16_t)api_version, &msgs, &counted);
+    const kafka::Status st2 = kafka::DecodePayload(payload, size, method_id, (int16_t)api_version, nullptr, &counted_only);   // the packer's mode
+    if (st2 != st || counted != msgs.size() || counted_only != counted) { if (status) *status = 99; return -1; }           // self-check of the two modes
     if (status) *status = (int)st;
     size_t need = 0;
     for (const auto& m : msgs) need += 16 + m.Topic.size() + m.Key.size() + m.Value.size();

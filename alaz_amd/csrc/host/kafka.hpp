@@ -23,7 +23,9 @@ enum class Status { kOk = 0, kInsufficientData = 1, kError = 2, kPanic = 3 };
 // method_id: 1 = PRODUCE_REQUEST, 2 = FETCH_RESPONSE (ebpf/c/kafka.c:15-16); api_version is the request's
 // (carried to the response event by the kernel side, l7.c:869).  Messages are ordered by (topic, partition,
 // position); the reference iterates Go maps, i.e. in no defined order.
-Status DecodePayload(const uint8_t* payload, size_t size, int method_id, int16_t api_version, std::vector<Message>* out);
+// out == nullptr: only *count is produced (what the packer needs: one packed event per message) and no key / value
+// is copied.
+Status DecodePayload(const uint8_t* payload, size_t size, int method_id, int16_t api_version, std::vector<Message>* out, size_t* count = nullptr);
 
 // codec 0 none, 1 gzip, 2 snappy, 3 lz4, 4 zstd.  *nil_slice: the Go decoder would have returned a nil slice.
 bool Decompress(int codec, const uint8_t* src, size_t n, std::string* out, bool* nil_slice = nullptr);

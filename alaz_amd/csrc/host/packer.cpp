@@ -169,6 +169,24 @@ int L7Packer::ParseMongo(const l7_req::L7Event& e, std::string* out) {
     return -1;
 }
 
+size_t L7Packer::PackWire(const uint8_t* rec, uint32_t kafka_msgs, std::vector<sg_event>* out) {
+    using namespace l7_req;
+    L7Event& e = scratch_;
+    DecodeWire(rec, &e, /*copy_payload=*/false);
+    bool needs_payload;
+    switch (e.ProtocolId) {
+    case BPF_L7_PROTOCOL_HTTP: needs_payload = !IsKnownIP(e.Daddr); break;
+    case BPF_L7_PROTOCOL_POSTGRES: case BPF_L7_PROTOCOL_MYSQL: case BPF_L7_PROTOCOL_MONGO: case BPF_L7_PROTOCOL_HTTP2: needs_payload = true; break;
+    case BPF_L7_PROTOCOL_KAFKA: needs_payload = kafka_decode_; break;
+    default: needs_payload = false;
+    }
+    if (needs_payload) {
+        std::memcpy(e.Payload, rec + 36, e.PayloadSize);
+        if (e.PayloadSize < kMaxPayload) e.Payload[e.PayloadSize] = 0;          // handlers only read [0, PayloadSize)
+    }
+    return Pack(e, kafka_msgs, out);
+}
+
 size_t L7Packer::Pack(const l7_req::L7Event& e, uint32_t kafka_msgs, std::vector<sg_event>* out) {
     using namespace l7_req;
     sg_event ev;
@@ -205,10 +223,10 @@ size_t L7Packer::Pack(const l7_req::L7Event& e, uint32_t kafka_msgs, std::vector
     case BPF_L7_PROTOCOL_KAFKA:
         if (e.MethodId == 2) ev.flags |= SG_EV_CONSUME;
         if (kafka_decode_) {                                            // decodeKafkaPayload, data.go:929-1017
-            std::vector<kafka::Message> msgs;
-            if (kafka::DecodePayload(e.Payload, e.PayloadSize, e.MethodId, e.KafkaApiVersion, &msgs) != kafka::Status::kOk) msgs.clear();
-            if (msgs.empty()) { dropped_parse_++; return 0; }
-            kafka_msgs = (uint32_t)msgs.size();
+            size_t n = 0;
+            if (kafka::DecodePayload(e.Payload, e.PayloadSize, e.MethodId, e.KafkaApiVersion, nullptr, &n) != kafka::Status::kOk) n = 0;
+            if (n == 0) { dropped_parse_++; return 0; }
+            kafka_msgs = (uint32_t)n;
         }
         for (uint32_t k = 0; k < kafka_msgs; k++) out->push_back(ev);    // one KafkaEvent per decoded message
         return kafka_msgs;

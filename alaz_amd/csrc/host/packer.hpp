@@ -43,6 +43,10 @@ public:
     // caller's side produced for this event (ignored for other protocols, and ignored when SetKafkaDecode(true):
     // then the payload is decoded here, kafka.hpp).  Returns the number appended.
     size_t Pack(const l7_req::L7Event& e, uint32_t kafka_msgs, std::vector<sg_event>* out);
+    // The same straight from a 1096-byte perf record (the "packed producer"): the header fields are
+    // read in place and the payload is copied — PayloadSize bytes of it, not the 1 KiB slot — only when the
+    // protocol handler will look at it (HTTP towards an unknown address, the SQL/Mongo filters, HTTP/2, Kafka decode).
+    size_t PackWire(const uint8_t* rec, uint32_t kafka_msgs, std::vector<sg_event>* out);
 
     const std::vector<std::string>& Labels() const { return labels_; }
     uint64_t DroppedParse() const { return dropped_parse_; }
@@ -62,6 +66,7 @@ private:
     std::unordered_map<std::string, std::string> pg_stmts_, mysql_stmts_;   // data.go pgStmts / mySqlStmts
     Http2Assembler h2_;
     bool kafka_decode_ = false;
+    l7_req::L7Event scratch_;
     uint64_t dropped_parse_ = 0;
 };
 

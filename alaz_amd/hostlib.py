@@ -254,8 +254,7 @@ class Packer:
         else:
             cap = n * 160 if getattr(self, "_kafka", False) else n      # a 1 KiB payload holds < 160 minimal records
         out = np.zeros(max(cap, 1), dtype=EVENT_DTYPE)
-        buf = (C.c_char * len(wire)).from_buffer_copy(wire)
-        k = self._l.sgh_packer_pack_wire(self._p, C.addressof(buf), n, km, out.ctypes.data, cap)
+        k = self._l.sgh_packer_pack_wire(self._p, C.cast(C.c_char_p(wire), C.c_void_p), n, km, out.ctypes.data, cap)
         return out[:k]
 
     @property
