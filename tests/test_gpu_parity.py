@@ -305,6 +305,29 @@ def test_cpp_graphds_end_to_end_from_wire_records():
     got = g.FlushWindow(124)
     compare_edge_dicts(got, o.edge_dict())
     assert sum(v[8] for v in got.values()) == o.alive_count() > 0
+    # f-4, third window: real HTTP/2 frames (HPACK) and Kafka payloads (record batches, compressed) decoded on the host
+    from tests.test_http2 import _h2_trace
+    from tests import kafka_builder as kb
+    h2_wire, pids = _h2_trace(topo, 300, seed=8)
+    rk = np.random.default_rng(9); krecs = []
+    for i in range(300):
+        batch = [kb.record(b"k%d" % j, b"v" * 12, offset_delta=j) for j in range(int(rk.integers(1, 6)))]
+        codec = int(rk.integers(0, 5)); s_ip = int(topo.pod_ips[int(rk.integers(0, 30))]); d_ip = int(topo.svc_ips[int(rk.integers(0, 5))])
+        if i % 2:
+            krecs.append(kb.l7_record(2, kb.fetch_response([(b"orders", [(i % 4, kb.record_batch(batch, codec=codec))])]), 10_000_000 + i, s_ip, d_ip, api_version=11))
+        else:
+            krecs.append(kb.l7_record(1, kb.produce_request([(b"orders", [(i % 4, kb.record_batch(batch, codec=codec))])]), 10_000_000 + i, s_ip, d_ip, api_version=7))
+    krecs.append(kb.l7_record(1, b"\x00\x00\x00\x09not kafka", 10_000_999, int(topo.pod_ips[0]), int(topo.svc_ips[0])))
+    w3 = h2_wire + b"".join(krecs)
+    o.set_kafka_decode(True); g.kafka_decode(True)
+    for p in pids:
+        o.h2().proc_exec(p); g.proc_exec(p)
+    d0 = o.dropped_parse
+    n3 = o.l7_wire(w3); assert g.ingest_wire(w3) == 0
+    o.window_close(W, 2)
+    got = g.FlushWindow(125)
+    compare_edge_dicts(got, o.edge_dict())
+    assert n3 > 900 and g.dropped_parse == o.dropped_parse == d0 + 1 and g.labels == o.labels and g.http2_stats()["pending"] == 0
 
 
 @pytest.mark.parametrize("layers", [1, 2])
