@@ -88,7 +88,7 @@ public:
     // :553-567): only events of live pids are assembled; a closed connection or an exited process drops its HPACK state
     void ProcExec(uint32_t pid) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ProcExec(pid); }
     void ProcExit(uint32_t pid) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ProcExit(pid); }
-    void ConnClosed(uint32_t pid, uint64_t fd) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ConnClosed(pid, fd); }
+    void ConnClosed(uint32_t pid, uint64_t fd) { std::lock_guard<std::mutex> g(mu_); packer_.ConnClosed(pid, fd); }
     void SetKafkaDecode(bool on) { std::lock_guard<std::mutex> g(mu_); packer_.SetKafkaDecode(on); }
     void SweepHttp2() { std::lock_guard<std::mutex> g(mu_); packer_.Http2().Sweep(); }
 

@@ -268,7 +268,8 @@ uint32_t sgh_xxh32(const uint8_t* p, size_t n, uint32_t seed) { return kafka::XX
 // the stand-alone packer's assembler
 void sgh_packer_proc_exec(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Http2().ProcExec(pid); }
 void sgh_packer_proc_exit(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Http2().ProcExit(pid); }
-void sgh_packer_conn_closed(void* p, uint32_t pid, uint64_t fd) { static_cast<L7Packer*>(p)->Http2().ConnClosed(pid, fd); }
+void sgh_packer_conn_closed(void* p, uint32_t pid, uint64_t fd) { static_cast<L7Packer*>(p)->ConnClosed(pid, fd); }
+size_t sgh_packer_pg_statements(void* p) { return static_cast<L7Packer*>(p)->PgStatements(); }
 size_t sgh_graphds_socklines(void* g) { return static_cast<HostCtx*>(g)->conns.Lines(); }
 void* sgh_graphds_sockline(void* g, uint32_t pid, uint64_t fd) { return static_cast<HostCtx*>(g)->conns.Line(pid, fd); }
 // one clearSocketLines tick: open connections -> GraphDS::PersistAliveConnection (-> SG_EV_ALIVE records)

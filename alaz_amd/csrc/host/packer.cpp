@@ -169,6 +169,14 @@ int L7Packer::ParseMongo(const l7_req::L7Event& e, std::string* out) {
     return -1;
 }
 
+void L7Packer::ConnClosed(uint32_t pid, uint64_t fd) {
+    h2_.ConnClosed(pid, fd);
+    const std::string prefix = std::to_string(pid) + "-" + std::to_string(fd);
+    for (auto it = pg_stmts_.begin(); it != pg_stmts_.end();) {
+        if (it->first.compare(0, prefix.size(), prefix) == 0) it = pg_stmts_.erase(it); else ++it;
+    }
+}
+
 size_t L7Packer::PackWire(const uint8_t* rec, uint32_t kafka_msgs, std::vector<sg_event>* out) {
     using namespace l7_req;
     L7Event& e = scratch_;

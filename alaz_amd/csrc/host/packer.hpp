@@ -50,6 +50,10 @@ public:
 
     const std::vector<std::string>& Labels() const { return labels_; }
     uint64_t DroppedParse() const { return dropped_parse_; }
+    // a closed connection (processTcpConnect, data.go:484-503): its HPACK state goes, and every remembered Postgres
+    // statement whose "pid-fd-name" key STARTS WITH "pid-fd" (the reference's HasPrefix: fd 7 also clears fd 70..79)
+    void ConnClosed(uint32_t pid, uint64_t fd);
+    size_t PgStatements() const { return pg_stmts_.size(); }
     void SetKafkaDecode(bool on) { kafka_decode_ = on; }
     Http2Assembler& Http2() { return h2_; }
     const Http2Assembler& Http2() const { return h2_; }

@@ -74,7 +74,7 @@ def load() -> C.CDLL:
             "sgh_h2_event": (C.c_int, [P, u32, u64, C.c_int, C.c_char_p, u32, u64, C.c_int, C.POINTER(H2OutC)]),
             "sgh_h2_proc_exec": (None, [P, u32]), "sgh_h2_proc_exit": (None, [P, u32]), "sgh_h2_conn_closed": (None, [P, u32, u64]),
             "sgh_h2_sweep": (None, [P]), "sgh_h2_pending": (sz, [P]), "sgh_h2_parsers": (sz, [P]),
-            "sgh_packer_proc_exec": (None, [P, u32]), "sgh_packer_proc_exit": (None, [P, u32]), "sgh_packer_conn_closed": (None, [P, u32, u64]),
+            "sgh_packer_proc_exec": (None, [P, u32]), "sgh_packer_proc_exit": (None, [P, u32]), "sgh_packer_conn_closed": (None, [P, u32, u64]), "sgh_packer_pg_statements": (sz, [P]),
             "sgh_packer_kafka_decode": (None, [P, C.c_int]), "sgh_graphds_kafka_decode": (None, [P, C.c_int]),
             "sgh_kafka_decode": (C.c_long, [C.c_char_p, sz, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p, sz]),
             "sgh_kafka_decompress": (C.c_long, [C.c_int, C.c_char_p, sz, C.c_char_p, sz]),
@@ -266,6 +266,7 @@ class Packer:
     def proc_exec(self, pid): self._l.sgh_packer_proc_exec(self._p, pid)
     def proc_exit(self, pid): self._l.sgh_packer_proc_exit(self._p, pid)
     def conn_closed(self, pid, fd): self._l.sgh_packer_conn_closed(self._p, pid, fd)
+    def pg_statements(self) -> int: return self._l.sgh_packer_pg_statements(self._p)
 
 
 class GraphDS:

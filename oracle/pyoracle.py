@@ -114,7 +114,7 @@ def _load():
         "or_sl_at": (C.c_int, [P, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(SockInfo)]),
         "or_process_tcp": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint16, C.c_char_p, C.c_uint16]),
         "or_process_tcp_wire": (C.c_size_t, [P, C.c_void_p, C.c_size_t]),
-        "or_sockline_of": (P, [P, C.c_uint32, C.c_uint64]), "or_sockline_count": (C.c_size_t, [P]),
+        "or_sockline_of": (P, [P, C.c_uint32, C.c_uint64]), "or_sockline_count": (C.c_size_t, [P]), "or_pg_stmt_count": (C.c_size_t, [P]),
         "or_sweep_socket_lines": (C.c_size_t, [P, C.c_int64, C.c_int]),
         "or_alive_count": (C.c_size_t, [P]), "or_alive_at": (C.POINTER(Alive), [P, C.c_size_t]),
         "or_hpack_create": (P, [C.c_uint32]), "or_hpack_destroy": (None, [P]),
@@ -363,6 +363,8 @@ class Oracle:
         return SockLine(_borrowed=p) if p else None
 
     def sockline_count(self) -> int: return self._l.or_sockline_count(self._o)
+
+    def pg_stmt_count(self) -> int: return self._l.or_pg_stmt_count(self._o)
 
     def set_kafka_decode(self, on: bool = True): self._l.or_set_kafka_decode(self._o, int(on))
 

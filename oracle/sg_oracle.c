@@ -69,6 +69,16 @@ static void sm_del(strmap* m, const char* k) {
     free(e->key); free(e->sval); e->key = e->sval = NULL; e->state = 2; m->used--;
 }
 
+/* delete(m, key) for every key with the given string prefix (Go: range + strings.HasPrefix + delete) */
+static size_t sm_del_prefix(strmap* m, const char* prefix) {
+    const size_t pl = strlen(prefix); size_t n = 0;
+    for (size_t i = 0; i < m->cap; i++) {
+        sm_ent* e = &m->e[i];
+        if (e->state == 1 && strncmp(e->key, prefix, pl) == 0) { free(e->key); free(e->sval); e->key = e->sval = NULL; e->state = 2; m->used--; n++; }
+    }
+    return n;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* oracle state                                                                               */
 /* ------------------------------------------------------------------------------------------ */
@@ -593,6 +603,7 @@ or_sockline* or_sockline_of(oracle_t* o, uint32_t pid, uint64_t fd) {
     return e ? o->socklines[e->uval] : NULL;
 }
 size_t or_sockline_count(const oracle_t* o) { return o->n_socklines; }
+size_t or_pg_stmt_count(const oracle_t* o) { return o->pg_stmts.used; }
 
 /* processTcpConnect — aggregator/data.go:404-506 */
 int or_process_tcp(oracle_t* o, uint32_t type, uint32_t pid, uint64_t fd, uint64_t ts,
@@ -616,7 +627,9 @@ int or_process_tcp(oracle_t* o, uint32_t type, uint32_t pid, uint64_t fd, uint64
     }
     if (!sl) return 0;                               /* CLOSED without a line: dropped (:472-477) */
     or_sl_add(sl, ts, NULL);                         /* :480-483 */
-    or_h2_conn_closed(o->h2, pid, fd);               /* :485-494 (pgStmts clean-up :496-503 is keyed the same way; not restated) */
+    or_h2_conn_closed(o->h2, pid, fd);               /* :485-494 */
+    { char ck[48]; snprintf(ck, sizeof ck, "%u-%llu", pid, (unsigned long long)fd);      /* :496-503: every pgStmts key that STARTS WITH */
+      sm_del_prefix(&o->pg_stmts, ck); }                                                  /* "pid-fd" goes - also "pid-fd7-..." of another fd   */
     return 1;
 }
 

@@ -147,6 +147,7 @@ int    or_process_tcp(oracle_t* o, uint32_t type, uint32_t pid, uint64_t fd, uin
                       const char* saddr, uint16_t sport, const char* daddr, uint16_t dport);
 size_t or_process_tcp_wire(oracle_t* o, const uint8_t* recs, size_t n);
 or_sockline* or_sockline_of(oracle_t* o, uint32_t pid, uint64_t fd);     /* NULL if none */
+size_t or_pg_stmt_count(const oracle_t* o);                                /* prepared statements remembered (pgStmts) */
 size_t or_sockline_count(const oracle_t* o);
 
 /* datastore.AliveConnection (datastore/dto.go:96-106) */

@@ -217,3 +217,25 @@ def test_cpp_tracker_feeds_alive_records_to_the_engine_boundary():
             a, b = g.sockline(pid, fd), o.sockline(pid, fd)
             if a is not None:
                 assert [(t, s is None) for t, _, s in a.values()] == [(t, s is None) for t, _, s in b.values()]
+
+
+def test_tcp_close_forgets_the_connections_prepared_statements_by_key_prefix():
+    """aggregator/data.go:496-503: on CLOSED every pgStmts key with the *string prefix* "pid-fd" is deleted — the keys are
+    "pid-fd-name" (:1619-1621), so closing fd 7 also clears the statements of fds 70..79 of that pid.  Oracle and packer."""
+    from alaz_amd import hostlib
+    from tests.test_oracle_golden import _wire
+    def parse(fd, name):                     # extended-query Parse message: 'P' len name\0 query\0 ...
+        body = name + b"\x00" + b"SELECT * FROM t WHERE id = $1\x00\x00\x00"
+        r = bytearray(_wire(0x0A000001, 0x0A000002, proto=3, method=3, status=1, payload=b"P" + (len(body) + 4).to_bytes(4, "big") + body))
+        r[0:8] = fd.to_bytes(8, "little")
+        return bytes(r)
+    wire = parse(7, b"s1") + parse(7, b"s2") + parse(70, b"s1") + parse(8, b"s1")
+    o = pyoracle.Oracle(0, 0); o.pod("ADD", "p1", "10.0.0.1"); o.pod("ADD", "p2", "10.0.0.2")
+    pk = hostlib.Packer()
+    assert o.l7_wire(wire) == 4 and len(pk.pack_wire(wire)) == 4
+    assert o.pg_stmt_count() == pk.pg_statements() == 4
+    o.tcp(5, 99, 7, 50, "10.0.0.1", 40000, "10.0.0.2", 5432)                      # CLOSED without a line: dropped, nothing forgotten
+    assert o.pg_stmt_count() == 4
+    o.tcp(1, 99, 7, 10, "10.0.0.1", 40000, "10.0.0.2", 5432); o.tcp(5, 99, 7, 60, "10.0.0.1", 40000, "10.0.0.2", 5432)
+    pk.conn_closed(99, 7)
+    assert o.pg_stmt_count() == pk.pg_statements() == 1                              # only "99-8-s1" is left
