@@ -420,8 +420,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // few edges but many events (a small shard of a busy map): the merge pass must still fill the chip, ~16
         // records per piece; 256 partitions hold every event count up to the 1 M-per-window class
         d.np = (u32)std::max<u64>(d.np, std::min<u64>(256, next_pow2(e->cfg.max_window_events / ((u64)d.nwg * 16) + 1) / 2));
-        if (const char* v = std::getenv("SG_NP")) d.np = (u32)std::strtoul(v, nullptr, 0);
-        if (const char* v = std::getenv("SG_NWG")) d.nwg = (u32)std::strtoul(v, nullptr, 0);
+        // tuning overrides (tools/gpu_probe_sweep.sh); anything that is not a legal geometry is ignored
+        if (const char* v = std::getenv("SG_NP")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 64 && x <= 4096 && (x & (x - 1)) == 0) d.np = (u32)x; }
+        if (const char* v = std::getenv("SG_NWG")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= (u64)SG_MAX_K1_WGS) d.nwg = (u32)x; }
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
         d.ss = (u32)(2.0 * m + 6.0 * std::sqrt(m + 1.0) + 8.0);
         d.ss = (d.ss + SG_PIECE_HDR + 7) / 8 * 8 - SG_PIECE_HDR;        // header + first aggregate + ss singles = whole 128-byte lines
