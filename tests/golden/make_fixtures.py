@@ -76,6 +76,27 @@ def main():
     }
     json.dump(sim, open(os.path.join(HERE, "sim_kat.json"), "w"), indent=1)
     print("wrote pg_kat.json, sim_kat.json")
+    hpack_fixture()
+
+
+def hpack_fixture(independent_copy: str = ""):
+    """hpack_huffman_rfc7541.json: RFC 7541 Appendix B as (code, length) per symbol.  The data is the RFC's, not the
+    reference repository's (HPACK is golang.org/x/net there, not vendored).  Written from the oracle's length table
+    (oracle/http2.c, canonical code) and — when a path to python-hpack's huffman_constants.py is given, as was done when
+    the fixture was first written — refused unless all 257 entries agree with that independent copy."""
+    import importlib.util, sys
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import pyoracle
+    tab = [list(pyoracle.huff_code(s)) for s in range(257)]
+    if independent_copy:
+        spec = importlib.util.spec_from_file_location("hc", independent_copy)
+        hc = importlib.util.module_from_spec(spec); spec.loader.exec_module(hc)
+        assert [[c, l] for c, l in zip(hc.REQUEST_CODES, hc.REQUEST_CODES_LENGTH)] == tab
+    json.dump({"source": "RFC 7541 Appendix B (symbol -> [code, bit length], 256 = EOS); written from oracle/http2.c's length table after "
+                         "checking all 257 entries against an independent copy of the appendix (python-hpack's huffman_constants.py, "
+                         "found in the build container's tooling; not a dependency of this repo)", "table": tab},
+              open(os.path.join(HERE, "hpack_huffman_rfc7541.json"), "w"))
+    print("wrote hpack_huffman_rfc7541.json")
 
 
 if __name__ == "__main__":

@@ -51,6 +51,21 @@ def test_huffman_table_is_a_complete_prefix_code():
         assert pyoracle.huff_code(sym) == (code, ln), sym
 
 
+def test_huffman_table_equals_the_rfc_appendix_fixture():
+    """All 257 codes of RFC 7541 Appendix B (tests/golden/hpack_huffman_rfc7541.json), on both implementations."""
+    import json, os
+    tab = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hpack_huffman_rfc7541.json")))["table"]
+    assert len(tab) == 257
+    for sym, (code, ln) in enumerate(tab):
+        assert pyoracle.huff_code(sym) == (code, ln)
+        if sym < 256:                                  # the C++ side through its encoder: the code, padded with ones
+            pad = (-ln) % 8
+            want = ((code << pad) | ((1 << pad) - 1)).to_bytes((ln + pad) // 8, "big")
+            assert hostlib.huffman_encode(bytes([sym])) == want
+            if pad < 8:
+                assert hostlib.huffman_decode(want) == bytes([sym]) == pyoracle.huff_decode(want)
+
+
 @pytest.mark.parametrize("plain,hexed", RFC_STRINGS)
 def test_huffman_known_answers(plain, hexed):
     enc = H(hexed)
