@@ -128,6 +128,14 @@ def test_rfc7541_appendix_c_sequences(who, cls, name):
 
 
 @pytest.mark.parametrize("who,cls", DECODERS)
+def test_static_table_is_rfc7541_appendix_a(who, cls):
+    """Indexed fields 1..61 against the builder's copy of Appendix A (itself checked once against python-hpack's table)."""
+    d = cls()
+    assert [d.write(bytes([0x80 | i]))[1][0] for i in range(1, 62)] == hb.STATIC
+    assert d.write(bytes([0x80 | 62]))[0] == -1 and d.table() == []
+
+
+@pytest.mark.parametrize("who,cls", DECODERS)
 def test_rfc7541_c2_single_field_representations(who, cls):
     d = cls()
     assert d.write(H("400a 6375 7374 6f6d 2d6b 6579 0d63 7573 746f 6d2d 6865 6164 6572")) == (0, [(b"custom-key", b"custom-header")])
