@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "graph_ds.hpp"
+#include "edges_payload.hpp"
 #include "sockline.hpp"
 
 using namespace alaz;
@@ -233,6 +234,44 @@ void sgh_h2_conn_closed(void* a, uint32_t pid, uint64_t fd) { static_cast<Http2A
 void sgh_h2_sweep(void* a) { static_cast<Http2Assembler*>(a)->Sweep(); }
 size_t sgh_h2_pending(void* a) { return static_cast<Http2Assembler*>(a)->Pending(); }
 size_t sgh_h2_parsers(void* a) { return static_cast<Http2Assembler*>(a)->Parsers(); }
+// ---- edge egress (edges_payload.hpp, f-3) ----
+// the rows of the last sgh_graphds_flush as "/edges/" payloads of at most `batch` rows, concatenated with '\n' into buf;
+// returns the number of payloads (0 when the window had no edge), or -(bytes needed) when buf is too small
+long sgh_graphds_edges_json(void* g, const char* monitoring_id, const char* idem_key, const char* node_id, const char* version, size_t batch,
+                            char* buf, size_t cap) {
+    auto* c = static_cast<HostCtx*>(g);
+    std::string all; long n = 0;
+    JsonEdgeSink sink(PayloadMetadata{monitoring_id ? monitoring_id : "", idem_key ? idem_key : "", node_id ? node_id : "", version ? version : ""}, batch,
+                      [&](const char*, const std::string& body) { if (n) all.push_back('\n'); all += body; n++; return 0; });
+    sink.PersistEdges(c->sink.window_end, c->sink.rows);
+    if (all.size() + 1 > cap) return -(long)(all.size() + 1);
+    std::memcpy(buf, all.data(), all.size()); buf[all.size()] = 0;
+    return n;
+}
+// the same encoder over caller-supplied rows (tests)
+long sgh_edges_json_from_rows(const sgh_edge_row* in, size_t n_rows, int64_t window_end_ms, const char* monitoring_id, const char* idem_key, const char* node_id,
+                              const char* version, size_t batch, char* buf, size_t cap) {
+    std::vector<EdgeRow> rows(n_rows);
+    for (size_t i = 0; i < n_rows; i++) {
+        EdgeRow& r = rows[i]; const sgh_edge_row& o = in[i];
+        r.FromType = o.from_type; r.FromUID = o.from_uid; r.ToType = o.to_type; r.ToUID = o.to_uid;
+        r.Count = o.count; r.ErrCount = o.err_count; r.SumNs = o.sum_ns; r.MaxNs = o.max_ns; r.SumSqUs = o.sumsq_us;
+        r.Score = o.score; r.LatZ = o.lat_z; r.ErrRatio = o.err_ratio; r.Alive = o.alive;
+    }
+    std::string all; long n = 0;
+    JsonEdgeSink sink(PayloadMetadata{monitoring_id ? monitoring_id : "", idem_key ? idem_key : "", node_id ? node_id : "", version ? version : ""}, batch,
+                      [&](const char*, const std::string& body) { if (n) all.push_back('\n'); all += body; n++; return 0; });
+    sink.PersistEdges(window_end_ms, rows);
+    if (all.size() + 1 > cap) return -(long)(all.size() + 1);
+    std::memcpy(buf, all.data(), all.size()); buf[all.size()] = 0;
+    return n;
+}
+size_t sgh_json_string(const char* s, size_t n, char* out, size_t cap) {
+    std::string o; AppendJsonString(std::string(s, n), &o);
+    if (o.size() + 1 <= cap) { std::memcpy(out, o.data(), o.size()); out[o.size()] = 0; }
+    return o.size();
+}
+
 // ---- Kafka payload decode (kafka.hpp) ----
 void sgh_packer_kafka_decode(void* p, int on) { static_cast<L7Packer*>(p)->SetKafkaDecode(on != 0); }
 void sgh_graphds_kafka_decode(void* g, int on) { static_cast<HostCtx*>(g)->ds->SetKafkaDecode(on != 0); }

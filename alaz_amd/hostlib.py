@@ -75,6 +75,9 @@ def load() -> C.CDLL:
             "sgh_h2_proc_exec": (None, [P, u32]), "sgh_h2_proc_exit": (None, [P, u32]), "sgh_h2_conn_closed": (None, [P, u32, u64]),
             "sgh_h2_sweep": (None, [P]), "sgh_h2_pending": (sz, [P]), "sgh_h2_parsers": (sz, [P]),
             "sgh_packer_proc_exec": (None, [P, u32]), "sgh_packer_proc_exit": (None, [P, u32]), "sgh_packer_conn_closed": (None, [P, u32, u64]), "sgh_packer_pg_statements": (sz, [P]),
+            "sgh_graphds_edges_json": (C.c_long, [P, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, C.c_char_p, sz]),
+            "sgh_json_string": (sz, [C.c_char_p, sz, C.c_char_p, sz]),
+            "sgh_edges_json_from_rows": (C.c_long, [C.POINTER(EdgeRowC), sz, C.c_int64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz, C.c_char_p, sz]),
             "sgh_packer_kafka_decode": (None, [P, C.c_int]), "sgh_graphds_kafka_decode": (None, [P, C.c_int]),
             "sgh_kafka_decode": (C.c_long, [C.c_char_p, sz, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p, sz]),
             "sgh_kafka_decompress": (C.c_long, [C.c_int, C.c_char_p, sz, C.c_char_p, sz]),
@@ -185,6 +188,27 @@ def huffman_encode(b: bytes) -> bytes:
 
 
 def go_atoi_u32(b: bytes) -> int: return load().sgh_go_atoi_u32(b, len(b))
+
+
+def edges_json_from_rows(rows, window_end_ms=0, monitoring_id="", idempotency_key="", node_id="", version="", batch=1000) -> List[str]:
+    """rows: [(from_type, from_uid, to_type, to_uid, count, err, sum_ns, max_ns, sumsq_us, score, lat_z, err_ratio, alive)] with bytes strings"""
+    arr = (EdgeRowC * max(1, len(rows)))()
+    for a, r in zip(arr, rows):
+        a.from_type, a.from_uid, a.to_type, a.to_uid = r[0], r[1], r[2], r[3]
+        a.count, a.err_count, a.sum_ns, a.max_ns, a.sumsq_us, a.score, a.lat_z, a.err_ratio, a.alive = r[4:13]
+    cap = 1 << 16
+    while True:
+        buf = C.create_string_buffer(cap)
+        n = load().sgh_edges_json_from_rows(arr, len(rows), window_end_ms, monitoring_id.encode(), idempotency_key.encode(), node_id.encode(), version.encode(), batch, buf, cap)
+        if n >= 0:
+            return buf.value.decode("utf-8").split("\n") if n else []
+        cap = -n + 16
+
+
+def json_string(b: bytes) -> str:
+    n = load().sgh_json_string(b, len(b), None, 0); out = C.create_string_buffer(n + 1)
+    load().sgh_json_string(b, len(b), out, n + 1)
+    return out.value.decode("utf-8")
 
 
 class Http2Assembler:
@@ -335,6 +359,16 @@ class GraphDS:
         return SocketLine(_borrowed=p) if p else None
 
     def sweep(self, now_ms: int, send_alive: bool = True) -> int: return self._l.sgh_graphds_sweep(self._g, now_ms, int(send_alive))
+
+    def edges_json(self, monitoring_id="", idempotency_key="", node_id="", version="", batch=1000) -> List[str]:
+        """The rows of the last FlushWindow as "/edges/" payloads (edges_payload.hpp), one JSON document per batch."""
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = self._l.sgh_graphds_edges_json(self._g, monitoring_id.encode(), idempotency_key.encode(), node_id.encode(), version.encode(), batch, buf, cap)
+            if n >= 0:
+                return buf.value.decode("utf-8").split("\n") if n else []
+            cap = -n + 16
 
     def kafka_decode(self, on: bool = True): self._l.sgh_graphds_kafka_decode(self._g, int(on))
     def proc_exec(self, pid: int): self._l.sgh_graphds_proc_exec(self._g, pid)

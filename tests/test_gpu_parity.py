@@ -328,6 +328,13 @@ def test_cpp_graphds_end_to_end_from_wire_records():
     got = g.FlushWindow(125)
     compare_edge_dicts(got, o.edge_dict())
     assert n3 > 900 and g.dropped_parse == o.dropped_parse == d0 + 1 and g.labels == o.labels and g.http2_stats()["pending"] == 0
+    # f-3: the same rows as "/edges/" payloads (edges_payload.hpp)
+    import json, struct
+    f32 = lambda x: struct.unpack("<f", struct.pack("<f", x))[0]
+    docs = [json.loads(d) for d in g.edges_json("mon", "key", "node", "v", batch=100)]
+    assert len(docs) == -(-len(got) // 100) and all(d["window_end"] == 125 for d in docs)
+    from_json = {(e[0], e[1], e[2], e[3]): (e[4], e[5], e[6], e[7], e[8], f32(e[10]), f32(e[11]), f32(e[12]), e[9]) for d in docs for e in d["edges"]}
+    assert from_json == got
 
 
 @pytest.mark.parametrize("layers", [1, 2])

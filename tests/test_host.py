@@ -115,3 +115,70 @@ def test_graphds_l7_tap_and_datastore_tap_produce_the_same_events():
     assert np.array_equal(e1["write_time_ns"] // ms, e2["write_time_ns"] // ms)
     assert (e1["flags"] & 2).tolist() == [0, 0, 0, 0, 2, 2, 0] and (e1["flags"] & 1).tolist() == [0, 0, 0, 1, 0, 0, 0]
     assert g1.labels == g2.labels == ["ext.example"] and g1.mock_label_count == 1
+
+
+def _go_runes(b: bytes):
+    """utf8.DecodeRune semantics: a valid sequence is one rune, anything else is U+FFFD for ONE byte."""
+    i = 0
+    while i < len(b):
+        for n in (1, 2, 3, 4):
+            try:
+                ch = b[i:i + n].decode("utf-8")
+                if len(ch) == 1:
+                    yield ch, True; i += n; break
+            except UnicodeDecodeError:
+                pass
+        else:
+            yield "\ufffd", False; i += 1
+
+
+def _go_json_string(b: bytes) -> str:
+    """encoding/json's string encoding with the default HTML escaping: the model the C++ encoder follows."""
+    out = ['"']
+    for ch, valid in _go_runes(b):
+        o = ord(ch)
+        if not valid: out.append("\\ufffd")
+        elif ch == '"': out.append('\\"')
+        elif ch == "\\": out.append("\\\\")
+        elif ch == "\n": out.append("\\n")
+        elif ch == "\r": out.append("\\r")
+        elif ch == "\t": out.append("\\t")
+        elif ch in "<>&" or o < 0x20 or o in (0x2028, 0x2029): out.append("\\u%04x" % o)
+        else: out.append(ch)
+    out.append('"')
+    return "".join(out)
+
+
+@pytest.mark.parametrize("raw", [b"", b"plain-uid-123", b'quote"back\\slash', b"ctl\x00\x01\x1f\x7f\n\r\t", b"<script>&amp;</script>",
+                                 "snow☃ line sep  \U0001F600".encode(), b"bad\xff\xfe utf8", b"\xc0\xaf overlong", b"\xed\xa0\x80 surrogate",
+                                 b"cut\xe2\x82", b"\xf4\x90\x80\x80 too big", "svc.namespace.svc.cluster.local:8080".encode()])
+def test_json_string_escaping_follows_encoding_json(raw):
+    import json
+    got = hostlib.json_string(raw)
+    assert got == _go_json_string(raw)
+    assert json.loads(got) == "".join(ch for ch, _ in _go_runes(raw))          # and it is JSON
+
+
+def test_edges_payload_json_round_trip_and_batching():
+    """f-3: the "/edges/" payload (edges_payload.hpp): metadata keys of datastore/payload.go:3-8, 13 positional slots per edge,
+    shortest round-trip floats, batches with distinct idempotency keys, nothing sent for an empty window."""
+    import json, struct
+    f32 = lambda x: struct.unpack("<f", struct.pack("<f", x))[0]
+    rows = [(b"pod", b"uid-a", b"service", b"uid-b", 10, 1, 123456789012, 99999999, 2**63 + 5, f32(0.731), f32(-1.25e-7), f32(0.1), 0),
+            (b"pod", b"uid-a", b"outbound", b"api.example.com", 1, 0, 5, 5, 0, f32(1.0), f32(0.0), f32(0.0), 3),
+            (b"pod", b'we"ird<uid>', b"outbound", b"8.8.8.8", 4294967295, 4294967295, 2**64 - 1, 2**64 - 1, 2**64 - 1, f32(3.4e38), f32(1e-45), float("nan"), 4294967295)]
+    docs = hostlib.edges_json_from_rows(rows, 1700000000123, "mon-1", "idem", "node-7", "v0.0.0", batch=2)
+    assert len(docs) == 2
+    p0, p1 = (json.loads(d) for d in docs)
+    assert list(p0) == ["metadata", "window_end", "edges"] and list(p0["metadata"]) == ["monitoring_id", "idempotency_key", "node_id", "alaz_version"]
+    assert p0["metadata"] == {"monitoring_id": "mon-1", "idempotency_key": "idem-1700000000123-0", "node_id": "node-7", "alaz_version": "v0.0.0"}
+    assert p1["metadata"]["idempotency_key"] == "idem-1700000000123-1" and p0["window_end"] == p1["window_end"] == 1700000000123
+    got = p0["edges"] + p1["edges"]
+    assert len(got) == 3 and all(len(e) == 13 for e in got)
+    for e, r in zip(got, rows):
+        assert e[:4] == [r[0].decode(), r[1].decode(), r[2].decode(), r[3].decode()]
+        assert e[4:9] == list(r[4:9]) and e[9] == r[12]                                  # integers exact, incl. > 2^63
+        for k, v in ((10, r[9]), (11, r[10]), (12, r[11])):
+            assert (e[k] is None and v != v) or f32(e[k]) == v                          # float32 round trip; NaN -> null
+    assert '"score"' not in docs[0] and "0.731" in docs[0]                               # positional rows, shortest float text
+    assert hostlib.edges_json_from_rows([], 5) == []
