@@ -68,6 +68,17 @@ size_t sgh_packer_pack_wire(void* p, const uint8_t* recs, size_t n, const uint32
     if (m) std::memcpy(out, v.data(), m * sizeof(sg_event));
     return v.size();
 }
+// the same through the user-space L7Event (DecodeWire with the full 1 KiB copy, then L7Packer::Pack): what a caller holding
+// l7_req.L7Event objects gets; must equal sgh_packer_pack_wire record for record (tests)
+size_t sgh_packer_pack_wire_full(void* p, const uint8_t* recs, size_t n, const uint32_t* kafka_msgs, sg_event* out, size_t cap) {
+    auto* pk = static_cast<L7Packer*>(p);
+    std::vector<sg_event> v; v.reserve(n);
+    auto e = std::make_unique<l7_req::L7Event>();
+    for (size_t i = 0; i < n; i++) { l7_req::DecodeWire(recs + i * l7_req::kWireSize, e.get(), true); pk->Pack(*e, kafka_msgs ? kafka_msgs[i] : 1u, &v); }
+    const size_t m = std::min(cap, v.size());
+    if (m) std::memcpy(out, v.data(), m * sizeof(sg_event));
+    return v.size();
+}
 static size_t join_labels(const std::vector<std::string>& l, char* buf, size_t cap) {
     std::string s;
     for (size_t i = 0; i < l.size(); i++) { if (i) s.push_back('\n'); s += l[i]; }

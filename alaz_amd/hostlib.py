@@ -45,7 +45,7 @@ def load() -> C.CDLL:
         P, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
         sig = {
             "sgh_packer_create": (P, []), "sgh_packer_destroy": (None, [P]), "sgh_packer_known_ip": (None, [P, u32, C.c_int]),
-            "sgh_packer_pack_wire": (sz, [P, P, sz, P, P, sz]), "sgh_packer_labels": (sz, [P, C.c_char_p, sz]),
+            "sgh_packer_pack_wire": (sz, [P, P, sz, P, P, sz]), "sgh_packer_pack_wire_full": (sz, [P, P, sz, P, P, sz]), "sgh_packer_labels": (sz, [P, C.c_char_p, sz]),
             "sgh_packer_dropped_parse": (u64, [P]),
             "sgh_parse_http": (None, [C.c_char_p, sz, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz]),
             "sgh_graphds_create": (P, [C.c_char_p, C.POINTER(SgConfig), sz]), "sgh_graphds_destroy": (None, [P]),
@@ -269,7 +269,7 @@ class Packer:
 
     def known_ip(self, ip: int, add: bool = True): self._l.sgh_packer_known_ip(self._p, ip, int(add))
 
-    def pack_wire(self, wire: bytes, kafka_msgs: Optional[np.ndarray] = None) -> np.ndarray:
+    def pack_wire(self, wire: bytes, kafka_msgs: Optional[np.ndarray] = None, full_copy: bool = False) -> np.ndarray:
         n = len(wire) // L7_WIRE_SIZE
         km = None
         if kafka_msgs is not None:
@@ -278,7 +278,8 @@ class Packer:
         else:
             cap = n * 160 if getattr(self, "_kafka", False) else n      # a 1 KiB payload holds < 160 minimal records
         out = np.zeros(max(cap, 1), dtype=EVENT_DTYPE)
-        k = self._l.sgh_packer_pack_wire(self._p, C.cast(C.c_char_p(wire), C.c_void_p), n, km, out.ctypes.data, cap)
+        fn = self._l.sgh_packer_pack_wire_full if full_copy else self._l.sgh_packer_pack_wire
+        k = fn(self._p, C.cast(C.c_char_p(wire), C.c_void_p), n, km, out.ctypes.data, cap)
         return out[:k]
 
     @property

@@ -182,3 +182,35 @@ def test_edges_payload_json_round_trip_and_batching():
             assert (e[k] is None and v != v) or f32(e[k]) == v                          # float32 round trip; NaN -> null
     assert '"score"' not in docs[0] and "0.731" in docs[0]                               # positional rows, shortest float text
     assert hostlib.edges_json_from_rows([], 5) == []
+
+
+def test_packwire_in_place_equals_the_full_copy_path_on_every_protocol():
+    """f-1: L7Packer::PackWire reads the perf record in place and copies the payload only for the handlers that look at it;
+    it must give the same packed events, labels and drop counts as DecodeWire(full 1 KiB copy) + Pack, record for record —
+    on a stream that mixes every protocol, stale payload bytes from the previous record included."""
+    from tests import h2_builder as hb, kafka_builder as kb
+    from tests.test_http2 import _h2_trace
+    topo = replay.make_topology(60, 400, seed=31)
+    ev, labels = replay.make_events(topo, 6000, seed=32, mixed=True, with_raw_outbound=True, with_reverse=True)
+    base = replay.to_wire(ev, labels)
+    h2, pids = _h2_trace(topo, 200, seed=33)
+    batch = [kb.record(b"k%d" % j, b"v" * 9, offset_delta=j) for j in range(3)]
+    kaf = b"".join(kb.l7_record(1 + (i & 1), (kb.fetch_response if i & 1 else kb.produce_request)([(b"t", [(0, kb.record_batch(batch, codec=i % 5))])]),
+                                1000 + i, int(topo.pod_ips[i % 20]), int(topo.svc_ips[i % 5]), api_version=11 if i & 1 else 7) for i in range(200))
+    recs = [base[i:i + 1096] for i in range(0, len(base), 1096)] + [h2[i:i + 1096] for i in range(0, len(h2), 1096)] + [kaf[i:i + 1096] for i in range(0, len(kaf), 1096)]
+    rng = np.random.default_rng(34); order = rng.permutation(len(recs))
+    # keep the per-connection order of the HTTP/2 frames: shuffle only the positions of the blocks, not within the h2 stream
+    h2_pos = sorted(i for i in order if len(base) // 1096 <= i < (len(base) + len(h2)) // 1096)
+    it = iter(h2_pos); order = [next(it) if len(base) // 1096 <= i < (len(base) + len(h2)) // 1096 else int(i) for i in order]
+    wire = b"".join(recs[i] for i in order)
+    outs = []
+    for full in (False, True):
+        pk = hostlib.Packer(); pk.kafka_decode(True)
+        for ip in list(topo.pod_ips) + list(topo.svc_ips):
+            pk.known_ip(int(ip))
+        for p in pids:
+            pk.proc_exec(p)
+        outs.append((pk.pack_wire(wire, full_copy=full), pk.labels, pk.dropped_parse))
+    (a, la, da), (b, lb, db) = outs
+    assert len(a) == len(b) > 6000 and a.tobytes() == b.tobytes() and la == lb and da == db
+    assert {int(x) for x in np.unique(a["protocol"])} >= {1, 2, 3, 4, 5, 6}
