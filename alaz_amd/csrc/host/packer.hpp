@@ -6,7 +6,8 @@
 //   processMySQLEvent  :1287-1321 (parseMySQLCommand :1431-1472)
 //   processMongoEvent  :1251-1285 (parseMongoEvent :1561-1617; recover() => keep the event)
 //   processRedisEvent  :1120-1160, processAmqpEvent :1081-1118 (ReverseDirection for PUSHED_EVENT / DELIVER)
-//   processKafkaEvent  :1035-1079 (one event per decoded message; the decoder itself is out of scope)
+//   processKafkaEvent  :1035-1079 (one event per decoded message: decoded here with SetKafkaDecode(true), kafka.hpp,
+//                      or counted by the caller)
 //   processHttp2Event  :1019-1033 -> processHttp2Frames :544-810 (Http2Assembler, http2.hpp): an event is
 //                      emitted when the second HEADERS frame of a stream arrives; latency = the distance of
 //                      the two write times, status = :status or grpc-status, host label = :authority

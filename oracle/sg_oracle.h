@@ -77,7 +77,8 @@ int or_process_svc(oracle_t* o, const char* event_type, const char* uid, const c
 
 /* n wire records of OR_L7_WIRE_SIZE bytes each, through processL7 (data.go:1364-1383).
  * kafka_msgs: optional per-record count of decoded Kafka messages (NULL => 1 for every KAFKA
- * record); the Sarama-derived decoder itself is out of scope.
+ * record), used while or_set_kafka_decode is off; with it on the payloads are decoded (kafka.c).
+ * HTTP2 records go through the frame assembler (http2.c) and need their pid marked live.
  * Returns the number of rows that reached PersistRequest/PersistKafkaEvent. */
 size_t or_process_l7_wire(oracle_t* o, const uint8_t* recs, size_t n, const uint32_t* kafka_msgs);
 
