@@ -191,11 +191,11 @@ void sgh_hpack_destroy(void* d) { delete static_cast<hpack::Decoder*>(d); }
 long sgh_hpack_write(void* d, const uint8_t* block, size_t n, char* buf, size_t cap, uint32_t* lens, size_t max_fields) {
     auto* dec = static_cast<hpack::Decoder*>(d);
     size_t used = 0, nf = 0;
-    dec->SetEmitFunc([&](const hpack::HeaderField& f) {
-        if (nf < max_fields && used + f.Name.size() + f.Value.size() <= cap) {
-            std::memcpy(buf + used, f.Name.data(), f.Name.size()); used += f.Name.size();
-            std::memcpy(buf + used, f.Value.data(), f.Value.size()); used += f.Value.size();
-            lens[2 * nf] = (uint32_t)f.Name.size(); lens[2 * nf + 1] = (uint32_t)f.Value.size();
+    dec->SetEmitFunc([&](std::string_view name, std::string_view value) {
+        if (nf < max_fields && used + name.size() + value.size() <= cap) {
+            std::memcpy(buf + used, name.data(), name.size()); used += name.size();
+            std::memcpy(buf + used, value.data(), value.size()); used += value.size();
+            lens[2 * nf] = (uint32_t)name.size(); lens[2 * nf + 1] = (uint32_t)value.size();
         }
         nf++;
     });
@@ -222,7 +222,7 @@ long sgh_huffman_encode(const char* p, size_t n, char* out, size_t cap) {
     if (s.size() > cap) return -2;
     std::memcpy(out, s.data(), s.size()); return (long)s.size();
 }
-uint32_t sgh_go_atoi_u32(const char* p, size_t n) { return GoAtoiU32(std::string(p, n)); }
+uint32_t sgh_go_atoi_u32(const char* p, size_t n) { return GoAtoiU32(std::string_view(p, n)); }
 
 struct sgh_h2_out { char method[64]; char path[1100]; char authority[160]; char protocol[8]; uint32_t status_code; uint64_t latency; };
 void* sgh_h2_create(void) { return new Http2Assembler(); }

@@ -156,12 +156,12 @@ void HuffmanEncode(const std::string& s, std::string* out) {
     if (have) out->push_back((char)(uint8_t)((acc << (8 - have)) | ((1u << (8 - have)) - 1)));
 }
 
-bool Decoder::At(uint64_t i, HeaderField* out) const {
+bool Decoder::At(uint64_t i, std::string_view* name, std::string_view* value) const {
     if (i == 0) return false;
-    if (i <= 61) { out->Name = kStatic[i - 1].name; out->Value = kStatic[i - 1].value; return true; }
+    if (i <= 61) { *name = kStatic[i - 1].name; *value = kStatic[i - 1].value; return true; }
     const uint64_t d = i - 62;
     if (d >= table_.size()) return false;
-    *out = table_[(size_t)d];
+    *name = table_[(size_t)d].Name; *value = table_[(size_t)d].Value;
     return true;
 }
 
@@ -184,10 +184,10 @@ Decoder::Result Decoder::ParseField(const uint8_t* p, size_t n, size_t* used) {
     if (b & 0x80) {                                                  // 6.1 indexed header field
         uint64_t idx; size_t k;
         const VarInt r = ReadVarInt(7, p, n, &idx, &k); if (r != kVarOk) return from(r);
-        HeaderField hf;
-        if (!At(idx, &hf)) return kError;
+        std::string_view name, value;
+        if (!At(idx, &name, &value)) return kError;
         *used = k;
-        if (emit_) emit_(hf);
+        if (emit_) emit_(name, value);
         return kOk;
     }
     if ((b & 0xE0) == 0x20) {                                        // 6.3 dynamic table size update
@@ -203,22 +203,26 @@ Decoder::Result Decoder::ParseField(const uint8_t* p, size_t n, size_t* used) {
     const unsigned prefix = indexing ? 6 : 4;
     uint64_t name_idx; size_t k;
     VarInt r = ReadVarInt(prefix, p, n, &name_idx, &k); if (r != kVarOk) return from(r);
-    HeaderField hf; RawString raw_name, raw_value; size_t u;
+    RawString raw_name, raw_value; size_t u;
+    std::string_view name, unused;
     if (name_idx > 0) {
-        HeaderField named;
-        if (!At(name_idx, &named)) return kError;
-        hf.Name = std::move(named.Name);
+        if (!At(name_idx, &name, &unused)) return kError;
     } else {
         r = ReadString(p + k, n - k, &raw_name, &u); if (r != kVarOk) return from(r);
         k += u;
     }
     r = ReadString(p + k, n - k, &raw_value, &u); if (r != kVarOk) return from(r);
     k += u;
-    if (name_idx == 0 && !DecodeString(raw_name, &hf.Name)) return kError;
-    if (!DecodeString(raw_value, &hf.Value)) return kError;
+    if (name_idx == 0) { if (!DecodeString(raw_name, &name_buf_)) return kError; name = name_buf_; }
+    if (!DecodeString(raw_value, &value_buf_)) return kError;
     *used = k;
-    if (indexing) Add(hf);
-    if (emit_) emit_(hf);
+    if (indexing) {
+        const std::string owned(name);                               // Add() may evict the entry `name` points into
+        Add(HeaderField{owned, value_buf_});
+        if (emit_) emit_(owned, value_buf_);
+        return kOk;
+    }
+    if (emit_) emit_(name, value_buf_);
     return kOk;
 }
 
@@ -239,7 +243,7 @@ bool Decoder::Write(const uint8_t* p, size_t n) {
 
 }  // namespace hpack
 
-uint32_t GoAtoiU32(const std::string& s) {
+uint32_t GoAtoiU32(std::string_view s) {
     size_t i = 0; bool neg = false;
     if (s.empty()) return 0;
     if (s[0] == '+' || s[0] == '-') { neg = s[0] == '-'; i = 1; }
@@ -304,20 +308,21 @@ bool Http2Assembler::OnEvent(const l7_req::L7Event& e, Http2Request* out) {
         bool complete;
         if (from_client) {
             f.client = true; f.client_write_ns = e.WriteTimeNs;
-            parser.client.SetEmitFunc([&f](const hpack::HeaderField& hf) {
-                if (hf.Name == ":method") { if (f.method.empty()) f.method = hf.Value; }
-                else if (hf.Name == ":path") { if (f.path.empty()) f.path = hf.Value; }
-                else if (hf.Name == ":authority") { if (f.authority.empty()) f.authority = hf.Value; }
-                else if (hf.Name == "content-type") { if (!f.grpc && hf.Value.compare(0, 16, "application/grpc") == 0) f.grpc = true; }
+            parser.client.SetEmitFunc([&f](std::string_view name, std::string_view value) {
+                if (name.empty() || (name[0] != ':' && name[0] != 'c')) return;
+                if (name == ":method") { if (f.method.empty()) f.method.assign(value); }
+                else if (name == ":path") { if (f.path.empty()) f.path.assign(value); }
+                else if (name == ":authority") { if (f.authority.empty()) f.authority.assign(value); }
+                else if (name == "content-type") { if (!f.grpc && value.substr(0, 16) == "application/grpc") f.grpc = true; }
             });
             parser.client.Write(buf + at, flen);
             parser.client.SetEmitFunc(nullptr);
             complete = f.server;
         } else {
             f.server = true;
-            parser.server.SetEmitFunc([&f](const hpack::HeaderField& hf) {
-                if (hf.Name == ":status") f.status = GoAtoiU32(hf.Value);
-                else if (hf.Name == "grpc-status") f.grpc_status = GoAtoiU32(hf.Value);
+            parser.server.SetEmitFunc([&f](std::string_view name, std::string_view value) {
+                if (name == ":status") f.status = GoAtoiU32(value);
+                else if (name == "grpc-status") f.grpc_status = GoAtoiU32(value);
             });
             parser.server.Write(buf + at, flen);
             parser.server.SetEmitFunc(nullptr);

@@ -16,6 +16,7 @@
 #include <deque>
 #include <functional>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -34,7 +35,8 @@ void HuffmanEncode(const std::string& s, std::string* out);
 
 class Decoder {
 public:
-    using EmitFunc = std::function<void(const HeaderField&)>;
+    // the views are valid during the call only (they point into the tables or into the decoder's scratch strings)
+    using EmitFunc = std::function<void(std::string_view name, std::string_view value)>;
     explicit Decoder(uint32_t max_dynamic_table_size = 4096) : max_size_(max_dynamic_table_size), allowed_max_(max_dynamic_table_size) {}
     void SetEmitFunc(EmitFunc f) { emit_ = std::move(f); }
     // false on a decoding error (the caller in the reference ignores it; state stays usable)
@@ -46,13 +48,14 @@ public:
 private:
     enum Result { kOk, kNeedMore, kError };
     Result ParseField(const uint8_t* p, size_t n, size_t* used);
-    bool At(uint64_t i, HeaderField* out) const;
+    bool At(uint64_t i, std::string_view* name, std::string_view* value) const;
     void Add(HeaderField f);
     void Evict();
 
     std::deque<HeaderField> table_;      // front = newest
     uint32_t size_ = 0, max_size_, allowed_max_;
     std::string save_;                   // tail of a block that ended inside a field
+    std::string name_buf_, value_buf_;   // decoded literals of the field being parsed
     bool first_field_ = true;
     EmitFunc emit_;
 };
@@ -104,6 +107,6 @@ private:
     uint64_t dropped_not_live_ = 0, dropped_unparsed_ = 0, dropped_time_ = 0;
 };
 
-uint32_t GoAtoiU32(const std::string& s);        // uint32(s) of `s, _ := strconv.Atoi(v)`
+uint32_t GoAtoiU32(std::string_view s);        // uint32(s) of `s, _ := strconv.Atoi(v)`
 
 }  // namespace alaz
