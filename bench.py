@@ -135,14 +135,23 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local)
     force_sharded = os.environ.get("SG_FORCE_SHARDED") == "1"      # exercise the multi-GPU code path at world = 1
-    if world > 1 or force_sharded:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-
-    if world > 1 or force_sharded:
-        from alaz_amd import sharded
-        res = sharded.bench(a, rank, world, local)
-    else:
-        res = bench_single(a, local)
+    # the contract is ONE line on stdout: libraries that print there (RCCL writes its version banner to stdout when the
+    # first communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1 or force_sharded:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if world > 1 or force_sharded:
+            from alaz_amd import sharded
+            res = sharded.bench(a, rank, world, local)
+        else:
+            res = bench_single(a, local)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1 or force_sharded:
