@@ -39,9 +39,10 @@ class H2OutC(C.Structure):
 def load() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(HOST_LIB):
-            raise RuntimeError(f"{HOST_LIB} is missing: build it with `python -m alaz_amd.build`")
-        lib = C.CDLL(HOST_LIB)
+        path = os.environ.get("SG_HOST_LIB_PATH") or HOST_LIB       # override: sanitizer builds (tools/asan_host_tests.sh)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `python -m alaz_amd.build`")
+        lib = C.CDLL(path)
         P, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
         sig = {
             "sgh_packer_create": (P, []), "sgh_packer_destroy": (None, [P]), "sgh_packer_known_ip": (None, [P, u32, C.c_int]),

@@ -180,7 +180,7 @@ static void dyn_evict(or_hpack* d) {                                 /* dynamicT
     size_t k = 0;
     while (d->size > d->max_size && k < d->n) { d->size -= (uint32_t)(d->ents[k].nlen + d->ents[k].vlen + 32); k++; }
     for (size_t i = 0; i < k; i++) field_free(&d->ents[i]);
-    memmove(d->ents, d->ents + k, (d->n - k) * sizeof(hp_field)); d->n -= k;
+    if (k) { memmove(d->ents, d->ents + k, (d->n - k) * sizeof(hp_field)); d->n -= k; }
 }
 static void dyn_add(or_hpack* d, const uint8_t* name, size_t nlen, const uint8_t* value, size_t vlen) {
     if (d->n == d->cap) { d->cap = d->cap ? d->cap * 2 : 16; d->ents = realloc(d->ents, d->cap * sizeof(hp_field)); }

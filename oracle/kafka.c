@@ -600,9 +600,9 @@ or_kafka_result* or_kafka_decode(const uint8_t* payload, size_t size, int method
                 if (m.t[i].parts[j].legacy || m.t[i].parts[j].nil_records) { r = K_PANIC; break; }   /* nil RecordBatch / nil *Record */
     res->status = r;
     if (r == K_OK) {
-        qsort(m.t, m.n, sizeof(ktopic), cmp_topic);
+        if (m.n) qsort(m.t, m.n, sizeof(ktopic), cmp_topic);
         for (size_t i = 0; i < m.n; i++) {
-            qsort(m.t[i].parts, m.t[i].n, sizeof(kpart), cmp_part);
+            if (m.t[i].n) qsort(m.t[i].parts, m.t[i].n, sizeof(kpart), cmp_part);
             for (size_t j = 0; j < m.t[i].n; j++)
                 for (size_t q = 0; q < m.t[i].parts[j].n; q++) {
                     if (res->n == res->cap) { res->cap = res->cap ? res->cap * 2 : 16; res->m = realloc(res->m, res->cap * sizeof(kmsg)); }

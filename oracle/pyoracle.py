@@ -83,7 +83,7 @@ class H2Out(C.Structure):
 
 
 def _load():
-    lib = C.CDLL(build())
+    lib = C.CDLL(os.environ.get("SG_ORACLE_LIB_PATH") or build())   # override: sanitizer builds (tools/asan_host_tests.sh)
     P = C.c_void_p
     sig = {
         "or_create": (P, []), "or_destroy": (None, [P]),
