@@ -214,3 +214,48 @@ def test_packwire_in_place_equals_the_full_copy_path_on_every_protocol():
     (a, la, da), (b, lb, db) = outs
     assert len(a) == len(b) > 6000 and a.tobytes() == b.tobytes() and la == lb and da == db
     assert {int(x) for x in np.unique(a["protocol"])} >= {1, 2, 3, 4, 5, 6}
+
+
+def test_graphds_is_safe_under_concurrent_callers():
+    """the data store is called from arbitrary goroutines / OS threads.  Eight threads ingest wire records (ctypes
+    releases the GIL), one keeps upserting pods and one flushes windows; nothing may be lost or duplicated."""
+    import threading
+    topo = replay.make_topology(40, 300, seed=41)
+    ev, labels = replay.make_events(topo, 16_000, seed=42, mixed=True)
+    kafka = np.where(ev["protocol"] == replay.PROTO_KAFKA, 2, 1).astype(np.uint32)
+    wire = replay.to_wire(ev, labels)
+    g = hostlib.GraphDS(_cfg(nodes=512), engine_lib=None, batch=64)
+    g.apply_ops(topo.k8s_ops())
+    single = hostlib.GraphDS(_cfg(nodes=512), engine_lib=None, batch=64); single.apply_ops(topo.k8s_ops())
+    single.ingest_wire(wire, kafka); single.FlushWindow()
+    want = single.mock_events()
+    chunks = [(wire[i * 2000 * 1096:(i + 1) * 2000 * 1096], kafka[i * 2000:(i + 1) * 2000]) for i in range(8)]
+    stop = threading.Event(); errs = []
+    def feeder(c):
+        try:
+            for j in range(0, 2000, 250):
+                g.ingest_wire(c[0][j * 1096:(j + 250) * 1096], c[1][j:j + 250])
+        except Exception as e:           # pragma: no cover
+            errs.append(e)
+    def churn():
+        k = 0
+        while not stop.is_set():
+            g.PersistPod("churn-%d" % (k % 7), "10.200.0.%d" % (k % 7 + 1), "UPDATE"); k += 1
+    def flusher():
+        while not stop.is_set():
+            g.FlushWindow()
+    ts = [threading.Thread(target=feeder, args=(c,)) for c in chunks] + [threading.Thread(target=churn), threading.Thread(target=flusher)]
+    for t in ts: t.start()
+    for t in ts[:8]: t.join()
+    stop.set()
+    for t in ts[8:]: t.join()
+    g.FlushWindow()
+    got = g.mock_events()
+    assert not errs and len(got) == len(want)
+    # label ids are handed out in first-use order, which depends on the interleaving: compare through the label strings
+    def canon(a, labs):
+        a = a.copy(); names = sorted(set(labs)); rank = {n: i + 1 for i, n in enumerate(names)}
+        a["host_label"] = [rank[labs[int(x) - 1]] if x else 0 for x in a["host_label"]]
+        return np.sort(a.view(np.uint8).reshape(len(a), -1).copy().view([("k", "V32")]).ravel())
+    assert sorted(g.labels) == sorted(single.labels)
+    assert np.array_equal(canon(got, g.labels), canon(want, single.labels))   # the same multiset of packed events, whatever the interleaving
