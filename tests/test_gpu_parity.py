@@ -589,3 +589,32 @@ def test_join_table_builds_and_resolves_at_full_load(pods):
     assert st.events_dropped_src == 0 and st.last_window_events == n and int(rows["count"].sum()) == n
     o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, []); o.window_close(weights.make_weights(1), 1)
     compare_edge_dicts(engine_edge_dict(rows, shim, [], g.outbound_ips()), o.edge_dict())
+
+
+def test_sg_ingest_from_many_threads_into_one_engine():
+    """sg_ingest is called from arbitrary OS threads (cgo).  Six threads feed disjoint slices of one window into
+    ONE engine through the C ABI (ctypes releases the GIL); the window equals the oracle's, nothing lost or counted twice."""
+    import threading
+    topo = replay.make_topology(200, 3000, seed=51)
+    ev, labels = replay.make_events(topo, 120_000, seed=52, mixed=True, with_raw_outbound=True, with_reverse=True)
+    ops = topo.k8s_ops()
+    g = _engine(topo.n_nodes + 8, 4 * len(topo.edge_src) + 1024, 2, max_window_events=len(ev) + 1)
+    shim = HostShim(); shim.apply(g, ops)
+    g.set_label_count(len(labels))
+    errs = []
+    def feed(part):
+        try:
+            for i in range(0, len(part), 3001):
+                while g.ingest(part[i:i + 3001]) != 0:      # SG_EAGAIN: staging ring momentarily full
+                    pass
+        except Exception as e:                               # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=feed, args=(ev[k::6].copy(),)) for k in range(6)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs
+    rows = g.flush_window()
+    o = _oracle(ops, 2); o.packed(ev, labels); o.window_close(weights.make_weights(2), 2)
+    compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
+    st = g.stats()
+    assert st.last_window_events == o.window_events and st.events_dropped_cap == 0
