@@ -386,7 +386,11 @@ static int parse_mysql(oracle_t* o, uint32_t pid, uint64_t fd, uint32_t prep_id,
 
 /* parseMongoEvent — aggregator/data.go:1561-1617.  Slice-out-of-range panics are recovered by the
  * deferred recover() (:1562-1567), which leaves the unnamed results at their zero values
- * ("", nil): the event is then persisted with an empty path.  Returns 0 ok, -1 error. */
+ * ("", nil): the event is then persisted with an empty path.  Returns 0 ok, -1 error.
+ * Bounds are checked against the captured length.  Go reslices (`payload[:4]`, `payload[4:docLen]`) are legal up to the
+ * slice's CAPACITY — the rest of the 1 KiB Payload array — so a capture whose declared lengths exceed the captured bytes
+ * without filling the slot would be parsed by the reference over stale array bytes; that case is not modelled (it needs a
+ * sender that lies about its lengths: a complete short message never has it, a truncated one fills the slot). */
 static int parse_mongo(const uint8_t* p, size_t n, char* out, size_t cap) {
     out[0] = 0;
 #define PANIC_IF(c) do { if (c) { out[0] = 0; return 0; } } while (0)

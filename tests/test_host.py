@@ -259,3 +259,54 @@ def test_graphds_is_safe_under_concurrent_callers():
         return np.sort(a.view(np.uint8).reshape(len(a), -1).copy().view([("k", "V32")]).ravel())
     assert sorted(g.labels) == sorted(single.labels)
     assert np.array_equal(canon(got, g.labels), canon(want, single.labels))   # the same multiset of packed events, whatever the interleaving
+
+
+def _rec(proto, method, payload, *, fd=7, pid=99, prep=0, wt=1000, status=1):
+    from tests.test_oracle_golden import _wire
+    r = bytearray(_wire(0x0A000001, 0x0A000002, proto=proto, method=method, status=status, payload=payload, wt=wt))
+    r[0:8] = fd.to_bytes(8, "little"); r[16:20] = pid.to_bytes(4, "little"); r[1072:1076] = prep.to_bytes(4, "little")
+    return bytes(r)
+
+
+def test_mysql_and_mongo_handlers_match_the_reference_rules():
+    """parseMySQLCommand (aggregator/data.go:1431-1472) and parseMongoEvent (:1561-1617): which events are dropped, and (in the
+    oracle's rows) which path string the reference would have persisted; the C++ packer must keep / drop the same events."""
+    my = lambda cmd, body: (len(body) + 1).to_bytes(3, "little") + b"\x00" + bytes([cmd]) + body
+    def mongo(opcode, body, kind=0):
+        msg = b"\x00" * 4 + bytes([kind]) + body                      # flags, section kind, section
+        return (16 + len(msg)).to_bytes(4, "little") + (1).to_bytes(4, "little") + (0).to_bytes(4, "little") + opcode.to_bytes(4, "little") + msg
+    def doc(name, value, type_=2):
+        el = bytes([type_]) + name + b"\x00" + (len(value) + 1).to_bytes(4, "little") + value + b"\x00"
+        return (4 + len(el) + 1).to_bytes(4, "little") + el + b"\x00"
+    cases = [  # (record, expected path or None when dropped)
+        (_rec(7, 1, my(3, b"SELECT * FROM users")), "SELECT * FROM users"),                     # TEXT_QUERY with a keyword
+        (_rec(7, 1, my(3, b"ping")), None),                                                       # no SQL keyword: dropped
+        (_rec(7, 1, b"\x01\x00\x00"), None),                                                      # shorter than the 5-byte header
+        (_rec(7, 2, my(22, b"INSERT INTO t VALUES (?)"), prep=5), "INSERT INTO t VALUES (?)"),    # PREPARE_STMT: remembered under pid-fd-5
+        (_rec(7, 3, my(23, (5).to_bytes(4, "little") + b"\x00\x01")), "INSERT INTO t VALUES (?)"),  # EXEC_STMT 5 -> the statement
+        (_rec(7, 3, my(23, (6).to_bytes(4, "little"))), "EXECUTE 6 *values*"),                    # unknown statement id
+        (_rec(7, 3, my(23, (5).to_bytes(4, "little")), fd=8), "EXECUTE 5 *values*"),              # other connection
+        (_rec(7, 4, my(25, (5).to_bytes(4, "little"))), "CLOSE STMT 5 "),                         # STMT_CLOSE forgets it
+        (_rec(7, 3, my(23, (5).to_bytes(4, "little"))), "EXECUTE 5 *values*"),
+        (_rec(8, 0, mongo(2013, doc(b"find", b"myCollection"))), "find myCollection"),            # OP_MSG, body section, first element a string
+        (_rec(8, 0, mongo(2012, b"whatever")), "compressed mongo event"),                         # OP_COMPRESSED
+        (_rec(8, 0, mongo(2013, doc(b"find", b"x", type_=16))), None),                            # "document element not a string": dropped
+        (_rec(8, 0, mongo(2004, doc(b"find", b"x"))), None),                                      # other opcode: "could not parse mongo event"
+        (_rec(8, 0, mongo(2013, doc(b"find", b"x"), kind=1)), None),                              # document-sequence section: not parsed
+        (_rec(8, 0, b"\x10\x00\x00\x00short"), ""),                                               # slice out of range -> recover() -> persisted, empty path
+        (_rec(8, 0, mongo(2013, (400).to_bytes(4, "little") + b"\x02find\x00")), ""),             # document longer than the capture: same
+    ]
+    wire = b"".join(r for r, _ in cases)
+    o = pyoracle.Oracle(0, 0, log_limit=100); o.pod("ADD", "p1", "10.0.0.1"); o.pod("ADD", "p2", "10.0.0.2")
+    kept = [want for _, want in cases if want is not None]
+    assert o.l7_wire(wire) == len(kept) and o.dropped_parse == len(cases) - len(kept)
+    assert [r[14] for r in o.reqinfos()] == kept
+    assert [r[10] for r in o.reqinfos()] == ["MYSQL"] * 7 + ["MONGO"] * 4
+    for full in (False, True):
+        pk = hostlib.Packer()
+        ev = pk.pack_wire(wire, full_copy=full)
+        assert len(ev) == len(kept) and pk.dropped_parse == len(cases) - len(kept)
+        assert ev["write_time_ns"].tolist() == [1000] * len(kept) and ev["protocol"].tolist() == [7] * 7 + [8] * 4
+    # keep / drop record by record
+    for rec, want in cases[:3] + cases[9:]:
+        pk = hostlib.Packer(); assert len(pk.pack_wire(rec)) == (want is not None)
