@@ -310,3 +310,24 @@ def test_mysql_and_mongo_handlers_match_the_reference_rules():
     # keep / drop record by record
     for rec, want in cases[:3] + cases[9:]:
         pk = hostlib.Packer(); assert len(pk.pack_wire(rec)) == (want is not None)
+
+
+def test_postgres_handler_keep_and_drop_rules():
+    """parsePostgresCommand (aggregator/data.go:1474-1556) beyond the Parse/Bind known answers of tests/golden/pg_kat.json: simple
+    queries need an SQL keyword, CLOSE_OR_TERMINATE passes its bytes through, unknown extended messages are dropped."""
+    q = lambda s: b"Q" + (len(s) + 5).to_bytes(4, "big") + s + b"\x00"
+    cases = [
+        (_rec(3, 2, q(b"select 1")), "select 1\x00"), (_rec(3, 2, q(b"hello world")), None), (_rec(3, 2, b"Q\x00\x00"), None),
+        (_rec(3, 1, b"X\x00\x00\x00\x04"), "X\x00\x00\x00\x04"),                       # CLOSE_OR_TERMINATE: the payload as it is
+        (_rec(3, 3, b"D\x00\x00\x00\x06P\x00"), None),                                  # Describe in an extended query: not parsed
+        (_rec(3, 3, b"P\x00\x00\x00\x10s9\x00"), "PREPARE s9 AS ..."),                  # Parse cut after the name: two parts, "query too long"
+        (_rec(3, 3, b"P\x00\x00\x00\x10s9"), None),                                     # not even the name's terminator: one part
+        (_rec(3, 0, b"whatever"), ""),                                                  # method Unknown: falls through with ""
+    ]
+    wire = b"".join(r for r, _ in cases)
+    o = pyoracle.Oracle(0, 0, log_limit=100); o.pod("ADD", "p1", "10.0.0.1"); o.pod("ADD", "p2", "10.0.0.2")
+    kept = [w for _, w in cases if w is not None]
+    assert o.l7_wire(wire) == len(kept)
+    assert [r[14] for r in o.reqinfos()] == [w.split("\x00")[0] if "\x00" in w else w for w in kept]     # rows are C strings in the oracle's log
+    pk = hostlib.Packer()
+    assert len(pk.pack_wire(wire)) == len(kept) and pk.dropped_parse == o.dropped_parse == len(cases) - len(kept)
