@@ -16,11 +16,15 @@
 #include <unordered_map>
 #include <vector>
 
+#include "join_host.hpp"
 #include "sg_kernels.h"
 
 namespace {
 
 constexpr int kStageSlots = 4;
+constexpr int kUpdSlots = 4;             // pinned ring for join-table word updates
+constexpr u32 kUpdCap = 1u << 15;         // (word offset, value) pairs per slot = sgjoin::Table::max_dirty
+constexpr size_t kLdsBytes = 160 * 1024;  // per workgroup on gfx950
 
 struct TimingRec { hipEvent_t a, b; int kernel; };
 
@@ -36,16 +40,22 @@ struct sg_engine {
     Dev d{};
     std::vector<void*> allocs;
 
-    // host mirror of the join tables (authoritative; the device table is rebuilt from it)
-    std::unordered_map<u32, u32> pod_ip, svc_ip;
-    std::vector<uint8_t> kind;
+    // join tables: the two reference maps + the word image the kernels read (join_host.hpp).  Mutations are logged as
+    // changed words and shipped to the device copy in stream order (k_join_apply); a whole-image upload only when
+    // the log overflows or a table was rebuilt.
+    sgjoin::Table jt;
+    std::vector<u32> jt_mirror;                      // host mirror (jt.blob)
+    u32* h_blob = nullptr; u32* d_blob = nullptr;    // pinned staging of a whole-image upload, device copy
+    hipEvent_t blob_ev = nullptr;                    // the last whole-image upload has finished reading h_blob
+    uint2* h_upd[kUpdSlots] = {}; uint2* d_upd[kUpdSlots] = {}; hipEvent_t upd_ev[kUpdSlots] = {}; int upd_next = 0;
+    hipEvent_t tab_ev = nullptr, k1_ev = nullptr;    // cross-stream ordering: table modification <-> K1 launches
+    u64 tab_seq = 0;                                 // table modifications so far
+    std::vector<std::pair<hipStream_t, u64>> seen_seq;   // per stream: the modification its K1 launches have been ordered after
+    std::vector<hipStream_t> k1_streams;             // streams with K1 launches since the last table modification
+    hipStream_t tab_stream = nullptr;
     u32 n_known = 0;
-    bool tab_dirty = true;
-    u64* h_iptab = nullptr; u64* d_iptab = nullptr; u32 ipcap = 0;       // main table, then the 'both maps' table (ip2cap entries)
-    u32 ip2cap = 0;
-    uint8_t* h_kind = nullptr; uint8_t* d_kind = nullptr;
-    hipEvent_t tab_ev = nullptr;
-
+    // pass-A launch geometry, follows the table state
+    bool l2_in_lds = false; u32 k1a_ct = 2048;
     // staging ring for sg_ingest()
     sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
     int stage_next = 0;
@@ -63,7 +73,7 @@ struct sg_engine {
     bool use_mfma = true;
     int k1_grid = 0;
     size_t k1a_lds = 0, k1b_lds = 0, k3in_lds = 0;
-    bool ip_lds = false;
+    u32 k1b_threads = 512, k1b_u = 4;
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
@@ -116,49 +126,75 @@ struct Timed {
     ~Timed() { if (on) { hipEventRecord(r.b, s); e->trecs.push_back(r); } }
 };
 
-// rebuild + upload the combined IP table if the host mirror changed (processPod/processSvc analogue)
-int sync_tables(sg_engine* e, hipStream_t s) {
-    if (!e->tab_dirty) return SG_OK;
-    HIP_TRY(e, hipEventSynchronize(e->tab_ev));            // previous upload finished reading h_iptab
-    if (e->slots.size() > 1) HIP_TRY(e, hipDeviceSynchronize());   // other windows in flight still read the old table
-    const size_t tot = (size_t)e->ipcap + e->ip2cap;
-    std::memset(e->h_iptab, 0xFF, tot * sizeof(u64));
-    u64* t1 = e->h_iptab; u64* t2 = e->h_iptab + e->ipcap;
-    // bucketized cuckoo insertion (2 hash functions x 2 entries per bucket), random-walk eviction: a key that
-    // finds both its buckets full takes a random slot of the bucket it was NOT just evicted from, and the
-    // evicted key continues.  (2,2)-cuckoo tables fill to ~0.89; the capacity keeps the load <= 0.8.
-    auto put = [](u64* tab, u32 mask, u32 ip, u32 val) -> bool {
-        const u32 bmask = mask >> 1;
-        u64 cur = (u64)ip | ((u64)val << 32);
-        u32 avoid = 0xFFFFFFFFu;                                       // bucket `cur` was just evicted from
-        u32 rng = sg_fmix32(ip) | 1u;
-        for (int kick = 0; kick < 8192; kick++) {
-            const u32 b1 = ip_h1((u32)cur, bmask), b2 = ip_h2((u32)cur, bmask);
-            for (u32 bb : {b1, b2}) for (int s2 = 0; s2 < 2; s2++) {
-                u64& slot = tab[2 * (size_t)bb + s2];
-                if (slot == SG_IP_EMPTY || (u32)slot == (u32)cur) { slot = cur; return true; }
-            }
-            rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;       // xorshift32
-            const u32 b = (b1 == avoid) ? b2 : (b2 == avoid ? b1 : ((rng & 2u) ? b2 : b1));
-            std::swap(cur, tab[2 * (size_t)b + (rng & 1u)]);
-            avoid = b;
-        }
-        return false;
-    };
-    size_t both = 0; bool ok = true;
-    for (auto& kv : e->pod_ip) {
-        auto sv = e->svc_ip.find(kv.first);
-        if (sv == e->svc_ip.end()) ok &= put(t1, e->ipcap - 1, kv.first, (1u << 30) | kv.second);
-        else if (both < e->ip2cap / 2) { ok &= put(t1, e->ipcap - 1, kv.first, (3u << 30) | sv->second); ok &= put(t2, e->ip2cap - 1, kv.first, (1u << 30) | kv.second); both++; }
-        else ok &= put(t1, e->ipcap - 1, kv.first, (2u << 30) | sv->second);   // second table full: the service mapping wins as destination
+// ---- join tables on the device: the host mirror's changes since the last launch, in stream order ------------------
+// (processPod / processSvc analogue: aggregator/persist.go:55-71, 114-130 — one map write there, a few words here)
+
+// pass-A geometry that follows the table state: does level 2 fit LDS beside the edge cache?
+void k1a_geometry(sg_engine* e) {
+    const Dev& d = e->d;
+    const size_t l1b = (size_t)e->jt.l1_entries * 8, l2b = (size_t)e->jt.blocks_bytes(), fixed = (size_t)d.np * 4 + 64 + l1b;
+    e->l2_in_lds = false; e->k1a_ct = 2048;
+    for (u32 ct : {2048u, 1024u}) {
+        if ((size_t)ct * 40 + fixed + l2b <= kLdsBytes && (l1b + l2b) / 16 <= (size_t)K1A_NJ * K1A_THREADS) { e->l2_in_lds = true; e->k1a_ct = ct; break; }
     }
-    for (auto& kv : e->svc_ip) if (e->pod_ip.find(kv.first) == e->pod_ip.end()) ok &= put(t1, e->ipcap - 1, kv.first, (2u << 30) | kv.second);
-    if (!ok) { e->err = "join table build failed (cuckoo cycle): raise max_ips"; return SG_ENOSPC; }
-    std::memcpy(e->h_kind, e->kind.data(), e->kind.size());
-    HIP_TRY(e, hipMemcpyAsync(e->d_iptab, e->h_iptab, tot * sizeof(u64), hipMemcpyHostToDevice, s));
-    HIP_TRY(e, hipMemcpyAsync(e->d_kind, e->h_kind, e->kind.size(), hipMemcpyHostToDevice, s));
+    if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) e->k1a_ct = x; }
+    if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
+    e->k1a_lds = (size_t)e->k1a_ct * 40 + fixed + (e->l2_in_lds ? l2b : 0);
+}
+// the sizes a K1 launch needs from the table state (pointers are fixed at create)
+void join_view(const sg_engine* e, Dev& d) {
+    d.jl1mask = e->jt.l1_entries - 1;
+    d.jl2_words = e->jt.use_blocks ? e->jt.blocks_used * 256u : 0u;
+    d.ck_n = e->jt.ck_n;
+    d.jstage_bytes = (u32)((size_t)e->jt.l1_entries * 8 + (e->l2_in_lds ? e->jt.blocks_bytes() : 0));
+    d.jl2_in_lds = e->l2_in_lds ? 1u : 0u;
+    d.k1a_ct = e->k1a_ct;
+}
+
+int sync_tables(sg_engine* e, hipStream_t s) {
+    sgjoin::Table& jt = e->jt;
+    if (!jt.need_full && jt.dirty.empty()) return SG_OK;
+    // the modification runs on stream s: after every K1 launch that may still read the tables on another stream
+    for (hipStream_t ks : e->k1_streams) if (ks != s) { HIP_TRY(e, hipEventRecord(e->k1_ev, ks)); HIP_TRY(e, hipStreamWaitEvent(s, e->k1_ev, 0)); }
+    e->k1_streams.clear();
+    if (jt.rebuilds == 0 && !jt.rebuild()) { e->err = "join table build failed: raise max_ips"; return SG_ENOSPC; }
+    if (jt.need_full) {
+        HIP_TRY(e, hipEventSynchronize(e->blob_ev));                 // the previous whole-image upload has finished reading h_blob
+        std::memcpy(e->h_blob, jt.blob, (size_t)jt.L.words * 4);
+        HIP_TRY(e, hipMemcpyAsync(e->d_blob, e->h_blob, (size_t)jt.L.words * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(e, hipEventRecord(e->blob_ev, s));
+        jt.uploaded_full();
+        e->st.join_full_uploads++;
+    } else {
+        std::vector<std::pair<u32, u32>> log;
+        jt.take_dirty(log);
+        // one pair per word (the last value wins): the apply kernel writes them in parallel
+        std::unordered_map<u32, u32> last;
+        last.reserve(log.size() * 2);
+        for (auto& kv : log) last[kv.first] = kv.second;
+        const int slot = e->upd_next; e->upd_next = (slot + 1) % kUpdSlots;
+        HIP_TRY(e, hipEventSynchronize(e->upd_ev[slot]));
+        u32 n = 0;
+        for (auto& kv : last) e->h_upd[slot][n++] = make_uint2(kv.first, kv.second);
+        HIP_TRY(e, hipMemcpyAsync(e->d_upd[slot], e->h_upd[slot], (size_t)n * sizeof(uint2), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_join_apply, dim3((n + 255) / 256), dim3(256), 0, s, e->d_blob, (const uint2*)e->d_upd[slot], n);
+        HIP_TRY(e, hipEventRecord(e->upd_ev[slot], s));
+        e->st.join_word_updates += n;
+    }
     HIP_TRY(e, hipEventRecord(e->tab_ev, s));
-    e->tab_dirty = false;
+    e->tab_seq++; e->tab_stream = s;
+    k1a_geometry(e);
+    return SG_OK;
+}
+// K1 on stream s reads the tables: after the last modification if that ran on another stream
+int order_after_tables(sg_engine* e, hipStream_t s) {
+    if (e->tab_seq) {
+        u64* seen = nullptr;
+        for (auto& kv : e->seen_seq) if (kv.first == s) seen = &kv.second;
+        if (!seen) { e->seen_seq.push_back({s, 0}); seen = &e->seen_seq.back().second; }
+        if (*seen != e->tab_seq) { if (e->tab_stream != s) HIP_TRY(e, hipStreamWaitEvent(s, e->tab_ev, 0)); *seen = e->tab_seq; }
+    }
+    if (std::find(e->k1_streams.begin(), e->k1_streams.end(), s) == e->k1_streams.end()) e->k1_streams.push_back(s);
     return SG_OK;
 }
 
@@ -176,20 +212,26 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     if (n == 0) return SG_OK;
     int rc = sync_tables(e, s);
     if (rc) return rc;
+    if ((rc = order_after_tables(e, s))) return rc;
+    Dev da = e->d;
+    join_view(e, da);
     if (e->d.variant == 0) {
         // single-kernel groups are timed by the dispatch's own begin/end stamps (hipExtLaunchKernel start/stop
         // events): the kernel's duration as rocprofv3 reports it, without the event-record round trip
         const bool tk = (e->timing >> 1) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
-        Dev da = e->d; da.batch_state = e->window_events_in == 0 ? 1u : 0u;     // first batch of this window?
-        if (e->ip_lds) hipExtLaunchKernelGGL(k1a_partition<true>, dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n);
-        else hipExtLaunchKernelGGL(k1a_partition<false>, dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n);
+        da.batch_state = e->window_events_in == 0 ? 1u : 0u;     // first batch of this window?
+        const bool sh = e->d.world > 1;
+#define K1A_GO(L2, SH) hipExtLaunchKernelGGL((k1a_partition<L2, SH>), dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
+        if (e->l2_in_lds) { if (sh) K1A_GO(true, true); else K1A_GO(true, false); }
+        else { if (sh) K1A_GO(false, true); else K1A_GO(false, false); }
+#undef K1A_GO
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 1; e->trecs.push_back(r); }
     } else {
         Timed t(e, s, 1);
         u64 want = (n + 255) / 256;
         int grid = (int)std::min<u64>(want, (u64)e->k1_grid);
-        hipLaunchKernelGGL(k1_resolve_aggregate, dim3(grid), dim3(256), 0, s, e->d, d_ev, (u64)n);
+        hipLaunchKernelGGL(k1_resolve_aggregate, dim3(grid), dim3(256), 0, s, da, d_ev, (u64)n);
     }
     HIP_TRY(e, hipGetLastError());
     e->st.events_in += n;
@@ -197,12 +239,12 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     return SG_OK;
 }
 
-int table_upsert(sg_engine* e, std::unordered_map<u32, u32>& m, u32 ip, u32 node_id, uint8_t kind) {
+int table_upsert(sg_engine* e, bool svc, u32 ip, u32 node_id, uint8_t kind) {
     if (node_id >= e->cfg.max_known_nodes) { e->err = "node_id beyond max_known_nodes"; return SG_ENOSPC; }
-    auto it = m.find(ip);
-    if (it == m.end() && e->pod_ip.size() + e->svc_ip.size() >= e->cfg.max_ips) { e->err = "join table full (max_ips)"; return SG_ENOSPC; }
-    if (it == m.end() || it->second != node_id) { m[ip] = node_id; e->tab_dirty = true; }
-    if (e->kind[node_id] != kind) { e->kind[node_id] = kind; e->tab_dirty = true; }
+    auto& m = svc ? e->jt.svc_ip : e->jt.pod_ip;
+    if (m.find(ip) == m.end() && e->jt.pod_ip.size() + e->jt.svc_ip.size() >= e->cfg.max_ips) { e->err = "join table full (max_ips)"; return SG_ENOSPC; }
+    if (!e->jt.upsert(svc, ip, node_id)) { e->err = "join table build failed: raise max_ips"; return SG_ENOSPC; }
+    e->jt.set_kind(node_id, kind);
     e->n_known = std::max(e->n_known, node_id + 1);
     return SG_OK;
 }
@@ -239,7 +281,8 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         const bool tk = (e->timing >> 7) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
-        hipExtLaunchKernelGGL(k1b_merge, dim3(d.np), dim3(K1B_THREADS), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
+        if (e->k1b_u == 8) hipExtLaunchKernelGGL(k1b_merge<8>, dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
+        else hipExtLaunchKernelGGL(k1b_merge<4>, dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
     }
     {
@@ -322,6 +365,7 @@ int do_reset(sg_engine* e, hipStream_t s) {
     hipLaunchKernelGGL(k_reset_window, dim3(grid_for(std::max<u64>((u64)e->d.ncap * SG_NODE_STAT_SUM_WORDS, e->obcap), 256, 512)), dim3(256), 0, s, e->d);
     HIP_TRY(e, hipGetLastError());
     e->closed = false;
+    e->window_events_in = 0;            // (an open window that is reset is discarded: the next batch is a first batch again)
     return SG_OK;
 }
 
@@ -397,45 +441,68 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     e->ecap = next_pow2(std::max<u64>(2 * ME, K2_TILE));
     e->obcap = next_pow2(std::max<u64>(2 * (u64)cfg->max_outbound_ips, 64));
     e->ob_list_cap = next_pow2(std::max<u64>((u64)cfg->max_outbound_ips * std::max<u32>(cfg->world, 1), 64));
-    e->ipcap = next_pow2(std::max<u64>((u64)e->cfg.max_ips * 5 / 4 + 1, 64));       // cuckoo 2x2: load factor <= 0.8
     d.max_known = cfg->max_known_nodes; d.max_labels = cfg->max_labels; d.max_obip = std::max<u32>(cfg->max_outbound_ips, 1);
     d.rank = cfg->rank; d.world = cfg->world; d.max_edges = ME; d.layers = cfg->layers;
     d.ncap = cfg->max_known_nodes + cfg->max_labels + d.max_obip;
-    d.emask = e->ecap - 1; d.obmask = e->obcap - 1; d.ipmask = e->ipcap - 1;
+    d.emask = e->ecap - 1; d.obmask = e->obcap - 1;
 
-    e->ip2cap = 1024;
-    CR(dev_alloc(e, &e->d_iptab, (size_t)e->ipcap + e->ip2cap, 0xFF));
-    CR(dev_alloc(e, &e->d_kind, cfg->max_known_nodes));
-    d.iptab = e->d_iptab; d.iptab2 = e->d_iptab + e->ipcap; d.ipmask2 = e->ip2cap - 1; d.kind = e->d_kind;
-    CH(hipHostMalloc((void**)&e->h_iptab, ((size_t)e->ipcap + e->ip2cap) * sizeof(u64)));
-    CH(hipHostMalloc((void**)&e->h_kind, cfg->max_known_nodes));
-    e->kind.assign(cfg->max_known_nodes, 0);
     // K1 variant: 0 = partitioned LDS aggregation (fast; bounded edges per partition), 1 = global table + atomics
     if (e->cfg.max_window_events == 0) e->cfg.max_window_events = e->cfg.max_batch;
     d.variant = cfg->k1_variant == 1 ? 1u : 0u;
     {
-        u64 np = next_pow2(std::max<u64>(ME / 160, 64));
-        if (cfg->k1_variant == 0 && np / 2 > 4096) d.variant = 1;       // beyond the partitioned path's range
-        d.np = (u32)std::min<u64>(std::max<u64>(np / 2, 64), 4096); d.nwg = 256; d.pcap = 768;
-        // few edges but many events (a small shard of a busy map): the merge pass must still fill the chip, ~16
-        // records per piece; 256 partitions hold every event count up to the 1 M-per-window class
-        d.np = (u32)std::max<u64>(d.np, std::min<u64>(256, next_pow2(e->cfg.max_window_events / ((u64)d.nwg * 16) + 1) / 2));
+        // partitions: ~500 distinct edges each at the configured capacity (pass B's LDS table has 1024 slots, 768 of
+        // them may fill), at least one per CU; pieces: mean records per (partition, workgroup) with head room, whole lines
+        u64 np = next_pow2(std::max<u64>(ME / 1200, 256));
+        d.k1b_ht = 1024;
+        if (np > 4096) { np = 4096; d.k1b_ht = 2048; }
+        if (cfg->k1_variant == 0 && ME > (u64)4096 * 1400) d.variant = 1;   // beyond the partitioned path's range
+        d.np = (u32)np; d.nwg = 256;
         // tuning overrides (tools/gpu_probe_sweep.sh); anything that is not a legal geometry is ignored
         if (const char* v = std::getenv("SG_NP")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 64 && x <= 4096 && (x & (x - 1)) == 0) d.np = (u32)x; }
+        if (const char* v = std::getenv("SG_HT")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 256 && x <= 2048 && (x & (x - 1)) == 0) d.k1b_ht = (u32)x; }
         if (const char* v = std::getenv("SG_NWG")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= (u64)SG_MAX_K1_WGS) d.nwg = (u32)x; }
+        d.pcap = d.k1b_ht * 3 / 4;
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
-        d.ss = (u32)(2.0 * m + 6.0 * std::sqrt(m + 1.0) + 8.0);
-        d.ss = (d.ss + SG_PIECE_HDR + 7) / 8 * 8 - SG_PIECE_HDR;        // header + first aggregate + ss singles = whole 128-byte lines
-        d.sa = 16;
+        d.ss = (u32)(2.0 * m + 8.0 * std::sqrt(m + 1.0) + 24.0);          // a hot key the cache missed lands in ONE piece: head room, then the overflow list
+        d.sa = std::min<u32>(24, std::max<u32>(8, (2 * 2048 / d.np + 6 + 1) & ~1u));   // aggregates per piece: cache slots / partitions, with head room
+        d.ss = (d.ss + 3 * d.sa + 7) / 8 * 8 - 3 * d.sa;                  // a piece = whole 128-byte lines
+        d.ss = std::min<u32>(d.ss, (1u << 20) - 8);
+        d.pslots = d.ss + 3 * d.sa;
         d.ovf_cap = 1u << 16;
+        e->k1b_threads = d.k1b_ht <= 1024 ? 512u : 1024u;
+        if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; }
+        if (const char* v = std::getenv("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if (x == 256 || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
+    }
+    // join tables: word image (join_host.hpp) on the host, one device copy, a pinned ring for word updates
+    {
+        const u32 max_blocks = d.variant == 0 ? (u32)std::min<u64>(1024, std::max<u64>(64, (u64)e->cfg.max_ips / 32)) : 2u;
+        const sgjoin::Layout L = sgjoin::Table::make_layout(e->cfg.max_ips, cfg->max_known_nodes, max_blocks);
+        e->jt_mirror.assign(L.words, 0);
+        e->jt.init(L, e->jt_mirror.data(), d.variant == 0);
+        e->jt.max_dirty = kUpdCap;
+        CR(dev_alloc(e, &e->d_blob, L.words));
+        CH(hipHostMalloc((void**)&e->h_blob, (size_t)L.words * 4));
+        CH(hipEventCreateWithFlags(&e->blob_ev, hipEventDisableTiming));
+        CH(hipEventCreateWithFlags(&e->k1_ev, hipEventDisableTiming));
+        for (int i = 0; i < kUpdSlots; i++) {
+            CH(hipHostMalloc((void**)&e->h_upd[i], (size_t)2 * kUpdCap * sizeof(uint2)));
+            CR(dev_alloc(e, &e->d_upd[i], (size_t)2 * kUpdCap));
+            CH(hipEventCreateWithFlags(&e->upd_ev[i], hipEventDisableTiming));
+        }
+        d.jl1 = reinterpret_cast<const u64*>(e->d_blob + L.off_l1);
+        d.jl2 = e->d_blob + L.off_l2;
+        d.iptab = reinterpret_cast<const u64*>(e->d_blob + L.off_ck); d.ipmask = L.ipcap - 1;
+        d.iptab2 = reinterpret_cast<const u64*>(e->d_blob + L.off_ck2); d.ipmask2 = L.ip2cap - 1;
+        d.kind = reinterpret_cast<const uint8_t*>(e->d_blob + L.off_kind);
     }
     if (d.variant == 0) {
-        e->ip_lds = e->ipcap <= SG_IP_LDS_MAX;
-        e->k1a_lds = (size_t)K1A_CT * 8 + (size_t)K1A_CT * 32 + (size_t)d.np * 8 + 64 + (e->ip_lds ? (size_t)e->ipcap * 8 : 0);
-        e->k1b_lds = (size_t)K1B_HT * (8 + 32);
-        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
-        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_partition<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1a_lds));
-        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
+        k1a_geometry(e);
+        e->k1b_lds = (size_t)d.k1b_ht * (8 + 32) + (size_t)d.nwg * 4;
+        for (const void* f : {reinterpret_cast<const void*>(k1a_partition<true, true>), reinterpret_cast<const void*>(k1a_partition<true, false>),
+                              reinterpret_cast<const void*>(k1a_partition<false, true>), reinterpret_cast<const void*>(k1a_partition<false, false>)})
+            CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
+        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }
     d.emask = e->ecap - 1;
@@ -451,9 +518,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         size_t eslots = ME;
         if (w.variant == 0) {
             eslots = std::max<size_t>(ME, (size_t)w.np * w.pcap);
-            LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * SG_PIECE_SLOTS(w)));
-            LR(dev_alloc(e, &w.slab_a, (size_t)w.np * w.nwg * w.sa * 5));
+            LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * w.pslots));
+            LR(dev_alloc(e, &w.hdr, (size_t)w.np * w.nwg));
             LR(dev_alloc(e, &w.ovf, (size_t)w.ovf_cap * 5));
+            LR(dev_alloc(e, &w.ovf_p, (size_t)w.ovf_cap));
             LR(dev_alloc(e, &w.part_n, w.np));
             LR(dev_alloc(e, &w.acc_src, (size_t)w.np * w.pcap * 4));
             LR(dev_alloc(e, &w.e_rank, (size_t)w.np * w.pcap));
@@ -524,8 +592,10 @@ int sg_destroy(sg_handle e) {
     hipDeviceSynchronize();
     for (size_t k = 0; k < e->slots.size(); k++) if ((int)k != e->cur && e->slots[k].stream) hipStreamDestroy(e->slots[k].stream);
     for (void* p : e->allocs) hipFree(p);
-    if (e->h_iptab) hipHostFree(e->h_iptab);
-    if (e->h_kind) hipHostFree(e->h_kind);
+    if (e->h_blob) hipHostFree(e->h_blob);
+    for (int i = 0; i < kUpdSlots; i++) { if (e->h_upd[i]) hipHostFree(e->h_upd[i]); if (e->upd_ev[i]) hipEventDestroy(e->upd_ev[i]); }
+    if (e->blob_ev) hipEventDestroy(e->blob_ev);
+    if (e->k1_ev) hipEventDestroy(e->k1_ev);
     for (int i = 0; i < kStageSlots; i++) { if (e->h_stage[i]) hipHostFree(e->h_stage[i]); if (e->stage_ev[i]) hipEventDestroy(e->stage_ev[i]); }
     for (auto& r : e->trecs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto v : e->ev_pool) hipEventDestroy(v);
@@ -538,23 +608,23 @@ int sg_destroy(sg_handle e) {
 int sg_upsert_pod(sg_handle e, uint32_t ip, uint32_t node_id) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    return table_upsert(e, e->pod_ip, ip, node_id, SG_NODE_POD);
+    return table_upsert(e, false, ip, node_id, SG_NODE_POD);
 }
 int sg_upsert_service(sg_handle e, uint32_t ip, uint32_t node_id) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    return table_upsert(e, e->svc_ip, ip, node_id, SG_NODE_SERVICE);
+    return table_upsert(e, true, ip, node_id, SG_NODE_SERVICE);
 }
 int sg_delete_pod(sg_handle e, uint32_t ip) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->pod_ip.erase(ip)) e->tab_dirty = true;
+    if (!e->jt.erase(false, ip)) { e->err = "join table rebuild failed"; return SG_ENOSPC; }
     return SG_OK;
 }
 int sg_delete_service(sg_handle e, uint32_t ip) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    if (e->svc_ip.erase(ip)) e->tab_dirty = true;
+    if (!e->jt.erase(true, ip)) { e->err = "join table rebuild failed"; return SG_ENOSPC; }
     return SG_OK;
 }
 
@@ -863,15 +933,15 @@ int sg_route(sg_handle e, const sg_event* ev, size_t n, uint32_t world, uint32_t
     for (size_t i = 0; i < n; i++) {
         const sg_event& x = ev[i];
         u32 owner;
-        auto sp = e->pod_ip.find(x.saddr);
-        if (sp == e->pod_ip.end()) { shard_out[i] = sg_fmix32(x.saddr) % world; continue; }   // will be dropped wherever it lands
+        auto sp = e->jt.pod_ip.find(x.saddr);
+        if (sp == e->jt.pod_ip.end()) { shard_out[i] = sg_fmix32(x.saddr) % world; continue; }   // will be dropped wherever it lands
         owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, sp->second));
         if ((x.flags & SG_EV_REVERSE) && !(x.flags & SG_EV_ALIVE)) {    // (K1 never reverses an alive record)
-            auto ds = e->svc_ip.find(x.daddr);
-            if (ds != e->svc_ip.end()) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, ds->second));
+            auto ds = e->jt.svc_ip.find(x.daddr);
+            if (ds != e->jt.svc_ip.end()) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, ds->second));
             else {
-                auto dp = e->pod_ip.find(x.daddr);
-                if (dp != e->pod_ip.end()) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, dp->second));
+                auto dp = e->jt.pod_ip.find(x.daddr);
+                if (dp != e->jt.pod_ip.end()) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_KNOWN, dp->second));
                 else if (x.host_label) owner = owner_hash_ref(SG_MAKE_REF(SG_REF_LABEL, x.host_label - 1));
                 else owner = owner_hash_obip(x.daddr);
             }

@@ -19,7 +19,19 @@ typedef uint32_t u32;
 // entry: low 32 bits = IP, high 32 bits = kind << 30 | id; kind 1 = pod, 2 = service, 3 = the IP
 // is in both maps (id = the service; the pod id is in the small second table).  All ones = empty.
 #define SG_IP_EMPTY   (~0ull)
-#define SG_IP_LDS_MAX 4096      // entries (32 KiB): tables up to this size are staged in LDS by K1
+#define SG_IP_LDS_MAX 4096      // entries (32 KiB): a residual cuckoo table up to this size may be staged in LDS by K1
+
+// Join, partitioned K1 (variant 0): a two-level block table in front of the cuckoo table.  Pod CIDRs are dense per
+// node (/24 per kubelet), so most of a cluster's IPs live in few /24 blocks:
+//   level 1  jl1[]: 2-choice hash of the block number b = ip >> 8 -> {tag = b, blk}; u64 entries, all-ones tag = empty;
+//            always staged in LDS (two independent ds_read_b64, no probe loop)
+//   level 2  jl2[blk * 256 + (ip & 255)] = kind << 30 | id, 0 = no such IP; block 0 is the all-zero "null" block a miss
+//            is steered to (no select on the result, no out-of-range read); staged in LDS when it fits beside the
+//            edge cache (C3: 60 blocks = 60 KiB), read from global memory otherwise
+// IPs of blocks that got no level-2 block (sparse /24s, block budget exhausted) stay in the cuckoo table (`iptab`,
+// "residual"); the fast path of k1a_partition hands an event whose block lookup missed to the general path only when
+// that table is not empty.  Variant 1 (global edge table) keeps every IP in the cuckoo table.
+// (hash functions and constants: sg_hash.h, shared with the host-side table builder join_host.hpp)
 
 // device counters (u64 each)
 enum {
@@ -77,6 +89,11 @@ struct Dev {
     const u64* iptab;  u32 ipmask;             // main join table: ipmask + 1 entries = (ipmask + 1) / 2 buckets
     const u64* iptab2; u32 ipmask2;            // pod ids of IPs that are in both maps
     const uint8_t* kind;            // [max_known] SG_NODE_POD / SG_NODE_SERVICE
+    const u64* jl1;  u32 jl1mask;              // block table level 1 (global copy; k1a stages it in LDS)
+    const u32* jl2;  u32 jl2_words;            // block table level 2: jl2_words = blocks * 256 (0 = no block table)
+    u32 ck_n;                                  // IPs in the (residual) cuckoo table iptab; 0 = never probed
+    u32 jstage_bytes;                          // bytes k1a copies into LDS: level 1 (jl1mask + 1 entries), then the used blocks of level 2 if they fit
+    u32 jl2_in_lds;                            // level 2 is part of that
     u32 max_known, max_labels, max_obip;
     u32 rank, world;
     // ---- open window (K1 state) ----
@@ -89,9 +106,14 @@ struct Dev {
     u32 variant;                              // 0 = partitioned (LDS aggregation), 1 = global edge table + atomics
     u32 np, nwg;                              // partitions (power of two), pass-A workgroups
     u32 ss, sa;                               // slab piece capacity: single / aggregate records
-    uint4* slab_s;                            // [np][nwg][4 + ss]  header {n_single, n_agg, 0, 0}, first aggregate (3 slots), singles {key.lo, key.hi, dur.lo, dur.hi | err<<31 | edge-only<<30}
-    u64*   slab_a;                            // [np][nwg][sa][5] the aggregates after a piece's first: {key, cnt|err<<32, sum_ns, max_ns, sumsq_us}
+    u32 pslots;                               // 16-byte slots per piece = ss + 3 * sa
+    uint4* slab_s;                            // [np][nwg][pslots]: slots [0, ss) singles {to, from, dur.lo, dur.hi | err<<31 | edge-only<<30};
+                                              //   slot ss + 3r: aggregate r {key, cnt|err<<32, sum_ns, max_ns, sumsq_us} (40 of 48 bytes)
+    u32*   hdr;                               // [np][nwg] records in piece (p, w): n_single | n_aggregate << 20
+    u32 k1a_ct;                               // pass A: LDS edge-cache slots (power of two; bucket = 2 adjacent slots)
+    u32 k1b_ht;                               // pass B: LDS table slots per partition (power of two)
     u64*   ovf;  u32 ovf_cap;                 // overflow records [ovf_cap][5] (pieces that ran full)
+    u32*   ovf_p;                             // [ovf_cap] partition of each overflow record (pass B filters on 4 bytes, not 40)
     u32*   part_n;                            // [np] distinct edges per partition
     u32 pcap;                                 // edge capacity per partition
     u64*   acc_src;                           // accumulators by slot: eacc (variant 1) or partition output (variant 0)

@@ -3,21 +3,17 @@
 // the per-node dense blocks of K4/K5, which run on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
 #pragma once
 #include "sg_device.h"
+#include "sg_hash.h"
 
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ u32 sg_fmix32(u32 h) {
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
-}
 __device__ __forceinline__ u32 hash_key64(u64 k) { return sg_fmix32((u32)k ^ sg_fmix32((u32)(k >> 32) + 0x9e3779b9u)); }
 
 // owner shard of a node: by its stable ref; OBIP nodes (window-local indices) by their IP.
 __host__ __device__ __forceinline__ u32 owner_hash_ref(u32 ref) { return sg_fmix32(ref); }
 __host__ __device__ __forceinline__ u32 owner_hash_obip(u32 ip) { return sg_fmix32(ip ^ 0xA5A5F00Du); }
 
-__host__ __device__ __forceinline__ u32 ip_h1(u32 ip, u32 bmask) { return sg_fmix32(ip) & bmask; }
-__host__ __device__ __forceinline__ u32 ip_h2(u32 ip, u32 bmask) { return sg_fmix32(ip ^ 0x7F4A7C15u) & bmask; }
 
 // two independent bucket reads; t may point to LDS (staged copy) or to global memory
 __device__ __forceinline__ u64 ip_probe(const u64* t, u32 mask, u32 ip) {
@@ -31,15 +27,12 @@ __device__ __forceinline__ u64 ip_probe(const u64* t, u32 mask, u32 ip) {
     e = ((u32)b.y == ip && b.y != SG_IP_EMPTY) ? b.y : e;
     return e;
 }
-__device__ __forceinline__ bool ip_lookup(const u64* t, u32 mask, const u64* __restrict__ t2, u32 mask2, u32 ip, u32& pod, u32& svc) {
-    const u64 e = ip_probe(t, mask, ip);
-    if (e == SG_IP_EMPTY) return false;
-    const u32 v = (u32)(e >> 32), kind = v >> 30, id = v & 0x3FFFFFFFu;
-    if (kind == 1) pod = id;
-    else if (kind == 2) svc = id;
-    else { svc = id; const u64 e2 = ip_probe(t2, mask2, ip); if (e2 != SG_IP_EMPTY) pod = (u32)(e2 >> 32) & 0x3FFFFFFFu; }
-    return true;
-}
+
+// A fresh read of an LDS word other lanes may be writing.  (Not `volatile`: a volatile access through a pointer the
+// compiler has to infer the address space of stays a FLAT load — flat_load_dwordx2 sc0 sc1 plus s_waitcnt vmcnt(0),
+// which also drains every global store in flight.)
+__device__ __forceinline__ u64 lds_fresh_u64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ u32 lds_fresh_u32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // find-or-insert in an open-addressing u64 key table.  A plain load may return a stale EMPTY (the
 // XCD L2s are not coherent); every EMPTY observation is confirmed by the device-scope CAS, and a
@@ -169,12 +162,32 @@ __device__ __forceinline__ u32 owner_of_dense(const Dev& d, u32 v, u32 nk, u32 n
 // (aggregator/data.go:1760-1767, 827-870; datastore/dto.go:226-231; backend.go:819-847).
 // Algorithmic bytes: 32 per event read + 32 per distinct edge written.
 // ------------------------------------------------------------------------------------------------
-struct K1Local { u64 tmin, tmax; u32 maxlabel, dsrc, dcap, misr, acc; };
+struct K1Local { u64 tmin, tmax; u32 maxlabel, dsrc, dcap, misr, acc, lost; };   // lost: accepted by a lane of this workgroup, then dropped for capacity
 struct K1Ev { u64 key, dur, wt; u32 err; u32 alive; };
 #define SG_DUR_MAX ((1ull << 62) - 1)      // durations saturate here: bits 62/63 of a single record carry flags
 
-// the join: one event -> edge key, or a counted drop.
-__device__ __forceinline__ bool k1_resolve(const Dev& d, const u64* iptab, const uint4 a, const uint4 b, K1Local& L, K1Ev& e) {
+// ---- the join, general form: block table (global copy), then the cuckoo table.  Returns kind << 30 | id, 0 = unknown IP;
+// kind 3 = the IP is in both reference maps (id = the service; the pod id is in the small second table).
+__device__ __forceinline__ u32 join_general(const Dev& d, u32 ip) {
+    if (d.jl2_words) {
+        const u32 b = ip >> 8;
+        const u64 e1 = d.jl1[jl1_h1(b, d.jl1mask)], e2 = d.jl1[jl1_h2(b, d.jl1mask)];
+        const u32 blk = (u32)e1 == b ? (u32)(e1 >> 32) : ((u32)e2 == b ? (u32)(e2 >> 32) : 0u);
+        const u32 v = d.jl2[(blk << 8) | (ip & 255u)];
+        if (v) return v;
+    }
+    if (d.ck_n) { const u64 e = ip_probe(d.iptab, d.ipmask, ip); if (e != SG_IP_EMPTY) return (u32)(e >> 32); }
+    return 0u;
+}
+__device__ __forceinline__ void join_pod_svc(const Dev& d, u32 ip, u32& pod, u32& svc) {
+    const u32 v = join_general(d, ip), kind = v >> 30, id = v & 0x3FFFFFFFu;
+    if (kind == 1) pod = id;
+    else if (kind == 2) svc = id;
+    else if (kind == 3) { svc = id; const u64 e2 = ip_probe(d.iptab2, d.ipmask2, ip); if (e2 != SG_IP_EMPTY) pod = (u32)(e2 >> 32) & 0x3FFFFFFFu; }
+}
+
+// the join of one event, general form: edge key, or a counted drop.
+__device__ __forceinline__ bool k1_resolve(const Dev& d, const uint4 a, const uint4 b, K1Local& L, K1Ev& e) {
     const u32 saddr = a.x, daddr = a.y;
     const u32 status = a.w & 0xFFFFu, proto = (a.w >> 16) & 0xFFu, flags = a.w >> 24;
     const bool alive = (flags & SG_EV_ALIVE) != 0;                // an open connection, not a request (data.go:1628-1679)
@@ -184,16 +197,16 @@ __device__ __forceinline__ bool k1_resolve(const Dev& d, const u64* iptab, const
     e.alive = alive ? 1u : 0u;
 
     u32 spod = SG_NONE, ssvc = SG_NONE;
-    const bool sf = ip_lookup(iptab, d.ipmask, d.iptab2, d.ipmask2, saddr, spod, ssvc);
-    if (!sf || spod == SG_NONE) { if (!alive) L.dsrc++; return false; }   // data.go:829-832: source must be a pod (:1643-1647 ignores silently)
+    join_pod_svc(d, saddr, spod, ssvc);
+    if (spod == SG_NONE) { if (!alive) L.dsrc++; return false; }   // data.go:829-832: source must be a pod (:1643-1647 ignores silently)
     u32 from = SG_MAKE_REF(SG_REF_KNOWN, spod);
     const bool sharded = d.world > 1;
     u32 from_owner = sharded ? owner_hash_ref(from) : 0u;
 
     u32 dpod = SG_NONE, dsvc = SG_NONE, to, to_owner;
-    const bool df = ip_lookup(iptab, d.ipmask, d.iptab2, d.ipmask2, daddr, dpod, dsvc);
-    if (df && dsvc != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dsvc); to_owner = sharded ? owner_hash_ref(to) : 0u; }       // service first (:840-843)
-    else if (df && dpod != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dpod); to_owner = sharded ? owner_hash_ref(to) : 0u; }  // then pod (:845-849)
+    join_pod_svc(d, daddr, dpod, dsvc);
+    if (dsvc != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dsvc); to_owner = sharded ? owner_hash_ref(to) : 0u; }       // service first (:840-843)
+    else if (dpod != SG_NONE) { to = SG_MAKE_REF(SG_REF_KNOWN, dpod); to_owner = sharded ? owner_hash_ref(to) : 0u; }  // then pod (:845-849)
     else if (label != 0) {                                       // outbound, Host header (:851-854)
         if (label > d.max_labels) { L.dcap++; return false; }
         to = SG_MAKE_REF(SG_REF_LABEL, label - 1); to_owner = owner_hash_ref(to);
@@ -234,17 +247,23 @@ __device__ __forceinline__ void k1_publish_stats(const Dev& d, const K1Local& L)
     }
 }
 
+// join-table maintenance: the host's changed words, applied in stream order (one pair per word)
+__global__ __launch_bounds__(256) void k_join_apply(u32* blob, const uint2* __restrict__ upd, u32 n) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) blob[upd[i].x] = upd[i].y;
+}
+
 // ---- variant 1: global open-addressing edge table + device-scope atomics.  General (any number
 // of edges, any degree) but bound by the chip's ~22 G atomics/s and 12 ns per same-sector atomic
 // (profiles/r01_atomic_probe.txt): kept for graphs the partitioned path cannot hold. ----------------
 __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_event* __restrict__ ev, u64 n) {
-    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
+    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = L.lost = 0;
     const uint4* __restrict__ p = reinterpret_cast<const uint4*>(ev);
     const u64 stride = (u64)gridDim.x * 256;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const uint4 a = p[2 * i], b = p[2 * i + 1];
         K1Ev e;
-        if (!k1_resolve(d, d.iptab, a, b, L, e)) continue;
+        if (!k1_resolve(d, a, b, L, e)) continue;
         u32 slot;
         if (!table_slot(d.ekeys, d.emask, e.key, SG_EKEY_EMPTY, hash_key64(e.key) & d.emask, slot)) { if (!e.alive) { L.dcap++; L.acc--; } continue; }
         if (e.alive) continue;                                       // the slot exists now (count 0): that is all an open connection adds here
@@ -258,200 +277,273 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
     k1_publish_stats(d, L);
 }
 
-// ---- variant 0: partitioned aggregation, no device-scope atomics on the data path. ---------------
-// Pass A (k1a_partition): each workgroup streams its contiguous share of the batch in chunks of
-// 1024 events, aggregates a chunk in an LDS hash table (LDS atomics), then sweeps the table and
-// appends one record per distinct edge to the slab piece [partition(edge)][this workgroup]:
-// 16 bytes if the edge was hit once in the chunk, 40 bytes otherwise.  Hot edges collapse here, so
-// partitions stay balanced; the long tail passes through as 16-byte singles.
-// Pass B (k1b_merge, at window close): workgroup p owns partition p exclusively, merges its pieces
-// in LDS and writes each distinct edge once with plain stores.
+// ---- variant 0: partitioned aggregation, no device-scope atomics on the event path. --------------
+// Pass A (k1a_partition, per batch): one fat workgroup per CU streams a contiguous share of the batch.  Every event is
+// joined against the LDS copy of the block table, its edge key hashed, and looked up in a first-come LDS cache; a cached
+// key folds in with LDS atomics (hot edges collapse to one 40-byte aggregate per workgroup, which also keeps the
+// partitions balanced: the hottest edge of C3 alone carries 1.3 % of the events), everything else leaves as a 16-byte
+// single record for partition hash(key) / 2^k, into the piece (partition, this workgroup) — private to the workgroup, so
+// the position inside it is an LDS counter.
+// Pass B (k1b_merge, at window close): one workgroup per partition merges its pieces in an LDS table and writes each
+// distinct edge once with plain stores.
 #define K1A_THREADS 1024
-#define K1A_CT      2048      // LDS cache slots per workgroup
 #define K1A_G       4         // events per thread per step
-#define K1B_HT      1024
-#define K1B_THREADS 1024
-#define K1B_LPP     4        // lanes per piece
-#define K1B_U       4
+#define K1A_NJ      6         // 16-byte join-blob words a thread stages into LDS (6 * 1024 * 16 B = 96 KiB at most)
 
 // Issue a global load NOW and leave it in flight; a later s_waitcnt (inline asm that names the
 // destination registers as in/out operands) is the matching wait.  Written as inline asm because the
-// compiler sinks a speculative load below the branch that makes its use conditional (k1b_merge:
-// header -> test -> records became two dependent round trips) and puts waits between conditional
-// loads.  vmcnt is in-order for loads, so the compiler's own (unaware) waits can only become
-// stronger, never too weak.  Rule: no loop-carried value and no branch merge between an issue and
-// its wait (a compiler-inserted register copy there would read a register that is still being loaded).
+// compiler puts waits between conditional loads.  vmcnt is in-order for loads, so the compiler's own
+// (unaware) waits can only become stronger, never too weak.  Rule: no loop-carried value and no branch
+// merge between an issue and its wait (a compiler-inserted register copy there would read a register that
+// is still being loaded).
 typedef u32 v4u_t __attribute__((ext_vector_type(4)));
 typedef u32 v2u_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gload16_issue(v4u_t& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory"); }
-__device__ __forceinline__ void gload8_issue(v2u_t& dst, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory"); }
 
-__device__ __forceinline__ u32 part_of_hash(const Dev& d, u32 hk) { return (hk >> 11) & (d.np - 1); }
-__device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return part_of_hash(d, hash_key64(key)); }
+// Edge-key hash of both passes: 24-bit multiplies (full rate; a murmur finaliser is 4 quarter-rate 32-bit multiplies per
+// key).  Node refs are small integers plus two type bits at the top: the low 24 bits go through the multipliers, the two
+// top bytes through a third.  The partition is taken from the top bits (they depend on every input bit), cache bucket
+// and pass-B table slot from lower bit ranges.  Balance on the C3 graph (1 M edges, 1024 partitions): sigma 29.7 edges
+// against 31.3 for a Poisson split — indistinguishable from the finaliser.
+__device__ __forceinline__ u32 edge_hash(u32 from, u32 to) {
+    u32 x = __umul24(from, 0x9E3779u) + __umul24(to, 0x85EBCBu);
+    x += __umul24((from >> 24) | ((to >> 24) << 8), 0xC2B2AFu);
+    return __umul24(x >> 8, 0x27D4EBu);
+}
+__device__ __forceinline__ u32 part_of_hash(const Dev& d, u32 hk) { return hk >> (32u - (u32)__builtin_ctz(d.np)); }
+__device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return part_of_hash(d, edge_hash((u32)(key >> 32), (u32)key)); }
 
-__device__ __forceinline__ void ovf_append(const Dev& d, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
+__device__ __forceinline__ void ovf_append(const Dev& d, u32 p, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
     const u64 idx = atomicAdd(&d.ctr[C_OVF_N], 1ull);
-    if (idx < d.ovf_cap) { u64* o = d.ovf + idx * 5; o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; }
-    else { const u32 c = (u32)(a0 & 0xFFFFFFFFull); L.dcap += c; L.acc -= c; }
+    if (idx < d.ovf_cap) { u64* o = d.ovf + idx * 5; o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; d.ovf_p[idx] = p; }
+    else { const u32 c = (u32)(a0 & 0xFFFFFFFFull); L.dcap += c; L.lost += c; }     // (the aggregate may carry other lanes' events: not L.acc -= c)
 }
+// exact for every 32-bit duration: floor(x / 1000) = (x * 0x10624DD3) >> 38
+__device__ __forceinline__ u32 div1000_u32(u32 x) { return __umulhi(x, 0x10624DD3u) >> 6; }
 
-// Slab geometry: piece (p, w) = records workgroup w produced for partition p, SG_PIECE_SLOTS 16-byte slots:
-//   slot 0      header {n_single, n_aggregate, 0, 0}
-//   slots 1..3  the piece's FIRST aggregate record {key, cnt | err<<32, sum_ns, max_ns, sumsq_us} (40 of 48 bytes)
-//   slots 4..   ss single records {key.lo, key.hi, dur.lo, dur.hi | err << 31 | edge-only << 30}
-//   slab_a[(p*nwg + w) * sa + r - 1] : the piece's aggregates r >= 1 (rare)
-// Header, first aggregate and the first four singles share one 128-byte line; pass B reads a piece's header, first
-// aggregate and first 16 singles in one round without touching slab_a.
-#define SG_PIECE_HDR 4u
-#define SG_PIECE_SLOTS(d) ((d).ss + SG_PIECE_HDR)
-__device__ __forceinline__ uint4* piece_of(const Dev& d, u32 p, u32 w) { return d.slab_s + ((size_t)p * d.nwg + w) * SG_PIECE_SLOTS(d); }
+// piece (p, w): pslots 16-byte slots; fc[p] = n_single | n_aggregate << 20 is this workgroup's LDS counter for it
+__device__ __forceinline__ uint4* piece_of(const Dev& d, u32 p, u32 w) { return d.slab_s + ((size_t)p * d.nwg + w) * d.pslots; }
+#define K1_NS(x) ((x) & 0xFFFFFu)
+#define K1_NA(x) ((x) >> 20)
 // zero = 1: a record that only creates the edge (SG_EV_ALIVE): count 0, all accumulators 0
-__device__ __forceinline__ void emit_single(const Dev& d, u32* fS, u32 w, u32 hk, u64 key, u64 dur, u32 err, K1Local& L, u32 zero = 0) {
-    const u32 p = part_of_hash(d, hk);
-    const u32 pos = atomicAdd(&fS[p], 1u);
-    if (pos < d.ss) piece_of(d, p, w)[SG_PIECE_HDR + pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31) | (zero << 30));
-    else if (zero) ovf_append(d, key, 0ull, 0ull, 0ull, 0ull, L);
-    else { const u64 us = dur / 1000ull; ovf_append(d, key, 1ull | ((u64)err << 32), dur, dur, us * us, L); }
-}
-__device__ __forceinline__ void emit_agg(const Dev& d, u32* fA, u32 w, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
-    const u32 p = part_of(d, key);
-    const u32 pos = atomicAdd(&fA[p], 1u);
-    if (pos < d.sa) {
-        u64* o = pos == 0 ? reinterpret_cast<u64*>(piece_of(d, p, w) + 1) : d.slab_a + (((size_t)p * d.nwg + w) * d.sa + pos - 1) * 5;
-        o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3;
+__device__ __forceinline__ void emit_single(const Dev& d, u32* fc, u32 w, u32 p, u64 key, u64 dur, u32 err, K1Local& L, u32 zero = 0) {
+    const u32 pos = K1_NS(atomicAdd(&fc[p], 1u));
+    if (pos < d.ss) { if (!(d.ablate & 0x1u)) piece_of(d, (d.ablate & 0x40u) ? (p & 63u) : p, w)[pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31) | (zero << 30)); }
+    else {
+        atomicSub(&fc[p], 1u);                                       // the count stays exact (and below 2^20)
+        if (zero) ovf_append(d, p, key, 0ull, 0ull, 0ull, 0ull, L);
+        else { const u64 us = dur / 1000ull; ovf_append(d, p, key, 1ull | ((u64)err << 32), dur, dur, us * us, L); }
     }
-    else ovf_append(d, key, a0, a1, a2, a3, L);
+}
+// One aggregate of this launch's cache for piece (p, w).  A hot key produces one per launch and workgroup — always for the
+// same piece — so in a window fed by many small batches the aggregates of EARLIER launches are searched first (they are the
+// entries below the count the header held when this launch began; the piece is private to this workgroup and a key is flushed
+// by exactly one lane, so the read-modify-write needs no atomics) and a match is updated in place.
+__device__ __forceinline__ void emit_agg(const Dev& d, u32* fc, u32 w, u32 p, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L, bool first) {
+    uint4* ag = piece_of(d, p, w) + d.ss;
+    if (!first) {
+        u32 na0 = K1_NA(d.hdr[(size_t)p * d.nwg + w]); na0 = na0 < d.sa ? na0 : d.sa;
+        for (u32 r = 0; r < na0; r++) {
+            uint4* o = ag + 3 * r;
+            const uint4 y0 = o[0];
+            if (y0.x != (u32)key || y0.y != (u32)(key >> 32)) continue;
+            const uint4 y1 = o[1]; const uint2 y2 = reinterpret_cast<const uint2*>(o + 2)[0];
+            const u64 b0 = ((u64)y0.z | ((u64)y0.w << 32)) + a0, b1 = ((u64)y1.x | ((u64)y1.y << 32)) + a1;
+            u64 b2 = (u64)y1.z | ((u64)y1.w << 32); b2 = a2 > b2 ? a2 : b2;
+            const u64 b3 = ((u64)y2.x | ((u64)y2.y << 32)) + a3;
+            o[0] = make_uint4(y0.x, y0.y, (u32)b0, (u32)(b0 >> 32));
+            o[1] = make_uint4((u32)b1, (u32)(b1 >> 32), (u32)b2, (u32)(b2 >> 32));
+            reinterpret_cast<uint2*>(o + 2)[0] = make_uint2((u32)b3, (u32)(b3 >> 32));
+            return;
+        }
+    }
+    const u32 pos = K1_NA(atomicAdd(&fc[p], 1u << 20));
+    if (pos < d.sa) {
+        uint4* o = ag + 3 * pos;
+        o[0] = make_uint4((u32)key, (u32)(key >> 32), (u32)a0, (u32)(a0 >> 32));
+        o[1] = make_uint4((u32)a1, (u32)(a1 >> 32), (u32)a2, (u32)(a2 >> 32));
+        reinterpret_cast<uint2*>(o + 2)[0] = make_uint2((u32)a3, (u32)(a3 >> 32));
+    } else { atomicSub(&fc[p], 1u << 20); ovf_append(d, p, key, a0, a1, a2, a3, L); }
 }
 
-// Pass A.  One fat workgroup per CU streams a contiguous share of the batch with no barrier in the
-// loop.  Each event is resolved (join table staged in LDS when IPLDS) and looked up in a
-// first-come LDS cache (2 probes): the first key to claim a slot owns it for the whole launch and
-// every later event of that key is folded in with LDS atomics; an event whose slots are taken by
-// other keys bypasses the cache as a 16-byte single record.  Hot edges appear early, claim their
-// slots and collapse to one aggregate record per workgroup; the long tail streams through.
-template <bool IPLDS>
+// LDS edge cache of pass A: CT slots, a bucket = two adjacent key slots (one ds_read_b128 sees both).  The first two
+// keys to arrive at a bucket own it for the launch (a slot never changes once it holds a key; every lane tries slot 0
+// before slot 1, so a key cannot end up in both).  k0, k1: what the caller read from the bucket.  Returns the slot of
+// `key`, or -1 (bucket owned by other keys).
+__device__ __forceinline__ int cache_claim(u64* ckey, u32 bucket, u64 key, u64 k0, u64 k1) {
+    if (k0 == SG_EKEY_EMPTY) { k0 = atomicCAS(&ckey[2 * bucket], SG_EKEY_EMPTY, key); if (k0 == SG_EKEY_EMPTY) k0 = key; }
+    if (k0 == key) return (int)(2 * bucket);
+    if (k1 == SG_EKEY_EMPTY) { k1 = atomicCAS(&ckey[2 * bucket + 1], SG_EKEY_EMPTY, key); if (k1 == SG_EKEY_EMPTY) k1 = key; }
+    return k1 == key ? (int)(2 * bucket + 1) : -1;
+}
+
+template <bool L2LDS, bool SHARDED>
 __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_event* __restrict__ ev, u64 n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* ckey = reinterpret_cast<u64*>(smem);                       // [K1A_CT]
-    u64* cacc = ckey + K1A_CT;                                       // [K1A_CT][4]
-    u32* fS = reinterpret_cast<u32*>(cacc + K1A_CT * 4);             // [np]
-    u32* fA = fS + d.np;                                             // [np]
-    u64* red = reinterpret_cast<u64*>(fA + d.np);                    // [8] workgroup statistics (WS_* order)
-    u64* ipl = red + 8;                                              // [ipmask + 1] when IPLDS
+    const u32 CT = d.k1a_ct;
+    u64* ckey = reinterpret_cast<u64*>(smem);                       // [CT]
+    u64* cacc = ckey + CT;                                           // [CT][4]
+    u32* fc = reinterpret_cast<u32*>(cacc + (size_t)CT * 4);         // [np]  n_single | n_aggregate << 20
+    u64* red = reinterpret_cast<u64*>(fc + d.np);                    // [8] workgroup statistics (WS_* order)
+    uint4* jl = reinterpret_cast<uint4*>(red + 8);                   // LDS copy of the join blob: jl1 | jl2 (L2LDS) | residual cuckoo (ck_in_lds)
+    const u64* l1 = reinterpret_cast<const u64*>(jl);
+    const u32* l2 = L2LDS ? reinterpret_cast<const u32*>(l1 + d.jl1mask + 1) : d.jl2;
     const u32 w = blockIdx.x, t = threadIdx.x;
     const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
     const u64 per = (n + d.nwg - 1) / d.nwg;
     const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
-    const bool first = d.batch_state == 1u;                          // first batch of the window: headers are zero by definition
+    const bool first = d.batch_state == 1u;                          // first batch of the window: the headers are zero by definition
     if (beg >= end) {                                                // no share of this batch: pieces and statistics stay as they are,
-        if (first) for (u32 p = t; p < d.np; p += K1A_THREADS) *piece_of(d, p, w) = make_uint4(0, 0, 0, 0);   // but stale headers must go
+        if (first) for (u32 p = t; p < d.np; p += K1A_THREADS) d.hdr[(size_t)p * d.nwg + w] = 0u;   // but stale headers must go
         return;
     }
     const u64 last = end - 1;
     SG_STAMP(d, 0, 0);
-    // K1A_G events per thread are fetched together (8 x 16 B in flight per lane).  Loads return in issue
-    // order, so the small set-up loads (join table, this workgroup's piece headers) go out first, the
-    // first event group right behind them; the LDS set-up then waits for the set-up loads only
-    // (vmcnt(8): the eight event loads stay in flight).  Out-of-range lanes re-read the share's last
-    // event and ignore it, so there is no branch between the loads.
-    static_assert(K1A_G == 4 && SG_IP_LDS_MAX / K1A_THREADS == 4, "written out for 4 event pairs and 4 table words per lane");
+    static_assert(K1A_G == 4, "the event loads and the fold are written out for 4 events per lane");
     u64 i = beg + t;
+    // K1A_G events per thread are fetched together (8 x 16 B in flight per lane); out-of-range lanes re-read the
+    // share's last event and ignore it, so there is no branch between the loads.
 #define K1A_ISSUE(base)                                                                                           \
         { const u64 j0 = (base), j1 = j0 + K1A_THREADS, j2 = j1 + K1A_THREADS, j3 = j2 + K1A_THREADS;               \
           const uint4* q0 = pe + 2 * (j0 < end ? j0 : last); const uint4* q1 = pe + 2 * (j1 < end ? j1 : last);     \
           const uint4* q2 = pe + 2 * (j2 < end ? j2 : last); const uint4* q3 = pe + 2 * (j3 < end ? j3 : last);     \
           gload16_issue(ea0, q0); gload16_issue(eb0, q0 + 1); gload16_issue(ea1, q1); gload16_issue(eb1, q1 + 1);   \
           gload16_issue(ea2, q2); gload16_issue(eb2, q2 + 1); gload16_issue(ea3, q3); gload16_issue(eb3, q3 + 1); }
-    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = 0;
-    const u64* iptab = IPLDS ? ipl : d.iptab;
-    auto resolve = [&](const u64 idx, const v4u_t va, const v4u_t vb, K1Ev& e) -> bool {
-        if (idx >= end) return false;
-        const uint4 ca = make_uint4(va.x, va.y, va.z, va.w), cb = make_uint4(vb.x, vb.y, vb.z, vb.w);
-        return k1_resolve(d, iptab, ca, cb, L, e);
-    };
-    auto insert = [&](const K1Ev& e) {
-        const u32 hk = hash_key64(e.key);
-        if (e.alive) { emit_single(d, fS, w, hk, e.key, 0ull, 0u, L, 1u); return; }
-        u32 h = hk & (K1A_CT - 1);
-        int slot = -1;
-#pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-            u64 k = ((volatile u64*)ckey)[h];
-            if (k == SG_EKEY_EMPTY) { k = atomicCAS(&ckey[h], SG_EKEY_EMPTY, e.key); if (k == SG_EKEY_EMPTY) k = e.key; }
-            if (k == e.key) { slot = (int)h; break; }
-            h = (h + 1) & (K1A_CT - 1);
-        }
+    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = L.lost = 0;
+    const u32 pshift = 32u - (u32)__builtin_ctz(d.np), bmask = CT / 2 - 1;
+    const bool ck_any = d.ck_n != 0;
+
+    // The general path (rare events: open connections, raw-IP outbound destinations, IPs in both maps or in the residual
+    // cuckoo table, durations of 2^32 ns and more, labels out of range): the full join on the global tables.
+    auto general = [&](const v4u_t va, const v4u_t vb) {
+        K1Ev e;
+        if (!k1_resolve(d, make_uint4(va.x, va.y, va.z, va.w), make_uint4(vb.x, vb.y, vb.z, vb.w), L, e)) return;
+        const u32 hk = edge_hash((u32)(e.key >> 32), (u32)e.key), p = hk >> pshift;
+        if (e.alive) { emit_single(d, fc, w, p, e.key, 0ull, 0u, L, 1u); return; }
+        const u32 bkt = (hk >> 5) & bmask;
+        const int slot = cache_claim(ckey, bkt, e.key, lds_fresh_u64(&ckey[2 * bkt]), lds_fresh_u64(&ckey[2 * bkt + 1]));
         if (slot >= 0) {
             const u64 us = e.dur / 1000ull;
             atomicAdd(&cacc[slot * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&cacc[slot * 4 + 1], e.dur);
             atomicMax(&cacc[slot * 4 + 2], e.dur); atomicAdd(&cacc[slot * 4 + 3], us * us);
-        } else emit_single(d, fS, w, hk, e.key, e.dur, e.err, L);
+        } else emit_single(d, fc, w, p, e.key, e.dur, e.err, L);
     };
-    // One copy of the per-event code, run four times (not unrolled): the kernel body is executed once
-    // per workgroup, so every instruction is an instruction-cache miss the first time through, and
-    // four inlined copies of the join cost more in fetch stalls than the loop does in selects.
+    // The fast path, one event: branch-free join (two-level block table in LDS), data.go:827-870 as selects, cheap hash,
+    // read-only cache probe.  `rare` hands the event to the general path instead.
+    auto join = [&](u32 ip) -> u32 {
+        const u32 b = ip >> 8;
+        const u64 e1 = l1[((__umul24(b, SG_JL1_K1)) >> 9) & d.jl1mask], e2 = l1[((__umul24(b, SG_JL1_K2)) >> 11) & d.jl1mask];
+        const u32 blk = (u32)e1 == b ? (u32)(e1 >> 32) : ((u32)e2 == b ? (u32)(e2 >> 32) : 0u);     // block 0 = the all-zero block
+        return l2[(blk << 8) | (ip & 255u)];
+    };
+#define K1A_FAST(idx, va, vb, rare_out)                                                                             \
+        {   const bool inr = (idx) < end;                                                                           \
+            const u32 flags = (va).w >> 24, label = (va).z;                                                         \
+            const u32 vs = join((va).x), vd = join((va).y);                                                         \
+            const u32 ks = vs >> 30, kd = vd >> 30;                                                                 \
+            bool rare = ((flags & SG_EV_ALIVE) != 0) | (ks == 3u) | (kd == 3u) | ((vb).y != 0u) |                   \
+                        ((kd == 0u) & ((label == 0u) | (label > d.max_labels))) | (ck_any & ((vs == 0u) | (vd == 0u))); \
+            rare &= inr; (rare_out) = rare;                                                                         \
+            const bool fastv = inr & !rare;                                                                         \
+            bool acc = fastv & (ks == 1u);                           /* data.go:829-832: the source must be a pod */ \
+            L.dsrc += (fastv & (ks != 1u)) ? 1u : 0u;                                                               \
+            u32 from = vs & 0x3FFFFFFFu;                                                                            \
+            u32 to = kd ? (vd & 0x3FFFFFFFu) : (SG_MAKE_REF(SG_REF_LABEL, label - 1u));   /* service / pod id, else Host label (:840-854) */ \
+            { const u32 ml = (acc & (kd == 0u)) ? label : 0u; L.maxlabel = ml > L.maxlabel ? ml : L.maxlabel; }     \
+            if (flags & SG_EV_REVERSE) { const u32 x_ = from; from = to; to = x_; }      /* dto.go:226-231 */       \
+            if (SHARDED) { const bool mine = (owner_hash_ref(from) % d.world) == d.rank; L.misr += (acc & !mine) ? 1u : 0u; acc &= mine; } \
+            const u32 status = (va).w & 0xFFFFu, proto = ((va).w >> 16) & 0xFFu, dur = (vb).x;                      \
+            const u32 err = is_error(proto, status);                                                                \
+            const u64 wt = (u64)(vb).z | ((u64)(vb).w << 32);                                                       \
+            L.acc += acc ? 1u : 0u;                                                                                 \
+            L.tmin = (acc && wt < L.tmin) ? wt : L.tmin; L.tmax = (acc && wt > L.tmax) ? wt : L.tmax;              \
+            const u32 hk = edge_hash(from, to), part = hk >> pshift, bucket = (hk >> 5) & bmask;                    \
+            const u64 key = ((u64)from << 32) | (u64)to;                                                            \
+            const ulonglong2 kk = reinterpret_cast<const ulonglong2*>(ckey)[bucket];                                \
+            int slot = kk.x == key ? (int)(2u * bucket) : (kk.y == key ? (int)(2u * bucket + 1u) : -1);             \
+            if (acc && slot < 0 && (kk.x == SG_EKEY_EMPTY || kk.y == SG_EKEY_EMPTY)) slot = cache_claim(ckey, bucket, key, kk.x, kk.y); \
+            if (d.ablate & 0x2u) slot = -1;                                                                         \
+            if (acc && !(d.ablate & 0x8u)) {                                                                        \
+                if (slot >= 0 && !(d.ablate & 0x4u)) {                                                              \
+                    const u32 us = div1000_u32(dur);                                                                \
+                    const u64 ssq = (u64)us * (u64)us;                        /* us < 2^23: 24-bit multiplies */             \
+                    atomicAdd(&cacc[slot * 4], 1ull | ((u64)err << 32)); atomicAdd(&cacc[slot * 4 + 1], (u64)dur);  \
+                    atomicMax(&cacc[slot * 4 + 2], (u64)dur); atomicAdd(&cacc[slot * 4 + 3], ssq);                  \
+                } else emit_single(d, fc, w, part, key, (u64)dur, err, L);                                          \
+            }                                                                                                       \
+        }
 #define K1A_FOLD(base)                                                                                            \
         { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(eb0), "+v"(ea1), "+v"(eb1), "+v"(ea2), "+v"(eb2), "+v"(ea3), "+v"(eb3) : : "memory"); \
-          _Pragma("unroll 1")                                                                                       \
-          for (u32 q = 0; q < K1A_G; q++) {                                                                         \
-              const v4u_t va = q == 0 ? ea0 : q == 1 ? ea1 : q == 2 ? ea2 : ea3;                                    \
-              const v4u_t vb = q == 0 ? eb0 : q == 1 ? eb1 : q == 2 ? eb2 : eb3;                                    \
-              K1Ev e;                                                                                               \
-              if (resolve((base) + (u64)q * K1A_THREADS, va, vb, e)) insert(e);                                     \
-          } }
+          bool r0, r1, r2, r3;                                                                                      \
+          K1A_FAST((base), ea0, eb0, r0) K1A_FAST((base) + K1A_THREADS, ea1, eb1, r1)                               \
+          K1A_FAST((base) + 2 * K1A_THREADS, ea2, eb2, r2) K1A_FAST((base) + 3 * K1A_THREADS, ea3, eb3, r3)         \
+          if (__builtin_amdgcn_ballot_w64(r0 | r1 | r2 | r3)) {             /* one copy of the general path: register selects */ \
+              _Pragma("unroll 1")                                                                                   \
+              for (u32 q = 0; q < K1A_G; q++) {                                                                     \
+                  const bool rq = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3;                                     \
+                  if (!__builtin_amdgcn_ballot_w64(rq)) continue;                                                   \
+                  const v4u_t va = q == 0 ? ea0 : q == 1 ? ea1 : q == 2 ? ea2 : ea3;                                \
+                  const v4u_t vb = q == 0 ? eb0 : q == 1 ? eb1 : q == 2 ? eb2 : eb3;                                \
+                  if (rq) general(va, vb);                                                                          \
+              } } }
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory")   /* LDS-only: does not drain the global stores */
     {
-        // piece headers: zero by definition in the first batch of a window (no loads: 65 k scattered sectors per launch
-        // saved); a later batch reads them with ordinary loads BEFORE anything is issued by hand — a hand-issued load
-        // behind a branch would put a register merge between its issue and its wait (the compiler then copies the
-        // still-loading register: seen in r02c, the LDS join table came out as garbage)
-        for (u32 p = t; p < d.np; p += K1A_THREADS) { const uint4 h = first ? make_uint4(0, 0, 0, 0) : *piece_of(d, p, w); fS[p] = h.x; fA[p] = h.y; }
-        v2u_t ip0, ip1, ip2, ip3;
-        v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
-        if (IPLDS) {
-            gload8_issue(ip0, d.iptab + (t & d.ipmask)); gload8_issue(ip1, d.iptab + ((t + K1A_THREADS) & d.ipmask));
-            gload8_issue(ip2, d.iptab + ((t + 2 * K1A_THREADS) & d.ipmask)); gload8_issue(ip3, d.iptab + ((t + 3 * K1A_THREADS) & d.ipmask));
-        }
-        K1A_ISSUE(i);
-        for (u32 k = t; k < K1A_CT; k += K1A_THREADS) ckey[k] = SG_EKEY_EMPTY;
-        for (u32 k = t; k < K1A_CT * 4; k += K1A_THREADS) cacc[k] = 0;
-        if (IPLDS) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ip0), "+v"(ip1), "+v"(ip2), "+v"(ip3) : : "memory");
-        if (IPLDS) {
-            if (t <= d.ipmask) ipl[t] = (u64)ip0.x | ((u64)ip0.y << 32);
-            if (t + K1A_THREADS <= d.ipmask) ipl[t + K1A_THREADS] = (u64)ip1.x | ((u64)ip1.y << 32);
-            if (t + 2 * K1A_THREADS <= d.ipmask) ipl[t + 2 * K1A_THREADS] = (u64)ip2.x | ((u64)ip2.y << 32);
-            if (t + 3 * K1A_THREADS <= d.ipmask) ipl[t + 3 * K1A_THREADS] = (u64)ip3.x | ((u64)ip3.y << 32);
-        }
+        // piece counters: zero by definition in the first batch of a window (no loads); a later batch reads them with
+        // ordinary loads BEFORE anything is issued by hand
+        for (u32 p = t; p < d.np; p += K1A_THREADS) fc[p] = first ? 0u : d.hdr[(size_t)p * d.nwg + w];
+        // The join blob goes out first; right behind it one load per event of the first group, into a register nobody
+        // reads: it pulls the group's lines towards this XCD's L2 while the LDS is being set up (every hand-issued load is
+        // waited for inside the straight-line region that issued it, so the first group's real loads belong to the loop).
+        v4u_t jb0, jb1, jb2, jb3, jb4, jb5; u32 pf;
+        static_assert(K1A_NJ == 6, "written out for 6 blob words per lane");
+        const u32 n16 = d.jstage_bytes >> 4, n1 = (d.jl1mask + 1) >> 1;   // 16-byte words to stage; of them level 1 (always there)
+        const uint4* g1 = reinterpret_cast<const uint4*>(d.jl1); const uint4* g2 = reinterpret_cast<const uint4*>(d.jl2) - n1;
+#define K1A_JIDX(k) ((t + (k) * K1A_THREADS) < n16 ? (t + (k) * K1A_THREADS) : n16 - 1)
+#define K1A_JSRC(k) ((K1A_JIDX(k) < n1 ? g1 : g2) + K1A_JIDX(k))
+        gload16_issue(jb0, K1A_JSRC(0)); gload16_issue(jb1, K1A_JSRC(1)); gload16_issue(jb2, K1A_JSRC(2));
+        gload16_issue(jb3, K1A_JSRC(3)); gload16_issue(jb4, K1A_JSRC(4)); gload16_issue(jb5, K1A_JSRC(5));
+#pragma unroll
+        for (u32 k = 0; k < K1A_G; k++) { const u64 j = i + (u64)k * K1A_THREADS; asm volatile("global_load_dword %0, %1, off" : "=&v"(pf) : "v"(pe + 2 * (j < end ? j : last)) : "memory"); }
+        for (u32 k = t; k < CT; k += K1A_THREADS) ckey[k] = SG_EKEY_EMPTY;
+        for (u32 k = t; k < CT * 4; k += K1A_THREADS) cacc[k] = 0;
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(jb0), "+v"(jb1), "+v"(jb2), "+v"(jb3), "+v"(jb4), "+v"(jb5) : : "memory");
+#define K1A_JST(k, r) if (t + (k) * K1A_THREADS < n16) jl[t + (k) * K1A_THREADS] = make_uint4((r).x, (r).y, (r).z, (r).w)
+        K1A_JST(0, jb0); K1A_JST(1, jb1); K1A_JST(2, jb2); K1A_JST(3, jb3); K1A_JST(4, jb4); K1A_JST(5, jb5);
+#undef K1A_JST
+#undef K1A_JSRC
+#undef K1A_JIDX
         if (t < 8) red[t] = t == WS_TMIN ? ~0ull : 0ull;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) : : "memory");
         LDS_BARRIER();
         SG_STAMP(d, 0, 1);
-        K1A_FOLD(i);
-        SG_STAMP(d, 0, 3);
     }
-    for (i += (u64)K1A_G * K1A_THREADS; i < end; i += (u64)K1A_G * K1A_THREADS) {
+    for (; i < end; i += (u64)K1A_G * K1A_THREADS) {
         v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
         K1A_ISSUE(i);
         K1A_FOLD(i);
     }
+    SG_STAMP(d, 0, 3);
 #undef K1A_ISSUE
 #undef K1A_FOLD
+#undef K1A_FAST
     LDS_BARRIER();
     SG_STAMP(d, 0, 4);
-    // flush the cache: one record per cached edge
-    for (u32 s = t; s < K1A_CT; s += K1A_THREADS) {
+    // flush the cache, singles first (they share the singles region with the loop's records), then the aggregates
+    for (u32 s = t; s < CT; s += K1A_THREADS) {
         const u64 k = ckey[s];
         if (k == SG_EKEY_EMPTY) continue;
-        const u64 x0 = cacc[s * 4], x1 = cacc[s * 4 + 1], x2 = cacc[s * 4 + 2], x3 = cacc[s * 4 + 3];
-        if ((x0 & 0xFFFFFFFFull) == 1ull) emit_single(d, fS, w, hash_key64(k), k, x1, (u32)(x0 >> 32), L);
-        else emit_agg(d, fA, w, k, x0, x1, x2, x3, L);
+        const u64 x0 = cacc[s * 4];
+        if ((x0 & 0xFFFFFFFFull) == 1ull) emit_single(d, fc, w, part_of(d, k), k, cacc[s * 4 + 1], (u32)(x0 >> 32), L);
+        else if ((x0 & 0xFFFFFFFFull) != 0ull) emit_agg(d, fc, w, part_of(d, k), k, x0, cacc[s * 4 + 1], cacc[s * 4 + 2], cacc[s * 4 + 3], L, first);
     }
     // workgroup statistics: wave reduce -> LDS -> one thread updates this workgroup's private line
     {
         const u64 tmin = wave_min_u64(L.tmin), tmax = wave_max_u64(L.tmax);
         const u32 ml = (u32)wave_max_u64(L.maxlabel);
-        const u32 ds = wave_sum_u32(L.dsrc), dc = wave_sum_u32(L.dcap), mr = wave_sum_u32(L.misr), ac = wave_sum_u32(L.acc);
+        const u32 ds = wave_sum_u32(L.dsrc), dc = wave_sum_u32(L.dcap), mr = wave_sum_u32(L.misr), ac = wave_sum_u32(L.acc), ls = wave_sum_u32(L.lost);
         if ((t & 63) == 0) {
             if (ac) { atomicMin(&red[WS_TMIN], tmin); atomicMax(&red[WS_TMAX], tmax); atomicAdd(&red[WS_ACCEPTED], (u64)ac); }
+            if (ls) atomicAdd(&red[WS_PAD], (u64)ls);
             if (ml) atomicMax(&red[WS_MAXLABEL], (u64)ml);
             if (ds) atomicAdd(&red[WS_DROPPED_SRC], (u64)ds);
             if (dc) atomicAdd(&red[WS_DROPPED_CAP], (u64)dc);
@@ -459,12 +551,12 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
         }
     }
     LDS_BARRIER();
-    for (u32 p = t; p < d.np; p += K1A_THREADS)
-        *piece_of(d, p, w) = make_uint4(fS[p] < d.ss ? fS[p] : d.ss, fA[p] < d.sa ? fA[p] : d.sa, 0u, 0u);
+    for (u32 p = t; p < d.np; p += K1A_THREADS) d.hdr[(size_t)p * d.nwg + w] = fc[p];
     SG_STAMP(d, 0, 5);
     if (t == 0) {
         u64* g = d.wgstat + (size_t)(blockIdx.x % SG_MAX_K1_WGS) * WS_WORDS;
-        if (red[WS_ACCEPTED]) { atomicMin(&g[WS_TMIN], red[WS_TMIN]); atomicMax(&g[WS_TMAX], red[WS_TMAX]); atomicAdd(&g[WS_ACCEPTED], red[WS_ACCEPTED]); }
+        // accepted = counted by the lanes - dropped afterwards for capacity (a workgroup only drops what it accepted itself)
+        if (red[WS_ACCEPTED]) { atomicMin(&g[WS_TMIN], red[WS_TMIN]); atomicMax(&g[WS_TMAX], red[WS_TMAX]); atomicAdd(&g[WS_ACCEPTED], red[WS_ACCEPTED] - red[WS_PAD]); }
         if (red[WS_MAXLABEL]) atomicMax(&g[WS_MAXLABEL], red[WS_MAXLABEL]);
         if (red[WS_DROPPED_SRC]) atomicAdd(&g[WS_DROPPED_SRC], red[WS_DROPPED_SRC]);
         if (red[WS_DROPPED_CAP]) atomicAdd(&g[WS_DROPPED_CAP], red[WS_DROPPED_CAP]);
@@ -474,114 +566,95 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
 #undef LDS_BARRIER
 }
 
-// Pass B.  Workgroup p owns partition p: it reads its nwg pieces, merges them in an LDS table and
-// writes every distinct edge once with plain stores:
+// Pass B.  Workgroup p owns partition p: it reads the record counts of its nwg pieces (one contiguous line of d.hdr),
+// then exactly the records that exist (K1B_U single records per lane in flight, the lanes of a piece side by side),
+// merges them in an LDS table and writes every distinct edge once with plain stores:
 //   e_from/e_to [p*pcap + i]  dense endpoints        acc_src [(p*pcap + i)*4]  accumulators
-//   deg[from] += 1 (atomic u32; a row's edges are spread over the partitions; the returned value is the
-//   edge's position inside its CSR row)
-__global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
+//   deg[from][replica] += 1 (atomic u32; a row's edges are spread over the partitions; the returned value is the
+//   edge's position inside its CSR row's replica)
+// blockDim = 512 or 1024 (host: d.k1b_ht * 40 bytes of LDS decide how many of these fit a CU).
+template <int K1B_U>              // single records a lane has in flight
+__global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* hkey = reinterpret_cast<u64*>(smem);                       // [K1B_HT]
-    u64* hacc = hkey + K1B_HT;                                       // [K1B_HT][4]
+    const u32 HT = d.k1b_ht, hmask = HT - 1;
+    u64* hkey = reinterpret_cast<u64*>(smem);                       // [HT]
+    u64* hacc = hkey + HT;                                           // [HT][4]
+    u32* hl = reinterpret_cast<u32*>(hacc + (size_t)HT * 4);         // [nwg] piece headers of this partition
     __shared__ u32 n_drop, out_n;
-    const u32 p = blockIdx.x, t = threadIdx.x;
+    const u32 p = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
     SG_STAMP(d, 1, 0);
+    const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
+    for (u32 i = t; i < d.nwg; i += NT) hl[i] = empty ? 0u : d.hdr[(size_t)p * d.nwg + i];
     // counters the tail needs: fetched now so their latency hides behind the merge
     const u64 ovf_n = d.ctr[C_OVF_N];
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
-    static_assert(K1B_U == 4, "the speculative first round is written out for 4 singles per lane");
-    const u32 sub = t % K1B_LPP;
-    // K1B_LPP lanes walk one piece (record r belongs to lane r % K1B_LPP).  A piece's header, the lane's
-    // first K1B_U singles and its first aggregate are fetched together (the slab memory is always
-    // mapped, stale contents are ignored): one round of latency for a typical piece (<= 16 singles)
-    // instead of three dependent ones.  The first round is in flight during the LDS set-up.
-#define K1B_SIDX(u) (SG_PIECE_HDR + ((sub + (u) * K1B_LPP) < d.ss ? (sub + (u) * K1B_LPP) : 0))
-#define K1B_ISSUE(piece)                                                                                  \
-        gload16_issue(hv, (piece));                                                                        \
-        gload16_issue(xv0, (piece) + K1B_SIDX(0)); gload16_issue(xv1, (piece) + K1B_SIDX(1));              \
-        gload16_issue(xv2, (piece) + K1B_SIDX(2)); gload16_issue(xv3, (piece) + K1B_SIDX(3));              \
-        gload16_issue(y01, (piece) + 1); gload16_issue(y23, (piece) + 2); gload8_issue(y4, (piece) + 3)
-#define K1B_WAIT() asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv), "+v"(xv0), "+v"(xv1), "+v"(xv2), "+v"(xv3), "+v"(y01), "+v"(y23), "+v"(y4) : : "memory")
-    const u32 w0 = t / K1B_LPP, wc = w0 < d.nwg ? w0 : 0;
-    const uint4* piece0 = piece_of(d, p, wc);
-    const u64* pa0 = d.slab_a + ((size_t)p * d.nwg + wc) * d.sa * 5;
-    v4u_t hv, xv0, xv1, xv2, xv3, y01, y23; v2u_t y4;
-    K1B_ISSUE(piece0);
-    for (u32 i = t; i < K1B_HT; i += K1B_THREADS) hkey[i] = SG_EKEY_EMPTY;
-    for (u32 i = t; i < K1B_HT * 4; i += K1B_THREADS) hacc[i] = 0;
+    for (u32 i = t; i < HT; i += NT) hkey[i] = SG_EKEY_EMPTY;
+    for (u32 i = t; i < HT * 4; i += NT) hacc[i] = 0;
     if (t == 0) { n_drop = 0; out_n = 0; }
     __syncthreads();
+    SG_STAMP(d, 1, 1);
 
     auto add = [&](u64 key, u64 a0, u64 a1, u64 a2, u64 a3) {
-        u32 h = hash_key64(key) & (K1B_HT - 1); bool ok = false;
-        for (u32 it = 0; it < K1B_HT; it++) {                        // bounded: the table holds at most K1B_HT distinct edges
-            u64 k = ((volatile u64*)hkey)[h];
+        u32 h = (edge_hash((u32)(key >> 32), (u32)key) >> 4) & hmask; bool ok = false;
+        for (u32 it = 0; it < HT; it++) {                            // bounded: the table holds at most HT distinct edges
+            u64 k = lds_fresh_u64(&hkey[h]);
             if (k == SG_EKEY_EMPTY) { k = atomicCAS(&hkey[h], SG_EKEY_EMPTY, key); if (k == SG_EKEY_EMPTY) k = key; }
             if (k == key) { ok = true; break; }
-            h = (h + 1) & (K1B_HT - 1);
+            h = (h + 1) & hmask;
         }
         if (!ok) { atomicAdd(&n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
         atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
     };
-    auto merge_piece = [&](const uint4* piece, const u64* pa, const v4u_t h, const v4u_t q0, const v4u_t q1, const v4u_t q2, const v4u_t q3,
-                           const v4u_t z01, const v4u_t z23, const v2u_t z4) {
-        if (!(h.x | h.y)) return;
-        uint4 x[K1B_U] = {make_uint4(q0.x, q0.y, q0.z, q0.w), make_uint4(q1.x, q1.y, q1.z, q1.w),
-                          make_uint4(q2.x, q2.y, q2.z, q2.w), make_uint4(q3.x, q3.y, q3.z, q3.w)};
-        u64 y[5] = {(u64)z01.x | ((u64)z01.y << 32), (u64)z01.z | ((u64)z01.w << 32), (u64)z23.x | ((u64)z23.y << 32),
-                    (u64)z23.z | ((u64)z23.w << 32), (u64)z4.x | ((u64)z4.y << 32)};
-        const u32 ns = h.x < d.ss ? h.x : d.ss, na = h.y < d.sa ? h.y : d.sa;
-        for (u32 r0 = sub; r0 < ns; r0 += K1B_LPP * K1B_U) {
-            if (r0 != sub) {
-#pragma unroll
-                for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) x[u] = piece[SG_PIECE_HDR + r0 + u * K1B_LPP];
-            }
-#pragma unroll
-            for (int u = 0; u < K1B_U; u++) if (r0 + u * K1B_LPP < ns) {
-                const u64 key = (u64)x[u].x | ((u64)x[u].y << 32), dur = (u64)x[u].z | ((u64)(x[u].w & 0x3FFFFFFFu) << 32), us = dur / 1000ull;
-                const u64 one = ((x[u].w >> 30) & 1u) ? 0ull : 1ull;             // bit 62: edge-only record (SG_EV_ALIVE)
-                add(key, one | ((u64)(x[u].w >> 31) << 32), dur, dur, us * us);
-            }
-        }
-        for (u32 r0 = sub; r0 < na; r0 += K1B_LPP) {                 // aggregate 0 came with the piece; the others (rare) from slab_a
-            if (r0 != 0) { const u64* q = pa + (size_t)(r0 - 1) * 5; y[0] = q[0]; y[1] = q[1]; y[2] = q[2]; y[3] = q[3]; y[4] = q[4]; }
-            add(y[0], y[1], y[2], y[3], y[4]);
-        }
-    };
-    SG_STAMP(d, 1, 1);
-    K1B_WAIT();
-    SG_STAMP(d, 1, 2);
-    const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
-    if (w0 < d.nwg && !empty) merge_piece(piece0, pa0, hv, xv0, xv1, xv2, xv3, y01, y23, y4);
-    for (u32 w = w0 + K1B_THREADS / K1B_LPP; w < d.nwg && !empty; w += K1B_THREADS / K1B_LPP) {    // only when nwg > 256
+    // LPP lanes walk one piece (record r belongs to lane r % LPP of the group); every load is unconditional (index
+    // clamped to the piece's last record, result ignored) so that the four of a round are in flight together.
+    const u32 LPP = NT > d.nwg ? NT / d.nwg : 1u;
+    const u32 sub = t % LPP;
+    for (u32 w = t / LPP; w < d.nwg; w += NT / LPP) {
+        const u32 h = hl[w];
+        const u32 ns = K1_NS(h) < d.ss ? K1_NS(h) : d.ss, na = K1_NA(h) < d.sa ? K1_NA(h) : d.sa;
+        if (!(ns | na)) continue;
         const uint4* piece = piece_of(d, p, w);
-        const u64* pa = d.slab_a + ((size_t)p * d.nwg + w) * d.sa * 5;
-        v4u_t hv, xv0, xv1, xv2, xv3, y01, y23; v2u_t y4;
-        K1B_ISSUE(piece);
-        K1B_WAIT();
-        merge_piece(piece, pa, hv, xv0, xv1, xv2, xv3, y01, y23, y4);
+        const u32 lastr = ns ? ns - 1 : 0;
+        for (u32 r0 = sub; r0 < ns; r0 += LPP * K1B_U) {
+            uint4 x[K1B_U];
+#pragma unroll
+            for (int u = 0; u < K1B_U; u++) { const u32 r = r0 + u * LPP; x[u] = piece[r < ns ? r : lastr]; }
+#pragma unroll
+            for (int u = 0; u < K1B_U; u++) if (r0 + u * LPP < ns) {
+                const u64 key = (u64)x[u].x | ((u64)x[u].y << 32);
+                const u32 dhi = x[u].w & 0x3FFFFFFFu;
+                const u64 dur = (u64)x[u].z | ((u64)dhi << 32);
+                u64 ssq;
+                if (dhi == 0) { const u32 us = div1000_u32(x[u].z); ssq = (u64)us * (u64)us; }
+                else { const u64 us = dur / 1000ull; ssq = us * us; }
+                const u64 one = ((x[u].w >> 30) & 1u) ? 0ull : 1ull;             // bit 62: edge-only record (SG_EV_ALIVE)
+                if (!(d.ablate & 0x10u)) add(key, one | ((u64)(x[u].w >> 31) << 32), dur, dur, ssq);
+            }
+        }
+        for (u32 r = sub; r < na; r += LPP) {
+            const uint4* q = piece + d.ss + 3 * r;
+            const uint4 y0 = q[0], y1 = q[1]; const uint2 y2 = reinterpret_cast<const uint2*>(q + 2)[0];
+            add((u64)y0.x | ((u64)y0.y << 32), (u64)y0.z | ((u64)y0.w << 32), (u64)y1.x | ((u64)y1.y << 32),
+                (u64)y1.z | ((u64)y1.w << 32), (u64)y2.x | ((u64)y2.y << 32));
+        }
     }
-#undef K1B_ISSUE
-#undef K1B_WAIT
-#undef K1B_SIDX
     __syncthreads();
     SG_STAMP(d, 1, 3);
-    // (no reset of the piece headers: the first batch of the next window rewrites every one of them)
-    {
+    // (no reset of the headers: the first batch of the next window rewrites every one of them)
+    if (ovf_n) {
         const u64 no = ovf_n < d.ovf_cap ? ovf_n : d.ovf_cap;
-        for (u64 i = t; i < no; i += K1B_THREADS) {
+        for (u64 i = t; i < no; i += NT) {
+            if (d.ovf_p[i] != p) continue;
             const u64* o = d.ovf + i * 5;
-            if (part_of(d, o[0]) == p) add(o[0], o[1], o[2], o[3], o[4]);
+            add(o[0], o[1], o[2], o[3], o[4]);
         }
+        __syncthreads();
     }
-    __syncthreads();
     SG_STAMP(d, 1, 4);
 
     // compact the table into the partition's output slots (order within a partition is arbitrary;
     // the CSR row sort makes the final order canonical)
-#pragma unroll
-    for (u32 q = 0; q < K1B_HT / K1B_THREADS; q++) {
-        const u32 s = q * K1B_THREADS + t;
+    for (u32 s = t; s < HT; s += NT) {
         const u64 k = hkey[s];
         if (k == SG_EKEY_EMPTY) continue;
         const u32 f = dense_of(d, (u32)(k >> 32), nk, nl, nob), to = dense_of(d, (u32)k, nk, nl, nob);
@@ -598,7 +671,10 @@ __global__ __launch_bounds__(K1B_THREADS) void k1b_merge(Dev d) {
     SG_STAMP(d, 1, 5);
     if (t == 0) {
         d.part_n[p] = out_n < d.pcap ? out_n : d.pcap;
-        if (n_drop) atomicAdd(&d.ctr[C_DROPPED_CAP], (u64)n_drop);
+        if (n_drop) {                                                // dropped after pass A had counted them as accepted
+            atomicAdd(&d.ctr[C_DROPPED_CAP], (u64)n_drop);
+            atomicAdd(&d.ctr[C_N_EVENTS], 0ull - (u64)n_drop);
+        }
     }
 }
 
@@ -1168,7 +1244,7 @@ __global__ __launch_bounds__(1024) void k3_in_stats(Dev d) {
                     u32 h = sg_fmix32(to[q]) & (K3_IN_HT - 1);
                     bool found = false;
                     for (u32 pr = 0; pr < K3_IN_PROBES; pr++) {
-                        u32 kk = ((volatile u32*)tkey)[h];
+                        u32 kk = lds_fresh_u32(&tkey[h]);
                         if (kk == SG_NONE) { kk = atomicCAS(&tkey[h], SG_NONE, to[q]); if (kk == SG_NONE) kk = to[q]; }
                         if (kk == to[q]) { found = true; break; }
                         h = (h + 1) & (K3_IN_HT - 1);
@@ -1257,6 +1333,10 @@ __global__ __launch_bounds__(256) void k_reset_window(Dev d) {
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
     for (u64 i = tid; i <= d.obmask; i += nt) d.obkeys[i] = 0;
+    // a window that is reset WITHOUT having been closed (sg_window_reset on an open window = discard): what the close
+    // path would have consumed and re-armed — the per-workgroup K1 statistics, the overflow and alive lists
+    for (u64 i = tid; i < (u64)SG_MAX_K1_WGS * WS_WORDS; i += nt) d.wgstat[i] = (i % WS_WORDS) == WS_TMIN ? ~0ull : 0ull;
+    if (tid == 0) { d.ctr[C_OVF_N] = 0; d.ctr[C_ALIVE_N] = 0; d.ctr[C_ALIVE_DROP] = 0; }
     if (d.variant == 1 && d.ctr[C_EDGES_FOUND] > d.max_edges) {
         for (u64 i = tid; i <= d.emask; i += nt) {
             d.ekeys[i] = SG_EKEY_EMPTY;

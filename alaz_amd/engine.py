@@ -50,7 +50,8 @@ class SgStats(C.Structure):
                 ("last_window_edges", C.c_uint64), ("last_window_nodes", C.c_uint64),
                 ("last_window_tmin_ms", C.c_int64), ("last_window_tmax_ms", C.c_int64), ("h2d_bytes", C.c_uint64),
                 ("events_misrouted", C.c_uint64), ("halo_overflow", C.c_uint64),
-                ("alive_in", C.c_uint64), ("alive_dropped", C.c_uint64)]
+                ("alive_in", C.c_uint64), ("alive_dropped", C.c_uint64),
+                ("join_word_updates", C.c_uint64), ("join_full_uploads", C.c_uint64)]
 
 
 class ServiceGraphError(RuntimeError):

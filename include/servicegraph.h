@@ -183,6 +183,8 @@ typedef struct sg_stats {
     uint64_t halo_overflow;        /* halo requests beyond the per-pair capacity (must be 0)     */
     uint64_t alive_in;             /* SG_EV_ALIVE records handed to K1 since create               */
     uint64_t alive_dropped;        /* ... of which beyond max_alive, or with an endpoint that was dropped */
+    uint64_t join_word_updates;    /* join-table words changed in place on the device (incremental upserts/deletes) */
+    uint64_t join_full_uploads;    /* whole join-table images uploaded (first build, rebuilds)        */
 } sg_stats;
 
 typedef struct sg_engine* sg_handle;

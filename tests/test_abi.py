@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_every_symbol(engine_lib):
 
 
 def test_struct_layouts_match_the_header():
-    assert C.sizeof(engine.SgConfig) == 72 and C.sizeof(engine.SgStats) == 120
+    assert C.sizeof(engine.SgConfig) == 72 and C.sizeof(engine.SgStats) == 136
     assert replay.EVENT_DTYPE.itemsize == 32 and replay.EDGE_OUT_DTYPE.itemsize == 56
     assert replay.EVENT_DTYPE.fields["duration_ns"][1] == 16 and replay.EVENT_DTYPE.fields["status"][1] == 12
     assert replay.EDGE_OUT_DTYPE.fields["from_ref"][1] == 24 and replay.EDGE_OUT_DTYPE.fields["score"][1] == 40

@@ -25,8 +25,8 @@ for i in range(6):
     g.ingest_device(dev[i % 3].data_ptr(), Ev, 0); g.window_run(0)
 torch.cuda.synchronize()
 st = g.debug_stamps()
-names = {0: ["start", "setup+barrier", "events landed", "folded", "barrier", "flushed", "stats"],
-         1: ["start", "setup+barrier", "loads landed", "merged+barrier", "reset/ovf+barrier", "compacted+barrier"]}
+names = {0: ["start", "tables staged+barrier", "-", "events folded", "barrier", "cache flushed, headers", "stats"],
+         1: ["start", "headers+table zeroed", "-", "merged+barrier", "overflow list", "compacted+barrier"]}
 for kid, kname in ((0, "k1a_partition"), (1, "k1b_merge")):
     a = st[kid].astype(np.int64)
     live = a[:, 0] != 0
@@ -36,6 +36,7 @@ for kid, kname in ((0, "k1a_partition"), (1, "k1b_merge")):
     t0 = a[:, 0].min()
     print(f"{kname}: {len(a)} workgroups; 100 MHz ticks -> us")
     for k, nm in enumerate(names[kid]):
+        if nm == "-": continue
         col = (a[:, k] - t0) / 100.0
         print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
 g.close()
