@@ -134,7 +134,7 @@ void k1a_geometry(sg_engine* e) {
     const Dev& d = e->d;
     const size_t l1b = (size_t)e->jt.l1_entries * 8, l2b = (size_t)e->jt.blocks_bytes(), fixed = (size_t)d.np * 4 + 64 + l1b;
     e->l2_in_lds = false; e->k1a_ct = 2048;
-    for (u32 ct : {2048u, 1024u}) {
+    for (u32 ct : {2048u, 1024u, 512u}) {
         if ((size_t)ct * 40 + fixed + l2b <= kLdsBytes && (l1b + l2b) / 16 <= (size_t)K1A_NJ * K1A_THREADS) { e->l2_in_lds = true; e->k1a_ct = ct; break; }
     }
     if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) e->k1a_ct = x; }
@@ -450,12 +450,13 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     if (e->cfg.max_window_events == 0) e->cfg.max_window_events = e->cfg.max_batch;
     d.variant = cfg->k1_variant == 1 ? 1u : 0u;
     {
-        // partitions: ~500 distinct edges each at the configured capacity (pass B's LDS table has 1024 slots, 768 of
-        // them may fill), at least one per CU; pieces: mean records per (partition, workgroup) with head room, whole lines
-        u64 np = next_pow2(std::max<u64>(ME / 1200, 256));
-        d.k1b_ht = 1024;
-        if (np > 4096) { np = 4096; d.k1b_ht = 2048; }
+        // partitions: at most ~1250 distinct edges each at the configured capacity (pass B's LDS table: 2048 slots, 1536 may
+        // fill; 1024 slots for small graphs), at least one per CU.  Fewer, larger partitions keep pass A's open lines per
+        // XCD (partitions x 32 workgroups) near the L2's size: C3 with 1024 partitions 181 us, 2048: 198 us, 4096: 292 us.
+        u64 np = next_pow2(std::max<u64>((ME + 1249) / 1250, 256));
+        if (np > 4096) np = 4096;
         if (cfg->k1_variant == 0 && ME > (u64)4096 * 1400) d.variant = 1;   // beyond the partitioned path's range
+        d.k1b_ht = ME / np > 600 ? 2048 : 1024;
         d.np = (u32)np; d.nwg = 256;
         // tuning overrides (tools/gpu_probe_sweep.sh); anything that is not a legal geometry is ignored
         if (const char* v = std::getenv("SG_NP")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 64 && x <= 4096 && (x & (x - 1)) == 0) d.np = (u32)x; }
@@ -469,7 +470,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         d.ss = std::min<u32>(d.ss, (1u << 20) - 8);
         d.pslots = d.ss + 3 * d.sa;
         d.ovf_cap = 1u << 16;
-        e->k1b_threads = d.k1b_ht <= 1024 ? 512u : 1024u;
+        e->k1b_threads = 1024u;                                          // measured: 1024 threads beat 2 x 512 (C3 135 vs 153 us, C2 15.5 vs 22.9 us)
         if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; }
         if (const char* v = std::getenv("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if (x == 256 || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
     }
@@ -497,7 +498,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     }
     if (d.variant == 0) {
         k1a_geometry(e);
-        e->k1b_lds = (size_t)d.k1b_ht * (8 + 32) + (size_t)d.nwg * 4;
+        e->k1b_lds = (size_t)d.k1b_ht * (8 + 32);
         for (const void* f : {reinterpret_cast<const void*>(k1a_partition<true, true>), reinterpret_cast<const void*>(k1a_partition<true, false>),
                               reinterpret_cast<const void*>(k1a_partition<false, true>), reinterpret_cast<const void*>(k1a_partition<false, false>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));

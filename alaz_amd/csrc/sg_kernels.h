@@ -572,45 +572,49 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
 //   e_from/e_to [p*pcap + i]  dense endpoints        acc_src [(p*pcap + i)*4]  accumulators
 //   deg[from][replica] += 1 (atomic u32; a row's edges are spread over the partitions; the returned value is the
 //   edge's position inside its CSR row's replica)
-// blockDim = 512 or 1024 (host: d.k1b_ht * 40 bytes of LDS decide how many of these fit a CU).
+// LDS: the table and nothing else — k1b_ht * 40 bytes; with 2048 slots that is exactly half of a CU's 160 KiB, so two
+// 512-thread workgroups share a CU and one's (latency-bound) header round trip and compaction overlap the other's
+// (LDS-atomic-bound) merge.  The last key slot is never used as a slot: its 8 bytes hold the two workgroup counters.
 template <int K1B_U>              // single records a lane has in flight
 __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 HT = d.k1b_ht, hmask = HT - 1;
-    u64* hkey = reinterpret_cast<u64*>(smem);                       // [HT]
+    u64* hkey = reinterpret_cast<u64*>(smem);                       // [HT]  (slot HT-1: n_drop, out_n)
     u64* hacc = hkey + HT;                                           // [HT][4]
-    u32* hl = reinterpret_cast<u32*>(hacc + (size_t)HT * 4);         // [nwg] piece headers of this partition
-    __shared__ u32 n_drop, out_n;
+    u32* n_drop = reinterpret_cast<u32*>(hkey + hmask); u32* out_n = n_drop + 1;
     const u32 p = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
     SG_STAMP(d, 1, 0);
     const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
-    for (u32 i = t; i < d.nwg; i += NT) hl[i] = empty ? 0u : d.hdr[(size_t)p * d.nwg + i];
+    // LPP lanes walk one piece; each reads the piece's header word itself (a partition's headers are one contiguous KiB)
+    const u32 LPP = NT > d.nwg ? NT / d.nwg : 1u;
+    const u32 sub = t % LPP;
+    const u32 w0 = t / LPP;
+    u32 h0 = (!empty && w0 < d.nwg) ? d.hdr[(size_t)p * d.nwg + w0] : 0u;
     // counters the tail needs: fetched now so their latency hides behind the merge
     const u64 ovf_n = d.ctr[C_OVF_N];
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
-    for (u32 i = t; i < HT; i += NT) hkey[i] = SG_EKEY_EMPTY;
+    for (u32 i = t; i < hmask; i += NT) hkey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < HT * 4; i += NT) hacc[i] = 0;
-    if (t == 0) { n_drop = 0; out_n = 0; }
+    if (t == 0) { *n_drop = 0; *out_n = 0; }
     __syncthreads();
     SG_STAMP(d, 1, 1);
 
     auto add = [&](u64 key, u64 a0, u64 a1, u64 a2, u64 a3) {
         u32 h = (edge_hash((u32)(key >> 32), (u32)key) >> 4) & hmask; bool ok = false;
-        for (u32 it = 0; it < HT; it++) {                            // bounded: the table holds at most HT distinct edges
+        h = h == hmask ? 0u : h;
+        for (u32 it = 0; it < HT; it++) {                            // bounded: the table holds at most HT - 1 distinct edges
             u64 k = lds_fresh_u64(&hkey[h]);
             if (k == SG_EKEY_EMPTY) { k = atomicCAS(&hkey[h], SG_EKEY_EMPTY, key); if (k == SG_EKEY_EMPTY) k = key; }
             if (k == key) { ok = true; break; }
-            h = (h + 1) & hmask;
+            h = h + 1 >= hmask ? 0u : h + 1;
         }
-        if (!ok) { atomicAdd(&n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
+        if (!ok) { atomicAdd(n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
         atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
     };
-    // LPP lanes walk one piece (record r belongs to lane r % LPP of the group); every load is unconditional (index
-    // clamped to the piece's last record, result ignored) so that the four of a round are in flight together.
-    const u32 LPP = NT > d.nwg ? NT / d.nwg : 1u;
-    const u32 sub = t % LPP;
-    for (u32 w = t / LPP; w < d.nwg; w += NT / LPP) {
-        const u32 h = hl[w];
+    // record r of a piece belongs to lane r % LPP of its group; every load is unconditional (index clamped to the piece's
+    // last record, result ignored) so that the K1B_U of a round are in flight together
+    for (u32 w = w0; w < d.nwg; w += NT / LPP) {
+        const u32 h = w == w0 ? h0 : d.hdr[(size_t)p * d.nwg + w];
         const u32 ns = K1_NS(h) < d.ss ? K1_NS(h) : d.ss, na = K1_NA(h) < d.sa ? K1_NA(h) : d.sa;
         if (!(ns | na)) continue;
         const uint4* piece = piece_of(d, p, w);
@@ -654,13 +658,13 @@ __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
 
     // compact the table into the partition's output slots (order within a partition is arbitrary;
     // the CSR row sort makes the final order canonical)
-    for (u32 s = t; s < HT; s += NT) {
+    for (u32 s = t; s < hmask; s += NT) {
         const u64 k = hkey[s];
         if (k == SG_EKEY_EMPTY) continue;
         const u32 f = dense_of(d, (u32)(k >> 32), nk, nl, nob), to = dense_of(d, (u32)k, nk, nl, nob);
-        if (f == SG_NONE || to == SG_NONE) { atomicAdd(&n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
-        const u32 i = atomicAdd(&out_n, 1u);
-        if (i >= d.pcap) { atomicAdd(&n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
+        if (f == SG_NONE || to == SG_NONE) { atomicAdd(n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
+        const u32 i = atomicAdd(out_n, 1u);
+        if (i >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
         const size_t slot = (size_t)p * d.pcap + i;
         d.e_from[slot] = f; d.e_to[slot] = to;
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
@@ -670,10 +674,11 @@ __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
     __syncthreads();
     SG_STAMP(d, 1, 5);
     if (t == 0) {
-        d.part_n[p] = out_n < d.pcap ? out_n : d.pcap;
-        if (n_drop) {                                                // dropped after pass A had counted them as accepted
-            atomicAdd(&d.ctr[C_DROPPED_CAP], (u64)n_drop);
-            atomicAdd(&d.ctr[C_N_EVENTS], 0ull - (u64)n_drop);
+        const u32 on = *out_n, nd = *n_drop;
+        d.part_n[p] = on < d.pcap ? on : d.pcap;
+        if (nd) {                                                    // dropped after pass A had counted them as accepted
+            atomicAdd(&d.ctr[C_DROPPED_CAP], (u64)nd);
+            atomicAdd(&d.ctr[C_N_EVENTS], 0ull - (u64)nd);
         }
     }
 }
