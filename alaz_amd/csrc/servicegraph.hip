@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -21,7 +22,7 @@
 
 namespace {
 
-constexpr int kStageSlots = 4;
+constexpr int kStageSlots = 8;
 constexpr int kUpdSlots = 4;             // pinned ring for join-table word updates
 constexpr u32 kUpdCap = 1u << 15;         // (word offset, value) pairs per slot = sgjoin::Table::max_dirty
 constexpr size_t kLdsBytes = 160 * 1024;  // per workgroup on gfx950
@@ -59,6 +60,8 @@ struct sg_engine {
     // staging ring for sg_ingest()
     sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
     int stage_next = 0;
+    bool stage_busy[kStageSlots] = {};                                   // a feeder thread is copying into the slot (outside the lock)
+    int pending_copies = 0; std::condition_variable cv;                 // window closes wait for the copies that began before them
 
     u64 first_kernel = 0, first_user = 0;
     float* d_W = nullptr; bool have_w = false;
@@ -299,7 +302,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 0, s, d);
     }
     {
-        Timed t3(e, s, 3);
+        Timed t3(e, s, 8);                                   // group 8 = k3_in_stats (group 3 = node + edge features)
         // dense-LDS case: few workgroups (every one flushes every node it saw); hashed case (too many nodes for
         // LDS): a workgroup aggregates HT/2 edges per round, so more of them, bounded by the flush atomics
         const int g3 = d.in_dense ? K3_IN_WGS : (int)std::min<u64>(128, std::max<u64>(K3_IN_WGS, (e->cfg.max_edges + K3_IN_ROUND - 1) / K3_IN_ROUND));
@@ -655,20 +658,26 @@ int sg_load_weights(sg_handle e, const float* w, size_t n) {
 
 int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
     if (!e || (!events && n)) return SG_EINVAL;
-    std::lock_guard<std::mutex> g(e->mu);
+    std::unique_lock<std::mutex> g(e->mu);
     if (n > e->cfg.max_batch) { e->err = "batch larger than max_batch"; return SG_EINVAL; }
     if (n == 0) return SG_OK;
     const int slot = e->stage_next;
-    if (hipEventQuery(e->stage_ev[slot]) == hipErrorNotReady) {          // ring full: drop, never block
+    if (e->stage_busy[slot] || hipEventQuery(e->stage_ev[slot]) == hipErrorNotReady) {   // ring full: drop, never block
         e->st.events_dropped_ring += n;
         return SG_EAGAIN;
     }
-    e->stage_next = (slot + 1) % kStageSlots;
-    std::memcpy(e->h_stage[slot], events, n * sizeof(sg_event));          // the caller's memory is not retained
-    HIP_TRY(e, hipMemcpyAsync(e->d_stage[slot], e->h_stage[slot], n * sizeof(sg_event), hipMemcpyHostToDevice, e->stream));
-    e->st.h2d_bytes += n * sizeof(sg_event);
-    int rc = launch_k1(e, e->d_stage[slot], n, e->stream);
-    HIP_TRY(e, hipEventRecord(e->stage_ev[slot], e->stream));
+    e->stage_busy[slot] = true; e->stage_next = (slot + 1) % kStageSlots; e->pending_copies++;
+    g.unlock();
+    // the caller's memory is not retained; the copy into the pinned slot runs OUTSIDE the engine lock, so several
+    // feeder threads (goroutines on different OS threads) fill different slots at the same time
+    std::memcpy(e->h_stage[slot], events, n * sizeof(sg_event));
+    g.lock();
+    int rc = SG_OK;
+    if (hipMemcpyAsync(e->d_stage[slot], e->h_stage[slot], n * sizeof(sg_event), hipMemcpyHostToDevice, e->stream) != hipSuccess) { e->err = "hipMemcpyAsync (staging ring)"; rc = SG_ENODEV; }
+    if (rc == SG_OK) { e->st.h2d_bytes += n * sizeof(sg_event); rc = launch_k1(e, e->d_stage[slot], n, e->stream); }
+    hipEventRecord(e->stage_ev[slot], e->stream);
+    e->stage_busy[slot] = false; e->pending_copies--;
+    e->cv.notify_all();
     return rc;
 }
 
@@ -680,7 +689,8 @@ int sg_ingest_device(sg_handle e, const sg_event* d_events, size_t n, void* stre
 
 int sg_window_close(sg_handle e, void* stream) {
     if (!e) return SG_EINVAL;
-    std::lock_guard<std::mutex> g(e->mu);
+    std::unique_lock<std::mutex> g(e->mu);
+    e->cv.wait(g, [&] { return e->pending_copies == 0; });
     return do_close(e, pick(e, stream), nullptr, nullptr, 1u);
 }
 
@@ -706,7 +716,8 @@ int sg_bind_buffers(sg_handle e, void* stats_sum, void* stats_max, void* const* 
 
 int sg_window_close_sharded(sg_handle e, const uint32_t* d_union_ips, const uint32_t* d_union_n, void* stream) {
     if (!e || !d_union_ips || !d_union_n) return SG_EINVAL;
-    std::lock_guard<std::mutex> g(e->mu);
+    std::unique_lock<std::mutex> g(e->mu);
+    e->cv.wait(g, [&] { return e->pending_copies == 0; });
     return do_close(e, pick(e, stream), d_union_ips, d_union_n, 0u);
 }
 
@@ -714,7 +725,8 @@ int sg_window_close_sharded(sg_handle e, const uint32_t* d_union_ips, const uint
 // [count, ip, ip, ...] buffer (stride u32 per shard), straight from the collective.
 int sg_window_close_gathered(sg_handle e, const uint32_t* d_gathered, uint32_t stride, uint32_t world, void* stream) {
     if (!e || !d_gathered || stride < 2 || world == 0 || world > 8) return SG_EINVAL;
-    std::lock_guard<std::mutex> g(e->mu);
+    std::unique_lock<std::mutex> g(e->mu);
+    e->cv.wait(g, [&] { return e->pending_copies == 0; });
     if ((u64)(stride - 1) * world > e->ob_list_cap) { e->err = "gathered outbound-ip lists exceed the engine's list capacity"; return SG_ENOSPC; }
     return do_close(e, pick(e, stream), d_gathered, nullptr, 2u, stride, world);
 }
@@ -794,7 +806,8 @@ int sg_window_reset(sg_handle e, void* stream) {
 int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_t cap, size_t* n) {
     (void)window_end_ms;
     if (!e) return SG_EINVAL;
-    std::lock_guard<std::mutex> g(e->mu);
+    std::unique_lock<std::mutex> g(e->mu);
+    e->cv.wait(g, [&] { return e->pending_copies == 0; });
     hipStream_t s = e->stream;
     int rc;
     if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
@@ -810,7 +823,8 @@ int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_
 // enqueue-only variant of the whole window pipeline (no read-back, no host sync): what bench.py times.
 int sg_window_run(sg_handle e, void* stream) {
     if (!e) return SG_EINVAL;
-    std::lock_guard<std::mutex> g(e->mu);
+    std::unique_lock<std::mutex> g(e->mu);
+    e->cv.wait(g, [&] { return e->pending_copies == 0; });
     hipStream_t s = pick(e, stream);
     int rc;
     if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;

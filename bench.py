@@ -1,16 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — L7 edge-events/s ingested -> scored service map on MI355X (BASELINE.json metric).
 
-A step = one window of the hot path over one batch of synthetic events that is already resident
-in HBM: K1 resolve_aggregate over the batch, then K2..K5 (CSR build, node/edge features, SAGE
-layer(s), edge scores) and the window reset.  N=1 workload = BASELINE config 2 (1k pods / 500
-services / 50k edges / 1M events per window, L=1).  Steps cycle through a ring of distinct batches
-larger than the 256 MiB Infinity Cache, so every step streams its events from HBM.
+A step = one window of the hot path over one batch of synthetic events that is already resident in HBM ("device-resident
+replay"): K1 resolve_aggregate over the batch, then K2..K5 (CSR build, node/edge features, SAGE layers, edge scores) and
+the window reset.  Workloads (BASELINE.json configs, alaz_amd/replay.py):
 
-One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel K1 (algorithmic bytes
-32*Ev + 32*E per launch, SURVEY.md §8d / DESIGN.md), timed with HIP events on the launch stream.
-`cpu_baseline` is the CPU oracle (a C restatement of the reference's aggregator path; the Go
-binary cannot be built here) timed single-threaded on a bounded sample of the same workload.
+  --gpus 1 (default)  C3: 10k pods / 5k services / 1M edges (power-law), 10M HTTP events per window, 2 SAGE layers —
+                      the largest single-GPU configuration.  --config 2 (1k pods / 50k edges / 1M events, 1 layer) and
+                      --config 5 (100k pods / 20M edges, 5M mixed HTTP/Kafka/Postgres events per window, on ONE GPU)
+                      are selectable.
+  --gpus N > 1        C4: C3's graph hash-sharded by source pod over the N GPUs (alaz_amd/sharded.py), 10M events per
+                      GPU per window (weak scaling in the event volume).
+
+Steps cycle through a ring of distinct batches larger than the 256 MiB Infinity Cache, so every step streams its events
+from HBM.  One JSON line on stdout (rank 0):
+
+  value        events/s of the timed device-resident steps (never includes PCIe; `end_to_end` does)
+  roofline     the dominant kernel K1 (k1a_partition + k1b_merge): algorithmic bytes 32*Ev + 32*E per window
+                / their dispatch durations (HIP events on the launch stream), vs 8 TB/s
+  kernels      the same for every kernel group of the window (K1a, K1b, K2, K3-in, K3-feat, K4, K5)
+  end_to_end   events accepted by sg_ingest from HOST memory (several feeder threads, pinned staging ring, H2D) until the
+               window's rows are back in host memory (sg_flush_window): SURVEY §8(d)(i); bounded by PCIe (32 B/event in)
+  cpu_baseline the reference's CPU path restated in C (oracle/, the Go aggregator cannot be built here), timed on this
+               box's host cores on a bounded sample of the same workload
 """
 from __future__ import annotations
 
@@ -18,6 +30,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,78 +40,142 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F_IN, F_HID = 32, 64
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3])
+    ap.add_argument("--steps", type=int, default=0, help="timed windows (0 = per config: C2 200, C3/C4 30, C5 10)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed windows (-1 = per config: C2 20, C3/C4 5, C5 2)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="0 = 3 for one GPU, 4 (C3's graph sharded) for several")
     ap.add_argument("--batches", type=int, default=0, help="distinct event batches in the HBM ring (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="seconds per CPU-baseline variant")
+    ap.add_argument("--feeders", type=int, default=8, help="host threads calling sg_ingest in the end-to-end pass")
     ap.add_argument("--windows", type=int, default=1, help="window slots in flight for the timed region (sg_config.windows_in_flight); "
                                                             "1 keeps the per-kernel timings uncontended")
     ap.add_argument("--overlap-windows", type=int, default=4, help="extra diagnostic pass with this many windows in flight (0 = skip)")
     ap.add_argument("--graph", choices=["fixed", "scaled"], default="fixed",
                     help="N > 1: 'fixed' shards the configuration's own graph over the N GPUs (what BASELINE's multi-GPU configurations "
-                         "do with theirs) and scales the event volume, 1 M events per GPU per window; 'scaled' also grows the graph N-fold")
+                         "do with theirs); 'scaled' also grows the graph N-fold")
     ap.add_argument("--profile-mode", action="store_true", help="only warm-up + the timed steps (no diagnostic passes, no CPU baseline): "
                                                                   "the run rocprofv3 wraps, so its per-kernel averages are those of the timed region")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config == 0:
+        a.config = 3 if a.gpus == 1 else 4
+    dflt = {2: (200, 20), 3: (30, 5), 4: (30, 5), 5: (10, 2)}[a.config]
+    if a.steps <= 0:
+        a.steps = dflt[0]
+    if a.warmup < 0:
+        a.warmup = dflt[1]
+    return a
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (oracle/ = measurement infrastructure; runs BEFORE the GPU runtime is initialised so that
+# the multi-process variant can fork)
+# ------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+_W = {}
+
+
+def _faithful_worker(secs):
+    """child process: one oracle instance, the faithful string path on the shared (copy-on-write) sample"""
+    from oracle import pyoracle
+    o = pyoracle.Oracle(1_000_000_000, 1_700_000_000_000_000_000)
+    o.apply_ops(_W["ops"])
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < secs:
+        o.l7_wire(_W["wire"]); done += _W["n"]
+    dt = time.perf_counter() - t0
+    o.close()
+    return done, dt
+
+
+def _lean_worker(secs):
+    from oracle import pyoracle
+    topo, ev = _W["topo"], _W["ev"]
+    l = pyoracle.Lean(topo.n_nodes, len(topo.edge_src) * 2 + 1024)
+    for i in range(topo.n_pods):
+        l.upsert_pod(int(topo.pod_ips[i]), i)
+    for j in range(topo.n_svcs):
+        l.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < secs:
+        l.reset_window(); l.process(ev); done += len(ev)
+    dt = time.perf_counter() - t0
+    l.close()
+    return done, dt
 
 
 def cpu_baseline(topo, events, labels, layers, seconds):
-    """The reference's CPU path restated (oracle/sg_oracle.c): full 1096-byte records through
-    processL7 -> processHttpEvent -> setFromToV2 -> PersistRequest, then the window close.
-    `value` is one core; `all_cores` runs one independent oracle per host core on the same sample
-    (no shared tables, so it is an upper bound for a lock-sharing aggregator, data.go:812-825)."""
-    import threading
+    """The reference's CPU path restated, every figure in events/s on this box's host cores:
+      faithful_1t  oracle/sg_oracle.c on full 1096-byte l7_event records: processL7 -> processHttpEvent -> setFromToV2 ->
+                   PersistRequest with dotted-quad strings and string-keyed tables, one heap row per request — what the Go
+                   aggregator does per event (aggregator/data.go:1208-1249, 827-870; datastore/backend.go:819-847), 1 thread
+      faithful_Nt  the same in one PROCESS per host core (independent tables: an upper bound for the lock-sharing original)
+      lean_1t/_Nt  oracle/lean_baseline.c: the same join + per-edge aggregation on u32 keys and open-addressing tables over
+                   packed 32-byte events — what a careful CPU implementation of K1 would do
+      scoring_1t   the window close (CSR, features, SAGE layers, scores — builder-defined, the reference has none) of the
+                   sample's graph, events of the sample / close time
+    `value` = faithful_1t (kind "port": a C restatement; the Go binary cannot be built here: no Go toolchain)."""
+    import multiprocessing as mp
     from alaz_amd import replay, weights
     from oracle import pyoracle
-    sample = events[: min(len(events), 200_000)]
+    pyoracle.build()
+    n_f = min(len(events), 200_000)
+    sample = events[:n_f]
     wire = replay.to_wire(sample, labels)
-    W = weights.make_weights(layers)
-    ops = topo.k8s_ops()
-
-    def run(secs, out, k):
-        o = pyoracle.Oracle(1_000_000_000, 1_700_000_000_000_000_000)
-        o.apply_ops(ops)
-        done, t0 = 0, time.perf_counter()
-        while True:
-            o.l7_wire(wire)             # ctypes releases the GIL for the whole call
-            o.window_close(W, layers)
-            done += len(sample)
-            if time.perf_counter() - t0 >= secs:
-                break
-        out[k] = done
-        o.close()
-
-    one = [0]
-    t0 = time.perf_counter(); run(seconds, one, 0); dt = time.perf_counter() - t0
-    res = {"value": one[0] / dt, "unit": "events/s", "cores": 1, "kind": "port",
-           "sample": f"{len(sample)} events of the same workload as full 1096-B l7_event records, repeated "
-                     f"{one[0] // len(sample)}x ({dt:.1f} s): C restatement of processL7..PersistRequest + window close "
-                     "(oracle/sg_oracle.c); the Go aggregator itself cannot be built here (no Go toolchain)"}
-    nc = max(1, min(os.cpu_count() or 1, 64))
+    lean_ev = np.ascontiguousarray(events[: min(len(events), 2_000_000)])
+    _W.update(ops=topo.k8s_ops(), wire=wire, n=n_f, topo=topo, ev=lean_ev)
+    res = {"unit": "events/s", "kind": "port", "cpu_model": _cpu_model(), "host_cpus": os.cpu_count()}
+    # 1 thread, in this process
+    d, dt = _faithful_worker(seconds)
+    res["faithful_1t"] = d / dt
+    d, dt = _lean_worker(max(2.0, seconds / 2))
+    res["lean_1t"] = d / dt
+    # the window close on the sample's graph
+    o = pyoracle.Oracle(1_000_000_000, 1_700_000_000_000_000_000)
+    o.apply_ops(_W["ops"]); o.packed(sample, labels)
+    t0 = time.perf_counter(); o.window_close(weights.make_weights(layers), layers); tc = time.perf_counter() - t0
+    res["scoring_1t"] = n_f / tc
+    res["scoring_1t_note"] = f"window close of the {n_f}-event sample's graph ({len(o.edge_dict())} edges) in {tc * 1e3:.0f} ms"
+    o.close()
+    nc = max(1, min(os.cpu_count() or 1, 128))
     if nc > 1:
-        outs = [0] * nc
-        th = [threading.Thread(target=run, args=(max(2.0, seconds / 2), outs, k)) for k in range(nc)]
-        t0 = time.perf_counter()
-        for t in th: t.start()
-        for t in th: t.join()
-        dtm = time.perf_counter() - t0
-        res["all_cores"] = {"value": sum(outs) / dtm, "unit": "events/s", "cores": nc, "host_cpus": os.cpu_count(),
-                            "sample": f"{nc} independent oracle instances (one thread each), same sample, {dtm:.1f} s"}
+        ctx = mp.get_context("fork")
+        for name, fn, secs in (("faithful_Nt", _faithful_worker, max(3.0, seconds / 2)), ("lean_Nt", _lean_worker, max(2.0, seconds / 3))):
+            with ctx.Pool(nc) as pool:
+                t0 = time.perf_counter()
+                outs = pool.map(fn, [secs] * nc)
+                wall = time.perf_counter() - t0
+            res[name] = sum(x[0] / x[1] for x in outs)                 # sum of per-process rates over the same interval
+            res[name + "_procs"] = nc
+            res[name + "_wall_s"] = round(wall, 1)
+    res["value"] = res["faithful_1t"]; res["cores"] = 1
+    res["sample"] = (f"{n_f} events of the same workload as full 1096-B l7_event records (faithful), {len(lean_ev)} packed events (lean), each "
+                     f"repeated for ~{seconds:.0f} s; C restatement of processL7..PersistRequest (oracle/sg_oracle.c) — the Go aggregator itself "
+                     "cannot be built here (no Go toolchain)")
     return res
 
 
 def pmc_traffic(config):
-    """HBM bytes per K1 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs of `bench.py --profile-mode`, tools/gpu_pmc.sh; gfx950 corrections per
-    MI355X_MICROARCH.md are applied by tools/pmc_summary.py).  Counters cannot be read from inside the
-    process being timed, so this is the last measured value for this workload, or null."""
+    """HBM bytes per K1 window from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    `bench.py --profile-mode`, tools/gpu_pmc.sh; gfx950 corrections per MI355X_MICROARCH.md are applied by
+    tools/pmc_k1_json.py).  Counters cannot be read from inside the process being timed, so this is the last committed
+    measurement for this workload (traffic_measured_in_run: false), or null."""
     path = os.path.join(ROOT, "profiles", f"pmc_k1_c{config}.json")
     try:
         with open(path) as f:
@@ -121,19 +198,24 @@ def measured_copy_gbs(torch):
     return 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def algorithmic_bytes(Ev, E, N, L):
+    """compulsory traffic per window and kernel group."""
+    b = {"K1a": 32.0 * Ev, "K1b": 32.0 * E, "K2": 16.0 * E + 4.0 * (N + 1), "K3-in": 32.0 * E, "K3-feat": 4.0 * F_IN * N,
+         "K5": 52.0 * E + 2 * 4.0 * F_HID * N}
+    k4 = 0.0
+    for l in range(L):
+        k4 += 4.0 * (N + 1) + 4.0 * E + 4.0 * (F_IN if l == 0 else F_HID) * N + 4.0 * F_HID * N
+    b["K4"] = k4
+    return b
+
+
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
-    from alaz_amd import engine, replay, weights
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local)
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     force_sharded = os.environ.get("SG_FORCE_SHARDED") == "1"      # exercise the multi-GPU code path at world = 1
     # the contract is ONE line on stdout: libraries that print there (RCCL writes its version banner to stdout when the
     # first communicator is created) are sent to stderr for the duration of the run
@@ -142,9 +224,11 @@ def main():
     os.dup2(2, 1)
     try:
         if world > 1 or force_sharded:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        if world > 1 or force_sharded:
+            import torch
+            import torch.distributed as dist
             from alaz_amd import sharded
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             res = sharded.bench(a, rank, world, local)
         else:
             res = bench_single(a, local)
@@ -155,23 +239,17 @@ def main():
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1 or force_sharded:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 
 
-def bench_single(a, device):
-    import torch
-    from alaz_amd import engine, replay, weights
-
-    c = replay.CONFIGS[a.config]
-    seed = replay.SEED_BASE + a.config
-    Ev, L = c["events"], c["layers"]
-    nb = a.batches or max(2, -(-(320 << 20) // (Ev * 32)))          # ring >= 320 MB > 256 MiB Infinity Cache
-    topo = replay.make_topology(c["pods"], c["edges"], seed)
-    ev_all, labels = replay.make_events(topo, Ev * nb, seed)
-    g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.25) + 4096, layers=L,
+def _engine_for(a, topo, labels, c, device, windows, engine, weights):
+    L = c["layers"]
+    big = a.config == 5
+    g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * (1.1 if big else 1.25)) + 4096, layers=L,
                             max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=1 << 18,
-                            max_window_events=Ev, windows_in_flight=a.windows)
+                            max_window_events=c["events"], windows_in_flight=windows)
     g.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
     g.load_weights(weights.make_weights(L))
     for i in range(topo.n_pods):
@@ -179,7 +257,27 @@ def bench_single(a, device):
     for j in range(topo.n_svcs):
         g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
     g.set_label_count(len(labels))
+    return g
 
+
+def bench_single(a, device):
+    from alaz_amd import replay
+
+    cfgno = 3 if a.config == 4 else a.config
+    c = replay.CONFIGS[cfgno]
+    seed = replay.SEED_BASE + cfgno
+    Ev, L = c["events"], c["layers"]
+    nb = a.batches or max(2, -(-(320 << 20) // (Ev * 32)))          # ring >= 320 MB > 256 MiB Infinity Cache
+    topo = replay.make_topology(c["pods"], c["edges"], seed)
+    ev_all, labels = replay.make_events(topo, Ev * nb, seed, mixed=(cfgno == 5))
+    cpu = None
+    if not a.no_cpu_baseline and not a.profile_mode:                 # before the GPU runtime exists in this process (fork)
+        cpu = cpu_baseline(topo, ev_all[:Ev], labels, L, a.cpu_seconds)
+
+    import torch
+    from alaz_amd import engine, weights
+    torch.cuda.set_device(device)
+    g = _engine_for(a, topo, labels, c, device, a.windows, engine, weights)
     s = 0          # NULL stream argument: the engine enqueues every window on its own slot's stream
     dev = [torch.from_numpy(ev_all[i * Ev:(i + 1) * Ev].view(np.uint8).reshape(-1)).cuda() for i in range(nb)]
     torch.cuda.synchronize()
@@ -191,7 +289,7 @@ def bench_single(a, device):
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
-    g.timing_reset(); g.timing_enable((1 << 1) | (1 << 7))  # HIP events around every K1 launch (pass A + pass B), on their stream
+    g.timing_reset(); g.timing_enable((1 << 1) | (1 << 7))  # dispatch stamps of every K1 launch (pass A + pass B), on their stream
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -200,57 +298,62 @@ def bench_single(a, device):
     dt = time.perf_counter() - t0
     g.timing_enable(0)
     k1a, k1b = g.timing(1), g.timing(7)
-    # untimed diagnostic pass: per-group durations of the rest of the window pipeline
-    k_us = {}
+    # untimed diagnostic pass: per-group durations of the rest of the window pipeline (hipEvent pairs cost a few us each)
+    grp = {}
+    nd = min(10, a.steps)
     if not a.profile_mode:
         g.timing_reset(); g.timing_enable(1)
-        for i in range(min(20, a.steps)):
+        for i in range(nd):
             step(i)
         torch.cuda.synchronize()
         g.timing_enable(0)
-        k_us = {k: g.timing(k) for k in range(1, 6)}
+        for name, k in (("K2", 2), ("K3-in", 8), ("K3-feat", 3), ("K4", 4), ("K5", 5)):
+            us, n = g.timing(k)
+            grp[name] = us * n / nd                                 # per window (a group may have several records per window)
 
     # one untimed window with copy-out: how many edges / nodes a window of this workload has
     g.ingest_device(dev[0].data_ptr(), Ev, s)
     torch.cuda.synchronize()
     rows = g.flush_window()
     st = g.stats()
-    E = int(st.last_window_edges)
+    E, N = int(st.last_window_edges), int(st.last_window_nodes)
     k1_us = k1a[0] + k1b[0]                                  # K1 = k1a_partition (per batch) + k1b_merge (per window)
-    alg_bytes = 32.0 * Ev + 32.0 * E
-    achieved = alg_bytes / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(a.config)
+    alg = algorithmic_bytes(Ev, E, N, L)
+    alg_k1 = alg["K1a"] + alg["K1b"]
+    achieved = alg_k1 / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(cfgno)
     copy_gbs = None if a.profile_mode else measured_copy_gbs(torch)
+    kern_us = {"K1a": k1a[0], "K1b": k1b[0], **grp}
+    kernels = [{"name": k, "us_per_window": round(kern_us[k], 2), "algorithmic_bytes": alg[k],
+                "GBs": round(alg[k] / (kern_us[k] * 1e-6) / 1e9, 1) if kern_us.get(k, 0) > 0 else None,
+                "frac_of_hbm_peak": round(alg[k] / (kern_us[k] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if kern_us.get(k, 0) > 0 else None}
+               for k in ("K1a", "K1b", "K2", "K3-in", "K3-feat", "K4", "K5") if k in kern_us]
+    b_total = sum(alg.values())
+    ms_step = dt / a.steps * 1e3
+    variant = "global-table K1 (variant 1)" if cfgno == 5 else "partitioned K1 (variant 0)"
     res = {
         "metric": "L7 edge-events/s ingested->scored service-map", "value": Ev * a.steps / dt, "unit": "events/s",
-        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"C{a.config}: {c['pods']} pods / {topo.n_svcs} services / {c['edges']} edges, "
-                               f"{Ev} HTTP l7 events per window, {L}-layer SAGE + MLP score; {nb}-batch HBM ring",
-                   "events_per_window": Ev, "edges_per_window": E, "nodes": int(st.last_window_nodes), "layers": L,
-                   "windows_in_flight": a.windows, "parallelism": "1 GPU"},
+        "config": {"workload": f"C{cfgno} device-resident replay: {c['pods']} pods / {topo.n_svcs} services / {c['edges']} edges, "
+                               f"{Ev} {'mixed HTTP/Kafka/Postgres' if cfgno == 5 else 'HTTP'} l7 events per window already in HBM, {L}-layer SAGE + MLP score, "
+                               f"{variant}; {nb}-batch HBM ring (value excludes PCIe: see end_to_end)",
+                   "events_per_window": Ev, "edges_per_window": E, "nodes": N, "layers": L,
+                   "events_dropped_cap": int(st.events_dropped_cap), "windows_in_flight": a.windows, "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = k1a_partition + k1b_merge", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": traffic_src, "measured_copy_GBs": copy_gbs,
+                     "traffic_source": traffic_src, "traffic_measured_in_run": False, "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": k1_us,
+                     "algorithmic_bytes_per_launch": alg_k1, "avg_launch_us": k1_us,
                      "k1a_partition_us": k1a[0], "k1b_merge_us": k1b[0], "launches": k1a[1]},
-        "kernel_group_us": {"K1a": round(k1a[0], 2), "K1b": round(k1b[0], 2), **{f"K{k}": round(v[0], 2) for k, v in k_us.items() if k > 1}},
+        "kernels": kernels,
+        "window_algorithmic_bytes": b_total, "window_algorithmic_bytes_per_event": b_total / Ev,
+        "window_algorithmic_GBs": b_total / (ms_step * 1e-3) / 1e9,
     }
     # diagnostic (never `value`): the same steps with several windows in flight inside one engine — the
-    # latency-bound close of window w overlaps the ingest of window w+1 (per-kernel durations stretch,
-    # throughput rises); no timing events in this pass
-    if a.overlap_windows > 1 and not a.profile_mode:
-        g2 = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.25) + 4096, layers=L,
-                                 max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=1 << 18,
-                                 max_window_events=Ev, windows_in_flight=a.overlap_windows)
-        g2.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
-        g2.load_weights(weights.make_weights(L))
-        for i in range(topo.n_pods):
-            g2.upsert_pod(int(topo.pod_ips[i]), i)
-        for j in range(topo.n_svcs):
-            g2.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
-        g2.set_label_count(len(labels))
+    # latency-bound close of window w overlaps the ingest of window w+1; no timing events in this pass
+    if a.overlap_windows > 1 and not a.profile_mode and cfgno != 5:
+        g2 = _engine_for(a, topo, labels, c, device, a.overlap_windows, engine, weights)
         for i in range(a.warmup):
             g2.ingest_device(dev[i % nb].data_ptr(), Ev, 0); g2.window_run(0)
         torch.cuda.synchronize()
@@ -261,25 +364,42 @@ def bench_single(a, device):
         dt2 = time.perf_counter() - t1
         res["overlapped"] = {"windows_in_flight": a.overlap_windows, "events_per_s": Ev * a.steps / dt2, "ms_per_step": dt2 / a.steps * 1e3}
         g2.close()
-    # diagnostic (never `value`): the same windows fed from host memory through sg_ingest
-    # (pinned staging ring + H2D over PCIe), DESIGN.md "PCIe-inclusive rate"
-    hs = 0 if a.profile_mode else min(10, a.steps)
-    chunk = 1 << 18
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(hs):
-        b = ev_all[(i % nb) * Ev:((i % nb) + 1) * Ev]
-        for j in range(0, Ev, chunk):
-            while g.ingest(b[j:j + chunk]) != 0:
-                pass
-        g.window_run()
-    torch.cuda.synchronize()
-    if hs:
-        res["host_fed_events_per_s"] = Ev * hs / (time.perf_counter() - t0)
-    if not a.no_cpu_baseline and not a.profile_mode:
-        res["cpu_baseline"] = cpu_baseline(topo, ev_all[:Ev], labels, L, a.cpu_seconds)
+    # events accepted by sg_ingest from HOST memory until their window's rows are readable on the host
+    if not a.no_end_to_end and not a.profile_mode:
+        res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E)
+    if cpu is not None:
+        res["cpu_baseline"] = cpu
     g.close()
     return res
+
+
+def end_to_end(g, ev_all, Ev, nb, feeders, E):
+    """`feeders` host threads split every window's events and call sg_ingest (copy into the pinned staging ring, H2D, K1a)
+    concurrently; when all have returned, sg_flush_window closes the window and copies the scored rows to host memory."""
+    import torch
+    chunk = 1 << 18
+    nwin = 3 if Ev >= 5_000_000 else 10
+    retries = [0]
+
+    def feed(part):
+        for j in range(0, len(part), chunk):
+            while g.ingest(part[j:j + chunk]) != 0:          # SG_EAGAIN: ring momentarily full -> this harness retries, production drops
+                retries[0] += 1
+    torch.cuda.synchronize()
+    rows_n = 0
+    t0 = time.perf_counter()
+    for wdx in range(nwin):
+        b = ev_all[(wdx % nb) * Ev:((wdx % nb) + 1) * Ev]
+        per = -(-Ev // feeders); per = -(-per // chunk) * chunk
+        ths = [threading.Thread(target=feed, args=(b[k * per:(k + 1) * per],)) for k in range(feeders) if k * per < Ev]
+        for t in ths: t.start()
+        for t in ths: t.join()
+        rows_n = len(g.flush_window())
+    dt = time.perf_counter() - t0
+    return {"events_per_s": Ev * nwin / dt, "ms_per_window": dt / nwin * 1e3, "windows": nwin, "feeders": feeders,
+            "includes": ["memcpy into pinned staging ring", "h2d", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows", "window reset"],
+            "rows_per_window": rows_n, "ring_full_retries": retries[0],
+            "bound": f"PCIe: 32 B/event host->device + 56 B/edge device->host ({(32.0 * Ev + 56.0 * E) / 1e6:.0f} MB per window)"}
 
 
 if __name__ == "__main__":

@@ -295,9 +295,11 @@ int sg_window_outbound_ips(sg_handle h, uint32_t* ips, size_t cap, size_t* n);
 
 int sg_stats_get(sg_handle h, sg_stats* out);
 
-/* Per-kernel timing of the last N launches, measured with hipEvents on the launch stream.
- * kernel: 1..6 = K1..K6.  Returns the average duration in microseconds over the recorded
- * launches since sg_timing_reset(), and the launch count.  Timing must be enabled first.        */
+/* Per-kernel timing, measured on the launch stream.  Groups: 1 = K1 pass A (k1a_partition / k1_resolve_aggregate, one record
+ * per batch), 7 = K1 pass B (k1b_merge) — both by the dispatch's own begin/end stamps; 2 = K2 csr_build (two records per window:
+ * window bookkeeping, then row pointers + scatter + row sort), 8 = K3 in-statistics, 3 = K3 node + edge features, 4 = K4 (one
+ * record per SAGE layer), 5 = K5, 6 = K6 halo kernels — by hipEvent pairs around the launches.  sg_timing_get returns the
+ * average duration in microseconds per record since sg_timing_reset(), and the number of records.                          */
 int sg_timing_enable(sg_handle h, int on);   /* 0 = off, 1 = every group, else bitmask: bit k = group Kk */
 int sg_timing_reset(sg_handle h);
 int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
