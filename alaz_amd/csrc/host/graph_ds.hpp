@@ -13,6 +13,7 @@
 //   * IngestL7 — one step earlier, straight from l7_req.L7Event, so that the reference's CPU join is
 //     not needed at all (the L7Packer does the payload-dependent part on the host).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -62,7 +63,11 @@ std::string FormatIPv4(uint32_t ip);                      // IntToIPv4().String(
 
 class GraphDS : public datastore::DataStore {
 public:
-    GraphDS(datastore::DataStore* inner, const SgApi& api, sg_handle h, EdgeSink* sink, size_t max_edges, size_t batch = 4096);
+    // max_known_nodes = sg_config.max_known_nodes (the id space the engine was created with).  divert_requests: false
+    // (default) = additive — PersistRequest / PersistKafkaEvent also reach the inner data store, so a backend without an
+    // "/edges/" route keeps receiving its per-request rows; true = the engine's per-edge rows replace them.
+    GraphDS(datastore::DataStore* inner, const SgApi& api, sg_handle h, EdgeSink* sink, size_t max_edges, size_t batch = 4096,
+            uint32_t max_known_nodes = 0x3FFFFFFFu, bool divert_requests = false);
     ~GraphDS() override;
 
     int PersistPod(const datastore::Pod& pod, const std::string& eventType) override;
@@ -84,37 +89,54 @@ public:
     // n perf records of l7_req::kWireSize bytes each, through L7Packer::PackWire (f-1: no 1 KiB copy per event)
     int IngestWire(const uint8_t* recs, size_t n, const uint32_t* kafka_msgs = nullptr);
 
-    // process / connection lifecycle as far as the HTTP/2 assembler needs it (aggregator/data.go:354-377, :484-494,
+    // process / connection lifecycle as far as the payload parsers need it (aggregator/data.go:354-401, :484-503,
     // :553-567): only events of live pids are assembled; a closed connection or an exited process drops its HPACK state
-    void ProcExec(uint32_t pid) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ProcExec(pid); }
-    void ProcExit(uint32_t pid) { std::lock_guard<std::mutex> g(mu_); packer_.Http2().ProcExit(pid); }
-    void ConnClosed(uint32_t pid, uint64_t fd) { std::lock_guard<std::mutex> g(mu_); packer_.ConnClosed(pid, fd); }
-    void SetKafkaDecode(bool on) { std::lock_guard<std::mutex> g(mu_); packer_.SetKafkaDecode(on); }
-    void SweepHttp2() { std::lock_guard<std::mutex> g(mu_); packer_.Http2().Sweep(); }
+    // and its remembered Postgres statements
+    void ProcExec(uint32_t pid) { std::lock_guard<std::mutex> g(pk_mu_); packer_.Http2().ProcExec(pid); }
+    void ProcExit(uint32_t pid) { std::lock_guard<std::mutex> g(pk_mu_); packer_.ProcExit(pid); }
+    void ConnClosed(uint32_t pid, uint64_t fd) { std::lock_guard<std::mutex> g(pk_mu_); packer_.ConnClosed(pid, fd); }
+    void SetKafkaDecode(bool on) { std::lock_guard<std::mutex> g(pk_mu_); packer_.SetKafkaDecode(on); }
+    void SweepHttp2() { std::lock_guard<std::mutex> g(pk_mu_); packer_.Http2().Sweep(); }
 
-    // close the window: pending batch -> engine, K2..K5, rows -> sink.  Returns the number of edges or < 0.
+    // close the window: pending batches -> engine, K2..K5, rows -> sink.  Returns the number of edges or < 0.
     long FlushWindow(int64_t window_end_ms);
 
-    uint64_t EventsOffered() const { return offered_; }
-    uint64_t BatchesDropped() const { return batches_dropped_; }
+    uint64_t EventsOffered() const { return offered_.load(); }
+    uint64_t BatchesDropped() const { return batches_dropped_.load(); }
+    uint64_t EngineErrors() const { return engine_errors_.load(); }   // sg_upsert_* failures (SG_ENOSPC: id space / join table full)
+    size_t LiveIds() const { return live_ids_; }
     const std::vector<std::string>& Labels() const { return packer_.Labels(); }
     const L7Packer& Packer() const { return packer_; }
 
 private:
-    uint32_t Intern(const std::string& uid, uint8_t kind);
-    int Append(const sg_event& ev);                    // under mu_
-    int FlushBatchLocked();
+    static constexpr uint32_t kNoId = 0xFFFFFFFFu;
+    static constexpr int kShards = 8;
+    struct Shard { std::mutex mu; std::vector<sg_event> batch; };
+
+    // node ids (under id_mu_): one per UID that currently owns at least one IP in the join tables.  An id whose last IP
+    // is gone is retired, and handed out again once the window that may still name it has been flushed.
+    uint32_t Intern(const std::string& uid, uint8_t kind);            // kNoId when the id space is exhausted
+    void BindIP(std::unordered_map<uint32_t, uint32_t>& m, uint32_t ip, uint32_t id);   // m[ip] = id, reference counts follow
+    void UnbindIP(std::unordered_map<uint32_t, uint32_t>& m, uint32_t ip);
+    int Append(const sg_event* ev, size_t n);
+    int FlushShard(Shard& s);                          // s.mu held
 
     datastore::DataStore* inner_;
     SgApi api_; sg_handle h_; EdgeSink* sink_;
     size_t max_edges_, batch_cap_;
-    std::mutex mu_;
-    std::vector<sg_event> batch_;
-    std::unordered_map<std::string, uint32_t> ids_;    // UID -> node id, arrival order
-    std::vector<std::string> uid_of_; std::vector<uint8_t> kind_of_;
+    uint32_t max_known_; bool divert_;
+    Shard shards_[kShards];                            // event batches, one per feeder-thread hash: appends do not serialise
+    std::mutex id_mu_;                                 // ids_, uid_of_, kind_of_, refs_, the IP mirrors
+    std::unordered_map<std::string, uint32_t> ids_;    // UID -> node id
+    std::vector<std::string> uid_of_; std::vector<uint8_t> kind_of_; std::vector<uint32_t> refs_;
+    std::unordered_map<uint32_t, uint32_t> pod_ip_id_, svc_ip_id_;   // ip -> id, what the engine's join tables hold
+    std::vector<uint32_t> free_ids_, retired_;         // retired_: no IP left, reusable after the next FlushWindow
+    size_t live_ids_ = 0;
+    std::mutex pk_mu_;                                 // packer_ (labels, prepared statements, HPACK state), dto_labels_
     L7Packer packer_;
     std::unordered_map<std::string, uint32_t> dto_labels_;   // labels seen through the PersistRequest tap share the packer's id space
-    uint64_t offered_ = 0, batches_dropped_ = 0;
+    std::mutex flush_mu_;                              // one FlushWindow at a time
+    std::atomic<uint64_t> offered_{0}, batches_dropped_{0}, engine_errors_{0};
 };
 
 }  // namespace alaz

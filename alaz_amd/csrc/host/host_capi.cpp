@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -22,13 +23,13 @@ namespace {
 struct MockEngine {
     std::vector<sg_event> events;
     std::vector<std::array<uint32_t, 3>> table_ops;   // {op: 1 upsert_pod 2 delete_pod 3 upsert_svc 4 delete_svc, ip, id}
-    uint32_t label_count = 0; uint32_t flushes = 0;
+    uint32_t label_count = 0; uint32_t flushes = 0; uint32_t max_known = 0x3FFFFFFFu;
 };
-int m_create(const sg_config*, sg_handle* out) { *out = reinterpret_cast<sg_handle>(new MockEngine()); return SG_OK; }
+int m_create(const sg_config* cfg, sg_handle* out) { auto* m = new MockEngine(); if (cfg && cfg->max_known_nodes) m->max_known = cfg->max_known_nodes; *out = reinterpret_cast<sg_handle>(m); return SG_OK; }
 int m_destroy(sg_handle h) { delete reinterpret_cast<MockEngine*>(h); return SG_OK; }
-int m_upsert_pod(sg_handle h, uint32_t ip, uint32_t id) { reinterpret_cast<MockEngine*>(h)->table_ops.push_back({1u, ip, id}); return SG_OK; }
+int m_upsert_pod(sg_handle h, uint32_t ip, uint32_t id) { auto* m = reinterpret_cast<MockEngine*>(h); if (id >= m->max_known) return SG_ENOSPC; m->table_ops.push_back({1u, ip, id}); return SG_OK; }
 int m_delete_pod(sg_handle h, uint32_t ip) { reinterpret_cast<MockEngine*>(h)->table_ops.push_back({2u, ip, 0u}); return SG_OK; }
-int m_upsert_svc(sg_handle h, uint32_t ip, uint32_t id) { reinterpret_cast<MockEngine*>(h)->table_ops.push_back({3u, ip, id}); return SG_OK; }
+int m_upsert_svc(sg_handle h, uint32_t ip, uint32_t id) { auto* m = reinterpret_cast<MockEngine*>(h); if (id >= m->max_known) return SG_ENOSPC; m->table_ops.push_back({3u, ip, id}); return SG_OK; }
 int m_delete_svc(sg_handle h, uint32_t ip) { reinterpret_cast<MockEngine*>(h)->table_ops.push_back({4u, ip, 0u}); return SG_OK; }
 int m_labels(sg_handle h, uint32_t n) { reinterpret_cast<MockEngine*>(h)->label_count = n; return SG_OK; }
 int m_ingest(sg_handle h, const sg_event* ev, size_t n) { auto* m = reinterpret_cast<MockEngine*>(h); m->events.insert(m->events.end(), ev, ev + n); return SG_OK; }
@@ -41,9 +42,19 @@ struct CollectSink : EdgeSink {
     int PersistEdges(int64_t w, const std::vector<EdgeRow>& r) override { window_end = w; rows = r; return 0; }
 };
 
+// the inner data store of the tests: the out-of-scope BackendDS stand-in, counting what reaches it
+struct CountingDataStore : datastore::NullDataStore {
+    std::atomic<uint64_t> requests{0}, kafka{0}, alive{0}, pods{0}, services{0};
+    int PersistPod(const datastore::Pod&, const std::string&) override { pods++; return 0; }
+    int PersistService(const datastore::Service&, const std::string&) override { services++; return 0; }
+    int PersistRequest(const datastore::Request*) override { requests++; return 0; }
+    int PersistKafkaEvent(const datastore::KafkaEvent*) override { kafka++; return 0; }
+    int PersistAliveConnection(const datastore::AliveConnection*) override { alive++; return 0; }
+};
+
 struct HostCtx {
     void* dl = nullptr; SgApi api; sg_handle h = nullptr; bool mock = false;
-    datastore::NullDataStore inner; CollectSink sink;
+    CountingDataStore inner; CollectSink sink;
     std::unique_ptr<GraphDS> ds;
     ConnTracker conns;                 // f-2: TCP connect events -> socket lines -> alive connections
 };
@@ -59,7 +70,7 @@ struct sgh_edge_row {
 
 void* sgh_packer_create(void) { return new L7Packer(); }
 void sgh_packer_destroy(void* p) { delete static_cast<L7Packer*>(p); }
-void sgh_packer_known_ip(void* p, uint32_t ip, int add) { if (add) static_cast<L7Packer*>(p)->AddKnownIP(ip); else static_cast<L7Packer*>(p)->RemoveKnownIP(ip); }
+void sgh_packer_known_ip(void* p, uint32_t ip, int add) { static_cast<L7Packer*>(p)->SetPodIP(ip, add != 0); }
 size_t sgh_packer_pack_wire(void* p, const uint8_t* recs, size_t n, const uint32_t* kafka_msgs, sg_event* out, size_t cap) {
     auto* pk = static_cast<L7Packer*>(p);
     std::vector<sg_event> v; v.reserve(n);
@@ -94,7 +105,9 @@ void sgh_parse_http(const char* req, size_t len, char* m, char* p, char* v, char
     put(m, sm); put(p, sp); put(v, sv); put(h, sh);
 }
 
-void* sgh_graphds_create(const char* engine_lib, const sg_config* cfg, size_t batch) {
+void* sgh_graphds_create2(const char* engine_lib, const sg_config* cfg, size_t batch, int divert_requests);
+void* sgh_graphds_create(const char* engine_lib, const sg_config* cfg, size_t batch) { return sgh_graphds_create2(engine_lib, cfg, batch, 0); }
+void* sgh_graphds_create2(const char* engine_lib, const sg_config* cfg, size_t batch, int divert_requests) {
     auto c = std::make_unique<HostCtx>();
     if (engine_lib) {
         c->dl = dlopen(engine_lib, RTLD_NOW | RTLD_GLOBAL);
@@ -106,7 +119,8 @@ void* sgh_graphds_create(const char* engine_lib, const sg_config* cfg, size_t ba
         c->api.flush_window = m_flush; c->api.window_outbound_ips = m_obips; c->api.last_error = m_err;
     }
     if (c->api.create(cfg, &c->h) != SG_OK) return nullptr;        // no usable GPU => no GraphDS: there is no CPU fallback
-    c->ds = std::make_unique<GraphDS>(&c->inner, c->api, c->h, &c->sink, cfg ? (size_t)cfg->max_edges : 1024, batch ? batch : 4096);
+    c->ds = std::make_unique<GraphDS>(&c->inner, c->api, c->h, &c->sink, cfg ? (size_t)cfg->max_edges : 1024, batch ? batch : 4096,
+                                      cfg && cfg->max_known_nodes ? cfg->max_known_nodes : 0x3FFFFFFFu, divert_requests != 0);
     return c.release();
 }
 void sgh_graphds_destroy(void* g) { auto* c = static_cast<HostCtx*>(g); if (!c) return; c->ds.reset(); if (c->h) c->api.destroy(c->h); delete c; }
@@ -317,7 +331,7 @@ uint32_t sgh_crc32(int castagnoli, const uint8_t* p, size_t n) { return kafka::C
 uint32_t sgh_xxh32(const uint8_t* p, size_t n, uint32_t seed) { return kafka::XXH32(p, n, seed); }
 // the stand-alone packer's assembler
 void sgh_packer_proc_exec(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Http2().ProcExec(pid); }
-void sgh_packer_proc_exit(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Http2().ProcExit(pid); }
+void sgh_packer_proc_exit(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->ProcExit(pid); }
 void sgh_packer_conn_closed(void* p, uint32_t pid, uint64_t fd) { static_cast<L7Packer*>(p)->ConnClosed(pid, fd); }
 size_t sgh_packer_pg_statements(void* p) { return static_cast<L7Packer*>(p)->PgStatements(); }
 size_t sgh_graphds_socklines(void* g) { return static_cast<HostCtx*>(g)->conns.Lines(); }
@@ -328,6 +342,12 @@ size_t sgh_graphds_sweep(void* g, int64_t now_ms, int send_alive) { auto* c = st
 size_t sgh_graphds_labels(void* g, char* buf, size_t cap) { return join_labels(static_cast<HostCtx*>(g)->ds->Labels(), buf, cap); }
 uint64_t sgh_graphds_dropped_parse(void* g) { return static_cast<HostCtx*>(g)->ds->Packer().DroppedParse(); }
 void* sgh_graphds_engine(void* g) { return static_cast<HostCtx*>(g)->h; }
+// {events offered, batches dropped, engine errors, live node ids, requests / kafka events / alive connections / pods / services that reached the inner store}
+void sgh_graphds_counters(void* g, uint64_t out[9]) {
+    auto* c = static_cast<HostCtx*>(g);
+    out[0] = c->ds->EventsOffered(); out[1] = c->ds->BatchesDropped(); out[2] = c->ds->EngineErrors(); out[3] = c->ds->LiveIds();
+    out[4] = c->inner.requests; out[5] = c->inner.kafka; out[6] = c->inner.alive; out[7] = c->inner.pods; out[8] = c->inner.services;
+}
 // mock inspection
 size_t sgh_mock_events(void* g, sg_event* out, size_t cap) {
     auto* c = static_cast<HostCtx*>(g); if (!c->mock) return 0;

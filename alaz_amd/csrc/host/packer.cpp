@@ -177,6 +177,14 @@ void L7Packer::ConnClosed(uint32_t pid, uint64_t fd) {
     }
 }
 
+void L7Packer::ProcExit(uint32_t pid) {
+    h2_.ProcExit(pid);
+    const std::string prefix = std::to_string(pid);
+    for (auto it = pg_stmts_.begin(); it != pg_stmts_.end();) {
+        if (it->first.compare(0, prefix.size(), prefix) == 0) it = pg_stmts_.erase(it); else ++it;
+    }
+}
+
 size_t L7Packer::PackWire(const uint8_t* rec, uint32_t kafka_msgs, std::vector<sg_event>* out) {
     using namespace l7_req;
     L7Event& e = scratch_;

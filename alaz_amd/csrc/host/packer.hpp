@@ -34,11 +34,12 @@ bool ContainsSQLKeywords(const uint8_t* s, size_t n);
 
 class L7Packer {
 public:
-    // IPs currently present in the join tables (pods + services): the Host header is interned only
-    // when the destination is not one of them, i.e. exactly when setFromToV2 would use it (:851-854).
-    void AddKnownIP(uint32_t ip) { known_[ip]++; }
-    void RemoveKnownIP(uint32_t ip) { auto it = known_.find(ip); if (it != known_.end() && --it->second == 0) known_.erase(it); }
-    bool IsKnownIP(uint32_t ip) const { return known_.count(ip) != 0; }
+    // IPs currently present in the join tables: the Host header is interned only when the destination is in neither, i.e.
+    // exactly when setFromToV2 would use it (:851-854).  Two plain sets with the reference's map semantics (persist.go:55-71,
+    // 114-130: ADD and UPDATE store, DELETE erases) — not a count: ADD + UPDATE + DELETE of one pod leaves nothing behind.
+    void SetPodIP(uint32_t ip, bool present) { if (present) pod_ips_.insert(ip); else pod_ips_.erase(ip); }
+    void SetServiceIP(uint32_t ip, bool present) { if (present) svc_ips_.insert(ip); else svc_ips_.erase(ip); }
+    bool IsKnownIP(uint32_t ip) const { return pod_ips_.count(ip) != 0 || svc_ips_.count(ip) != 0; }
 
     // Appends 0..n packed events for `e` to `out`.  kafka_msgs = number of messages a Kafka decoder on the
     // caller's side produced for this event (ignored for other protocols, and ignored when SetKafkaDecode(true):
@@ -54,6 +55,10 @@ public:
     // a closed connection (processTcpConnect, data.go:484-503): its HPACK state goes, and every remembered Postgres
     // statement whose "pid-fd-name" key STARTS WITH "pid-fd" (the reference's HasPrefix: fd 7 also clears fd 70..79)
     void ConnClosed(uint32_t pid, uint64_t fd);
+    // an exited process (processExit, data.go:363-401): its HTTP/2 parsers, and every remembered Postgres statement whose key
+    // starts with the decimal pid (HasPrefix again: pid 12 also clears pid 120..129).  The reference's loop over mySqlStmts
+    // iterates pgStmts' keys after they were deleted, so MySQL statements survive an exit there — and here.
+    void ProcExit(uint32_t pid);
     size_t PgStatements() const { return pg_stmts_.size(); }
     void SetKafkaDecode(bool on) { kafka_decode_ = on; }
     Http2Assembler& Http2() { return h2_; }
@@ -65,7 +70,7 @@ private:
     int ParseMySQL(const l7_req::L7Event& e, std::string* out);
     static int ParseMongo(const l7_req::L7Event& e, std::string* out);
 
-    std::unordered_map<uint32_t, uint32_t> known_;
+    std::unordered_set<uint32_t> pod_ips_, svc_ips_;
     std::unordered_map<std::string, uint32_t> label_ids_;
     std::vector<std::string> labels_;
     std::unordered_map<std::string, std::string> pg_stmts_, mysql_stmts_;   // data.go pgStmts / mySqlStmts

@@ -76,6 +76,7 @@ struct sg_engine {
     bool use_mfma = true;
     int k1_grid = 0;
     size_t k1a_lds = 0, k1b_lds = 0, k3in_lds = 0;
+    u32 k3_ranges = 1, k3_slices = 8;
     u32 k1b_threads = 512, k1b_u = 4;
     u64 window_events_in = 0;
 
@@ -302,11 +303,9 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 0, s, d);
     }
     {
-        Timed t3(e, s, 8);                                   // group 8 = k3_in_stats (group 3 = node + edge features)
-        // dense-LDS case: few workgroups (every one flushes every node it saw); hashed case (too many nodes for
-        // LDS): a workgroup aggregates HT/2 edges per round, so more of them, bounded by the flush atomics
-        const int g3 = d.in_dense ? K3_IN_WGS : (int)std::min<u64>(128, std::max<u64>(K3_IN_WGS, (e->cfg.max_edges + K3_IN_ROUND - 1) / K3_IN_ROUND));
-        hipLaunchKernelGGL(k3_in_stats, dim3(g3), dim3(1024), e->k3in_lds, s, d);
+        Timed t3(e, s, 8);                                   // group 8 = in-statistics (group 3 = node + edge features)
+        hipLaunchKernelGGL(k3_in_part, dim3(e->k3_ranges * e->k3_slices), dim3(1024), e->k3in_lds, s, d, e->k3_slices);
+        hipLaunchKernelGGL(k3_in_reduce, dim3(grid_for((u64)d.ncap * 6, 256, 1024)), dim3(256), 0, s, d, e->k3_slices);
     }
     HIP_TRY(e, hipGetLastError());
     e->closed = true;
@@ -510,10 +509,12 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }
     d.emask = e->ecap - 1;
-    d.in_dense = d.ncap <= K3_IN_NODES ? 1u : 0u;
     d.alive_cap = cfg->max_alive ? cfg->max_alive : 65536u;
-    e->k3in_lds = d.in_dense ? (size_t)d.ncap * 48 : (size_t)K3_IN_HT * 52;
-    CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
+    e->k3_ranges = (d.ncap + K3_IN_NR - 1) / K3_IN_NR;
+    e->k3_slices = (u32)std::min<u64>(K3_IN_SMAX, std::max<u64>(8, ME / 8192));
+    if (const char* v = std::getenv("SG_K3_SLICES")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= 256) e->k3_slices = (u32)x; }
+    e->k3in_lds = (size_t)K3_IN_NR * 48;
+    CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
     CR(dev_alloc(e, &d.dbg, (size_t)4 * 4096 * 8));
     // everything a window owns; allocated once per slot
@@ -553,6 +554,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.P, (size_t)w.ncap * SG_F_HID)); LR(dev_alloc(e, &w.Q, (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.efeat, ME * SG_F_EDGE)); LR(dev_alloc(e, &w.latz, ME)); LR(dev_alloc(e, &w.errr, ME));
         LR(dev_alloc(e, &w.rows, ME));
+        LR(dev_alloc(e, &w.in_part, (size_t)e->k3_ranges * e->k3_slices * K3_IN_NR * 6));
         LR(dev_alloc(e, &w.alive_keys, w.alive_cap)); LR(dev_alloc(e, &w.alive_csr, ME));
         LR(dev_alloc(e, &w.act_l, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.act_p, (size_t)w.ncap + 1));
         // arm the per-workgroup statistic slots (tmin = ~0)

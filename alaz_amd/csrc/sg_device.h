@@ -119,7 +119,7 @@ struct Dev {
     u64*   acc_src;                           // accumulators by slot: eacc (variant 1) or partition output (variant 0)
     u32*   longrows;                          // [ncap] rows with more than 64 edges (work list of the row sort)
     u32*   e_rank;                            // [np*pcap] position of the edge inside its row (arrival order)
-    u32 in_dense;                             // 1: node-indexed LDS accumulation (ncap small enough), 0: hashed
+    u64* in_part;                             // k3_in_part -> k3_in_reduce: [node ranges][edge slices][K3_IN_NR][6] partial in-statistics
     u32 batch_state;                          // per launch: k1a_partition 1 = first batch of the window (piece headers are
                                               // not read, every workgroup rewrites all of its headers); k1b_merge 2 = the
                                               // window had no batch (pieces hold the previous window: ignore them)

@@ -1018,7 +1018,49 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
             if (m == 0) continue;
             u32* key = d.col + b; u32* val = d.cslot + b;
             u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
-            if (BW <= K2_SORT_LDS) {
+            if (BW <= K2_SORT_LDS && m <= 1024) {
+                // The common long row (65..1024 edges): bitmap rank as below, but every thread keeps its (<= 4) elements
+                // and their accumulators in registers — one global round trip (the accumulator gather, issued before the
+                // rank is known), no scratch arrays, three barriers.
+                for (u32 w = threadIdx.x; w < BW; w += 256) sk[w] = 0;
+                __syncthreads();
+                u32 mk[4], mv[4]; ulonglong2 ax[4], ay[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32 i = threadIdx.x + q * 256;
+                    mk[q] = i < m ? key[i] : 0u; mv[q] = i < m ? val[i] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32 i = threadIdx.x + q * 256;
+                    if (i < m) { atomicOr(&sk[mk[q] >> 5], 1u << (mk[q] & 31)); const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q] * 4); ax[q] = a[0]; ay[q] = a[1]; }
+                    else { ax[q] = make_ulonglong2(0, 0); ay[q] = make_ulonglong2(0, 0); }
+                }
+                __syncthreads();
+                {   // sv[w] = number of set bits in words [0, w)
+                    const u32 per = (BW + 255) / 256, w0 = threadIdx.x * per < BW ? threadIdx.x * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
+                    u32 c = 0;
+                    for (u32 w = w0; w < w1; w++) c += __popc(sk[w]);
+                    u32 tot;
+                    u32 run = block_excl_scan<256>(c, bsum, &tot);
+                    for (u32 w = w0; w < w1; w++) { sv[w] = run; run += __popc(sk[w]); }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; q++) { cnt += ax[q].x & 0xFFFFFFFFull; err += ax[q].x >> 32; sum += ax[q].y; ssq += ay[q].y; mx = ay[q].x > mx ? ay[q].x : mx; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) {
+                    const u32 k = mk[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
+                    key[r] = k;                                           // every key of the row was read before the barriers
+                    edge_emit(ea, b + r, rr, mv[q], 0, 0, 0, ax[q], ay[q]);
+                }
+                cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+                if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+                __syncthreads();
+                cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+                sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+                mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+            } else if (BW <= K2_SORT_LDS) {
                 // Bitmap rank: the destinations of one row are distinct node ids < N, so setting bit `to` in an
                 // N-bit LDS bitmap and counting the bits below it IS the sorted position — O(m + N/32) per row
                 // instead of a comparison sort (a 3000-edge hub row cost ~100 us in the bitonic network).
@@ -1157,21 +1199,16 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 }
 
 // ---- in-statistics: per destination node, reduce over its in-edges --------------------------------
-// A handful of workgroups each accumulate a contiguous range of CSR positions in LDS (node-indexed
-// arrays when ncap <= K3_IN_NODES, else a hash table refilled per round) with LDS atomics, then
-// flush the touched nodes with device-scope atomics: a popular service with thousands of in-edges
-// receives one atomic per word per workgroup instead of one per edge.
-#define K3_IN_NODES 2560
-#define K3_IN_HT    2048
-#define K3_IN_ROUND 8192      // edges per round of the hashed path
-#define K3_IN_PROBES 32
-#define K3_IN_WGS   16
-__device__ __forceinline__ void in_flush(const Dev& d, u32 to, const u64* o) {
-    u64* gsum = d.st_sum + (size_t)to * SG_NODE_STAT_SUM_WORDS;
-    atomicAdd(&gsum[ST_IN_DEG], o[0]); atomicAdd(&gsum[ST_IN_CNT], o[1]); atomicAdd(&gsum[ST_IN_ERR], o[2]);
-    atomicAdd(&gsum[ST_IN_SUM], o[3]); atomicAdd(&gsum[ST_IN_SSQ], o[4]);
-    atomicMax(&d.st_max[(size_t)to * 2 + 1], o[5]);
-}
+// No device-scope atomics (they top out at ~22 G/s chip-wide: the hashed-LDS + atomic-flush version of round 1 spent
+// 175 us on C3's 1 M edges = 2.4 % of the HBM roofline).  Two launches instead:
+//   k3_in_part   grid = node ranges x edge slices.  Workgroup (r, s) owns the K3_IN_NR nodes of range r in node-indexed
+//                LDS arrays, scans slice s of the CSR destination column (coalesced u32 reads, L2-resident across the
+//                ranges) and folds the accumulators of the edges that point into its range with LDS atomics; then it
+//                writes its arrays to the partial buffer with plain coalesced stores.
+//   k3_in_reduce one thread per (node, word): sums (max for the last word) the slices' partials into st_sum / st_max.
+// Exact (integer sums and max are order-free) and deterministic.
+#define K3_IN_NR    3072      // nodes per range: 3072 x 6 x 8 B = 144 KiB of LDS
+#define K3_IN_SMAX  32        // edge slices at most
 // The window's open connections (SG_EV_ALIVE, f-2) are marked here too: every record's edge exists in
 // the CSR (K1 created it with count 0 if it carried no request); a binary search in the sorted row
 // finds it.  Costs one scalar load when the window has none.
@@ -1200,73 +1237,46 @@ __device__ __forceinline__ void alive_mark(const Dev& d, u32 g, u32 G, u32 t) {
     }
 }
 
-__global__ __launch_bounds__(1024) void k3_in_stats(Dev d) {
+__global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 E = (u32)d.ctr[C_N_EDGES], N = (u32)d.ctr[C_N_NODES];
     const u32 G = gridDim.x, g = blockIdx.x, t = threadIdx.x;
     alive_mark(d, g, G, t);
-    const u32 per = (E + G - 1) / G, p0 = g * per < E ? g * per : E, p1 = p0 + per < E ? p0 + per : E;
-    if (d.in_dense) {
-        u64* acc = reinterpret_cast<u64*>(smem);                     // [N][6]: deg, cnt, err, sum, ssq, max
-        for (u32 i = t; i < N * 6; i += 1024) acc[i] = 0;
-        __syncthreads();
-        for (u32 pb = p0 + t; pb < p1; pb += 1024 * 4) {          // 4 edges per thread in flight
-            u32 to[4]; ulonglong2 x[4], y[4];
+    const u32 r = g / S, sl = g % S, n0 = r * K3_IN_NR;
+    if (n0 >= N) return;
+    const u32 nr = N - n0 < K3_IN_NR ? N - n0 : K3_IN_NR;
+    u64* acc = reinterpret_cast<u64*>(smem);                         // [nr][6]: deg, cnt, err, sum, ssq, max
+    for (u32 i = t; i < nr * 6; i += 1024) acc[i] = 0;
+    __syncthreads();
+    const u32 per = (E + S - 1) / S, p0 = sl * per < E ? sl * per : E, p1 = p0 + per < E ? p0 + per : E;
+    for (u32 pb = p0 + t; pb < p1; pb += 1024 * 4) {              // 4 edges per thread in flight
+        u32 to[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32 p = pb + q * 1024;
-                if (p < p1) { to[q] = d.col[p]; const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4); x[q] = a[0]; y[q] = a[1]; }
-            }
+        for (int q = 0; q < 4; q++) { const u32 p = pb + q * 1024; to[q] = p < p1 ? d.col[p] - n0 : 0xFFFFFFFFu; }
+        ulonglong2 x[4], y[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (pb + q * 1024 < p1) {
-                u64* o = acc + (size_t)to[q] * 6;
-                atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x[q].x & 0xFFFFFFFFull); atomicAdd(&o[2], x[q].x >> 32);
-                atomicAdd(&o[3], x[q].y); atomicAdd(&o[4], y[q].y); atomicMax(&o[5], y[q].x);
-            }
+        for (int q = 0; q < 4; q++) if (to[q] < nr) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)(pb + q * 1024) * 4); x[q] = a[0]; y[q] = a[1]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (to[q] < nr) {
+            u64* o = acc + (size_t)to[q] * 6;
+            atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x[q].x & 0xFFFFFFFFull); if (x[q].x >> 32) atomicAdd(&o[2], x[q].x >> 32);
+            atomicAdd(&o[3], x[q].y); atomicAdd(&o[4], y[q].y); atomicMax(&o[5], y[q].x);
         }
-        __syncthreads();
-        for (u32 v = t; v < N; v += 1024) if (acc[(size_t)v * 6]) in_flush(d, v, acc + (size_t)v * 6);
-    } else {
-        u64* tacc = reinterpret_cast<u64*>(smem);                    // [K3_IN_HT][6]
-        u32* tkey = reinterpret_cast<u32*>(tacc + K3_IN_HT * 6);     // [K3_IN_HT]
-        // Rounds of K3_IN_ROUND edges (8 per thread, loads of a thread's edges in flight together).  The table holds
-        // K3_IN_HT distinct destinations; a destination that finds no slot within K3_IN_PROBES probes (a round with
-        // too many distinct destinations) is added with device-scope atomics directly — rare, and exact either way.
-        for (u32 c0 = p0; c0 < p1; c0 += K3_IN_ROUND) {
-            for (u32 i = t; i < K3_IN_HT; i += 1024) tkey[i] = SG_NONE;
-            for (u32 i = t; i < K3_IN_HT * 6; i += 1024) tacc[i] = 0;
-            __syncthreads();
-            const u32 c1 = c0 + K3_IN_ROUND < p1 ? c0 + K3_IN_ROUND : p1;
-            for (u32 pb = c0 + t; pb < c1; pb += 1024 * 4) {
-                u32 to[4]; ulonglong2 x[4], y[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const u32 p = pb + q * 1024;
-                    if (p < c1) { to[q] = d.col[p]; const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4); x[q] = a[0]; y[q] = a[1]; }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) if (pb + q * 1024 < c1) {
-                    u32 h = sg_fmix32(to[q]) & (K3_IN_HT - 1);
-                    bool found = false;
-                    for (u32 pr = 0; pr < K3_IN_PROBES; pr++) {
-                        u32 kk = lds_fresh_u32(&tkey[h]);
-                        if (kk == SG_NONE) { kk = atomicCAS(&tkey[h], SG_NONE, to[q]); if (kk == SG_NONE) kk = to[q]; }
-                        if (kk == to[q]) { found = true; break; }
-                        h = (h + 1) & (K3_IN_HT - 1);
-                    }
-                    if (found) {
-                        u64* o = tacc + (size_t)h * 6;
-                        atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x[q].x & 0xFFFFFFFFull); atomicAdd(&o[2], x[q].x >> 32);
-                        atomicAdd(&o[3], x[q].y); atomicAdd(&o[4], y[q].y); atomicMax(&o[5], y[q].x);
-                    } else {
-                        const u64 one[6] = {1ull, x[q].x & 0xFFFFFFFFull, x[q].x >> 32, x[q].y, y[q].y, y[q].x};
-                        in_flush(d, to[q], one);
-                    }
-                }
-            }
-            __syncthreads();
-            for (u32 s = t; s < K3_IN_HT; s += 1024) if (tkey[s] != SG_NONE) in_flush(d, tkey[s], tacc + (size_t)s * 6);
-            __syncthreads();
+    }
+    __syncthreads();
+    u64* out = d.in_part + ((size_t)r * S + sl) * K3_IN_NR * 6;
+    for (u32 i = t; i < nr * 6; i += 1024) out[i] = acc[i];
+}
+__global__ __launch_bounds__(256) void k3_in_reduce(Dev d, u32 S) {
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < (u64)N * 6; i += (u64)gridDim.x * 256) {
+        const u32 v = (u32)(i / 6), k = (u32)(i % 6), r = v / K3_IN_NR;
+        const u64* p = d.in_part + ((size_t)r * S * K3_IN_NR + (v - r * K3_IN_NR)) * 6 + k;
+        u64 a = 0;
+        if (k == 5) { for (u32 sl = 0; sl < S; sl++) { const u64 x = p[(size_t)sl * K3_IN_NR * 6]; a = x > a ? x : a; } d.st_max[(size_t)v * 2 + 1] = a; }
+        else {
+            for (u32 sl = 0; sl < S; sl++) a += p[(size_t)sl * K3_IN_NR * 6];
+            d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + (k == 0 ? ST_IN_DEG : k == 1 ? ST_IN_CNT : k == 2 ? ST_IN_ERR : k == 3 ? ST_IN_SUM : ST_IN_SSQ)] = a;
         }
     }
 }

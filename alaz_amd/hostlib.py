@@ -83,6 +83,7 @@ def load() -> C.CDLL:
             "sgh_kafka_decode": (C.c_long, [C.c_char_p, sz, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_char_p, sz]),
             "sgh_kafka_decompress": (C.c_long, [C.c_int, C.c_char_p, sz, C.c_char_p, sz]),
             "sgh_crc32": (u32, [C.c_int, C.c_char_p, sz]), "sgh_xxh32": (u32, [C.c_char_p, sz, u32]),
+            "sgh_graphds_create2": (P, [C.c_char_p, P, sz, C.c_int]), "sgh_graphds_counters": (None, [P, P]),
             "sgh_mock_events": (sz, [P, P, sz]), "sgh_mock_table_ops": (sz, [P, P, sz]), "sgh_mock_label_count": (u32, [P]),
         }
         for name, (res, args) in sig.items():
@@ -299,9 +300,9 @@ class GraphDS:
     """C++ GraphDS over the real engine (engine_lib = path of libservicegraph.so) or over a recording
     stand-in (engine_lib=None; host-logic tests)."""
 
-    def __init__(self, cfg: SgConfig, engine_lib: Optional[str] = ENGINE_LIB, batch: int = 4096):
+    def __init__(self, cfg: SgConfig, engine_lib: Optional[str] = ENGINE_LIB, batch: int = 4096, divert_requests: bool = False):
         self._l = load()
-        self._g = self._l.sgh_graphds_create(engine_lib.encode() if engine_lib else None, C.byref(cfg), batch)
+        self._g = self._l.sgh_graphds_create2(engine_lib.encode() if engine_lib else None, C.byref(cfg), batch, int(divert_requests))
         if not self._g:
             raise RuntimeError("GraphDS: engine could not be created (no usable gfx950 device or library missing); no CPU fallback")
         self.max_edges = int(cfg.max_edges)
@@ -397,6 +398,11 @@ class GraphDS:
         from . import engine
         w = np.ascontiguousarray(w, dtype=np.float32)
         assert engine.load_library().sg_load_weights(self.engine_handle, w.ctypes.data, len(w)) == 0
+
+    def counters(self) -> dict:
+        a = (C.c_uint64 * 9)()
+        self._l.sgh_graphds_counters(self._g, a)
+        return dict(zip(("offered", "batches_dropped", "engine_errors", "live_ids", "inner_requests", "inner_kafka", "inner_alive", "inner_pods", "inner_services"), list(a)))
 
     def mock_events(self) -> np.ndarray:
         n = self._l.sgh_mock_events(self._g, None, 0)

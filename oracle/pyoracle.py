@@ -341,6 +341,8 @@ class Oracle:
         km = None
         if kafka_msgs is not None:
             kafka_msgs = np.ascontiguousarray(kafka_msgs, dtype=np.uint32); km = kafka_msgs.ctypes.data
+        if not isinstance(recs, bytes):
+            recs = bytes(recs)
         # no copy: the C side only reads (a 219 MB from_buffer_copy per call was a third of the measured "CPU baseline")
         return self._l.or_process_l7_wire(self._o, C.cast(C.c_char_p(recs), C.c_void_p), n, km)
 

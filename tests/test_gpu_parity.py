@@ -424,22 +424,28 @@ def _feed(g, ev, chunk=1 << 18):
             pass
 
 
-def test_config3_graph_two_layers_against_the_oracle():
-    """BASELINE config 3's graph (10k pods / 5k services / 1M edges, power-law out-degree up to 3750) with 2M
-    events and 2 SAGE layers, on the partitioned K1 (4096 partitions): row-for-row against the oracle
-    (~590k edges; rows come out in the same canonical order, so arrays are compared directly)."""
-    from oracle import pyoracle
+def _c3_engine_and_rows(n_events):
     topo = replay.make_topology(10_000, 1_000_000, replay.SEED_BASE + 3)
-    ev, labels = replay.make_events(topo, 2_000_000, replay.SEED_BASE + 3)
+    ev, labels = replay.make_events(topo, n_events, replay.SEED_BASE + 3)
     g = _engine(topo.n_nodes, 1_250_000, 2, max_labels=128, max_outbound_ips=128, max_window_events=len(ev))
     shim = HostShim(); shim.apply(g, topo.k8s_ops())
     _feed(g, ev)
     g.set_label_count(len(labels))
-    rows = g.flush_window()
+    return topo, ev, labels, g, g.flush_window()
+
+
+def test_config3_full_size_row_for_row_against_the_oracle():
+    """BASELINE config 3 at FULL size — 10k pods / 5k services / 1M edges (power-law out-degree up to 3750), 10M events,
+    2 SAGE layers, fed as 40 host batches — row for row against the oracle: every edge identity, every integer
+    accumulator, err_ratio bit-exact; score within 1e-5, lat_z within 1e-5 relative (north_star).  Rows come out in
+    the same canonical order, so the arrays are compared directly (~1.0 M rows)."""
+    from oracle import pyoracle
+    topo, ev, labels, g, rows = _c3_engine_and_rows(10_000_000)
     o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(2), 2)
     want = o.edge_rows()
     st = g.stats()
-    assert st.events_dropped_cap == 0 and st.last_window_events == o.window_events and len(rows) == len(want) > 500_000
+    assert st.events_dropped_cap == 0 and st.last_window_events == o.window_events and len(rows) == len(want) > 1_000_000
+    assert st.events_dropped_src == o.dropped_src and st.last_window_nodes == o.n_nodes
     for f in ("from_ref", "to_ref", "count", "err_count", "sum_ns", "max_ns", "sumsq_us", "err_ratio"):
         assert np.array_equal(rows[f], want[f]), f
     assert np.abs(rows["score"] - want["score"]).max() <= 1e-5
@@ -450,13 +456,7 @@ def test_config3_full_size_invariants():
     """BASELINE config 3 at full size (10M events, 1M edges, L=2): size-independent properties — event
     conservation, checksums of the integer accumulators against numpy, canonical strictly increasing
     row order, scores inside (0, 1)."""
-    topo = replay.make_topology(10_000, 1_000_000, replay.SEED_BASE + 3)
-    ev, labels = replay.make_events(topo, 10_000_000, replay.SEED_BASE + 3)
-    g = _engine(topo.n_nodes, 1_250_000, 2, max_labels=128, max_outbound_ips=128, max_window_events=len(ev))
-    HostShim().apply(g, topo.k8s_ops())
-    _feed(g, ev)
-    g.set_label_count(len(labels))
-    rows = g.flush_window()
+    topo, ev, labels, g, rows = _c3_engine_and_rows(10_000_000)
     st = g.stats()
     acc = np.isin(ev["saddr"], topo.pod_ips)
     assert st.events_dropped_cap == 0 and st.events_dropped_src == int((~acc).sum())
@@ -476,6 +476,82 @@ def test_config3_full_size_invariants():
     assert ((rows["score"] > 0) & (rows["score"] < 1)).all() and np.isfinite(rows["lat_z"]).all()
     key_ev = np.unique((ev["saddr"][acc].astype(np.uint64) << np.uint64(32)) | ev["daddr"][acc].astype(np.uint64))
     assert len(rows) == len(key_ev)                 # HTTP-only trace: one edge per distinct (saddr, daddr) of accepted events
+
+
+def _logical_shards(topo, ev, labels, layers, world, *, max_edges, max_labels=128, max_obip=128):
+    """`world` shard engines on ONE device, one thread per shard, the real HipBackend + exchange logic with the
+    collectives going through ThreadComm; returns the concatenated rows and the engines' summed drop counters."""
+    import threading
+    import torch
+    from alaz_amd import engine, sharded
+    W = weights.make_weights(layers)
+    pod = {int(ip): i for i, ip in enumerate(topo.pod_ips)}; svc = {int(ip): topo.n_pods + j for j, ip in enumerate(topo.svc_ips)}
+    shard = sharded.route_events(ev, world, pod, svc)
+    shared = sharded.ThreadComm.Shared(world)
+    dev = torch.device("cuda", 0)
+    ncap = topo.n_nodes + max_labels + max_obip
+    engs, bes, outs = [], [], [None] * world
+    for r in range(world):
+        g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=max_edges, layers=layers, max_labels=max_labels, max_outbound_ips=max_obip,
+                                rank=r, world=world, max_window_events=int((shard == r).sum()) + 1)
+        g.set_clock(*CLOCK); g.load_weights(W); HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
+        _feed(g, ev[shard == r])
+        engs.append(g)
+        bes.append(sharded.HipBackend(g, ncap=ncap, layers=layers, world=world, rank=r, device=dev, max_obip=max_obip, stream=torch.cuda.Stream(dev)))
+
+    def run(r):
+        sharded.run_window(bes[r], sharded.ThreadComm(shared, r))
+        outs[r] = engs[r].window_read().copy()
+        engs[r].window_reset(bes[r].s)
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths: t.start()
+    for t in ths: t.join(timeout=600)
+    assert all(o is not None for o in outs)
+    bad = sum(e.stats().events_dropped_cap + e.stats().events_misrouted + e.stats().halo_overflow for e in engs)
+    for g in engs: g.close()
+    return np.concatenate(outs), bad, [len(o) for o in outs]
+
+
+def test_config4_eight_logical_shards_of_the_config3_graph_equal_one_engine():
+    """BASELINE config 4 = config 3's graph hash-sharded by source pod over 8 GPUs.  Here: 8 logical shards on one
+    device (SURVEY.md §8e validation), 4 M events, 2 layers — the concatenated rows must equal the unsharded
+    engine's bit for bit (halo rows are copied, never reduced; integer statistics are exact), with the halo capacity
+    the multi-GPU bench uses (sized from the node space / world) and no overflow."""
+    topo, ev, labels, g, want = _c3_engine_and_rows(4_000_000)
+    g.close()
+    got, bad, per = _logical_shards(topo, ev, labels, 2, 8, max_edges=1_250_000 // 4)
+    assert bad == 0 and min(per) > 50_000
+    key = lambda a: np.lexsort((a["to_ref"], a["from_ref"]))
+    got = got[key(got)]; exp = want[key(want)]
+    assert len(got) == len(exp) > 800_000
+    assert got.tobytes() == exp.tobytes()
+
+
+def test_config5_mixed_protocol_window_on_the_global_table_path_against_the_oracle():
+    """BASELINE config 5's graph at full size (100k pods / 50k services / 20M edges) with one 5 M-event window of the
+    70/15/15 HTTP / Kafka / Postgres mix, on ONE GPU: the engine picks the global-table K1 (variant 1; the graph is
+    beyond the partitioned path's range) and a join table that does not fit LDS.  Row for row against the oracle."""
+    from oracle import pyoracle
+    c = replay.CONFIGS[5]
+    topo = replay.make_topology(c["pods"], c["edges"], replay.SEED_BASE + 5)
+    ev, labels = replay.make_events(topo, c["events"], replay.SEED_BASE + 5, mixed=True)
+    g = _engine(topo.n_nodes, int(c["edges"] * 1.1), 2, max_labels=128, max_outbound_ips=128, max_window_events=len(ev), max_batch=1 << 20)
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    _feed(g, ev, chunk=1 << 20)
+    g.set_label_count(len(labels))
+    rows = g.flush_window()
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(2), 2)
+    want = o.edge_rows()
+    st = g.stats()
+    assert st.events_dropped_cap == 0 and st.last_window_events == o.window_events and len(rows) == len(want) > 2_000_000
+    assert st.events_dropped_src == o.dropped_src and st.last_window_nodes == o.n_nodes
+    for f in ("from_ref", "to_ref", "count", "err_count", "sum_ns", "max_ns", "sumsq_us", "err_ratio"):
+        assert np.array_equal(rows[f], want[f]), f
+    assert np.abs(rows["score"] - want["score"]).max() <= 1e-5
+    assert (np.abs(rows["lat_z"] - want["lat_z"]) <= 1e-5 * np.maximum(1.0, np.abs(want["lat_z"]))).all()
+    pg = ev["protocol"] == replay.PROTO_POSTGRES
+    acc = np.isin(ev["saddr"], topo.pod_ips)
+    assert int(rows["err_count"].sum()) == int(((ev["status"] >= 500) & acc & (ev["protocol"] == replay.PROTO_HTTP)).sum() + ((ev["status"] == 2) & acc & pg).sum())
 
 
 def test_windows_in_flight_give_the_same_rows_as_one_window_at_a_time():

@@ -331,3 +331,81 @@ def test_postgres_handler_keep_and_drop_rules():
     assert [r[14] for r in o.reqinfos()] == [w.split("\x00")[0] if "\x00" in w else w for w in kept]     # rows are C strings in the oracle's log
     pk = hostlib.Packer()
     assert len(pk.pack_wire(wire)) == len(kept) and pk.dropped_parse == o.dropped_parse == len(cases) - len(kept)
+
+
+def test_known_ip_sets_have_map_semantics_not_reference_counts():
+    """ADD + UPDATE + DELETE of one pod must leave its IP unknown again (persist.go:55-71 is a map store / delete, not a
+    count): afterwards a request to that address is outbound and its Host header is interned as the label.  The reverse
+    case too: DELETE of a pod that was never added must not remove a service that holds the same IP."""
+    A, X = 0x0A000001, 0x0A000063
+    g = hostlib.GraphDS(_cfg(), engine_lib=None, batch=1)
+    g.PersistPod("src", "10.0.0.1")
+    g.PersistPod("px", "10.0.0.99", "ADD"); g.PersistPod("px", "10.0.0.99", "UPDATE"); g.PersistPod("px", "10.0.0.99", "DELETE")
+    g.ingest_wire(_wire(A, X, payload=b"GET / HTTP/1.1\r\nHost: ext.example\r\n"))
+    assert g.labels == ["ext.example"] and int(g.mock_events()[-1]["host_label"]) == 1
+    g.PersistService("sx", "10.0.0.99", "ADD")
+    g.PersistPod("ghost", "10.0.0.99", "DELETE")                   # a pod nobody added: the service's entry stays
+    g.ingest_wire(_wire(A, X, payload=b"GET / HTTP/1.1\r\nHost: other.example\r\n"))
+    assert g.labels == ["ext.example"] and int(g.mock_events()[-1]["host_label"]) == 0
+
+
+def test_node_ids_are_recycled_after_the_window_that_could_name_them():
+    """Every rollout brings new pod UIDs; ids of pods whose last IP is gone must come back, or a long-running agent hits
+    sg_config.max_known_nodes (ADVICE r1).  16 ids, 40 generations of 6 pods (old and new generation overlap): no engine error;
+    an id is only reused after a FlushWindow (the open window may still name it); a DELETE of an unknown UID creates
+    nothing; a genuinely full id space is reported (SG_ENOSPC) and counted."""
+    g = hostlib.GraphDS(_cfg(nodes=16), engine_lib=None)
+    for gen in range(40):
+        for k in range(6):
+            assert g.PersistPod(f"pod-{gen}-{k}", f"10.1.{gen % 200}.{k + 1}") == 0
+        if gen:
+            for k in range(6):
+                g.PersistPod(f"pod-{gen - 1}-{k}", f"10.1.{(gen - 1) % 200}.{k + 1}", "DELETE")
+        g.PersistPod(f"never-seen-{gen}", "10.9.9.9", "DELETE")
+        c = g.counters()
+        assert c["engine_errors"] == 0 and c["live_ids"] <= 12, (gen, c)
+        g.FlushWindow(gen)
+        assert g.counters()["live_ids"] <= 6
+    ops = g.mock_table_ops()
+    assert ops[ops[:, 0] == 1][:, 2].max() < 16                     # every id handed to the engine is inside its id space
+    # without a flush in between nothing is reused: the 3rd new pod does not fit beside 6 live + ... ids
+    g2 = hostlib.GraphDS(_cfg(nodes=4), engine_lib=None)
+    for k in range(4):
+        assert g2.PersistPod(f"a{k}", f"10.2.0.{k + 1}") == 0
+    g2.PersistPod("a0", "10.2.0.1", "DELETE")
+    assert g2.PersistPod("b0", "10.2.0.9") == engine.SG_ENOSPC and g2.counters()["engine_errors"] == 1
+    g2.FlushWindow(1)
+    assert g2.PersistPod("b0", "10.2.0.9") == 0                       # a0's id is free now
+    # the same UID coming back before the flush keeps its id
+    g2.PersistPod("a1", "10.2.0.2", "DELETE"); assert g2.PersistPod("a1", "10.2.0.2") == 0
+    assert g2.counters()["engine_errors"] == 1
+
+
+def test_datastore_tap_is_additive_unless_diverted():
+    """PersistRequest / PersistKafkaEvent reach the inner data store by default (f-3 is additive: a backend without an
+    /edges/ route keeps its per-request rows); divert_requests=True keeps them in the engine only."""
+    row = (5, 1000, "10.0.0.1", "pod", "p1", 40000, "10.96.0.1", "service", "s1", 80, "HTTP", 200, "", "GET", "/", False)
+    for divert, want in ((False, 3), (True, 0)):
+        g = hostlib.GraphDS(_cfg(), engine_lib=None, divert_requests=divert)
+        g.PersistPod("p1", "10.0.0.1"); g.PersistService("s1", "10.96.0.1")
+        for _ in range(3):
+            assert g.PersistRequest(row) == 0
+        c = g.counters()
+        assert c["inner_requests"] == want and c["offered"] == 3 and c["inner_pods"] == 1 and c["inner_services"] == 1
+
+
+def test_process_exit_forgets_the_prepared_statements_of_the_pid():
+    """processExit (data.go:363-401) deletes every pgStmts key that starts with the pid — also of connections whose
+    close was never seen."""
+    from tests.test_oracle_golden import _wire as w
+    pk = hostlib.Packer()
+    parse = b"P" + (4 + 3 + 9 + 2).to_bytes(4, "big") + b"s1\x00" + b"SELECT 1\x00" + b"\x00\x00"
+    A, S = 0x0A000001, 0x0A600001
+    def rec(pid, fd):
+        r = bytearray(w(A, S, proto=3, method=3, status=1, payload=parse))   # EXTENDED_QUERY: a Parse message
+        r[16:20] = pid.to_bytes(4, "little"); r[0:8] = fd.to_bytes(8, "little")
+        return bytes(r)
+    pk.pack_wire(rec(12, 5) + rec(12, 6) + rec(120, 5) + rec(7, 5))
+    assert pk.pg_statements() == 4
+    pk.proc_exit(12)                                                   # HasPrefix("12"): pid 12 and pid 120
+    assert pk.pg_statements() == 1
