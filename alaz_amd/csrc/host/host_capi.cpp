@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,16 +25,18 @@ struct MockEngine {
     std::vector<sg_event> events;
     std::vector<std::array<uint32_t, 3>> table_ops;   // {op: 1 upsert_pod 2 delete_pod 3 upsert_svc 4 delete_svc, ip, id}
     uint32_t label_count = 0; uint32_t flushes = 0; uint32_t max_known = 0x3FFFFFFFu;
+    std::mutex mu;                                     // like the real engine, the stand-in serialises the calls on one handle
 };
+#define M_LOCK(h) std::lock_guard<std::mutex> _g(reinterpret_cast<MockEngine*>(h)->mu)
 int m_create(const sg_config* cfg, sg_handle* out) { auto* m = new MockEngine(); if (cfg && cfg->max_known_nodes) m->max_known = cfg->max_known_nodes; *out = reinterpret_cast<sg_handle>(m); return SG_OK; }
 int m_destroy(sg_handle h) { delete reinterpret_cast<MockEngine*>(h); return SG_OK; }
-int m_upsert_pod(sg_handle h, uint32_t ip, uint32_t id) { auto* m = reinterpret_cast<MockEngine*>(h); if (id >= m->max_known) return SG_ENOSPC; m->table_ops.push_back({1u, ip, id}); return SG_OK; }
-int m_delete_pod(sg_handle h, uint32_t ip) { reinterpret_cast<MockEngine*>(h)->table_ops.push_back({2u, ip, 0u}); return SG_OK; }
-int m_upsert_svc(sg_handle h, uint32_t ip, uint32_t id) { auto* m = reinterpret_cast<MockEngine*>(h); if (id >= m->max_known) return SG_ENOSPC; m->table_ops.push_back({3u, ip, id}); return SG_OK; }
-int m_delete_svc(sg_handle h, uint32_t ip) { reinterpret_cast<MockEngine*>(h)->table_ops.push_back({4u, ip, 0u}); return SG_OK; }
-int m_labels(sg_handle h, uint32_t n) { reinterpret_cast<MockEngine*>(h)->label_count = n; return SG_OK; }
-int m_ingest(sg_handle h, const sg_event* ev, size_t n) { auto* m = reinterpret_cast<MockEngine*>(h); m->events.insert(m->events.end(), ev, ev + n); return SG_OK; }
-int m_flush(sg_handle h, uint64_t, sg_edge_out*, size_t, size_t* n) { reinterpret_cast<MockEngine*>(h)->flushes++; if (n) *n = 0; return SG_OK; }
+int m_upsert_pod(sg_handle h, uint32_t ip, uint32_t id) { M_LOCK(h); auto* m = reinterpret_cast<MockEngine*>(h); if (id >= m->max_known) return SG_ENOSPC; m->table_ops.push_back({1u, ip, id}); return SG_OK; }
+int m_delete_pod(sg_handle h, uint32_t ip) { M_LOCK(h); reinterpret_cast<MockEngine*>(h)->table_ops.push_back({2u, ip, 0u}); return SG_OK; }
+int m_upsert_svc(sg_handle h, uint32_t ip, uint32_t id) { M_LOCK(h); auto* m = reinterpret_cast<MockEngine*>(h); if (id >= m->max_known) return SG_ENOSPC; m->table_ops.push_back({3u, ip, id}); return SG_OK; }
+int m_delete_svc(sg_handle h, uint32_t ip) { M_LOCK(h); reinterpret_cast<MockEngine*>(h)->table_ops.push_back({4u, ip, 0u}); return SG_OK; }
+int m_labels(sg_handle h, uint32_t n) { M_LOCK(h); reinterpret_cast<MockEngine*>(h)->label_count = n; return SG_OK; }
+int m_ingest(sg_handle h, const sg_event* ev, size_t n) { M_LOCK(h); auto* m = reinterpret_cast<MockEngine*>(h); m->events.insert(m->events.end(), ev, ev + n); return SG_OK; }
+int m_flush(sg_handle h, uint64_t, sg_edge_out*, size_t, size_t* n) { M_LOCK(h); reinterpret_cast<MockEngine*>(h)->flushes++; if (n) *n = 0; return SG_OK; }
 int m_obips(sg_handle, uint32_t*, size_t, size_t* n) { if (n) *n = 0; return SG_OK; }
 const char* m_err(sg_handle) { return ""; }
 

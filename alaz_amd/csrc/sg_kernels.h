@@ -491,6 +491,12 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
         // piece counters: zero by definition in the first batch of a window (no loads); a later batch reads them with
         // ordinary loads BEFORE anything is issued by hand
         for (u32 p = t; p < d.np; p += K1A_THREADS) fc[p] = first ? 0u : d.hdr[(size_t)p * d.nwg + w];
+        // the LDS set-up happens BEFORE anything is issued by hand: between a hand-issued load and its wait there must be no
+        // code at all (a loop there once made the register allocator move in-flight registers: the staged join table came
+        // out as garbage -> wild record addresses -> a memory fault, or a few hundred silently lost events)
+        for (u32 k = t; k < CT; k += K1A_THREADS) ckey[k] = SG_EKEY_EMPTY;
+        for (u32 k = t; k < CT * 4; k += K1A_THREADS) cacc[k] = 0;
+        if (t < 8) red[t] = t == WS_TMIN ? ~0ull : 0ull;
         // The join blob goes out first; right behind it one load per event of the first group, into a register nobody
         // reads: it pulls the group's lines towards this XCD's L2 while the LDS is being set up (every hand-issued load is
         // waited for inside the straight-line region that issued it, so the first group's real loads belong to the loop).
@@ -500,19 +506,22 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
         const uint4* g1 = reinterpret_cast<const uint4*>(d.jl1); const uint4* g2 = reinterpret_cast<const uint4*>(d.jl2) - n1;
 #define K1A_JIDX(k) ((t + (k) * K1A_THREADS) < n16 ? (t + (k) * K1A_THREADS) : n16 - 1)
 #define K1A_JSRC(k) ((K1A_JIDX(k) < n1 ? g1 : g2) + K1A_JIDX(k))
-        gload16_issue(jb0, K1A_JSRC(0)); gload16_issue(jb1, K1A_JSRC(1)); gload16_issue(jb2, K1A_JSRC(2));
-        gload16_issue(jb3, K1A_JSRC(3)); gload16_issue(jb4, K1A_JSRC(4)); gload16_issue(jb5, K1A_JSRC(5));
-#pragma unroll
-        for (u32 k = 0; k < K1A_G; k++) { const u64 j = i + (u64)k * K1A_THREADS; asm volatile("global_load_dword %0, %1, off" : "=&v"(pf) : "v"(pe + 2 * (j < end ? j : last)) : "memory"); }
-        for (u32 k = t; k < CT; k += K1A_THREADS) ckey[k] = SG_EKEY_EMPTY;
-        for (u32 k = t; k < CT * 4; k += K1A_THREADS) cacc[k] = 0;
-        asm volatile("s_waitcnt vmcnt(4)" : "+v"(jb0), "+v"(jb1), "+v"(jb2), "+v"(jb3), "+v"(jb4), "+v"(jb5) : : "memory");
+        const uint4* js0 = K1A_JSRC(0); const uint4* js1 = K1A_JSRC(1); const uint4* js2 = K1A_JSRC(2);
+        const uint4* js3 = K1A_JSRC(3); const uint4* js4 = K1A_JSRC(4); const uint4* js5 = K1A_JSRC(5);
+        const uint4* pf0 = pe + 2 * (i < end ? i : last); const uint4* pf1 = pe + 2 * (i + K1A_THREADS < end ? i + K1A_THREADS : last);
+        const uint4* pf2 = pe + 2 * (i + 2 * K1A_THREADS < end ? i + 2 * K1A_THREADS : last); const uint4* pf3 = pe + 2 * (i + 3 * K1A_THREADS < end ? i + 3 * K1A_THREADS : last);
+        // all addresses are in registers: ten issues and the wait in ONE statement
+        asm volatile("global_load_dwordx4 %0, %7, off\n\tglobal_load_dwordx4 %1, %8, off\n\tglobal_load_dwordx4 %2, %9, off\n\t"
+                     "global_load_dwordx4 %3, %10, off\n\tglobal_load_dwordx4 %4, %11, off\n\tglobal_load_dwordx4 %5, %12, off\n\t"
+                     "global_load_dword %6, %13, off\n\tglobal_load_dword %6, %14, off\n\tglobal_load_dword %6, %15, off\n\tglobal_load_dword %6, %16, off\n\t"
+                     "s_waitcnt vmcnt(4)"
+                     : "=&v"(jb0), "=&v"(jb1), "=&v"(jb2), "=&v"(jb3), "=&v"(jb4), "=&v"(jb5), "=&v"(pf)
+                     : "v"(js0), "v"(js1), "v"(js2), "v"(js3), "v"(js4), "v"(js5), "v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3) : "memory");
 #define K1A_JST(k, r) if (t + (k) * K1A_THREADS < n16) jl[t + (k) * K1A_THREADS] = make_uint4((r).x, (r).y, (r).z, (r).w)
         K1A_JST(0, jb0); K1A_JST(1, jb1); K1A_JST(2, jb2); K1A_JST(3, jb3); K1A_JST(4, jb4); K1A_JST(5, jb5);
 #undef K1A_JST
 #undef K1A_JSRC
 #undef K1A_JIDX
-        if (t < 8) red[t] = t == WS_TMIN ? ~0ull : 0ull;
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) : : "memory");
         LDS_BARRIER();
         SG_STAMP(d, 0, 1);

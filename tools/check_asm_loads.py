@@ -36,20 +36,23 @@ def check(asm_text):
             kernel, inflight = m.group(1), []
         t = ln.strip()
         if t.startswith(";;#ASMSTART"):
-            body = lines[i + 1].strip()
-            if body.startswith("global_load"):
-                ops = [o.strip() for o in body.split(None, 1)[1].split(",")]
-                # the address operand must not be an in-flight register either
-                for o in ops[1:]:
-                    bad = regs(o) & set().union(*[r for r, _ in inflight]) if inflight else set()
-                    if bad:
-                        findings.append((kernel, i + 2, body, sorted(bad)))
-                inflight.append((regs(ops[0]), i + 2))
-            elif body.startswith("s_waitcnt"):
-                m2 = re.search(r"vmcnt\((\d+)\)", body)
-                keep = int(m2.group(1)) if m2 else 0
-                inflight = inflight[len(inflight) - keep:] if keep else []
-            i += 3                       # ASMSTART, body, ASMEND
+            j = i + 1                    # an asm statement may hold several instructions (issues + their wait)
+            while j < len(lines) and not lines[j].strip().startswith(";;#ASMEND"):
+                body = lines[j].strip()
+                if body.startswith("global_load"):
+                    ops = [o.strip() for o in body.split(None, 1)[1].split(",")]
+                    # the address operand must not be an in-flight register either
+                    for o in ops[1:]:
+                        bad = regs(o.split()[0]) & set().union(*[r for r, _ in inflight]) if inflight else set()
+                        if bad:
+                            findings.append((kernel, j + 1, body, sorted(bad)))
+                    inflight.append((regs(ops[0]), j + 1))
+                elif body.startswith("s_waitcnt"):
+                    m2 = re.search(r"vmcnt\((\d+)\)", body)
+                    keep = int(m2.group(1)) if m2 else 0
+                    inflight = inflight[len(inflight) - keep:] if keep else []
+                j += 1
+            i = j + 1
             continue
         if inflight and t and not t.startswith((";", ".")) and re.match(r"^[a-z]", t):
             parts = t.split(None, 1)
