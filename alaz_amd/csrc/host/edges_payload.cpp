@@ -66,7 +66,8 @@ std::string EdgesPayloadJson(const PayloadMetadata& md, int64_t window_end_ms, c
         AppendJsonString(e.ToType, &o); o += ','; AppendJsonString(e.ToUID, &o); o += ',';
         AppendU64(e.Count, &o); o += ','; AppendU64(e.ErrCount, &o); o += ','; AppendU64(e.SumNs, &o); o += ',';
         AppendU64(e.MaxNs, &o); o += ','; AppendU64(e.SumSqUs, &o); o += ','; AppendU64(e.Alive, &o); o += ',';
-        AppendJsonFloat(e.Score, &o); o += ','; AppendJsonFloat(e.LatZ, &o); o += ','; AppendJsonFloat(e.ErrRatio, &o);
+        AppendJsonFloat(e.Score, &o); o += ','; AppendJsonFloat(e.LatZ, &o); o += ','; AppendJsonFloat(e.ErrRatio, &o); o += ',';
+        AppendU64(e.P50Us, &o); o += ','; AppendU64(e.P99Us, &o);          // slots 13, 14: latency percentiles in microseconds (f-3)
         o += ']';
     }
     o += "]}";

@@ -255,7 +255,7 @@ long GraphDS::FlushWindow(int64_t window_end_ms) {
             const sg_edge_out& r = rows[i]; EdgeRow& o = out[i];
             name(r.from_ref, &o.FromType, &o.FromUID); name(r.to_ref, &o.ToType, &o.ToUID);
             o.Count = r.count; o.ErrCount = r.err_count; o.SumNs = r.sum_ns; o.MaxNs = r.max_ns; o.SumSqUs = r.sumsq_us;
-            o.Score = r.score; o.LatZ = r.lat_z; o.ErrRatio = r.err_ratio; o.Alive = r.alive;
+            o.Score = r.score; o.LatZ = r.lat_z; o.ErrRatio = r.err_ratio; o.Alive = r.alive; o.P50Us = r.p50_us; o.P99Us = r.p99_us;
         }
     }
     {   // the window that could still name the retired ids has been read: they may be handed out again, unless an IP

@@ -50,6 +50,7 @@ struct EdgeRow {                       // one edge of a closed window, in the re
     uint64_t SumNs = 0, MaxNs = 0, SumSqUs = 0;
     float Score = 0, LatZ = 0, ErrRatio = 0;
     uint32_t Alive = 0;                // open connections reported on the edge in the window
+    uint32_t P50Us = 0, P99Us = 0;     // latency percentiles off the edge's log2 histogram (0 unless SG_CFG_EDGE_HISTOGRAM)
 };
 
 class EdgeSink {

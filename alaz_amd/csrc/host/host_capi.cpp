@@ -68,7 +68,7 @@ extern "C" {
 
 struct sgh_edge_row {
     char from_type[12], to_type[12], from_uid[160], to_uid[160];
-    uint32_t count, err_count; uint64_t sum_ns, max_ns, sumsq_us; float score, lat_z, err_ratio; uint32_t alive;
+    uint32_t count, err_count; uint64_t sum_ns, max_ns, sumsq_us; float score, lat_z, err_ratio; uint32_t alive; uint32_t p50_us, p99_us;
 };
 
 void* sgh_packer_create(void) { return new L7Packer(); }
@@ -149,7 +149,7 @@ long sgh_graphds_flush(void* g, int64_t window_end_ms, sgh_edge_row* out, size_t
         std::memset(&o, 0, sizeof o);
         std::strncpy(o.from_type, r.FromType.c_str(), sizeof o.from_type - 1); std::strncpy(o.to_type, r.ToType.c_str(), sizeof o.to_type - 1);
         std::strncpy(o.from_uid, r.FromUID.c_str(), sizeof o.from_uid - 1); std::strncpy(o.to_uid, r.ToUID.c_str(), sizeof o.to_uid - 1);
-        o.count = r.Count; o.err_count = r.ErrCount; o.sum_ns = r.SumNs; o.max_ns = r.MaxNs; o.sumsq_us = r.SumSqUs;
+        o.count = r.Count; o.err_count = r.ErrCount; o.sum_ns = r.SumNs; o.max_ns = r.MaxNs; o.sumsq_us = r.SumSqUs; o.p50_us = r.P50Us; o.p99_us = r.P99Us;
         o.score = r.Score; o.lat_z = r.LatZ; o.err_ratio = r.ErrRatio; o.alive = r.Alive;
     }
     return n;
@@ -283,7 +283,7 @@ long sgh_edges_json_from_rows(const sgh_edge_row* in, size_t n_rows, int64_t win
     for (size_t i = 0; i < n_rows; i++) {
         EdgeRow& r = rows[i]; const sgh_edge_row& o = in[i];
         r.FromType = o.from_type; r.FromUID = o.from_uid; r.ToType = o.to_type; r.ToUID = o.to_uid;
-        r.Count = o.count; r.ErrCount = o.err_count; r.SumNs = o.sum_ns; r.MaxNs = o.max_ns; r.SumSqUs = o.sumsq_us;
+        r.Count = o.count; r.ErrCount = o.err_count; r.SumNs = o.sum_ns; r.MaxNs = o.max_ns; r.SumSqUs = o.sumsq_us; r.P50Us = o.p50_us; r.P99Us = o.p99_us;
         r.Score = o.score; r.LatZ = o.lat_z; r.ErrRatio = o.err_ratio; r.Alive = o.alive;
     }
     std::string all; long n = 0;

@@ -137,13 +137,14 @@ struct Timed {
 void k1a_geometry(sg_engine* e) {
     const Dev& d = e->d;
     const size_t l1b = (size_t)e->jt.l1_entries * 8, l2b = (size_t)e->jt.blocks_bytes(), fixed = (size_t)d.np * 4 + 64 + l1b;
+    const size_t slot = d.hist ? 72 : 40;                    // cache slot: key + 4 accumulators (+ 16 x u16 bins)
     e->l2_in_lds = false; e->k1a_ct = 2048;
     for (u32 ct : {2048u, 1024u, 512u}) {
-        if ((size_t)ct * 40 + fixed + l2b <= kLdsBytes && (l1b + l2b) / 16 <= (size_t)K1A_NJ * K1A_THREADS) { e->l2_in_lds = true; e->k1a_ct = ct; break; }
+        if ((size_t)ct * slot + fixed + l2b <= kLdsBytes && (l1b + l2b) / 16 <= (size_t)K1A_NJ * K1A_THREADS) { e->l2_in_lds = true; e->k1a_ct = ct; break; }
     }
-    if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) e->k1a_ct = x; }
+    if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * slot + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) e->k1a_ct = x; }
     if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
-    e->k1a_lds = (size_t)e->k1a_ct * 40 + fixed + (e->l2_in_lds ? l2b : 0);
+    e->k1a_lds = (size_t)e->k1a_ct * slot + fixed + (e->l2_in_lds ? l2b : 0);
 }
 // the sizes a K1 launch needs from the table state (pointers are fixed at create)
 void join_view(const sg_engine* e, Dev& d) {
@@ -214,6 +215,12 @@ void rotate_window(sg_engine* e) {
 
 int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     if (n == 0) return SG_OK;
+    // the pass-A cache keeps 16-bit histogram bins: a workgroup must see fewer than 65536 events per launch
+    const size_t kMaxHist = (size_t)65535 * 256;
+    if (e->d.hist && e->d.variant == 0 && n > kMaxHist) {
+        for (size_t o = 0; o < n; o += kMaxHist) { const int rc = launch_k1(e, d_ev + o, std::min(kMaxHist, n - o), s); if (rc) return rc; }
+        return SG_OK;
+    }
     int rc = sync_tables(e, s);
     if (rc) return rc;
     if ((rc = order_after_tables(e, s))) return rc;
@@ -226,9 +233,11 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         da.batch_state = e->window_events_in == 0 ? 1u : 0u;     // first batch of this window?
         const bool sh = e->d.world > 1;
-#define K1A_GO(L2, SH) hipExtLaunchKernelGGL((k1a_partition<L2, SH>), dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
-        if (e->l2_in_lds) { if (sh) K1A_GO(true, true); else K1A_GO(true, false); }
-        else { if (sh) K1A_GO(false, true); else K1A_GO(false, false); }
+#define K1A_GO(L2, SH, HI) hipExtLaunchKernelGGL((k1a_partition<L2, SH, HI>), dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
+#define K1A_GO2(L2, SH) do { if (e->d.hist) K1A_GO(L2, SH, true); else K1A_GO(L2, SH, false); } while (0)
+        if (e->l2_in_lds) { if (sh) K1A_GO2(true, true); else K1A_GO2(true, false); }
+        else { if (sh) K1A_GO2(false, true); else K1A_GO2(false, false); }
+#undef K1A_GO2
 #undef K1A_GO
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 1; e->trecs.push_back(r); }
     } else {
@@ -285,8 +294,9 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         const bool tk = (e->timing >> 7) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
-        if (e->k1b_u == 8) hipExtLaunchKernelGGL(k1b_merge<8>, dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
-        else hipExtLaunchKernelGGL(k1b_merge<4>, dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
+        if (d.hist) hipExtLaunchKernelGGL((k1b_merge<4, true>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
+        else if (e->k1b_u == 8) hipExtLaunchKernelGGL((k1b_merge<8, false>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
+        else hipExtLaunchKernelGGL((k1b_merge<4, false>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
     }
     {
@@ -451,6 +461,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     // K1 variant: 0 = partitioned LDS aggregation (fast; bounded edges per partition), 1 = global table + atomics
     if (e->cfg.max_window_events == 0) e->cfg.max_window_events = e->cfg.max_batch;
     d.variant = cfg->k1_variant == 1 ? 1u : 0u;
+    d.hist = (cfg->flags & SG_CFG_EDGE_HISTOGRAM) ? 1u : 0u;
+    d.agg_slots = d.hist ? 5u : 3u;
     {
         // partitions: at most ~1250 distinct edges each at the configured capacity (pass B's LDS table: 2048 slots, 1536 may
         // fill; 1024 slots for small graphs), at least one per CU.  Fewer, larger partitions keep pass A's open lines per
@@ -459,6 +471,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         if (np > 4096) np = 4096;
         if (cfg->k1_variant == 0 && ME > (u64)4096 * 1400) d.variant = 1;   // beyond the partitioned path's range
         d.k1b_ht = ME / np > 600 ? 2048 : 1024;
+        if (d.hist && d.k1b_ht == 2048) { d.k1b_ht = 1024; np = std::min<u64>(4096, np * 2); }   // 16 x u32 bins per slot: 104 bytes, half the slots, twice the partitions
         d.np = (u32)np; d.nwg = 256;
         // tuning overrides (tools/gpu_probe_sweep.sh); anything that is not a legal geometry is ignored
         if (const char* v = std::getenv("SG_NP")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 64 && x <= 4096 && (x & (x - 1)) == 0) d.np = (u32)x; }
@@ -468,9 +481,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
         d.ss = (u32)(2.0 * m + 8.0 * std::sqrt(m + 1.0) + 24.0);          // a hot key the cache missed lands in ONE piece: head room, then the overflow list
         d.sa = std::min<u32>(24, std::max<u32>(8, (2 * 2048 / d.np + 6 + 1) & ~1u));   // aggregates per piece: cache slots / partitions, with head room
-        d.ss = (d.ss + 3 * d.sa + 7) / 8 * 8 - 3 * d.sa;                  // a piece = whole 128-byte lines
+        d.ss = (d.ss + d.agg_slots * d.sa + 7) / 8 * 8 - d.agg_slots * d.sa;   // a piece = whole 128-byte lines
         d.ss = std::min<u32>(d.ss, (1u << 20) - 8);
-        d.pslots = d.ss + 3 * d.sa;
+        d.pslots = d.ss + d.agg_slots * d.sa;
         d.ovf_cap = 1u << 16;
         e->k1b_threads = 1024u;                                          // measured: 1024 threads beat 2 x 512 (C3 135 vs 153 us, C2 15.5 vs 22.9 us)
         if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; }
@@ -500,12 +513,14 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     }
     if (d.variant == 0) {
         k1a_geometry(e);
-        e->k1b_lds = (size_t)d.k1b_ht * (8 + 32);
-        for (const void* f : {reinterpret_cast<const void*>(k1a_partition<true, true>), reinterpret_cast<const void*>(k1a_partition<true, false>),
-                              reinterpret_cast<const void*>(k1a_partition<false, true>), reinterpret_cast<const void*>(k1a_partition<false, false>)})
+        e->k1b_lds = (size_t)d.k1b_ht * (8 + 32 + (d.hist ? 4 * SG_HIST_BINS : 0));
+        for (const void* f : {reinterpret_cast<const void*>(k1a_partition<true, true, false>), reinterpret_cast<const void*>(k1a_partition<true, false, false>),
+                              reinterpret_cast<const void*>(k1a_partition<false, true, false>), reinterpret_cast<const void*>(k1a_partition<false, false, false>),
+                              reinterpret_cast<const void*>(k1a_partition<true, true, true>), reinterpret_cast<const void*>(k1a_partition<true, false, true>),
+                              reinterpret_cast<const void*>(k1a_partition<false, true, true>), reinterpret_cast<const void*>(k1a_partition<false, false, true>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
-        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
-        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_merge<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
+        for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>)})
+            CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }
     d.emask = e->ecap - 1;
@@ -525,7 +540,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             eslots = std::max<size_t>(ME, (size_t)w.np * w.pcap);
             LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * w.pslots));
             LR(dev_alloc(e, &w.hdr, (size_t)w.np * w.nwg));
-            LR(dev_alloc(e, &w.ovf, (size_t)w.ovf_cap * 5));
+            LR(dev_alloc(e, &w.ovf, (size_t)w.ovf_cap * 9));
             LR(dev_alloc(e, &w.ovf_p, (size_t)w.ovf_cap));
             LR(dev_alloc(e, &w.part_n, w.np));
             LR(dev_alloc(e, &w.acc_src, (size_t)w.np * w.pcap * 4));
@@ -548,6 +563,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cslot, ME)); LR(dev_alloc(e, &w.csr_from, ME));
         LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));
+        if (w.hist) { LR(dev_alloc(e, &w.hist_src, (w.variant == 0 ? (size_t)w.np * w.pcap : (size_t)e->ecap) * SG_HIST_BINS)); LR(dev_alloc(e, &w.hist_csr, ME * SG_HIST_BINS)); }
         LR(dev_alloc(e, &w.st_sum, (size_t)w.ncap * SG_NODE_STAT_SUM_WORDS)); LR(dev_alloc(e, &w.st_max, (size_t)w.ncap * SG_NODE_STAT_MAX_WORDS));
         LR(dev_alloc(e, &w.x0, (size_t)w.ncap * SG_F_IN));
         for (u32 l = 1; l <= cfg->layers; l++) LR(dev_alloc(e, &w.h[l], (size_t)w.ncap * SG_F_HID));
@@ -898,6 +914,17 @@ int sg_window_outbound_ips(sg_handle e, uint32_t* ips, size_t cap, size_t* n) {
     std::lock_guard<std::mutex> g(e->mu);
     if (n) *n = e->last_obips.size();
     if (ips) std::memcpy(ips, e->last_obips.data(), std::min(cap, e->last_obips.size()) * sizeof(u32));
+    return SG_OK;
+}
+
+int sg_window_hist(sg_handle e, uint32_t* bins, size_t cap_rows, size_t* n) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->d.hist) { e->err = "sg_window_hist: the engine was created without SG_CFG_EDGE_HISTOGRAM"; return SG_ESTATE; }
+    const size_t E = (size_t)e->h_ctr[C_N_EDGES];                      // of the last read window
+    if (n) *n = E;
+    const size_t take = std::min(E, cap_rows);
+    if (bins && take) { HIP_TRY(e, hipDeviceSynchronize()); HIP_TRY(e, hipMemcpy(bins, e->d.hist_csr, take * SG_HIST_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost)); }
     return SG_OK;
 }
 

@@ -112,6 +112,11 @@ struct Dev {
     u32*   hdr;                               // [np][nwg] records in piece (p, w): n_single | n_aggregate << 20
     u32 k1a_ct;                               // pass A: LDS edge-cache slots (power of two; bucket = 2 adjacent slots)
     u32 k1b_ht;                               // pass B: LDS table slots per partition (power of two)
+    // f-3 (SG_CFG_EDGE_HISTOGRAM): per-edge log2 latency histogram, SG_HIST_BINS u32 bins
+    u32 hist;                                 // 0 = off (the kernels' HIST = false instantiations run)
+    u32 agg_slots;                            // 16-byte slots per aggregate record: 3, or 5 with the 16 x u16 bins of the launch
+    u32* hist_src;                            // bins by slot: [np * pcap][16] (variant 0, written by pass B) or [edge table][16] (variant 1)
+    u32* hist_csr;                            // [max_edges][16] bins in CSR (= row) order
     u64*   ovf;  u32 ovf_cap;                 // overflow records [ovf_cap][5] (pieces that ran full)
     u32*   ovf_p;                             // [ovf_cap] partition of each overflow record (pass B filters on 4 bytes, not 40)
     u32*   part_n;                            // [np] distinct edges per partition

@@ -166,6 +166,10 @@ struct K1Local { u64 tmin, tmax; u32 maxlabel, dsrc, dcap, misr, acc, lost; };  
 struct K1Ev { u64 key, dur, wt; u32 err; u32 alive; };
 #define SG_DUR_MAX ((1ull << 62) - 1)      // durations saturate here: bits 62/63 of a single record carry flags
 
+// f-3: latency histogram bin of a duration (include/servicegraph.h): 0 below 2^17 ns, one bin per octave, 15 from 2^31 ns
+__device__ __forceinline__ u32 hist_bin32(u32 dur) { return dur < (1u << 17) ? 0u : (dur >> 31) ? 15u : (15u - (u32)__builtin_clz(dur)); }   // 31 - clz - 16
+__device__ __forceinline__ u32 hist_bin64(u64 dur) { return (dur >> 32) ? 15u : hist_bin32((u32)dur); }
+
 // ---- the join, general form: block table (global copy), then the cuckoo table.  Returns kind << 30 | id, 0 = unknown IP;
 // kind 3 = the IP is in both reference maps (id = the service; the pod id is in the small second table).
 __device__ __forceinline__ u32 join_general(const Dev& d, u32 ip) {
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(256) void k1_resolve_aggregate(Dev d, const sg_even
         atomicAdd(&acc[1], e.dur);
         atomicMax(&acc[2], e.dur);
         atomicAdd(&acc[3], us * us);
+        if (d.hist) atomicAdd(&d.hist_src[(size_t)slot * SG_HIST_BINS + hist_bin64(e.dur)], 1u);
     }
     k1_publish_stats(d, L);
 }
@@ -313,9 +318,17 @@ __device__ __forceinline__ u32 edge_hash(u32 from, u32 to) {
 __device__ __forceinline__ u32 part_of_hash(const Dev& d, u32 hk) { return hk >> (32u - (u32)__builtin_ctz(d.np)); }
 __device__ __forceinline__ u32 part_of(const Dev& d, u64 key) { return part_of_hash(d, edge_hash((u32)(key >> 32), (u32)key)); }
 
-__device__ __forceinline__ void ovf_append(const Dev& d, u32 p, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L) {
+// hb: 16 x u16 bins (8 words) of an aggregate, or nullptr (a single record's bin follows from its duration = a1)
+__device__ __forceinline__ void ovf_append(const Dev& d, u32 p, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L, const u32* hb = nullptr) {
     const u64 idx = atomicAdd(&d.ctr[C_OVF_N], 1ull);
-    if (idx < d.ovf_cap) { u64* o = d.ovf + idx * 5; o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; d.ovf_p[idx] = p; }
+    if (idx < d.ovf_cap) {
+        u64* o = d.ovf + idx * 9; o[0] = key; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; d.ovf_p[idx] = p;
+        if (d.hist) {                                                // words 5..8: the record's bins, 16 x u16
+            u32* hw = reinterpret_cast<u32*>(o + 5);
+            if (hb) { for (int j = 0; j < 8; j++) hw[j] = hb[j]; }
+            else { for (int j = 0; j < 8; j++) hw[j] = 0; if (a0 & 0xFFFFFFFFull) { const u32 b = hist_bin64(a1); hw[b >> 1] = 1u << ((b & 1u) * 16); } }
+        }
+    }
     else { const u32 c = (u32)(a0 & 0xFFFFFFFFull); L.dcap += c; L.lost += c; }     // (the aggregate may carry other lanes' events: not L.acc -= c)
 }
 // exact for every 32-bit duration: floor(x / 1000) = (x * 0x10624DD3) >> 38
@@ -339,14 +352,25 @@ __device__ __forceinline__ void emit_single(const Dev& d, u32* fc, u32 w, u32 p,
 // same piece — so in a window fed by many small batches the aggregates of EARLIER launches are searched first (they are the
 // entries below the count the header held when this launch began; the piece is private to this workgroup and a key is flushed
 // by exactly one lane, so the read-modify-write needs no atomics) and a match is updated in place.
-__device__ __forceinline__ void emit_agg(const Dev& d, u32* fc, u32 w, u32 p, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L, bool first) {
+// hb: the launch's 16 x u16 bins of the key (8 words, two bins each), or nullptr without the histogram
+__device__ __forceinline__ void emit_agg(const Dev& d, u32* fc, u32 w, u32 p, u64 key, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L, bool first, const u32* hb) {
     uint4* ag = piece_of(d, p, w) + d.ss;
+    const u32 AS = d.agg_slots;
     if (!first) {
         u32 na0 = K1_NA(d.hdr[(size_t)p * d.nwg + w]); na0 = na0 < d.sa ? na0 : d.sa;
         for (u32 r = 0; r < na0; r++) {
-            uint4* o = ag + 3 * r;
+            uint4* o = ag + AS * r;
             const uint4 y0 = o[0];
             if (y0.x != (u32)key || y0.y != (u32)(key >> 32)) continue;
+            u32 nb[8];
+            if (hb) {                                                // the bins are 16-bit: merge only if none of them overflows
+                const uint4 h0 = o[3], h1 = o[4];
+                const u32 ob[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                bool fits = true;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const u32 lo = (ob[j] & 0xFFFFu) + (hb[j] & 0xFFFFu), hi = (ob[j] >> 16) + (hb[j] >> 16); fits &= lo <= 0xFFFFu && hi <= 0xFFFFu; nb[j] = lo | (hi << 16); }
+                if (!fits) break;                                    // -> a second aggregate of the same key: pass B adds them up
+            }
             const uint4 y1 = o[1]; const uint2 y2 = reinterpret_cast<const uint2*>(o + 2)[0];
             const u64 b0 = ((u64)y0.z | ((u64)y0.w << 32)) + a0, b1 = ((u64)y1.x | ((u64)y1.y << 32)) + a1;
             u64 b2 = (u64)y1.z | ((u64)y1.w << 32); b2 = a2 > b2 ? a2 : b2;
@@ -354,16 +378,18 @@ __device__ __forceinline__ void emit_agg(const Dev& d, u32* fc, u32 w, u32 p, u6
             o[0] = make_uint4(y0.x, y0.y, (u32)b0, (u32)(b0 >> 32));
             o[1] = make_uint4((u32)b1, (u32)(b1 >> 32), (u32)b2, (u32)(b2 >> 32));
             reinterpret_cast<uint2*>(o + 2)[0] = make_uint2((u32)b3, (u32)(b3 >> 32));
+            if (hb) { o[3] = make_uint4(nb[0], nb[1], nb[2], nb[3]); o[4] = make_uint4(nb[4], nb[5], nb[6], nb[7]); }
             return;
         }
     }
     const u32 pos = K1_NA(atomicAdd(&fc[p], 1u << 20));
     if (pos < d.sa) {
-        uint4* o = ag + 3 * pos;
+        uint4* o = ag + AS * pos;
         o[0] = make_uint4((u32)key, (u32)(key >> 32), (u32)a0, (u32)(a0 >> 32));
         o[1] = make_uint4((u32)a1, (u32)(a1 >> 32), (u32)a2, (u32)(a2 >> 32));
         reinterpret_cast<uint2*>(o + 2)[0] = make_uint2((u32)a3, (u32)(a3 >> 32));
-    } else { atomicSub(&fc[p], 1u << 20); ovf_append(d, p, key, a0, a1, a2, a3, L); }
+        if (hb) { o[3] = make_uint4(hb[0], hb[1], hb[2], hb[3]); o[4] = make_uint4(hb[4], hb[5], hb[6], hb[7]); }
+    } else { atomicSub(&fc[p], 1u << 20); ovf_append(d, p, key, a0, a1, a2, a3, L, hb); }
 }
 
 // LDS edge cache of pass A: CT slots, a bucket = two adjacent key slots (one ds_read_b128 sees both).  The first two
@@ -377,13 +403,14 @@ __device__ __forceinline__ int cache_claim(u64* ckey, u32 bucket, u64 key, u64 k
     return k1 == key ? (int)(2 * bucket + 1) : -1;
 }
 
-template <bool L2LDS, bool SHARDED>
+template <bool L2LDS, bool SHARDED, bool HIST>
 __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_event* __restrict__ ev, u64 n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 CT = d.k1a_ct;
     u64* ckey = reinterpret_cast<u64*>(smem);                       // [CT]
     u64* cacc = ckey + CT;                                           // [CT][4]
-    u32* fc = reinterpret_cast<u32*>(cacc + (size_t)CT * 4);         // [np]  n_single | n_aggregate << 20
+    u32* chist = reinterpret_cast<u32*>(cacc + (size_t)CT * 4);      // HIST: [CT][8] 16 x u16 bins per slot (a workgroup sees < 65536 events per launch)
+    u32* fc = chist + (HIST ? (size_t)CT * 8 : 0);                   // [np]  n_single | n_aggregate << 20
     u64* red = reinterpret_cast<u64*>(fc + d.np);                    // [8] workgroup statistics (WS_* order)
     uint4* jl = reinterpret_cast<uint4*>(red + 8);                   // LDS copy of the join blob: jl1 | jl2 (L2LDS) | residual cuckoo (ck_in_lds)
     const u64* l1 = reinterpret_cast<const u64*>(jl);
@@ -426,6 +453,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
             const u64 us = e.dur / 1000ull;
             atomicAdd(&cacc[slot * 4], 1ull | ((u64)e.err << 32)); atomicAdd(&cacc[slot * 4 + 1], e.dur);
             atomicMax(&cacc[slot * 4 + 2], e.dur); atomicAdd(&cacc[slot * 4 + 3], us * us);
+            if (HIST) { const u32 b = hist_bin64(e.dur); atomicAdd(&chist[slot * 8 + (b >> 1)], 1u << ((b & 1u) * 16)); }
         } else emit_single(d, fc, w, p, e.key, e.dur, e.err, L);
     };
     // The fast path, one event: branch-free join (two-level block table in LDS), data.go:827-870 as selects, cheap hash,
@@ -469,6 +497,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
                     const u64 ssq = (u64)us * (u64)us;                        /* us < 2^23: 24-bit multiplies */             \
                     atomicAdd(&cacc[slot * 4], 1ull | ((u64)err << 32)); atomicAdd(&cacc[slot * 4 + 1], (u64)dur);  \
                     atomicMax(&cacc[slot * 4 + 2], (u64)dur); atomicAdd(&cacc[slot * 4 + 3], ssq);                  \
+                    if (HIST) { const u32 hb_ = hist_bin32(dur); atomicAdd(&chist[slot * 8 + (hb_ >> 1)], 1u << ((hb_ & 1u) * 16)); } \
                 } else emit_single(d, fc, w, part, key, (u64)dur, err, L);                                          \
             }                                                                                                       \
         }
@@ -496,6 +525,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
         // out as garbage -> wild record addresses -> a memory fault, or a few hundred silently lost events)
         for (u32 k = t; k < CT; k += K1A_THREADS) ckey[k] = SG_EKEY_EMPTY;
         for (u32 k = t; k < CT * 4; k += K1A_THREADS) cacc[k] = 0;
+        if (HIST) for (u32 k = t; k < CT * 8; k += K1A_THREADS) chist[k] = 0;
         if (t < 8) red[t] = t == WS_TMIN ? ~0ull : 0ull;
         // The join blob goes out first; right behind it one load per event of the first group, into a register nobody
         // reads: it pulls the group's lines towards this XCD's L2 while the LDS is being set up (every hand-issued load is
@@ -543,7 +573,11 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
         if (k == SG_EKEY_EMPTY) continue;
         const u64 x0 = cacc[s * 4];
         if ((x0 & 0xFFFFFFFFull) == 1ull) emit_single(d, fc, w, part_of(d, k), k, cacc[s * 4 + 1], (u32)(x0 >> 32), L);
-        else if ((x0 & 0xFFFFFFFFull) != 0ull) emit_agg(d, fc, w, part_of(d, k), k, x0, cacc[s * 4 + 1], cacc[s * 4 + 2], cacc[s * 4 + 3], L, first);
+        else if ((x0 & 0xFFFFFFFFull) != 0ull) {
+            u32 hb[8];
+            if (HIST) { for (int j = 0; j < 8; j++) hb[j] = chist[s * 8 + j]; }
+            emit_agg(d, fc, w, part_of(d, k), k, x0, cacc[s * 4 + 1], cacc[s * 4 + 2], cacc[s * 4 + 3], L, first, HIST ? hb : nullptr);
+        }
     }
     // workgroup statistics: wave reduce -> LDS -> one thread updates this workgroup's private line
     {
@@ -584,12 +618,13 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
 // LDS: the table and nothing else — k1b_ht * 40 bytes; with 2048 slots that is exactly half of a CU's 160 KiB, so two
 // 512-thread workgroups share a CU and one's (latency-bound) header round trip and compaction overlap the other's
 // (LDS-atomic-bound) merge.  The last key slot is never used as a slot: its 8 bytes hold the two workgroup counters.
-template <int K1B_U>              // single records a lane has in flight
+template <int K1B_U, bool HIST>   // K1B_U: single records a lane has in flight; HIST: per-edge latency histogram (f-3)
 __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 HT = d.k1b_ht, hmask = HT - 1;
     u64* hkey = reinterpret_cast<u64*>(smem);                       // [HT]  (slot HT-1: n_drop, out_n)
     u64* hacc = hkey + HT;                                           // [HT][4]
+    u32* hh = reinterpret_cast<u32*>(hacc + (size_t)HT * 4);         // HIST: [HT][16] bins
     u32* n_drop = reinterpret_cast<u32*>(hkey + hmask); u32* out_n = n_drop + 1;
     const u32 p = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
     SG_STAMP(d, 1, 0);
@@ -604,11 +639,13 @@ __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
     for (u32 i = t; i < hmask; i += NT) hkey[i] = SG_EKEY_EMPTY;
     for (u32 i = t; i < HT * 4; i += NT) hacc[i] = 0;
+    if (HIST) for (u32 i = t; i < HT * SG_HIST_BINS; i += NT) hh[i] = 0;
     if (t == 0) { *n_drop = 0; *out_n = 0; }
     __syncthreads();
     SG_STAMP(d, 1, 1);
 
-    auto add = [&](u64 key, u64 a0, u64 a1, u64 a2, u64 a3) {
+    // bins: nullptr = a single record (its bin follows from the duration a1, if it counts a request), else 16 x u16 in 8 words
+    auto add = [&](u64 key, u64 a0, u64 a1, u64 a2, u64 a3, const u32* bins) {
         u32 h = (edge_hash((u32)(key >> 32), (u32)key) >> 4) & hmask; bool ok = false;
         h = h == hmask ? 0u : h;
         for (u32 it = 0; it < HT; it++) {                            // bounded: the table holds at most HT - 1 distinct edges
@@ -619,6 +656,13 @@ __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
         }
         if (!ok) { atomicAdd(n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
         atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
+        if (HIST) {
+            if (!bins) { if (a0 & 0xFFFFFFFFull) atomicAdd(&hh[h * SG_HIST_BINS + hist_bin64(a1)], 1u); }
+            else for (u32 j = 0; j < 8; j++) {
+                if (bins[j] & 0xFFFFu) atomicAdd(&hh[h * SG_HIST_BINS + 2 * j], bins[j] & 0xFFFFu);
+                if (bins[j] >> 16) atomicAdd(&hh[h * SG_HIST_BINS + 2 * j + 1], bins[j] >> 16);
+            }
+        }
     };
     // record r of a piece belongs to lane r % LPP of its group; every load is unconditional (index clamped to the piece's
     // last record, result ignored) so that the K1B_U of a round are in flight together
@@ -641,14 +685,16 @@ __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
                 if (dhi == 0) { const u32 us = div1000_u32(x[u].z); ssq = (u64)us * (u64)us; }
                 else { const u64 us = dur / 1000ull; ssq = us * us; }
                 const u64 one = ((x[u].w >> 30) & 1u) ? 0ull : 1ull;             // bit 62: edge-only record (SG_EV_ALIVE)
-                if (!(d.ablate & 0x10u)) add(key, one | ((u64)(x[u].w >> 31) << 32), dur, dur, ssq);
+                if (!(d.ablate & 0x10u)) add(key, one | ((u64)(x[u].w >> 31) << 32), dur, dur, ssq, nullptr);
             }
         }
         for (u32 r = sub; r < na; r += LPP) {
-            const uint4* q = piece + d.ss + 3 * r;
+            const uint4* q = piece + d.ss + d.agg_slots * r;
             const uint4 y0 = q[0], y1 = q[1]; const uint2 y2 = reinterpret_cast<const uint2*>(q + 2)[0];
+            u32 hb[8];
+            if (HIST) { const uint4 h0 = q[3], h1 = q[4]; hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w; }
             add((u64)y0.x | ((u64)y0.y << 32), (u64)y0.z | ((u64)y0.w << 32), (u64)y1.x | ((u64)y1.y << 32),
-                (u64)y1.z | ((u64)y1.w << 32), (u64)y2.x | ((u64)y2.y << 32));
+                (u64)y1.z | ((u64)y1.w << 32), (u64)y2.x | ((u64)y2.y << 32), hb);     // (an aggregate always carries bins in HIST mode; hb is ignored otherwise)
         }
     }
     __syncthreads();
@@ -658,8 +704,8 @@ __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
         const u64 no = ovf_n < d.ovf_cap ? ovf_n : d.ovf_cap;
         for (u64 i = t; i < no; i += NT) {
             if (d.ovf_p[i] != p) continue;
-            const u64* o = d.ovf + i * 5;
-            add(o[0], o[1], o[2], o[3], o[4]);
+            const u64* o = d.ovf + i * 9;
+            add(o[0], o[1], o[2], o[3], o[4], reinterpret_cast<const u32*>(o + 5));   // (overflow records always carry their bins as 16 x u16)
         }
         __syncthreads();
     }
@@ -678,6 +724,11 @@ __global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
         d.e_from[slot] = f; d.e_to[slot] = to;
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
         o[0] = make_ulonglong2(hacc[s * 4], hacc[s * 4 + 1]); o[1] = make_ulonglong2(hacc[s * 4 + 2], hacc[s * 4 + 3]);
+        if (HIST) {
+            uint4* ho = reinterpret_cast<uint4*>(d.hist_src + slot * SG_HIST_BINS); const u32* hs = hh + s * SG_HIST_BINS;
+            ho[0] = make_uint4(hs[0], hs[1], hs[2], hs[3]); ho[1] = make_uint4(hs[4], hs[5], hs[6], hs[7]);
+            ho[2] = make_uint4(hs[8], hs[9], hs[10], hs[11]); ho[3] = make_uint4(hs[12], hs[13], hs[14], hs[15]);
+        }
         d.e_rank[slot] = atomicAdd(&d.deg[SG_DEG_IDX(f, p & (SG_DEG_REP - 1))], 1u);        // arrival order inside the row's replica
     }
     __syncthreads();
@@ -944,6 +995,7 @@ __global__ __launch_bounds__(256) void k2_scatter_table(Dev d) {
             const u32 sl = d.e_slot[i];
             d.ekeys[sl] = SG_EKEY_EMPTY;
             ulonglong2* a = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)sl * 4); a[0] = make_ulonglong2(0, 0); a[1] = make_ulonglong2(0, 0);
+            if (d.hist) { uint4* hs = reinterpret_cast<uint4*>(d.hist_src + (size_t)sl * SG_HIST_BINS); const uint4 z = make_uint4(0, 0, 0, 0); hs[0] = z; hs[1] = z; hs[2] = z; hs[3] = z; }
             continue;
         }
         const u32 pos = d.rowptr[f] + atomicAdd(&d.cursor[f], 1u);
@@ -975,12 +1027,18 @@ __device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
 // The fp32 edge features, lat_z and err_ratio are computed afterwards, one thread per edge, by the edge
 // workgroups of k3_node_features: inside the row sort they were ~1000 fp64-heavy instructions per edge run
 // by the few threads that own a long row (a 3000-edge hub row kept one 256-thread workgroup busy for tens of us).
-struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; };
+struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; u32* hist_src; u32* hist_csr; u32 hist; };
 __device__ __forceinline__ void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row, u32 slot, u64, u64, u64, const ulonglong2 x, const ulonglong2 y) {
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)pos * 4);
     dst[0] = x; dst[1] = y;
     d.csr_from[pos] = row;
     d.alive_csr[pos] = 0;                                            // k3_in_stats adds the window's open connections
+    if (d.hist) {                                                    // f-3: the edge's latency histogram follows it into row order
+        uint4* hs = reinterpret_cast<uint4*>(d.hist_src + (size_t)slot * SG_HIST_BINS); uint4* hd = reinterpret_cast<uint4*>(d.hist_csr + (size_t)pos * SG_HIST_BINS);
+        const uint4 h0 = hs[0], h1 = hs[1], h2 = hs[2], h3 = hs[3];
+        hd[0] = h0; hd[1] = h1; hd[2] = h2; hd[3] = h3;
+        if (d.variant == 1) { const uint4 z = make_uint4(0, 0, 0, 0); hs[0] = z; hs[1] = z; hs[2] = z; hs[3] = z; }   // ... and the table's bins are re-armed
+    }
     if (d.variant == 1) {                                            // variant 1: this is also the window reset of the edge table
         ulonglong2* src = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)slot * 4);
         src[0] = make_ulonglong2(0, 0); src[1] = make_ulonglong2(0, 0);
@@ -1010,7 +1068,7 @@ __device__ __forceinline__ void edge_features(const Dev& d, u32 pos) {
 #define K2_LONG_WGS 1024
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
-    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant};
+    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant, d.hist_src, d.hist_csr, d.hist};
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
     __shared__ u64 red[5][4];
     __shared__ u32 bsum[5];
@@ -1366,6 +1424,7 @@ __global__ __launch_bounds__(256) void k_reset_window(Dev d) {
             d.ekeys[i] = SG_EKEY_EMPTY;
             ulonglong2* a = reinterpret_cast<ulonglong2*>(d.eacc + (size_t)i * 4);
             a[0] = make_ulonglong2(0, 0); a[1] = make_ulonglong2(0, 0);
+            if (d.hist) { uint4* hs = reinterpret_cast<uint4*>(d.hist_src + (size_t)i * SG_HIST_BINS); const uint4 z = make_uint4(0, 0, 0, 0); hs[0] = z; hs[1] = z; hs[2] = z; hs[3] = z; }
         }
     }
 }
@@ -1724,6 +1783,21 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
             o.from_ref = ref_of_dense(u, nk, nl); o.to_ref = ref_of_dense(v, nk, nl);
             o.count = (u32)(wx.x & 0xFFFFFFFFull); o.err_count = (u32)(wx.x >> 32);
             o.score = score; o.lat_z = w_latz; o.err_ratio = w_errr; o.alive = w_alive;
+            o.p50_us = 0; o.p99_us = 0;
+            if (d.hist && o.count) {                                 // percentiles off the log2 histogram (include/servicegraph.h)
+                const uint4* hp = reinterpret_cast<const uint4*>(d.hist_csr + (size_t)p * SG_HIST_BINS);
+                const uint4 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
+                const u32 hb[SG_HIST_BINS] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+                u64 r50 = ((u64)o.count * 50 + 99) / 100, r99 = ((u64)o.count * 99 + 99) / 100;
+                r50 = r50 ? r50 : 1; r99 = r99 ? r99 : 1;
+                u64 cum = 0; u32 b50 = SG_HIST_BINS - 1, b99 = SG_HIST_BINS - 1; bool f50 = false, f99 = false;
+#pragma unroll
+                for (u32 b = 0; b < SG_HIST_BINS; b++) { cum += hb[b]; if (!f50 && cum >= r50) { b50 = b; f50 = true; } if (!f99 && cum >= r99) { b99 = b; f99 = true; } }
+                u64 e50 = b50 == SG_HIST_BINS - 1 ? o.max_ns : (1ull << (17 + b50)), e99 = b99 == SG_HIST_BINS - 1 ? o.max_ns : (1ull << (17 + b99));
+                e50 = e50 > o.max_ns ? o.max_ns : e50; e99 = e99 > o.max_ns ? o.max_ns : e99;
+                e50 /= 1000ull; e99 /= 1000ull;
+                o.p50_us = e50 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e50; o.p99_us = e99 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e99;
+            }
             d.rows[p] = o;
         }
     }

@@ -32,7 +32,7 @@ EXPORTS = [
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
-    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route",
+    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist",
 ]
 
 
@@ -41,7 +41,11 @@ class SgConfig(C.Structure):
                 ("max_labels", C.c_uint32), ("max_outbound_ips", C.c_uint32), ("max_ips", C.c_uint32),
                 ("max_edges", C.c_uint64), ("max_batch", C.c_uint32), ("layers", C.c_uint32),
                 ("rank", C.c_uint32), ("world", C.c_uint32), ("k1_variant", C.c_uint32),
-                ("max_window_events", C.c_uint64), ("windows_in_flight", C.c_uint32), ("max_alive", C.c_uint32)]
+                ("max_window_events", C.c_uint64), ("windows_in_flight", C.c_uint32), ("max_alive", C.c_uint32), ("flags", C.c_uint32)]
+
+
+CFG_EDGE_HISTOGRAM = 1
+ABI_VERSION = 2
 
 
 class SgStats(C.Structure):
@@ -111,6 +115,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_timing_get": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
         "sg_debug_stamps": (C.c_int, [H, P, sz]),
         "sg_route": (C.c_int, [H, P, sz, u32, P]),
+        "sg_window_hist": (C.c_int, [H, P, sz, C.POINTER(sz)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)          # AttributeError if the library does not export it
@@ -129,11 +134,12 @@ class ServiceGraph:
 
     def __init__(self, *, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 1024,
                  max_outbound_ips: int = 1024, max_ips: int = 0, max_batch: int = 1 << 20, device: int = 0,
-                 rank: int = 0, world: int = 1, k1_variant: int = 0, max_window_events: int = 0, windows_in_flight: int = 1):
+                 rank: int = 0, world: int = 1, k1_variant: int = 0, max_window_events: int = 0, windows_in_flight: int = 1,
+                 edge_histogram: bool = False):
         self._l = load_library()
         cfg = SgConfig(self._l.sg_abi_version(), device, max_known_nodes, max_labels, max_outbound_ips,
                        max_ips or max_known_nodes, max_edges, max_batch, layers, rank, world, k1_variant,
-                       max_window_events, windows_in_flight, 0)
+                       max_window_events, windows_in_flight, 0, CFG_EDGE_HISTOGRAM if edge_histogram else 0)
         h = C.c_void_p()
         rc = self._l.sg_create(C.byref(cfg), C.byref(h))
         if rc != SG_OK:
@@ -246,6 +252,15 @@ class ServiceGraph:
         out = np.zeros(n.value, dtype=np.uint32)
         if n.value:
             self._ck(self._l.sg_window_outbound_ips(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def window_hist(self) -> np.ndarray:
+        """[rows][16] u32 latency histogram bins of the last read window (engine created with edge_histogram=True)."""
+        n = C.c_size_t(0)
+        self._ck(self._l.sg_window_hist(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 16), dtype=np.uint32)
+        if n.value:
+            self._ck(self._l.sg_window_hist(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out
 
     def stats(self) -> SgStats:

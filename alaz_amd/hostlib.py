@@ -18,7 +18,8 @@ HOST_LIB = os.path.join(_HERE, "lib", "libsgdatastore.so")
 class EdgeRowC(C.Structure):
     _fields_ = [("from_type", C.c_char * 12), ("to_type", C.c_char * 12), ("from_uid", C.c_char * 160), ("to_uid", C.c_char * 160),
                 ("count", C.c_uint32), ("err_count", C.c_uint32), ("sum_ns", C.c_uint64), ("max_ns", C.c_uint64), ("sumsq_us", C.c_uint64),
-                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float), ("alive", C.c_uint32)]
+                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float), ("alive", C.c_uint32),
+                ("p50_us", C.c_uint32), ("p99_us", C.c_uint32)]
 
 
 class SockInfoC(C.Structure):
@@ -193,11 +194,13 @@ def go_atoi_u32(b: bytes) -> int: return load().sgh_go_atoi_u32(b, len(b))
 
 
 def edges_json_from_rows(rows, window_end_ms=0, monitoring_id="", idempotency_key="", node_id="", version="", batch=1000) -> List[str]:
-    """rows: [(from_type, from_uid, to_type, to_uid, count, err, sum_ns, max_ns, sumsq_us, score, lat_z, err_ratio, alive)] with bytes strings"""
+    """rows: [(from_type, from_uid, to_type, to_uid, count, err, sum_ns, max_ns, sumsq_us, score, lat_z, err_ratio, alive[, p50_us, p99_us])] with bytes strings"""
     arr = (EdgeRowC * max(1, len(rows)))()
     for a, r in zip(arr, rows):
         a.from_type, a.from_uid, a.to_type, a.to_uid = r[0], r[1], r[2], r[3]
         a.count, a.err_count, a.sum_ns, a.max_ns, a.sumsq_us, a.score, a.lat_z, a.err_ratio, a.alive = r[4:13]
+        if len(r) > 14:
+            a.p50_us, a.p99_us = r[13], r[14]
     cap = 1 << 16
     while True:
         buf = C.create_string_buffer(cap)
@@ -346,7 +349,7 @@ class GraphDS:
         for i in range(min(n, self.max_edges)):
             r = out[i]
             d[(r.from_type.decode(), r.from_uid.decode(), r.to_type.decode(), r.to_uid.decode())] = (
-                r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio, r.alive)
+                r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio, r.alive, r.p50_us, r.p99_us)
         return d
 
     # ---- f-2: TCP connect events -> socket lines -> alive connections ----

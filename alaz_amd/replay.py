@@ -27,9 +27,19 @@ assert EVENT_DTYPE.itemsize == 32
 EDGE_OUT_DTYPE = np.dtype([
     ("sum_ns", "<u8"), ("max_ns", "<u8"), ("sumsq_us", "<u8"), ("from_ref", "<u4"), ("to_ref", "<u4"),
     ("count", "<u4"), ("err_count", "<u4"), ("score", "<f4"), ("lat_z", "<f4"), ("err_ratio", "<f4"),
-    ("alive", "<u4"),
+    ("alive", "<u4"), ("p50_us", "<u4"), ("p99_us", "<u4"),
 ])
-assert EDGE_OUT_DTYPE.itemsize == 56
+assert EDGE_OUT_DTYPE.itemsize == 64
+HIST_BINS = 16
+
+
+def hist_bin(dur_ns: np.ndarray) -> np.ndarray:
+    """include/servicegraph.h: latency histogram bin of a duration in ns (one bin per octave from 2^17 ns)."""
+    d = np.maximum(np.asarray(dur_ns, dtype=np.uint64), np.uint64(1))
+    lg = np.floor(np.log2(d.astype(np.float64))).astype(np.int64)
+    lg = np.where((np.uint64(1) << lg.astype(np.uint64)) > d, lg - 1, lg)          # float rounding at exact powers of two
+    lg = np.where((np.uint64(2) << lg.astype(np.uint64)) <= d, lg + 1, lg)
+    return np.clip(lg - 16, 0, HIST_BINS - 1).astype(np.int64)
 
 PROTO_HTTP, PROTO_AMQP, PROTO_POSTGRES, PROTO_HTTP2, PROTO_REDIS, PROTO_KAFKA, PROTO_MYSQL, PROTO_MONGO = 1, 2, 3, 4, 5, 6, 7, 8
 EV_TLS, EV_REVERSE, EV_CONSUME, EV_ALIVE = 1, 2, 4, 8

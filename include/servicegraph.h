@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 1u
+#define SG_ABI_VERSION 2u   /* 2: sg_edge_out carries p50_us / p99_us, sg_config.flags, sg_window_hist */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define SG_OK        0
@@ -122,7 +122,14 @@ typedef struct sg_event {
  *  score      GraphSAGE + factorised MLP anomaly score in (0,1)          (fp32, |d| <= 1e-5)
  *  lat_z      (mean_us(edge) - mean_us(src out-events)) / max(std_us(src), 1)  (fp32)
  *  err_ratio  err_count / count                                            (fp32)
+ *  p50_us / p99_us  latency percentiles from the edge's log2 histogram, 0 unless the engine was created with
+ *        SG_CFG_EDGE_HISTOGRAM.  Bin of a duration d (ns): 0 for d < 2^17 (131 us), k = floor(log2 d) - 16 for
+ *        2^17 <= d < 2^31, 15 for d >= 2^31 (2.1 s): one bin per octave.  The q-th percentile is reported as the upper
+ *        edge of the first bin whose cumulative count reaches ceil(count * q / 100) — 2^(17+k) ns, max_ns for the open
+ *        last bin — capped at max_ns, in microseconds (floor); 0 for an edge without requests.  Integer arithmetic
+ *        throughout: bit-exact.  The bins themselves: sg_window_hist().
  */
+#define SG_HIST_BINS 16u
 typedef struct sg_edge_out {
     uint64_t sum_ns;
     uint64_t max_ns;
@@ -135,6 +142,8 @@ typedef struct sg_edge_out {
     float    lat_z;
     float    err_ratio;
     uint32_t alive;             /* open connections reported on this edge in the window (SG_EV_ALIVE) */
+    uint32_t p50_us;
+    uint32_t p99_us;
 } sg_edge_out;
 
 typedef struct sg_config {
@@ -158,7 +167,12 @@ typedef struct sg_config {
                                    and moves on to the next slot, so the (latency-bound) close of
                                    window w overlaps the ingest of window w+1.  0 = 1.              */
     uint32_t max_alive;         /* most SG_EV_ALIVE records one window may carry (0 = 65536)        */
+    uint32_t flags;             /* SG_CFG_*                                                          */
 } sg_config;
+
+#define SG_CFG_EDGE_HISTOGRAM 0x1u /* keep a 16-bin log2 latency histogram per edge (p50_us / p99_us in the rows, the bins through
+                                      sg_window_hist).  Costs LDS in both K1 passes (smaller edge cache, half-size partitions) and
+                                      64 bytes per edge of extra traffic: off by default.                                          */
 
 #define SG_MAX_LAYERS 4u
 #define SG_F_IN    32u   /* node feature width                                                  */
@@ -292,6 +306,9 @@ int sg_halo_unpack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, c
 
 /* Ascending raw IPs of the last read window's OBIP nodes.                                       */
 int sg_window_outbound_ips(sg_handle h, uint32_t* ips, size_t cap, size_t* n);
+/* The latency histograms of the last read window (SG_CFG_EDGE_HISTOGRAM): bins[i * SG_HIST_BINS + b] = requests of row i in
+ * bin b, rows in the order sg_flush_window / sg_window_read returned them.  *n = rows available.  SG_ESTATE without the flag. */
+int sg_window_hist(sg_handle h, uint32_t* bins, size_t cap_rows, size_t* n);
 
 int sg_stats_get(sg_handle h, sg_stats* out);
 

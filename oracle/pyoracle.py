@@ -25,7 +25,8 @@ def build(force: bool = False) -> str:
 class EdgeOut(C.Structure):
     _fields_ = [("sum_ns", C.c_uint64), ("max_ns", C.c_uint64), ("sumsq_us", C.c_uint64),
                 ("from_ref", C.c_uint32), ("to_ref", C.c_uint32), ("count", C.c_uint32), ("err_count", C.c_uint32),
-                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float), ("alive", C.c_uint32)]
+                ("score", C.c_float), ("lat_z", C.c_float), ("err_ratio", C.c_float), ("alive", C.c_uint32),
+                ("p50_us", C.c_uint32), ("p99_us", C.c_uint32)]
 
 
 class OrEdge(C.Structure):
@@ -404,13 +405,20 @@ class Oracle:
             out[i] = np.frombuffer(bytes(e.row), dtype=EDGE_OUT_DTYPE)[0]
         return out
 
+    def edge_hist(self) -> np.ndarray:
+        """[edges][16] u32 latency histogram bins of the closed window, row order (f-3)."""
+        n = self._l.or_edge_count(self._o)
+        self._l.or_edge_hist.restype = C.POINTER(C.c_uint32); self._l.or_edge_hist.argtypes = [C.c_void_p]
+        p = self._l.or_edge_hist(self._o)
+        return np.ctypeslib.as_array(p, shape=(n, 16)).copy() if n else np.zeros((0, 16), np.uint32)
+
     def edge_dict(self):
-        """{(from_type, from_uid, to_type, to_uid): (count, err, sum, max, sumsq, score, lat_z, err_ratio, alive)}"""
+        """{(from_type, from_uid, to_type, to_uid): (count, err, sum, max, sumsq, score, lat_z, err_ratio, alive, p50_us, p99_us)}"""
         d = {}
         for e in self.edges():
             k = (e.from_type.decode(), e.from_uid.decode(), e.to_type.decode(), e.to_uid.decode())
             r = e.row
-            d[k] = (r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio, r.alive)
+            d[k] = (r.count, r.err_count, r.sum_ns, r.max_ns, r.sumsq_us, r.score, r.lat_z, r.err_ratio, r.alive, r.p50_us, r.p99_us)
         return d
 
     def reqinfos(self):

@@ -89,6 +89,7 @@ typedef struct {             /* one (FromType,FromUID,ToType,ToUID) edge of the 
     uint32_t count, err;
     uint64_t sum_ns, max_ns, sumsq_us;
     uint32_t alive;              /* alive connections reported on this edge (f-2) */
+    uint32_t hist[SG_HIST_BINS]; /* f-3: log2 latency histogram, bins as defined in include/servicegraph.h */
 } w_edge;
 
 struct oracle {
@@ -118,6 +119,7 @@ struct oracle {
 
     /* last closed window */
     or_edge* edges; size_t n_edges;
+    uint32_t* edge_hist;         /* [n_edges][SG_HIST_BINS], row order */
     size_t n_nodes;
     float* x0; float* h[SG_MAX_LAYERS + 1];
     uint64_t* st_sum; uint64_t* st_max;
@@ -506,6 +508,26 @@ static int set_from_to_v2(oracle_t* o, const char* saddr, const char* daddr, uin
     return 0;
 }
 
+/* f-3: per-edge log2 latency histogram and the percentiles read off it — include/servicegraph.h is the definition */
+uint32_t or_hist_bin(uint64_t dur_ns) {
+    if (dur_ns < (1ull << 17)) return 0;
+    if (dur_ns >= (1ull << 31)) return SG_HIST_BINS - 1;
+    uint32_t lg = 0; while ((dur_ns >> (lg + 1)) != 0) lg++;     /* floor(log2) */
+    return lg - 16;
+}
+uint32_t or_percentile_us(const uint32_t* hist, uint32_t count, uint64_t max_ns, uint32_t q) {
+    if (count == 0) return 0;
+    uint64_t rank = ((uint64_t)count * q + 99) / 100; if (rank == 0) rank = 1;
+    uint64_t cum = 0; uint32_t b = 0;
+    for (; b < SG_HIST_BINS; b++) { cum += hist[b]; if (cum >= rank) break; }
+    if (b >= SG_HIST_BINS) b = SG_HIST_BINS - 1;
+    uint64_t edge = b == SG_HIST_BINS - 1 ? max_ns : (1ull << (17 + b));
+    if (edge > max_ns) edge = max_ns;
+    uint64_t us = edge / 1000ull;
+    return us > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)us;
+}
+const uint32_t* or_edge_hist(const oracle_t* o) { return o->edge_hist; }
+
 static w_edge* window_edge(oracle_t* o, const endpoint* f, const endpoint* t) {
     char key[2 * OR_UID_MAX + 32];
     snprintf(key, sizeof key, "%s\x1f%s\x1f%s\x1f%s", f->type, f->uid, t->type, t->uid);
@@ -567,6 +589,7 @@ static int resolve_and_persist(oracle_t* o, uint32_t saddr, uint16_t sport, uint
     if (duration > w->max_ns) w->max_ns = duration;
     uint64_t us = duration / 1000ull;
     w->sumsq_us += us * us;
+    w->hist[or_hist_bin(duration)] += 1;
     if (st < o->tmin) o->tmin = st;
     if (st > o->tmax) o->tmax = st;
     o->wevents++;
@@ -975,6 +998,7 @@ size_t or_window_close(oracle_t* o, const float* W, uint32_t L) {
     }
 
     o->edges = calloc(E + 1, sizeof(or_edge)); o->n_edges = E;
+    free(o->edge_hist); o->edge_hist = calloc((E + 1) * SG_HIST_BINS, sizeof(uint32_t));
     for (size_t i = 0; i < E; i++) {
         const w_edge* w = &o->wedges[se[i].src];
         or_edge* oe = &o->edges[i];
@@ -987,6 +1011,9 @@ size_t or_window_close(oracle_t* o, const float* W, uint32_t L) {
         oe->row.count = w->count; oe->row.err_count = w->err;
         oe->row.sum_ns = w->sum_ns; oe->row.max_ns = w->max_ns; oe->row.sumsq_us = w->sumsq_us;
         oe->row.alive = w->alive;
+        memcpy(o->edge_hist + i * SG_HIST_BINS, w->hist, sizeof w->hist);
+        oe->row.p50_us = or_percentile_us(w->hist, w->count, w->max_ns, 50);
+        oe->row.p99_us = or_percentile_us(w->hist, w->count, w->max_ns, 99);
 
         /* edge features */
         const uint64_t* su = ss + (size_t)uu * SG_NODE_STAT_SUM_WORDS;

@@ -105,6 +105,11 @@ size_t      or_known_count(const oracle_t* o);
 size_t or_window_close(oracle_t* o, const float* weights, uint32_t layers);
 size_t or_edge_count(const oracle_t* o);
 const or_edge* or_edge_at(const oracle_t* o, size_t i);
+/* f-3: latency histograms of the closed window's edges, [or_edge_count][SG_HIST_BINS] in row order; the bin of a duration and
+ * the percentile read off a histogram (the definitions are in include/servicegraph.h) */
+const uint32_t* or_edge_hist(const oracle_t* o);
+uint32_t or_hist_bin(uint64_t dur_ns);
+uint32_t or_percentile_us(const uint32_t* hist, uint32_t count, uint64_t max_ns, uint32_t q);
 size_t or_node_count(const oracle_t* o);
 /* debug/inspection of the last closed window */
 const float*    or_node_features(const oracle_t* o);           /* [N][SG_F_IN]           */

@@ -55,11 +55,11 @@ def engine_edge_dict(rows: np.ndarray, shim: HostShim, labels: Sequence[str], ob
         ft, fu = shim.ref_identity(int(r["from_ref"]), labels, obips)
         tt, tu = shim.ref_identity(int(r["to_ref"]), labels, obips)
         d[(ft, fu, tt, tu)] = (int(r["count"]), int(r["err_count"]), int(r["sum_ns"]), int(r["max_ns"]), int(r["sumsq_us"]),
-                               float(r["score"]), float(r["lat_z"]), float(r["err_ratio"]), int(r["alive"]))
+                               float(r["score"]), float(r["lat_z"]), float(r["err_ratio"]), int(r["alive"]), int(r["p50_us"]), int(r["p99_us"]))
     return d
 
 
-def compare_edge_dicts(got: dict, want: dict, score_tol: float = 1e-5):
+def compare_edge_dicts(got: dict, want: dict, score_tol: float = 1e-5, percentiles: bool = False):
     """Identities + integer accumulators bit-exact; fp32 outputs within tolerance (north_star:
     1e-5 abs on scores; lat_z 1e-5 relative with an absolute floor; err_ratio is one correctly
     rounded division of exact integers, so it is compared exactly)."""
@@ -73,5 +73,7 @@ def compare_edge_dicts(got: dict, want: dict, score_tol: float = 1e-5):
         assert g[7] == w[7], f"err_ratio differs on {k}: {g[7]} vs {w[7]}"
         if len(g) > 8 and len(w) > 8:
             assert g[8] == w[8], f"alive count differs on {k}: {g[8]} vs {w[8]}"
+        if percentiles:                                    # f-3: only engines created with edge_histogram report them (the oracle always does)
+            assert g[9:11] == w[9:11], f"p50/p99 differ on {k}: {g[9:11]} vs {w[9:11]}"
         worst = max(worst, abs(g[5] - w[5]))
     return worst

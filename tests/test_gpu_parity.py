@@ -205,11 +205,11 @@ def test_device_resident_ingest_and_staged_pipeline():
     g.ingest_device(t.data_ptr(), len(ev), s)
     g.window_run(s)
     torch.cuda.synchronize()
-    rows = torch.empty(len(a) * 56, dtype=torch.uint8, device="cuda")
+    rows = torch.empty(len(a) * 64, dtype=torch.uint8, device="cuda")
     import ctypes
     hip = ctypes.CDLL(None)          # the HIP runtime already loaded by torch / the engine
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-    assert hip.hipMemcpy(ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(g.rows_buffer()), len(a) * 56, 3) == 0
+    assert hip.hipMemcpy(ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(g.rows_buffer()), len(a) * 64, 3) == 0
     assert rows.cpu().numpy().tobytes() == a.tobytes()
     # staged calls with the reset folded into the score kernel (what the sharded driver's steady state uses):
     # same rows on the device, and the window is open and clean afterwards
@@ -219,7 +219,7 @@ def test_device_resident_ingest_and_staged_pipeline():
         g.window_layer(l, s)
     g.window_score_reset(s)
     torch.cuda.synchronize()
-    assert hip.hipMemcpy(ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(g.rows_buffer()), len(a) * 56, 3) == 0
+    assert hip.hipMemcpy(ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(g.rows_buffer()), len(a) * 64, 3) == 0
     assert rows.cpu().numpy().tobytes() == a.tobytes()
     assert g.ingest(ev[:1000]) == 0
     c = g.flush_window()
@@ -280,7 +280,7 @@ def test_cpp_graphds_end_to_end_from_wire_records():
     wire = bytes(wire)
     W = weights.make_weights(2)
     o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.l7_wire(wire, kafka); o.window_close(W, 2)
-    cfg = engine.SgConfig(1, 0, topo.n_nodes + 8, 256, 256, topo.n_nodes + 8, 4096, 1 << 16, 2, 0, 1, 0, 1 << 16, 1, 0)
+    cfg = engine.SgConfig(engine.ABI_VERSION, 0, topo.n_nodes + 8, 256, 256, topo.n_nodes + 8, 4096, 1 << 16, 2, 0, 1, 0, 1 << 16, 1, 0)
     g = hostlib.GraphDS(cfg, batch=1000)
     g.set_clock(*CLOCK); g.load_weights(W)
     g.apply_ops(topo.k8s_ops())
@@ -333,7 +333,7 @@ def test_cpp_graphds_end_to_end_from_wire_records():
     f32 = lambda x: struct.unpack("<f", struct.pack("<f", x))[0]
     docs = [json.loads(d) for d in g.edges_json("mon", "key", "node", "v", batch=100)]
     assert len(docs) == -(-len(got) // 100) and all(d["window_end"] == 125 for d in docs)
-    from_json = {(e[0], e[1], e[2], e[3]): (e[4], e[5], e[6], e[7], e[8], f32(e[10]), f32(e[11]), f32(e[12]), e[9]) for d in docs for e in d["edges"]}
+    from_json = {(e[0], e[1], e[2], e[3]): (e[4], e[5], e[6], e[7], e[8], f32(e[10]), f32(e[11]), f32(e[12]), e[9], e[13], e[14]) for d in docs for e in d["edges"]}
     assert from_json == got
 
 
@@ -585,7 +585,7 @@ def test_windows_in_flight_give_the_same_rows_as_one_window_at_a_time():
     for i in (3, 4, 5):                               # the last three windows are still resident in their slots
         n = len(want[i])
         buf = np.zeros(n, dtype=replay.EDGE_OUT_DTYPE)
-        assert hip.hipMemcpy(buf.ctypes.data, ctypes.c_void_p(ptrs[i]), n * 56, 2) == 0
+        assert hip.hipMemcpy(buf.ctypes.data, ctypes.c_void_p(ptrs[i]), n * 64, 2) == 0
         assert buf.tobytes() == want[i].tobytes(), i
     # and the synchronous API keeps working on the current slot
     assert g.ingest(wins[0]) == 0
@@ -694,3 +694,71 @@ def test_sg_ingest_from_many_threads_into_one_engine():
     compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
     st = g.stats()
     assert st.last_window_events == o.window_events and st.events_dropped_cap == 0
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_edge_latency_histogram_and_percentiles(variant):
+    """f-3: with SG_CFG_EDGE_HISTOGRAM every edge carries a 16-bin log2 latency histogram and p50 / p99 read off
+    it.  Bins and percentiles must equal the oracle's bit for bit — through pass A's cache (16-bit bins per launch, aggregates
+    merged across the many small batches of a window), single records (bin from the duration), pass B's table, the CSR
+    gather and K5; durations from microseconds to beyond 2^32 ns; alive-only edges report 0.  Everything else in the rows
+    must be what the engine reports without the flag."""
+    from alaz_amd import engine
+    topo = replay.make_topology(120, 1500, seed=131)
+    ev, labels = replay.make_events(topo, 150_000, seed=132, mixed=True, with_raw_outbound=True, with_reverse=True)
+    rng = np.random.default_rng(133)
+    ev = ev.copy()
+    ev["duration_ns"] = np.where(rng.random(len(ev)) < 0.02, rng.integers(1, 1 << 36, len(ev)), ev["duration_ns"]).astype(np.uint64)   # tails: < 1 us .. 68 s
+    ev["duration_ns"][:2000] = (1 << 17) - 1; ev["duration_ns"][2000:4000] = 1 << 17; ev["duration_ns"][4000:4500] = 1 << 31
+    al = np.zeros(500, dtype=replay.EVENT_DTYPE); al["flags"] = replay.EV_ALIVE
+    al["saddr"] = topo.pod_ips[rng.integers(0, topo.n_pods, len(al))]; al["daddr"] = topo.svc_ips[rng.integers(0, topo.n_svcs, len(al))]
+    ev = np.concatenate([ev[:70_000], al, ev[70_000:]])
+    ops = topo.k8s_ops()
+    W = weights.make_weights(2)
+    out = {}
+    for hist in (True, False):
+        g = _engine(topo.n_nodes + 8, 8192, 2, k1_variant=variant, max_window_events=len(ev) + 1, edge_histogram=hist)
+        shim = HostShim(); shim.apply(g, ops)
+        for i in range(0, len(ev), 9001):                               # 17 batches: the hot keys' aggregates meet again and again
+            while g.ingest(ev[i:i + 9001]) != 0:
+                pass
+        g.set_label_count(len(labels))
+        rows = g.flush_window()
+        out[hist] = (rows.copy(), g.window_hist() if hist else None, shim, g.outbound_ips())
+        if not hist:
+            with pytest.raises(engine.ServiceGraphError):
+                g.window_hist()
+        assert g.stats().events_dropped_cap == 0
+        g.close()
+    o = _oracle(ops, 2); o.packed(ev, labels); o.window_close(W, 2)
+    rows, hist, shim, obips = out[True]
+    compare_edge_dicts(engine_edge_dict(rows, shim, labels, obips), o.edge_dict(), percentiles=True)
+    assert np.array_equal(rows["from_ref"], o.edge_rows()["from_ref"]) and np.array_equal(rows["to_ref"], o.edge_rows()["to_ref"])
+    want_h = o.edge_hist()
+    assert hist.shape == want_h.shape and np.array_equal(hist, want_h)
+    assert np.array_equal(hist.sum(axis=1), rows["count"]) and (hist[:, 0].sum() > 1500) and (hist[:, 15].sum() >= 400)
+    assert int((rows["count"] == 0).sum()) > 0 and not rows["p50_us"][rows["count"] == 0].any()
+    assert (rows["p50_us"] <= rows["p99_us"]).all() and (rows["p99_us"].astype(np.uint64) * 1000 <= rows["max_ns"]).all()
+    plain = out[False][0]
+    for f in plain.dtype.names:
+        if f not in ("p50_us", "p99_us"):
+            assert np.array_equal(plain[f], rows[f]), f
+    assert not plain["p50_us"].any() and not plain["p99_us"].any()
+
+
+def test_edge_histogram_at_config2_scale():
+    """Config 2 at full size with the histogram on: bins against numpy (every accepted event lands in exactly one bin of
+    its edge: column sums = the trace's bin counts), row for row against the oracle."""
+    topo, ev, labels, L = replay.make_config(2)
+    g = _engine(topo.n_nodes + 8, 1 << 16, L, max_window_events=len(ev) + 1, edge_histogram=True)
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    _feed(g, ev)
+    g.set_label_count(len(labels))
+    rows = g.flush_window(); hist = g.window_hist()
+    acc = np.isin(ev["saddr"], topo.pod_ips)
+    assert np.array_equal(hist.sum(axis=0), np.bincount(replay.hist_bin(ev["duration_ns"][acc]), minlength=16))
+    o = _oracle(topo.k8s_ops(), L); o.packed(ev, labels); o.window_close(weights.make_weights(L), L)
+    want = o.edge_rows()
+    for f in ("from_ref", "to_ref", "count", "sum_ns", "max_ns", "p50_us", "p99_us"):
+        assert np.array_equal(rows[f], want[f]), f
+    assert np.array_equal(hist, o.edge_hist()) and g.stats().events_dropped_cap == 0

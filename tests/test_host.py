@@ -16,7 +16,7 @@ def _built():
 
 
 def _cfg(nodes=256, edges=4096):
-    return engine.SgConfig(1, 0, nodes, 256, 64, nodes, edges, 1 << 16, 1, 0, 1, 0, 0, 1, 0)
+    return engine.SgConfig(engine.ABI_VERSION, 0, nodes, 256, 64, nodes, edges, 1 << 16, 1, 0, 1, 0, 0, 1, 0)
 
 
 @pytest.mark.parametrize("req", [b"GET /user HTTP1.1", b"GET /a HTTP/1.1\r\nHost: example.com\r\nX: y\r\n\r\n",
@@ -160,11 +160,11 @@ def test_json_string_escaping_follows_encoding_json(raw):
 
 
 def test_edges_payload_json_round_trip_and_batching():
-    """f-3: the "/edges/" payload (edges_payload.hpp): metadata keys of datastore/payload.go:3-8, 13 positional slots per edge,
+    """f-3: the "/edges/" payload (edges_payload.hpp): metadata keys of datastore/payload.go:3-8, 15 positional slots per edge (13, 14 = p50 / p99 in us),
     shortest round-trip floats, batches with distinct idempotency keys, nothing sent for an empty window."""
     import json, struct
     f32 = lambda x: struct.unpack("<f", struct.pack("<f", x))[0]
-    rows = [(b"pod", b"uid-a", b"service", b"uid-b", 10, 1, 123456789012, 99999999, 2**63 + 5, f32(0.731), f32(-1.25e-7), f32(0.1), 0),
+    rows = [(b"pod", b"uid-a", b"service", b"uid-b", 10, 1, 123456789012, 99999999, 2**63 + 5, f32(0.731), f32(-1.25e-7), f32(0.1), 0, 4194, 99999),
             (b"pod", b"uid-a", b"outbound", b"api.example.com", 1, 0, 5, 5, 0, f32(1.0), f32(0.0), f32(0.0), 3),
             (b"pod", b'we"ird<uid>', b"outbound", b"8.8.8.8", 4294967295, 4294967295, 2**64 - 1, 2**64 - 1, 2**64 - 1, f32(3.4e38), f32(1e-45), float("nan"), 4294967295)]
     docs = hostlib.edges_json_from_rows(rows, 1700000000123, "mon-1", "idem", "node-7", "v0.0.0", batch=2)
@@ -174,7 +174,7 @@ def test_edges_payload_json_round_trip_and_batching():
     assert p0["metadata"] == {"monitoring_id": "mon-1", "idempotency_key": "idem-1700000000123-0", "node_id": "node-7", "alaz_version": "v0.0.0"}
     assert p1["metadata"]["idempotency_key"] == "idem-1700000000123-1" and p0["window_end"] == p1["window_end"] == 1700000000123
     got = p0["edges"] + p1["edges"]
-    assert len(got) == 3 and all(len(e) == 13 for e in got)
+    assert len(got) == 3 and all(len(e) == 15 for e in got) and got[0][13:] == [4194, 99999] and got[1][13:] == [0, 0]
     for e, r in zip(got, rows):
         assert e[:4] == [r[0].decode(), r[1].decode(), r[2].decode(), r[3].decode()]
         assert e[4:9] == list(r[4:9]) and e[9] == r[12]                                  # integers exact, incl. > 2^63

@@ -246,3 +246,32 @@ def test_generator_is_deterministic_and_splitmix_known_answer():
     a = replay.make_config(1); b = replay.make_config(1)
     assert np.array_equal(a[1], b[1]) and a[2] == b[2]
     assert int(replay.hash32(np.array([1], dtype=np.uint32))[0]) == pyoracle.lib().or_hash32(1)
+
+
+def test_latency_histogram_bins_and_percentiles_known_answers(oracle_lib):
+    """f-3 (include/servicegraph.h): bin 0 below 2^17 ns, one bin per octave, bin 15 from 2^31 ns; the q-th percentile is the
+    upper edge of the first bin whose cumulative count reaches ceil(count * q / 100), capped at max_ns, in whole microseconds."""
+    import ctypes as C
+    from alaz_amd import replay
+    l = oracle_lib.lib()
+    l.or_hist_bin.restype = C.c_uint32; l.or_hist_bin.argtypes = [C.c_uint64]
+    l.or_percentile_us.restype = C.c_uint32; l.or_percentile_us.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64, C.c_uint32]
+    edges = [0, 1, (1 << 17) - 1, 1 << 17, (1 << 18) - 1, 1 << 18, 5_000_000, (1 << 31) - 1, 1 << 31, 1 << 40, (1 << 62) - 1]
+    want = [0, 0, 0, 1, 1, 2, 6, 14, 15, 15, 15]
+    assert [l.or_hist_bin(d) for d in edges] == want
+    assert replay.hist_bin(np.array(edges, dtype=np.uint64)).tolist() == want
+    rng = np.random.default_rng(1)
+    d = rng.integers(1, 1 << 40, 20000, dtype=np.uint64) >> rng.integers(0, 30, 20000).astype(np.uint64)
+    assert replay.hist_bin(d).tolist() == [l.or_hist_bin(int(x)) for x in d]
+
+    def pct(h, count, mx, q):
+        a = (C.c_uint32 * 16)(*h)
+        return l.or_percentile_us(a, count, mx, q)
+    h = [0] * 16; h[5] = 98; h[9] = 2                               # 98 requests in [2^21, 2^22) ns, 2 in [2^25, 2^26)
+    assert pct(h, 100, 50_000_000, 50) == (1 << 22) // 1000 and pct(h, 100, 50_000_000, 99) == 50_000                    # p99 = bin 9's edge 2^26 = 67.1 ms, capped at max 50 ms
+    assert pct(h, 100, 1 << 40, 98) == (1 << 22) // 1000 and pct(h, 100, 1 << 40, 99) == (1 << 26) // 1000
+    assert pct([0] * 16, 0, 0, 99) == 0                                                                                     # an edge kept alive only by open connections
+    h = [0] * 16; h[15] = 1
+    assert pct(h, 1, 3_000_000_000, 50) == 3_000_000                                                                        # open last bin -> max_ns
+    h = [1] + [0] * 15
+    assert pct(h, 1, 90_000, 50) == 90                                                                                      # capped at max_ns inside bin 0
