@@ -88,6 +88,10 @@ __device__ __forceinline__ float wave_butterfly_sum_f32(float r) {
     r = r + xor_partner_f32(r, 4);  r = r + xor_partner_f32(r, 2);  r = r + xor_partner_f32(r, 1);
     return r;
 }
+// Storage order of the score head's per-node projections P, Q (private to K4's fused projection, k5_node_proj and
+// k5_edge_score): hidden unit j lives at position (j & 15) * 4 + (j >> 4), so that the four units {q, q+16, q+32, q+48}
+// a lane of k5_edge_score owns are one 16-byte load.
+#define SG_PQ_POS(j) ((((j) & 15) << 2) | ((j) >> 4))
 #define SG_OP_MIN(a, b) ((b) < (a) ? (b) : (a))
 #define SG_OP_MAX(a, b) ((b) > (a) ? (b) : (a))
 #define SG_OP_ADD(a, b) ((a) + (b))
@@ -1656,7 +1660,7 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
                     f32x4 c = { bj, bj, bj, bj };
                     c = dense_tile_mfma<SG_F_HID>(H, LDH, Wm, jb, c);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { const u32 row = (lane >> 4) * 4 + r; if (v0 + row < N) dst[(size_t)(v0 + row) * SG_F_HID + jb + i] = c[r]; }
+                    for (int r = 0; r < 4; r++) { const u32 row = (lane >> 4) * 4 + r; if (v0 + row < N) dst[(size_t)(v0 + row) * SG_F_HID + SG_PQ_POS(jb + i)] = c[r]; }
                 } else {
                     // VALU twin: lane -> (row = lane >> 2, 4 columns)
                     const u32 row = lane >> 2, jq = jb + (lane & 3) * 4;
@@ -1670,7 +1674,7 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
                     }
                     if (v0 + row < N)
 #pragma unroll
-                        for (int c = 0; c < 4; c++) dst[(size_t)(v0 + row) * SG_F_HID + jq + c] = acc[c];
+                        for (int c = 0; c < 4; c++) dst[(size_t)(v0 + row) * SG_F_HID + SG_PQ_POS(jq + c)] = acc[c];
                 }
             }
         }
@@ -1710,7 +1714,7 @@ __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restri
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const u32 row = (lane >> 4) * 4 + r;
-                if (v0 + row < N) { d.P[(size_t)vid[row] * SG_F_HID + jb + i] = p[r]; d.Q[(size_t)vid[row] * SG_F_HID + jb + i] = q[r]; }
+                if (v0 + row < N) { d.P[(size_t)vid[row] * SG_F_HID + SG_PQ_POS(jb + i)] = p[r]; d.Q[(size_t)vid[row] * SG_F_HID + SG_PQ_POS(jb + i)] = q[r]; }
             }
         } else {
             const u32 row = threadIdx.x >> 4, jq = (threadIdx.x & 15) * 4;
@@ -1724,59 +1728,61 @@ __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restri
             }
             if (v0 + row < N)
 #pragma unroll
-                for (int c = 0; c < 4; c++) { d.P[(size_t)vid[row] * SG_F_HID + jq + c] = p[c]; d.Q[(size_t)vid[row] * SG_F_HID + jq + c] = q[c]; }
+                for (int c = 0; c < 4; c++) { d.P[(size_t)vid[row] * SG_F_HID + SG_PQ_POS(jq + c)] = p[c]; d.Q[(size_t)vid[row] * SG_F_HID + SG_PQ_POS(jq + c)] = q[c]; }
         }
         __syncthreads();
     }
 }
 
-// one wave scores K5_U edges at a time (lane = hidden unit j): the index loads, then the 2*K5_U row
-// gathers of a step are independent and in flight together.
-#define K5_U 4
+// One wave scores 4 edges per step: 16 lanes per edge, lane q of a group owns hidden units q + 16 m (m = 0..3).
+//   t_j = P[u][j] + Q[v][j] + sum_k e_k We[k][j] (fmaf chain over k), ReLU, * w2[j]
+//   sum over j in the canonical butterfly order (strides 32, 16, 8, 4, 2, 1): strides 32 and 16 pair units of
+//   the SAME lane (j ^ 32 <-> m ^ 2, j ^ 16 <-> m ^ 1), strides 8..1 are DPP steps inside the group's row of 16 lanes — the
+//   same additions in the same order as one lane per unit (fp32 addition commutes bitwise), at a quarter of the
+//   instructions per edge.  Lane 0 of a group writes the edge's row.
 template <bool RESET>
 __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
     const u32 E = (u32)d.ctr[C_N_EDGES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const float* __restrict__ We = Wh + 2 * SG_F_HID * SG_F_HID;
     const float* __restrict__ w2 = We + SG_F_EDGE * SG_F_HID + SG_F_HID;
     const float b2 = w2[SG_F_HID];
-    const u32 lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
-    float we[SG_F_EDGE];
+    const u32 lane = threadIdx.x & 63, q = lane & 15, g = lane >> 4;
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    float we[SG_F_EDGE][4], w2r[4];
 #pragma unroll
-    for (int k = 0; k < (int)SG_F_EDGE; k++) we[k] = We[k * SG_F_HID + lane];
-    const float w2j = w2[lane];
-    for (u32 p0 = wave * K5_U; p0 < E; p0 += nw * K5_U) {
-        u32 uu[K5_U], vv[K5_U]; float t[K5_U], ev[K5_U];
+    for (int m = 0; m < 4; m++) {
+        w2r[m] = w2[q + 16 * m];
 #pragma unroll
-        for (int q = 0; q < K5_U; q++) { const u32 p = p0 + q < E ? p0 + q : E - 1; uu[q] = d.csr_from[p]; vv[q] = d.col[p]; }
-        // what the row writer (lane q -> edge p0 + q) needs is fetched now, beside the index loads, not after the sums
-        const u32 pw = p0 + (lane < K5_U ? lane : 0) < E ? p0 + (lane < K5_U ? lane : 0) : E - 1;
-        const ulonglong2* __restrict__ aw = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)pw * 4);
-        const ulonglong2 wx = aw[0], wy = aw[1];
-        const float w_latz = d.latz[pw], w_errr = d.errr[pw]; const u32 w_alive = d.alive_csr[pw];
-#pragma unroll
-        for (int q = 0; q < K5_U; q++) {
-            const u32 p = p0 + q < E ? p0 + q : E - 1;
-            t[q] = d.P[(size_t)uu[q] * SG_F_HID + lane] + d.Q[(size_t)vv[q] * SG_F_HID + lane];
-            ev[q] = lane < SG_F_EDGE ? d.efeat[(size_t)p * SG_F_EDGE + lane] : 0.0f;
+        for (int k = 0; k < (int)SG_F_EDGE; k++) we[k][m] = We[k * SG_F_HID + q + 16 * m];
+    }
+    for (u32 p0 = wave * 4; p0 < E; p0 += nw * 4) {
+        const bool live = p0 + g < E;
+        const u32 p = live ? p0 + g : E - 1;
+        const u32 u = d.csr_from[p], v = d.col[p];
+        const float4 P4 = reinterpret_cast<const float4*>(d.P + (size_t)u * SG_F_HID)[q], Q4 = reinterpret_cast<const float4*>(d.Q + (size_t)v * SG_F_HID)[q];
+        const float4 e0 = reinterpret_cast<const float4*>(d.efeat + (size_t)p * SG_F_EDGE)[0], e1 = reinterpret_cast<const float4*>(d.efeat + (size_t)p * SG_F_EDGE)[1];
+        // what the row writer needs is fetched now, beside the gathers, not after the sums
+        ulonglong2 wx = make_ulonglong2(0, 0), wy = make_ulonglong2(0, 0); float w_latz = 0.0f, w_errr = 0.0f; u32 w_alive = 0;
+        if (q == 0) {
+            const ulonglong2* __restrict__ aw = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
+            wx = aw[0]; wy = aw[1]; w_latz = d.latz[p]; w_errr = d.errr[p]; w_alive = d.alive_csr[p];
         }
+        const float ek[SG_F_EDGE] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        const float pq[4] = {P4.x + Q4.x, P4.y + Q4.y, P4.z + Q4.z, P4.w + Q4.w};
+        float r[4];
 #pragma unroll
-        for (int q = 0; q < K5_U; q++) {
-            float x = t[q];
+        for (int m = 0; m < 4; m++) {
+            float x = pq[m];
 #pragma unroll
-            for (int k = 0; k < (int)SG_F_EDGE; k++) x = fmaf(__uint_as_float(rdlane32(__float_as_uint(ev[q]), k)), we[k], x);
+            for (int k = 0; k < (int)SG_F_EDGE; k++) x = fmaf(ek[k], we[k][m], x);
             x = x > 0.0f ? x : 0.0f;
-            float r = x * w2j;
-            t[q] = wave_butterfly_sum_f32(r);
+            r[m] = x * w2r[m];
         }
-        if (lane < K5_U && p0 + lane < E) {
-            const u32 p = p0 + lane;
-            float r = t[0];
-#pragma unroll
-            for (int q = 1; q < K5_U; q++) r = lane == (u32)q ? t[q] : r;
-            u32 u = uu[0], v = vv[0];
-#pragma unroll
-            for (int q = 1; q < K5_U; q++) { u = lane == (u32)q ? uu[q] : u; v = lane == (u32)q ? vv[q] : v; }
-            const float logit = r + b2;
+        float sum = (r[0] + r[2]) + (r[1] + r[3]);                  // strides 32, then 16
+        sum = sum + xor_partner_f32(sum, 8); sum = sum + xor_partner_f32(sum, 4);
+        sum = sum + xor_partner_f32(sum, 2); sum = sum + xor_partner_f32(sum, 1);
+        if (q == 0 && live) {
+            const float logit = sum + b2;
             const float score = 1.0f / (1.0f + expf(-logit));
             sg_edge_out o;
             o.sum_ns = wx.y; o.max_ns = wy.x; o.sumsq_us = wy.y;

@@ -269,7 +269,15 @@ def bench_single(a, device):
     Ev, L = c["events"], c["layers"]
     nb = a.batches or max(2, -(-(320 << 20) // (Ev * 32)))          # ring >= 320 MB > 256 MiB Infinity Cache
     topo = replay.make_topology(c["pods"], c["edges"], seed)
-    ev_all, labels = replay.make_events(topo, Ev * nb, seed, mixed=(cfgno == 5))
+    cache = os.environ.get("SG_BENCH_CACHE")                         # tools/gpu_round2.sh: several profiler passes over the same trace on one box
+    cpath = os.path.join(cache, f"bench_ev_c{cfgno}_{nb}.npy") if cache else None
+    if cpath and os.path.exists(cpath):
+        ev_all = np.load(cpath); labels = list(replay.EXTERNAL_HOSTS)
+        labels = labels[: int(ev_all["host_label"].max())]
+    else:
+        ev_all, labels = replay.make_events(topo, Ev * nb, seed, mixed=(cfgno == 5))
+        if cpath:
+            np.save(cpath, ev_all)
     cpu = None
     if not a.no_cpu_baseline and not a.profile_mode:                 # before the GPU runtime exists in this process (fork)
         cpu = cpu_baseline(topo, ev_all[:Ev], labels, L, a.cpu_seconds)
