@@ -20,3 +20,11 @@ for C in 3 2; do
   cat "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_k1_c$C.json"
   rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_c$C"
 done
+# SQ / LDS activity of the K1 kernels at C3 (why they are where they are: issue, wait and LDS-array cycles)
+i=0
+for c in "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAVES"; do
+  i=$((i+1)); rm -rf "$GRAFT_REPO_ROOT/gpurun_out/pmcq_$i"
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmcq_$i" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --config 3 --steps 6 --warmup 2 --profile-mode > "$GRAFT_REPO_ROOT/gpurun_out/pmcq_$i.log" 2>&1
+done
+python "$GRAFT_REPO_ROOT/tools/pmc_summary.py" "$GRAFT_REPO_ROOT/gpurun_out/pmcq_1" "$GRAFT_REPO_ROOT/gpurun_out/pmcq_2" | grep -E "k1a|k1b|==" > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_k1_sq_counters_c3.txt"
+cat "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_k1_sq_counters_c3.txt"
