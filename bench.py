@@ -407,7 +407,7 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E):
     return {"events_per_s": Ev * nwin / dt, "ms_per_window": dt / nwin * 1e3, "windows": nwin, "feeders": feeders,
             "includes": ["memcpy into pinned staging ring", "h2d", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows", "window reset"],
             "rows_per_window": rows_n, "ring_full_retries": retries[0],
-            "bound": f"PCIe: 32 B/event host->device + 56 B/edge device->host ({(32.0 * Ev + 56.0 * E) / 1e6:.0f} MB per window)"}
+            "bound": f"PCIe: 32 B/event host->device + 64 B/edge device->host ({(32.0 * Ev + 64.0 * E) / 1e6:.0f} MB per window)"}
 
 
 if __name__ == "__main__":

@@ -29,7 +29,8 @@ for var in variants:
     for kv in var.split():
         k, v = kv.split("="); os.environ[k] = v
     g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.25) + 4096, layers=L, max_labels=64,
-                            max_outbound_ips=64, max_batch=1 << 18, max_window_events=Ev)
+                            max_outbound_ips=64, max_batch=1 << 18, max_window_events=Ev,
+                            edge_histogram=bool(int(os.environ.get("SG_SWEEP_HIST", "0"))))
     g.set_clock(1_000_000_000, 1_700_000_000_000_000_000); g.load_weights(W)
     for i in range(topo.n_pods): g.upsert_pod(int(topo.pod_ips[i]), i)
     for j in range(topo.n_svcs): g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
