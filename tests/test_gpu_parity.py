@@ -762,3 +762,76 @@ def test_edge_histogram_at_config2_scale():
     for f in ("from_ref", "to_ref", "count", "sum_ns", "max_ns", "p50_us", "p99_us"):
         assert np.array_equal(rows[f], want[f]), f
     assert np.array_equal(hist, o.edge_hist()) and g.stats().events_dropped_cap == 0
+
+
+def test_join_table_churn_at_150k_ips_with_windows_in_flight():
+    """pod / service churn at config-5 table size (100 k pods + 50 k services = 150 k IPs) while four
+    windows are in flight.  Between every 50 k-event batch the tables change (new pods in old and in new /24s, deleted pods,
+    pods that move to another IP, a service that appears and goes) — in the reference that is one map write per k8s event
+    (aggregator/persist.go:55-71, 114-130), here a few table words shipped in stream order.  Every window must equal the
+    oracle that saw the same operations at the same points of the stream, the device copy must never be replaced as a whole
+    after the initial upload, and a churned window must not cost more than twice a quiet one."""
+    import time
+    from alaz_amd import engine
+    from oracle import pyoracle
+    P, S = 100_000, 50_000
+    topo = replay.make_topology(P, 300_000, seed=171, svcs=S)
+    ev, labels = replay.make_events(topo, 8 * 200_000, seed=172)
+    ops0 = topo.k8s_ops()
+    g = _engine(topo.n_nodes + 4096, 600_000, 1, max_window_events=200_000, windows_in_flight=4, max_ips=topo.n_nodes + 4096)
+    shim = HostShim(); shim.apply(g, ops0)
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(ops0)
+    W = weights.make_weights(1)
+    g.set_label_count(len(labels))
+    rng = np.random.default_rng(173)
+    next_new = [0]
+
+    def churn():
+        ops = []
+        for _ in range(12):                                          # new pods: half in the pods' own /24s' neighbourhood, half far away
+            k = next_new[0]; next_new[0] += 1
+            ip = int(topo.pod_ips[-1]) + 1 + k if k % 2 == 0 else engine.ip_u32("172.31.0.0") + 37 * k
+            ops.append(("pod", "ADD", f"churn-pod-{k}", replay.ip_str(ip)))
+        for _ in range(8):                                           # deleted pods (their events are dropped from now on)
+            i = int(rng.integers(0, P)); ops.append(("pod", "DELETE", topo.pod_uid(i), replay.ip_str(int(topo.pod_ips[i]))))
+        for _ in range(4):                                           # a pod gets a second IP (UPDATE adds, the old key stays: persist.go:55-71)
+            i = int(rng.integers(0, P)); k = next_new[0]; next_new[0] += 1
+            ops.append(("pod", "UPDATE", topo.pod_uid(i), replay.ip_str(engine.ip_u32("172.30.0.0") + 11 * k)))
+        j = int(rng.integers(0, S))
+        ops.append(("svc", "DELETE", topo.svc_uid(j), replay.ip_str(int(topo.svc_ips[j]))))
+        ops.append(("svc", "ADD", f"churn-svc-{next_new[0]}", replay.ip_str(int(topo.svc_ips[j]))))   # the ClusterIP is taken over
+        return ops
+
+    def window(e, with_churn):
+        dt = 0.0                                                     # engine time only (table calls, ingest, flush)
+        for i in range(0, len(e), 50_000):
+            b = e[i:i + 50_000].copy()
+            ops = churn() if with_churn else []
+            if ops:
+                new_ips = [engine.ip_u32(ip) for k, et, _, ip in ops if k == "pod" and et != "DELETE"]
+                b["saddr"][:len(new_ips)] = new_ips                  # the new addresses are used at once
+            t0 = time.perf_counter()
+            shim.apply(g, ops)
+            rc = g.ingest(b)
+            while rc != 0:
+                rc = g.ingest(b)
+            dt += time.perf_counter() - t0
+            o.apply_ops(ops); o.packed(b, labels)
+        t0 = time.perf_counter()
+        rows = g.flush_window()
+        dt += time.perf_counter() - t0
+        o.window_close(W, 1)
+        compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
+        assert g.stats().last_window_events == o.window_events
+        return dt
+
+    wins = [ev[i * 200_000:(i + 1) * 200_000] for i in range(8)]
+    window(wins[0], False)                                            # warm-up (first upload)
+    full0 = g.stats().join_full_uploads
+    quiet = min(window(wins[1], False), window(wins[2], False))
+    churned = [window(w, True) for w in wins[3:8]]
+    st = g.stats()
+    assert st.join_full_uploads == full0, "a table change replaced the whole device copy"
+    assert st.join_word_updates > 0
+    assert g.stats().events_dropped_src == o.dropped_src
+    assert min(churned) < 2.0 * quiet + 0.01, (quiet, churned)
