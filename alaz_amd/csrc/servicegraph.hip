@@ -341,7 +341,14 @@ int do_layer(sg_engine* e, u32 l, hipStream_t s, bool fuse_proj) {
     const int grid = grid_for(d.ncap, 16);
     const bool pj = fuse_proj && l + 1 == e->cfg.layers && d.world == 1;
     Timed t(e, s, 4);
-#define K4_LAUNCH(FI, MF, PJ, HIN, HOUT) hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ, (FI == 32 ? 1024 : 512)>), dim3(grid), dim3(FI == 32 ? 1024 : 512), 0, s, d, HIN, HOUT, Wl, Wh)
+    // two launches per layer: the gather-mean at high occupancy (8 rows per workgroup), then the dense tiles
+    // (small graphs keep the fused kernel: at C2 the second launch costs more than the gather gains — 16.6 vs 20.9 us)
+    bool split = e->cfg.max_edges > (1u << 18);
+    if (const char* v = std::getenv("SG_K4_FUSED")) split = std::atoi(v) == 0;
+#define K4_LAUNCH(FI, MF, PJ, HIN, HOUT) do { if (split) { \
+            hipLaunchKernelGGL((k4_gather<FI>), dim3(grid_for(d.ncap, K4G_ROWS, 4096)), dim3(512), 0, s, d, HIN); \
+            hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ, (PJ ? 512 : 256), true>), dim3(grid), dim3(PJ ? 512 : 256), 0, s, d, HIN, HOUT, Wl, Wh); \
+        } else hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ, (FI == 32 ? 1024 : 512), false>), dim3(grid), dim3(FI == 32 ? 1024 : 512), 0, s, d, HIN, HOUT, Wl, Wh); } while (0)
     if (l == 0) {
         if (e->use_mfma) { if (pj) K4_LAUNCH(32, true, true, d.x0, d.h[1]); else K4_LAUNCH(32, true, false, d.x0, d.h[1]); }
         else { if (pj) K4_LAUNCH(32, false, true, d.x0, d.h[1]); else K4_LAUNCH(32, false, false, d.x0, d.h[1]); }
@@ -366,8 +373,8 @@ int do_score(sg_engine* e, hipStream_t s, bool proj_done, bool fuse_reset, bool*
         else hipLaunchKernelGGL((k5_node_proj<false>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
     }
     const bool fr = fuse_reset && d.variant == 0;
-    if (fr) hipLaunchKernelGGL(k5_edge_score<true>, dim3(grid_for(e->cfg.max_edges, 16)), dim3(256), 0, s, d, Wh);
-    else hipLaunchKernelGGL(k5_edge_score<false>, dim3(grid_for(e->cfg.max_edges, 16)), dim3(256), 0, s, d, Wh);
+    if (fr) hipLaunchKernelGGL(k5_edge_score<true>, dim3(grid_for(e->cfg.max_edges, 32)), dim3(256), 0, s, d, Wh);
+    else hipLaunchKernelGGL(k5_edge_score<false>, dim3(grid_for(e->cfg.max_edges, 32)), dim3(256), 0, s, d, Wh);
     if (did_reset) *did_reset = fr;
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
@@ -568,6 +575,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.x0, (size_t)w.ncap * SG_F_IN));
         for (u32 l = 1; l <= cfg->layers; l++) LR(dev_alloc(e, &w.h[l], (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.P, (size_t)w.ncap * SG_F_HID)); LR(dev_alloc(e, &w.Q, (size_t)w.ncap * SG_F_HID));
+        LR(dev_alloc(e, &w.nmean, (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.efeat, ME * SG_F_EDGE)); LR(dev_alloc(e, &w.latz, ME)); LR(dev_alloc(e, &w.errr, ME));
         LR(dev_alloc(e, &w.rows, ME));
         LR(dev_alloc(e, &w.in_part, (size_t)e->k3_ranges * e->k3_slices * K3_IN_NR * 6));

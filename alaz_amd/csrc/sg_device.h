@@ -147,6 +147,7 @@ struct Dev {
     float* x0;                                // [ncap][32]
     float* h[SG_MAX_LAYERS + 1];              // h[l] = output of layer l (l>=1): [ncap][64]
     float* P; float* Q;                       // [ncap][64]
+    float* nmean;                             // [ncap][64] neighbour means of the layer being computed (k4_gather -> k4_sage_layer)
     float* efeat;                             // [max_edges][8]
     float* latz; float* errr;                 // [max_edges]
     sg_edge_out* rows;                        // [max_edges]

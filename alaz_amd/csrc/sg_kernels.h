@@ -1541,15 +1541,116 @@ __device__ __forceinline__ void gather_block_sum(const float* __restrict__ hin, 
 }
 #define SG_MEAN_BLOCK 512        // neighbours per block of the canonical mean: block sums are added in block order
 
+// gather_block_sum for the stand-alone gather kernel: same sums in the same order, scheduled for the memory system.
+//  * every row load is unconditional (index clamped to the block's last neighbour, the value dropped by a select), so
+//    there is no branch per load: the batch's ids come out of NL back-to-back ds_bpermutes and its NL 16-byte row loads
+//    go out back to back (the predicated version interleaved bpermute / wait / branch / load sixteen times);
+//  * the 16 slot sums are combined through a wave-private LDS scratch (16 x FI floats): one store per accumulator,
+//    then 16 independent 16-byte reads added in slot order by the lanes of group 0 — instead of 64 dependent shuffles.
+template <int FI>
+__device__ __forceinline__ void gather_block_sum2(const float* __restrict__ hin, const u32* __restrict__ nb, u32 i_beg, u32 i_end, float* dst, float* scr) {
+    constexpr int C = FI / 4, G = 64 / C, NL = 64 / G, NA = 16 / G;
+    const u32 lane = threadIdx.x & 63, c = lane % C, g = lane / C;
+    const float4* __restrict__ h4 = reinterpret_cast<const float4*>(hin);
+    float4 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) acc[a] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    u32 nxt = i_beg + lane < i_end ? nb[i_beg + lane] : 0u;             // ids of the next batch are fetched one batch ahead
+    for (u32 base = i_beg; base < i_end; base += 64) {
+        const u32 cnt = i_end - base < 64 ? i_end - base : 64;
+        const u32 my = nxt;
+        nxt = base + 64 + lane < i_end ? nb[base + 64 + lane] : 0u;
+        u32 id[NL];
+#pragma unroll
+        for (int a = 0; a < NL; a++) { const u32 i = (u32)(G * a) + g; id[a] = __shfl(my, (int)(i < cnt ? i : cnt - 1), 64); }
+        float4 tmp[NL];
+#pragma unroll
+        for (int a = 0; a < NL; a++) tmp[a] = h4[id[a] * (u32)C + c];
+#pragma unroll
+        for (int a = 0; a < NL; a++) {                                   // ascending neighbour index inside every slot
+            const bool in = (u32)(G * a) + g < cnt;
+            float4& o = acc[a % NA];
+            o.x = in ? o.x + tmp[a].x : o.x; o.y = in ? o.y + tmp[a].y : o.y; o.z = in ? o.z + tmp[a].z : o.z; o.w = in ? o.w + tmp[a].w : o.w;
+        }
+    }
+    // slot s = G*a + g  (accumulator a of group g)  ->  scr[s][4c..4c+3]
+#pragma unroll
+    for (int a = 0; a < NA; a++) reinterpret_cast<float4*>(scr + (size_t)(G * a + (int)g) * FI)[c] = acc[a];
+    if (g == 0) {                                                        // (same wave: LDS operations of a wave are executed in order)
+        float4 t = reinterpret_cast<const float4*>(scr)[c];
+#pragma unroll
+        for (int sl = 1; sl < 16; sl++) { const float4 v = reinterpret_cast<const float4*>(scr + (size_t)sl * FI)[c]; t.x = t.x + v.x; t.y = t.y + v.y; t.z = t.z + v.z; t.w = t.w + v.w; }
+        dst[4 * c] = t.x; dst[4 * c + 1] = t.y; dst[4 * c + 2] = t.z; dst[4 * c + 3] = t.w;
+    }
+}
+#define K4_HUB_BLOCKS 32         // block sums of a hub row kept in LDS per round
+// Gather-mean as its own launch: 8 rows per 512-thread workgroup, a wave per row, two workgroups per CU — the gathers are
+// L2-latency-bound and want waves in flight, the dense part wants 16-row tiles; fused in one kernel (round 1) a tile's waves
+// waited for its longest row and a CU held one tile (C3: 57 + 99 us for the two layers).  Rows of more than one block: the
+// blocks of the row are spread over the workgroup's 8 waves and added in block order, as before.  The result, mean[v][0..FI),
+// is bit-identical to the fused version's (same gather_block_sum, same order of the block sums, one division).
+#define K4G_ROWS 8              // rows per workgroup tile of k4_gather: one per wave.  (32 rows handed out by an LDS counter balanced the
+                                // one-block rows better — 33 -> 28 us at C3 — but put several multi-block rows into one workgroup: 53 -> 62 us.)
+template <int FI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k4_gather(Dev d, const float* __restrict__ hin) {
+    __shared__ __attribute__((aligned(16))) float scr_all[8 * 16 * FI];
+    __shared__ __attribute__((aligned(16))) float part[8 * FI];
+    __shared__ __attribute__((aligned(16))) float hub[K4_HUB_BLOCKS * FI];
+    __shared__ u32 vid[8], tdeg[8];
+    const bool listed = d.world > 1 && d.ctr[C_ACT_L] != SG_ACT_NONE;
+    const u32 N = listed ? (u32)d.ctr[C_ACT_L] : (u32)d.ctr[C_N_NODES];
+    const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* scr = scr_all + wave * 16 * FI;
+    for (u32 tile = blockIdx.x; tile * K4G_ROWS < N; tile += gridDim.x) {
+        const u32 i = tile * K4G_ROWS + wave;
+        bool sk = i >= N;
+        const u32 v = sk ? 0u : (listed ? d.act_l[i] : i);
+        if (!sk && !listed && d.world > 1) {
+            const bool has_out = d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0;
+            sk = has_out && owner_of_dense(d, v, nk, nl) != d.rank;
+        }
+        u32 deg = 0;
+        if (!sk) {
+            const u32 beg = d.rowptr[v];
+            deg = d.rowptr[v + 1] - beg;
+            float* dst = part + wave * FI;
+            if (deg && deg <= SG_MEAN_BLOCK) gather_block_sum2<FI>(hin, d.col + beg, 0, deg, dst, scr);
+            if (deg <= SG_MEAN_BLOCK && lane < FI) d.nmean[(size_t)v * SG_F_HID + lane] = deg ? dst[lane] / (float)deg : 0.0f;   // (same wave wrote dst)
+        }
+        if (lane == 0) { vid[wave] = v; tdeg[wave] = sk ? 0u : deg; }
+        __syncthreads();
+        // rows of more than one block: ALL their blocks are spread over the 8 waves (the row's own wave did nothing above)
+        for (u32 r = 0; r < 8; r++) {
+            const u32 dg = tdeg[r];
+            if (dg <= SG_MEAN_BLOCK) continue;                       // uniform
+            const u32 hv = vid[r], beg = d.rowptr[hv], nblk = (dg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
+            float total = 0.0f;
+            for (u32 b0 = 0; b0 < nblk; b0 += K4_HUB_BLOCKS) {
+                const u32 bn = nblk - b0 < K4_HUB_BLOCKS ? nblk - b0 : K4_HUB_BLOCKS;
+                for (u32 j = wave; j < bn; j += 8) {
+                    const u32 i0 = (b0 + j) * SG_MEAN_BLOCK, i1 = i0 + SG_MEAN_BLOCK < dg ? i0 + SG_MEAN_BLOCK : dg;
+                    gather_block_sum2<FI>(hin, d.col + beg, i0, i1, hub + j * FI, scr);
+                }
+                __syncthreads();
+                if (wave == 0 && lane < FI) for (u32 j = 0; j < bn; j++) total = (b0 + j) ? total + hub[j * FI + lane] : hub[j * FI + lane];   // block 0 starts the sum
+                __syncthreads();
+            }
+            if (wave == 0 && lane < FI) d.nmean[(size_t)hv * SG_F_HID + lane] = total / (float)dg;
+        }
+        __syncthreads();
+    }
+}
+
 // 16-node tiles, 1024 threads: in the gather phase every wave owns one node of the tile (the rows
 // follow a power law, so per-node parallelism is what bounds this kernel); the dense phase runs on
 // the first 4 waves.  With PROJ the tile's fresh h rows are immediately projected to the score
 // head's P = b1 + h Wu and Q = h Wv (last layer, unsharded), saving a launch.
-#define K4_HUB_BLOCKS 32         // block sums of a hub row kept in LDS per round
 // NT = 1024 (one wave per tile row) for the 32-feature first layer; NT = 512 (a wave takes two rows) for the
 // 64-feature hidden layers: twice the registers per lane, so all 16 loads of a batch in the 16-byte layout are in
 // flight (a quarter of the round trips on hub rows; C3 layer 2: 369 us before).
-template <int FI, bool USE_MFMA, bool PROJ, int NT>
+// PRE: the neighbour means were computed by k4_gather (d.nmean): phase 1 only copies rows, the hub loop is gone.
+template <int FI, bool USE_MFMA, bool PROJ, int NT, bool PRE = false>
 __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restrict__ hin, float* __restrict__ hout, const float* __restrict__ Wl, const float* __restrict__ Wh) {
     constexpr int LDA = 2 * FI + 2;                               // +2 floats: conflict-free A-fragment reads
     constexpr int LDH = SG_F_HID + 2;
@@ -1557,7 +1658,7 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
     __shared__ float H[PROJ ? 16 * LDH : 1];
     __shared__ u32 skip[16];
     __shared__ u32 vid[16], tdeg[16];
-    __shared__ float hub[K4_HUB_BLOCKS * FI];
+    __shared__ float hub[PRE ? 1 : K4_HUB_BLOCKS * FI];
     // world > 1: walk the shard's active list (local sources + local leaf destinations; the rows of remote
     // sources arrive by halo exchange); unsharded: every node
     const bool listed = !PROJ && d.world > 1 && d.ctr[C_ACT_L] != SG_ACT_NONE;   // lists are built with the halo requests
@@ -1583,11 +1684,16 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
                 for (u32 k = lane; k < FI; k += 64) row[k] = hin[(size_t)v * FI + k];
                 const u32 beg = d.rowptr[v];
                 deg = d.rowptr[v + 1] - beg;
+                if constexpr (PRE) {
+                    for (u32 k = lane; k < FI; k += 64) row[FI + k] = deg ? d.nmean[(size_t)v * SG_F_HID + k] : 0.0f;
+                    deg = 0;                                         // (nothing left for the hub loop)
+                } else {
                 // block 0 here (one wave per row, all rows at once); the further blocks of a hub row below
                 if (deg) gather_block_sum<FI, WIDE>(hin, d.col + beg, 0, deg < SG_MEAN_BLOCK ? deg : SG_MEAN_BLOCK, row + FI);
                 if (lane < FI) {                                     // (same wave wrote row[FI..): ordered by the LDS counter)
                     const float t = deg ? row[FI + lane] : 0.0f;
                     row[FI + lane] = deg > SG_MEAN_BLOCK ? t : (deg ? t / (float)deg : 0.0f);
+                }
                 }
             }
             if (lane == 0) { skip[r] = sk ? 1u : 0u; vid[r] = v; tdeg[r] = deg; }
@@ -1595,7 +1701,7 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
         __syncthreads();
         // hub rows (more than one block): the blocks of a row are spread over the 16 waves, the block sums are
         // then added in block order by one wave — a 3000-neighbour row no longer serialises on a single wave
-        for (u32 r = 0; r < 16; r++) {
+        if constexpr (!PRE) for (u32 r = 0; r < 16; r++) {
             const u32 deg = tdeg[r];
             if (deg <= SG_MEAN_BLOCK) continue;                      // uniform
             const u32 v = vid[r], beg = d.rowptr[v], nblk = (deg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
@@ -1741,7 +1847,7 @@ __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restri
 //   same additions in the same order as one lane per unit (fp32 addition commutes bitwise), at a quarter of the
 //   instructions per edge.  Lane 0 of a group writes the edge's row.
 template <bool RESET>
-__global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
     const u32 E = (u32)d.ctr[C_N_EDGES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const float* __restrict__ We = Wh + 2 * SG_F_HID * SG_F_HID;
     const float* __restrict__ w2 = We + SG_F_EDGE * SG_F_HID + SG_F_HID;
@@ -1755,18 +1861,11 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
 #pragma unroll
         for (int k = 0; k < (int)SG_F_EDGE; k++) we[k][m] = We[k * SG_F_HID + q + 16 * m];
     }
-    for (u32 p0 = wave * 4; p0 < E; p0 += nw * 4) {
-        const bool live = p0 + g < E;
-        const u32 p = live ? p0 + g : E - 1;
-        const u32 u = d.csr_from[p], v = d.col[p];
-        const float4 P4 = reinterpret_cast<const float4*>(d.P + (size_t)u * SG_F_HID)[q], Q4 = reinterpret_cast<const float4*>(d.Q + (size_t)v * SG_F_HID)[q];
-        const float4 e0 = reinterpret_cast<const float4*>(d.efeat + (size_t)p * SG_F_EDGE)[0], e1 = reinterpret_cast<const float4*>(d.efeat + (size_t)p * SG_F_EDGE)[1];
-        // what the row writer needs is fetched now, beside the gathers, not after the sums
-        ulonglong2 wx = make_ulonglong2(0, 0), wy = make_ulonglong2(0, 0); float w_latz = 0.0f, w_errr = 0.0f; u32 w_alive = 0;
-        if (q == 0) {
-            const ulonglong2* __restrict__ aw = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)p * 4);
-            wx = aw[0]; wy = aw[1]; w_latz = d.latz[p]; w_errr = d.errr[p]; w_alive = d.alive_csr[p];
-        }
+    // Two steps of four edges per iteration, and the endpoints of the NEXT iteration's edges are fetched while this one's
+    // rows are gathered: the dependent chain per iteration is one round trip (the gathers), not two (ids, then gathers),
+    // with four 16-byte gathers per lane in flight instead of two.
+    auto step = [&](u32 pp, bool live, u32 u, u32 v, const float4 P4, const float4 Q4, const float4 e0, const float4 e1,
+                    const ulonglong2 wx, const ulonglong2 wy, float w_latz, float w_errr, u32 w_alive) {
         const float ek[SG_F_EDGE] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
         const float pq[4] = {P4.x + Q4.x, P4.y + Q4.y, P4.z + Q4.z, P4.w + Q4.w};
         float r[4];
@@ -1791,7 +1890,7 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
             o.score = score; o.lat_z = w_latz; o.err_ratio = w_errr; o.alive = w_alive;
             o.p50_us = 0; o.p99_us = 0;
             if (d.hist && o.count) {                                 // percentiles off the log2 histogram (include/servicegraph.h)
-                const uint4* hp = reinterpret_cast<const uint4*>(d.hist_csr + (size_t)p * SG_HIST_BINS);
+                const uint4* hp = reinterpret_cast<const uint4*>(d.hist_csr + (size_t)pp * SG_HIST_BINS);
                 const uint4 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
                 const u32 hb[SG_HIST_BINS] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
                 u64 r50 = ((u64)o.count * 50 + 99) / 100, r99 = ((u64)o.count * 99 + 99) / 100;
@@ -1804,7 +1903,34 @@ __global__ __launch_bounds__(256) void k5_edge_score(Dev d, const float* __restr
                 e50 /= 1000ull; e99 /= 1000ull;
                 o.p50_us = e50 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e50; o.p99_us = e99 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e99;
             }
-            d.rows[p] = o;
+            d.rows[pp] = o;
+        }
+    };
+    if (E) {
+        const u32 stride = nw * 8, last = E - 1;
+        u32 pa = wave * 8 + g, pb = pa + 4;                          // this iteration's two edges of the lane group (clamped when beyond E)
+        u32 ua = d.csr_from[pa < E ? pa : last], va = d.col[pa < E ? pa : last], ub = d.csr_from[pb < E ? pb : last], vb = d.col[pb < E ? pb : last];
+        for (u32 p0 = wave * 8; p0 < E; p0 += stride) {
+            const bool la = pa < E, lb = pb < E;
+            const u32 ca = la ? pa : last, cb = lb ? pb : last;
+            const float4 PA = reinterpret_cast<const float4*>(d.P + (size_t)ua * SG_F_HID)[q], QA = reinterpret_cast<const float4*>(d.Q + (size_t)va * SG_F_HID)[q];
+            const float4 PB = reinterpret_cast<const float4*>(d.P + (size_t)ub * SG_F_HID)[q], QB = reinterpret_cast<const float4*>(d.Q + (size_t)vb * SG_F_HID)[q];
+            const float4 ea0 = reinterpret_cast<const float4*>(d.efeat + (size_t)ca * SG_F_EDGE)[0], ea1 = reinterpret_cast<const float4*>(d.efeat + (size_t)ca * SG_F_EDGE)[1];
+            const float4 eb0 = reinterpret_cast<const float4*>(d.efeat + (size_t)cb * SG_F_EDGE)[0], eb1 = reinterpret_cast<const float4*>(d.efeat + (size_t)cb * SG_F_EDGE)[1];
+            // what the row writer needs is fetched now, beside the gathers, not after the sums
+            ulonglong2 wxa = make_ulonglong2(0, 0), wya = wxa, wxb = wxa, wyb = wxa; float lza = 0.0f, era = 0.0f, lzb = 0.0f, erb = 0.0f; u32 ala = 0, alb = 0;
+            if (q == 0) {
+                const ulonglong2* __restrict__ aa = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)ca * 4);
+                const ulonglong2* __restrict__ ab = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)cb * 4);
+                wxa = aa[0]; wya = aa[1]; lza = d.latz[ca]; era = d.errr[ca]; ala = d.alive_csr[ca];
+                wxb = ab[0]; wyb = ab[1]; lzb = d.latz[cb]; erb = d.errr[cb]; alb = d.alive_csr[cb];
+            }
+            // next iteration's endpoints: behind the gathers in issue order, so waiting for the gathers does not wait for them
+            const u32 na = pa + stride, nb = pb + stride;
+            const u32 ua_n = d.csr_from[na < E ? na : last], va_n = d.col[na < E ? na : last], ub_n = d.csr_from[nb < E ? nb : last], vb_n = d.col[nb < E ? nb : last];
+            step(ca, la, ua, va, PA, QA, ea0, ea1, wxa, wya, lza, era, ala);
+            step(cb, lb, ub, vb, PB, QB, eb0, eb1, wxb, wyb, lzb, erb, alb);
+            pa = na; pb = nb; ua = ua_n; va = va_n; ub = ub_n; vb = vb_n;
         }
     }
     if (RESET) {
