@@ -1137,7 +1137,15 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                 // instead of a comparison sort (a 3000-edge hub row cost ~100 us in the bitonic network).
                 for (u32 w = threadIdx.x; w < BW; w += 256) sk[w] = 0;
                 __syncthreads();
-                for (u32 i = threadIdx.x; i < m; i += 256) { const u32 k = key[i]; atomicOr(&sk[k >> 5], 1u << (k & 31)); }
+                // (every pass over the row takes four elements per thread and round: their loads are independent and in flight
+                // together — one element per round made a 3 700-edge row cost five passes x 15 dependent round trips, 75-95 us)
+                for (u32 i0 = 0; i0 < m; i0 += 1024) {
+                    u32 k4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; k4[q] = key[i < m ? i : m - 1]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (i0 + threadIdx.x + q * 256 < m) atomicOr(&sk[k4[q] >> 5], 1u << (k4[q] & 31));
+                }
                 __syncthreads();
                 {   // sv[w] = number of set bits in words [0, w)
                     const u32 per = (BW + 255) / 256, w0 = threadIdx.x * per < BW ? threadIdx.x * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
@@ -1149,30 +1157,35 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                 }
                 __syncthreads();
                 u32* gk = d.sort_k + 2 * (size_t)b; u32* gv = d.sort_v + 2 * (size_t)b;     // the row's private slice of the scratch
-                for (u32 i = threadIdx.x; i < m; i += 256) {
-                    const u32 k = key[i], v = val[i];
-                    const u32 r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
-                    gk[r] = k; gv[r] = v;
+                for (u32 i0 = 0; i0 < m; i0 += 1024) {               // rank -> scratch; the row totals from the same elements' accumulators
+                    u32 k4[4], v4[4]; ulonglong2 x4[4], y4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256, c = i < m ? i : m - 1; k4[q] = key[c]; v4[q] = val[c]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v4[q] * 4); x4[q] = a[0]; y4[q] = a[1]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (i0 + threadIdx.x + q * 256 < m) {
+                        const u32 k = k4[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
+                        gk[r] = k; gv[r] = v4[q];
+                        cnt += x4[q].x & 0xFFFFFFFFull; err += x4[q].x >> 32; sum += x4[q].y; ssq += y4[q].y; mx = y4[q].x > mx ? y4[q].x : mx;
+                    }
                 }
                 __threadfence_block();
                 __syncthreads();
-                for (u32 i = threadIdx.x; i < m; i += 256) {
-                    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
-                    const ulonglong2 x = a[0], y = a[1];
-                    cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
-                }
                 cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
                 if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
                 __syncthreads();
                 cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
                 sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
                 mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-                for (u32 i = threadIdx.x; i < m; i += 256) {
-                    const u32 slot = gv[i];
-                    key[i] = gk[i];
-                    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
-                    const ulonglong2 x = a[0], y = a[1];
-                    edge_emit(ea, b + i, rr, slot, cnt, sum, ssq, x, y);
+                for (u32 i0 = 0; i0 < m; i0 += 1024) {
+                    u32 k4[4], v4[4]; ulonglong2 x4[4], y4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256, c = i < m ? i : m - 1; k4[q] = gk[c]; v4[q] = gv[c]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v4[q] * 4); x4[q] = a[0]; y4[q] = a[1]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; if (i < m) { key[i] = k4[q]; edge_emit(ea, b + i, rr, v4[q], cnt, sum, ssq, x4[q], y4[q]); } }
                 }
             } else if (m <= 1024) {
                 // rank sort: keys in LDS, every thread counts the smaller keys of its (<= 4) elements
