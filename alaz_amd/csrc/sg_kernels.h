@@ -623,7 +623,7 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
 // 512-thread workgroups share a CU and one's (latency-bound) header round trip and compaction overlap the other's
 // (LDS-atomic-bound) merge.  The last key slot is never used as a slot: its 8 bytes hold the two workgroup counters.
 template <int K1B_U, bool HIST>   // K1B_U: single records a lane has in flight; HIST: per-edge latency histogram (f-3)
-__global__ __launch_bounds__(1024) void k1b_merge(Dev d) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_merge(Dev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 HT = d.k1b_ht, hmask = HT - 1;
     u64* hkey = reinterpret_cast<u64*>(smem);                       // [HT]  (slot HT-1: n_drop, out_n)
