@@ -627,7 +627,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 HT = d.k1b_ht, hmask = HT - 1;
     u64* hkey = reinterpret_cast<u64*>(smem);                       // [HT]  (slot HT-1: n_drop, out_n)
-    u64* hacc = hkey + HT;                                           // [HT][4]
+    u64* hacc = hkey + HT;                                           // [4][HT]: accumulator j of slot h at j*HT + h — an 8-byte stride across
+                                                                     // lanes (a 32-byte stride puts a lane group's 16 addresses on 4 bank pairs)
     u32* hh = reinterpret_cast<u32*>(hacc + (size_t)HT * 4);         // HIST: [HT][16] bins
     u32* n_drop = reinterpret_cast<u32*>(hkey + hmask); u32* out_n = n_drop + 1;
     const u32 p = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
@@ -638,6 +639,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b
     const u32 sub = t % LPP;
     const u32 w0 = t / LPP;
     u32 h0 = (!empty && w0 < d.nwg) ? d.hdr[(size_t)p * d.nwg + w0] : 0u;
+    // the first K1B_U records of the lane's first piece go out together with the header word, not after it (index clamped to
+    // the piece's capacity; what lies beyond the count is ignored): one round trip instead of two, hidden behind the table set-up
+    uint4 xf[K1B_U];
+    {
+        const uint4* piece0 = piece_of(d, p, w0 < d.nwg ? w0 : 0u);
+        const u32 ssm1 = d.ss - 1;
+#pragma unroll
+        for (int u = 0; u < K1B_U; u++) { const u32 r = sub + (u32)u * LPP; xf[u] = piece0[r < ssm1 ? r : ssm1]; }
+    }
     // counters the tail needs: fetched now so their latency hides behind the merge
     const u64 ovf_n = d.ctr[C_OVF_N];
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
@@ -659,7 +669,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b
             h = h + 1 >= hmask ? 0u : h + 1;
         }
         if (!ok) { atomicAdd(n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
-        atomicAdd(&hacc[h * 4], a0); atomicAdd(&hacc[h * 4 + 1], a1); atomicMax(&hacc[h * 4 + 2], a2); atomicAdd(&hacc[h * 4 + 3], a3);
+        atomicAdd(&hacc[h], a0); atomicAdd(&hacc[HT + h], a1); atomicMax(&hacc[2 * HT + h], a2); atomicAdd(&hacc[3 * HT + h], a3);
         if (HIST) {
             if (!bins) { if (a0 & 0xFFFFFFFFull) atomicAdd(&hh[h * SG_HIST_BINS + hist_bin64(a1)], 1u); }
             else for (u32 j = 0; j < 8; j++) {
@@ -678,8 +688,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b
         const u32 lastr = ns ? ns - 1 : 0;
         for (u32 r0 = sub; r0 < ns; r0 += LPP * K1B_U) {
             uint4 x[K1B_U];
+            if (w == w0 && r0 == sub) {
 #pragma unroll
-            for (int u = 0; u < K1B_U; u++) { const u32 r = r0 + u * LPP; x[u] = piece[r < ns ? r : lastr]; }
+                for (int u = 0; u < K1B_U; u++) x[u] = xf[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < K1B_U; u++) { const u32 r = r0 + u * LPP; x[u] = piece[r < ns ? r : lastr]; }
+            }
 #pragma unroll
             for (int u = 0; u < K1B_U; u++) if (r0 + u * LPP < ns) {
                 const u64 key = (u64)x[u].x | ((u64)x[u].y << 32);
@@ -717,23 +732,39 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b
 
     // compact the table into the partition's output slots (order within a partition is arbitrary;
     // the CSR row sort makes the final order canonical)
-    for (u32 s = t; s < hmask; s += NT) {
-        const u64 k = hkey[s];
-        if (k == SG_EKEY_EMPTY) continue;
-        const u32 f = dense_of(d, (u32)(k >> 32), nk, nl, nob), to = dense_of(d, (u32)k, nk, nl, nob);
-        if (f == SG_NONE || to == SG_NONE) { atomicAdd(n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
-        const u32 i = atomicAdd(out_n, 1u);
-        if (i >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[s * 4] & 0xFFFFFFFFull)); continue; }
-        const size_t slot = (size_t)p * d.pcap + i;
-        d.e_from[slot] = f; d.e_to[slot] = to;
-        ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
-        o[0] = make_ulonglong2(hacc[s * 4], hacc[s * 4 + 1]); o[1] = make_ulonglong2(hacc[s * 4 + 2], hacc[s * 4 + 3]);
-        if (HIST) {
-            uint4* ho = reinterpret_cast<uint4*>(d.hist_src + slot * SG_HIST_BINS); const u32* hs = hh + s * SG_HIST_BINS;
-            ho[0] = make_uint4(hs[0], hs[1], hs[2], hs[3]); ho[1] = make_uint4(hs[4], hs[5], hs[6], hs[7]);
-            ho[2] = make_uint4(hs[8], hs[9], hs[10], hs[11]); ho[3] = make_uint4(hs[12], hs[13], hs[14], hs[15]);
+    // Two table slots per thread at most (k1b_ht <= 2 x threads): the returning `deg` atomics of both are issued before
+    // either result is stored — one round trip per partition instead of two.
+    for (u32 s0 = t; s0 < hmask; s0 += 2 * NT) {
+        u32 f[2], to[2], oi[2], rk[2]; bool live[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+            const u32 s = s0 + (u32)k2 * NT;
+            live[k2] = false; f[k2] = to[k2] = oi[k2] = rk[k2] = 0;
+            if (s >= hmask) continue;
+            const u64 k = hkey[s];
+            if (k == SG_EKEY_EMPTY) continue;
+            f[k2] = dense_of(d, (u32)(k >> 32), nk, nl, nob); to[k2] = dense_of(d, (u32)k, nk, nl, nob);
+            if (f[k2] == SG_NONE || to[k2] == SG_NONE) { atomicAdd(n_drop, (u32)(hacc[s] & 0xFFFFFFFFull)); continue; }
+            oi[k2] = atomicAdd(out_n, 1u);
+            if (oi[k2] >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[s] & 0xFFFFFFFFull)); continue; }
+            live[k2] = true;
+            rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], p & (SG_DEG_REP - 1))], 1u);     // arrival order inside the row's replica
         }
-        d.e_rank[slot] = atomicAdd(&d.deg[SG_DEG_IDX(f, p & (SG_DEG_REP - 1))], 1u);        // arrival order inside the row's replica
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+            if (!live[k2]) continue;
+            const u32 s = s0 + (u32)k2 * NT;
+            const size_t slot = (size_t)p * d.pcap + oi[k2];
+            d.e_from[slot] = f[k2]; d.e_to[slot] = to[k2];
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
+            o[0] = make_ulonglong2(hacc[s], hacc[HT + s]); o[1] = make_ulonglong2(hacc[2 * HT + s], hacc[3 * HT + s]);
+            if (HIST) {
+                uint4* ho = reinterpret_cast<uint4*>(d.hist_src + slot * SG_HIST_BINS); const u32* hs = hh + s * SG_HIST_BINS;
+                ho[0] = make_uint4(hs[0], hs[1], hs[2], hs[3]); ho[1] = make_uint4(hs[4], hs[5], hs[6], hs[7]);
+                ho[2] = make_uint4(hs[8], hs[9], hs[10], hs[11]); ho[3] = make_uint4(hs[12], hs[13], hs[14], hs[15]);
+            }
+            d.e_rank[slot] = rk[k2];
+        }
     }
     __syncthreads();
     SG_STAMP(d, 1, 5);
