@@ -41,6 +41,19 @@ __global__ __launch_bounds__(1024) void k_store(uint4* slab, u32 np, u32 pslots,
             pos = __shfl(pos, (t & 63) & ~(G - 1), 64) + (t & (G - 1));
             uint4* dst = slab + ((size_t)p * gridDim.x + w) * pslots + (pos % pslots);
             *dst = rec;
+        } else if (MODE == 6) {                                      // one record per lane in a 32-byte slot: record + 16 bytes of padding, two stores
+            const u32 p = seed & (np - 1);
+            const u32 pos = atomicAdd(&cnt[p], 1u) % (pslots / 2);
+            uint4* dst = slab + ((size_t)p * gridDim.x + w) * pslots + 2 * pos;
+            dst[0] = rec; dst[1] = make_uint4(0, 0, 0, 0);
+        } else if (MODE == 7) {                                      // one record per LANE PAIR in a 32-byte slot: one instruction writes the whole sector
+            const u32 leader = __shfl(seed, (t & 63) & ~1u, 64);
+            const u32 p = leader & (np - 1);
+            u32 pos = 0;
+            if ((t & 1) == 0) pos = atomicAdd(&cnt[p], 1u) % (pslots / 2);
+            pos = __shfl(pos, (t & 63) & ~1u, 64);
+            uint4* dst = slab + ((size_t)p * gridDim.x + w) * pslots + 2 * pos + (t & 1);
+            *dst = rec;
         } else {
             if ((t & 3) == 0) {
                 const u32 p = seed & (np - 1);
@@ -98,6 +111,8 @@ int main() {
         RUN(3, "4 lanes x 16 B contiguous, one instruction");
         RUN(4, "1 lane x 4 dwordx4 contiguous (64 B), 16 lanes active");
         RUN(5, "8 lanes x 16 B contiguous, one instruction");
+        RUN(6, "16 B record + 16 B pad per lane (32-B slot, two stores)");
+        RUN(7, "2 lanes x 16 B (32-B slot, one instruction; half the records)");
     }
     for (u32 slots : {1024u, 2048u, 4096u}) {
         char nm[128];
