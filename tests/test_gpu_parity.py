@@ -181,6 +181,35 @@ def test_mfma_dense_equals_valu_dense_bitwise():
     assert out[0].tobytes() == out[1].tobytes()
 
 
+def test_k4_gather_launch_equals_the_fused_layer_bitwise():
+    """K4 as two launches (k4_gather at high occupancy + dense tiles) vs the fused kernel (what small graphs still run):
+    same block sums in the same order, so every row must be bit-identical — on a graph with rows shorter than one
+    64-neighbour batch, of several batches and of more than one 512-neighbour block (the multi-block path of both)."""
+    topo = replay.make_topology(600, 60_000, seed=43)           # Pareto out-degrees clipped at N/4 = 225 ...
+    ev, labels = replay.make_events(topo, 400_000, seed=44)
+    ev = ev.copy()
+    hub = topo.pod_ips[0]                                        # ... so one source is made to talk to every service and pod
+    dst = np.concatenate([topo.svc_ips, topo.pod_ips[1:]])
+    ev["saddr"][:len(dst)] = hub; ev["daddr"][:len(dst)] = dst; ev["host_label"][:len(dst)] = 0; ev["flags"][:len(dst)] = 0
+    out = []
+    for fused in ("1", "0"):
+        os.environ["SG_K4_FUSED"] = fused
+        try:
+            g = _engine(topo.n_nodes + 8, 1 << 17, 2, max_window_events=len(ev))
+            HostShim().apply(g, topo.k8s_ops())
+            for i in range(0, len(ev), 1 << 17):
+                assert g.ingest(ev[i:i + (1 << 17)]) == 0
+            g.set_label_count(len(labels))
+            out.append(g.flush_window().copy())
+            g.close()
+        finally:
+            os.environ.pop("SG_K4_FUSED", None)
+    from collections import Counter
+    deg = Counter(out[0]["from_ref"].tolist())
+    assert max(deg.values()) > 512 and min(deg.values()) < 64, (max(deg.values()), min(deg.values()))
+    assert out[0].tobytes() == out[1].tobytes()
+
+
 def test_device_resident_ingest_and_staged_pipeline():
     """sg_ingest_device on a torch-owned buffer + the staged window calls == sg_ingest + sg_flush_window."""
     import torch
