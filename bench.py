@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--batches", type=int, default=0, help="distinct event batches in the HBM ring (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--stream", action="store_true", help="config 5 only: add the streaming run (tools/c5_stream.py: raw 1096-byte records at the "
+                                                         "nominal 5 M events/s through the C++ host side, a window per second, ten windows)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="seconds per CPU-baseline variant")
     ap.add_argument("--feeders", type=int, default=8, help="host threads calling sg_ingest in the end-to-end pass")
     ap.add_argument("--windows", type=int, default=1, help="window slots in flight for the timed region (sg_config.windows_in_flight); "
@@ -378,6 +380,12 @@ def bench_single(a, device):
     if cpu is not None:
         res["cpu_baseline"] = cpu
     g.close()
+    if cfgno == 5 and a.stream and not a.profile_mode:                 # after the engine above has released its 8 GB of window buffers
+        import subprocess
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "c5_stream.py")],
+                             capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        res["streaming"] = json.loads(lines[-1]) if lines else {"error": (out.stderr or "no output")[-400:]}
     return res
 
 
@@ -404,7 +412,16 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E):
         for t in ths: t.join()
         rows_n = len(g.flush_window())
     dt = time.perf_counter() - t0
+    # what the link itself does on this box: pinned 256 MiB copies, best of 3 (the bound the figure above is held against)
+    hp = torch.empty(256 << 20, dtype=torch.uint8).pin_memory(); dv = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    h2d = d2h = 0.0
+    for _ in range(3):
+        torch.cuda.synchronize(); t1 = time.perf_counter(); dv.copy_(hp, non_blocking=True); torch.cuda.synchronize(); h2d = max(h2d, (256 << 20) / (time.perf_counter() - t1) / 1e9)
+        torch.cuda.synchronize(); t1 = time.perf_counter(); hp.copy_(dv, non_blocking=True); torch.cuda.synchronize(); d2h = max(d2h, (256 << 20) / (time.perf_counter() - t1) / 1e9)
+    link_ms = (32.0 * Ev / h2d + 64.0 * E / d2h) / 1e6
     return {"events_per_s": Ev * nwin / dt, "ms_per_window": dt / nwin * 1e3, "windows": nwin, "feeders": feeders,
+            "pcie_measured_GBs": {"h2d": round(h2d, 1), "d2h": round(d2h, 1)}, "pcie_bound_ms_per_window": round(link_ms, 3),
+            "frac_of_pcie_bound": round(link_ms / (dt / nwin * 1e3), 3),
             "includes": ["memcpy into pinned staging ring", "h2d", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows", "window reset"],
             "rows_per_window": rows_n, "ring_full_retries": retries[0],
             "bound": f"PCIe: 32 B/event host->device + 64 B/edge device->host ({(32.0 * Ev + 64.0 * E) / 1e6:.0f} MB per window)"}
