@@ -883,3 +883,60 @@ def test_config5_stream_of_raw_records_at_the_nominal_rate_loses_nothing():
     assert r["engine_events_per_s"] >= 4.9e6, r
     assert r["window_close_ms"]["max"] < 800.0, r
     assert r["rows_per_window"]["min"] == r["rows_per_window"]["max"] > 100_000, r
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_small_windows_against_the_oracle(seed):
+    """Randomised sweep over what the big tests fix: graph size (5..400 pods), events per window (0..30 k), batch raggedness,
+    SAGE depth, both K1 variants, the histogram flag, alive records, raw-IP / Host-label destinations, reversal, table
+    changes between the windows — three windows each, every window row for row against the oracle."""
+    from alaz_amd import engine
+    rng = np.random.default_rng(9000 + seed)
+    pods = int(rng.integers(5, 400)); edges = int(rng.integers(pods, min(pods * 12, pods * (pods + pods // 2 - 1)) + 1))
+    layers = 1 + seed % 2; variant = (seed // 2) % 2; hist = (seed // 4) % 2 == 1
+    topo = replay.make_topology(pods, edges, seed=9100 + seed)
+    ops = topo.k8s_ops()
+    g = _engine(topo.n_nodes + 64, 1 << 14, layers, k1_variant=variant, max_window_events=40_000, edge_histogram=hist)
+    shim = HostShim(); shim.apply(g, ops)
+    o = _oracle(ops, layers)
+    W = weights.make_weights(layers)
+    lab_all = []
+    for w in range(3):
+        n = int(rng.integers(0, 30_000)) if w else int(rng.integers(1, 30_000))
+        ev, labels = replay.make_events(topo, n, seed=9200 + 10 * seed + w, mixed=True, with_raw_outbound=True, with_reverse=True, stream_base=1000 * w)
+        remap = np.zeros(len(labels) + 1, dtype=np.uint32)
+        for i, s in enumerate(labels):
+            if s not in lab_all: lab_all.append(s)
+            remap[i + 1] = lab_all.index(s) + 1
+        ev = ev.copy(); ev["host_label"] = remap[ev["host_label"]]
+        if n > 10:
+            k = int(rng.integers(1, min(n, 200)))
+            ev["duration_ns"][:k] = rng.integers(1, 1 << 36, k).astype(np.uint64)                       # sub-microsecond .. 68 s
+            al = np.zeros(int(rng.integers(0, 50)), dtype=replay.EVENT_DTYPE); al["flags"] = replay.EV_ALIVE
+            al["saddr"] = topo.pod_ips[rng.integers(0, topo.n_pods, len(al))]
+            al["daddr"] = np.concatenate([topo.svc_ips, topo.pod_ips])[rng.integers(0, topo.n_nodes, len(al))]
+            ev = np.concatenate([ev[: n // 2], al, ev[n // 2:]])
+        if w == 1:                                                   # the tables move between the windows
+            i = int(rng.integers(0, pods)); j = int(rng.integers(0, topo.n_svcs))
+            chg = [("pod", "DELETE", topo.pod_uid(i), replay.ip_str(int(topo.pod_ips[i]))),
+                   ("pod", "ADD", f"late-pod-{seed}", "10.250.%d.%d" % (seed, 1 + i % 250)),
+                   ("svc", "UPDATE", topo.svc_uid(j), "10.251.%d.7" % seed)]
+            shim.apply(g, chg); o.apply_ops(chg)
+            if len(ev): ev["saddr"][: max(1, len(ev) // 50)] = engine.ip_u32("10.250.%d.%d" % (seed, 1 + i % 250))
+        pos = 0
+        while pos < len(ev):                                         # ragged batches
+            step = int(rng.integers(1, 9000))
+            while g.ingest(ev[pos:pos + step]) != 0:
+                pass
+            pos += step
+        g.set_label_count(len(lab_all))
+        rows = g.flush_window()
+        o.packed(ev, lab_all); o.window_close(W, layers)
+        compare_edge_dicts(engine_edge_dict(rows, shim, lab_all, g.outbound_ips()), o.edge_dict(), percentiles=hist)
+        want = o.edge_rows()
+        assert np.array_equal(rows["from_ref"], want["from_ref"]) and np.array_equal(rows["to_ref"], want["to_ref"])
+        st = g.stats()
+        assert st.last_window_events == o.window_events and st.events_dropped_cap == 0 and st.events_dropped_src == o.dropped_src
+        if hist and len(rows):
+            assert np.array_equal(g.window_hist(), o.edge_hist())
+    g.close()
