@@ -109,7 +109,7 @@ def _faithful_worker(secs):
 def _lean_worker(secs):
     from oracle import pyoracle
     topo, ev = _W["topo"], _W["ev"]
-    l = pyoracle.Lean(topo.n_nodes, len(topo.edge_src) * 2 + 1024)
+    l = pyoracle.Lean(topo.n_nodes, 2 * min(len(topo.edge_src), len(ev)) + 1024)     # (sized by what the sample can touch: a C5-sized table per process exhausted a box)
     for i in range(topo.n_pods):
         l.upsert_pod(int(topo.pod_ips[i]), i)
     for j in range(topo.n_svcs):
@@ -156,6 +156,14 @@ def cpu_baseline(topo, events, labels, layers, seconds):
     res["scoring_1t_note"] = f"window close of the {n_f}-event sample's graph ({len(o.edge_dict())} edges) in {tc * 1e3:.0f} ms"
     o.close()
     nc = max(1, min(os.cpu_count() or 1, 128))
+    try:                                                             # never more processes than a quarter of the free memory carries
+        avail = next(int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable"))
+        ent = 2 * (2 * min(len(topo.edge_src), len(lean_ev)) + 1024) + 16                  # oracle/lean_baseline.c: next power of two of this
+        per_proc = (256 << 20) + 48 * (1 << (ent - 1).bit_length()) + 600 * topo.n_nodes + 2 * len(wire)
+        nc = max(1, min(nc, int(0.25 * avail / per_proc)))
+        if len(topo.edge_src) > 5_000_000: nc = min(nc, 32)          # C5: the forked children also share a multi-GB topology copy-on-write
+    except Exception:
+        nc = min(nc, 16)
     if nc > 1:
         ctx = mp.get_context("fork")
         for name, fn, secs in (("faithful_Nt", _faithful_worker, max(3.0, seconds / 2)), ("lean_Nt", _lean_worker, max(2.0, seconds / 3))):
