@@ -15,6 +15,7 @@ bool SgApi::FromLibrary(void* dl, SgApi* o) {
     SG_SYM(create, "sg_create"); SG_SYM(destroy, "sg_destroy"); SG_SYM(upsert_pod, "sg_upsert_pod"); SG_SYM(delete_pod, "sg_delete_pod");
     SG_SYM(upsert_service, "sg_upsert_service"); SG_SYM(delete_service, "sg_delete_service"); SG_SYM(set_label_count, "sg_set_label_count");
     SG_SYM(ingest, "sg_ingest"); SG_SYM(flush_window, "sg_flush_window"); SG_SYM(window_outbound_ips, "sg_window_outbound_ips");
+    o->flush_window_view = reinterpret_cast<decltype(o->flush_window_view)>(dlsym(dl, "sg_flush_window_view"));   // optional
     SG_SYM(last_error, "sg_last_error");
 #undef SG_SYM
     return true;
@@ -221,7 +222,8 @@ int GraphDS::IngestWire(const uint8_t* recs, size_t n, const uint32_t* kafka_msg
 
 long GraphDS::FlushWindow(int64_t window_end_ms) {
     std::lock_guard<std::mutex> fg(flush_mu_);
-    std::vector<sg_edge_out> rows(max_edges_);
+    std::vector<sg_edge_out> own;                  // only without sg_flush_window_view: a pageable copy of up to max_edges rows
+    const sg_edge_out* rows = nullptr;
     std::vector<uint32_t> obips;
     size_t n = 0;
     std::vector<std::string> labels;
@@ -232,7 +234,9 @@ long GraphDS::FlushWindow(int64_t window_end_ms) {
     { std::lock_guard<std::mutex> g(pk_mu_); labels = packer_.Labels(); }
     { std::lock_guard<std::mutex> g(id_mu_); retire_now.swap(retired_); }     // ids whose last IP went away before this window closed
     api_.set_label_count(h_, (uint32_t)labels.size());
-    int rc = api_.flush_window(h_, (uint64_t)window_end_ms, rows.data(), rows.size(), &n);
+    int rc;
+    if (api_.flush_window_view) rc = api_.flush_window_view(h_, (uint64_t)window_end_ms, &rows, &n);     // rows stay valid: flush_mu_ is held
+    else { own.resize(max_edges_); rc = api_.flush_window(h_, (uint64_t)window_end_ms, own.data(), own.size(), &n); rows = own.data(); n = std::min(n, own.size()); }
     if (rc != SG_OK) return rc;
     {
         size_t no = 0;
@@ -240,7 +244,6 @@ long GraphDS::FlushWindow(int64_t window_end_ms) {
         obips.resize(no);
         if (no) api_.window_outbound_ips(h_, obips.data(), no, &no);
     }
-    n = std::min(n, rows.size());
     std::vector<EdgeRow> out(n);
     auto name = [&](uint32_t ref, std::string* type, std::string* uid) {
         const uint32_t t = SG_REF_TYPE(ref), v = SG_REF_VALUE(ref);

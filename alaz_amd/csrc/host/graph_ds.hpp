@@ -39,6 +39,7 @@ struct SgApi {
     int (*set_label_count)(sg_handle, uint32_t) = nullptr;
     int (*ingest)(sg_handle, const sg_event*, size_t) = nullptr;
     int (*flush_window)(sg_handle, uint64_t, sg_edge_out*, size_t, size_t*) = nullptr;
+    int (*flush_window_view)(sg_handle, uint64_t, const sg_edge_out**, size_t*) = nullptr;   // optional (absent in a recording stand-in): rows stay in the engine's pinned buffer
     int (*window_outbound_ips)(sg_handle, uint32_t*, size_t, size_t*) = nullptr;
     const char* (*last_error)(sg_handle) = nullptr;
     static bool FromLibrary(void* dl_handle, SgApi* out);      // dlsym of every entry; false if one is missing

@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int kStageSlots = 8;
+constexpr int kStageSlots = 16;
 constexpr int kUpdSlots = 4;             // pinned ring for join-table word updates
 constexpr u32 kUpdCap = 1u << 15;         // (word offset, value) pairs per slot = sgjoin::Table::max_dirty
 constexpr size_t kLdsBytes = 160 * 1024;  // per workgroup on gfx950
@@ -60,6 +60,7 @@ struct sg_engine {
     // staging ring for sg_ingest()
     sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
     int stage_next = 0;
+    sg_edge_out* h_rows = nullptr; size_t h_rows_cap = 0;              // page-locked destination of sg_flush_window_view (grown on demand)
     bool stage_busy[kStageSlots] = {};                                   // a feeder thread is copying into the slot (outside the lock)
     int pending_copies = 0; std::condition_variable cv;                 // window closes wait for the copies that began before them
 
@@ -388,12 +389,23 @@ int do_reset(sg_engine* e, hipStream_t s) {
     return SG_OK;
 }
 
-int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n) {
+// view != nullptr: the rows go to the engine's page-locked buffer and *view points at them (out / cap unused)
+int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n, const sg_edge_out** view = nullptr) {
     HIP_TRY(e, hipDeviceSynchronize());
     HIP_TRY(e, hipMemcpy(e->h_ctr, e->d.ctr, sizeof(e->h_ctr), hipMemcpyDeviceToHost));
     const size_t E = (size_t)e->h_ctr[C_N_EDGES];
     if (n) *n = E;
-    const size_t take = std::min(E, cap);
+    if (view) {
+        if (E > e->h_rows_cap) {
+            if (e->h_rows) { hipHostFree(e->h_rows); e->h_rows = nullptr; e->h_rows_cap = 0; }
+            const size_t want = std::min<size_t>(next_pow2(std::max<size_t>(E, 1024)), std::max<size_t>(e->cfg.max_edges, E));
+            HIP_TRY(e, hipHostMalloc((void**)&e->h_rows, want * sizeof(sg_edge_out)));
+            e->h_rows_cap = want;
+        }
+        if (E) HIP_TRY(e, hipMemcpy(e->h_rows, e->d.rows, E * sizeof(sg_edge_out), hipMemcpyDeviceToHost));
+        *view = e->h_rows;
+    }
+    const size_t take = view ? 0 : std::min(E, cap);
     if (out && take) HIP_TRY(e, hipMemcpy(out, e->d.rows, take * sizeof(sg_edge_out), hipMemcpyDeviceToHost));
     const size_t nob = (size_t)e->h_ctr[C_N_OBIP];
     e->last_obips.resize(nob);
@@ -627,6 +639,7 @@ int sg_destroy(sg_handle e) {
     if (e->blob_ev) hipEventDestroy(e->blob_ev);
     if (e->k1_ev) hipEventDestroy(e->k1_ev);
     for (int i = 0; i < kStageSlots; i++) { if (e->h_stage[i]) hipHostFree(e->h_stage[i]); if (e->stage_ev[i]) hipEventDestroy(e->stage_ev[i]); }
+    if (e->h_rows) hipHostFree(e->h_rows);
     for (auto& r : e->trecs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto v : e->ev_pool) hipEventDestroy(v);
     if (e->tab_ev) hipEventDestroy(e->tab_ev);
@@ -687,8 +700,12 @@ int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
     std::unique_lock<std::mutex> g(e->mu);
     if (n > e->cfg.max_batch) { e->err = "batch larger than max_batch"; return SG_EINVAL; }
     if (n == 0) return SG_OK;
-    const int slot = e->stage_next;
-    if (e->stage_busy[slot] || hipEventQuery(e->stage_ev[slot]) == hipErrorNotReady) {   // ring full: drop, never block
+    int slot = -1;
+    for (int k = 0; k < kStageSlots; k++) {                              // any slot that is neither being filled by another feeder nor still in flight
+        const int c = (e->stage_next + k) % kStageSlots;
+        if (!e->stage_busy[c] && hipEventQuery(e->stage_ev[c]) != hipErrorNotReady) { slot = c; break; }
+    }
+    if (slot < 0) {                                                      // ring full: drop, never block
         e->st.events_dropped_ring += n;
         return SG_EAGAIN;
     }
@@ -842,6 +859,23 @@ int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_
     bool did = false;
     if ((rc = do_score(e, s, true, true, &did))) return rc;
     if ((rc = do_read(e, out, cap, n))) return rc;
+    if (did) { e->closed = false; return SG_OK; }
+    return do_reset(e, s);
+}
+
+int sg_flush_window_view(sg_handle e, uint64_t window_end_ms, const sg_edge_out** rows, size_t* n) {
+    (void)window_end_ms;
+    if (!e || !rows) return SG_EINVAL;
+    std::unique_lock<std::mutex> g(e->mu);
+    e->cv.wait(g, [&] { return e->pending_copies == 0; });
+    hipStream_t s = e->stream;
+    int rc;
+    if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
+    if ((rc = do_features(e, s))) return rc;
+    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
+    bool did = false;
+    if ((rc = do_score(e, s, true, true, &did))) return rc;
+    if ((rc = do_read(e, nullptr, 0, n, rows))) return rc;
     if (did) { e->closed = false; return SG_OK; }
     return do_reset(e, s);
 }

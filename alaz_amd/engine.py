@@ -26,7 +26,7 @@ REF_KNOWN, REF_LABEL, REF_OBIP = 0, 1, 2
 EXPORTS = [
     "sg_abi_version", "sg_weights_count", "sg_hash32", "sg_last_error", "sg_create", "sg_destroy",
     "sg_upsert_pod", "sg_delete_pod", "sg_upsert_service", "sg_delete_service", "sg_set_clock",
-    "sg_set_label_count", "sg_load_weights", "sg_ingest", "sg_ingest_device", "sg_flush_window",
+    "sg_set_label_count", "sg_load_weights", "sg_ingest", "sg_ingest_device", "sg_flush_window", "sg_flush_window_view",
     "sg_window_run", "sg_window_rows_buffer", "sg_window_close", "sg_window_obip_list",
     "sg_window_close_sharded", "sg_bind_buffers", "sg_window_features", "sg_window_layer", "sg_window_score", "sg_window_score_reset",
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
@@ -94,6 +94,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_load_weights": (C.c_int, [H, P, sz]),
         "sg_ingest": (C.c_int, [H, P, sz]), "sg_ingest_device": (C.c_int, [H, P, sz, P]),
         "sg_flush_window": (C.c_int, [H, u64, P, sz, C.POINTER(sz)]),
+        "sg_flush_window_view": (C.c_int, [H, u64, C.POINTER(C.c_void_p), C.POINTER(sz)]),
         "sg_window_run": (C.c_int, [H, P]), "sg_window_rows_buffer": (C.c_int, [H, C.POINTER(P)]),
         "sg_window_close": (C.c_int, [H, P]),
         "sg_window_obip_list": (C.c_int, [H, P, u32, P, P]),
@@ -193,6 +194,19 @@ class ServiceGraph:
         n = C.c_size_t(0)
         self._ck(self._l.sg_flush_window(self._h, window_end_ms, out.ctypes.data, cap, C.byref(n)))
         return out[: min(n.value, cap)]
+
+    def flush_window_view(self, window_end_ms: int = 0) -> np.ndarray:
+        """The window's rows as a read-only VIEW of the engine's page-locked host buffer (no copy): valid until the next
+        flush_window / flush_window_view / window_read on this engine."""
+        ptr = C.c_void_p(); n = C.c_size_t(0)
+        self._ck(self._l.sg_flush_window_view(self._h, window_end_ms, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            z = np.zeros(0, dtype=EDGE_OUT_DTYPE); z.flags.writeable = False
+            return z
+        buf = (C.c_char * (n.value * EDGE_OUT_DTYPE.itemsize)).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=EDGE_OUT_DTYPE)
+        a.flags.writeable = False
+        return a
 
     def window_run(self, stream: int = 0): self._ck(self._l.sg_window_run(self._h, stream or None))
     def window_close(self, stream: int = 0): self._ck(self._l.sg_window_close(self._h, stream or None))

@@ -418,7 +418,7 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E):
         ths = [threading.Thread(target=feed, args=(b[k * per:(k + 1) * per],)) for k in range(feeders) if k * per < Ev]
         for t in ths: t.start()
         for t in ths: t.join()
-        rows_n = len(g.flush_window())
+        rows_n = len(g.flush_window_view())              # rows readable in the engine's page-locked host buffer (no copy into pageable memory)
     dt = time.perf_counter() - t0
     # what the link itself does on this box: pinned 256 MiB copies, best of 3 (the bound the figure above is held against)
     hp = torch.empty(256 << 20, dtype=torch.uint8).pin_memory(); dv = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
@@ -430,7 +430,7 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E):
     return {"events_per_s": Ev * nwin / dt, "ms_per_window": dt / nwin * 1e3, "windows": nwin, "feeders": feeders,
             "pcie_measured_GBs": {"h2d": round(h2d, 1), "d2h": round(d2h, 1)}, "pcie_bound_ms_per_window": round(link_ms, 3),
             "frac_of_pcie_bound": round(link_ms / (dt / nwin * 1e3), 3),
-            "includes": ["memcpy into pinned staging ring", "h2d", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows", "window reset"],
+            "includes": ["memcpy into pinned staging ring", "h2d", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows into page-locked host memory (sg_flush_window_view)", "window reset"],
             "rows_per_window": rows_n, "ring_full_retries": retries[0],
             "bound": f"PCIe: 32 B/event host->device + 64 B/edge device->host ({(32.0 * Ev + 64.0 * E) / 1e6:.0f} MB per window)"}
 

@@ -245,6 +245,12 @@ int sg_ingest_device(sg_handle h, const sg_event* d_events, size_t n, void* stre
  * *n the number of edges of the window (may exceed cap; then only cap rows were written).       */
 int sg_flush_window(sg_handle h, uint64_t window_end_ms, sg_edge_out* out, size_t cap, size_t* n);
 
+/* The same window close without the copy into caller memory: the rows are transferred into page-locked host memory the
+ * engine owns and *rows points at them — valid until the next sg_flush_window / sg_flush_window_view / sg_window_read on
+ * this handle, or sg_destroy.  *n = edges of the window (all of them are there).  For callers that only walk the rows once
+ * (a Go shim building its payload, GraphDS::FlushWindow): a pageable 64 MB destination costs more than the transfer. */
+int sg_flush_window_view(sg_handle h, uint64_t window_end_ms, const sg_edge_out** rows, size_t* n);
+
 /* Enqueue-only form of the same pipeline (K2..K5 + reset, no copy-out, no host sync) for
  * callers that keep results on the device (sg_window_rows_buffer) or time the pipeline.         */
 int sg_window_run(sg_handle h, void* stream);

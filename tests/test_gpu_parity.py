@@ -210,6 +210,35 @@ def test_k4_gather_launch_equals_the_fused_layer_bitwise():
     assert out[0].tobytes() == out[1].tobytes()
 
 
+def test_flush_window_view_returns_the_same_rows_without_the_copy():
+    """sg_flush_window_view: the rows of the window in the engine's page-locked buffer must be the rows sg_flush_window
+    copies out — for a window, an empty window, and a larger one after it (the buffer grows); many feeder threads at once
+    (any free staging slot is used, not only the next one in ring order)."""
+    import threading
+    topo = replay.make_topology(300, 9000, seed=61)
+    ev, labels = replay.make_events(topo, 600_000, seed=62, mixed=True, with_raw_outbound=True)
+    a = _engine(topo.n_nodes + 8, 1 << 15, 2, max_window_events=400_000, max_batch=1 << 14)
+    b = _engine(topo.n_nodes + 8, 1 << 15, 2, max_window_events=400_000, max_batch=1 << 14)
+    for g in (a, b):
+        HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
+
+    def feed(g, e, threads):
+        parts = np.array_split(np.arange(0, len(e), 1 << 14), threads) if len(e) else []
+        def run(idx):
+            for i in idx:
+                while g.ingest(e[i:i + (1 << 14)]) != 0:
+                    pass
+        ths = [threading.Thread(target=run, args=(p,)) for p in parts]
+        for t in ths: t.start()
+        for t in ths: t.join()
+    for lo, hi in ((0, 50_000), (50_000, 50_000), (50_000, 450_000)):
+        feed(a, ev[lo:hi], 6); feed(b, ev[lo:hi], 1)
+        v = a.flush_window_view(); c = b.flush_window()
+        assert len(v) == len(c) and v.tobytes() == c.tobytes()
+        assert not v.flags.writeable
+    assert a.stats().events_dropped_cap == 0
+
+
 def test_device_resident_ingest_and_staged_pipeline():
     """sg_ingest_device on a torch-owned buffer + the staged window calls == sg_ingest + sg_flush_window."""
     import torch
