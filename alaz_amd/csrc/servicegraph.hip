@@ -78,7 +78,7 @@ struct sg_engine {
     int k1_grid = 0;
     size_t k1a_lds = 0, k1b_lds = 0, k3in_lds = 0;
     u32 k3_ranges = 1, k3_slices = 8;
-    u32 k1b_threads = 512, k1b_u = 4;
+    u32 k1b_threads = 512, k1b_u = 4, k1b_cus = 256;
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
@@ -295,9 +295,11 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         const bool tk = (e->timing >> 7) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
-        if (d.hist) hipExtLaunchKernelGGL((k1b_merge<4, true>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
-        else if (e->k1b_u == 8) hipExtLaunchKernelGGL((k1b_merge<8, false>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
-        else hipExtLaunchKernelGGL((k1b_merge<4, false>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db);
+        const bool share = d.np > e->k1b_cus;                           // several partitions per CU: the SGPR-capped build lets two workgroups share a CU
+#define K1B_GO(U_, H_) do { if (share) hipExtLaunchKernelGGL((k1b_merge<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
+                            else hipExtLaunchKernelGGL((k1b_merge_wide<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
+        if (d.hist) K1B_GO(4, true); else if (e->k1b_u == 8) K1B_GO(8, false); else K1B_GO(4, false);
+#undef K1B_GO
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
     }
     {
@@ -464,6 +466,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CH(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CH(hipEventCreateWithFlags(&e->tab_ev, hipEventDisableTiming));
     e->k1_grid = std::min<int>(SG_MAX_K1_WGS, prop.multiProcessorCount * 8);
+    e->k1b_cus = (u32)std::max(1, prop.multiProcessorCount);
     const char* env = std::getenv("SG_DENSE_VALU");
     e->use_mfma = !(env && env[0] == '1');
 
@@ -538,7 +541,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
                               reinterpret_cast<const void*>(k1a_partition<true, true, true>), reinterpret_cast<const void*>(k1a_partition<true, false, true>),
                               reinterpret_cast<const void*>(k1a_partition<false, true, true>), reinterpret_cast<const void*>(k1a_partition<false, false, true>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
-        for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>)})
+        for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>),
+                              reinterpret_cast<const void*>(k1b_merge_wide<4, false>), reinterpret_cast<const void*>(k1b_merge_wide<8, false>), reinterpret_cast<const void*>(k1b_merge_wide<4, true>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }

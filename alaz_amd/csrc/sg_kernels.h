@@ -622,8 +622,11 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
 // LDS: the table and nothing else — k1b_ht * 40 bytes; with 2048 slots that is exactly half of a CU's 160 KiB, so two
 // 512-thread workgroups share a CU and one's (latency-bound) header round trip and compaction overlap the other's
 // (LDS-atomic-bound) merge.  The last key slot is never used as a slot: its 8 bytes hold the two workgroup counters.
+// NSG: scalar-register cap.  72 when a CU gets several partitions (above 80 SGPRs a CU holds ONE 1024-thread workgroup, below it
+// two, tools/occupancy_probe.hip); uncapped (k1b_merge_wide: no scalar spills) when every CU has at most one partition anyway
+// (C2: 15.4 vs 16.8 us).
 template <int K1B_U, bool HIST>   // K1B_U: single records a lane has in flight; HIST: per-edge latency histogram (f-3)
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_merge(Dev d) {
+__device__ __forceinline__ void k1b_body(const Dev& d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 HT = d.k1b_ht, hmask = HT - 1;
     u64* hkey = reinterpret_cast<u64*>(smem);                       // [HT]  (slot HT-1: n_drop, out_n)
@@ -777,6 +780,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b
         }
     }
 }
+
+template <int K1B_U, bool HIST> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_merge(Dev d) { k1b_body<K1B_U, HIST>(d); }
+template <int K1B_U, bool HIST> __global__ __launch_bounds__(1024) void k1b_merge_wide(Dev d) { k1b_body<K1B_U, HIST>(d); }
 
 // ------------------------------------------------------------------------------------------------
 // K2  csr_build: canonical node numbering, CSR with sorted rows.

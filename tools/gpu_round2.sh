@@ -28,3 +28,7 @@ for c in "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLI
 done
 python "$GRAFT_REPO_ROOT/tools/pmc_summary.py" "$GRAFT_REPO_ROOT/gpurun_out/pmcq_1" "$GRAFT_REPO_ROOT/gpurun_out/pmcq_2" | grep -E "k1a|k1b|==" > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_k1_sq_counters_c3.txt"
 cat "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_k1_sq_counters_c3.txt"
+# config 5 as a stream of raw records (nominal rate, then as fast as the host side can offer)
+cd "$GRAFT_REPO_ROOT"
+timeout 300 python tools/c5_stream.py > gpurun_out/${TAG}_c5_stream_5M.json 2> gpurun_out/${TAG}_c5_stream_5M.err; cut -c1-900 gpurun_out/${TAG}_c5_stream_5M.json
+timeout 300 python tools/c5_stream.py --rate 3e7 --windows 5 --feeders 16 > gpurun_out/${TAG}_c5_stream_max.json 2> gpurun_out/${TAG}_c5_stream_max.err; cut -c1-900 gpurun_out/${TAG}_c5_stream_max.json
