@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 2u   /* 2: sg_edge_out carries p50_us / p99_us, sg_config.flags, sg_window_hist */
+#define SG_ABI_VERSION 2u   /* 2: sg_edge_out carries p50_us / p99_us, sg_config.flags, sg_window_hist; sg_flush_window_view was added
+                               later without a bump (a new symbol: a binding may dlsym it and fall back to sg_flush_window) */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define SG_OK        0
