@@ -593,6 +593,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.P, (size_t)w.ncap * SG_F_HID)); LR(dev_alloc(e, &w.Q, (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.nmean, (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.efeat, ME * SG_F_EDGE)); LR(dev_alloc(e, &w.latz, ME)); LR(dev_alloc(e, &w.errr, ME));
+        LR(dev_alloc(e, &w.row_mu, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.row_sd, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.rows, ME));
         LR(dev_alloc(e, &w.in_part, (size_t)e->k3_ranges * e->k3_slices * K3_IN_NR * 6));
         LR(dev_alloc(e, &w.alive_keys, w.alive_cap)); LR(dev_alloc(e, &w.alive_csr, ME));
@@ -608,6 +609,13 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CR(alloc_window(d, e->d_ob_list, e->d_ob_n));
     CR(dev_alloc(e, &e->d_W, weights_count(cfg->layers)));
     d.W = e->d_W;
+    {   // (float)log1p((double)i) for small integer counts, by the device's own log1p
+        float* tab = nullptr;
+        CR(dev_alloc(e, &tab, (size_t)SG_L1P_TAB));
+        hipLaunchKernelGGL(k_l1p_table, dim3((SG_L1P_TAB + 255) / 256), dim3(256), 0, e->stream, tab);
+        CH(hipStreamSynchronize(e->stream));
+        d.l1p_tab = tab;
+    }
     for (int i = 0; i < kStageSlots; i++) {
         CH(hipHostMalloc((void**)&e->h_stage[i], (size_t)e->cfg.max_batch * sizeof(sg_event)));
         CR(dev_alloc(e, &e->d_stage[i], e->cfg.max_batch));

@@ -81,6 +81,7 @@ enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, 
 #define K2_RP_ROWS 256           // rows per workgroup of k2_rowptr (a multiple of 128; 1024 threads: 8 lanes per row, 2 passes)
 
 // phase stamps for kernel tuning (off unless SG_ABLATE & 0x100): 100 MHz wall clock, thread 0 of a workgroup
+#define SG_L1P_TAB 4096u
 #define SG_STAMP(d, kid, k) do { if (((d).ablate & 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096) (d).dbg[((size_t)(kid) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
 
 // Everything the kernels need, passed by value as one kernel argument.
@@ -148,6 +149,8 @@ struct Dev {
     float* h[SG_MAX_LAYERS + 1];              // h[l] = output of layer l (l>=1): [ncap][64]
     float* P; float* Q;                       // [ncap][64]
     float* nmean;                             // [ncap][64] neighbour means of the layer being computed (k4_gather -> k4_sage_layer)
+    double* row_mu; double* row_sd;           // [ncap] mean / std (us) of a source's out-events: written by the row sort, read once per edge by edge_features
+    const float* l1p_tab;                     // [SG_L1P_TAB] (float)log1p((double)i), filled on the device at create: small counts skip the fp64 log1p
     float* efeat;                             // [max_edges][8]
     float* latz; float* errr;                 // [max_edges]
     sg_edge_out* rows;                        // [max_edges]

@@ -1086,22 +1086,25 @@ __device__ __forceinline__ void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row
         d.ekeys[slot] = SG_EKEY_EMPTY;
     }
 }
+// (float)log1p((double)c) for an integer count: from the table the device itself filled with the same expression (bit-identical
+// by construction), the fp64 log1p only beyond it
+__global__ void k_l1p_table(float* tab) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < SG_L1P_TAB) tab[i] = (float)log1p((double)i); }
+__device__ __forceinline__ float log1p_count(const Dev& d, u64 c) { return c < SG_L1P_TAB ? d.l1p_tab[c] : (float)log1p((double)c); }
 // e_uv, lat_z, err_ratio of edge `pos` from its accumulators and its row's out-statistics
 __device__ __forceinline__ void edge_features(const Dev& d, u32 pos) {
     const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)pos * 4);
     const ulonglong2 x = a[0], y = a[1];
-    const u64* rs = d.st_sum + (size_t)d.csr_from[pos] * SG_NODE_STAT_SUM_WORDS;
-    const u64 r_cnt = rs[ST_OUT_CNT], r_sum = rs[ST_OUT_SUM], r_ssq = rs[ST_OUT_SSQ];
+    const u32 from = d.csr_from[pos];
     const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
     const double m_e = mean_us(sum, cnt), s_e = std_us(sum, ssq, cnt);
-    const double mu = mean_us(r_sum, r_cnt), sd = std_us(r_sum, r_ssq, r_cnt);
+    const double mu = d.row_mu[from], sd = d.row_sd[from];           // mean_us / std_us of the row's out-statistics: computed once per row by the row sort
     const double z = (m_e - mu) / (sd > 1.0 ? sd : 1.0);
     const float lat_z = (float)z;
     const float err_ratio = cnt ? (float)((double)err / (double)cnt) : 0.0f;
     const float zc = lat_z < -8.0f ? -8.0f : (lat_z > 8.0f ? 8.0f : lat_z);
     float4* e = reinterpret_cast<float4*>(d.efeat + (size_t)pos * SG_F_EDGE);
-    e[0] = make_float4((float)log1p((double)cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
-    e[1] = make_float4(err_ratio, (float)log1p((double)err), zc * 0.125f, 1.0f);
+    e[0] = make_float4(log1p_count(d, cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
+    e[1] = make_float4(err_ratio, log1p_count(d, err), zc * 0.125f, 1.0f);
     d.latz[pos] = lat_z; d.errr[pos] = err_ratio;
 }
 
@@ -1291,6 +1294,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                 u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
                 t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
                 d.st_max[(size_t)rr * 2] = mx;
+                d.row_mu[rr] = mean_us(sum, cnt); d.row_sd[rr] = std_us(sum, ssq, cnt);
             }
             __syncthreads();
         }
@@ -1314,6 +1318,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
             u64* t = d.st_sum + (size_t)r * SG_NODE_STAT_SUM_WORDS;
             t[ST_OUT_DEG] = n; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
             d.st_max[(size_t)r * 2] = mx;
+            d.row_mu[r] = mean_us(sum, cnt); d.row_sd[r] = std_us(sum, ssq, cnt);
         }
         if (lane < n) edge_emit(ea, beg + rank, r, v, cnt, sum, ssq, x, y);
     }
