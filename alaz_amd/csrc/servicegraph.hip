@@ -583,7 +583,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.e_slot, ME)); LR(dev_alloc(e, &w.e_from, eslots)); LR(dev_alloc(e, &w.e_to, eslots));
         LR(dev_alloc(e, &w.longrows, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS) / K2_RP_ROWS + 1)); LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
-        LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cslot, ME)); LR(dev_alloc(e, &w.csr_from, ME));
+        LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cs, ME)); LR(dev_alloc(e, &w.csr_from, ME));
         LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));
         if (w.hist) { LR(dev_alloc(e, &w.hist_src, (w.variant == 0 ? (size_t)w.np * w.pcap : (size_t)e->ecap) * SG_HIST_BINS)); LR(dev_alloc(e, &w.hist_csr, ME * SG_HIST_BINS)); }

@@ -140,7 +140,8 @@ struct Dev {
     u32* tile_cnt;  u32* tile_off;            // compaction scratch
     u32* e_slot;    u32* e_from;  u32* e_to;  // [max_edges] compacted (table order)
     u32* deg;       u32* rowptr;  u32* cursor;// [ncap+1]
-    u32* col;       u32* cslot;               // [max_edges] CSR order: destination, table slot
+    u32* col;                                 // [max_edges] CSR order: destination (written by the row sort, sorted inside every row)
+    uint2* cs;                                // [max_edges] {destination, table slot} in row order, unsorted: ONE 8-byte scattered write per edge (scatter -> row sort)
     u32* csr_from;                            // [max_edges] CSR order: source (row id per edge)
     u32* sort_k;    u32* sort_v;              // [2*max_edges] scratch for rows longer than the LDS sort
     u64* acc_csr;                             // [max_edges][4]

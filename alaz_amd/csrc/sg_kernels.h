@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void k2_scatter_table(Dev d) {
             continue;
         }
         const u32 pos = d.rowptr[f] + atomicAdd(&d.cursor[f], 1u);
-        d.col[pos] = d.e_to[i]; d.cslot[pos] = d.e_slot[i];
+        d.cs[pos] = make_uint2(d.e_to[i], d.e_slot[i]);
     }
 }
 __global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
         const u32 slot = p * d.pcap + i;
         const u32 f = d.e_from[slot];
         const u64 pos = (u64)d.rowptr[f] + d.deg[SG_DEG_IDX(f, p & (SG_DEG_REP - 1))] + d.e_rank[slot];   // row + replica offset + arrival order
-        if (pos < d.max_edges) { d.col[pos] = d.e_to[slot]; d.cslot[pos] = slot; }
+        if (pos < d.max_edges) d.cs[pos] = make_uint2(d.e_to[slot], slot);     // (one scattered 8-byte write: the cost is per write request, not per byte)
     }
 }
 
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
             u32 m = d.rowptr[rr + 1] - b;
             if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
             if (m == 0) continue;
-            u32* key = d.col + b; u32* val = d.cslot + b;
+            const uint2* in = d.cs + b; u32* key = d.col + b;              // in: {destination, slot} as scattered; key: the row's sorted destinations (output only)
             u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
             if (BW <= K2_SORT_LDS && m <= 1024) {
                 // The common long row (65..1024 edges): bitmap rank as below, but every thread keeps its (<= 4) elements
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const u32 i = threadIdx.x + q * 256;
-                    mk[q] = i < m ? key[i] : 0u; mv[q] = i < m ? val[i] : 0u;
+                    const uint2 kv = in[i < m ? i : m - 1]; mk[q] = i < m ? kv.x : 0u; mv[q] = i < m ? kv.y : 0u;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) {
                     const u32 k = mk[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
-                    key[r] = k;                                           // every key of the row was read before the barriers
+                    key[r] = k;
                     edge_emit(ea, b + r, rr, mv[q], 0, 0, 0, ax[q], ay[q]);
                 }
                 cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                 for (u32 i0 = 0; i0 < m; i0 += 1024) {
                     u32 k4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; k4[q] = key[i < m ? i : m - 1]; }
+                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; k4[q] = in[i < m ? i : m - 1].x; }
 #pragma unroll
                     for (int q = 0; q < 4; q++) if (i0 + threadIdx.x + q * 256 < m) atomicOr(&sk[k4[q] >> 5], 1u << (k4[q] & 31));
                 }
@@ -1196,46 +1196,35 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                     for (u32 w = w0; w < w1; w++) { sv[w] = run; run += __popc(sk[w]); }
                 }
                 __syncthreads();
-                u32* gk = d.sort_k + 2 * (size_t)b; u32* gv = d.sort_v + 2 * (size_t)b;     // the row's private slice of the scratch
-                for (u32 i0 = 0; i0 < m; i0 += 1024) {               // rank -> scratch; the row totals from the same elements' accumulators
+                for (u32 i0 = 0; i0 < m; i0 += 1024) {               // rank -> CSR position: destination, accumulators; the row totals on the way
                     u32 k4[4], v4[4]; ulonglong2 x4[4], y4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256, c = i < m ? i : m - 1; k4[q] = key[c]; v4[q] = val[c]; }
+                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; const uint2 kv = in[i < m ? i : m - 1]; k4[q] = kv.x; v4[q] = kv.y; }
 #pragma unroll
                     for (int q = 0; q < 4; q++) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v4[q] * 4); x4[q] = a[0]; y4[q] = a[1]; }
 #pragma unroll
                     for (int q = 0; q < 4; q++) if (i0 + threadIdx.x + q * 256 < m) {
                         const u32 k = k4[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
-                        gk[r] = k; gv[r] = v4[q];
+                        key[r] = k;                                  // (input and output are different arrays: no scratch, no second pass)
+                        edge_emit(ea, b + r, rr, v4[q], 0, 0, 0, x4[q], y4[q]);
                         cnt += x4[q].x & 0xFFFFFFFFull; err += x4[q].x >> 32; sum += x4[q].y; ssq += y4[q].y; mx = y4[q].x > mx ? y4[q].x : mx;
                     }
                 }
-                __threadfence_block();
-                __syncthreads();
                 cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
                 if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
                 __syncthreads();
                 cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
                 sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
                 mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-                for (u32 i0 = 0; i0 < m; i0 += 1024) {
-                    u32 k4[4], v4[4]; ulonglong2 x4[4], y4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256, c = i < m ? i : m - 1; k4[q] = gk[c]; v4[q] = gv[c]; }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v4[q] * 4); x4[q] = a[0]; y4[q] = a[1]; }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; if (i < m) { key[i] = k4[q]; edge_emit(ea, b + i, rr, v4[q], cnt, sum, ssq, x4[q], y4[q]); } }
-                }
             } else if (m <= 1024) {
                 // rank sort: keys in LDS, every thread counts the smaller keys of its (<= 4) elements
-                for (u32 i = threadIdx.x; i < m; i += 256) sk[i] = key[i];
+                for (u32 i = threadIdx.x; i < m; i += 256) sk[i] = in[i].x;
                 __syncthreads();
                 u32 mk[4], mv[4], rk[4]; ulonglong2 ax[4], ay[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const u32 i = threadIdx.x + q * 256;
-                    mk[q] = i < m ? sk[i] : 0xFFFFFFFFu; mv[q] = i < m ? val[i] : 0u; rk[q] = 0;
+                    mk[q] = i < m ? sk[i] : 0xFFFFFFFFu; mv[q] = i < m ? in[i].y : 0u; rk[q] = 0;
                     if (i < m) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q] * 4); ax[q] = a[0]; ay[q] = a[1]; }
                     else { ax[q] = make_ulonglong2(0, 0); ay[q] = make_ulonglong2(0, 0); }
                 }
@@ -1258,7 +1247,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                 u32 np2 = 1; while (np2 < m) np2 <<= 1;
                 u32* gk = sk; u32* gv = sv;
                 if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
-                for (u32 i = threadIdx.x; i < np2; i += 256) { gk[i] = i < m ? key[i] : 0xFFFFFFFFu; gv[i] = i < m ? val[i] : 0; }
+                for (u32 i = threadIdx.x; i < np2; i += 256) { const uint2 kv = in[i < m ? i : m - 1]; gk[i] = i < m ? kv.x : 0xFFFFFFFFu; gv[i] = i < m ? kv.y : 0; }
                 __syncthreads();
                 for (u32 k = 2; k <= np2; k <<= 1)
                     for (u32 j = k >> 1; j > 0; j >>= 1) {
@@ -1307,7 +1296,8 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
         if (n == 0 || n > 64) continue;
         if ((u64)beg + n > d.max_edges) n = beg < d.max_edges ? (u32)(d.max_edges - beg) : 0;
         if (n == 0) continue;
-        const u32 k = lane < n ? d.col[beg + lane] : 0xFFFFFFFFu, v = lane < n ? d.cslot[beg + lane] : 0;
+        const uint2 kv = d.cs[beg + (lane < n ? lane : 0u)];
+        const u32 k = lane < n ? kv.x : 0xFFFFFFFFu, v = lane < n ? kv.y : 0;
         u32 rank = 0;
         for (u32 j = 0; j < n; j++) rank += rdlane32(k, (int)j) < k;   // j uniform: v_readlane
         ulonglong2 x = make_ulonglong2(0, 0), y = make_ulonglong2(0, 0);
