@@ -409,3 +409,17 @@ def test_process_exit_forgets_the_prepared_statements_of_the_pid():
     assert pk.pg_statements() == 4
     pk.proc_exit(12)                                                   # HasPrefix("12"): pid 12 and pid 120
     assert pk.pg_statements() == 1
+
+
+def test_streaming_harness_runs_on_the_recording_engine():
+    """tools/c5_stream.py (feeder threads -> C++ GraphDS::IngestWire, a dispatcher closing windows) with the recording
+    stand-in and a small cluster: the harness itself must work without a GPU — everything offered is accounted for."""
+    import json, os, subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "c5_stream.py")
+    out = subprocess.run([sys.executable, tool, "--mock", "--pods", "200", "--ring", "4096", "--rate", "1e5", "--windows", "2",
+                          "--feeders", "3", "--window-s", "0.25", "--chunk", "256"], capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert lines, out.stderr[-1500:]
+    r = json.loads(lines[-1])
+    assert r["windows"] == 2 and r["host_batches_dropped"] == 0 and r["engine_errors"] == 0 and r["ingest_rc_nonzero"] == 0
+    assert 0.8e5 < r["offered_events_per_s"] < 1.3e5 and r["labels"] > 0

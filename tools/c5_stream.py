@@ -19,7 +19,11 @@ import numpy as np
 from alaz_amd import replay, weights
 
 
-def load_or_make(ring: int):
+def load_or_make(ring: int, pods: int = 0, edges: int = 0):
+    if pods:                                                         # a small cluster instead of C5's (harness smoke tests): never cached
+        topo = replay.make_topology(pods, edges or pods * 20, replay.SEED_BASE + 5)
+        ev, labels = replay.make_events(topo, ring, replay.SEED_BASE + 5, mixed=True)
+        return ev, labels, topo.pod_ips, topo.svc_ips
     cache = os.environ.get("SG_C5_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "c5_stream_cache.npz"))
     if os.path.exists(cache):
         z = np.load(cache, allow_pickle=False)
@@ -42,15 +46,18 @@ def main():
     ap.add_argument("--window-s", type=float, default=1.0); ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--make-cache-only", action="store_true")
     ap.add_argument("--mock", action="store_true", help="recording stand-in instead of the engine (CPU smoke test of this harness only)")
+    ap.add_argument("--pods", type=int, default=0, help="a small synthetic cluster of this many pods instead of config 5's 100 k (smoke tests)")
+    ap.add_argument("--edges", type=int, default=0)
     a = ap.parse_args()
-    ev, labels, pod_ips, svc_ips = load_or_make(a.ring)
+    ev, labels, pod_ips, svc_ips = load_or_make(a.ring, a.pods, a.edges)
     if a.make_cache_only:
         print("cache ready:", len(ev), "records,", len(pod_ips), "pods,", len(svc_ips), "services"); return
     from alaz_amd import engine, hostlib
     c = replay.CONFIGS[5]
     wire = np.frombuffer(replay.to_wire(ev, labels), dtype=np.uint8).copy()
     n_nodes = len(pod_ips) + len(svc_ips)
-    cfg = engine.SgConfig(engine.ABI_VERSION, 0, n_nodes + 1024, 256, 256, n_nodes + 1024, int(c["edges"] * 1.1), 1 << 18, c["layers"], 0, 1, 0,
+    max_edges = int(c["edges"] * 1.1) if not a.pods else max(1 << 16, 4 * (a.edges or a.pods * 20))
+    cfg = engine.SgConfig(engine.ABI_VERSION, 0, n_nodes + 1024, 256, 256, n_nodes + 1024, max_edges, 1 << 18, c["layers"], 0, 1, 0,
                           int(a.rate * a.window_s * 1.5), 3, 0, 0)
     t0 = time.perf_counter()
     g = hostlib.GraphDS(cfg, batch=a.chunk, **({"engine_lib": None} if a.mock else {}))
@@ -99,7 +106,7 @@ def main():
     st = engine.SgStats()
     if not a.mock: engine.load_library().sg_stats_get(g.engine_handle, C.byref(st))
     ctr = g.counters()
-    res = {"workload": f"C5 streaming: {len(pod_ips)} pods / {len(svc_ips)} services, raw 1096-B l7_event records (70/15/15 HTTP/Kafka/Postgres) from a {nrec}-record ring, "
+    res = {"workload": f"{'C5' if not a.pods else 'small-cluster'} streaming: {len(pod_ips)} pods / {len(svc_ips)} services, raw 1096-B l7_event records (70/15/15 HTTP/Kafka/Postgres) from a {nrec}-record ring, "
                        f"{a.feeders} feeder threads -> C++ GraphDS::IngestWire -> sg_ingest; one window per {a.window_s:g} s closed by a dispatcher thread",
            "target_events_per_s": a.rate, "offered_events_per_s": sum(fed) / dt, "windows": a.windows,
            "engine_events_in": int(st.events_in), "engine_events_per_s": int(st.events_in) / dt,
