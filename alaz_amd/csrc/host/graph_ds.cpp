@@ -238,6 +238,9 @@ long GraphDS::FlushWindow(int64_t window_end_ms) {
     if (api_.flush_window_view) rc = api_.flush_window_view(h_, (uint64_t)window_end_ms, &rows, &n);     // rows stay valid: flush_mu_ is held
     else { own.resize(max_edges_); rc = api_.flush_window(h_, (uint64_t)window_end_ms, own.data(), own.size(), &n); rows = own.data(); n = std::min(n, own.size()); }
     if (rc != SG_OK) return rc;
+    // the label table again, AFTER the window has closed: a feeder may have interned a label and pushed its event into this
+    // window between the first snapshot and the close (labels are append-only, so the later snapshot is a superset)
+    { std::lock_guard<std::mutex> g(pk_mu_); if (packer_.Labels().size() != labels.size()) labels = packer_.Labels(); }
     {
         size_t no = 0;
         api_.window_outbound_ips(h_, nullptr, 0, &no);

@@ -141,11 +141,22 @@ public:
             for (auto& kv : svc_ip) if (!pod_ip.count(kv.first)) pop[kv.first >> 8]++;
             std::vector<std::pair<u32, u32>> order;                 // (population, block number)
             order.reserve(pop.size());
-            for (auto& kv : pop) if (kv.second >= kMinBlockPop) order.push_back({kv.second, kv.first});
+            for (auto& kv : pop) order.push_back({kv.second, kv.first});   // (singleton /24s too: the incremental path gives them blocks
+                                                                           // as well, and a rebuild that cannot use the free blocks would be
+                                                                           // triggered again and again by the stale-assignment rule)
             std::sort(order.begin(), order.end(), [](const std::pair<u32, u32>& a, const std::pair<u32, u32>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
             const u32 take = (u32)std::min<size_t>(order.size(), L.max_blocks - 1);
             l1_entries = std::min<u32>(L.l1_cap, next_pow2_u32(std::max<u64>((u64)4 * (take + take / 4 + 8), 16)));   // load <= 0.25 with room to grow
-            for (u32 i = 0; i < take; i++) if (!alloc_block(order[i].second)) break;
+            for (;;) {
+                bool placed = true;
+                for (u32 i = 0; i < take && placed; i++) placed = alloc_block(order[i].second);
+                if (placed || l1_entries >= L.l1_cap) break;        // (at the cap the /24s that found no slot stay in the cuckoo table)
+                // an insert walked 512 kicks at load <= 1/3: start over with twice the slots
+                const u32 grown = l1_entries * 2;
+                std::memset(blob + L.off_l1, 0xFF, (size_t)L.l1_cap * 8);
+                for (u32 i = 0; i < L.l1_cap; i++) blob[L.off_l1 + 2 * i + 1] = 0;
+                blk_of_.clear(); blocks_used = 1; l1_entries = grown;
+            }
         }
         bool ok = true;
         for (auto& kv : pod_ip) ok &= place_fresh(kv.first);
@@ -157,7 +168,6 @@ public:
     u32 blocks_bytes() const { return blocks_used * 1024u; }
 
 private:
-    static constexpr u32 kMinBlockPop = 2;
     std::vector<uint8_t> kinds_;
     std::unordered_map<u32, u32> blk_of_;        // block number -> level-2 block index (>= 1)
     std::unordered_map<u32, u32> ck_pop_;        // block number -> IPs of it in the cuckoo table
@@ -233,24 +243,32 @@ private:
     }
 
     // ---- block table ----------------------------------------------------------------------------------------------
+    // Insert {b -> blk} into level 1 (2-choice, one entry per slot, random-walk eviction).  TRANSACTIONAL: when the walk does
+    // not end within the kick budget every slot it touched is put back, so a failure costs nothing but the block (the caller
+    // keeps the /24 in the cuckoo table) — it used to drop the last evicted, live /24 and leave a dangling entry behind.
     bool l1_put(u32 b, u32 blk) {
         const u32 mask = l1_entries - 1;
         u64 cur = (u64)b | ((u64)blk << 32);
         u32 rng = sg_fmix32(b) | 1u, avoid = 0xFFFFFFFFu;
+        std::vector<std::pair<u32, u64>> undo;                       // (slot, what it held) in write order
         for (int kick = 0; kick < 512; kick++) {
             const u32 s1 = jl1_h1((u32)cur, mask), s2 = jl1_h2((u32)cur, mask);
             for (u32 s : {s1, s2}) if (blob[L.off_l1 + 2 * s] == (u32)cur) { wr64(L.off_l1 + 2 * s, cur); return true; }
             for (u32 s : {s1, s2}) if (blob[L.off_l1 + 2 * s] == SG_JL1_EMPTY) { wr64(L.off_l1 + 2 * s, cur); return true; }
             rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;
             const u32 s = (s1 == avoid) ? s2 : (s2 == avoid ? s1 : ((rng & 1u) ? s2 : s1));
-            const u64 ev = rd64(L.off_l1 + 2 * s); wr64(L.off_l1 + 2 * s, cur); cur = ev;
+            const u64 ev = rd64(L.off_l1 + 2 * s);
+            undo.push_back({s, ev});
+            wr64(L.off_l1 + 2 * s, cur); cur = ev;
             avoid = s;
         }
+        for (size_t i = undo.size(); i-- > 0;) wr64(L.off_l1 + 2 * undo[i].first, undo[i].second);
         return false;
     }
     bool alloc_block(u32 b) {
         if (blocks_used >= L.max_blocks) return false;
-        if ((u64)4 * (blk_of_.size() + 1) > (u64)2 * l1_entries) return false;     // level 1 beyond load 0.5: grows at the next rebuild
+        if ((u64)3 * (blk_of_.size() + 1) > (u64)l1_entries) return false;         // level 1 beyond load 1/3 (2-choice single-slot cuckoo
+                                                                                   // gives out at 1/2): grows at the next rebuild
         if (!l1_put(b, blocks_used)) return false;
         blk_of_[b] = blocks_used++;
         return true;

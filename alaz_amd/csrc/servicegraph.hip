@@ -60,7 +60,7 @@ struct sg_engine {
     // staging ring for sg_ingest()
     sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
     int stage_next = 0;
-    sg_edge_out* h_rows = nullptr; size_t h_rows_cap = 0;              // page-locked destination of sg_flush_window_view (grown on demand)
+    sg_edge_out* h_rows = nullptr; sg_edge_out* h_rows_old = nullptr; size_t h_rows_cap = 0;              // page-locked destination of sg_flush_window_view (grown on demand)
     bool stage_busy[kStageSlots] = {};                                   // a feeder thread is copying into the slot (outside the lock)
     int pending_copies = 0; std::condition_variable cv;                 // window closes wait for the copies that began before them
 
@@ -134,18 +134,39 @@ struct Timed {
 // ---- join tables on the device: the host mirror's changes since the last launch, in stream order ------------------
 // (processPod / processSvc analogue: aggregator/persist.go:55-71, 114-130 — one map write there, a few words here)
 
-// pass-A geometry that follows the table state: does level 2 fit LDS beside the edge cache?
-void k1a_geometry(sg_engine* e) {
+// pass-A geometry that follows the table state: does level 2 fit LDS beside the edge cache (and, narrow path, the tile)?
+// Returns false when no legal geometry exists (the caller fails the call with a message instead of launching a kernel that
+// asks for more than a CU's LDS).
+bool k1a_geometry(sg_engine* e) {
     const Dev& d = e->d;
-    const size_t l1b = (size_t)e->jt.l1_entries * 8, l2b = (size_t)e->jt.blocks_bytes(), fixed = (size_t)d.np * 4 + 64 + l1b;
-    const size_t slot = d.hist ? 72 : 40;                    // cache slot: key + 4 accumulators (+ 16 x u16 bins)
-    e->l2_in_lds = false; e->k1a_ct = 2048;
-    for (u32 ct : {2048u, 1024u, 512u}) {
-        if ((size_t)ct * slot + fixed + l2b <= kLdsBytes && (l1b + l2b) / 16 <= (size_t)K1A_NJ * K1A_THREADS) { e->l2_in_lds = true; e->k1a_ct = ct; break; }
+    const size_t l1b = (size_t)e->jt.l1_entries * 8, l2b = (size_t)e->jt.blocks_bytes();
+    const size_t stage_max = (size_t)K1A_NJ * K1A_THREADS * 16;    // what the prologue can stage: six 16-byte words per lane
+    e->l2_in_lds = false;
+    if (d.narrow) {
+        // cache | 5 counters per partition | statistics | tile | join tables
+        const size_t fixed = (size_t)d.np * 20 + 64 + (size_t)K1T_TS * 8 + l1b;
+        u32 ct = 0;
+        for (u32 c : {1024u, 512u, 256u, 128u}) if ((size_t)c * 40 + fixed + l2b <= kLdsBytes && l1b + l2b <= stage_max) { e->l2_in_lds = true; ct = c; break; }
+        if (!ct) for (u32 c : {1024u, 512u, 256u, 128u, 64u}) if ((size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
+        if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) ct = x; }
+        if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
+        if (!ct || l1b > stage_max) return false;
+        e->k1a_ct = ct;
+        e->k1a_lds = (size_t)ct * 40 + fixed + (e->l2_in_lds ? l2b : 0);
+        return true;
     }
-    if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * slot + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) e->k1a_ct = x; }
+    const size_t fixed = (size_t)d.np * 4 + 64 + l1b;
+    const size_t slot = d.hist ? 72 : 40;                    // cache slot: key + 4 accumulators (+ 16 x u16 bins)
+    u32 ct = 0;
+    for (u32 c : {2048u, 1024u, 512u}) if ((size_t)c * slot + fixed + l2b <= kLdsBytes && l1b + l2b <= stage_max) { e->l2_in_lds = true; ct = c; break; }
+    // level 2 stays in global memory: the largest cache that fits beside the counters and level 1
+    if (!ct) for (u32 c : {2048u, 1024u, 512u, 256u, 128u, 64u}) if ((size_t)c * slot + fixed <= kLdsBytes) { ct = c; break; }
+    if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * slot + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) ct = x; }
     if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
-    e->k1a_lds = (size_t)e->k1a_ct * slot + fixed + (e->l2_in_lds ? l2b : 0);
+    if (!ct || l1b > stage_max) return false;
+    e->k1a_ct = ct;
+    e->k1a_lds = (size_t)ct * slot + fixed + (e->l2_in_lds ? l2b : 0);
+    return true;
 }
 // the sizes a K1 launch needs from the table state (pointers are fixed at create)
 void join_view(const sg_engine* e, Dev& d) {
@@ -189,7 +210,7 @@ int sync_tables(sg_engine* e, hipStream_t s) {
     }
     HIP_TRY(e, hipEventRecord(e->tab_ev, s));
     e->tab_seq++; e->tab_stream = s;
-    k1a_geometry(e);
+    if (e->d.variant == 0 && !k1a_geometry(e)) { e->err = "K1 pass A: the join tables' level 1 and the piece counters do not fit a CU's LDS (fewer partitions / IP blocks needed)"; return SG_ENOSPC; }
     return SG_OK;
 }
 // K1 on stream s reads the tables: after the last modification if that ran on another stream
@@ -236,8 +257,14 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
         const bool sh = e->d.world > 1;
 #define K1A_GO(L2, SH, HI) hipExtLaunchKernelGGL((k1a_partition<L2, SH, HI>), dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
 #define K1A_GO2(L2, SH) do { if (e->d.hist) K1A_GO(L2, SH, true); else K1A_GO(L2, SH, false); } while (0)
-        if (e->l2_in_lds) { if (sh) K1A_GO2(true, true); else K1A_GO2(true, false); }
+#define K1T_GO(L2, SH) hipExtLaunchKernelGGL((k1a_tile_partition<L2, SH>), dim3(e->d.nwg), dim3(K1T_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
+        if (e->d.narrow) {
+            if (e->l2_in_lds) { if (sh) K1T_GO(true, true); else K1T_GO(true, false); }
+            else { if (sh) K1T_GO(false, true); else K1T_GO(false, false); }
+        }
+        else if (e->l2_in_lds) { if (sh) K1A_GO2(true, true); else K1A_GO2(true, false); }
         else { if (sh) K1A_GO2(false, true); else K1A_GO2(false, false); }
+#undef K1T_GO
 #undef K1A_GO2
 #undef K1A_GO
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 1; e->trecs.push_back(r); }
@@ -295,10 +322,14 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         const bool tk = (e->timing >> 7) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
-        const bool share = d.np > e->k1b_cus;                           // several partitions per CU: the SGPR-capped build lets two workgroups share a CU
+        const bool share = d.np > e->k1b_cus && 2 * e->k1b_lds <= kLdsBytes;   // several partitions per CU and room for two tables: the SGPR-capped build lets two workgroups share a CU
 #define K1B_GO(U_, H_) do { if (share) hipExtLaunchKernelGGL((k1b_merge<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
                             else hipExtLaunchKernelGGL((k1b_merge_wide<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
-        if (d.hist) K1B_GO(4, true); else if (e->k1b_u == 8) K1B_GO(8, false); else K1B_GO(4, false);
+#define K1B8_GO(U_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
+                         else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
+        if (d.narrow) { if (e->k1b_u == 8) K1B8_GO(8); else K1B8_GO(4); }
+        else if (d.hist) K1B_GO(4, true); else if (e->k1b_u == 8) K1B_GO(8, false); else K1B_GO(4, false);
+#undef K1B8_GO
 #undef K1B_GO
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
     }
@@ -399,7 +430,10 @@ int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n, const sg_edge
     if (n) *n = E;
     if (view) {
         if (E > e->h_rows_cap) {
-            if (e->h_rows) { hipHostFree(e->h_rows); e->h_rows = nullptr; e->h_rows_cap = 0; }
+            // the buffer the previous view pointed into stays alive for one more generation: a caller that still holds the
+            // last view (a numpy array over it, a Go slice) reads stale rows, not freed memory
+            if (e->h_rows_old) { hipHostFree(e->h_rows_old); e->h_rows_old = nullptr; }
+            e->h_rows_old = e->h_rows; e->h_rows = nullptr; e->h_rows_cap = 0;
             const size_t want = std::min<size_t>(next_pow2(std::max<size_t>(E, 1024)), std::max<size_t>(e->cfg.max_edges, E));
             HIP_TRY(e, hipHostMalloc((void**)&e->h_rows, want * sizeof(sg_edge_out)));
             e->h_rows_cap = want;
@@ -447,6 +481,13 @@ const char* sg_last_error(sg_handle h) { return h ? h->err.c_str() : "null handl
 int sg_create(const sg_config* cfg, sg_handle* out) {
     if (!cfg || !out) return SG_EINVAL;
     *out = nullptr;
+    // ABI 3: the caller states how much of sg_config it knows about; the rest is zero
+    constexpr uint32_t kCfgMin = 88;                                 // sizeof(sg_config) when struct_size was introduced
+    if (cfg->struct_size < kCfgMin || cfg->struct_size > 4096) return SG_EINVAL;
+    sg_config full; std::memset(&full, 0, sizeof full);
+    std::memcpy(&full, cfg, std::min<size_t>(cfg->struct_size, sizeof full));
+    full.struct_size = (uint32_t)sizeof full;
+    cfg = &full;
     if (cfg->abi_version != SG_ABI_VERSION || cfg->layers < 1 || cfg->layers > SG_MAX_LAYERS || cfg->max_edges == 0 ||
         cfg->max_known_nodes == 0 || cfg->world == 0 || cfg->rank >= cfg->world || cfg->max_known_nodes > 0x3FFFFFFFu)
         return SG_EINVAL;
@@ -486,29 +527,62 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     d.hist = (cfg->flags & SG_CFG_EDGE_HISTOGRAM) ? 1u : 0u;
     d.agg_slots = d.hist ? 5u : 3u;
     {
-        // partitions: at most ~1250 distinct edges each at the configured capacity (pass B's LDS table: 2048 slots, 1536 may
-        // fill; 1024 slots for small graphs), at least one per CU.  Fewer, larger partitions keep pass A's open lines per
-        // XCD (partitions x 32 workgroups) near the L2's size: C3 with 1024 partitions 181 us, 2048: 198 us, 4096: 292 us.
-        u64 np = next_pow2(std::max<u64>((ME + 1249) / 1250, 256));
-        if (np > 4096) np = 4096;
-        if (cfg->k1_variant == 0 && ME > (u64)4096 * 1400) d.variant = 1;   // beyond the partitioned path's range
-        d.k1b_ht = ME / np > 600 ? 2048 : 1024;
-        if (d.hist && d.k1b_ht == 2048) { d.k1b_ht = 1024; np = std::min<u64>(4096, np * 2); }   // 16 x u32 bins per slot: 104 bytes, half the slots, twice the partitions
+        // Narrow-record K1 (default): an endpoint is a compact index below 2^nb — KNOWN ids, then LABEL ids, then slots of the
+        // outbound-IP table — and the mixed pair's top bits are the partition (sg_hash.h sg_kmix); it needs the in-partition
+        // remainder of the key to fit 31 bits.  k1_variant 2 (or SG_K1_LEGACY) keeps the 16-byte-record kernels, which also
+        // carry the per-edge histogram.
+        const u64 cn = (u64)cfg->max_known_nodes + cfg->max_labels + e->obcap;
+        u32 nb = 12; while ((1ull << nb) < cn && nb < 31) nb++;
+        bool narrow = d.variant == 0 && !d.hist && cfg->k1_variant != 2 && !std::getenv("SG_K1_LEGACY") && nb <= 24;
+        u64 np = 0;
+        if (narrow) {
+            // partitions: ~2700 distinct edges each at the configured capacity at most (pass B's LDS table: 4096 slots of 36
+            // bytes, 3072 may fill), at least 256.  Fewer partitions = longer runs per tile in pass A.
+            np = next_pow2(std::max<u64>((ME + 2699) / 2700, 256));
+            u32 pbt = 0; while ((1ull << pbt) < np) pbt++;
+            if (np > 2048 || 2 * nb - pbt > 31) narrow = false;          // (one wave scans the run lengths: beyond this the 16-byte kernels / variant 1)
+        }
+        if (narrow) {
+            d.k1b_ht = ME / np > 1150 ? 4096 : (ME / np > 550 ? 2048 : 1024);
+        } else {
+            // 16-byte records: at most ~1250 distinct edges per partition (pass B's LDS table: 2048 slots, 1536 may fill; 1024 slots
+            // for small graphs), at least one per CU.  C3 with 1024 partitions 181 us, 2048: 198 us, 4096: 292 us.
+            np = next_pow2(std::max<u64>((ME + 1249) / 1250, 256));
+            if (np > 4096) np = 4096;
+            if (cfg->k1_variant != 1 && ME > (u64)4096 * 1400) d.variant = 1;   // beyond the partitioned path's range
+            d.k1b_ht = ME / np > 600 ? 2048 : 1024;
+            if (d.hist && d.k1b_ht == 2048) { d.k1b_ht = 1024; np = std::min<u64>(4096, np * 2); }   // 16 x u32 bins per slot: 104 bytes, half the slots, twice the partitions
+        }
         d.np = (u32)np; d.nwg = 256;
-        // tuning overrides (tools/gpu_probe_sweep.sh); anything that is not a legal geometry is ignored
-        if (const char* v = std::getenv("SG_NP")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 64 && x <= 4096 && (x & (x - 1)) == 0) d.np = (u32)x; }
-        if (const char* v = std::getenv("SG_HT")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 256 && x <= 2048 && (x & (x - 1)) == 0) d.k1b_ht = (u32)x; }
+        // tuning overrides (tools/k1_sweep.py); anything that is not a legal geometry is ignored
+        if (const char* v = std::getenv("SG_NP")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 64 && x <= (narrow ? 2048u : 4096u) && (x & (x - 1)) == 0) d.np = (u32)x; }
+        if (const char* v = std::getenv("SG_HT")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 256 && x <= (narrow ? 4096u : 2048u) && (x & (x - 1)) == 0) d.k1b_ht = (u32)x; }
         if (const char* v = std::getenv("SG_NWG")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= (u64)SG_MAX_K1_WGS) d.nwg = (u32)x; }
+        d.pb = 0; while ((1u << d.pb) < d.np) d.pb++;
+        if (narrow && 2 * nb - d.pb > 31) { d.np = (u32)np; d.pb = 0; while ((1u << d.pb) < d.np) d.pb++; }   // an SG_NP override that would not leave 31 remainder bits
+        d.narrow = (narrow && d.variant == 0) ? 1u : 0u;
+        d.nb = nb; d.rb = 2 * nb - d.pb;
         d.pcap = d.k1b_ht * 3 / 4;
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
-        d.ss = (u32)(2.0 * m + 8.0 * std::sqrt(m + 1.0) + 24.0);          // a hot key the cache missed lands in ONE piece: head room, then the overflow list
         d.sa = std::min<u32>(24, std::max<u32>(8, (2 * 2048 / d.np + 6 + 1) & ~1u));   // aggregates per piece: cache slots / partitions, with head room
-        d.ss = (d.ss + d.agg_slots * d.sa + 7) / 8 * 8 - d.agg_slots * d.sa;   // a piece = whole 128-byte lines
-        d.ss = std::min<u32>(d.ss, (1u << 20) - 8);
-        d.pslots = d.ss + d.agg_slots * d.sa;
+        if (d.narrow) {
+            // a hot key the cache missed lands in ONE piece: twice the mean + 8 sigma + 24 records, then the overflow list
+            d.sn = ((u32)(2.0 * m + 8.0 * std::sqrt(m + 1.0) + 24.0) + 1u) & ~1u;
+            d.sn = std::min<u32>(d.sn, (1u << 20) - 16);
+            d.sw = std::min<u32>(64, std::max<u32>(8, d.sn / 8));
+            d.punits = (d.sn + 2 * d.sw + 5 * d.sa + 15) / 16 * 16;     // a piece = whole 128-byte lines; the slack goes to the narrow region
+            d.sn = d.punits - 2 * d.sw - 5 * d.sa;
+            d.ss = 0; d.pslots = 0;
+        } else {
+            d.ss = (u32)(2.0 * m + 8.0 * std::sqrt(m + 1.0) + 24.0);          // a hot key the cache missed lands in ONE piece: head room, then the overflow list
+            d.ss = (d.ss + d.agg_slots * d.sa + 7) / 8 * 8 - d.agg_slots * d.sa;   // a piece = whole 128-byte lines
+            d.ss = std::min<u32>(d.ss, (1u << 20) - 8);
+            d.pslots = d.ss + d.agg_slots * d.sa;
+        }
         d.ovf_cap = 1u << 16;
         e->k1b_threads = 1024u;                                          // measured: 1024 threads beat 2 x 512 (C3 135 vs 153 us, C2 15.5 vs 22.9 us)
-        if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; }
+        if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; if (std::atoi(v) == 4) e->k1b_u = 4; }
+        else if (d.narrow && m > 24.0) e->k1b_u = 8;                     // 8 x 16 bytes per lane in flight = 64 records per piece and round
         if (const char* v = std::getenv("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if (x == 256 || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
     }
     // join tables: word image (join_host.hpp) on the host, one device copy, a pinned ring for word updates
@@ -534,15 +608,19 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         d.kind = reinterpret_cast<const uint8_t*>(e->d_blob + L.off_kind);
     }
     if (d.variant == 0) {
-        k1a_geometry(e);
-        e->k1b_lds = (size_t)d.k1b_ht * (8 + 32 + (d.hist ? 4 * SG_HIST_BINS : 0));
+        if (!k1a_geometry(e)) { e->err = "K1 pass A: piece counters and join level 1 do not fit a CU's LDS"; return fail(SG_ENOSPC); }
+        e->k1b_lds = d.narrow ? ((size_t)d.k1b_ht * 36 + 8 + 15) / 16 * 16 : (size_t)d.k1b_ht * (8 + 32 + (d.hist ? 4 * SG_HIST_BINS : 0));
         for (const void* f : {reinterpret_cast<const void*>(k1a_partition<true, true, false>), reinterpret_cast<const void*>(k1a_partition<true, false, false>),
                               reinterpret_cast<const void*>(k1a_partition<false, true, false>), reinterpret_cast<const void*>(k1a_partition<false, false, false>),
                               reinterpret_cast<const void*>(k1a_partition<true, true, true>), reinterpret_cast<const void*>(k1a_partition<true, false, true>),
-                              reinterpret_cast<const void*>(k1a_partition<false, true, true>), reinterpret_cast<const void*>(k1a_partition<false, false, true>)})
+                              reinterpret_cast<const void*>(k1a_partition<false, true, true>), reinterpret_cast<const void*>(k1a_partition<false, false, true>),
+                              reinterpret_cast<const void*>(k1a_tile_partition<true, true>), reinterpret_cast<const void*>(k1a_tile_partition<true, false>),
+                              reinterpret_cast<const void*>(k1a_tile_partition<false, true>), reinterpret_cast<const void*>(k1a_tile_partition<false, false>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
         for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>),
-                              reinterpret_cast<const void*>(k1b_merge_wide<4, false>), reinterpret_cast<const void*>(k1b_merge_wide<8, false>), reinterpret_cast<const void*>(k1b_merge_wide<4, true>)})
+                              reinterpret_cast<const void*>(k1b_merge_wide<4, false>), reinterpret_cast<const void*>(k1b_merge_wide<8, false>), reinterpret_cast<const void*>(k1b_merge_wide<4, true>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<4>), reinterpret_cast<const void*>(k1b_stream_merge<8>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }
@@ -561,8 +639,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         size_t eslots = ME;
         if (w.variant == 0) {
             eslots = std::max<size_t>(ME, (size_t)w.np * w.pcap);
-            LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * w.pslots));
-            LR(dev_alloc(e, &w.hdr, (size_t)w.np * w.nwg));
+            if (w.narrow) { LR(dev_alloc(e, &w.slab8, (size_t)w.np * w.nwg * w.punits)); LR(dev_alloc(e, &w.hdr8, (size_t)w.np * w.nwg)); }
+            else { LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * w.pslots)); LR(dev_alloc(e, &w.hdr, (size_t)w.np * w.nwg)); }
             LR(dev_alloc(e, &w.ovf, (size_t)w.ovf_cap * 9));
             LR(dev_alloc(e, &w.ovf_p, (size_t)w.ovf_cap));
             LR(dev_alloc(e, &w.part_n, w.np));
@@ -652,11 +730,23 @@ int sg_destroy(sg_handle e) {
     if (e->k1_ev) hipEventDestroy(e->k1_ev);
     for (int i = 0; i < kStageSlots; i++) { if (e->h_stage[i]) hipHostFree(e->h_stage[i]); if (e->stage_ev[i]) hipEventDestroy(e->stage_ev[i]); }
     if (e->h_rows) hipHostFree(e->h_rows);
+    if (e->h_rows_old) hipHostFree(e->h_rows_old);
     for (auto& r : e->trecs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto v : e->ev_pool) hipEventDestroy(v);
     if (e->tab_ev) hipEventDestroy(e->tab_ev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
+    return SG_OK;
+}
+
+int sg_geometry_get(sg_handle e, sg_geometry* out) {
+    if (!e || !out) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    const Dev& d = e->d;
+    out->k1_variant = d.variant; out->k1_narrow = d.narrow; out->partitions = d.np; out->table_slots = d.k1b_ht;
+    out->pass_a_workgroups = d.nwg; out->cache_slots = e->k1a_ct; out->join_l2_in_lds = e->l2_in_lds ? 1u : 0u;
+    out->tile_records = d.narrow ? K1T_TS : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
+    out->piece_bytes = d.variant != 0 ? 0u : (d.narrow ? d.punits * 8u : d.pslots * 16u);
     return SG_OK;
 }
 

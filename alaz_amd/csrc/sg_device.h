@@ -112,6 +112,14 @@ struct Dev {
                                               //   slot ss + 3r: aggregate r {key, cnt|err<<32, sum_ns, max_ns, sumsq_us} (40 of 48 bytes)
     u32*   hdr;                               // [np][nwg] records in piece (p, w): n_single | n_aggregate << 20
     u32 k1a_ct;                               // pass A: LDS edge-cache slots (power of two; bucket = 2 adjacent slots)
+    // ---- narrow-record K1 (variant 0 default): 8-byte records, partition by a bijective key mix (sg_hash.h sg_kmix) ----
+    u32 narrow;                               // 1 = k1a_tile_partition / k1b_stream_merge run; 0 = the 16-byte-record kernels (k1a_partition / k1b_merge)
+    u32 nb, pb, rb;                           // bits per compact endpoint index, log2(np), bits of the in-partition remainder (2 nb - pb <= 31)
+    u64*   slab8;                             // [np][nwg][punits] 8-byte units.  Piece (p, w): units [0, sn) narrow records {dur u32, rem | err << 31};
+                                              //   then sw wide singles of 2 units {mixed key, dur | err << 63 | edge-only << 62}; then sa aggregates of 5
+                                              //   units {mixed key, cnt | err << 32, sum_ns, max_ns, sumsq_us}
+    uint2* hdr8;                              // [np][nwg] {narrow records, wide singles | aggregates << 16} in piece (p, w)
+    u32 sn, sw, punits;                       // piece geometry (sa is shared with the 16-byte layout); punits = sn + 2 sw + 5 sa, a multiple of 16
     u32 k1b_ht;                               // pass B: LDS table slots per partition (power of two)
     // f-3 (SG_CFG_EDGE_HISTOGRAM): per-edge log2 latency histogram, SG_HIST_BINS u32 bins
     u32 hist;                                 // 0 = off (the kernels' HIST = false instantiations run)

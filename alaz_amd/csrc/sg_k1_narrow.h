@@ -1,0 +1,477 @@
+// sg_k1_narrow.h — K1 resolve_aggregate, narrow-record form (the default of variant 0).  Included by sg_kernels.h.
+//
+// Same job as k1a_partition / k1b_merge (extractAddressPair + setFromToV2 + ReverseDirection + PersistRequest,
+// aggregator/data.go:1760-1767, 827-870; datastore/dto.go:226-231; backend.go:819-847), different exchange format:
+//
+//   * an edge is the pair of COMPACT endpoint indices (cf, ct) < 2^nb; sg_kmix (sg_hash.h) is a bijection of that pair, its
+//     top pb bits are the partition, the other rb = 2 nb - pb <= 31 bits ("rem") name the edge inside the partition.  A
+//     record is therefore 8 bytes {duration u32, rem | error << 31} instead of 16, and pass B keys its LDS table by a u32;
+//   * pass A sorts every tile of 8192 records by partition in LDS before it writes them: the records of a partition leave as
+//     one contiguous run written by adjacent lanes (full or nearly full 64/128-byte write requests) instead of one scattered
+//     16-byte store per record.  The r02 kernel issued 8.6 M write requests per C3 window (one per record,
+//     profiles/r02_store_probe.txt: the cost is per request, not per byte); a run of 16 records is ~3.
+//
+// Everything that does not fit a narrow record (durations of 2^32 ns and more, SG_EV_ALIVE edge-only records) travels as a
+// 16-byte "wide" single in its own region of the piece; hot keys are folded in the first-come LDS cache exactly as before
+// and leave as 40-byte aggregates.  Integer adds / max only: bit-exact whatever the order.
+#pragma once
+
+#define K1T_THREADS 1024
+#define K1T_TS      8192u         // records per tile: 8 events per thread
+#define K1T_NONE    0xFFFFFFFFu
+#define K1T_RANK_SHIFT 12         // stash word: partition (<= 12 bits) | rank in the partition's run << 12
+
+__device__ __forceinline__ u32 ci_of_ref(const Dev& d, u32 ref) {
+    const u32 t = SG_REF_TYPE(ref), v = SG_REF_VALUE(ref);
+    return t == SG_REF_KNOWN ? v : (t == SG_REF_LABEL ? d.max_known + v : d.max_known + d.max_labels + v);
+}
+__device__ __forceinline__ u32 ref_of_ci(const Dev& d, u32 c) {
+    if (c < d.max_known) return SG_MAKE_REF(SG_REF_KNOWN, c);
+    if (c < d.max_known + d.max_labels) return SG_MAKE_REF(SG_REF_LABEL, c - d.max_known);
+    return SG_MAKE_REF(SG_REF_OBIP, c - d.max_known - d.max_labels);
+}
+__device__ __forceinline__ u64* piece8(const Dev& d, u32 p, u32 w) { return d.slab8 + ((size_t)p * d.nwg + w) * d.punits; }
+
+// a record that found no room in its piece: the window's overflow list (pass B filters it by partition); mk = mixed key
+__device__ __forceinline__ void ovf8_single(const Dev& d, u32 p, u64 mk, u64 dur, u32 err, u32 zero, K1Local& L) {
+    if (zero) ovf_append(d, p, mk, 0ull, 0ull, 0ull, 0ull, L);
+    else { const u64 us = dur / 1000ull; ovf_append(d, p, mk, 1ull | ((u64)err << 32), dur, dur, us * us, L); }
+}
+// one narrow record outside the tile (cache flush): position from the piece's LDS counter
+__device__ __forceinline__ void emit_narrow_direct(const Dev& d, u32* fcn, u32 w, u32 p, u32 rem, u32 dur, u32 err, K1Local& L) {
+    const u32 pos = atomicAdd(&fcn[p], 1u);
+    if (pos < d.sn) piece8(d, p, w)[pos] = (u64)dur | ((u64)(rem | (err << 31)) << 32);
+    else { atomicSub(&fcn[p], 1u); ovf8_single(d, p, ((u64)p << d.rb) | rem, (u64)dur, err, 0u, L); }
+}
+// a wide single: {mixed key, dur | err << 63 | edge-only << 62}; fcw[p] = wide singles | aggregates << 16
+__device__ __forceinline__ void emit_wide(const Dev& d, u32* fcw, u32 w, u32 p, u64 mk, u64 dur, u32 err, u32 zero, K1Local& L) {
+    const u32 pos = atomicAdd(&fcw[p], 1u) & 0xFFFFu;
+    if (pos < d.sw) reinterpret_cast<uint4*>(piece8(d, p, w) + d.sn)[pos] = make_uint4((u32)mk, (u32)(mk >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31) | (zero << 30));
+    else { atomicSub(&fcw[p], 1u); ovf8_single(d, p, mk, dur, err, zero, L); }
+}
+// one aggregate of this launch's cache; an aggregate of the same key left by an EARLIER launch of the window is updated
+// in place (the piece is private to this workgroup and a key is flushed by exactly one lane: no atomics needed)
+__device__ __forceinline__ void emit_agg8(const Dev& d, u32* fcw, u32 w, u32 p, u64 mk, u64 a0, u64 a1, u64 a2, u64 a3, K1Local& L, bool first) {
+    u64* ag = piece8(d, p, w) + d.sn + 2 * d.sw;
+    if (!first) {
+        u32 na0 = d.hdr8[(size_t)p * d.nwg + w].y >> 16; na0 = na0 < d.sa ? na0 : d.sa;
+        for (u32 r = 0; r < na0; r++) {
+            u64* o = ag + 5 * r;
+            if (o[0] != mk) continue;
+            o[1] += a0; o[2] += a1; { const u64 m = o[3]; o[3] = a2 > m ? a2 : m; } o[4] += a3;
+            return;
+        }
+    }
+    const u32 pos = atomicAdd(&fcw[p], 1u << 16) >> 16;
+    if (pos < d.sa) { u64* o = ag + 5 * pos; o[0] = mk; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; }
+    else { atomicSub(&fcw[p], 1u << 16); ovf_append(d, p, mk, a0, a1, a2, a3, L); }
+}
+
+// ---- pass A ---------------------------------------------------------------------------------------------------------
+// 256 workgroups x 1024 threads, one per CU; one launch per ingested batch.  LDS: edge cache | piece counters | run counters
+// (two sets, alternating tiles) | run offsets | statistics | tile | join tables.
+// Per tile (8 events per thread, fetched as two groups of four):
+//   P1  join + setFromToV2 as selects + key mix + cache probe (the r02 fast path); a record that is not folded into the
+//       cache takes a rank in its partition's run (returning LDS add) and stays in registers
+//   P2  wave 0 turns the run lengths into offsets           P3  every thread drops its records at offset + rank
+//   P4  16 lanes per partition copy its run to the piece: adjacent lanes, adjacent addresses
+// Three LDS-only barriers per tile; the run counters alternate so that P4 of tile k may overlap P1 of tile k + 1.
+template <bool L2LDS, bool SHARDED>
+__global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const sg_event* __restrict__ ev, u64 n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 CT = d.k1a_ct, NP = d.np;
+    u64* ckey = reinterpret_cast<u64*>(smem);                       // [CT] mixed keys
+    u64* cacc = ckey + CT;                                           // [CT][4]
+    u32* fcn = reinterpret_cast<u32*>(cacc + (size_t)CT * 4);        // [np] narrow records in piece (p, this workgroup)
+    u32* fcw = fcn + NP;                                             // [np] wide singles | aggregates << 16
+    u32* bcnt = fcw + NP;                                            // [2][np] run lengths of the tile being built / written
+    u32* boff = bcnt + 2 * NP;                                       // [np] run offsets inside the tile
+    u64* red = reinterpret_cast<u64*>(boff + NP);                    // [8] workgroup statistics (WS_* order)
+    u64* tile = red + 8;                                             // [K1T_TS]
+    uint4* jl = reinterpret_cast<uint4*>(tile + K1T_TS);             // LDS copy of the join blob: jl1 | jl2 (L2LDS)
+    const u64* l1 = reinterpret_cast<const u64*>(jl);
+    const u32* l2 = L2LDS ? reinterpret_cast<const u32*>(l1 + d.jl1mask + 1) : d.jl2;
+    const u32 w = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
+    const u64 per = (n + d.nwg - 1) / d.nwg;
+    const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
+    const bool first = d.batch_state == 1u;                          // first batch of the window: the headers are zero by definition
+    if (beg >= end) {                                                // no share of this batch: pieces and statistics stay as they are,
+        if (first) for (u32 p = t; p < NP; p += K1T_THREADS) d.hdr8[(size_t)p * d.nwg + w] = make_uint2(0u, 0u);   // but stale headers must go
+        return;
+    }
+    const u64 last = end - 1;
+    SG_STAMP(d, 0, 0);
+    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = L.lost = 0;
+    const u32 nb = d.nb, nbmask = (1u << nb) - 1u, pshift = nb - d.pb, rbmask = (1u << d.rb) - 1u, bmask = CT / 2 - 1;
+    const bool ck_any = d.ck_n != 0;
+
+#define K1T_ISSUE(base)                                                                                           \
+        { const u64 j0 = (base), j1 = j0 + K1T_THREADS, j2 = j1 + K1T_THREADS, j3 = j2 + K1T_THREADS;               \
+          const uint4* q0 = pe + 2 * (j0 < end ? j0 : last); const uint4* q1 = pe + 2 * (j1 < end ? j1 : last);     \
+          const uint4* q2 = pe + 2 * (j2 < end ? j2 : last); const uint4* q3 = pe + 2 * (j3 < end ? j3 : last);     \
+          gload16_issue(ea0, q0); gload16_issue(eb0, q0 + 1); gload16_issue(ea1, q1); gload16_issue(eb1, q1 + 1);   \
+          gload16_issue(ea2, q2); gload16_issue(eb2, q2 + 1); gload16_issue(ea3, q3); gload16_issue(eb3, q3 + 1); }
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory")   /* LDS-only: does not drain the global stores */
+
+    // cache fold of one accepted event whose bucket the caller has read (k0, k1); returns false when the event must travel
+    auto cache_fold = [&](u32 bucket, u64 mk, u64 k0, u64 k1, u64 dur, u32 err) -> bool {
+        int slot = k0 == mk ? (int)(2u * bucket) : (k1 == mk ? (int)(2u * bucket + 1u) : -1);
+        if (slot < 0 && (k0 == SG_EKEY_EMPTY || k1 == SG_EKEY_EMPTY)) slot = cache_claim(ckey, bucket, mk, k0, k1);
+        if (slot < 0) return false;
+        u64 ssq;
+        if ((dur >> 32) == 0) { const u32 us = div1000_u32((u32)dur); ssq = (u64)us * (u64)us; }
+        else { const u64 us = dur / 1000ull; ssq = us * us; }
+        atomicAdd(&cacc[slot * 4], 1ull | ((u64)err << 32)); atomicAdd(&cacc[slot * 4 + 1], dur);
+        atomicMax(&cacc[slot * 4 + 2], dur); atomicAdd(&cacc[slot * 4 + 3], ssq);
+        return true;
+    };
+    // The general path (rare events: open connections, raw-IP outbound destinations, IPs in both maps or in the residual
+    // cuckoo table, durations of 2^32 ns and more, labels out of range): the full join on the global tables.  A request
+    // that fits a narrow record comes back as one (slo, shi, spr) and joins the tile like a fast-path record.
+    auto general = [&](const v4u_t va, const v4u_t vb, u32* bc, u32& slo, u32& shi, u32& spr) {
+        spr = K1T_NONE;
+        K1Ev e;
+        if (!k1_resolve(d, make_uint4(va.x, va.y, va.z, va.w), make_uint4(vb.x, vb.y, vb.z, vb.w), L, e)) return;
+        u32 Lm, Rm;
+        sg_kmix(ci_of_ref(d, (u32)(e.key >> 32)), ci_of_ref(d, (u32)e.key), nbmask, &Lm, &Rm);
+        const u32 part = Lm >> pshift;
+        const u64 mk = ((u64)Lm << nb) | Rm;
+        if (e.alive) { emit_wide(d, fcw, w, part, mk, 0ull, 0u, 1u, L); return; }
+        const u32 bkt = Rm & bmask;
+        if (cache_fold(bkt, mk, lds_fresh_u64(&ckey[2 * bkt]), lds_fresh_u64(&ckey[2 * bkt + 1]), e.dur, e.err)) return;
+        if (e.dur >> 32) { emit_wide(d, fcw, w, part, mk, e.dur, e.err, 0u, L); return; }
+        const u32 rank = atomicAdd(&bc[part], 1u);
+        slo = (u32)e.dur; shi = ((u32)mk & rbmask) | (e.err << 31); spr = part | (rank << K1T_RANK_SHIFT);
+    };
+    auto join = [&](u32 ip) -> u32 {
+        const u32 b = ip >> 8;
+        const u64 e1 = l1[((__umul24(b, SG_JL1_K1)) >> 9) & d.jl1mask], e2 = l1[((__umul24(b, SG_JL1_K2)) >> 11) & d.jl1mask];
+        const u32 blk = (u32)e1 == b ? (u32)(e1 >> 32) : ((u32)e2 == b ? (u32)(e2 >> 32) : 0u);     // block 0 = the all-zero block
+        return l2[(blk << 8) | (ip & 255u)];
+    };
+    // The fast path, one event: branch-free join (two-level block table in LDS), data.go:827-870 as selects, key mix,
+    // read-only cache probe.  `rare` hands the event to the general path instead.
+    auto fast = [&](const u64 idx, const v4u_t va, const v4u_t vb, u32* bc, bool& rare_out, u32& slo, u32& shi, u32& spr) {
+        const bool inr = idx < end;
+        const u32 flags = va.w >> 24, label = va.z;
+        const u32 vs = join(va.x), vd = join(va.y);
+        const u32 ks = vs >> 30, kd = vd >> 30;
+        bool rare = ((flags & SG_EV_ALIVE) != 0) | (ks == 3u) | (kd == 3u) | (vb.y != 0u) |
+                    ((kd == 0u) & ((label == 0u) | (label > d.max_labels))) | (ck_any & ((vs == 0u) | (vd == 0u)));
+        rare &= inr; rare_out = rare;
+        const bool fastv = inr & !rare;
+        bool acc = fastv & (ks == 1u);                               /* data.go:829-832: the source must be a pod */
+        L.dsrc += (fastv & (ks != 1u)) ? 1u : 0u;
+        u32 cf = vs & 0x3FFFFFFFu;
+        u32 ct = kd ? (vd & 0x3FFFFFFFu) : (d.max_known + label - 1u);   /* service / pod id, else Host label (:840-854) */
+        { const u32 ml = (acc & (kd == 0u)) ? label : 0u; L.maxlabel = ml > L.maxlabel ? ml : L.maxlabel; }
+        if (flags & SG_EV_REVERSE) { const u32 x_ = cf; cf = ct; ct = x_; }      /* dto.go:226-231 */
+        if (SHARDED) { const bool mine = (owner_hash_ref(ref_of_ci(d, cf)) % d.world) == d.rank; L.misr += (acc & !mine) ? 1u : 0u; acc &= mine; }
+        const u32 status = va.w & 0xFFFFu, proto = (va.w >> 16) & 0xFFu, dur = vb.x;
+        const u32 err = is_error(proto, status);
+        const u64 wt = (u64)vb.z | ((u64)vb.w << 32);
+        L.acc += acc ? 1u : 0u;
+        L.tmin = (acc && wt < L.tmin) ? wt : L.tmin; L.tmax = (acc && wt > L.tmax) ? wt : L.tmax;
+        u32 Lm, Rm;
+        sg_kmix(cf & nbmask, ct & nbmask, nbmask, &Lm, &Rm);        /* (the masks only matter for events that are not accepted) */
+        const u32 part = Lm >> pshift, bucket = Rm & bmask;
+        const u64 mk = ((u64)Lm << nb) | Rm;
+        const ulonglong2 kk = reinterpret_cast<const ulonglong2*>(ckey)[bucket];
+        spr = K1T_NONE; slo = 0; shi = 0;
+        if (acc && !cache_fold(bucket, mk, kk.x, kk.y, (u64)dur, err)) {
+            const u32 rank = atomicAdd(&bc[part], 1u);
+            slo = dur; shi = ((u32)mk & rbmask) | (err << 31); spr = part | (rank << K1T_RANK_SHIFT);
+        }
+    };
+#define K1T_FOLD(base, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3)                                \
+        { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(eb0), "+v"(ea1), "+v"(eb1), "+v"(ea2), "+v"(eb2), "+v"(ea3), "+v"(eb3) : : "memory"); \
+          bool r0, r1, r2, r3;                                                                                      \
+          fast((base), ea0, eb0, (bc), r0, lo0, hi0, pr0); fast((base) + K1T_THREADS, ea1, eb1, (bc), r1, lo1, hi1, pr1); \
+          fast((base) + 2 * K1T_THREADS, ea2, eb2, (bc), r2, lo2, hi2, pr2); fast((base) + 3 * K1T_THREADS, ea3, eb3, (bc), r3, lo3, hi3, pr3); \
+          if (__builtin_amdgcn_ballot_w64(r0 | r1 | r2 | r3)) {             /* one copy of the general path: register selects */ \
+              _Pragma("unroll 1")                                                                                   \
+              for (u32 q = 0; q < 4; q++) {                                                                         \
+                  const bool rq = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : r3;                                     \
+                  if (!__builtin_amdgcn_ballot_w64(rq)) continue;                                                   \
+                  const v4u_t va = q == 0 ? ea0 : q == 1 ? ea1 : q == 2 ? ea2 : ea3;                                \
+                  const v4u_t vb = q == 0 ? eb0 : q == 1 ? eb1 : q == 2 ? eb2 : eb3;                                \
+                  u32 glo = 0, ghi = 0, gpr = K1T_NONE;                                                             \
+                  if (rq) general(va, vb, (bc), glo, ghi, gpr);                                                     \
+                  if (rq && q == 0) { lo0 = glo; hi0 = ghi; pr0 = gpr; }                                            \
+                  if (rq && q == 1) { lo1 = glo; hi1 = ghi; pr1 = gpr; }                                            \
+                  if (rq && q == 2) { lo2 = glo; hi2 = ghi; pr2 = gpr; }                                            \
+                  if (rq && q == 3) { lo3 = glo; hi3 = ghi; pr3 = gpr; }                                            \
+              } } }
+    {
+        // piece counters: zero by definition in the first batch of a window (no loads); a later batch reads them with
+        // ordinary loads BEFORE anything is issued by hand
+        for (u32 p = t; p < NP; p += K1T_THREADS) {
+            uint2 h = make_uint2(0u, 0u);
+            if (!first) h = d.hdr8[(size_t)p * d.nwg + w];
+            fcn[p] = h.x; fcw[p] = h.y; bcnt[p] = 0u; bcnt[NP + p] = 0u;
+        }
+        for (u32 k = t; k < CT; k += K1T_THREADS) ckey[k] = SG_EKEY_EMPTY;
+        for (u32 k = t; k < CT * 4; k += K1T_THREADS) cacc[k] = 0;
+        if (t < 8) red[t] = t == WS_TMIN ? ~0ull : 0ull;
+        // the join blob: six 16-byte loads per lane at most, issued and waited for in ONE asm statement (see k1a_partition: no
+        // code may sit between a hand-issued load and the wait that names its registers)
+        v4u_t jb0, jb1, jb2, jb3, jb4, jb5;
+        static_assert(K1A_NJ == 6, "written out for 6 blob words per lane");
+        const u32 n16 = d.jstage_bytes >> 4, n1 = (d.jl1mask + 1) >> 1;   // 16-byte words to stage; of them level 1 (always there)
+        const uint4* g1 = reinterpret_cast<const uint4*>(d.jl1); const uint4* g2 = reinterpret_cast<const uint4*>(d.jl2) - n1;
+#define K1T_JIDX(k) ((t + (k) * K1T_THREADS) < n16 ? (t + (k) * K1T_THREADS) : n16 - 1)
+#define K1T_JSRC(k) ((K1T_JIDX(k) < n1 ? g1 : g2) + K1T_JIDX(k))
+        const uint4* js0 = K1T_JSRC(0); const uint4* js1 = K1T_JSRC(1); const uint4* js2 = K1T_JSRC(2);
+        const uint4* js3 = K1T_JSRC(3); const uint4* js4 = K1T_JSRC(4); const uint4* js5 = K1T_JSRC(5);
+        asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %7, off\n\tglobal_load_dwordx4 %2, %8, off\n\t"
+                     "global_load_dwordx4 %3, %9, off\n\tglobal_load_dwordx4 %4, %10, off\n\tglobal_load_dwordx4 %5, %11, off\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(jb0), "=&v"(jb1), "=&v"(jb2), "=&v"(jb3), "=&v"(jb4), "=&v"(jb5)
+                     : "v"(js0), "v"(js1), "v"(js2), "v"(js3), "v"(js4), "v"(js5) : "memory");
+#define K1T_JST(k, r) if (t + (k) * K1T_THREADS < n16) jl[t + (k) * K1T_THREADS] = make_uint4((r).x, (r).y, (r).z, (r).w)
+        K1T_JST(0, jb0); K1T_JST(1, jb1); K1T_JST(2, jb2); K1T_JST(3, jb3); K1T_JST(4, jb4); K1T_JST(5, jb5);
+#undef K1T_JST
+#undef K1T_JSRC
+#undef K1T_JIDX
+        LDS_BARRIER();
+        SG_STAMP(d, 0, 1);
+    }
+    const u32 bpw = NP >> 4;                                         // partitions whose runs a wave writes out (np >= 64)
+    u32 cur = 0;
+    for (u64 base = beg; base < end; base += K1T_TS, cur ^= 1u) {
+        u32* bc = bcnt + cur * NP;
+        u32 lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7;
+        {   // P1: two groups of four events per thread
+            v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
+            const u64 i0 = base + t;
+            K1T_ISSUE(i0);
+            K1T_FOLD(i0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
+            const u64 i1 = i0 + 4 * K1T_THREADS;
+            K1T_ISSUE(i1);
+            K1T_FOLD(i1, bc, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7);
+        }
+        LDS_BARRIER();
+        if (wave == 0) {                                             // P2: exclusive scan of the run lengths (np / 64 per lane)
+            const u32 pl = NP >> 6, b0 = lane * pl;
+            u32 s = 0;
+            for (u32 k = 0; k < pl; k++) s += bc[b0 + k];
+            u32 incl = s;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) { const u32 o = __shfl_up(incl, sh, 64); if ((int)lane >= sh) incl += o; }
+            u32 run = incl - s;
+            for (u32 k = 0; k < pl; k++) { const u32 c = bc[b0 + k]; boff[b0 + k] = run; run += c; }
+        }
+        LDS_BARRIER();
+#define K1T_DROP(lo, hi, pr) if ((pr) != K1T_NONE) tile[boff[(pr) & ((1u << K1T_RANK_SHIFT) - 1u)] + ((pr) >> K1T_RANK_SHIFT)] = (u64)(lo) | ((u64)(hi) << 32)
+        K1T_DROP(lo0, hi0, pr0); K1T_DROP(lo1, hi1, pr1); K1T_DROP(lo2, hi2, pr2); K1T_DROP(lo3, hi3, pr3);   // P3
+        K1T_DROP(lo4, hi4, pr4); K1T_DROP(lo5, hi5, pr5); K1T_DROP(lo6, hi6, pr6); K1T_DROP(lo7, hi7, pr7);
+#undef K1T_DROP
+        LDS_BARRIER();
+        for (u32 b4 = 0; b4 < bpw; b4 += 4) {                        // P4: four runs per wave step, 16 lanes each
+            const u32 b = wave * bpw + b4 + (lane >> 4), j0 = lane & 15u;
+            const u32 cnt = bc[b], off = boff[b], pos0 = fcn[b];
+            u64* dst = piece8(d, b, w);
+            for (u32 j = j0; j < cnt; j += 16) {
+                const u64 rec = tile[off + j];
+                const u32 pos = pos0 + j;
+                if (pos < d.sn) { if (!(d.ablate & 0x1u)) dst[pos] = rec; }
+                else ovf8_single(d, b, ((u64)b << d.rb) | ((u32)(rec >> 32) & rbmask), rec & 0xFFFFFFFFull, (u32)(rec >> 63), 0u, L);
+            }
+            if (j0 == 0) { bc[b] = 0u; const u32 np_ = pos0 + cnt; fcn[b] = np_ < d.sn ? np_ : d.sn; }
+        }
+    }
+    SG_STAMP(d, 0, 3);
+#undef K1T_ISSUE
+#undef K1T_FOLD
+    LDS_BARRIER();
+    SG_STAMP(d, 0, 4);
+    // flush the cache: a key seen once leaves as a single record, the others as aggregates
+    for (u32 s = t; s < CT; s += K1T_THREADS) {
+        const u64 k = ckey[s];
+        if (k == SG_EKEY_EMPTY) continue;
+        const u64 x0 = cacc[s * 4];
+        const u32 part = (u32)(k >> d.rb), rem = (u32)k & rbmask;
+        if ((x0 & 0xFFFFFFFFull) == 1ull) {
+            const u64 dur = cacc[s * 4 + 1];
+            if (dur >> 32) emit_wide(d, fcw, w, part, k, dur, (u32)(x0 >> 32), 0u, L);
+            else emit_narrow_direct(d, fcn, w, part, rem, (u32)dur, (u32)(x0 >> 32), L);
+        } else if ((x0 & 0xFFFFFFFFull) != 0ull) emit_agg8(d, fcw, w, part, k, x0, cacc[s * 4 + 1], cacc[s * 4 + 2], cacc[s * 4 + 3], L, first);
+    }
+    // workgroup statistics: wave reduce -> LDS -> one thread updates this workgroup's private line
+    {
+        const u64 tmin = wave_min_u64(L.tmin), tmax = wave_max_u64(L.tmax);
+        const u32 ml = (u32)wave_max_u64(L.maxlabel);
+        const u32 ds = wave_sum_u32(L.dsrc), dc = wave_sum_u32(L.dcap), mr = wave_sum_u32(L.misr), ac = wave_sum_u32(L.acc), ls = wave_sum_u32(L.lost);
+        if (lane == 0) {
+            if (ac) { atomicMin(&red[WS_TMIN], tmin); atomicMax(&red[WS_TMAX], tmax); atomicAdd(&red[WS_ACCEPTED], (u64)ac); }
+            if (ls) atomicAdd(&red[WS_PAD], (u64)ls);
+            if (ml) atomicMax(&red[WS_MAXLABEL], (u64)ml);
+            if (ds) atomicAdd(&red[WS_DROPPED_SRC], (u64)ds);
+            if (dc) atomicAdd(&red[WS_DROPPED_CAP], (u64)dc);
+            if (mr) atomicAdd(&red[WS_MISROUTED], (u64)mr);
+        }
+    }
+    LDS_BARRIER();
+    for (u32 p = t; p < NP; p += K1T_THREADS) d.hdr8[(size_t)p * d.nwg + w] = make_uint2(fcn[p], fcw[p]);
+    SG_STAMP(d, 0, 5);
+    if (t == 0) {
+        u64* g = d.wgstat + (size_t)(blockIdx.x % SG_MAX_K1_WGS) * WS_WORDS;
+        // accepted = counted by the lanes - dropped afterwards for capacity (a workgroup only drops what it accepted itself)
+        if (red[WS_ACCEPTED]) { atomicMin(&g[WS_TMIN], red[WS_TMIN]); atomicMax(&g[WS_TMAX], red[WS_TMAX]); atomicAdd(&g[WS_ACCEPTED], red[WS_ACCEPTED] - red[WS_PAD]); }
+        if (red[WS_MAXLABEL]) atomicMax(&g[WS_MAXLABEL], red[WS_MAXLABEL]);
+        if (red[WS_DROPPED_SRC]) atomicAdd(&g[WS_DROPPED_SRC], red[WS_DROPPED_SRC]);
+        if (red[WS_DROPPED_CAP]) atomicAdd(&g[WS_DROPPED_CAP], red[WS_DROPPED_CAP]);
+        if (red[WS_MISROUTED]) atomicAdd(&g[WS_MISROUTED], red[WS_MISROUTED]);
+    }
+    SG_STAMP(d, 0, 6);
+#undef LDS_BARRIER
+}
+
+// ---- pass B ---------------------------------------------------------------------------------------------------------
+// Workgroup p owns partition p.  It reads the record counts of its nwg pieces, then exactly the records that exist — U
+// 16-byte loads (two narrow records each) per lane in flight, the lanes of a piece side by side —, merges them in an LDS
+// table keyed by the u32 remainder and writes every distinct edge once with plain stores; the endpoints come back out of the
+// key with sg_kunmix.  Outputs as k1b_merge: e_from / e_to / acc_src / e_rank per partition slot, deg[from][replica].
+// LDS: hacc[4][HT] u64 | hkey[HT] u32 | two counters: 36 bytes per slot.
+template <int U>
+__device__ __forceinline__ void k1b8_body(const Dev& d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 HT = d.k1b_ht, hmask = HT - 1;
+    u64* hacc = reinterpret_cast<u64*>(smem);                        // [4][HT]: accumulator j of slot h at j*HT + h
+    u32* hkey = reinterpret_cast<u32*>(hacc + (size_t)HT * 4);       // [HT] remainders, all ones = empty
+    u32* n_drop = hkey + HT; u32* out_n = n_drop + 1;
+    const u32 p = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
+    const u32 nb = d.nb, nbmask = (1u << nb) - 1u, rbmask = (1u << d.rb) - 1u;
+    SG_STAMP(d, 1, 0);
+    const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
+    const u32 LPP = NT > d.nwg ? NT / d.nwg : 1u;                    // lanes per piece
+    const u32 sub = t % LPP, w0 = t / LPP;
+    uint2 h0 = make_uint2(0u, 0u);
+    if (!empty && w0 < d.nwg) h0 = d.hdr8[(size_t)p * d.nwg + w0];
+    // the first U record pairs of the lane's first piece go out together with the header (index clamped to the narrow region;
+    // what lies beyond the count is ignored): one round trip instead of two, hidden behind the table set-up
+    uint4 xf[U];
+    {
+        const uint4* piece0 = reinterpret_cast<const uint4*>(piece8(d, p, w0 < d.nwg ? w0 : 0u));
+        const u32 pm1 = (d.sn >> 1) - 1;
+#pragma unroll
+        for (int u = 0; u < U; u++) { const u32 r = sub + (u32)u * LPP; xf[u] = piece0[r < pm1 ? r : pm1]; }
+    }
+    const u64 ovf_n = d.ctr[C_OVF_N];
+    const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
+    for (u32 i = t; i < HT; i += NT) hkey[i] = 0xFFFFFFFFu;
+    for (u32 i = t; i < HT * 4; i += NT) hacc[i] = 0;
+    if (t == 0) { *n_drop = 0; *out_n = 0; }
+    __syncthreads();
+    SG_STAMP(d, 1, 1);
+
+    auto add = [&](u32 rem, u64 a0, u64 a1, u64 a2, u64 a3) {
+        u32 h = rem & hmask; bool ok = false;
+        for (u32 it = 0; it < HT; it++) {
+            u32 k = lds_fresh_u32(&hkey[h]);
+            if (k == 0xFFFFFFFFu) { k = atomicCAS(&hkey[h], 0xFFFFFFFFu, rem); if (k == 0xFFFFFFFFu) k = rem; }
+            if (k == rem) { ok = true; break; }
+            h = (h + 1) & hmask;
+        }
+        if (!ok) { atomicAdd(n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
+        atomicAdd(&hacc[h], a0); atomicAdd(&hacc[HT + h], a1); atomicMax(&hacc[2 * HT + h], a2); atomicAdd(&hacc[3 * HT + h], a3);
+    };
+    auto add_narrow = [&](u32 lo, u32 hi) {
+        const u32 us = div1000_u32(lo);
+        if (!(d.ablate & 0x10u)) add(hi & rbmask, 1ull | ((u64)(hi >> 31) << 32), (u64)lo, (u64)lo, (u64)us * (u64)us);
+    };
+    for (u32 w = w0; w < d.nwg; w += NT / LPP) {
+        const uint2 h = w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w];
+        const u32 nn = h.x < d.sn ? h.x : d.sn;
+        const u32 nw = (h.y & 0xFFFFu) < d.sw ? (h.y & 0xFFFFu) : d.sw, na = (h.y >> 16) < d.sa ? (h.y >> 16) : d.sa;
+        if (!(nn | nw | na)) continue;
+        const u64* piece = piece8(d, p, w);
+        const uint4* pairs = reinterpret_cast<const uint4*>(piece);
+        const u32 npair = (nn + 1) >> 1, lastp = npair ? npair - 1 : 0;
+        for (u32 r0 = sub; r0 < npair; r0 += LPP * U) {
+            uint4 x[U];
+            if (w == w0 && r0 == sub) {
+#pragma unroll
+                for (int u = 0; u < U; u++) x[u] = xf[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++) { const u32 r = r0 + u * LPP; x[u] = pairs[r < npair ? r : lastp]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const u32 r = r0 + u * LPP;
+                if (r < npair) { add_narrow(x[u].x, x[u].y); if (2 * r + 1 < nn) add_narrow(x[u].z, x[u].w); }
+            }
+        }
+        for (u32 r = sub; r < nw; r += LPP) {
+            const uint4 q = reinterpret_cast<const uint4*>(piece + d.sn)[r];
+            const u32 dhi = q.w & 0x3FFFFFFFu;
+            const u64 dur = (u64)q.z | ((u64)dhi << 32);
+            const u64 us = dur / 1000ull;
+            const u64 one = ((q.w >> 30) & 1u) ? 0ull : 1ull;            // bit 62: edge-only record (SG_EV_ALIVE)
+            add(q.x & rbmask, one | ((u64)(q.w >> 31) << 32), dur, dur, us * us);
+        }
+        for (u32 r = sub; r < na; r += LPP) {
+            const u64* q = piece + d.sn + 2 * d.sw + 5 * r;
+            add((u32)q[0] & rbmask, q[1], q[2], q[3], q[4]);
+        }
+    }
+    __syncthreads();
+    SG_STAMP(d, 1, 3);
+    if (ovf_n) {
+        const u64 no = ovf_n < d.ovf_cap ? ovf_n : d.ovf_cap;
+        for (u64 i = t; i < no; i += NT) {
+            if (d.ovf_p[i] != p) continue;
+            const u64* o = d.ovf + i * 9;
+            add((u32)o[0] & rbmask, o[1], o[2], o[3], o[4]);
+        }
+        __syncthreads();
+    }
+    SG_STAMP(d, 1, 4);
+    // compaction: two table slots per thread and round; the returning `deg` atomics of both are in flight together
+    for (u32 s0 = t; s0 < HT; s0 += 2 * NT) {
+        u32 f[2], to[2], oi[2], rk[2]; bool live[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+            const u32 s = s0 + (u32)k2 * NT;
+            live[k2] = false; f[k2] = to[k2] = oi[k2] = rk[k2] = 0;
+            if (s >= HT) continue;
+            const u32 rem = hkey[s];
+            if (rem == 0xFFFFFFFFu) continue;
+            const u64 mk = ((u64)p << d.rb) | rem;
+            u32 cf, ct;
+            sg_kunmix((u32)(mk >> nb), (u32)mk & nbmask, nbmask, &cf, &ct);
+            f[k2] = dense_of(d, ref_of_ci(d, cf), nk, nl, nob); to[k2] = dense_of(d, ref_of_ci(d, ct), nk, nl, nob);
+            if (f[k2] == SG_NONE || to[k2] == SG_NONE) { atomicAdd(n_drop, (u32)(hacc[s] & 0xFFFFFFFFull)); continue; }
+            oi[k2] = atomicAdd(out_n, 1u);
+            if (oi[k2] >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[s] & 0xFFFFFFFFull)); continue; }
+            live[k2] = true;
+            rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], p & (SG_DEG_REP - 1))], 1u);     // arrival order inside the row's replica
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+            if (!live[k2]) continue;
+            const u32 s = s0 + (u32)k2 * NT;
+            const size_t slot = (size_t)p * d.pcap + oi[k2];
+            d.e_from[slot] = f[k2]; d.e_to[slot] = to[k2];
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
+            o[0] = make_ulonglong2(hacc[s], hacc[HT + s]); o[1] = make_ulonglong2(hacc[2 * HT + s], hacc[3 * HT + s]);
+            d.e_rank[slot] = rk[k2];
+        }
+    }
+    __syncthreads();
+    SG_STAMP(d, 1, 5);
+    if (t == 0) {
+        const u32 on = *out_n, nd = *n_drop;
+        d.part_n[p] = on < d.pcap ? on : d.pcap;
+        if (nd) {                                                    // dropped after pass A had counted them as accepted
+            atomicAdd(&d.ctr[C_DROPPED_CAP], (u64)nd);
+            atomicAdd(&d.ctr[C_N_EVENTS], 0ull - (u64)nd);
+        }
+    }
+}
+// (the SGPR cap lets two 1024-thread workgroups share a CU — tools/occupancy_probe.hip; the uncapped build for geometries
+// where a CU holds one workgroup anyway)
+template <int U> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_stream_merge(Dev d) { k1b8_body<U>(d); }
+template <int U> __global__ __launch_bounds__(1024) void k1b_stream_merge_wide(Dev d) { k1b8_body<U>(d); }

@@ -784,6 +784,8 @@ __device__ __forceinline__ void k1b_body(const Dev& d) {
 template <int K1B_U, bool HIST> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_merge(Dev d) { k1b_body<K1B_U, HIST>(d); }
 template <int K1B_U, bool HIST> __global__ __launch_bounds__(1024) void k1b_merge_wide(Dev d) { k1b_body<K1B_U, HIST>(d); }
 
+#include "sg_k1_narrow.h"   // the narrow-record form of both passes (default of variant 0)
+
 // ------------------------------------------------------------------------------------------------
 // K2  csr_build: canonical node numbering, CSR with sorted rows.
 // ------------------------------------------------------------------------------------------------

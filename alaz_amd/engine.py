@@ -32,12 +32,12 @@ EXPORTS = [
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
-    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist",
+    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
 ]
 
 
 class SgConfig(C.Structure):
-    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("max_known_nodes", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("device", C.c_int32), ("max_known_nodes", C.c_uint32),
                 ("max_labels", C.c_uint32), ("max_outbound_ips", C.c_uint32), ("max_ips", C.c_uint32),
                 ("max_edges", C.c_uint64), ("max_batch", C.c_uint32), ("layers", C.c_uint32),
                 ("rank", C.c_uint32), ("world", C.c_uint32), ("k1_variant", C.c_uint32),
@@ -45,7 +45,20 @@ class SgConfig(C.Structure):
 
 
 CFG_EDGE_HISTOGRAM = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
+
+
+def make_config(*, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 256, max_outbound_ips: int = 64,
+                max_ips: int = 0, max_batch: int = 1 << 16, device: int = 0, rank: int = 0, world: int = 1, k1_variant: int = 0,
+                max_window_events: int = 0, windows_in_flight: int = 1, max_alive: int = 0, flags: int = 0) -> "SgConfig":
+    """sg_config by field name (struct_size and abi_version filled in)."""
+    return SgConfig(C.sizeof(SgConfig), ABI_VERSION, device, max_known_nodes, max_labels, max_outbound_ips, max_ips or max_known_nodes,
+                    max_edges, max_batch, layers, rank, world, k1_variant, max_window_events, windows_in_flight, max_alive, flags)
+
+
+class SgGeometry(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("k1_variant", "k1_narrow", "partitions", "table_slots", "pass_a_workgroups", "cache_slots",
+                                          "join_l2_in_lds", "tile_records", "endpoint_bits", "piece_bytes")]
 
 
 class SgStats(C.Structure):
@@ -117,6 +130,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_debug_stamps": (C.c_int, [H, P, sz]),
         "sg_route": (C.c_int, [H, P, sz, u32, P]),
         "sg_window_hist": (C.c_int, [H, P, sz, C.POINTER(sz)]),
+        "sg_geometry_get": (C.c_int, [H, C.POINTER(SgGeometry)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)          # AttributeError if the library does not export it
@@ -138,9 +152,10 @@ class ServiceGraph:
                  rank: int = 0, world: int = 1, k1_variant: int = 0, max_window_events: int = 0, windows_in_flight: int = 1,
                  edge_histogram: bool = False):
         self._l = load_library()
-        cfg = SgConfig(self._l.sg_abi_version(), device, max_known_nodes, max_labels, max_outbound_ips,
-                       max_ips or max_known_nodes, max_edges, max_batch, layers, rank, world, k1_variant,
-                       max_window_events, windows_in_flight, 0, CFG_EDGE_HISTOGRAM if edge_histogram else 0)
+        cfg = make_config(max_known_nodes=max_known_nodes, max_edges=max_edges, layers=layers, max_labels=max_labels,
+                          max_outbound_ips=max_outbound_ips, max_ips=max_ips, max_batch=max_batch, device=device, rank=rank, world=world,
+                          k1_variant=k1_variant, max_window_events=max_window_events, windows_in_flight=windows_in_flight,
+                          flags=CFG_EDGE_HISTOGRAM if edge_histogram else 0)
         h = C.c_void_p()
         rc = self._l.sg_create(C.byref(cfg), C.byref(h))
         if rc != SG_OK:
@@ -165,6 +180,18 @@ class ServiceGraph:
             self.close()
         except Exception:
             pass
+
+    def geometry(self) -> dict:
+        """What sg_create chose for K1 (sg_geometry_get)."""
+        g = SgGeometry()
+        self._ck(self._l.sg_geometry_get(self._h, C.byref(g)))
+        return {n: int(getattr(g, n)) for n, _ in SgGeometry._fields_}
+
+    def k1_kernels(self) -> tuple:
+        """Names of the two K1 kernels this engine launches (as rocprofv3 lists them), or the single global-table kernel."""
+        g = self.geometry()
+        if g["k1_variant"] == 1: return ("k1_resolve_aggregate",)
+        return ("k1a_tile_partition", "k1b_stream_merge") if g["k1_narrow"] else ("k1a_partition", "k1b_merge")
 
     # ---- join tables (aggregator/persist.go:55-71,114-130) ----
     def upsert_pod(self, ip: int, node_id: int): self._ck(self._l.sg_upsert_pod(self._h, ip, node_id))

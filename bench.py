@@ -16,7 +16,7 @@ Steps cycle through a ring of distinct batches larger than the 256 MiB Infinity 
 from HBM.  One JSON line on stdout (rank 0):
 
   value        events/s of the timed device-resident steps (never includes PCIe; `end_to_end` does)
-  roofline     the dominant kernel K1 (k1a_partition + k1b_merge): algorithmic bytes 32*Ev + 32*E per window
+  roofline     the dominant kernel K1 (pass A k1a_tile_partition + pass B k1b_stream_merge): algorithmic bytes 32*Ev + 32*E per window
                 / their dispatch durations (HIP events on the launch stream), vs 8 TB/s
   kernels      the same for every kernel group of the window (K1a, K1b, K2, K3-in, K3-feat, K4, K5)
   end_to_end   events accepted by sg_ingest from HOST memory (several feeder threads, pinned staging ring, H2D) until the
@@ -181,18 +181,31 @@ def cpu_baseline(topo, events, labels, layers, seconds):
     return res
 
 
+def kernel_src_sha():
+    """Hash of the kernel sources (the same function as tools/pmc_k1_json.py): names the build the counters were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "alaz_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(config):
     """HBM bytes per K1 window from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    `bench.py --profile-mode`, tools/gpu_pmc.sh; gfx950 corrections per MI355X_MICROARCH.md are applied by
+    `bench.py --profile-mode`, `tools/gpu.sh pmc:TAG:CONFIG`; gfx950 corrections per MI355X_MICROARCH.md are applied by
     tools/pmc_k1_json.py).  Counters cannot be read from inside the process being timed, so this is the last committed
-    measurement for this workload (traffic_measured_in_run: false), or null."""
+    measurement for this workload (traffic_measured_in_run: false), or null.  The third value says whether the counters
+    were taken on the kernel sources this run is timing."""
     path = os.path.join(ROOT, "profiles", f"pmc_k1_c{config}.json")
     try:
         with open(path) as f:
             j = json.load(f)
-        return float(j["k1_total_hbm_bytes"]), f"profiles/pmc_k1_c{config}.json ({j.get('round', '?')})"
+        src = f"profiles/pmc_k1_c{config}.json ({j.get('round', '?')}, git {j.get('git_head', '?')})"
+        return float(j["k1_total_hbm_bytes"]), src, j.get("kernel_src_sha") == kernel_src_sha()
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def measured_copy_gbs(torch):
@@ -219,13 +232,44 @@ def algorithmic_bytes(Ev, E, N, L):
     return b
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: check that the node has N GPUs, then re-run this script under
+    torch.distributed.run (one process per GPU over RCCL) and pass rank 0's JSON line through.  Failures come out as ONE JSON
+    object with an "error" field and a non-zero exit code, never as a traceback."""
+    import socket
+    import subprocess
+
+    def fail(msg, **kw):
+        print(json.dumps({"metric": "L7 edge-events/s ingested->scored service-map", "value": None, "unit": "events/s", "n_gpus": a.gpus,
+                          "error": msg, **kw}), flush=True)
+        return 2
+    try:
+        probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        have = int(probe.stdout.strip().splitlines()[-1])
+    except Exception as ex:                                          # noqa: BLE001
+        return fail(f"could not count GPUs: {ex}")
+    if have < a.gpus:
+        return fail(f"--gpus {a.gpus} needs {a.gpus} visible GPUs, this node has {have}", gpus_visible=have)
+    with socket.socket() as sk:                                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)     # (stderr passes through)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return fail(f"torch.distributed.run exited with {out.returncode}", stdout_tail=out.stdout[-400:])
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)                                        # `python bench.py --gpus N`: one rank per GPU under torch.distributed.run
     force_sharded = os.environ.get("SG_FORCE_SHARDED") == "1"      # exercise the multi-GPU code path at world = 1
     # the contract is ONE line on stdout: libraries that print there (RCCL writes its version banner to stdout when the
     # first communicator is created) are sent to stderr for the duration of the run
@@ -279,7 +323,7 @@ def bench_single(a, device):
     Ev, L = c["events"], c["layers"]
     nb = a.batches or max(2, -(-(320 << 20) // (Ev * 32)))          # ring >= 320 MB > 256 MiB Infinity Cache
     topo = replay.make_topology(c["pods"], c["edges"], seed)
-    cache = os.environ.get("SG_BENCH_CACHE")                         # tools/gpu_round2.sh: several profiler passes over the same trace on one box
+    cache = os.environ.get("SG_BENCH_CACHE")                         # tools/gpu.sh: several profiler passes over the same trace on one box
     cpath = os.path.join(cache, f"bench_ev_c{cfgno}_{nb}.npy") if cache else None
     if cpath and os.path.exists(cpath):
         ev_all = np.load(cpath); labels = list(replay.EXTERNAL_HOSTS)
@@ -339,7 +383,8 @@ def bench_single(a, device):
     alg = algorithmic_bytes(Ev, E, N, L)
     alg_k1 = alg["K1a"] + alg["K1b"]
     achieved = alg_k1 / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(cfgno)
+    traffic, traffic_src, traffic_match = pmc_traffic(cfgno)
+    kn = g.k1_kernels(); geo = g.geometry()
     copy_gbs = None if a.profile_mode else measured_copy_gbs(torch)
     kern_us = {"K1a": k1a[0], "K1b": k1b[0], **grp}
     kernels = [{"name": k, "us_per_window": round(kern_us[k], 2), "algorithmic_bytes": alg[k],
@@ -348,7 +393,8 @@ def bench_single(a, device):
                for k in ("K1a", "K1b", "K2", "K3-in", "K3-feat", "K4", "K5") if k in kern_us]
     b_total = sum(alg.values())
     ms_step = dt / a.steps * 1e3
-    variant = "global-table K1 (variant 1)" if cfgno == 5 else "partitioned K1 (variant 0)"
+    variant = ("global-table K1 (variant 1)" if geo["k1_variant"] == 1 else
+               f"partitioned K1 (variant 0, {'8' if geo['k1_narrow'] else '16'}-byte records, {geo['partitions']} partitions)")
     res = {
         "metric": "L7 edge-events/s ingested->scored service-map", "value": Ev * a.steps / dt, "unit": "events/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -358,12 +404,13 @@ def bench_single(a, device):
                                f"{variant}; {nb}-batch HBM ring (value excludes PCIe: see end_to_end)",
                    "events_per_window": Ev, "edges_per_window": E, "nodes": N, "layers": L,
                    "events_dropped_cap": int(st.events_dropped_cap), "windows_in_flight": a.windows, "parallelism": "1 GPU"},
-        "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = k1a_partition + k1b_merge", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = " + " + ".join(kn), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": traffic_src, "traffic_measured_in_run": False, "measured_copy_GBs": copy_gbs,
+                     "traffic_source": traffic_src, "traffic_measured_in_run": False, "traffic_build_matches": traffic_match,
+                     "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
                      "algorithmic_bytes_per_launch": alg_k1, "avg_launch_us": k1_us,
-                     "k1a_partition_us": k1a[0], "k1b_merge_us": k1b[0], "launches": k1a[1]},
+                     "pass_a_us": k1a[0], "pass_b_us": k1b[0], "kernels": list(kn), "launches": k1a[1], "geometry": geo},
         "kernels": kernels,
         "window_algorithmic_bytes": b_total, "window_algorithmic_bytes_per_event": b_total / Ev,
         "window_algorithmic_GBs": b_total / (ms_step * 1e-3) / 1e9,
@@ -436,4 +483,4 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

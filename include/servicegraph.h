@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 2u   /* 2: sg_edge_out carries p50_us / p99_us, sg_config.flags, sg_window_hist; sg_flush_window_view was added
-                               later without a bump (a new symbol: a binding may dlsym it and fall back to sg_flush_window) */
+#define SG_ABI_VERSION 3u   /* 3: sg_config begins with its own size (a binding compiled against an older, shorter sg_config is
+                               detected instead of read past its end; members added later are zero for it), sg_geometry_get;
+                               2: sg_edge_out carries p50_us / p99_us, sg_config.flags, sg_window_hist, sg_flush_window_view */
 
 /* ---- return codes ---------------------------------------------------------------------- */
 #define SG_OK        0
@@ -148,6 +149,8 @@ typedef struct sg_edge_out {
 } sg_edge_out;
 
 typedef struct sg_config {
+    uint32_t struct_size;       /* sizeof(sg_config) as the CALLER compiled it.  sg_create accepts any size from the ABI-3
+                                   layout (88 bytes) up to its own; members beyond the caller's size read as zero         */
     uint32_t abi_version;       /* SG_ABI_VERSION                                              */
     int32_t  device;            /* HIP device ordinal                                          */
     uint32_t max_known_nodes;   /* capacity of the pod+service id space                        */
@@ -159,8 +162,11 @@ typedef struct sg_config {
     uint32_t layers;            /* GraphSAGE layers L, 1..SG_MAX_LAYERS                         */
     uint32_t rank;              /* this shard                                                   */
     uint32_t world;             /* number of shards (1 = unsharded)                             */
-    uint32_t k1_variant;        /* 0 = auto (partitioned LDS aggregation when the graph fits it),
-                                   1 = global edge table + device-scope atomics (any size)       */
+    uint32_t k1_variant;        /* 0 = auto: partitioned LDS aggregation when the graph fits it — 8-byte records sorted by
+                                       partition in LDS before they are written; with SG_CFG_EDGE_HISTOGRAM or a node space
+                                       beyond 2^24 the 16-byte-record form of 2,
+                                   1 = global edge table + device-scope atomics (any size),
+                                   2 = partitioned aggregation with 16-byte records (the round-2 kernels)      */
     uint64_t max_window_events; /* most events one window may carry (sizes the K1 record slabs;
                                    0 = max_batch)                                               */
     uint32_t windows_in_flight; /* 1..8 window slots, each with its own buffers and HIP stream:
@@ -318,6 +324,21 @@ int sg_window_outbound_ips(sg_handle h, uint32_t* ips, size_t cap, size_t* n);
 int sg_window_hist(sg_handle h, uint32_t* bins, size_t cap_rows, size_t* n);
 
 int sg_stats_get(sg_handle h, sg_stats* out);
+
+/* What sg_create chose for K1 (diagnostic: bench.py and the tuning scripts name the kernels they time with it). */
+typedef struct sg_geometry {
+    uint32_t k1_variant;        /* 0 partitioned aggregation, 1 global table + atomics                                      */
+    uint32_t k1_narrow;         /* variant 0: 1 = 8-byte records (k1a_tile_partition / k1b_stream_merge), 0 = 16-byte records */
+    uint32_t partitions;        /* np                                                                                        */
+    uint32_t table_slots;       /* pass B: LDS table slots per partition                                                     */
+    uint32_t pass_a_workgroups; /* pieces per partition                                                                      */
+    uint32_t cache_slots;       /* pass A: LDS edge-cache slots (follows the join tables' size)                              */
+    uint32_t join_l2_in_lds;    /* pass A: level 2 of the join staged in LDS (1) or read from global memory (0)              */
+    uint32_t tile_records;      /* narrow: records sorted per tile                                                           */
+    uint32_t endpoint_bits;     /* narrow: nb; remainder bits = 2 nb - log2(partitions)                                      */
+    uint32_t piece_bytes;       /* record slab bytes per (partition, workgroup) piece                                        */
+} sg_geometry;
+int sg_geometry_get(sg_handle h, sg_geometry* out);
 
 /* Per-kernel timing, measured on the launch stream.  Groups: 1 = K1 pass A (k1a_partition / k1_resolve_aggregate, one record
  * per batch), 7 = K1 pass B (k1b_merge) — both by the dispatch's own begin/end stamps; 2 = K2 csr_build (two records per window:

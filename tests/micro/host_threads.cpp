@@ -36,7 +36,7 @@ static void l7(uint8_t* r, uint32_t pid, uint64_t fd, uint8_t proto, uint8_t met
 
 int main() {
     sg_config cfg; std::memset(&cfg, 0, sizeof cfg);
-    cfg.max_known_nodes = 256; cfg.max_edges = 4096;
+    cfg.struct_size = sizeof cfg; cfg.abi_version = SG_ABI_VERSION; cfg.max_known_nodes = 256; cfg.max_edges = 4096;
     void* g = sgh_graphds_create(nullptr, &cfg, 64);
     if (!g) { std::fprintf(stderr, "create failed\n"); return 2; }
     for (int i = 0; i < 32; i++) { char uid[16], ip[16]; std::snprintf(uid, sizeof uid, "p%d", i); std::snprintf(ip, sizeof ip, "10.0.0.%d", i + 1); sgh_graphds_persist_pod(g, "ADD", uid, ip); }

@@ -74,7 +74,43 @@ static int run(int mode, bool blocks, u32 n_ips, u32 max_blocks, unsigned seed) 
     return 0;
 }
 
+// Level 1 grown INCREMENTALLY to its load limit (a failed l1_put used to drop a live /24 and leave a dangling entry
+// that the next allocation handed to another /24): a small or empty first build, then single upserts across 10..50 random
+// /24s; after every upsert-batch every IP must resolve to its own id.
+static int run_growth(unsigned seed) {
+    std::mt19937 rng(seed);
+    const u32 n_ips = 4000;
+    Layout L = Table::make_layout(n_ips, n_ips + 8, 64);
+    std::vector<u32> mem(L.words), shadow(L.words);
+    Table t; t.init(L, mem.data(), true);
+    std::vector<u32> all;
+    const u32 first = rng() % 3 == 0 ? 0 : 1 + rng() % 40;
+    for (u32 k = 0; k < first; k++) { const u32 ip = 0x0A000000u + ((rng() % 4) << 8) + rng() % 250; t.upsert(false, ip, k); all.push_back(ip); }
+    t.rebuild(); shadow.assign(t.blob, t.blob + L.words); t.uploaded_full();
+    const u32 nblk = 10 + rng() % 41;
+    std::vector<u32> blocks;
+    for (u32 k = 0; k < nblk; k++) blocks.push_back(rng() & 0xFFFFFFu);
+    u32 id = first;
+    for (int round = 0; round < 12; round++) {
+        for (int k = 0; k < 40 && id < n_ips; k++) {
+            const u32 ip = (blocks[rng() % nblk] << 8) | (1 + rng() % 250);
+            if (!t.upsert(rng() % 4 == 0, ip, id++)) { std::printf("growth: upsert failed\n"); return 1; }
+            all.push_back(ip);
+        }
+        if (t.need_full) { shadow.assign(t.blob, t.blob + L.words); t.uploaded_full(); }
+        else { std::vector<std::pair<u32, u32>> d; t.take_dirty(d); for (auto& kv : d) shadow[kv.first] = kv.second; }
+        if (check(t, shadow, all)) { std::printf("growth seed %u round %d (blocks_used %u l1 %u rebuilds %llu)\n", seed, round, t.blocks_used, t.l1_entries, (unsigned long long)t.rebuilds); return 1; }
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 2 && std::atoi(argv[2]) == 1) {                       // growth mode: argv[1] seeds
+        const int n = std::atoi(argv[1]);
+        for (int sd = 0; sd < n; sd++) if (run_growth(1000 + sd)) return 1;
+        std::printf("ok growth %d seeds\n", n);
+        return 0;
+    }
     const unsigned seed = argc > 1 ? (unsigned)std::atoi(argv[1]) : 1;
     int rc = 0;
     rc |= run(0, true, 15000, 512, seed);

@@ -25,7 +25,7 @@ def test_header_and_binding_declare_the_same_symbols():
 def test_library_builds_loads_and_exports_every_symbol(engine_lib):
     for name in _declared():
         assert hasattr(engine_lib, name), name
-    assert engine_lib.sg_abi_version() == engine.ABI_VERSION == 2
+    assert engine_lib.sg_abi_version() == engine.ABI_VERSION == 3
     from alaz_amd import weights
     assert engine_lib.sg_weights_count(1) == weights.weights_count(1) == 12993
     assert engine_lib.sg_weights_count(2) == weights.weights_count(2)
@@ -33,7 +33,8 @@ def test_library_builds_loads_and_exports_every_symbol(engine_lib):
 
 
 def test_struct_layouts_match_the_header():
-    assert C.sizeof(engine.SgConfig) == 80 and C.sizeof(engine.SgStats) == 136
+    assert C.sizeof(engine.SgConfig) == 88 and C.sizeof(engine.SgStats) == 136 and C.sizeof(engine.SgGeometry) == 40
+    assert engine.SgConfig.struct_size.offset == 0 and engine.SgConfig.abi_version.offset == 4 and engine.SgConfig.max_edges.offset == 32
     assert replay.EVENT_DTYPE.itemsize == 32 and replay.EDGE_OUT_DTYPE.itemsize == 64
     assert replay.EVENT_DTYPE.fields["duration_ns"][1] == 16 and replay.EVENT_DTYPE.fields["status"][1] == 12
     assert replay.EDGE_OUT_DTYPE.fields["from_ref"][1] == 24 and replay.EDGE_OUT_DTYPE.fields["score"][1] == 40
@@ -61,8 +62,13 @@ def test_no_cpu_fallback_create_fails_loudly(engine_lib):
 
 
 def test_bad_config_rejected(engine_lib):
-    cfg = engine.SgConfig(999, 0, 16, 16, 16, 16, 16, 16, 1, 0, 1, 0, 0, 1, 0)
+    cfg = engine.make_config(max_known_nodes=16, max_edges=16)
     h = C.c_void_p()
+    cfg.abi_version = 999
+    assert engine_lib.sg_create(C.byref(cfg), C.byref(h)) == engine.SG_EINVAL
+    cfg.abi_version = engine.ABI_VERSION; cfg.struct_size = 80          # an ABI-2 caller's sg_config: shorter than ABI 3's first layout
+    assert engine_lib.sg_create(C.byref(cfg), C.byref(h)) == engine.SG_EINVAL
+    cfg.struct_size = 0
     assert engine_lib.sg_create(C.byref(cfg), C.byref(h)) == engine.SG_EINVAL
     assert engine_lib.sg_create(None, C.byref(h)) == engine.SG_EINVAL
     assert engine_lib.sg_destroy(None) == engine.SG_EINVAL

@@ -77,7 +77,7 @@ def test_config1_full_reference_path():
     assert st.events_dropped_src == o.dropped_src > 0 and st.events_in == len(ev)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("layers", [1, 2])
 def test_edge_cases_mixed_trace(layers, variant):
     """raw-IP outbound, Host-header outbound, unknown sources, AMQP/Redis reversal, TLS, Kafka and
@@ -97,7 +97,7 @@ def test_edge_cases_mixed_trace(layers, variant):
     _run_both(topo, [ev1, ev2], lab_all, layers, chunk=7777, variant=variant)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_empty_and_tiny_windows(variant):
     topo = replay.make_topology(20, 40, seed=5)
     ev, labels = replay.make_events(topo, 3, seed=6)
@@ -105,7 +105,7 @@ def test_empty_and_tiny_windows(variant):
     assert g.stats().windows == 4
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_table_updates_between_windows(variant):
     """ADD / UPDATE / DELETE between windows (persist.go:55-71,114-130), incl. an IP that is both a
     pod and a service (service wins, data.go:840-849) and a deleted source (events dropped)."""
@@ -139,7 +139,7 @@ def test_table_updates_between_windows(variant):
     assert g.stats().events_dropped_src == o.dropped_src
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_config2_full_size_bit_exact_and_deterministic(variant):
     """BASELINE config 2 (1k pods / 50k edges / 1M events, L=1) against the oracle, run twice: the
     second run must reproduce the first bit for bit (integer atomics + canonical CSR order)."""
@@ -338,7 +338,7 @@ def test_cpp_graphds_end_to_end_from_wire_records():
     wire = bytes(wire)
     W = weights.make_weights(2)
     o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.l7_wire(wire, kafka); o.window_close(W, 2)
-    cfg = engine.SgConfig(engine.ABI_VERSION, 0, topo.n_nodes + 8, 256, 256, topo.n_nodes + 8, 4096, 1 << 16, 2, 0, 1, 0, 1 << 16, 1, 0)
+    cfg = engine.make_config(max_known_nodes=topo.n_nodes + 8, max_edges=4096, layers=2, max_outbound_ips=256, max_window_events=1 << 16)
     g = hostlib.GraphDS(cfg, batch=1000)
     g.set_clock(*CLOCK); g.load_weights(W)
     g.apply_ops(topo.k8s_ops())
@@ -461,7 +461,7 @@ def test_outbound_ip_capacity_overflow_is_counted():
     from oracle import pyoracle
     topo = replay.make_topology(40, 200, seed=81)
     ev, labels = replay.make_events(topo, 20_000, seed=82, with_raw_outbound=True)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         g = _engine(topo.n_nodes + 8, 4096, 1, max_outbound_ips=16, k1_variant=variant)
         shim = HostShim(); shim.apply(g, topo.k8s_ops())
         assert g.ingest(ev) == 0
@@ -650,7 +650,7 @@ def test_windows_in_flight_give_the_same_rows_as_one_window_at_a_time():
     assert g.flush_window().tobytes() == want[0].tobytes()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_alive_connections_are_count_only_edges(variant):
     """f-2: SG_EV_ALIVE records (open TCP connections, data.go:1628-1679) go through the same join — no Host
     header, no reversal, a non-pod source is ignored silently — create their edge if the window has no request
@@ -754,7 +754,7 @@ def test_sg_ingest_from_many_threads_into_one_engine():
     assert st.last_window_events == o.window_events and st.events_dropped_cap == 0
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_edge_latency_histogram_and_percentiles(variant):
     """f-3: with SG_CFG_EDGE_HISTOGRAM every edge carries a 16-bin log2 latency histogram and p50 / p99 read off
     it.  Bins and percentiles must equal the oracle's bit for bit — through pass A's cache (16-bit bins per launch, aggregates
@@ -922,7 +922,7 @@ def test_random_small_windows_against_the_oracle(seed):
     from alaz_amd import engine
     rng = np.random.default_rng(9000 + seed)
     pods = int(rng.integers(5, 400)); edges = int(rng.integers(pods, min(pods * 12, pods * (pods + pods // 2 - 1)) + 1))
-    layers = 1 + seed % 2; variant = (seed // 2) % 2; hist = (seed // 4) % 2 == 1
+    layers = 1 + seed % 2; variant = (seed // 2) % 3; hist = (seed // 6) % 2 == 1
     topo = replay.make_topology(pods, edges, seed=9100 + seed)
     ops = topo.k8s_ops()
     g = _engine(topo.n_nodes + 64, 1 << 14, layers, k1_variant=variant, max_window_events=40_000, edge_histogram=hist)

@@ -16,7 +16,7 @@ def _built():
 
 
 def _cfg(nodes=256, edges=4096):
-    return engine.SgConfig(engine.ABI_VERSION, 0, nodes, 256, 64, nodes, edges, 1 << 16, 1, 0, 1, 0, 0, 1, 0)
+    return engine.make_config(max_known_nodes=nodes, max_edges=edges)
 
 
 @pytest.mark.parametrize("req", [b"GET /user HTTP1.1", b"GET /a HTTP/1.1\r\nHost: example.com\r\nX: y\r\n\r\n",

@@ -421,7 +421,7 @@ def test_http2_records_through_packer_equal_the_oracle_wire_path():
 
 
 def test_graphds_ingest_wire_assembles_http2_and_tcp_close_drops_the_parser():
-    cfg = engine.SgConfig(engine.ABI_VERSION, 0, 256, 256, 64, 256, 4096, 1 << 16, 1, 0, 1, 0, 0, 1, 0)
+    cfg = engine.make_config(max_known_nodes=256, max_edges=4096)
     g = hostlib.GraphDS(cfg, engine_lib=None)
     g.PersistPod("p1", "10.0.0.1"); g.PersistService("s1", "10.96.0.1")
     A, S = 0x0A000001, 0x0A600001

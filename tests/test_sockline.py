@@ -187,7 +187,7 @@ def test_cpp_tracker_feeds_alive_records_to_the_engine_boundary():
         recs.append((E if rng.random() < 0.6 else (Cl if rng.random() < 0.9 else 3), pid, fd, 1000 + 10 * k, s, 30000 + k, d, 80))
     wire = _tcp_wire(recs)
     o = pyoracle.Oracle(0, 0, log_limit=10_000)
-    cfg = engine.SgConfig(engine.ABI_VERSION, 0, 64, 64, 64, 64, 1024, 1 << 16, 1, 0, 1, 0, 0, 1, 0)
+    cfg = engine.make_config(max_known_nodes=64, max_edges=1024, max_labels=64)
     g = hostlib.GraphDS(cfg, engine_lib=None, batch=1)
     for i in range(1, 5):
         o.pod("ADD", f"pod-{i}", f"10.0.0.{i}"); g.PersistPod(f"pod-{i}", f"10.0.0.{i}")

@@ -57,8 +57,8 @@ def main():
     wire = np.frombuffer(replay.to_wire(ev, labels), dtype=np.uint8).copy()
     n_nodes = len(pod_ips) + len(svc_ips)
     max_edges = int(c["edges"] * 1.1) if not a.pods else max(1 << 16, 4 * (a.edges or a.pods * 20))
-    cfg = engine.SgConfig(engine.ABI_VERSION, 0, n_nodes + 1024, 256, 256, n_nodes + 1024, max_edges, 1 << 18, c["layers"], 0, 1, 0,
-                          int(a.rate * a.window_s * 1.5), 3, 0, 0)
+    cfg = engine.make_config(max_known_nodes=n_nodes + 1024, max_edges=max_edges, layers=c["layers"], max_labels=256, max_outbound_ips=256,
+                             max_batch=1 << 18, max_window_events=int(a.rate * a.window_s * 1.5), windows_in_flight=3)
     t0 = time.perf_counter()
     g = hostlib.GraphDS(cfg, batch=a.chunk, **({"engine_lib": None} if a.mock else {}))
     if not a.mock:

@@ -1,11 +1,24 @@
 #!/usr/bin/env python3
-"""Fold the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc.sh into profiles-style JSON:
+"""Fold the FETCH_SIZE / WRITE_SIZE passes of `tools/gpu.sh pmc:TAG:CONFIG` into profiles-style JSON:
 HBM bytes per launch of the two K1 kernels (bench.py reads it for roofline.traffic).
 
 Corrections (MI355X_MICROARCH.md, HBM section): counter values are KiB; on gfx950 FETCH_SIZE reports
-half the bytes of a wide coalesced 16 B/lane streaming read, so the event stream of k1a_partition is
-doubled; k1b_merge's piece reads and every WRITE_SIZE are uncalibrated and taken as reported."""
-import csv, glob, json, os, sys
+half the bytes of a wide coalesced 16 B/lane streaming read, so the event stream of pass A is doubled; pass B's
+piece reads and every WRITE_SIZE are uncalibrated and taken as reported.  The JSON carries the git HEAD the
+caller names and a hash of the kernel sources, so that bench.py can say whether the counters belong to the
+build it is timing (`traffic_build_matches`)."""
+import csv, glob, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_src_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "alaz_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 from collections import defaultdict
 
 
@@ -27,16 +40,18 @@ def pick(m, prefix):
 
 def main():
     fdir, wdir, config, tag = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    head = sys.argv[5] if len(sys.argv) > 5 else "unknown"
     F, W = avg(fdir, "FETCH_SIZE"), avg(wdir, "WRITE_SIZE")
-    out = {"round": tag, "config": int(config),
+    out = {"round": tag, "config": int(config), "git_head": head, "kernel_src_sha": kernel_src_sha(),
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --profile-mode",
            "unit_note": "counter values are KiB; k1a FETCH_SIZE doubled (gfx950 reports half of a coalesced 16 B/lane stream); "
                         "k1b FETCH_SIZE and all WRITE_SIZE taken as reported (uncalibrated)"}
     tot = 0.0
-    for name, key, fmul in (("k1a_partition", "k1a_partition", 2.0), ("k1b_merge", "k1b_merge", 1.0)):
+    for name, key, fmul in (("k1a", "k1a_", 2.0), ("k1b", "k1b_", 1.0)):
         f, nf = pick(F, key); w, nw = pick(W, key)
         b = (fmul * f + w) * 1024.0
-        out[name] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "launches": [nf, nw], "hbm_bytes": int(b)}
+        kname = next((k.split("(")[0] for k in F if key in k), key)
+        out[name] = {"kernel": kname, "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "launches": [nf, nw], "hbm_bytes": int(b)}
         tot += b
     out["k1_total_hbm_bytes"] = int(tot)
     print(json.dumps(out, indent=1))

@@ -25,9 +25,10 @@ for i in range(6):
     g.ingest_device(dev[i % 3].data_ptr(), Ev, 0); g.window_run(0)
 torch.cuda.synchronize()
 st = g.debug_stamps()
+print("geometry", g.geometry())
 names = {0: ["start", "tables staged+barrier", "-", "events folded", "barrier", "cache flushed, headers", "stats"],
          1: ["start", "headers+table zeroed", "-", "merged+barrier", "overflow list", "compacted+barrier"]}
-for kid, kname in ((0, "k1a_partition"), (1, "k1b_merge")):
+for kid, kname in zip((0, 1), g.k1_kernels()):
     a = st[kid].astype(np.int64)
     live = a[:, 0] != 0
     a = a[live]
