@@ -322,13 +322,15 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         const bool tk = (e->timing >> 7) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
-        const bool share = d.np > e->k1b_cus && 2 * e->k1b_lds <= kLdsBytes;   // several partitions per CU and room for two tables: the SGPR-capped build lets two workgroups share a CU
+        const bool share = d.npb > e->k1b_cus && 2 * e->k1b_lds <= kLdsBytes;   // several partitions per CU and room for two tables: the SGPR-capped build lets two workgroups share a CU
 #define K1B_GO(U_, H_) do { if (share) hipExtLaunchKernelGGL((k1b_merge<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
                             else hipExtLaunchKernelGGL((k1b_merge_wide<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
-#define K1B8_GO(U_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
-                         else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
-        if (d.narrow) { if (e->k1b_u == 8) K1B8_GO(8); else K1B8_GO(4); }
+#define K1B8_GO(U_, SPT_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_>), dim3(d.npb), dim3(1024), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
+                               else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_>), dim3(d.npb), dim3(1024), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
+#define K1B8_GO2(U_) do { if (d.k1b_ht == 4096) K1B8_GO(U_, 4); else if (d.k1b_ht == 2048) K1B8_GO(U_, 2); else K1B8_GO(U_, 1); } while (0)
+        if (d.narrow) { if (e->k1b_u == 8) K1B8_GO2(8); else K1B8_GO2(4); }
         else if (d.hist) K1B_GO(4, true); else if (e->k1b_u == 8) K1B_GO(8, false); else K1B_GO(4, false);
+#undef K1B8_GO2
 #undef K1B8_GO
 #undef K1B_GO
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
@@ -343,7 +345,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         }
         hipLaunchKernelGGL(k2_rowptr, dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, d, ++e->rp_epoch);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
-        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.np), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, s, d);
         hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 0, s, d);
     }
     {
@@ -542,8 +544,13 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             u32 pbt = 0; while ((1ull << pbt) < np) pbt++;
             if (np > 2048 || 2 * nb - pbt > 31) narrow = false;          // (one wave scans the run lengths: beyond this the 16-byte kernels / variant 1)
         }
+        d.k1b_split = 1;
         if (narrow) {
-            d.k1b_ht = ME / np > 1150 ? 4096 : (ME / np > 550 ? 2048 : 1024);
+            // pass B: a partition that may hold more than ~1150 edges is merged by TWO workgroups (sub-tables of 2048 slots, two
+            // workgroups per CU) rather than by one with a 4096-slot table that owns the CU alone
+            if (ME / np > 1150) { d.k1b_split = 2; d.k1b_ht = 2048; }
+            else d.k1b_ht = ME / np > 550 ? 2048 : 1024;
+            if (const char* v = std::getenv("SG_SPLIT")) { const int x = std::atoi(v); if (x == 1 || x == 2) { d.k1b_split = (u32)x; d.k1b_ht = ME / (np * x) > 1150 ? 4096 : (ME / (np * x) > 550 ? 2048 : 1024); } }
         } else {
             // 16-byte records: at most ~1250 distinct edges per partition (pass B's LDS table: 2048 slots, 1536 may fill; 1024 slots
             // for small graphs), at least one per CU.  C3 with 1024 partitions 181 us, 2048: 198 us, 4096: 292 us.
@@ -561,8 +568,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         d.pb = 0; while ((1u << d.pb) < d.np) d.pb++;
         if (narrow && 2 * nb - d.pb > 31) { d.np = (u32)np; d.pb = 0; while ((1u << d.pb) < d.np) d.pb++; }   // an SG_NP override that would not leave 31 remainder bits
         d.narrow = (narrow && d.variant == 0) ? 1u : 0u;
+        if (!d.narrow) d.k1b_split = 1;
+        d.npb = d.np * d.k1b_split;
         d.nb = nb; d.rb = 2 * nb - d.pb;
-        d.pcap = d.k1b_ht * 3 / 4;
+        d.pcap = d.narrow ? d.k1b_ht * 13 / 16 : d.k1b_ht * 3 / 4;       // (u32 keys probe cheaply: the narrow tables may fill to 0.81)
         const double m = (double)e->cfg.max_window_events / ((double)d.np * d.nwg);
         d.sa = std::min<u32>(24, std::max<u32>(8, (2 * 2048 / d.np + 6 + 1) & ~1u));   // aggregates per piece: cache slots / partitions, with head room
         if (d.narrow) {
@@ -581,8 +590,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         }
         d.ovf_cap = 1u << 16;
         e->k1b_threads = 1024u;                                          // measured: 1024 threads beat 2 x 512 (C3 135 vs 153 us, C2 15.5 vs 22.9 us)
+        // narrow pass B: 8 x 16 bytes per lane in flight where a CU holds one table anyway; two workgroups per CU need <= 64 VGPRs
+        if (d.narrow) e->k1b_u = ((size_t)d.k1b_ht * 36 + 8) * 2 > kLdsBytes && m > 24.0 ? 8 : 4;
         if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; if (std::atoi(v) == 4) e->k1b_u = 4; }
-        else if (d.narrow && m > 24.0) e->k1b_u = 8;                     // 8 x 16 bytes per lane in flight = 64 records per piece and round
         if (const char* v = std::getenv("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if (x == 256 || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
     }
     // join tables: word image (join_host.hpp) on the host, one device copy, a pinned ring for word updates
@@ -619,8 +629,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
         for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>),
                               reinterpret_cast<const void*>(k1b_merge_wide<4, false>), reinterpret_cast<const void*>(k1b_merge_wide<8, false>), reinterpret_cast<const void*>(k1b_merge_wide<4, true>),
-                              reinterpret_cast<const void*>(k1b_stream_merge<4>), reinterpret_cast<const void*>(k1b_stream_merge<8>),
-                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8>)})
+                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<8, 1>), reinterpret_cast<const void*>(k1b_stream_merge<8, 2>), reinterpret_cast<const void*>(k1b_stream_merge<8, 4>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 4>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }
@@ -638,14 +650,14 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
 #define LR(call) do { int _rc = (call); if (_rc) return _rc; } while (0)
         size_t eslots = ME;
         if (w.variant == 0) {
-            eslots = std::max<size_t>(ME, (size_t)w.np * w.pcap);
+            eslots = std::max<size_t>(ME, (size_t)w.npb * w.pcap);
             if (w.narrow) { LR(dev_alloc(e, &w.slab8, (size_t)w.np * w.nwg * w.punits)); LR(dev_alloc(e, &w.hdr8, (size_t)w.np * w.nwg)); }
             else { LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * w.pslots)); LR(dev_alloc(e, &w.hdr, (size_t)w.np * w.nwg)); }
             LR(dev_alloc(e, &w.ovf, (size_t)w.ovf_cap * 9));
             LR(dev_alloc(e, &w.ovf_p, (size_t)w.ovf_cap));
-            LR(dev_alloc(e, &w.part_n, w.np));
-            LR(dev_alloc(e, &w.acc_src, (size_t)w.np * w.pcap * 4));
-            LR(dev_alloc(e, &w.e_rank, (size_t)w.np * w.pcap));
+            LR(dev_alloc(e, &w.part_n, w.npb));
+            LR(dev_alloc(e, &w.acc_src, (size_t)w.npb * w.pcap * 4));
+            LR(dev_alloc(e, &w.e_rank, (size_t)w.npb * w.pcap));
         }
         LR(dev_alloc(e, &w.ekeys, e->ecap, 0xFF));
         LR(dev_alloc(e, &w.eacc, (size_t)e->ecap * 4));
@@ -664,7 +676,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cs, ME)); LR(dev_alloc(e, &w.csr_from, ME));
         LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));
-        if (w.hist) { LR(dev_alloc(e, &w.hist_src, (w.variant == 0 ? (size_t)w.np * w.pcap : (size_t)e->ecap) * SG_HIST_BINS)); LR(dev_alloc(e, &w.hist_csr, ME * SG_HIST_BINS)); }
+        if (w.hist) { LR(dev_alloc(e, &w.hist_src, (w.variant == 0 ? (size_t)w.npb * w.pcap : (size_t)e->ecap) * SG_HIST_BINS)); LR(dev_alloc(e, &w.hist_csr, ME * SG_HIST_BINS)); }
         LR(dev_alloc(e, &w.st_sum, (size_t)w.ncap * SG_NODE_STAT_SUM_WORDS)); LR(dev_alloc(e, &w.st_max, (size_t)w.ncap * SG_NODE_STAT_MAX_WORDS));
         LR(dev_alloc(e, &w.x0, (size_t)w.ncap * SG_F_IN));
         for (u32 l = 1; l <= cfg->layers; l++) LR(dev_alloc(e, &w.h[l], (size_t)w.ncap * SG_F_HID));
@@ -743,7 +755,7 @@ int sg_geometry_get(sg_handle e, sg_geometry* out) {
     if (!e || !out) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
     const Dev& d = e->d;
-    out->k1_variant = d.variant; out->k1_narrow = d.narrow; out->partitions = d.np; out->table_slots = d.k1b_ht;
+    out->k1_variant = d.variant; out->k1_narrow = d.narrow; out->partitions = d.np; out->table_slots = d.k1b_ht; out->pass_b_split = d.k1b_split;
     out->pass_a_workgroups = d.nwg; out->cache_slots = e->k1a_ct; out->join_l2_in_lds = e->l2_in_lds ? 1u : 0u;
     out->tile_records = d.narrow ? K1T_TS : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
     out->piece_bytes = d.variant != 0 ? 0u : (d.narrow ? d.punits * 8u : d.pslots * 16u);

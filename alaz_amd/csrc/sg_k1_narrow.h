@@ -93,23 +93,29 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     const u32* l2 = L2LDS ? reinterpret_cast<const u32*>(l1 + d.jl1mask + 1) : d.jl2;
     const u32 w = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
+    // The batch is cut into chunks of `chunk` events (1024 .. 4096, a multiple of 1024: up to four events per lane and group);
+    // chunk c belongs to workgroup c % nwg.  At any moment the 256 workgroups therefore read ONE contiguous stretch of the batch
+    // (256 x 128 KB) instead of 256 streams 1.25 MB apart (which lean on a few HBM channels at a time), and a small batch
+    // (n <= 1024 nwg) still gives every workgroup its 1024 events, so the pieces of a window fed by many small batches fill evenly.
     const u64 per = (n + d.nwg - 1) / d.nwg;
-    const u64 beg = (u64)w * per, end = (beg + per < n) ? beg + per : n;
+    const u32 chunk = per >= 4096 ? 4096u : (u32)((per + 1023) / 1024 * 1024);
+    const u64 nchunk = (n + chunk - 1) / chunk;
+    const u64 end = n;
     const bool first = d.batch_state == 1u;                          // first batch of the window: the headers are zero by definition
-    if (beg >= end) {                                                // no share of this batch: pieces and statistics stay as they are,
+    if ((u64)w >= nchunk) {                                          // no share of this batch: pieces and statistics stay as they are,
         if (first) for (u32 p = t; p < NP; p += K1T_THREADS) d.hdr8[(size_t)p * d.nwg + w] = make_uint2(0u, 0u);   // but stale headers must go
         return;
     }
-    const u64 last = end - 1;
     SG_STAMP(d, 0, 0);
     K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = L.lost = 0;
     const u32 nb = d.nb, nbmask = (1u << nb) - 1u, pshift = nb - d.pb, rbmask = (1u << d.rb) - 1u, bmask = CT / 2 - 1;
     const bool ck_any = d.ck_n != 0;
 
-#define K1T_ISSUE(base)                                                                                           \
+    // events (base) + k * 1024, k = 0..3, below `cend`; out-of-range lanes re-read the chunk's first event and ignore it
+#define K1T_ISSUE(base, cend, cfirst)                                                                             \
         { const u64 j0 = (base), j1 = j0 + K1T_THREADS, j2 = j1 + K1T_THREADS, j3 = j2 + K1T_THREADS;               \
-          const uint4* q0 = pe + 2 * (j0 < end ? j0 : last); const uint4* q1 = pe + 2 * (j1 < end ? j1 : last);     \
-          const uint4* q2 = pe + 2 * (j2 < end ? j2 : last); const uint4* q3 = pe + 2 * (j3 < end ? j3 : last);     \
+          const uint4* q0 = pe + 2 * (j0 < (cend) ? j0 : (cfirst)); const uint4* q1 = pe + 2 * (j1 < (cend) ? j1 : (cfirst)); \
+          const uint4* q2 = pe + 2 * (j2 < (cend) ? j2 : (cfirst)); const uint4* q3 = pe + 2 * (j3 < (cend) ? j3 : (cfirst)); \
           gload16_issue(ea0, q0); gload16_issue(eb0, q0 + 1); gload16_issue(ea1, q1); gload16_issue(eb1, q1 + 1);   \
           gload16_issue(ea2, q2); gload16_issue(eb2, q2 + 1); gload16_issue(ea3, q3); gload16_issue(eb3, q3 + 1); }
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory")   /* LDS-only: does not drain the global stores */
@@ -152,8 +158,8 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     };
     // The fast path, one event: branch-free join (two-level block table in LDS), data.go:827-870 as selects, key mix,
     // read-only cache probe.  `rare` hands the event to the general path instead.
-    auto fast = [&](const u64 idx, const v4u_t va, const v4u_t vb, u32* bc, bool& rare_out, u32& slo, u32& shi, u32& spr) {
-        const bool inr = idx < end;
+    auto fast = [&](const u64 idx, const u64 cend, const v4u_t va, const v4u_t vb, u32* bc, bool& rare_out, u32& slo, u32& shi, u32& spr) {
+        const bool inr = idx < cend;
         const u32 flags = va.w >> 24, label = va.z;
         const u32 vs = join(va.x), vd = join(va.y);
         const u32 ks = vs >> 30, kd = vd >> 30;
@@ -184,11 +190,11 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
             slo = dur; shi = ((u32)mk & rbmask) | (err << 31); spr = part | (rank << K1T_RANK_SHIFT);
         }
     };
-#define K1T_FOLD(base, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3)                                \
+#define K1T_FOLD(base, cend, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3)                          \
         { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(eb0), "+v"(ea1), "+v"(eb1), "+v"(ea2), "+v"(eb2), "+v"(ea3), "+v"(eb3) : : "memory"); \
           bool r0, r1, r2, r3;                                                                                      \
-          fast((base), ea0, eb0, (bc), r0, lo0, hi0, pr0); fast((base) + K1T_THREADS, ea1, eb1, (bc), r1, lo1, hi1, pr1); \
-          fast((base) + 2 * K1T_THREADS, ea2, eb2, (bc), r2, lo2, hi2, pr2); fast((base) + 3 * K1T_THREADS, ea3, eb3, (bc), r3, lo3, hi3, pr3); \
+          fast((base), (cend), ea0, eb0, (bc), r0, lo0, hi0, pr0); fast((base) + K1T_THREADS, (cend), ea1, eb1, (bc), r1, lo1, hi1, pr1); \
+          fast((base) + 2 * K1T_THREADS, (cend), ea2, eb2, (bc), r2, lo2, hi2, pr2); fast((base) + 3 * K1T_THREADS, (cend), ea3, eb3, (bc), r3, lo3, hi3, pr3); \
           if (__builtin_amdgcn_ballot_w64(r0 | r1 | r2 | r3)) {             /* one copy of the general path: register selects */ \
               _Pragma("unroll 1")                                                                                   \
               for (u32 q = 0; q < 4; q++) {                                                                         \
@@ -239,19 +245,26 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     }
     const u32 bpw = NP >> 4;                                         // partitions whose runs a wave writes out (np >= 64)
     u32 cur = 0;
-    for (u64 base = beg; base < end; base += K1T_TS, cur ^= 1u) {
+    u64 tk_p1 = 0, tk_wait = 0;                                      // SG_ABLATE & 0x100: wave 0's clock ticks in P1 / at the barrier behind it
+    for (u64 c0 = w; c0 < nchunk; c0 += 2 * (u64)d.nwg, cur ^= 1u) {
         u32* bc = bcnt + cur * NP;
         u32 lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7;
-        {   // P1: two groups of four events per thread
+        const u64 tk0 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
+        {   // P1: two chunks of up to four events per thread
             v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
-            const u64 i0 = base + t;
-            K1T_ISSUE(i0);
-            K1T_FOLD(i0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
-            const u64 i1 = i0 + 4 * K1T_THREADS;
-            K1T_ISSUE(i1);
-            K1T_FOLD(i1, bc, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7);
+            const u64 cb0 = c0 * chunk, ce0 = cb0 + chunk < end ? cb0 + chunk : end;
+            const u64 i0 = cb0 + t;
+            K1T_ISSUE(i0, ce0, cb0);
+            K1T_FOLD(i0, ce0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
+            const u64 c1 = c0 + d.nwg;
+            const u64 cb1 = c1 < nchunk ? c1 * chunk : cb0, ce1 = c1 < nchunk ? (cb1 + chunk < end ? cb1 + chunk : end) : cb0;   // no second chunk: an empty range
+            const u64 i1 = cb1 + t;
+            K1T_ISSUE(i1, ce1, cb1);
+            K1T_FOLD(i1, ce1, bc, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7);
         }
+        const u64 tk1 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         LDS_BARRIER();
+        if (d.ablate & 0x100u) { const u64 tk2 = wall_clock64(); tk_p1 += tk1 - tk0; tk_wait += tk2 - tk1; }
         if (wave == 0) {                                             // P2: exclusive scan of the run lengths (np / 64 per lane)
             const u32 pl = NP >> 6, b0 = lane * pl;
             u32 s = 0;
@@ -282,6 +295,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         }
     }
     SG_STAMP(d, 0, 3);
+    if ((d.ablate & 0x100u) && t == 0 && blockIdx.x < 4096) { u64* g = d.dbg + ((size_t)0 * 4096 + blockIdx.x) * 8; g[2] = tk_p1; g[7] = tk_wait; }
 #undef K1T_ISSUE
 #undef K1T_FOLD
     LDS_BARRIER();
@@ -329,20 +343,31 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
 }
 
 // ---- pass B ---------------------------------------------------------------------------------------------------------
-// Workgroup p owns partition p.  It reads the record counts of its nwg pieces, then exactly the records that exist — U
-// 16-byte loads (two narrow records each) per lane in flight, the lanes of a piece side by side —, merges them in an LDS
-// table keyed by the u32 remainder and writes every distinct edge once with plain stores; the endpoints come back out of the
-// key with sg_kunmix.  Outputs as k1b_merge: e_from / e_to / acc_src / e_rank per partition slot, deg[from][replica].
-// LDS: hacc[4][HT] u64 | hkey[HT] u32 | two counters: 36 bytes per slot.
-template <int U>
+// Workgroup q = p * S + s owns SUB-TABLE s of partition p (S = d.k1b_split = 1 or 2; the top remainder bit picks the
+// sub-table): pass A wants few partitions (long runs per tile), pass B wants tables small enough for two workgroups per CU
+// — with S = 2 both workgroups of a partition read all of its records (the second read comes out of L2 / the Infinity Cache:
+// the two are 8 blocks apart, i.e. on the same XCD, and start together) and each merges the half that is its own.
+// A workgroup reads the record counts of the partition's nwg pieces, then exactly the records that exist — U 16-byte loads
+// (two narrow records each) per lane in flight, the lanes of a piece side by side —, merges them in an LDS table keyed by the
+// u32 remainder and writes every distinct edge once with plain stores; the endpoints come back out of the key with
+// sg_kunmix.  Outputs as k1b_merge, per OUTPUT partition q: e_from / e_to / acc_src / e_rank, part_n[q], deg[from][replica].
+// Narrow records first — their durations are below 2^32, so count, error count and max are 32-bit LDS atomics on the low
+// words of the accumulators —, then, behind a barrier, the wide singles, aggregates and overflow records with 64-bit ones.
+// LDS: hacc[4][HT] u64 | hkey[HT] u32 | two counters: 36 bytes per slot.  SPT = table slots per thread in the compaction
+// (HT / threads): one round, all returning `deg` atomics of a thread in flight together.
+template <int U, int SPT>
 __device__ __forceinline__ void k1b8_body(const Dev& d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 HT = d.k1b_ht, hmask = HT - 1;
     u64* hacc = reinterpret_cast<u64*>(smem);                        // [4][HT]: accumulator j of slot h at j*HT + h
     u32* hkey = reinterpret_cast<u32*>(hacc + (size_t)HT * 4);       // [HT] remainders, all ones = empty
     u32* n_drop = hkey + HT; u32* out_n = n_drop + 1;
-    const u32 p = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
-    const u32 nb = d.nb, nbmask = (1u << nb) - 1u, rbmask = (1u << d.rb) - 1u;
+    const u32 t = threadIdx.x, NT = blockDim.x;
+    // q -> (partition, sub-table): blocks b and b + 8 run on the same XCD (b % 8) and are dispatched back to back
+    const u32 S = d.k1b_split, q = blockIdx.x;
+    const u32 p = S == 2 ? ((q >> 4) << 3) | (q & 7u) : q, sidx = S == 2 ? (q >> 3) & 1u : 0u;
+    const u32 oq = p * S + sidx;                                     // output partition
+    const u32 nb = d.nb, nbmask = (1u << nb) - 1u, rbmask = (1u << d.rb) - 1u, sbit = d.rb - 1;
     SG_STAMP(d, 1, 0);
     const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
     const u32 LPP = NT > d.nwg ? NT / d.nwg : 1u;                    // lanes per piece
@@ -366,29 +391,43 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     __syncthreads();
     SG_STAMP(d, 1, 1);
 
-    auto add = [&](u32 rem, u64 a0, u64 a1, u64 a2, u64 a3) {
-        u32 h = rem & hmask; bool ok = false;
+    // slot of a key (find or insert), or HT when the table is full
+    auto slot_of = [&](u32 rem) -> u32 {
+        u32 h = rem & hmask;
         for (u32 it = 0; it < HT; it++) {
             u32 k = lds_fresh_u32(&hkey[h]);
             if (k == 0xFFFFFFFFu) { k = atomicCAS(&hkey[h], 0xFFFFFFFFu, rem); if (k == 0xFFFFFFFFu) k = rem; }
-            if (k == rem) { ok = true; break; }
+            if (k == rem) return h;
             h = (h + 1) & hmask;
         }
-        if (!ok) { atomicAdd(n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
-        atomicAdd(&hacc[h], a0); atomicAdd(&hacc[HT + h], a1); atomicMax(&hacc[2 * HT + h], a2); atomicAdd(&hacc[3 * HT + h], a3);
+        return HT;
     };
+    auto mine = [&](u32 rem) -> bool { return S == 1 || ((rem >> sbit) & 1u) == sidx; };
+    u32* hacc32 = reinterpret_cast<u32*>(hacc);                       // low word of accumulator j of slot h: 2 * (j*HT + h)
     auto add_narrow = [&](u32 lo, u32 hi) {
+        const u32 rem = hi & rbmask;
+        if (!mine(rem) || (d.ablate & 0x10u)) return;
+        const u32 h = slot_of(rem);
+        if (h == HT) { atomicAdd(n_drop, 1u); return; }
         const u32 us = div1000_u32(lo);
-        if (!(d.ablate & 0x10u)) add(hi & rbmask, 1ull | ((u64)(hi >> 31) << 32), (u64)lo, (u64)lo, (u64)us * (u64)us);
+        atomicAdd(&hacc32[2 * h], 1u);                               // count (low word of accumulator 0)
+        if (hi >> 31) atomicAdd(&hacc32[2 * h + 1], 1u);             // errors (high word)
+        atomicAdd(&hacc[HT + h], (u64)lo);
+        atomicMax(&hacc32[2 * (2 * HT + h)], lo);                    // max: no wide record has touched the table yet
+        atomicAdd(&hacc[3 * HT + h], (u64)us * (u64)us);
+    };
+    auto add_wide = [&](u32 rem, u64 a0, u64 a1, u64 a2, u64 a3) {
+        if (!mine(rem)) return;
+        const u32 h = slot_of(rem);
+        if (h == HT) { atomicAdd(n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
+        atomicAdd(&hacc[h], a0); atomicAdd(&hacc[HT + h], a1); atomicMax(&hacc[2 * HT + h], a2); atomicAdd(&hacc[3 * HT + h], a3);
     };
     for (u32 w = w0; w < d.nwg; w += NT / LPP) {
         const uint2 h = w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w];
         const u32 nn = h.x < d.sn ? h.x : d.sn;
-        const u32 nw = (h.y & 0xFFFFu) < d.sw ? (h.y & 0xFFFFu) : d.sw, na = (h.y >> 16) < d.sa ? (h.y >> 16) : d.sa;
-        if (!(nn | nw | na)) continue;
-        const u64* piece = piece8(d, p, w);
-        const uint4* pairs = reinterpret_cast<const uint4*>(piece);
-        const u32 npair = (nn + 1) >> 1, lastp = npair ? npair - 1 : 0;
+        if (!nn) continue;
+        const uint4* pairs = reinterpret_cast<const uint4*>(piece8(d, p, w));
+        const u32 npair = (nn + 1) >> 1, lastp = npair - 1;
         for (u32 r0 = sub; r0 < npair; r0 += LPP * U) {
             uint4 x[U];
             if (w == w0 && r0 == sub) {
@@ -404,59 +443,65 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
                 if (r < npair) { add_narrow(x[u].x, x[u].y); if (2 * r + 1 < nn) add_narrow(x[u].z, x[u].w); }
             }
         }
+    }
+    __syncthreads();                                                 // every 32-bit max is in: 64-bit updates may follow
+    SG_STAMP(d, 1, 3);
+    for (u32 w = w0; w < d.nwg; w += NT / LPP) {
+        const uint2 h = w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w];
+        const u32 nw = (h.y & 0xFFFFu) < d.sw ? (h.y & 0xFFFFu) : d.sw, na = (h.y >> 16) < d.sa ? (h.y >> 16) : d.sa;
+        if (!(nw | na)) continue;
+        const u64* piece = piece8(d, p, w);
         for (u32 r = sub; r < nw; r += LPP) {
-            const uint4 q = reinterpret_cast<const uint4*>(piece + d.sn)[r];
-            const u32 dhi = q.w & 0x3FFFFFFFu;
-            const u64 dur = (u64)q.z | ((u64)dhi << 32);
+            const uint4 x = reinterpret_cast<const uint4*>(piece + d.sn)[r];
+            const u32 dhi = x.w & 0x3FFFFFFFu;
+            const u64 dur = (u64)x.z | ((u64)dhi << 32);
             const u64 us = dur / 1000ull;
-            const u64 one = ((q.w >> 30) & 1u) ? 0ull : 1ull;            // bit 62: edge-only record (SG_EV_ALIVE)
-            add(q.x & rbmask, one | ((u64)(q.w >> 31) << 32), dur, dur, us * us);
+            const u64 one = ((x.w >> 30) & 1u) ? 0ull : 1ull;            // bit 62: edge-only record (SG_EV_ALIVE)
+            add_wide(x.x & rbmask, one | ((u64)(x.w >> 31) << 32), dur, dur, us * us);
         }
         for (u32 r = sub; r < na; r += LPP) {
-            const u64* q = piece + d.sn + 2 * d.sw + 5 * r;
-            add((u32)q[0] & rbmask, q[1], q[2], q[3], q[4]);
+            const u64* a = piece + d.sn + 2 * d.sw + 5 * r;
+            add_wide((u32)a[0] & rbmask, a[1], a[2], a[3], a[4]);
         }
     }
-    __syncthreads();
-    SG_STAMP(d, 1, 3);
     if (ovf_n) {
         const u64 no = ovf_n < d.ovf_cap ? ovf_n : d.ovf_cap;
         for (u64 i = t; i < no; i += NT) {
             if (d.ovf_p[i] != p) continue;
             const u64* o = d.ovf + i * 9;
-            add((u32)o[0] & rbmask, o[1], o[2], o[3], o[4]);
+            add_wide((u32)o[0] & rbmask, o[1], o[2], o[3], o[4]);
         }
-        __syncthreads();
     }
+    __syncthreads();
     SG_STAMP(d, 1, 4);
-    // compaction: two table slots per thread and round; the returning `deg` atomics of both are in flight together
-    for (u32 s0 = t; s0 < HT; s0 += 2 * NT) {
-        u32 f[2], to[2], oi[2], rk[2]; bool live[2];
+    // compaction: SPT table slots per thread, one round; the returning `deg` atomics of a thread are in flight together
+    {
+        u32 f[SPT], to[SPT], oi[SPT], rk[SPT]; bool live[SPT];
 #pragma unroll
-        for (int k2 = 0; k2 < 2; k2++) {
-            const u32 s = s0 + (u32)k2 * NT;
+        for (int k2 = 0; k2 < SPT; k2++) {
+            const u32 sl = t + (u32)k2 * NT;
             live[k2] = false; f[k2] = to[k2] = oi[k2] = rk[k2] = 0;
-            if (s >= HT) continue;
-            const u32 rem = hkey[s];
+            if (sl >= HT) continue;
+            const u32 rem = hkey[sl];
             if (rem == 0xFFFFFFFFu) continue;
             const u64 mk = ((u64)p << d.rb) | rem;
             u32 cf, ct;
             sg_kunmix((u32)(mk >> nb), (u32)mk & nbmask, nbmask, &cf, &ct);
             f[k2] = dense_of(d, ref_of_ci(d, cf), nk, nl, nob); to[k2] = dense_of(d, ref_of_ci(d, ct), nk, nl, nob);
-            if (f[k2] == SG_NONE || to[k2] == SG_NONE) { atomicAdd(n_drop, (u32)(hacc[s] & 0xFFFFFFFFull)); continue; }
+            if (f[k2] == SG_NONE || to[k2] == SG_NONE) { atomicAdd(n_drop, (u32)(hacc[sl] & 0xFFFFFFFFull)); continue; }
             oi[k2] = atomicAdd(out_n, 1u);
-            if (oi[k2] >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[s] & 0xFFFFFFFFull)); continue; }
+            if (oi[k2] >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[sl] & 0xFFFFFFFFull)); continue; }
             live[k2] = true;
-            rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], p & (SG_DEG_REP - 1))], 1u);     // arrival order inside the row's replica
+            if (!(d.ablate & 0x20u)) rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], oq & (SG_DEG_REP - 1))], 1u);   // arrival order inside the row's replica
         }
 #pragma unroll
-        for (int k2 = 0; k2 < 2; k2++) {
+        for (int k2 = 0; k2 < SPT; k2++) {
             if (!live[k2]) continue;
-            const u32 s = s0 + (u32)k2 * NT;
-            const size_t slot = (size_t)p * d.pcap + oi[k2];
+            const u32 sl = t + (u32)k2 * NT;
+            const size_t slot = (size_t)oq * d.pcap + oi[k2];
             d.e_from[slot] = f[k2]; d.e_to[slot] = to[k2];
             ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
-            o[0] = make_ulonglong2(hacc[s], hacc[HT + s]); o[1] = make_ulonglong2(hacc[2 * HT + s], hacc[3 * HT + s]);
+            o[0] = make_ulonglong2(hacc[sl], hacc[HT + sl]); o[1] = make_ulonglong2(hacc[2 * HT + sl], hacc[3 * HT + sl]);
             d.e_rank[slot] = rk[k2];
         }
     }
@@ -464,7 +509,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     SG_STAMP(d, 1, 5);
     if (t == 0) {
         const u32 on = *out_n, nd = *n_drop;
-        d.part_n[p] = on < d.pcap ? on : d.pcap;
+        d.part_n[oq] = on < d.pcap ? on : d.pcap;
         if (nd) {                                                    // dropped after pass A had counted them as accepted
             atomicAdd(&d.ctr[C_DROPPED_CAP], (u64)nd);
             atomicAdd(&d.ctr[C_N_EVENTS], 0ull - (u64)nd);
@@ -473,5 +518,5 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
 }
 // (the SGPR cap lets two 1024-thread workgroups share a CU — tools/occupancy_probe.hip; the uncapped build for geometries
 // where a CU holds one workgroup anyway)
-template <int U> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_stream_merge(Dev d) { k1b8_body<U>(d); }
-template <int U> __global__ __launch_bounds__(1024) void k1b_stream_merge_wide(Dev d) { k1b8_body<U>(d); }
+template <int U, int SPT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_stream_merge(Dev d) { k1b8_body<U, SPT>(d); }
+template <int U, int SPT> __global__ __launch_bounds__(1024) void k1b_stream_merge_wide(Dev d) { k1b8_body<U, SPT>(d); }

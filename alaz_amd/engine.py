@@ -58,7 +58,7 @@ def make_config(*, max_known_nodes: int, max_edges: int, layers: int = 1, max_la
 
 class SgGeometry(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("k1_variant", "k1_narrow", "partitions", "table_slots", "pass_a_workgroups", "cache_slots",
-                                          "join_l2_in_lds", "tile_records", "endpoint_bits", "piece_bytes")]
+                                          "join_l2_in_lds", "tile_records", "endpoint_bits", "piece_bytes", "pass_b_split", "reserved")]
 
 
 class SgStats(C.Structure):

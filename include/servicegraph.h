@@ -337,6 +337,8 @@ typedef struct sg_geometry {
     uint32_t tile_records;      /* narrow: records sorted per tile                                                           */
     uint32_t endpoint_bits;     /* narrow: nb; remainder bits = 2 nb - log2(partitions)                                      */
     uint32_t piece_bytes;       /* record slab bytes per (partition, workgroup) piece                                        */
+    uint32_t pass_b_split;      /* narrow: pass-B workgroups (sub-tables) per partition                                      */
+    uint32_t reserved;
 } sg_geometry;
 int sg_geometry_get(sg_handle h, sg_geometry* out);
 

@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_every_symbol(engine_lib):
 
 
 def test_struct_layouts_match_the_header():
-    assert C.sizeof(engine.SgConfig) == 88 and C.sizeof(engine.SgStats) == 136 and C.sizeof(engine.SgGeometry) == 40
+    assert C.sizeof(engine.SgConfig) == 88 and C.sizeof(engine.SgStats) == 136 and C.sizeof(engine.SgGeometry) == 48
     assert engine.SgConfig.struct_size.offset == 0 and engine.SgConfig.abi_version.offset == 4 and engine.SgConfig.max_edges.offset == 32
     assert replay.EVENT_DTYPE.itemsize == 32 and replay.EDGE_OUT_DTYPE.itemsize == 64
     assert replay.EVENT_DTYPE.fields["duration_ns"][1] == 16 and replay.EVENT_DTYPE.fields["status"][1] == 12

@@ -56,6 +56,6 @@ for var in variants:
     E = int(st.last_window_edges)
     frac = (32.0 * Ev + 32.0 * E) / ((a + b) * 1e-6) / 8e12 if a + b > 0 else 0
     geo = g.geometry()
-    print(f"[{var or 'default'}] {'narrow' if geo['k1_narrow'] else 'wide'} np {geo['partitions']} ht {geo['table_slots']} ct {geo['cache_slots']} l2lds {geo['join_l2_in_lds']} | k1a {a:7.1f} k1b {b:7.1f} us  frac {frac:.3f}  window {dt:8.1f} us  groups {grp}  edges {E} events {st.last_window_events} "
+    print(f"[{var or 'default'}] {'narrow' if geo['k1_narrow'] else 'wide'} np {geo['partitions']} x{geo['pass_b_split']} ht {geo['table_slots']} ct {geo['cache_slots']} l2lds {geo['join_l2_in_lds']} | k1a {a:7.1f} k1b {b:7.1f} us  frac {frac:.3f}  window {dt:8.1f} us  groups {grp}  edges {E} events {st.last_window_events} "
           f"dropped_cap {st.events_dropped_cap} count_sum {int(rows['count'].astype(np.uint64).sum())}", flush=True)
     g.close()

@@ -40,4 +40,8 @@ for kid, kname in zip((0, 1), g.k1_kernels()):
         if nm == "-": continue
         col = (a[:, k] - t0) / 100.0
         print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
+    if kid == 0 and a.shape[1] > 7 and a[:, 2].max() > 0:          # narrow pass A: wave 0's accumulated time in P1 / at the barrier behind it
+        for k, nm in ((2, "sum of P1 (wave 0)"), (7, "sum of barrier-1 waits")):
+            col = a[:, k] / 100.0
+            print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}   (durations)")
 g.close()
