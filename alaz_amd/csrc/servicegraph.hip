@@ -56,7 +56,7 @@ struct sg_engine {
     hipStream_t tab_stream = nullptr;
     u32 n_known = 0;
     // pass-A launch geometry, follows the table state
-    bool l2_in_lds = false; u32 k1a_ct = 2048;
+    bool l2_in_lds = false, l2_u16 = false; u32 k1a_ct = 2048, k1a_nsub = 2;
     // staging ring for sg_ingest()
     sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
     int stage_next = 0;
@@ -143,16 +143,20 @@ bool k1a_geometry(sg_engine* e) {
     const size_t stage_max = (size_t)K1A_NJ * K1A_THREADS * 16;    // what the prologue can stage: six 16-byte words per lane
     e->l2_in_lds = false;
     if (d.narrow) {
-        // cache | 5 counters per partition | statistics | tile | join tables
-        const size_t fixed = (size_t)d.np * 20 + 64 + (size_t)K1T_TS * 8 + l1b;
+        // cache | 5 counters per partition | statistics | tile | prefetch pad | join tables.  Level 2 is staged as u16 entries
+        // (half the bytes) when every node id fits 14 bits.
+        e->l2_u16 = e->cfg.max_known_nodes <= 16384 && !std::getenv("SG_L2_U32");
+        const size_t l2lds = e->l2_u16 ? l2b / 2 : l2b;
+        if (const char* v = std::getenv("SG_NSUB")) { const int x = std::atoi(v); if (x == 1 || x == 2) e->k1a_nsub = (u32)x; }
+        const size_t fixed = (size_t)d.np * 20 + 64 + (size_t)K1T_TS(e->k1a_nsub) * 8 + 256 + l1b;
         u32 ct = 0;
-        for (u32 c : {1024u, 512u, 256u, 128u}) if ((size_t)c * 40 + fixed + l2b <= kLdsBytes && l1b + l2b <= stage_max) { e->l2_in_lds = true; ct = c; break; }
-        if (!ct) for (u32 c : {1024u, 512u, 256u, 128u, 64u}) if ((size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
-        if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) ct = x; }
+        for (u32 c : {2048u, 1024u, 512u, 256u, 128u}) if ((size_t)c * 40 + fixed + l2lds <= kLdsBytes && l1b + l2b <= stage_max) { e->l2_in_lds = true; ct = c; break; }
+        if (!ct) for (u32 c : {2048u, 1024u, 512u, 256u, 128u, 64u}) if ((size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
+        if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2lds : 0) <= kLdsBytes) ct = x; }
         if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
         if (!ct || l1b > stage_max) return false;
         e->k1a_ct = ct;
-        e->k1a_lds = (size_t)ct * 40 + fixed + (e->l2_in_lds ? l2b : 0);
+        e->k1a_lds = (size_t)ct * 40 + fixed + (e->l2_in_lds ? l2lds : 0);
         return true;
     }
     const size_t fixed = (size_t)d.np * 4 + 64 + l1b;
@@ -257,13 +261,16 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
         const bool sh = e->d.world > 1;
 #define K1A_GO(L2, SH, HI) hipExtLaunchKernelGGL((k1a_partition<L2, SH, HI>), dim3(e->d.nwg), dim3(K1A_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
 #define K1A_GO2(L2, SH) do { if (e->d.hist) K1A_GO(L2, SH, true); else K1A_GO(L2, SH, false); } while (0)
-#define K1T_GO(L2, SH) hipExtLaunchKernelGGL((k1a_tile_partition<L2, SH>), dim3(e->d.nwg), dim3(K1T_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
+#define K1T_GO(L2, SH, NS) hipExtLaunchKernelGGL((k1a_tile_partition<L2, SH, NS>), dim3(e->d.nwg), dim3(K1T_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
+#define K1T_GO2(L2, SH) do { if (e->k1a_nsub == 2) K1T_GO(L2, SH, 2); else K1T_GO(L2, SH, 1); } while (0)
         if (e->d.narrow) {
-            if (e->l2_in_lds) { if (sh) K1T_GO(true, true); else K1T_GO(true, false); }
-            else { if (sh) K1T_GO(false, true); else K1T_GO(false, false); }
+            if (e->l2_in_lds && e->l2_u16) { if (sh) K1T_GO2(2, true); else K1T_GO2(2, false); }
+            else if (e->l2_in_lds) { if (sh) K1T_GO2(1, true); else K1T_GO2(1, false); }
+            else { if (sh) K1T_GO2(0, true); else K1T_GO2(0, false); }
         }
         else if (e->l2_in_lds) { if (sh) K1A_GO2(true, true); else K1A_GO2(true, false); }
         else { if (sh) K1A_GO2(false, true); else K1A_GO2(false, false); }
+#undef K1T_GO2
 #undef K1T_GO
 #undef K1A_GO2
 #undef K1A_GO
@@ -624,8 +631,12 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
                               reinterpret_cast<const void*>(k1a_partition<false, true, false>), reinterpret_cast<const void*>(k1a_partition<false, false, false>),
                               reinterpret_cast<const void*>(k1a_partition<true, true, true>), reinterpret_cast<const void*>(k1a_partition<true, false, true>),
                               reinterpret_cast<const void*>(k1a_partition<false, true, true>), reinterpret_cast<const void*>(k1a_partition<false, false, true>),
-                              reinterpret_cast<const void*>(k1a_tile_partition<true, true>), reinterpret_cast<const void*>(k1a_tile_partition<true, false>),
-                              reinterpret_cast<const void*>(k1a_tile_partition<false, true>), reinterpret_cast<const void*>(k1a_tile_partition<false, false>)})
+                              reinterpret_cast<const void*>(k1a_tile_partition<2, true, 2>), reinterpret_cast<const void*>(k1a_tile_partition<2, false, 2>),
+                              reinterpret_cast<const void*>(k1a_tile_partition<1, true, 2>), reinterpret_cast<const void*>(k1a_tile_partition<1, false, 2>),
+                              reinterpret_cast<const void*>(k1a_tile_partition<0, true, 2>), reinterpret_cast<const void*>(k1a_tile_partition<0, false, 2>),
+                              reinterpret_cast<const void*>(k1a_tile_partition<2, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<2, false, 1>),
+                              reinterpret_cast<const void*>(k1a_tile_partition<1, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<1, false, 1>),
+                              reinterpret_cast<const void*>(k1a_tile_partition<0, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<0, false, 1>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
         for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>),
                               reinterpret_cast<const void*>(k1b_merge_wide<4, false>), reinterpret_cast<const void*>(k1b_merge_wide<8, false>), reinterpret_cast<const void*>(k1b_merge_wide<4, true>),
@@ -756,8 +767,8 @@ int sg_geometry_get(sg_handle e, sg_geometry* out) {
     std::lock_guard<std::mutex> g(e->mu);
     const Dev& d = e->d;
     out->k1_variant = d.variant; out->k1_narrow = d.narrow; out->partitions = d.np; out->table_slots = d.k1b_ht; out->pass_b_split = d.k1b_split;
-    out->pass_a_workgroups = d.nwg; out->cache_slots = e->k1a_ct; out->join_l2_in_lds = e->l2_in_lds ? 1u : 0u;
-    out->tile_records = d.narrow ? K1T_TS : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
+    out->pass_a_workgroups = d.nwg; out->cache_slots = e->k1a_ct; out->join_l2_in_lds = e->l2_in_lds ? (e->d.narrow && e->l2_u16 ? 2u : 1u) : 0u;
+    out->tile_records = d.narrow ? K1T_TS(e->k1a_nsub) : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
     out->piece_bytes = d.variant != 0 ? 0u : (d.narrow ? d.punits * 8u : d.pslots * 16u);
     return SG_OK;
 }

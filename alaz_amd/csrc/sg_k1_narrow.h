@@ -17,7 +17,8 @@
 #pragma once
 
 #define K1T_THREADS 1024
-#define K1T_TS      8192u         // records per tile: 8 events per thread
+#define K1T_CHUNK   4096u         // events per chunk at most: four per thread
+#define K1T_TS(NSUB) (K1T_CHUNK * (NSUB))   // records per tile: NSUB chunks (1 or 2)
 #define K1T_NONE    0xFFFFFFFFu
 #define K1T_RANK_SHIFT 12         // stash word: partition (<= 12 bits) | rank in the partition's run << 12
 
@@ -73,10 +74,14 @@ __device__ __forceinline__ void emit_agg8(const Dev& d, u32* fcw, u32 w, u32 p, 
 // Per tile (8 events per thread, fetched as two groups of four):
 //   P1  join + setFromToV2 as selects + key mix + cache probe (the r02 fast path); a record that is not folded into the
 //       cache takes a rank in its partition's run (returning LDS add) and stays in registers
-//   P2  wave 0 turns the run lengths into offsets           P3  every thread drops its records at offset + rank
+//   P2  every wave turns the run lengths into offsets       P3  every thread drops its records at offset + rank
 //   P4  16 lanes per partition copy its run to the piece: adjacent lanes, adjacent addresses
-// Three LDS-only barriers per tile; the run counters alternate so that P4 of tile k may overlap P1 of tile k + 1.
-template <bool L2LDS, bool SHARDED>
+// Two LDS-only barriers per tile (behind P1 and P3); the run counters alternate so that P4 of tile k may overlap P1 of tile k + 1.
+// L2M: level 2 of the join 0 = read from global memory, 1 = staged in LDS as it is (u32 entries), 2 = staged in LDS as u16
+// entries kind << 14 | id (engines whose id space fits 14 bits: half the LDS, which goes to the edge cache).
+// NSUB: chunks per tile (2: 8192-record tiles = longer runs, 24 registers of parked records; 1: 4096-record tiles = half the
+// LDS, which goes to the edge cache, half the registers, twice the barriers per event).
+template <int L2M, bool SHARDED, int NSUB>
 __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const sg_event* __restrict__ ev, u64 n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 CT = d.k1a_ct, NP = d.np;
@@ -87,10 +92,12 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     u32* bcnt = fcw + NP;                                            // [2][np] run lengths of the tile being built / written
     u32* boff = bcnt + 2 * NP;                                       // [np] run offsets inside the tile
     u64* red = reinterpret_cast<u64*>(boff + NP);                    // [8] workgroup statistics (WS_* order)
-    u64* tile = red + 8;                                             // [K1T_TS]
-    uint4* jl = reinterpret_cast<uint4*>(tile + K1T_TS);             // LDS copy of the join blob: jl1 | jl2 (L2LDS)
+    u64* tile = red + 8;                                             // [K1T_TS(NSUB)]
+    u32* pfs = reinterpret_cast<u32*>(tile + K1T_TS(NSUB));                // [64] landing pad of the L2 prefetch (LDS-DMA: no register is in flight)
+    uint4* jl = reinterpret_cast<uint4*>(pfs + 64);                  // LDS copy of the join blob: jl1 | jl2 (L2M != 0)
     const u64* l1 = reinterpret_cast<const u64*>(jl);
-    const u32* l2 = L2LDS ? reinterpret_cast<const u32*>(l1 + d.jl1mask + 1) : d.jl2;
+    const u32* l2 = L2M == 1 ? reinterpret_cast<const u32*>(l1 + d.jl1mask + 1) : d.jl2;
+    const unsigned short* l2h = reinterpret_cast<const unsigned short*>(l1 + d.jl1mask + 1);      // L2M == 2
     const u32 w = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
     // The batch is cut into chunks of `chunk` events (1024 .. 4096, a multiple of 1024: up to four events per lane and group);
@@ -119,6 +126,19 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
           gload16_issue(ea0, q0); gload16_issue(eb0, q0 + 1); gload16_issue(ea1, q1); gload16_issue(eb1, q1 + 1);   \
           gload16_issue(ea2, q2); gload16_issue(eb2, q2 + 1); gload16_issue(ea3, q3); gload16_issue(eb3, q3 + 1); }
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory")   /* LDS-only: does not drain the global stores */
+    // Pull the 64-byte sectors of events [cb, ce) towards this XCD's L2 while the previous chunk is being folded: the barriers keep
+    // the waves of a workgroup in step, so nothing else overlaps a chunk's HBM latency with work.  Two LDS-DMA loads per lane
+    // (global_load_lds_dword: the destination is an LDS landing pad nobody reads — no register is in flight, so the compiler's
+    // code between this and the next wait cannot touch one).  M0 (the LDS address of the pad) is saved and restored.
+    const u32 pfs_lds = (u32)(size_t)pfs;
+#define K1T_PREFETCH(cb, ce)                                                                                       \
+        { const u64 nb_ = ((ce) - (cb)) * 32ull;                              /* bytes of the chunk (> 0) */            \
+          const u64 o0 = (u64)t * 64ull, o1 = o0 + 65536ull;                                                           \
+          const char* base_ = reinterpret_cast<const char*>(pe + 2 * (cb));                                            \
+          const char* a0 = base_ + (o0 < nb_ ? o0 : 0ull); const char* a1 = base_ + (o1 < nb_ ? o1 : 0ull);           \
+          u32 m0s_;                                                                                                    \
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dword %2, off\n\tglobal_load_lds_dword %3, off\n\ts_mov_b32 m0, %0" \
+                                : "=&s"(m0s_) : "s"(pfs_lds), "v"(a0), "v"(a1) : "memory"); }
 
     // cache fold of one accepted event whose bucket the caller has read (k0, k1); returns false when the event must travel
     auto cache_fold = [&](u32 bucket, u64 mk, u64 k0, u64 k1, u64 dur, u32 err) -> bool {
@@ -150,11 +170,12 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         const u32 rank = atomicAdd(&bc[part], 1u);
         slo = (u32)e.dur; shi = ((u32)mk & rbmask) | (e.err << 31); spr = part | (rank << K1T_RANK_SHIFT);
     };
+    constexpr u32 KSH = L2M == 2 ? 14u : 30u, IDM = L2M == 2 ? 0x3FFFu : 0x3FFFFFFFu;   // kind shift / id mask of a level-2 entry as this build reads it
     auto join = [&](u32 ip) -> u32 {
         const u32 b = ip >> 8;
         const u64 e1 = l1[((__umul24(b, SG_JL1_K1)) >> 9) & d.jl1mask], e2 = l1[((__umul24(b, SG_JL1_K2)) >> 11) & d.jl1mask];
         const u32 blk = (u32)e1 == b ? (u32)(e1 >> 32) : ((u32)e2 == b ? (u32)(e2 >> 32) : 0u);     // block 0 = the all-zero block
-        return l2[(blk << 8) | (ip & 255u)];
+        return L2M == 2 ? (u32)l2h[(blk << 8) | (ip & 255u)] : l2[(blk << 8) | (ip & 255u)];
     };
     // The fast path, one event: branch-free join (two-level block table in LDS), data.go:827-870 as selects, key mix,
     // read-only cache probe.  `rare` hands the event to the general path instead.
@@ -162,15 +183,15 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         const bool inr = idx < cend;
         const u32 flags = va.w >> 24, label = va.z;
         const u32 vs = join(va.x), vd = join(va.y);
-        const u32 ks = vs >> 30, kd = vd >> 30;
+        const u32 ks = vs >> KSH, kd = vd >> KSH;
         bool rare = ((flags & SG_EV_ALIVE) != 0) | (ks == 3u) | (kd == 3u) | (vb.y != 0u) |
                     ((kd == 0u) & ((label == 0u) | (label > d.max_labels))) | (ck_any & ((vs == 0u) | (vd == 0u)));
         rare &= inr; rare_out = rare;
         const bool fastv = inr & !rare;
         bool acc = fastv & (ks == 1u);                               /* data.go:829-832: the source must be a pod */
         L.dsrc += (fastv & (ks != 1u)) ? 1u : 0u;
-        u32 cf = vs & 0x3FFFFFFFu;
-        u32 ct = kd ? (vd & 0x3FFFFFFFu) : (d.max_known + label - 1u);   /* service / pod id, else Host label (:840-854) */
+        u32 cf = vs & IDM;
+        u32 ct = kd ? (vd & IDM) : (d.max_known + label - 1u);           /* service / pod id, else Host label (:840-854) */
         { const u32 ml = (acc & (kd == 0u)) ? label : 0u; L.maxlabel = ml > L.maxlabel ? ml : L.maxlabel; }
         if (flags & SG_EV_REVERSE) { const u32 x_ = cf; cf = ct; ct = x_; }      /* dto.go:226-231 */
         if (SHARDED) { const bool mine = (owner_hash_ref(ref_of_ci(d, cf)) % d.world) == d.rank; L.misr += (acc & !mine) ? 1u : 0u; acc &= mine; }
@@ -190,8 +211,9 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
             slo = dur; shi = ((u32)mk & rbmask) | (err << 31); spr = part | (rank << K1T_RANK_SHIFT);
         }
     };
-#define K1T_FOLD(base, cend, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3)                          \
-        { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ea0), "+v"(eb0), "+v"(ea1), "+v"(eb1), "+v"(ea2), "+v"(eb2), "+v"(ea3), "+v"(eb3) : : "memory"); \
+    // WAITCNT: loads issued AFTER the group's eight (the prefetch of the next chunk) that may stay in flight
+#define K1T_FOLD(WAITCNT, base, cend, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3)                 \
+        { asm volatile("s_waitcnt vmcnt(" #WAITCNT ")" : "+v"(ea0), "+v"(eb0), "+v"(ea1), "+v"(eb1), "+v"(ea2), "+v"(eb2), "+v"(ea3), "+v"(eb3) : : "memory"); \
           bool r0, r1, r2, r3;                                                                                      \
           fast((base), (cend), ea0, eb0, (bc), r0, lo0, hi0, pr0); fast((base) + K1T_THREADS, (cend), ea1, eb1, (bc), r1, lo1, hi1, pr1); \
           fast((base) + 2 * K1T_THREADS, (cend), ea2, eb2, (bc), r2, lo2, hi2, pr2); fast((base) + 3 * K1T_THREADS, (cend), ea3, eb3, (bc), r3, lo3, hi3, pr3); \
@@ -235,9 +257,14 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
                      "s_waitcnt vmcnt(0)"
                      : "=&v"(jb0), "=&v"(jb1), "=&v"(jb2), "=&v"(jb3), "=&v"(jb4), "=&v"(jb5)
                      : "v"(js0), "v"(js1), "v"(js2), "v"(js3), "v"(js4), "v"(js5) : "memory");
-#define K1T_JST(k, r) if (t + (k) * K1T_THREADS < n16) jl[t + (k) * K1T_THREADS] = make_uint4((r).x, (r).y, (r).z, (r).w)
+        // (level-1 words go in as they are; a level-2 word = four u32 entries kind << 30 | id -> four u16 entries kind << 14 | id)
+#define K1T_P16(x) ((((x) >> 30) << 14) | ((x) & 0x3FFFu))
+#define K1T_JST(k, r) { const u32 i_ = t + (k) * K1T_THREADS;                                                          \
+            if (i_ < n16) { if (L2M == 2 && i_ >= n1) reinterpret_cast<uint2*>(jl + n1)[i_ - n1] = make_uint2(K1T_P16((r).x) | (K1T_P16((r).y) << 16), K1T_P16((r).z) | (K1T_P16((r).w) << 16)); \
+                            else jl[i_] = make_uint4((r).x, (r).y, (r).z, (r).w); } }
         K1T_JST(0, jb0); K1T_JST(1, jb1); K1T_JST(2, jb2); K1T_JST(3, jb3); K1T_JST(4, jb4); K1T_JST(5, jb5);
 #undef K1T_JST
+#undef K1T_P16
 #undef K1T_JSRC
 #undef K1T_JIDX
         LDS_BARRIER();
@@ -246,26 +273,35 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     const u32 bpw = NP >> 4;                                         // partitions whose runs a wave writes out (np >= 64)
     u32 cur = 0;
     u64 tk_p1 = 0, tk_wait = 0;                                      // SG_ABLATE & 0x100: wave 0's clock ticks in P1 / at the barrier behind it
-    for (u64 c0 = w; c0 < nchunk; c0 += 2 * (u64)d.nwg, cur ^= 1u) {
+    for (u64 c0 = w; c0 < nchunk; c0 += (u64)NSUB * d.nwg, cur ^= 1u) {
         u32* bc = bcnt + cur * NP;
         u32 lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7;
         const u64 tk0 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
-        {   // P1: two chunks of up to four events per thread
+        {   // P1: two chunks of up to four events per thread; behind each group's loads goes the prefetch of the chunk after it
             v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
             const u64 cb0 = c0 * chunk, ce0 = cb0 + chunk < end ? cb0 + chunk : end;
+            const u64 c1 = c0 + d.nwg, c2 = c0 + (u64)NSUB * d.nwg;
+            const u64 cb1 = c1 < nchunk ? c1 * chunk : cb0, ce1 = c1 < nchunk ? (cb1 + chunk < end ? cb1 + chunk : end) : cb0;   // no such chunk: an empty range
+            const u64 cb2 = c2 < nchunk ? c2 * chunk : cb0, ce2 = c2 < nchunk ? (cb2 + chunk < end ? cb2 + chunk : end) : cb0;   // the next tile's first chunk
+            // (no next chunk, or SG_ABLATE & 0x200: the prefetch re-touches the chunk being loaded — same instructions, no effect)
+            const bool pf1 = ce1 > cb1 && !(d.ablate & 0x200u), pf2 = ce2 > cb2 && !(d.ablate & 0x200u);
             const u64 i0 = cb0 + t;
             K1T_ISSUE(i0, ce0, cb0);
-            K1T_FOLD(i0, ce0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
-            const u64 c1 = c0 + d.nwg;
-            const u64 cb1 = c1 < nchunk ? c1 * chunk : cb0, ce1 = c1 < nchunk ? (cb1 + chunk < end ? cb1 + chunk : end) : cb0;   // no second chunk: an empty range
-            const u64 i1 = cb1 + t;
-            K1T_ISSUE(i1, ce1, cb1);
-            K1T_FOLD(i1, ce1, bc, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7);
+            if (NSUB == 2) { K1T_PREFETCH(pf1 ? cb1 : cb0, pf1 ? ce1 : ce0); } else { K1T_PREFETCH(pf2 ? cb2 : cb0, pf2 ? ce2 : ce0); }
+            K1T_FOLD(2, i0, ce0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
+            if constexpr (NSUB == 2) {
+                const u64 i1 = cb1 + t;
+                K1T_ISSUE(i1, ce1, cb1);
+                K1T_PREFETCH(pf2 ? cb2 : cb0, pf2 ? ce2 : ce0);
+                K1T_FOLD(2, i1, ce1, bc, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7);
+            } else { pr4 = pr5 = pr6 = pr7 = K1T_NONE; lo4 = hi4 = lo5 = hi5 = lo6 = hi6 = lo7 = hi7 = 0; }
         }
         const u64 tk1 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         LDS_BARRIER();
         if (d.ablate & 0x100u) { const u64 tk2 = wall_clock64(); tk_p1 += tk1 - tk0; tk_wait += tk2 - tk1; }
-        if (wave == 0) {                                             // P2: exclusive scan of the run lengths (np / 64 per lane)
+        {                                                            // P2: exclusive scan of the run lengths (np / 64 per lane) by EVERY wave
+            // (sixteen identical scans cost less than a barrier behind one: the offsets a wave needs in P3 are its own writes, and
+            // every wave writes the same values)
             const u32 pl = NP >> 6, b0 = lane * pl;
             u32 s = 0;
             for (u32 k = 0; k < pl; k++) s += bc[b0 + k];
@@ -275,10 +311,9 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
             u32 run = incl - s;
             for (u32 k = 0; k < pl; k++) { const u32 c = bc[b0 + k]; boff[b0 + k] = run; run += c; }
         }
-        LDS_BARRIER();
 #define K1T_DROP(lo, hi, pr) if ((pr) != K1T_NONE) tile[boff[(pr) & ((1u << K1T_RANK_SHIFT) - 1u)] + ((pr) >> K1T_RANK_SHIFT)] = (u64)(lo) | ((u64)(hi) << 32)
         K1T_DROP(lo0, hi0, pr0); K1T_DROP(lo1, hi1, pr1); K1T_DROP(lo2, hi2, pr2); K1T_DROP(lo3, hi3, pr3);   // P3
-        K1T_DROP(lo4, hi4, pr4); K1T_DROP(lo5, hi5, pr5); K1T_DROP(lo6, hi6, pr6); K1T_DROP(lo7, hi7, pr7);
+        if constexpr (NSUB == 2) { K1T_DROP(lo4, hi4, pr4); K1T_DROP(lo5, hi5, pr5); K1T_DROP(lo6, hi6, pr6); K1T_DROP(lo7, hi7, pr7); }
 #undef K1T_DROP
         LDS_BARRIER();
         for (u32 b4 = 0; b4 < bpw; b4 += 4) {                        // P4: four runs per wave step, 16 lanes each
