@@ -143,15 +143,16 @@ bool k1a_geometry(sg_engine* e) {
     const size_t stage_max = (size_t)K1A_NJ * K1A_THREADS * 16;    // what the prologue can stage: six 16-byte words per lane
     e->l2_in_lds = false;
     if (d.narrow) {
-        // cache | 5 counters per partition | statistics | tile | prefetch pad | join tables.  Level 2 is staged as u16 entries
+        // cache | 6 counters per partition | statistics | tile | join tables.  Level 2 is staged as u16 entries
         // (half the bytes) when every node id fits 14 bits.
         e->l2_u16 = e->cfg.max_known_nodes <= 16384 && !std::getenv("SG_L2_U32");
         const size_t l2lds = e->l2_u16 ? l2b / 2 : l2b;
         if (const char* v = std::getenv("SG_NSUB")) { const int x = std::atoi(v); if (x == 1 || x == 2) e->k1a_nsub = (u32)x; }
-        const size_t fixed = (size_t)d.np * 20 + 64 + (size_t)K1T_TS(e->k1a_nsub) * 8 + 256 + l1b;
+        const size_t fixed = (size_t)d.np * 24 + 64 + (size_t)K1T_TS(e->k1a_nsub) * 8 + l1b;
         u32 ct = 0;
-        for (u32 c : {2048u, 1024u, 512u, 256u, 128u}) if ((size_t)c * 40 + fixed + l2lds <= kLdsBytes && l1b + l2b <= stage_max) { e->l2_in_lds = true; ct = c; break; }
-        if (!ct) for (u32 c : {2048u, 1024u, 512u, 256u, 128u, 64u}) if ((size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
+        // (the cache flattens the hottest keys; beyond 1024 slots it costs more aggregates than it saves records)
+        for (u32 c : {1024u, 512u, 256u, 128u}) if ((size_t)c * 40 + fixed + l2lds <= kLdsBytes && l1b + l2b <= stage_max) { e->l2_in_lds = true; ct = c; break; }
+        if (!ct) for (u32 c : {1024u, 512u, 256u, 128u, 64u}) if ((size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
         if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2lds : 0) <= kLdsBytes) ct = x; }
         if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
         if (!ct || l1b > stage_max) return false;

@@ -87,14 +87,14 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     const u32 CT = d.k1a_ct, NP = d.np;
     u64* ckey = reinterpret_cast<u64*>(smem);                       // [CT] mixed keys
     u64* cacc = ckey + CT;                                           // [CT][4]
-    u32* fcn = reinterpret_cast<u32*>(cacc + (size_t)CT * 4);        // [np] narrow records in piece (p, this workgroup)
-    u32* fcw = fcn + NP;                                             // [np] wide singles | aggregates << 16
+    u32* fcn2 = reinterpret_cast<u32*>(cacc + (size_t)CT * 4);       // [2][np] narrow records in piece (p, this workgroup): the set a tile's copy-out reads,
+                                                                     //         and the set its scan writes for the next tile
+    u32* fcw = fcn2 + 2 * NP;                                        // [np] wide singles | aggregates << 16
     u32* bcnt = fcw + NP;                                            // [2][np] run lengths of the tile being built / written
     u32* boff = bcnt + 2 * NP;                                       // [np] run offsets inside the tile
     u64* red = reinterpret_cast<u64*>(boff + NP);                    // [8] workgroup statistics (WS_* order)
     u64* tile = red + 8;                                             // [K1T_TS(NSUB)]
-    u32* pfs = reinterpret_cast<u32*>(tile + K1T_TS(NSUB));                // [64] landing pad of the L2 prefetch (LDS-DMA: no register is in flight)
-    uint4* jl = reinterpret_cast<uint4*>(pfs + 64);                  // LDS copy of the join blob: jl1 | jl2 (L2M != 0)
+    uint4* jl = reinterpret_cast<uint4*>(tile + K1T_TS(NSUB));       // LDS copy of the join blob: jl1 | jl2 (L2M != 0)
     const u64* l1 = reinterpret_cast<const u64*>(jl);
     const u32* l2 = L2M == 1 ? reinterpret_cast<const u32*>(l1 + d.jl1mask + 1) : d.jl2;
     const unsigned short* l2h = reinterpret_cast<const unsigned short*>(l1 + d.jl1mask + 1);      // L2M == 2
@@ -114,7 +114,19 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         return;
     }
     SG_STAMP(d, 0, 0);
-    K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = L.lost = 0;
+    // statistics: accepted events and their time-stamp range stay in registers; everything rare (drops, labels, misrouted events, what
+    // the general path and the overflow paths count) is added to the workgroup's LDS line where it happens — six registers less
+    // across the fold
+    u32 st_acc = 0; u64 st_tmin = ~0ull, st_tmax = 0;
+    auto lflush = [&](const K1Local& x) {
+        if (x.acc) { atomicAdd(&red[WS_ACCEPTED], (u64)x.acc); atomicMin(&red[WS_TMIN], x.tmin); atomicMax(&red[WS_TMAX], x.tmax); }
+        if (x.lost) atomicAdd(&red[WS_PAD], (u64)x.lost);
+        if (x.maxlabel) atomicMax(&red[WS_MAXLABEL], (u64)x.maxlabel);
+        if (x.dsrc) atomicAdd(&red[WS_DROPPED_SRC], (u64)x.dsrc);
+        if (x.dcap) atomicAdd(&red[WS_DROPPED_CAP], (u64)x.dcap);
+        if (x.misr) atomicAdd(&red[WS_MISROUTED], (u64)x.misr);
+    };
+#define K1T_LNEW(L) K1Local L; L.tmin = ~0ull; L.tmax = 0; L.maxlabel = L.dsrc = L.dcap = L.misr = L.acc = L.lost = 0
     const u32 nb = d.nb, nbmask = (1u << nb) - 1u, pshift = nb - d.pb, rbmask = (1u << d.rb) - 1u, bmask = CT / 2 - 1;
     const bool ck_any = d.ck_n != 0;
 
@@ -126,20 +138,6 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
           gload16_issue(ea0, q0); gload16_issue(eb0, q0 + 1); gload16_issue(ea1, q1); gload16_issue(eb1, q1 + 1);   \
           gload16_issue(ea2, q2); gload16_issue(eb2, q2 + 1); gload16_issue(ea3, q3); gload16_issue(eb3, q3 + 1); }
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory")   /* LDS-only: does not drain the global stores */
-    // Pull the 64-byte sectors of events [cb, ce) towards this XCD's L2 while the previous chunk is being folded: the barriers keep
-    // the waves of a workgroup in step, so nothing else overlaps a chunk's HBM latency with work.  Two LDS-DMA loads per lane
-    // (global_load_lds_dword: the destination is an LDS landing pad nobody reads — no register is in flight, so the compiler's
-    // code between this and the next wait cannot touch one).  M0 (the LDS address of the pad) is saved and restored.
-    const u32 pfs_lds = (u32)(size_t)pfs;
-#define K1T_PREFETCH(cb, ce)                                                                                       \
-        { const u64 nb_ = ((ce) - (cb)) * 32ull;                              /* bytes of the chunk (> 0) */            \
-          const u64 o0 = (u64)t * 64ull, o1 = o0 + 65536ull;                                                           \
-          const char* base_ = reinterpret_cast<const char*>(pe + 2 * (cb));                                            \
-          const char* a0 = base_ + (o0 < nb_ ? o0 : 0ull); const char* a1 = base_ + (o1 < nb_ ? o1 : 0ull);           \
-          u32 m0s_;                                                                                                    \
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dword %2, off\n\tglobal_load_lds_dword %3, off\n\ts_mov_b32 m0, %0" \
-                                : "=&s"(m0s_) : "s"(pfs_lds), "v"(a0), "v"(a1) : "memory"); }
-
     // cache fold of one accepted event whose bucket the caller has read (k0, k1); returns false when the event must travel
     auto cache_fold = [&](u32 bucket, u64 mk, u64 k0, u64 k1, u64 dur, u32 err) -> bool {
         int slot = k0 == mk ? (int)(2u * bucket) : (k1 == mk ? (int)(2u * bucket + 1u) : -1);
@@ -158,17 +156,20 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     auto general = [&](const v4u_t va, const v4u_t vb, u32* bc, u32& slo, u32& shi, u32& spr) {
         spr = K1T_NONE;
         K1Ev e;
-        if (!k1_resolve(d, make_uint4(va.x, va.y, va.z, va.w), make_uint4(vb.x, vb.y, vb.z, vb.w), L, e)) return;
+        K1T_LNEW(L);
+        const bool ok = k1_resolve(d, make_uint4(va.x, va.y, va.z, va.w), make_uint4(vb.x, vb.y, vb.z, vb.w), L, e);
+        if (!ok) { lflush(L); return; }
         u32 Lm, Rm;
         sg_kmix(ci_of_ref(d, (u32)(e.key >> 32)), ci_of_ref(d, (u32)e.key), nbmask, &Lm, &Rm);
         const u32 part = Lm >> pshift;
         const u64 mk = ((u64)Lm << nb) | Rm;
-        if (e.alive) { emit_wide(d, fcw, w, part, mk, 0ull, 0u, 1u, L); return; }
+        if (e.alive) { emit_wide(d, fcw, w, part, mk, 0ull, 0u, 1u, L); lflush(L); return; }
         const u32 bkt = Rm & bmask;
-        if (cache_fold(bkt, mk, lds_fresh_u64(&ckey[2 * bkt]), lds_fresh_u64(&ckey[2 * bkt + 1]), e.dur, e.err)) return;
-        if (e.dur >> 32) { emit_wide(d, fcw, w, part, mk, e.dur, e.err, 0u, L); return; }
+        if (cache_fold(bkt, mk, lds_fresh_u64(&ckey[2 * bkt]), lds_fresh_u64(&ckey[2 * bkt + 1]), e.dur, e.err)) { lflush(L); return; }
+        if (e.dur >> 32) { emit_wide(d, fcw, w, part, mk, e.dur, e.err, 0u, L); lflush(L); return; }
         const u32 rank = atomicAdd(&bc[part], 1u);
         slo = (u32)e.dur; shi = ((u32)mk & rbmask) | (e.err << 31); spr = part | (rank << K1T_RANK_SHIFT);
+        lflush(L);
     };
     constexpr u32 KSH = L2M == 2 ? 14u : 30u, IDM = L2M == 2 ? 0x3FFFu : 0x3FFFFFFFu;   // kind shift / id mask of a level-2 entry as this build reads it
     auto join = [&](u32 ip) -> u32 {
@@ -189,17 +190,17 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         rare &= inr; rare_out = rare;
         const bool fastv = inr & !rare;
         bool acc = fastv & (ks == 1u);                               /* data.go:829-832: the source must be a pod */
-        L.dsrc += (fastv & (ks != 1u)) ? 1u : 0u;
+        if (fastv & (ks != 1u)) atomicAdd(&red[WS_DROPPED_SRC], 1ull);
         u32 cf = vs & IDM;
         u32 ct = kd ? (vd & IDM) : (d.max_known + label - 1u);           /* service / pod id, else Host label (:840-854) */
-        { const u32 ml = (acc & (kd == 0u)) ? label : 0u; L.maxlabel = ml > L.maxlabel ? ml : L.maxlabel; }
+        if (acc & (kd == 0u)) atomicMax(&red[WS_MAXLABEL], (u64)label);
         if (flags & SG_EV_REVERSE) { const u32 x_ = cf; cf = ct; ct = x_; }      /* dto.go:226-231 */
-        if (SHARDED) { const bool mine = (owner_hash_ref(ref_of_ci(d, cf)) % d.world) == d.rank; L.misr += (acc & !mine) ? 1u : 0u; acc &= mine; }
+        if (SHARDED) { const bool mine = (owner_hash_ref(ref_of_ci(d, cf)) % d.world) == d.rank; if (acc & !mine) atomicAdd(&red[WS_MISROUTED], 1ull); acc &= mine; }
         const u32 status = va.w & 0xFFFFu, proto = (va.w >> 16) & 0xFFu, dur = vb.x;
         const u32 err = is_error(proto, status);
         const u64 wt = (u64)vb.z | ((u64)vb.w << 32);
-        L.acc += acc ? 1u : 0u;
-        L.tmin = (acc && wt < L.tmin) ? wt : L.tmin; L.tmax = (acc && wt > L.tmax) ? wt : L.tmax;
+        st_acc += acc ? 1u : 0u;
+        st_tmin = (acc && wt < st_tmin) ? wt : st_tmin; st_tmax = (acc && wt > st_tmax) ? wt : st_tmax;
         u32 Lm, Rm;
         sg_kmix(cf & nbmask, ct & nbmask, nbmask, &Lm, &Rm);        /* (the masks only matter for events that are not accepted) */
         const u32 part = Lm >> pshift, bucket = Rm & bmask;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         for (u32 p = t; p < NP; p += K1T_THREADS) {
             uint2 h = make_uint2(0u, 0u);
             if (!first) h = d.hdr8[(size_t)p * d.nwg + w];
-            fcn[p] = h.x; fcw[p] = h.y; bcnt[p] = 0u; bcnt[NP + p] = 0u;
+            fcn2[p] = h.x; fcn2[NP + p] = h.x; fcw[p] = h.y; bcnt[p] = 0u; bcnt[NP + p] = 0u;
         }
         for (u32 k = t; k < CT; k += K1T_THREADS) ckey[k] = SG_EKEY_EMPTY;
         for (u32 k = t; k < CT * 4; k += K1T_THREADS) cacc[k] = 0;
@@ -270,65 +271,105 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         LDS_BARRIER();
         SG_STAMP(d, 0, 1);
     }
-    const u32 bpw = NP >> 4;                                         // partitions whose runs a wave writes out (np >= 64)
+    // PACKB: the partition number rides in the free bits [rb, rb + pb) of a parked record's high word (2 nb <= 31): the copy-out
+    // is then one thread per tile position, all of a thread's LDS reads in flight together; otherwise 16 lanes walk a run.
+    const bool packb = 2u * nb <= 31u;
+    const u32 rb = d.rb;
     u32 cur = 0;
     u64 tk_p1 = 0, tk_wait = 0;                                      // SG_ABLATE & 0x100: wave 0's clock ticks in P1 / at the barrier behind it
     for (u64 c0 = w; c0 < nchunk; c0 += (u64)NSUB * d.nwg, cur ^= 1u) {
         u32* bc = bcnt + cur * NP;
+        u32* fcn = fcn2 + cur * NP;                                  // counts before this tile; the scan writes fcn2[cur ^ 1] = counts behind it
         u32 lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7;
         const u64 tk0 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
-        {   // P1: two chunks of up to four events per thread; behind each group's loads goes the prefetch of the chunk after it
+        {   // P1: NSUB chunks of up to four events per thread
             v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
             const u64 cb0 = c0 * chunk, ce0 = cb0 + chunk < end ? cb0 + chunk : end;
-            const u64 c1 = c0 + d.nwg, c2 = c0 + (u64)NSUB * d.nwg;
-            const u64 cb1 = c1 < nchunk ? c1 * chunk : cb0, ce1 = c1 < nchunk ? (cb1 + chunk < end ? cb1 + chunk : end) : cb0;   // no such chunk: an empty range
-            const u64 cb2 = c2 < nchunk ? c2 * chunk : cb0, ce2 = c2 < nchunk ? (cb2 + chunk < end ? cb2 + chunk : end) : cb0;   // the next tile's first chunk
-            // (no next chunk, or SG_ABLATE & 0x200: the prefetch re-touches the chunk being loaded — same instructions, no effect)
-            const bool pf1 = ce1 > cb1 && !(d.ablate & 0x200u), pf2 = ce2 > cb2 && !(d.ablate & 0x200u);
             const u64 i0 = cb0 + t;
             K1T_ISSUE(i0, ce0, cb0);
-            if (NSUB == 2) { K1T_PREFETCH(pf1 ? cb1 : cb0, pf1 ? ce1 : ce0); } else { K1T_PREFETCH(pf2 ? cb2 : cb0, pf2 ? ce2 : ce0); }
-            K1T_FOLD(2, i0, ce0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
+            K1T_FOLD(0, i0, ce0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
             if constexpr (NSUB == 2) {
+                const u64 c1 = c0 + d.nwg;
+                const u64 cb1 = c1 < nchunk ? c1 * chunk : cb0, ce1 = c1 < nchunk ? (cb1 + chunk < end ? cb1 + chunk : end) : cb0;   // no second chunk: an empty range
                 const u64 i1 = cb1 + t;
                 K1T_ISSUE(i1, ce1, cb1);
-                K1T_PREFETCH(pf2 ? cb2 : cb0, pf2 ? ce2 : ce0);
-                K1T_FOLD(2, i1, ce1, bc, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7);
+                K1T_FOLD(0, i1, ce1, bc, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7);
             } else { pr4 = pr5 = pr6 = pr7 = K1T_NONE; lo4 = hi4 = lo5 = hi5 = lo6 = hi6 = lo7 = hi7 = 0; }
         }
         const u64 tk1 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         LDS_BARRIER();
         if (d.ablate & 0x100u) { const u64 tk2 = wall_clock64(); tk_p1 += tk1 - tk0; tk_wait += tk2 - tk1; }
-        {                                                            // P2: exclusive scan of the run lengths (np / 64 per lane) by EVERY wave
-            // (sixteen identical scans cost less than a barrier behind one: the offsets a wave needs in P3 are its own writes, and
-            // every wave writes the same values)
+        {   // P2: exclusive scan of the run lengths by EVERY wave (sixteen identical scans cost less than a barrier behind one: the
+            // offsets a wave needs in P3 are its own writes, every wave writes the same values).  Lane l owns the np / 64 consecutive
+            // partitions from l * np / 64; the wave-wide part is DPP + readlane, no LDS round trip.
             const u32 pl = NP >> 6, b0 = lane * pl;
-            u32 s = 0;
-            for (u32 k = 0; k < pl; k++) s += bc[b0 + k];
-            u32 incl = s;
+            u32 c8[8], s = 0;                                        // (np <= 512: at most 8 per lane in registers; larger np loops)
+            if (pl <= 8) {
 #pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) { const u32 o = __shfl_up(incl, sh, 64); if ((int)lane >= sh) incl += o; }
+                for (u32 k = 0; k < 8; k++) { c8[k] = k < pl ? bc[b0 + k] : 0u; s += c8[k]; }
+            } else for (u32 k = 0; k < pl; k++) s += bc[b0 + k];
+            u32 incl = s;                                            // inclusive scan over the 64 lanes
+            incl += dpp32<0x111>(incl); incl += dpp32<0x112>(incl); incl += dpp32<0x114>(incl); incl += dpp32<0x118>(incl);   // row_shr 1, 2, 4, 8 (zero fill)
+            const u32 r0 = rdlane32(incl, 15), r1 = rdlane32(incl, 31), r2 = rdlane32(incl, 47);
+            incl += (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
             u32 run = incl - s;
-            for (u32 k = 0; k < pl; k++) { const u32 c = bc[b0 + k]; boff[b0 + k] = run; run += c; }
+            // the wave that owns a partition (wave = partition / (np / 16)) also moves its piece counter on and re-arms the run counter the
+            // NEXT tile's ranks come from (this tile's is re-armed behind the next barrier-1, when every wave is past this scan)
+            const bool own = (b0 / (NP >> 4)) == wave;
+            u32* fnext = fcn2 + (cur ^ 1u) * NP;
+            if (pl <= 8) {
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) if (k < pl) {
+                    boff[b0 + k] = run; run += c8[k];
+                    if (own) { const u32 nx = fcn[b0 + k] + c8[k]; fnext[b0 + k] = nx < d.sn ? nx : d.sn; }
+                }
+            } else for (u32 k = 0; k < pl; k++) {
+                const u32 c = bc[b0 + k]; boff[b0 + k] = run; run += c;
+                if (own) { const u32 nx = fcn[b0 + k] + c; fnext[b0 + k] = nx < d.sn ? nx : d.sn; }
+            }
+            // re-arm the OTHER run-counter set (tile k - 1's, read for the last time in its scan): ranks of tile k + 1 start at zero
+            u32* bprev = bcnt + (cur ^ 1u) * NP;
+            if (own) for (u32 k = 0; k < pl; k++) bprev[b0 + k] = 0u;
         }
-#define K1T_DROP(lo, hi, pr) if ((pr) != K1T_NONE) tile[boff[(pr) & ((1u << K1T_RANK_SHIFT) - 1u)] + ((pr) >> K1T_RANK_SHIFT)] = (u64)(lo) | ((u64)(hi) << 32)
-        K1T_DROP(lo0, hi0, pr0); K1T_DROP(lo1, hi1, pr1); K1T_DROP(lo2, hi2, pr2); K1T_DROP(lo3, hi3, pr3);   // P3
+        // P3: every thread drops its records at offset + rank (PACKB: with the partition number in the free bits of the high word)
+#define K1T_DROP(lo, hi, pr) if ((pr) != K1T_NONE) { const u32 pt_ = (pr) & ((1u << K1T_RANK_SHIFT) - 1u);                                  \
+            tile[boff[pt_] + ((pr) >> K1T_RANK_SHIFT)] = (u64)(lo) | ((u64)((hi) | (packb ? pt_ << rb : 0u)) << 32); }
+        K1T_DROP(lo0, hi0, pr0); K1T_DROP(lo1, hi1, pr1); K1T_DROP(lo2, hi2, pr2); K1T_DROP(lo3, hi3, pr3);
         if constexpr (NSUB == 2) { K1T_DROP(lo4, hi4, pr4); K1T_DROP(lo5, hi5, pr5); K1T_DROP(lo6, hi6, pr6); K1T_DROP(lo7, hi7, pr7); }
 #undef K1T_DROP
         LDS_BARRIER();
-        for (u32 b4 = 0; b4 < bpw; b4 += 4) {                        // P4: four runs per wave step, 16 lanes each
-            const u32 b = wave * bpw + b4 + (lane >> 4), j0 = lane & 15u;
-            const u32 cnt = bc[b], off = boff[b], pos0 = fcn[b];
-            u64* dst = piece8(d, b, w);
-            for (u32 j = j0; j < cnt; j += 16) {
-                const u64 rec = tile[off + j];
-                const u32 pos = pos0 + j;
-                if (pos < d.sn) { if (!(d.ablate & 0x1u)) dst[pos] = rec; }
-                else ovf8_single(d, b, ((u64)b << d.rb) | ((u32)(rec >> 32) & rbmask), rec & 0xFFFFFFFFull, (u32)(rec >> 63), 0u, L);
+        // P4: copy the runs to the pieces — adjacent lanes, adjacent addresses
+        if (packb) {
+            const u32 total = boff[NP - 1] + bc[NP - 1];             // records in the tile
+            const u32 strip = ~(((1u << d.pb) - 1u) << rb);         // clears the partition bits (bit 31 = error stays)
+#pragma unroll
+            for (u32 k = 0; k < 4 * NSUB; k++) {
+                const u32 i = t + k * K1T_THREADS;
+                if (i < total) {
+                    const u64 rec = tile[i];
+                    const u32 hi = (u32)(rec >> 32), b = (hi >> rb) & ((1u << d.pb) - 1u);
+                    const u32 pos = fcn[b] + (i - boff[b]);
+                    const u64 out = (rec & 0xFFFFFFFFull) | ((u64)(hi & strip) << 32);
+                    if (pos < d.sn) { if (!(d.ablate & 0x1u)) piece8(d, b, w)[pos] = out; }
+                    else { K1T_LNEW(L); ovf8_single(d, b, ((u64)b << rb) | (hi & rbmask), rec & 0xFFFFFFFFull, hi >> 31, 0u, L); lflush(L); }
+                }
             }
-            if (j0 == 0) { bc[b] = 0u; const u32 np_ = pos0 + cnt; fcn[b] = np_ < d.sn ? np_ : d.sn; }
+        } else {
+            const u32 bpw = NP >> 4;                                 // partitions whose runs a wave writes out (np >= 64): four per step, 16 lanes each
+            for (u32 b4 = 0; b4 < bpw; b4 += 4) {
+                const u32 b = wave * bpw + b4 + (lane >> 4), j0 = lane & 15u;
+                const u32 cnt = bc[b], off = boff[b], pos0 = fcn[b];
+                u64* dst = piece8(d, b, w);
+                for (u32 j = j0; j < cnt; j += 16) {
+                    const u64 rec = tile[off + j];
+                    const u32 pos = pos0 + j;
+                    if (pos < d.sn) { if (!(d.ablate & 0x1u)) dst[pos] = rec; }
+                    else { K1T_LNEW(L); ovf8_single(d, b, ((u64)b << rb) | ((u32)(rec >> 32) & rbmask), rec & 0xFFFFFFFFull, (u32)(rec >> 63), 0u, L); lflush(L); }
+                }
+            }
         }
     }
+    u32* fcn = fcn2 + cur * NP;                                      // the counts behind the last tile (written by its scan)
     SG_STAMP(d, 0, 3);
     if ((d.ablate & 0x100u) && t == 0 && blockIdx.x < 4096) { u64* g = d.dbg + ((size_t)0 * 4096 + blockIdx.x) * 8; g[2] = tk_p1; g[7] = tk_wait; }
 #undef K1T_ISSUE
@@ -336,6 +377,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     LDS_BARRIER();
     SG_STAMP(d, 0, 4);
     // flush the cache: a key seen once leaves as a single record, the others as aggregates
+    K1T_LNEW(L);
     for (u32 s = t; s < CT; s += K1T_THREADS) {
         const u64 k = ckey[s];
         if (k == SG_EKEY_EMPTY) continue;
@@ -348,18 +390,11 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         } else if ((x0 & 0xFFFFFFFFull) != 0ull) emit_agg8(d, fcw, w, part, k, x0, cacc[s * 4 + 1], cacc[s * 4 + 2], cacc[s * 4 + 3], L, first);
     }
     // workgroup statistics: wave reduce -> LDS -> one thread updates this workgroup's private line
+    lflush(L);
     {
-        const u64 tmin = wave_min_u64(L.tmin), tmax = wave_max_u64(L.tmax);
-        const u32 ml = (u32)wave_max_u64(L.maxlabel);
-        const u32 ds = wave_sum_u32(L.dsrc), dc = wave_sum_u32(L.dcap), mr = wave_sum_u32(L.misr), ac = wave_sum_u32(L.acc), ls = wave_sum_u32(L.lost);
-        if (lane == 0) {
-            if (ac) { atomicMin(&red[WS_TMIN], tmin); atomicMax(&red[WS_TMAX], tmax); atomicAdd(&red[WS_ACCEPTED], (u64)ac); }
-            if (ls) atomicAdd(&red[WS_PAD], (u64)ls);
-            if (ml) atomicMax(&red[WS_MAXLABEL], (u64)ml);
-            if (ds) atomicAdd(&red[WS_DROPPED_SRC], (u64)ds);
-            if (dc) atomicAdd(&red[WS_DROPPED_CAP], (u64)dc);
-            if (mr) atomicAdd(&red[WS_MISROUTED], (u64)mr);
-        }
+        const u64 tmin = wave_min_u64(st_tmin), tmax = wave_max_u64(st_tmax);
+        const u32 ac = wave_sum_u32(st_acc);
+        if (lane == 0 && ac) { atomicMin(&red[WS_TMIN], tmin); atomicMax(&red[WS_TMAX], tmax); atomicAdd(&red[WS_ACCEPTED], (u64)ac); }
     }
     LDS_BARRIER();
     for (u32 p = t; p < NP; p += K1T_THREADS) d.hdr8[(size_t)p * d.nwg + w] = make_uint2(fcn[p], fcw[p]);
@@ -375,6 +410,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     }
     SG_STAMP(d, 0, 6);
 #undef LDS_BARRIER
+#undef K1T_LNEW
 }
 
 // ---- pass B ---------------------------------------------------------------------------------------------------------
