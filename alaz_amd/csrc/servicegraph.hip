@@ -694,6 +694,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         for (u32 l = 1; l <= cfg->layers; l++) LR(dev_alloc(e, &w.h[l], (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.P, (size_t)w.ncap * SG_F_HID)); LR(dev_alloc(e, &w.Q, (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.nmean, (size_t)w.ncap * SG_F_HID));
+        w.hub_cap = (u32)std::min<u64>(ME / 256 + 16, 1u << 24);         // blocks of the rows longer than one block: at most E / 512 + one per such row
+        LR(dev_alloc(e, &w.hub_items, w.hub_cap)); LR(dev_alloc(e, &w.hub_base, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.hub_part, (size_t)w.hub_cap * SG_F_HID));
         LR(dev_alloc(e, &w.efeat, ME * SG_F_EDGE)); LR(dev_alloc(e, &w.latz, ME)); LR(dev_alloc(e, &w.errr, ME));
         LR(dev_alloc(e, &w.row_mu, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.row_sd, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.rows, ME));

@@ -56,6 +56,7 @@ enum {
     C_ALIVE_DROPPED,  // closed window: records not marked (capacity / unlisted endpoint)
     C_ACT_L,          // world > 1: nodes whose layer output this shard computes (local sources + local leaf destinations)
     C_ACT_P,          // world > 1: nodes whose score projections this shard needs (local sources + local destinations)
+    C_HUB_ITEMS,      // (row, block) work items of the rows with more than SG_MEAN_BLOCK neighbours (k2_rowptr -> k4_gather)
     C_COUNT = 24
 };
 
@@ -160,6 +161,9 @@ struct Dev {
     float* h[SG_MAX_LAYERS + 1];              // h[l] = output of layer l (l>=1): [ncap][64]
     float* P; float* Q;                       // [ncap][64]
     float* nmean;                             // [ncap][64] neighbour means of the layer being computed (k4_gather -> k4_sage_layer)
+    uint2* hub_items; u32 hub_cap;            // [hub_cap] {row, block}: the 512-neighbour blocks of the rows longer than one block, one work item each
+    u32* hub_base;                            // [ncap] first work item of a hub row
+    float* hub_part;                          // [hub_cap][64] block sums of the layer being computed (k4_gather -> k4_sage_layer adds them in block order)
     double* row_mu; double* row_sd;           // [ncap] mean / std (us) of a source's out-events: written by the row sort, read once per edge by edge_features
     const float* l1p_tab;                     // [SG_L1P_TAB] (float)log1p((double)i), filled on the device at create: small counts skip the fp64 log1p
     float* efeat;                             // [max_edges][8]

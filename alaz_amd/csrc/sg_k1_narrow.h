@@ -276,7 +276,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     const bool packb = 2u * nb <= 31u;
     const u32 rb = d.rb;
     u32 cur = 0;
-    u64 tk_p1 = 0, tk_wait = 0;                                      // SG_ABLATE & 0x100: wave 0's clock ticks in P1 / at the barrier behind it
+    u64 tk_p1 = 0, tk_wait = 0, tk_scan = 0, tk_p3 = 0, tk_b3 = 0, tk_p4 = 0;   // SG_ABLATE & 0x100: wave 0's clock ticks per phase
     for (u64 c0 = w; c0 < nchunk; c0 += (u64)NSUB * d.nwg, cur ^= 1u) {
         u32* bc = bcnt + cur * NP;
         u32* fcn = fcn2 + cur * NP;                                  // counts before this tile; the scan writes fcn2[cur ^ 1] = counts behind it
@@ -298,7 +298,8 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         }
         const u64 tk1 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         LDS_BARRIER();
-        if (d.ablate & 0x100u) { const u64 tk2 = wall_clock64(); tk_p1 += tk1 - tk0; tk_wait += tk2 - tk1; }
+        const u64 tk2 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
+        tk_p1 += tk1 - tk0; tk_wait += tk2 - tk1;
         {   // P2: exclusive scan of the run lengths by EVERY wave (sixteen identical scans cost less than a barrier behind one: the
             // offsets a wave needs in P3 are its own writes, every wave writes the same values).  Lane l owns the np / 64 consecutive
             // partitions from l * np / 64; the wave-wide part is DPP + readlane, no LDS round trip.
@@ -331,13 +332,16 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
             u32* bprev = bcnt + (cur ^ 1u) * NP;
             if (own) for (u32 k = 0; k < pl; k++) bprev[b0 + k] = 0u;
         }
+        const u64 tk3 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         // P3: every thread drops its records at offset + rank (PACKB: with the partition number in the free bits of the high word)
 #define K1T_DROP(lo, hi, pr) if ((pr) != K1T_NONE) { const u32 pt_ = (pr) & ((1u << K1T_RANK_SHIFT) - 1u);                                  \
             tile[boff[pt_] + ((pr) >> K1T_RANK_SHIFT)] = (u64)(lo) | ((u64)((hi) | (packb ? pt_ << rb : 0u)) << 32); }
         K1T_DROP(lo0, hi0, pr0); K1T_DROP(lo1, hi1, pr1); K1T_DROP(lo2, hi2, pr2); K1T_DROP(lo3, hi3, pr3);
         if constexpr (NSUB == 2) { K1T_DROP(lo4, hi4, pr4); K1T_DROP(lo5, hi5, pr5); K1T_DROP(lo6, hi6, pr6); K1T_DROP(lo7, hi7, pr7); }
 #undef K1T_DROP
+        const u64 tk4 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         LDS_BARRIER();
+        const u64 tk5 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         // P4: copy the runs to the pieces — adjacent lanes, adjacent addresses
         if (packb) {
             const u32 total = boff[NP - 1] + bc[NP - 1];             // records in the tile
@@ -368,10 +372,11 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
                 }
             }
         }
+        if (d.ablate & 0x100u) { const u64 tk6 = wall_clock64(); tk_scan += tk3 - tk2; tk_p3 += tk4 - tk3; tk_b3 += tk5 - tk4; tk_p4 += tk6 - tk5; }
     }
     u32* fcn = fcn2 + cur * NP;                                      // the counts behind the last tile (written by its scan)
     SG_STAMP(d, 0, 3);
-    if ((d.ablate & 0x100u) && t == 0 && blockIdx.x < 4096) { u64* g = d.dbg + ((size_t)0 * 4096 + blockIdx.x) * 8; g[2] = tk_p1; g[7] = tk_wait; }
+    if ((d.ablate & 0x100u) && t == 0 && blockIdx.x < 4096) { u64* g = d.dbg + ((size_t)2 * 4096 + blockIdx.x) * 8; g[0] = tk_p1; g[1] = tk_wait; g[2] = tk_scan; g[3] = tk_p3; g[4] = tk_b3; g[5] = tk_p4; }
 #undef K1T_ISSUE
 #undef K1T_FOLD
     LDS_BARRIER();

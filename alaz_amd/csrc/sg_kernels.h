@@ -92,6 +92,7 @@ __device__ __forceinline__ float wave_butterfly_sum_f32(float r) {
 // k5_edge_score): hidden unit j lives at position (j & 15) * 4 + (j >> 4), so that the four units {q, q+16, q+32, q+48}
 // a lane of k5_edge_score owns are one 16-byte load.
 #define SG_PQ_POS(j) ((((j) & 15) << 2) | ((j) >> 4))
+#define SG_MEAN_BLOCK 512        // neighbours per block of the canonical mean: block sums are added in block order
 #define SG_OP_MIN(a, b) ((b) < (a) ? (b) : (a))
 #define SG_OP_MAX(a, b) ((b) > (a) ? (b) : (a))
 #define SG_OP_ADD(a, b) ((a) + (b))
@@ -829,6 +830,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
             d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
             d.ctr[C_DROPPED_CAP] = red[4][0];                        // K1b / K2 add their own drops afterwards
             d.ctr[C_N_LONG] = 0;                                     // k2_rowptr's workgroups append to the long-row list
+            d.ctr[C_HUB_ITEMS] = 0;                                  // ... and to the hub-block work list
         }
     }
     // (b)
@@ -1005,6 +1007,12 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     if (t < K2_RP_ROWS && r0 + t < N) {
         d.rowptr[r0 + t] = base + run;
         if (dg > 64) atomicAdd(&nlong, 1u);
+        if (dg > SG_MEAN_BLOCK) {                                    // a hub row: one work item per 512-neighbour block (k4_gather spreads them over the chip)
+            const u32 nblk = (dg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
+            const u32 ib = (u32)atomicAdd(&d.ctr[C_HUB_ITEMS], (u64)nblk);   // C_HUB_ITEMS is zeroed by kc_prepare
+            d.hub_base[r0 + t] = ib;
+            for (u32 j = 0; j < nblk; j++) if (ib + j < d.hub_cap) d.hub_items[ib + j] = make_uint2(r0 + t, j);
+        }
     }
     __syncthreads();
     if (t == 0) lbase = nlong ? (u32)atomicAdd(&d.ctr[C_N_LONG], (u64)nlong) : 0u;   // C_N_LONG is zeroed by kc_prepare
@@ -1112,180 +1120,255 @@ __device__ __forceinline__ void edge_features(const Dev& d, u32 pos) {
 
 #define K2_SORT_LDS 4096
 #define K2_LONG_WGS 1024
+#define K2_WAVE_ROW 512          // rows of up to this many edges are sorted by ONE wave (bitmap rank in a wave-private slice of the LDS arrays)
+#define K2_WAVE_BW  1024         // ... when the node bitmap fits this many words (N <= 32768)
+// One row sorted by the whole workgroup (rows of more than K2_WAVE_ROW edges, or node spaces beyond the wave-private bitmaps).
+__device__ __forceinline__ void k2_row_wg(const Dev& d, const EdgeEmitArgs& ea, const u32 rr, u32* sk, u32* sv, u64 (*red)[4], u32* bsum, const u32 BW) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 b = d.rowptr[rr];
+    u32 m = d.rowptr[rr + 1] - b;
+    if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
+    if (m == 0) return;
+    const uint2* in = d.cs + b; u32* key = d.col + b;              // in: {destination, slot} as scattered; key: the row's sorted destinations (output only)
+    u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
+    if (BW <= K2_SORT_LDS && m <= 1024) {
+        // The common long row (65..1024 edges): bitmap rank as below, but every thread keeps its (<= 4) elements
+        // and their accumulators in registers — one global round trip (the accumulator gather, issued before the
+        // rank is known), no scratch arrays, three barriers.
+        for (u32 w = threadIdx.x; w < BW; w += 256) sk[w] = 0;
+        __syncthreads();
+        u32 mk[4], mv[4]; ulonglong2 ax[4], ay[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 i = threadIdx.x + q * 256;
+            const uint2 kv = in[i < m ? i : m - 1]; mk[q] = i < m ? kv.x : 0u; mv[q] = i < m ? kv.y : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 i = threadIdx.x + q * 256;
+            if (i < m) { atomicOr(&sk[mk[q] >> 5], 1u << (mk[q] & 31)); const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q] * 4); ax[q] = a[0]; ay[q] = a[1]; }
+            else { ax[q] = make_ulonglong2(0, 0); ay[q] = make_ulonglong2(0, 0); }
+        }
+        __syncthreads();
+        {   // sv[w] = number of set bits in words [0, w)
+            const u32 per = (BW + 255) / 256, w0 = threadIdx.x * per < BW ? threadIdx.x * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
+            u32 c = 0;
+            for (u32 w = w0; w < w1; w++) c += __popc(sk[w]);
+            u32 tot;
+            u32 run = block_excl_scan<256>(c, bsum, &tot);
+            for (u32 w = w0; w < w1; w++) { sv[w] = run; run += __popc(sk[w]); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) { cnt += ax[q].x & 0xFFFFFFFFull; err += ax[q].x >> 32; sum += ax[q].y; ssq += ay[q].y; mx = ay[q].x > mx ? ay[q].x : mx; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) {
+            const u32 k = mk[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
+            key[r] = k;
+            edge_emit(ea, b + r, rr, mv[q], 0, 0, 0, ax[q], ay[q]);
+        }
+        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+        if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+        __syncthreads();
+        cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+        mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+    } else if (BW <= K2_SORT_LDS) {
+        // Bitmap rank: the destinations of one row are distinct node ids < N, so setting bit `to` in an
+        // N-bit LDS bitmap and counting the bits below it IS the sorted position — O(m + N/32) per row
+        // instead of a comparison sort (a 3000-edge hub row cost ~100 us in the bitonic network).
+        for (u32 w = threadIdx.x; w < BW; w += 256) sk[w] = 0;
+        __syncthreads();
+        // (every pass over the row takes four elements per thread and round: their loads are independent and in flight
+        // together — one element per round made a 3 700-edge row cost five passes x 15 dependent round trips, 75-95 us)
+        for (u32 i0 = 0; i0 < m; i0 += 1024) {
+            u32 k4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; k4[q] = in[i < m ? i : m - 1].x; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (i0 + threadIdx.x + q * 256 < m) atomicOr(&sk[k4[q] >> 5], 1u << (k4[q] & 31));
+        }
+        __syncthreads();
+        {   // sv[w] = number of set bits in words [0, w)
+            const u32 per = (BW + 255) / 256, w0 = threadIdx.x * per < BW ? threadIdx.x * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
+            u32 c = 0;
+            for (u32 w = w0; w < w1; w++) c += __popc(sk[w]);
+            u32 tot;
+            u32 run = block_excl_scan<256>(c, bsum, &tot);
+            for (u32 w = w0; w < w1; w++) { sv[w] = run; run += __popc(sk[w]); }
+        }
+        __syncthreads();
+        for (u32 i0 = 0; i0 < m; i0 += 1024) {               // rank -> CSR position: destination, accumulators; the row totals on the way
+            u32 k4[4], v4[4]; ulonglong2 x4[4], y4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; const uint2 kv = in[i < m ? i : m - 1]; k4[q] = kv.x; v4[q] = kv.y; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v4[q] * 4); x4[q] = a[0]; y4[q] = a[1]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (i0 + threadIdx.x + q * 256 < m) {
+                const u32 k = k4[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
+                key[r] = k;                                  // (input and output are different arrays: no scratch, no second pass)
+                edge_emit(ea, b + r, rr, v4[q], 0, 0, 0, x4[q], y4[q]);
+                cnt += x4[q].x & 0xFFFFFFFFull; err += x4[q].x >> 32; sum += x4[q].y; ssq += y4[q].y; mx = y4[q].x > mx ? y4[q].x : mx;
+            }
+        }
+        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+        if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+        __syncthreads();
+        cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+        mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+    } else if (m <= 1024) {
+        // rank sort: keys in LDS, every thread counts the smaller keys of its (<= 4) elements
+        for (u32 i = threadIdx.x; i < m; i += 256) sk[i] = in[i].x;
+        __syncthreads();
+        u32 mk[4], mv[4], rk[4]; ulonglong2 ax[4], ay[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 i = threadIdx.x + q * 256;
+            mk[q] = i < m ? sk[i] : 0xFFFFFFFFu; mv[q] = i < m ? in[i].y : 0u; rk[q] = 0;
+            if (i < m) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q] * 4); ax[q] = a[0]; ay[q] = a[1]; }
+            else { ax[q] = make_ulonglong2(0, 0); ay[q] = make_ulonglong2(0, 0); }
+        }
+        for (u32 j = 0; j < m; j++) {
+            const u32 kj = sk[j];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rk[q] += kj < mk[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { cnt += ax[q].x & 0xFFFFFFFFull; err += ax[q].x >> 32; sum += ax[q].y; ssq += ay[q].y; mx = ay[q].x > mx ? ay[q].x : mx; }
+        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+        if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+        __syncthreads();
+        cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+        mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) { key[rk[q]] = mk[q]; edge_emit(ea, b + rk[q], rr, mv[q], cnt, sum, ssq, ax[q], ay[q]); }
+    } else {
+        u32 np2 = 1; while (np2 < m) np2 <<= 1;
+        u32* gk = sk; u32* gv = sv;
+        if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
+        for (u32 i = threadIdx.x; i < np2; i += 256) { const uint2 kv = in[i < m ? i : m - 1]; gk[i] = i < m ? kv.x : 0xFFFFFFFFu; gv[i] = i < m ? kv.y : 0; }
+        __syncthreads();
+        for (u32 k = 2; k <= np2; k <<= 1)
+            for (u32 j = k >> 1; j > 0; j >>= 1) {
+                for (u32 i = threadIdx.x; i < np2; i += 256) {
+                    const u32 x = i ^ j;
+                    if (x > i) {
+                        const u32 a = gk[i], c = gk[x];
+                        if ((a > c) == ((i & k) == 0)) { gk[i] = c; gk[x] = a; const u32 tt = gv[i]; gv[i] = gv[x]; gv[x] = tt; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (u32 i = threadIdx.x; i < m; i += 256) {
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
+            const ulonglong2 x = a[0], y = a[1];
+            cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
+        }
+        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+        if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+        __syncthreads();
+        cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+        mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+        for (u32 i = threadIdx.x; i < m; i += 256) {
+            const u32 slot = gv[i];
+            key[i] = gk[i];
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
+            const ulonglong2 x = a[0], y = a[1];
+            edge_emit(ea, b + i, rr, slot, cnt, sum, ssq, x, y);
+        }
+    }
+    if (threadIdx.x == 0) {
+        u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
+        t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+        d.st_max[(size_t)rr * 2] = mx;
+        d.row_mu[rr] = mean_us(sum, cnt); d.row_sd[rr] = std_us(sum, ssq, cnt);
+    }
+    __syncthreads();
+}
+// One row of 65 .. K2_WAVE_ROW edges sorted by one wave, no barrier: the destinations of a row are distinct node ids < N, so
+// setting bit `to` in an N-bit bitmap and counting the bits below it IS the sorted position.  bm / pf: the wave's private
+// BW-word bitmap and word-prefix arrays (LDS operations of one wave execute in order).
+__device__ __forceinline__ void k2_row_wave(const Dev& d, const EdgeEmitArgs& ea, const u32 rr, u32* bm, u32* pf, const u32 BW) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 b = d.rowptr[rr];
+    u32 m = d.rowptr[rr + 1] - b;
+    if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
+    if (m == 0) return;
+    const uint2* in = d.cs + b; u32* key = d.col + b;
+    constexpr int Q = K2_WAVE_ROW / 64;
+    u32 mk[Q], mv[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) { const u32 i = lane + 64u * q; const uint2 kv = in[i < m ? i : m - 1]; mk[q] = kv.x; mv[q] = kv.y; }
+    for (u32 w = lane; w < BW; w += 64) bm[w] = 0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) if (lane + 64u * q < m) atomicOr(&bm[mk[q] >> 5], 1u << (mk[q] & 31));
+    {   // pf[w] = set bits in words [0, w): lane l owns the words [l * per, (l + 1) * per)
+        const u32 per = (BW + 63) >> 6, w0 = lane * per < BW ? lane * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
+        u32 c = 0;
+        for (u32 w = w0; w < w1; w++) c += __popc(bm[w]);
+        u32 incl = c;
+        incl += dpp32<0x111>(incl); incl += dpp32<0x112>(incl); incl += dpp32<0x114>(incl); incl += dpp32<0x118>(incl);   // row_shr 1, 2, 4, 8
+        const u32 r0 = rdlane32(incl, 15), r1 = rdlane32(incl, 31), r2 = rdlane32(incl, 47);
+        incl += (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
+        u32 run = incl - c;
+        for (u32 w = w0; w < w1; w++) { pf[w] = run; run += __popc(bm[w]); }
+    }
+    u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
+#pragma unroll
+    for (int q0 = 0; q0 < Q; q0 += 4) {                              // four accumulator gathers in flight
+        ulonglong2 x4[4], y4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q0 + q] * 4); x4[q] = a[0]; y4[q] = a[1]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (lane + 64u * (q0 + q) < m) {
+            const u32 k = mk[q0 + q], r = pf[k >> 5] + __popc(bm[k >> 5] & ((1u << (k & 31)) - 1u));
+            key[r] = k;
+            edge_emit(ea, b + r, rr, mv[q0 + q], 0, 0, 0, x4[q], y4[q]);
+            cnt += x4[q].x & 0xFFFFFFFFull; err += x4[q].x >> 32; sum += x4[q].y; ssq += y4[q].y; mx = y4[q].x > mx ? y4[q].x : mx;
+        }
+    }
+    cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+    if (lane == 0) {
+        u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
+        t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+        d.st_max[(size_t)rr * 2] = mx;
+        d.row_mu[rr] = mean_us(sum, cnt); d.row_sd[rr] = std_us(sum, ssq, cnt);
+    }
+}
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
     const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant, d.hist_src, d.hist_csr, d.hist};
     __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
     __shared__ u64 red[5][4];
     __shared__ u32 bsum[5];
+    __shared__ u32 bigrow[4];
     const u32 BW = (N + 31) >> 5;                                    // words of a node bitmap
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // ---- long rows: the first K2_LONG_WGS workgroups, one row at a time each ----
+    // ---- long rows (more than 64 edges): the first K2_LONG_WGS workgroups take four list entries at a time, a wave each; a row of
+    // up to K2_WAVE_ROW edges is sorted by its wave alone (wave-private quarter of sk / sv), a longer one by the whole workgroup
+    // afterwards (rows of 65..1024 edges used to cost a workgroup three barriers and a 256-thread scan of the bitmap EACH) ----
     const u32 nlw = gridDim.x > 2 * K2_LONG_WGS ? K2_LONG_WGS : (gridDim.x / 2 ? gridDim.x / 2 : 1);   // host launches >= 2 workgroups
     if (blockIdx.x < nlw) {
-        for (u32 li = blockIdx.x; li < nlong; li += nlw) {
-            const u32 rr = d.longrows[li];
-            const u32 b = d.rowptr[rr];
-            u32 m = d.rowptr[rr + 1] - b;
-            if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
-            if (m == 0) continue;
-            const uint2* in = d.cs + b; u32* key = d.col + b;              // in: {destination, slot} as scattered; key: the row's sorted destinations (output only)
-            u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
-            if (BW <= K2_SORT_LDS && m <= 1024) {
-                // The common long row (65..1024 edges): bitmap rank as below, but every thread keeps its (<= 4) elements
-                // and their accumulators in registers — one global round trip (the accumulator gather, issued before the
-                // rank is known), no scratch arrays, three barriers.
-                for (u32 w = threadIdx.x; w < BW; w += 256) sk[w] = 0;
-                __syncthreads();
-                u32 mk[4], mv[4]; ulonglong2 ax[4], ay[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const u32 i = threadIdx.x + q * 256;
-                    const uint2 kv = in[i < m ? i : m - 1]; mk[q] = i < m ? kv.x : 0u; mv[q] = i < m ? kv.y : 0u;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const u32 i = threadIdx.x + q * 256;
-                    if (i < m) { atomicOr(&sk[mk[q] >> 5], 1u << (mk[q] & 31)); const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q] * 4); ax[q] = a[0]; ay[q] = a[1]; }
-                    else { ax[q] = make_ulonglong2(0, 0); ay[q] = make_ulonglong2(0, 0); }
-                }
-                __syncthreads();
-                {   // sv[w] = number of set bits in words [0, w)
-                    const u32 per = (BW + 255) / 256, w0 = threadIdx.x * per < BW ? threadIdx.x * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
-                    u32 c = 0;
-                    for (u32 w = w0; w < w1; w++) c += __popc(sk[w]);
-                    u32 tot;
-                    u32 run = block_excl_scan<256>(c, bsum, &tot);
-                    for (u32 w = w0; w < w1; w++) { sv[w] = run; run += __popc(sk[w]); }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < 4; q++) { cnt += ax[q].x & 0xFFFFFFFFull; err += ax[q].x >> 32; sum += ax[q].y; ssq += ay[q].y; mx = ay[q].x > mx ? ay[q].x : mx; }
-#pragma unroll
-                for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) {
-                    const u32 k = mk[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
-                    key[r] = k;
-                    edge_emit(ea, b + r, rr, mv[q], 0, 0, 0, ax[q], ay[q]);
-                }
-                cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
-                if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
-                __syncthreads();
-                cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-                sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
-                mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-            } else if (BW <= K2_SORT_LDS) {
-                // Bitmap rank: the destinations of one row are distinct node ids < N, so setting bit `to` in an
-                // N-bit LDS bitmap and counting the bits below it IS the sorted position — O(m + N/32) per row
-                // instead of a comparison sort (a 3000-edge hub row cost ~100 us in the bitonic network).
-                for (u32 w = threadIdx.x; w < BW; w += 256) sk[w] = 0;
-                __syncthreads();
-                // (every pass over the row takes four elements per thread and round: their loads are independent and in flight
-                // together — one element per round made a 3 700-edge row cost five passes x 15 dependent round trips, 75-95 us)
-                for (u32 i0 = 0; i0 < m; i0 += 1024) {
-                    u32 k4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; k4[q] = in[i < m ? i : m - 1].x; }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) if (i0 + threadIdx.x + q * 256 < m) atomicOr(&sk[k4[q] >> 5], 1u << (k4[q] & 31));
-                }
-                __syncthreads();
-                {   // sv[w] = number of set bits in words [0, w)
-                    const u32 per = (BW + 255) / 256, w0 = threadIdx.x * per < BW ? threadIdx.x * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
-                    u32 c = 0;
-                    for (u32 w = w0; w < w1; w++) c += __popc(sk[w]);
-                    u32 tot;
-                    u32 run = block_excl_scan<256>(c, bsum, &tot);
-                    for (u32 w = w0; w < w1; w++) { sv[w] = run; run += __popc(sk[w]); }
-                }
-                __syncthreads();
-                for (u32 i0 = 0; i0 < m; i0 += 1024) {               // rank -> CSR position: destination, accumulators; the row totals on the way
-                    u32 k4[4], v4[4]; ulonglong2 x4[4], y4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { const u32 i = i0 + threadIdx.x + q * 256; const uint2 kv = in[i < m ? i : m - 1]; k4[q] = kv.x; v4[q] = kv.y; }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)v4[q] * 4); x4[q] = a[0]; y4[q] = a[1]; }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) if (i0 + threadIdx.x + q * 256 < m) {
-                        const u32 k = k4[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
-                        key[r] = k;                                  // (input and output are different arrays: no scratch, no second pass)
-                        edge_emit(ea, b + r, rr, v4[q], 0, 0, 0, x4[q], y4[q]);
-                        cnt += x4[q].x & 0xFFFFFFFFull; err += x4[q].x >> 32; sum += x4[q].y; ssq += y4[q].y; mx = y4[q].x > mx ? y4[q].x : mx;
-                    }
-                }
-                cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
-                if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
-                __syncthreads();
-                cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-                sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
-                mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-            } else if (m <= 1024) {
-                // rank sort: keys in LDS, every thread counts the smaller keys of its (<= 4) elements
-                for (u32 i = threadIdx.x; i < m; i += 256) sk[i] = in[i].x;
-                __syncthreads();
-                u32 mk[4], mv[4], rk[4]; ulonglong2 ax[4], ay[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const u32 i = threadIdx.x + q * 256;
-                    mk[q] = i < m ? sk[i] : 0xFFFFFFFFu; mv[q] = i < m ? in[i].y : 0u; rk[q] = 0;
-                    if (i < m) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q] * 4); ax[q] = a[0]; ay[q] = a[1]; }
-                    else { ax[q] = make_ulonglong2(0, 0); ay[q] = make_ulonglong2(0, 0); }
-                }
-                for (u32 j = 0; j < m; j++) {
-                    const u32 kj = sk[j];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) rk[q] += kj < mk[q];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) { cnt += ax[q].x & 0xFFFFFFFFull; err += ax[q].x >> 32; sum += ax[q].y; ssq += ay[q].y; mx = ay[q].x > mx ? ay[q].x : mx; }
-                cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
-                if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
-                __syncthreads();
-                cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-                sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
-                mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-#pragma unroll
-                for (int q = 0; q < 4; q++) if (threadIdx.x + q * 256 < m) { key[rk[q]] = mk[q]; edge_emit(ea, b + rk[q], rr, mv[q], cnt, sum, ssq, ax[q], ay[q]); }
-            } else {
-                u32 np2 = 1; while (np2 < m) np2 <<= 1;
-                u32* gk = sk; u32* gv = sv;
-                if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
-                for (u32 i = threadIdx.x; i < np2; i += 256) { const uint2 kv = in[i < m ? i : m - 1]; gk[i] = i < m ? kv.x : 0xFFFFFFFFu; gv[i] = i < m ? kv.y : 0; }
-                __syncthreads();
-                for (u32 k = 2; k <= np2; k <<= 1)
-                    for (u32 j = k >> 1; j > 0; j >>= 1) {
-                        for (u32 i = threadIdx.x; i < np2; i += 256) {
-                            const u32 x = i ^ j;
-                            if (x > i) {
-                                const u32 a = gk[i], c = gk[x];
-                                if ((a > c) == ((i & k) == 0)) { gk[i] = c; gk[x] = a; const u32 tt = gv[i]; gv[i] = gv[x]; gv[x] = tt; }
-                            }
-                        }
-                        __syncthreads();
-                    }
-                for (u32 i = threadIdx.x; i < m; i += 256) {
-                    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)gv[i] * 4);
-                    const ulonglong2 x = a[0], y = a[1];
-                    cnt += x.x & 0xFFFFFFFFull; err += x.x >> 32; sum += x.y; ssq += y.y; mx = y.x > mx ? y.x : mx;
-                }
-                cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
-                if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
-                __syncthreads();
-                cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-                sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
-                mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-                for (u32 i = threadIdx.x; i < m; i += 256) {
-                    const u32 slot = gv[i];
-                    key[i] = gk[i];
-                    const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)slot * 4);
-                    const ulonglong2 x = a[0], y = a[1];
-                    edge_emit(ea, b + i, rr, slot, cnt, sum, ssq, x, y);
-                }
+        const bool wave_ok = BW <= K2_WAVE_BW && !(d.ablate & 0x400u);
+        for (u32 l0 = blockIdx.x * 4; l0 < nlong; l0 += nlw * 4) {
+            const u32 li = l0 + wave;
+            u32 big = SG_NONE;
+            if (li < nlong) {
+                const u32 rr = d.longrows[li];
+                const u32 m = d.rowptr[rr + 1] - d.rowptr[rr];
+                if (wave_ok && m <= K2_WAVE_ROW) k2_row_wave(d, ea, rr, sk + wave * K2_WAVE_BW, sv + wave * K2_WAVE_BW, BW);
+                else big = rr;
             }
-            if (threadIdx.x == 0) {
-                u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
-                t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
-                d.st_max[(size_t)rr * 2] = mx;
-                d.row_mu[rr] = mean_us(sum, cnt); d.row_sd[rr] = std_us(sum, ssq, cnt);
+            if (lane == 0) bigrow[wave] = big;
+            __syncthreads();
+            for (u32 w2 = 0; w2 < 4; w2++) {
+                const u32 rr = bigrow[w2];
+                if (rr == SG_NONE) continue;                         // uniform
+                k2_row_wg(d, ea, rr, sk, sv, red, bsum, BW);
             }
             __syncthreads();
         }
@@ -1586,7 +1669,6 @@ __device__ __forceinline__ void gather_block_sum(const float* __restrict__ hin, 
     }
     if (g == 0) { dst[4 * c] = t.x; dst[4 * c + 1] = t.y; dst[4 * c + 2] = t.z; dst[4 * c + 3] = t.w; }   // (dst is only 8-byte aligned in the tile)
 }
-#define SG_MEAN_BLOCK 512        // neighbours per block of the canonical mean: block sums are added in block order
 
 // gather_block_sum for the stand-alone gather kernel: same sums in the same order, scheduled for the memory system.
 //  * every row load is unconditional (index clamped to the block's last neighbour, the value dropped by a select), so
@@ -1642,13 +1724,28 @@ template <int FI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k4_gather(Dev d, const float* __restrict__ hin) {
     __shared__ __attribute__((aligned(16))) float scr_all[8 * 16 * FI];
     __shared__ __attribute__((aligned(16))) float part[8 * FI];
-    __shared__ __attribute__((aligned(16))) float hub[K4_HUB_BLOCKS * FI];
-    __shared__ u32 vid[8], tdeg[8];
     const bool listed = d.world > 1 && d.ctr[C_ACT_L] != SG_ACT_NONE;
     const u32 N = listed ? (u32)d.ctr[C_ACT_L] : (u32)d.ctr[C_N_NODES];
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* scr = scr_all + wave * 16 * FI;
+    // Rows of more than one block first: every 512-neighbour block of such a row is ONE work item of the list k2_rowptr built,
+    // and the items are dealt to all waves of the launch (the 164 hub rows of C3 hold half of its edges: walked by the one
+    // workgroup whose tile they fell into they were ~20 us of each launch).  The item's block sum goes to hub_part[item]; the
+    // dense kernel adds a row's block sums in block order and divides — the same sums in the same order as before.
+    {
+        const u32 H = (u32)(d.ctr[C_HUB_ITEMS] < d.hub_cap ? d.ctr[C_HUB_ITEMS] : d.hub_cap);
+        const u32 gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+        for (u32 it = gw; it < H; it += nw) {
+            const uint2 x = d.hub_items[it];
+            bool sk = false;
+            if (d.world > 1) sk = owner_of_dense(d, x.x, nk, nl) != d.rank;      // (a hub row has out-edges: only its owner computes it)
+            if (sk) continue;
+            const u32 beg = d.rowptr[x.x], dg = d.rowptr[x.x + 1] - beg;
+            const u32 i0 = x.y * SG_MEAN_BLOCK, i1 = i0 + SG_MEAN_BLOCK < dg ? i0 + SG_MEAN_BLOCK : dg;
+            gather_block_sum2<FI>(hin, d.col + beg, i0, i1, d.hub_part + (size_t)it * SG_F_HID, scr);
+        }
+    }
     for (u32 tile = blockIdx.x; tile * K4G_ROWS < N; tile += gridDim.x) {
         const u32 i = tile * K4G_ROWS + wave;
         bool sk = i >= N;
@@ -1657,35 +1754,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
             const bool has_out = d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG] != 0;
             sk = has_out && owner_of_dense(d, v, nk, nl) != d.rank;
         }
-        u32 deg = 0;
         if (!sk) {
             const u32 beg = d.rowptr[v];
-            deg = d.rowptr[v + 1] - beg;
+            const u32 deg = d.rowptr[v + 1] - beg;
             float* dst = part + wave * FI;
             if (deg && deg <= SG_MEAN_BLOCK) gather_block_sum2<FI>(hin, d.col + beg, 0, deg, dst, scr);
             if (deg <= SG_MEAN_BLOCK && lane < FI) d.nmean[(size_t)v * SG_F_HID + lane] = deg ? dst[lane] / (float)deg : 0.0f;   // (same wave wrote dst)
         }
-        if (lane == 0) { vid[wave] = v; tdeg[wave] = sk ? 0u : deg; }
-        __syncthreads();
-        // rows of more than one block: ALL their blocks are spread over the 8 waves (the row's own wave did nothing above)
-        for (u32 r = 0; r < 8; r++) {
-            const u32 dg = tdeg[r];
-            if (dg <= SG_MEAN_BLOCK) continue;                       // uniform
-            const u32 hv = vid[r], beg = d.rowptr[hv], nblk = (dg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
-            float total = 0.0f;
-            for (u32 b0 = 0; b0 < nblk; b0 += K4_HUB_BLOCKS) {
-                const u32 bn = nblk - b0 < K4_HUB_BLOCKS ? nblk - b0 : K4_HUB_BLOCKS;
-                for (u32 j = wave; j < bn; j += 8) {
-                    const u32 i0 = (b0 + j) * SG_MEAN_BLOCK, i1 = i0 + SG_MEAN_BLOCK < dg ? i0 + SG_MEAN_BLOCK : dg;
-                    gather_block_sum2<FI>(hin, d.col + beg, i0, i1, hub + j * FI, scr);
-                }
-                __syncthreads();
-                if (wave == 0 && lane < FI) for (u32 j = 0; j < bn; j++) total = (b0 + j) ? total + hub[j * FI + lane] : hub[j * FI + lane];   // block 0 starts the sum
-                __syncthreads();
-            }
-            if (wave == 0 && lane < FI) d.nmean[(size_t)hv * SG_F_HID + lane] = total / (float)dg;
-        }
-        __syncthreads();
     }
 }
 
@@ -1732,7 +1807,14 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
                 const u32 beg = d.rowptr[v];
                 deg = d.rowptr[v + 1] - beg;
                 if constexpr (PRE) {
-                    for (u32 k = lane; k < FI; k += 64) row[FI + k] = deg ? d.nmean[(size_t)v * SG_F_HID + k] : 0.0f;
+                    if (deg > SG_MEAN_BLOCK) {                       // a hub row: its block sums (k4_gather's work items) in block order, one division
+                        const u32 nblk = (deg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK, ib = d.hub_base[v];
+                        for (u32 k = lane; k < FI; k += 64) {
+                            float total = d.hub_part[(size_t)ib * SG_F_HID + k];
+                            for (u32 j = 1; j < nblk; j++) total = total + d.hub_part[(size_t)(ib + j) * SG_F_HID + k];
+                            row[FI + k] = total / (float)deg;
+                        }
+                    } else for (u32 k = lane; k < FI; k += 64) row[FI + k] = deg ? d.nmean[(size_t)v * SG_F_HID + k] : 0.0f;
                     deg = 0;                                         // (nothing left for the hub loop)
                 } else {
                 // block 0 here (one wave per row, all rows at once); the further blocks of a hub row below
@@ -1893,6 +1975,10 @@ __global__ __launch_bounds__(256) void k5_node_proj(Dev d, const float* __restri
 //   the SAME lane (j ^ 32 <-> m ^ 2, j ^ 16 <-> m ^ 1), strides 8..1 are DPP steps inside the group's row of 16 lanes — the
 //   same additions in the same order as one lane per unit (fp32 addition commutes bitwise), at a quarter of the
 //   instructions per edge.  Lane 0 of a group writes the edge's row.
+static_assert(sizeof(sg_edge_out) == 64 && offsetof(sg_edge_out, sum_ns) == 0 && offsetof(sg_edge_out, max_ns) == 8 && offsetof(sg_edge_out, sumsq_us) == 16 &&
+              offsetof(sg_edge_out, from_ref) == 24 && offsetof(sg_edge_out, to_ref) == 28 && offsetof(sg_edge_out, count) == 32 && offsetof(sg_edge_out, err_count) == 36 &&
+              offsetof(sg_edge_out, score) == 40 && offsetof(sg_edge_out, lat_z) == 44 && offsetof(sg_edge_out, err_ratio) == 48 && offsetof(sg_edge_out, alive) == 52 &&
+              offsetof(sg_edge_out, p50_us) == 56 && offsetof(sg_edge_out, p99_us) == 60, "k5_edge_score writes a row as eight 8-byte words");
 template <bool RESET>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
     const u32 E = (u32)d.ctr[C_N_EDGES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
@@ -1911,8 +1997,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     // Two steps of four edges per iteration, and the endpoints of the NEXT iteration's edges are fetched while this one's
     // rows are gathered: the dependent chain per iteration is one round trip (the gathers), not two (ids, then gathers),
     // with four 16-byte gathers per lane in flight instead of two.
-    auto step = [&](u32 pp, bool live, u32 u, u32 v, const float4 P4, const float4 Q4, const float4 e0, const float4 e1,
-                    const ulonglong2 wx, const ulonglong2 wy, float w_latz, float w_errr, u32 w_alive) {
+    auto step = [&](const float4 P4, const float4 Q4, const float4 e0, const float4 e1) -> float {
         const float ek[SG_F_EDGE] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
         const float pq[4] = {P4.x + Q4.x, P4.y + Q4.y, P4.z + Q4.z, P4.w + Q4.w};
         float r[4];
@@ -1927,56 +2012,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         float sum = (r[0] + r[2]) + (r[1] + r[3]);                  // strides 32, then 16
         sum = sum + xor_partner_f32(sum, 8); sum = sum + xor_partner_f32(sum, 4);
         sum = sum + xor_partner_f32(sum, 2); sum = sum + xor_partner_f32(sum, 1);
-        if (q == 0 && live) {
-            const float logit = sum + b2;
-            const float score = 1.0f / (1.0f + expf(-logit));
-            sg_edge_out o;
-            o.sum_ns = wx.y; o.max_ns = wy.x; o.sumsq_us = wy.y;
-            o.from_ref = ref_of_dense(u, nk, nl); o.to_ref = ref_of_dense(v, nk, nl);
-            o.count = (u32)(wx.x & 0xFFFFFFFFull); o.err_count = (u32)(wx.x >> 32);
-            o.score = score; o.lat_z = w_latz; o.err_ratio = w_errr; o.alive = w_alive;
-            o.p50_us = 0; o.p99_us = 0;
-            if (d.hist && o.count) {                                 // percentiles off the log2 histogram (include/servicegraph.h)
-                const uint4* hp = reinterpret_cast<const uint4*>(d.hist_csr + (size_t)pp * SG_HIST_BINS);
-                const uint4 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
-                const u32 hb[SG_HIST_BINS] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
-                u64 r50 = ((u64)o.count * 50 + 99) / 100, r99 = ((u64)o.count * 99 + 99) / 100;
-                r50 = r50 ? r50 : 1; r99 = r99 ? r99 : 1;
-                u64 cum = 0; u32 b50 = SG_HIST_BINS - 1, b99 = SG_HIST_BINS - 1; bool f50 = false, f99 = false;
-#pragma unroll
-                for (u32 b = 0; b < SG_HIST_BINS; b++) { cum += hb[b]; if (!f50 && cum >= r50) { b50 = b; f50 = true; } if (!f99 && cum >= r99) { b99 = b; f99 = true; } }
-                u64 e50 = b50 == SG_HIST_BINS - 1 ? o.max_ns : (1ull << (17 + b50)), e99 = b99 == SG_HIST_BINS - 1 ? o.max_ns : (1ull << (17 + b99));
-                e50 = e50 > o.max_ns ? o.max_ns : e50; e99 = e99 > o.max_ns ? o.max_ns : e99;
-                e50 /= 1000ull; e99 /= 1000ull;
-                o.p50_us = e50 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e50; o.p99_us = e99 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e99;
-            }
-            d.rows[pp] = o;
-        }
+        return sum;                                                  // (every lane of the 16 holds it)
     };
+    // The ROWS of an iteration's eight edges are written by the whole wave: 8 x 64 bytes = 64 lanes x 8 bytes, lane l holds
+    // 8-byte word l % 8 of edge l / 8 — one fully coalesced store per iteration instead of four 16-byte stores from one lane in
+    // sixteen per step (whose ~100 instructions of row assembly ran with 4 of 64 lanes active).
+    //   word 0..2 sum_ns, max_ns, sumsq_us = accumulators 1..3; word 3 from_ref | to_ref; word 4 count | err = accumulator 0;
+    //   word 5 score | lat_z; word 6 err_ratio | alive; word 7 p50_us | p99_us
+    const u32 wk = lane & 7u, we8 = lane >> 3;
+    const u32* __restrict__ srcA = wk == 3 ? d.csr_from : reinterpret_cast<const u32*>(d.errr);
+    const u32* __restrict__ srcB = wk == 3 ? d.col : (wk == 5 ? reinterpret_cast<const u32*>(d.latz) : d.alive_csr);
+    const u32 accj = wk < 3 ? wk + 1 : 0u;
+    const int srcl = (int)((we8 & 3u) << 4);                         // lane that holds the score sum of this lane's edge (in its step)
     if (E) {
         const u32 stride = nw * 8, last = E - 1;
         u32 pa = wave * 8 + g, pb = pa + 4;                          // this iteration's two edges of the lane group (clamped when beyond E)
         u32 ua = d.csr_from[pa < E ? pa : last], va = d.col[pa < E ? pa : last], ub = d.csr_from[pb < E ? pb : last], vb = d.col[pb < E ? pb : last];
         for (u32 p0 = wave * 8; p0 < E; p0 += stride) {
-            const bool la = pa < E, lb = pb < E;
-            const u32 ca = la ? pa : last, cb = lb ? pb : last;
+            const u32 ca = pa < E ? pa : last, cb = pb < E ? pb : last;
             const float4 PA = reinterpret_cast<const float4*>(d.P + (size_t)ua * SG_F_HID)[q], QA = reinterpret_cast<const float4*>(d.Q + (size_t)va * SG_F_HID)[q];
             const float4 PB = reinterpret_cast<const float4*>(d.P + (size_t)ub * SG_F_HID)[q], QB = reinterpret_cast<const float4*>(d.Q + (size_t)vb * SG_F_HID)[q];
             const float4 ea0 = reinterpret_cast<const float4*>(d.efeat + (size_t)ca * SG_F_EDGE)[0], ea1 = reinterpret_cast<const float4*>(d.efeat + (size_t)ca * SG_F_EDGE)[1];
             const float4 eb0 = reinterpret_cast<const float4*>(d.efeat + (size_t)cb * SG_F_EDGE)[0], eb1 = reinterpret_cast<const float4*>(d.efeat + (size_t)cb * SG_F_EDGE)[1];
-            // what the row writer needs is fetched now, beside the gathers, not after the sums
-            ulonglong2 wxa = make_ulonglong2(0, 0), wya = wxa, wxb = wxa, wyb = wxa; float lza = 0.0f, era = 0.0f, lzb = 0.0f, erb = 0.0f; u32 ala = 0, alb = 0;
-            if (q == 0) {
-                const ulonglong2* __restrict__ aa = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)ca * 4);
-                const ulonglong2* __restrict__ ab = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)cb * 4);
-                wxa = aa[0]; wya = aa[1]; lza = d.latz[ca]; era = d.errr[ca]; ala = d.alive_csr[ca];
-                wxb = ab[0]; wyb = ab[1]; lzb = d.latz[cb]; erb = d.errr[cb]; alb = d.alive_csr[cb];
-            }
+            // what this lane's row word is made of: fetched now, beside the gathers
+            const u32 er = p0 + we8, ec = er < E ? er : last;
+            const u64 wacc = d.acc_csr[(size_t)ec * 4 + accj];
+            const u32 wa = srcA[ec], wb = srcB[ec];
             // next iteration's endpoints: behind the gathers in issue order, so waiting for the gathers does not wait for them
             const u32 na = pa + stride, nb = pb + stride;
             const u32 ua_n = d.csr_from[na < E ? na : last], va_n = d.col[na < E ? na : last], ub_n = d.csr_from[nb < E ? nb : last], vb_n = d.col[nb < E ? nb : last];
-            step(ca, la, ua, va, PA, QA, ea0, ea1, wxa, wya, lza, era, ala);
-            step(cb, lb, ub, vb, PB, QB, eb0, eb1, wxb, wyb, lzb, erb, alb);
+            const float sa = step(PA, QA, ea0, ea1);
+            const float sb = step(PB, QB, eb0, eb1);
+            const float mysum = we8 < 4 ? __shfl(sa, srcl, 64) : __shfl(sb, srcl, 64);
+            u64 val = wacc;                                          // words 0..2 and 4
+            if (wk == 3) val = (u64)ref_of_dense(wa, nk, nl) | ((u64)ref_of_dense(wb, nk, nl) << 32);
+            else if (wk == 5) { const float logit = mysum + b2; val = (u64)__float_as_uint(1.0f / (1.0f + expf(-logit))) | ((u64)wb << 32); }
+            else if (wk == 6) val = (u64)wa | ((u64)wb << 32);
+            else if (wk == 7) {
+                val = 0;
+                if (d.hist) {                                        // percentiles off the log2 histogram (include/servicegraph.h)
+                    const ulonglong2* __restrict__ ac = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)ec * 4);
+                    const u32 count = (u32)(ac[0].x & 0xFFFFFFFFull); const u64 max_ns = ac[1].x;
+                    if (count) {
+                        const uint4* hp = reinterpret_cast<const uint4*>(d.hist_csr + (size_t)ec * SG_HIST_BINS);
+                        const uint4 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
+                        const u32 hb[SG_HIST_BINS] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+                        u64 r50 = ((u64)count * 50 + 99) / 100, r99 = ((u64)count * 99 + 99) / 100;
+                        r50 = r50 ? r50 : 1; r99 = r99 ? r99 : 1;
+                        u64 cum = 0; u32 b50 = SG_HIST_BINS - 1, b99 = SG_HIST_BINS - 1; bool f50 = false, f99 = false;
+#pragma unroll
+                        for (u32 b = 0; b < SG_HIST_BINS; b++) { cum += hb[b]; if (!f50 && cum >= r50) { b50 = b; f50 = true; } if (!f99 && cum >= r99) { b99 = b; f99 = true; } }
+                        u64 e50 = b50 == SG_HIST_BINS - 1 ? max_ns : (1ull << (17 + b50)), e99 = b99 == SG_HIST_BINS - 1 ? max_ns : (1ull << (17 + b99));
+                        e50 = e50 > max_ns ? max_ns : e50; e99 = e99 > max_ns ? max_ns : e99;
+                        e50 /= 1000ull; e99 /= 1000ull;
+                        val = (u64)(e50 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e50) | ((u64)(e99 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e99) << 32);
+                    }
+                }
+            }
+            if (er < E) reinterpret_cast<u64*>(d.rows)[(size_t)er * 8 + wk] = val;
             pa = na; pb = nb; ua = ua_n; va = va_n; ub = ub_n; vb = vb_n;
         }
     }

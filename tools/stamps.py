@@ -40,8 +40,9 @@ for kid, kname in zip((0, 1), g.k1_kernels()):
         if nm == "-": continue
         col = (a[:, k] - t0) / 100.0
         print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
-    if kid == 0 and a.shape[1] > 7 and a[:, 2].max() > 0:          # narrow pass A: wave 0's accumulated time in P1 / at the barrier behind it
-        for k, nm in ((2, "sum of P1 (wave 0)"), (7, "sum of barrier-1 waits")):
-            col = a[:, k] / 100.0
-            print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}   (durations)")
+if st[2][:, 0].max() > 0:                                            # narrow pass A: wave 0's accumulated clock ticks per phase (kernel slot 2)
+    a = st[2].astype(np.int64); a = a[a[:, 0] != 0]
+    for k, nm in enumerate(("P1 fold", "barrier-1 wait", "P2 scan", "P3 drop", "barrier-3 wait", "P4 copy-out")):
+        col = a[:, k] / 100.0
+        print(f"  sum {nm:<16} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
 g.close()
