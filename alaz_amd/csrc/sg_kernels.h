@@ -2023,7 +2023,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const u32* __restrict__ srcA = wk == 3 ? d.csr_from : reinterpret_cast<const u32*>(d.errr);
     const u32* __restrict__ srcB = wk == 3 ? d.col : (wk == 5 ? reinterpret_cast<const u32*>(d.latz) : d.alive_csr);
     const u32 accj = wk < 3 ? wk + 1 : 0u;
-    const int srcl = (int)((we8 & 3u) << 4);                         // lane that holds the score sum of this lane's edge (in its step)
+    const int srcl = (int)(((we8 & 3u) << 4) | (we8 < 4 ? 0u : 8u));     // lane that holds the score sum of this lane's edge: group (edge & 3), its
+                                                                         // lower half for the first step's four edges, its upper half for the second's
     if (E) {
         const u32 stride = nw * 8, last = E - 1;
         u32 pa = wave * 8 + g, pb = pa + 4;                          // this iteration's two edges of the lane group (clamped when beyond E)
@@ -2043,7 +2044,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             const u32 ua_n = d.csr_from[na < E ? na : last], va_n = d.col[na < E ? na : last], ub_n = d.csr_from[nb < E ? nb : last], vb_n = d.col[nb < E ? nb : last];
             const float sa = step(PA, QA, ea0, ea1);
             const float sb = step(PB, QB, eb0, eb1);
-            const float mysum = we8 < 4 ? __shfl(sa, srcl, 64) : __shfl(sb, srcl, 64);
+            const float mysum = __shfl(q < 8 ? sa : sb, srcl, 64);     // ONE shuffle executed by all lanes (two under a select were sunk into exec-masked
+                                                                       // branches by the compiler: ds_bpermute returns 0 for an inactive source lane)
             u64 val = wacc;                                          // words 0..2 and 4
             if (wk == 3) val = (u64)ref_of_dense(wa, nk, nl) | ((u64)ref_of_dense(wb, nk, nl) << 32);
             else if (wk == 5) { const float logit = mysum + b2; val = (u64)__float_as_uint(1.0f / (1.0f + expf(-logit))) | ((u64)wb << 32); }
