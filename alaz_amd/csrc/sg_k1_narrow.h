@@ -303,34 +303,47 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         {   // P2: exclusive scan of the run lengths by EVERY wave (sixteen identical scans cost less than a barrier behind one: the
             // offsets a wave needs in P3 are its own writes, every wave writes the same values).  Lane l owns the np / 64 consecutive
             // partitions from l * np / 64; the wave-wide part is DPP + readlane, no LDS round trip.
+            // (16-byte LDS accesses: a lane's partitions are consecutive words — read one by one, 64 lanes 32 bytes apart hit four banks)
             const u32 pl = NP >> 6, b0 = lane * pl;
-            u32 c8[8], s = 0;                                        // (np <= 512: at most 8 per lane in registers; larger np loops)
-            if (pl <= 8) {
+            const bool own = (b0 / (NP >> 4)) == wave;               // the wave that owns a partition (wave = partition / (np / 16)) also moves its piece
+            u32* fnext = fcn2 + (cur ^ 1u) * NP;                     // counter on and re-arms the run counters tile k + 1's ranks come from (tile k - 1's
+            u32* bprev = bcnt + (cur ^ 1u) * NP;                     // set: read for the last time in its scan, every wave is past that)
+            if ((pl & 3u) == 0 && pl <= 16) {
+                const u32 nq = pl >> 2;                              // 1, 2 or 4 quads per lane (np = 256, 512, 1024)
+                uint4 cq[4];
+                u32 s = 0;
 #pragma unroll
-                for (u32 k = 0; k < 8; k++) { c8[k] = k < pl ? bc[b0 + k] : 0u; s += c8[k]; }
-            } else for (u32 k = 0; k < pl; k++) s += bc[b0 + k];
-            u32 incl = s;                                            // inclusive scan over the 64 lanes
-            incl += dpp32<0x111>(incl); incl += dpp32<0x112>(incl); incl += dpp32<0x114>(incl); incl += dpp32<0x118>(incl);   // row_shr 1, 2, 4, 8 (zero fill)
-            const u32 r0 = rdlane32(incl, 15), r1 = rdlane32(incl, 31), r2 = rdlane32(incl, 47);
-            incl += (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
-            u32 run = incl - s;
-            // the wave that owns a partition (wave = partition / (np / 16)) also moves its piece counter on and re-arms the run counter the
-            // NEXT tile's ranks come from (this tile's is re-armed behind the next barrier-1, when every wave is past this scan)
-            const bool own = (b0 / (NP >> 4)) == wave;
-            u32* fnext = fcn2 + (cur ^ 1u) * NP;
-            if (pl <= 8) {
+                for (u32 k = 0; k < 4; k++) { cq[k] = k < nq ? reinterpret_cast<const uint4*>(bc + b0)[k] : make_uint4(0u, 0u, 0u, 0u); s += cq[k].x + cq[k].y + cq[k].z + cq[k].w; }
+                u32 incl = s;                                        // inclusive scan over the 64 lanes: DPP row_shr 1, 2, 4, 8 (zero fill), then the row totals
+                incl += dpp32<0x111>(incl); incl += dpp32<0x112>(incl); incl += dpp32<0x114>(incl); incl += dpp32<0x118>(incl);
+                const u32 r0 = rdlane32(incl, 15), r1 = rdlane32(incl, 31), r2 = rdlane32(incl, 47);
+                incl += (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
+                u32 run = incl - s;
 #pragma unroll
-                for (u32 k = 0; k < 8; k++) if (k < pl) {
-                    boff[b0 + k] = run; run += c8[k];
-                    if (own) { const u32 nx = fcn[b0 + k] + c8[k]; fnext[b0 + k] = nx < d.sn ? nx : d.sn; }
+                for (u32 k = 0; k < 4; k++) if (k < nq) {
+                    uint4 o; o.x = run; run += cq[k].x; o.y = run; run += cq[k].y; o.z = run; run += cq[k].z; o.w = run; run += cq[k].w;
+                    reinterpret_cast<uint4*>(boff + b0)[k] = o;
+                    if (own) {
+                        const uint4 f = reinterpret_cast<const uint4*>(fcn + b0)[k];
+                        uint4 nx; nx.x = f.x + cq[k].x; nx.y = f.y + cq[k].y; nx.z = f.z + cq[k].z; nx.w = f.w + cq[k].w;
+                        nx.x = nx.x < d.sn ? nx.x : d.sn; nx.y = nx.y < d.sn ? nx.y : d.sn; nx.z = nx.z < d.sn ? nx.z : d.sn; nx.w = nx.w < d.sn ? nx.w : d.sn;
+                        reinterpret_cast<uint4*>(fnext + b0)[k] = nx;
+                        reinterpret_cast<uint4*>(bprev + b0)[k] = make_uint4(0u, 0u, 0u, 0u);
+                    }
                 }
-            } else for (u32 k = 0; k < pl; k++) {
-                const u32 c = bc[b0 + k]; boff[b0 + k] = run; run += c;
-                if (own) { const u32 nx = fcn[b0 + k] + c; fnext[b0 + k] = nx < d.sn ? nx : d.sn; }
+            } else {
+                u32 s = 0;
+                for (u32 k = 0; k < pl; k++) s += bc[b0 + k];
+                u32 incl = s;
+                incl += dpp32<0x111>(incl); incl += dpp32<0x112>(incl); incl += dpp32<0x114>(incl); incl += dpp32<0x118>(incl);
+                const u32 r0 = rdlane32(incl, 15), r1 = rdlane32(incl, 31), r2 = rdlane32(incl, 47);
+                incl += (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
+                u32 run = incl - s;
+                for (u32 k = 0; k < pl; k++) {
+                    const u32 c = bc[b0 + k]; boff[b0 + k] = run; run += c;
+                    if (own) { const u32 nx = fcn[b0 + k] + c; fnext[b0 + k] = nx < d.sn ? nx : d.sn; bprev[b0 + k] = 0u; }
+                }
             }
-            // re-arm the OTHER run-counter set (tile k - 1's, read for the last time in its scan): ranks of tile k + 1 start at zero
-            u32* bprev = bcnt + (cur ^ 1u) * NP;
-            if (own) for (u32 k = 0; k < pl; k++) bprev[b0 + k] = 0u;
         }
         const u64 tk3 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         // P3: every thread drops its records at offset + rank (PACKB: with the partition number in the free bits of the high word)
