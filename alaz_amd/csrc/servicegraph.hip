@@ -333,9 +333,9 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         const bool share = d.npb > e->k1b_cus && 2 * e->k1b_lds <= kLdsBytes;   // several partitions per CU and room for two tables: the SGPR-capped build lets two workgroups share a CU
 #define K1B_GO(U_, H_) do { if (share) hipExtLaunchKernelGGL((k1b_merge<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
                             else hipExtLaunchKernelGGL((k1b_merge_wide<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
-#define K1B8_GO(U_, SPT_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_>), dim3(d.npb), dim3(1024), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
-                               else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_>), dim3(d.npb), dim3(1024), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
-#define K1B8_GO2(U_) do { if (d.k1b_ht == 4096) K1B8_GO(U_, 4); else if (d.k1b_ht == 2048) K1B8_GO(U_, 2); else K1B8_GO(U_, 1); } while (0)
+#define K1B8_GO(U_, SPT_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
+                               else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
+#define K1B8_GO2(U_) do { const u32 spt = d.k1b_ht / e->k1b_threads; if (spt >= 4) K1B8_GO(U_, 4); else if (spt == 2) K1B8_GO(U_, 2); else K1B8_GO(U_, 1); } while (0)
         if (d.narrow) { if (e->k1b_u == 8) K1B8_GO2(8); else K1B8_GO2(4); }
         else if (d.hist) K1B_GO(4, true); else if (e->k1b_u == 8) K1B_GO(8, false); else K1B_GO(4, false);
 #undef K1B8_GO2
@@ -601,7 +601,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // narrow pass B: 8 x 16 bytes per lane in flight where a CU holds one table anyway; two workgroups per CU need <= 64 VGPRs
         if (d.narrow) e->k1b_u = ((size_t)d.k1b_ht * 36 + 8) * 2 > kLdsBytes && m > 24.0 ? 8 : 4;
         if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; if (std::atoi(v) == 4) e->k1b_u = 4; }
-        if (const char* v = std::getenv("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if (x == 256 || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
+        if (const char* v = std::getenv("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if ((x == 256 && !d.narrow) || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
+        if (d.narrow && d.k1b_ht / e->k1b_threads > 4) e->k1b_threads = 1024u;    // (the compaction takes at most four table slots per thread)
     }
     // join tables: word image (join_host.hpp) on the host, one device copy, a pinned ring for word updates
     {

@@ -1,0 +1,626 @@
+// Package servicegraph puts the MI355X ServiceGraph engine (include/servicegraph.h, libservicegraph.so) behind Alaz's own
+// plugin interface, datastore.DataStore (datastore/datastore.go:3-20).  GraphDS DECORATES the data store the agent already
+// has: every call is forwarded to it unchanged, and the edge-relevant fields are also fed to the GPU engine, which emits one
+// scored row per EDGE per window.  It is injected where the reference injects its BackendDS — the last argument of
+// aggregator.NewAggregator (aggregator/data.go:135-140, main.go:103):
+//
+//	dsBackend := datastore.NewBackendDS(ctx, config.BackendDSConfig{...})          // main.go:82-93, unchanged
+//	gds, err := servicegraph.New(dsBackend, servicegraph.Config{MaxKnownNodes: 1 << 16, MaxEdges: 1 << 21, Layers: 2})
+//	var ds datastore.DataStore = dsBackend
+//	if err == nil { ds = gds; go gds.Run(ctx, time.Second, onEdges) }            // no GPU: the CPU path stays as it is
+//	a := aggregator.NewAggregator(ctx, ct, kubeEvents, ec.EbpfEvents(), ec.EbpfProcEvents(), ec.EbpfTcpEvents(), ec.TlsAttachQueue(), ds)
+//
+// The C++ mirror of this file, alaz_amd/csrc/host/graph_ds.{hpp,cpp}, is what the repository's tests drive (no Go toolchain
+// exists in its build environment: this file is written against the reference's sources, not compiled there).  Behaviour
+// that must match it: one node id per live UID, reference-counted by the IPs bound to it and recycled only after the next
+// FlushWindow; DELETE never creates an id; ReverseDirection() is undone before the event is handed over (K1 re-applies it
+// after its own join); the engine is never allowed to block the aggregator (sg_ingest drops and counts on a full ring).
+package servicegraph
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../alaz_amd/lib -lservicegraph
+#include <stdlib.h>
+#include <string.h>
+#include "servicegraph.h"
+*/
+import "C"
+
+import (
+	"context"
+	"fmt"
+	"net"
+	"strings"
+	"sync"
+	"sync/atomic"
+	"time"
+	"unsafe"
+
+	"github.com/ddosify/alaz/datastore"
+	"github.com/ddosify/alaz/ebpf/l7_req"
+)
+
+// Config is the subset of sg_config a deployment chooses; everything else keeps the engine's default.
+type Config struct {
+	Device          int
+	MaxKnownNodes   uint32 // live pods + services
+	MaxLabels       uint32 // distinct Host-header names of outbound destinations
+	MaxOutboundIPs  uint32 // distinct raw-IP outbound destinations per window
+	MaxEdges        uint64 // distinct edges per window
+	MaxWindowEvents uint64 // most events one window may carry (sizes the K1 record slabs)
+	Layers          uint32 // GraphSAGE layers, 1..4
+	EdgeHistogram   bool   // p50 / p99 per edge (SG_CFG_EDGE_HISTOGRAM)
+	Divert          bool   // true: PersistRequest / PersistKafkaEvent are NOT forwarded to the inner store (edge rows replace them)
+	Weights         []float32
+}
+
+// EdgeRow is one scored edge of a closed window (sg_edge_out with the refs resolved to the reference's (Type, UID) pairs).
+type EdgeRow struct {
+	FromType, FromUID, ToType, ToUID string
+	Count, ErrCount                  uint32
+	SumNs, MaxNs, SumSqUs            uint64
+	Score, LatZ, ErrRatio            float32
+	Alive, P50Us, P99Us              uint32
+}
+
+const (
+	kindPod     = uint8(C.SG_NODE_POD)
+	kindService = uint8(C.SG_NODE_SERVICE)
+	noID        = ^uint32(0)
+	nShards     = 8
+	batchCap    = 4096 // events per cgo call: a call costs 50-100 ns, sg_ingest copies the batch
+)
+
+type shard struct {
+	mu    sync.Mutex
+	batch []C.sg_event
+}
+
+// GraphDS implements datastore.DataStore.
+type GraphDS struct {
+	inner  datastore.DataStore
+	h      C.sg_handle
+	divert bool
+
+	idMu    sync.Mutex
+	ids     map[string]uint32 // UID -> node id
+	uidOf   []string
+	kindOf  []uint8
+	refs    []uint32          // IPs bound to the id
+	freeIDs []uint32
+	retired []uint32          // ids whose last IP went away since the last FlushWindow
+	podIP   map[uint32]uint32 // ip -> id: what sg_upsert_pod / sg_delete_pod were told
+	svcIP   map[uint32]uint32
+	maxKnown uint32
+
+	lblMu  sync.RWMutex
+	labels map[string]uint32 // Host header -> label id (>= 1), cumulative
+	names  []string
+
+	shards  [nShards]shard
+	next    atomic.Uint32
+	flushMu sync.Mutex
+
+	EngineErrors   atomic.Uint64 // SG_ENOSPC and friends from the engine (the inner store still got the call)
+	BatchesDropped atomic.Uint64 // SG_EAGAIN: staging ring full, batch dropped and counted by the engine
+	// Filter, when set, is asked before an event of the early tap (IngestL7) is packed: the aggregator's own
+	// parsePostgresCommand / parseMySQLCommand / parseMongoEvent results (aggregator/data.go:1251-1362) — false drops the event.
+	Filter func(*l7_req.L7Event) bool
+}
+
+var _ datastore.DataStore = (*GraphDS)(nil)
+
+func ip4(s string) (uint32, bool) {
+	p := net.ParseIP(s).To4()
+	if p == nil {
+		return 0, false
+	}
+	return uint32(p[0])<<24 | uint32(p[1])<<16 | uint32(p[2])<<8 | uint32(p[3]), true
+}
+
+func ipString(ip uint32) string { // aggregator/data.go:1751-1758 IntToIPv4
+	return fmt.Sprintf("%d.%d.%d.%d", ip>>24, (ip>>16)&255, (ip>>8)&255, ip&255)
+}
+
+// New creates the engine.  It fails when no usable MI355X is present: there is no CPU fallback, the caller keeps `inner`.
+func New(inner datastore.DataStore, c Config) (*GraphDS, error) {
+	if uint32(C.sg_abi_version()) != uint32(C.SG_ABI_VERSION) {
+		return nil, fmt.Errorf("servicegraph: library ABI %d, header ABI %d", uint32(C.sg_abi_version()), uint32(C.SG_ABI_VERSION))
+	}
+	var cfg C.sg_config
+	C.memset(unsafe.Pointer(&cfg), 0, C.size_t(unsafe.Sizeof(cfg)))
+	cfg.struct_size = C.uint32_t(unsafe.Sizeof(cfg))
+	cfg.abi_version = C.SG_ABI_VERSION
+	cfg.device = C.int32_t(c.Device)
+	cfg.max_known_nodes = C.uint32_t(c.MaxKnownNodes)
+	cfg.max_labels = C.uint32_t(c.MaxLabels)
+	cfg.max_outbound_ips = C.uint32_t(c.MaxOutboundIPs)
+	cfg.max_ips = C.uint32_t(c.MaxKnownNodes)
+	cfg.max_edges = C.uint64_t(c.MaxEdges)
+	cfg.max_batch = C.uint32_t(batchCap)
+	cfg.max_window_events = C.uint64_t(c.MaxWindowEvents)
+	cfg.layers = C.uint32_t(c.Layers)
+	cfg.world = 1
+	cfg.windows_in_flight = 1
+	if c.EdgeHistogram {
+		cfg.flags |= C.SG_CFG_EDGE_HISTOGRAM
+	}
+	g := &GraphDS{inner: inner, divert: c.Divert, ids: map[string]uint32{}, podIP: map[uint32]uint32{}, svcIP: map[uint32]uint32{},
+		labels: map[string]uint32{}, maxKnown: c.MaxKnownNodes}
+	if rc := C.sg_create(&cfg, &g.h); rc != 0 {
+		return nil, fmt.Errorf("servicegraph: sg_create = %d (no usable gfx950 device, or bad config)", int(rc))
+	}
+	if n := int(C.sg_weights_count(C.uint32_t(c.Layers))); len(c.Weights) == n {
+		C.sg_load_weights(g.h, (*C.float)(unsafe.Pointer(&c.Weights[0])), C.size_t(n))
+	} else if len(c.Weights) != 0 {
+		C.sg_destroy(g.h)
+		return nil, fmt.Errorf("servicegraph: %d weights given, the %d-layer model has %d", len(c.Weights), c.Layers, n)
+	}
+	return g, nil
+}
+
+// Close flushes nothing and frees the engine; no call may be in flight.
+func (g *GraphDS) Close() { C.sg_destroy(g.h) }
+
+// SetClock hands over FirstKernelTime / FirstUserspaceTime (ebpf/l7_req/l7.go:707-710) for the early tap's StartTime.
+func (g *GraphDS) SetClock(firstKernelNs, firstUserNs uint64) {
+	C.sg_set_clock(g.h, C.uint64_t(firstKernelNs), C.uint64_t(firstUserNs))
+}
+
+// ---- node ids (idMu held) --------------------------------------------------------------------------------------------
+
+func (g *GraphDS) intern(uid string, kind uint8) uint32 {
+	if id, ok := g.ids[uid]; ok {
+		g.kindOf[id] = kind
+		return id
+	}
+	var id uint32
+	if n := len(g.freeIDs); n > 0 {
+		id = g.freeIDs[n-1]
+		g.freeIDs = g.freeIDs[:n-1]
+		g.uidOf[id], g.kindOf[id], g.refs[id] = uid, kind, 0
+	} else {
+		if uint32(len(g.uidOf)) >= g.maxKnown {
+			return noID // the engine's id space is full (sg_config.max_known_nodes bounds the LIVE pods + services)
+		}
+		id = uint32(len(g.uidOf))
+		g.uidOf, g.kindOf, g.refs = append(g.uidOf, uid), append(g.kindOf, kind), append(g.refs, 0)
+	}
+	g.ids[uid] = id
+	return id
+}
+
+func (g *GraphDS) bind(m map[uint32]uint32, ip, id uint32) {
+	old, had := m[ip]
+	if had && old == id {
+		return
+	}
+	g.refs[id]++ // before the unbind: re-binding an id's only IP must not retire it
+	m[ip] = id
+	if had {
+		if g.refs[old]--; g.refs[old] == 0 {
+			g.retired = append(g.retired, old)
+		}
+	}
+}
+
+func (g *GraphDS) unbind(m map[uint32]uint32, ip uint32) {
+	id, ok := m[ip]
+	if !ok {
+		return
+	}
+	delete(m, ip)
+	if g.refs[id]--; g.refs[id] == 0 {
+		g.retired = append(g.retired, id) // the open window may still name it: recycled after the next FlushWindow
+	}
+}
+
+// ---- k8s resources: PodIPToPodUid / ServiceIPToServiceUid (aggregator/persist.go:55-71, 114-130) ------------------------
+
+func (g *GraphDS) upsertOrDelete(svc bool, uid, ipStr, eventType string) {
+	ip, ok := ip4(ipStr)
+	if !ok {
+		return // pods without an IP never reach the data store (persist.go:37-40); not IPv4: nothing the join could do
+	}
+	g.idMu.Lock()
+	defer g.idMu.Unlock()
+	m, kind := g.podIP, kindPod
+	if svc {
+		m, kind = g.svcIP, kindService
+	}
+	switch eventType {
+	case "ADD", "UPDATE":
+		id := g.intern(uid, kind)
+		if id == noID {
+			g.EngineErrors.Add(1)
+			return
+		}
+		var rc C.int
+		if svc {
+			rc = C.sg_upsert_service(g.h, C.uint32_t(ip), C.uint32_t(id))
+		} else {
+			rc = C.sg_upsert_pod(g.h, C.uint32_t(ip), C.uint32_t(id))
+		}
+		if rc != 0 {
+			g.EngineErrors.Add(1)
+			return
+		}
+		g.bind(m, ip, id)
+	case "DELETE": // never creates an id
+		if svc {
+			C.sg_delete_service(g.h, C.uint32_t(ip))
+		} else {
+			C.sg_delete_pod(g.h, C.uint32_t(ip))
+		}
+		g.unbind(m, ip)
+	}
+}
+
+func (g *GraphDS) PersistPod(pod datastore.Pod, eventType string) error {
+	g.upsertOrDelete(false, pod.UID, pod.IP, eventType)
+	return g.inner.PersistPod(pod, eventType)
+}
+
+// The aggregator keys its table on Spec.ClusterIP (persist.go:117), which the DTO carries as ClusterIPs[0]
+// (ClusterIP itself is never filled in, persist.go:105-112).
+func (g *GraphDS) PersistService(service datastore.Service, eventType string) error {
+	ip := service.ClusterIP
+	if len(service.ClusterIPs) > 0 {
+		ip = service.ClusterIPs[0]
+	}
+	g.upsertOrDelete(true, service.UID, ip, eventType)
+	return g.inner.PersistService(service, eventType)
+}
+
+func (g *GraphDS) PersistReplicaSet(rs datastore.ReplicaSet, eventType string) error { return g.inner.PersistReplicaSet(rs, eventType) }
+func (g *GraphDS) PersistDeployment(d datastore.Deployment, eventType string) error  { return g.inner.PersistDeployment(d, eventType) }
+func (g *GraphDS) PersistEndpoints(e datastore.Endpoints, eventType string) error    { return g.inner.PersistEndpoints(e, eventType) }
+func (g *GraphDS) PersistContainer(c datastore.Container, eventType string) error    { return g.inner.PersistContainer(c, eventType) }
+func (g *GraphDS) PersistDaemonSet(ds datastore.DaemonSet, eventType string) error   { return g.inner.PersistDaemonSet(ds, eventType) }
+func (g *GraphDS) PersistStatefulSet(ss datastore.StatefulSet, eventType string) error {
+	return g.inner.PersistStatefulSet(ss, eventType)
+}
+
+// ---- events ----------------------------------------------------------------------------------------------------------
+
+func (g *GraphDS) label(name string) uint32 {
+	g.lblMu.RLock()
+	id, ok := g.labels[name]
+	g.lblMu.RUnlock()
+	if ok {
+		return id
+	}
+	g.lblMu.Lock()
+	defer g.lblMu.Unlock()
+	if id, ok = g.labels[name]; ok {
+		return id
+	}
+	g.names = append(g.names, name)
+	id = uint32(len(g.names)) // ids start at 1: 0 = no Host header
+	g.labels[name] = id
+	return id
+}
+
+func (g *GraphDS) knownIP(ip uint32) bool {
+	g.idMu.Lock()
+	_, p := g.podIP[ip]
+	_, s := g.svcIP[ip]
+	g.idMu.Unlock()
+	return p || s
+}
+
+func protoID(p string) (C.uint8_t, bool) { // (id, tls implied by the "HTTPS" rewrite of aggregator/data.go:1240-1242)
+	switch p {
+	case l7_req.L7_PROTOCOL_HTTP:
+		return C.SG_PROTO_HTTP, false
+	case "HTTPS":
+		return C.SG_PROTO_HTTP, true
+	case l7_req.L7_PROTOCOL_AMQP:
+		return C.SG_PROTO_AMQP, false
+	case l7_req.L7_PROTOCOL_POSTGRES:
+		return C.SG_PROTO_POSTGRES, false
+	case l7_req.L7_PROTOCOL_HTTP2:
+		return C.SG_PROTO_HTTP2, false
+	case l7_req.L7_PROTOCOL_REDIS:
+		return C.SG_PROTO_REDIS, false
+	case l7_req.L7_PROTOCOL_KAFKA:
+		return C.SG_PROTO_KAFKA, false
+	case l7_req.L7_PROTOCOL_MYSQL:
+		return C.SG_PROTO_MYSQL, false
+	case l7_req.L7_PROTOCOL_MONGO:
+		return C.SG_PROTO_MONGO, false
+	}
+	return C.SG_PROTO_UNKNOWN, false
+}
+
+func clamp16(v uint32) C.uint16_t {
+	if v > 0xFFFF {
+		v = 0xFFFF
+	}
+	return C.uint16_t(v)
+}
+
+// hostHeader is parseHttpPayload's Host rule (aggregator/data.go:508-531): the second space-separated field of the first
+// line after the request line that starts with "Host:", '\r' trimmed.
+func hostHeader(payload string) string {
+	lines := strings.Split(payload, "\n")
+	for _, line := range lines[1:] {
+		if strings.HasPrefix(line, "Host:") {
+			if parts := strings.Split(line, " "); len(parts) >= 2 {
+				return strings.TrimSuffix(parts[1], "\r")
+			}
+		}
+	}
+	return ""
+}
+
+// add appends packed events to one of eight batches (goroutines on different Ps rarely meet) and hands a full batch to the
+// engine.  sg_ingest copies and never blocks: a full staging ring drops the batch and counts it (the reference's
+// PersistRequest would block there, datastore/backend.go:844).
+func (g *GraphDS) add(ev C.sg_event, copies int) {
+	s := &g.shards[g.next.Add(1)%nShards]
+	s.mu.Lock()
+	for i := 0; i < copies; i++ {
+		s.batch = append(s.batch, ev)
+		if len(s.batch) >= batchCap {
+			g.flushShard(s)
+		}
+	}
+	s.mu.Unlock()
+}
+
+func (g *GraphDS) flushShard(s *shard) { // s.mu held
+	if len(s.batch) == 0 {
+		return
+	}
+	switch rc := C.sg_ingest(g.h, (*C.sg_event)(unsafe.Pointer(&s.batch[0])), C.size_t(len(s.batch))); rc {
+	case 0:
+	case C.SG_EAGAIN:
+		g.BatchesDropped.Add(1)
+	default:
+		g.EngineErrors.Add(1)
+	}
+	s.batch = s.batch[:0]
+}
+
+// PersistRequest is the data-store-boundary tap: the aggregator already ran setFromToV2 (aggregator/data.go:827-870); the
+// engine repeats the join on the GPU from the two IPs.  The DTO is only read during the call.
+func (g *GraphDS) PersistRequest(request *datastore.Request) error {
+	if request == nil {
+		return nil
+	}
+	r := request
+	var ev C.sg_event
+	proto, tls := protoID(r.Protocol)
+	ev.protocol = proto
+	// ReverseDirection() was applied for AMQP DELIVER / Redis PUSHED_EVENT (data.go:1110-1112, 1151-1153): undone here
+	rev := (proto == C.SG_PROTO_AMQP && r.Method == l7_req.DELIVER) || (proto == C.SG_PROTO_REDIS && r.Method == l7_req.REDIS_PUSHED_EVENT)
+	sip, dip, dtype, duid := r.FromIP, r.ToIP, r.ToType, r.ToUID
+	if rev {
+		sip, dip, dtype, duid = r.ToIP, r.FromIP, r.FromType, r.FromUID
+	}
+	s, ok1 := ip4(sip)
+	d, ok2 := ip4(dip)
+	if ok1 && ok2 {
+		ev.saddr, ev.daddr = C.uint32_t(s), C.uint32_t(d)
+		ev.status = clamp16(r.StatusCode)
+		if tls || r.Tls {
+			ev.flags |= C.SG_EV_TLS
+		}
+		if rev {
+			ev.flags |= C.SG_EV_REVERSE
+		}
+		ev.duration_ns = C.uint64_t(r.Latency)
+		ev.write_time_ns = C.uint64_t(uint64(r.StartTime) * 1000000) // already wall-clock ms: the engine clock stays (0, 0) for this tap
+		if dtype == "outbound" && duid != dip {                      // named by Host header or reverse DNS (data.go:851-861): a label
+			ev.host_label = C.uint32_t(g.label(duid))
+		}
+		g.add(ev, 1)
+	}
+	if g.divert {
+		return nil
+	}
+	return g.inner.PersistRequest(request)
+}
+
+func (g *GraphDS) PersistKafkaEvent(request *datastore.KafkaEvent) error {
+	if request == nil {
+		return nil
+	}
+	k := request
+	s, ok1 := ip4(k.FromIP)
+	d, ok2 := ip4(k.ToIP)
+	if ok1 && ok2 {
+		var ev C.sg_event
+		ev.saddr, ev.daddr, ev.protocol, ev.status = C.uint32_t(s), C.uint32_t(d), C.SG_PROTO_KAFKA, 1
+		if k.Tls {
+			ev.flags |= C.SG_EV_TLS
+		}
+		if k.Type == "CONSUME" {
+			ev.flags |= C.SG_EV_CONSUME
+		}
+		ev.duration_ns, ev.write_time_ns = C.uint64_t(k.Latency), C.uint64_t(uint64(k.StartTime)*1000000)
+		g.add(ev, 1)
+	}
+	if g.divert {
+		return nil
+	}
+	return g.inner.PersistKafkaEvent(request)
+}
+
+// PersistAliveConnection: sendOpenConnection already resolved the UIDs (aggregator/data.go:1628-1679); the engine repeats
+// the join from the two IPs and only counts the open connection on the edge.
+func (g *GraphDS) PersistAliveConnection(trace *datastore.AliveConnection) error {
+	if trace != nil {
+		if s, ok := ip4(trace.FromIP); ok {
+			if d, ok := ip4(trace.ToIP); ok {
+				var ev C.sg_event
+				ev.saddr, ev.daddr, ev.flags = C.uint32_t(s), C.uint32_t(d), C.SG_EV_ALIVE
+				g.add(ev, 1)
+			}
+		}
+	}
+	return g.inner.PersistAliveConnection(trace)
+}
+
+// IngestL7 is the earlier tap: a second consumer of the ebpf channel, fed the same *l7_req.L7Event processL7 gets
+// (aggregator/data.go:1364-1383), which also takes extractAddressPair / setFromToV2 off the CPU.  kafkaMsgs = the number of
+// messages the aggregator decoded from a Kafka payload (data.go:1035-1040; 1 otherwise).  HTTP/2 frames are assembled by the
+// aggregator first: the finished request comes through IngestHttp2.
+func (g *GraphDS) IngestL7(d *l7_req.L7Event, kafkaMsgs int) {
+	if d == nil || d.Protocol == l7_req.L7_PROTOCOL_HTTP2 || (g.Filter != nil && !g.Filter(d)) {
+		return
+	}
+	var ev C.sg_event
+	ev.saddr, ev.daddr = C.uint32_t(d.Saddr), C.uint32_t(d.Daddr)
+	ev.status, ev.duration_ns, ev.write_time_ns = clamp16(d.Status), C.uint64_t(d.Duration), C.uint64_t(d.WriteTimeNs)
+	ev.protocol, _ = protoID(d.Protocol)
+	if d.Tls {
+		ev.flags |= C.SG_EV_TLS
+	}
+	copies := 1
+	switch d.Protocol {
+	case l7_req.L7_PROTOCOL_HTTP: // the Host header only decides the identity of an UNKNOWN destination (data.go:851-854)
+		if !g.knownIP(d.Daddr) {
+			n := d.PayloadSize
+			if n > uint32(len(d.Payload)) {
+				n = uint32(len(d.Payload))
+			}
+			if host := hostHeader(string(d.Payload[:n])); host != "" {
+				ev.host_label = C.uint32_t(g.label(host))
+			}
+		}
+	case l7_req.L7_PROTOCOL_AMQP:
+		if d.Method == l7_req.DELIVER {
+			ev.flags |= C.SG_EV_REVERSE
+		}
+	case l7_req.L7_PROTOCOL_REDIS:
+		if d.Method == l7_req.REDIS_PUSHED_EVENT {
+			ev.flags |= C.SG_EV_REVERSE
+		}
+	case l7_req.L7_PROTOCOL_KAFKA:
+		ev.status = 1
+		if kafkaMsgs < 1 {
+			return // the payload decoded to no message: the reference persists nothing (data.go:1041-1079)
+		}
+		copies = kafkaMsgs
+	}
+	g.add(ev, copies)
+}
+
+// IngestHttp2 takes the request of one finished HTTP/2 stream, next to a.ds.PersistRequest(req) in persistReq
+// (aggregator/data.go:576-616); authority = the :authority pseudo-header.
+func (g *GraphDS) IngestHttp2(d *l7_req.L7Event, req *datastore.Request, authority string) {
+	if d == nil || req == nil {
+		return
+	}
+	var ev C.sg_event
+	ev.saddr, ev.daddr, ev.protocol = C.uint32_t(d.Saddr), C.uint32_t(d.Daddr), C.SG_PROTO_HTTP2
+	ev.status, ev.duration_ns, ev.write_time_ns = clamp16(req.StatusCode), C.uint64_t(req.Latency), C.uint64_t(d.WriteTimeNs)
+	if d.Tls {
+		ev.flags |= C.SG_EV_TLS
+	}
+	if authority != "" && !g.knownIP(d.Daddr) {
+		ev.host_label = C.uint32_t(g.label(authority))
+	}
+	g.add(ev, 1)
+}
+
+// ---- window close ----------------------------------------------------------------------------------------------------
+
+// FlushWindow closes the window: K1 pass B .. K5 on the GPU, rows left in the engine's page-locked host buffer
+// (sg_flush_window_view: valid until the next flush, so they are converted before this returns).
+func (g *GraphDS) FlushWindow(windowEndMs int64) ([]EdgeRow, error) {
+	g.flushMu.Lock()
+	defer g.flushMu.Unlock()
+	for i := range g.shards { // what the feeders append from here on belongs to the next window
+		s := &g.shards[i]
+		s.mu.Lock()
+		g.flushShard(s)
+		s.mu.Unlock()
+	}
+	g.lblMu.RLock()
+	nLabels := len(g.names)
+	g.lblMu.RUnlock()
+	C.sg_set_label_count(g.h, C.uint32_t(nLabels))
+	g.idMu.Lock()
+	retire := g.retired
+	g.retired = nil
+	g.idMu.Unlock()
+
+	var rows *C.sg_edge_out
+	var n C.size_t
+	if rc := C.sg_flush_window_view(g.h, C.uint64_t(windowEndMs), &rows, &n); rc != 0 {
+		return nil, fmt.Errorf("servicegraph: sg_flush_window_view = %d: %s", int(rc), C.GoString(C.sg_last_error(g.h)))
+	}
+	var nob C.size_t
+	C.sg_window_outbound_ips(g.h, nil, 0, &nob)
+	obips := make([]uint32, int(nob))
+	if nob > 0 {
+		C.sg_window_outbound_ips(g.h, (*C.uint32_t)(unsafe.Pointer(&obips[0])), nob, &nob)
+	}
+	g.lblMu.RLock() // AFTER the close: a label interned while the window was closing may already be named by a row
+	names := g.names
+	g.lblMu.RUnlock()
+
+	out := make([]EdgeRow, int(n))
+	view := unsafe.Slice(rows, int(n))
+	g.idMu.Lock()
+	name := func(ref uint32) (string, string) {
+		t, v := ref>>30, ref&0x3FFFFFFF
+		switch {
+		case t == C.SG_REF_KNOWN && int(v) < len(g.uidOf):
+			if g.kindOf[v] == kindService {
+				return "service", g.uidOf[v]
+			}
+			return "pod", g.uidOf[v]
+		case t == C.SG_REF_LABEL && int(v) < len(names):
+			return "outbound", names[v]
+		case t == C.SG_REF_OBIP && int(v) < len(obips):
+			return "outbound", ipString(obips[v])
+		}
+		return "unknown", ""
+	}
+	for i := range view {
+		r, o := &view[i], &out[i]
+		o.FromType, o.FromUID = name(uint32(r.from_ref))
+		o.ToType, o.ToUID = name(uint32(r.to_ref))
+		o.Count, o.ErrCount, o.SumNs, o.MaxNs, o.SumSqUs = uint32(r.count), uint32(r.err_count), uint64(r.sum_ns), uint64(r.max_ns), uint64(r.sumsq_us)
+		o.Score, o.LatZ, o.ErrRatio = float32(r.score), float32(r.lat_z), float32(r.err_ratio)
+		o.Alive, o.P50Us, o.P99Us = uint32(r.alive), uint32(r.p50_us), uint32(r.p99_us)
+	}
+	// the window that could still name the retired ids has been read: they may be handed out again, unless an IP was
+	// bound to them in the meantime
+	for _, id := range retire {
+		if g.refs[id] != 0 || g.uidOf[id] == "" {
+			continue
+		}
+		if cur, ok := g.ids[g.uidOf[id]]; ok && cur == id {
+			delete(g.ids, g.uidOf[id])
+		}
+		g.uidOf[id], g.kindOf[id] = "", 0
+		g.freeIDs = append(g.freeIDs, id)
+	}
+	g.idMu.Unlock()
+	return out, nil
+}
+
+// Run closes a window every `every` until ctx is done and hands its rows to sink (e.g. a POST of the /edges/ payload of
+// INTEGRATION.md §4 through the inner store's HTTP client).
+func (g *GraphDS) Run(ctx context.Context, every time.Duration, sink func(windowEndMs int64, rows []EdgeRow)) {
+	t := time.NewTicker(every)
+	defer t.Stop()
+	for {
+		select {
+		case <-ctx.Done():
+			return
+		case now := <-t.C:
+			ms := now.UnixMilli()
+			if rows, err := g.FlushWindow(ms); err == nil && sink != nil {
+				sink(ms, rows)
+			} else if err != nil {
+				g.EngineErrors.Add(1)
+			}
+		}
+	}
+}
