@@ -368,3 +368,9 @@ size_t sgh_mock_table_ops(void* g, uint32_t* out3, size_t cap) {
 uint32_t sgh_mock_label_count(void* g) { auto* c = static_cast<HostCtx*>(g); return c->mock ? reinterpret_cast<MockEngine*>(c->h)->label_count : 0; }
 
 }  // extern "C"
+
+// ---- the sharded window sequence with caller-supplied stages and collectives (alaz_amd/csrc/shard_seq.hpp) ------------------
+// The engine library runs the very same function with its HIP stages and RCCL (sg_window_run_sharded); exported here so that
+// the sequence can be driven without a GPU: tests/test_sharded.py plugs the numpy stand-in backend and gloo collectives in.
+#include "../shard_seq.hpp"
+extern "C" int sgh_run_sharded_window(const sg_shard_stages* stages, const sg_shard_comm* comm) { return sg_run_sharded_window(stages, comm); }

@@ -33,6 +33,7 @@ EXPORTS = [
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
     "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
+    "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded",
 ]
 
 
@@ -131,12 +132,38 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_route": (C.c_int, [H, P, sz, u32, P]),
         "sg_window_hist": (C.c_int, [H, P, sz, C.POINTER(sz)]),
         "sg_geometry_get": (C.c_int, [H, C.POINTER(SgGeometry)]),
+        "sg_comm_unique_id": (C.c_int, [P, sz]), "sg_comm_create": (C.c_int, [P, sz, C.c_int, C.c_int, C.c_int, C.POINTER(P)]),
+        "sg_comm_destroy": (C.c_int, [P]), "sg_window_run_sharded": (C.c_int, [H, P, P]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)          # AttributeError if the library does not export it
         f.restype = res; f.argtypes = args
     _lib = lib
     return lib
+
+
+class RcclComm:
+    """The engine library's own RCCL communicator (sg_comm_*): rank 0 draws the unique id, `bcast(bytes) -> bytes` hands it to
+    every rank (torch.distributed.broadcast_object_list, MPI, a file ...), every rank joins."""
+
+    def __init__(self, rank: int, world: int, device: int, bcast):
+        l = load_library()
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            rc = l.sg_comm_unique_id(buf, 128)
+            if rc != SG_OK:
+                raise ServiceGraphError(rc, "sg_comm_unique_id: librccl could not be loaded")
+        raw = bcast(bytes(buf.raw))
+        idb = (C.c_char * 128).from_buffer_copy(raw)
+        p = C.c_void_p()
+        rc = l.sg_comm_create(idb, 128, rank, world, device, C.byref(p))
+        if rc != SG_OK:
+            raise ServiceGraphError(rc, "sg_comm_create (ncclCommInitRank) failed")
+        self._l, self.ptr, self.rank, self.world = l, p, rank, world
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self._l.sg_comm_destroy(self.ptr); self.ptr = None
 
 
 def ip_u32(s: str) -> int:
@@ -242,6 +269,10 @@ class ServiceGraph:
     def window_score(self, stream: int = 0): self._ck(self._l.sg_window_score(self._h, stream or None))
 
     def window_score_reset(self, stream: int = 0): self._ck(self._l.sg_window_score_reset(self._h, stream or None))
+
+    def window_run_sharded(self, comm: "RcclComm", stream: int = 0):
+        """K1 pass B .. K5 of this shard's window with every exchange, ONE C call (sg_window_run_sharded); rows stay on the device."""
+        self._ck(self._l.sg_window_run_sharded(self._h, comm.ptr, stream or None))
     def window_reset(self, stream: int = 0): self._ck(self._l.sg_window_reset(self._h, stream or None))
 
     def window_close_sharded(self, d_union_ips: int, d_union_n: int, stream: int = 0):

@@ -180,6 +180,90 @@ def _run_window(be, comm, fused_reset: bool = False) -> None:
 
 
 # ------------------------------------------------------------------------------------------------
+# the same sequence through the C sequencer (alaz_amd/csrc/shard_seq.hpp)
+# ------------------------------------------------------------------------------------------------
+def run_window_c(be, comm=None) -> None:
+    """The window sequence of `_run_window`, but issued by the C function the engine library itself runs inside
+    sg_window_run_sharded (sg_run_sharded_window, exported by libsgdatastore.so as sgh_run_sharded_window): the stages are
+    callbacks into `be`, the collectives callbacks into `comm`.  The HIP engine does not need this detour (it has
+    sg_window_run_sharded with RCCL inside); it exists so that the C sequence itself is driven by the CPU tests (gloo)."""
+    import ctypes as C
+    from . import hostlib
+    comm = comm if comm is not None else DistComm()
+    lib = hostlib.load()
+    world, layers = be.world, be.layers
+    # fixed exchange buffers (the sequencer passes pointers, not tensors)
+    ob_local = be.ob_local().clone()
+    bufs = {"ob_local": ob_local, "ob_all": be.ob_all, "serve": be.serve, "rows_in": be.rows_in,
+            "req": torch.zeros_like(be.serve), "rows_out": torch.zeros_like(be.rows_in)}
+    by_ptr = {}
+
+    def reg(t):
+        by_ptr[t.data_ptr()] = t
+        return C.c_void_p(t.data_ptr())
+    STAGE0 = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    STAGE1 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)
+    GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+    class Comm(C.Structure):
+        _fields_ = [("ctx", C.c_void_p), ("all_gather", GATHER), ("all_reduce_u64", REDUCE), ("all_to_all", GATHER)]
+
+    class Stages(C.Structure):
+        _fields_ = [("ctx", C.c_void_p), ("layers", C.c_uint32), ("world", C.c_uint32),
+                    ("obip_list", STAGE0), ("close_gathered", STAGE0), ("features", STAGE0), ("halo_build", STAGE0),
+                    ("layer", STAGE1), ("pack", STAGE1), ("unpack", STAGE1), ("score", STAGE0),
+                    ("ob_local", C.c_void_p), ("ob_all", C.c_void_p), ("ob_bytes", C.c_size_t),
+                    ("stats_sum", C.c_void_p), ("stats_sum_words", C.c_size_t), ("stats_max", C.c_void_p), ("stats_max_words", C.c_size_t),
+                    ("req", C.c_void_p), ("serve", C.c_void_p), ("list_bytes", C.c_size_t),
+                    ("rows_out", C.c_void_p), ("rows_in", C.c_void_p), ("rows_bytes", C.c_size_t)]
+    errs = []
+
+    def guard(fn):
+        def w(*a):
+            try:
+                fn(*a)
+                return 0
+            except Exception as ex:                                  # noqa: BLE001 — reported through the return code
+                errs.append(ex)
+                return -5
+        return w
+
+    def per_rank(t):
+        return t.numel() * t.element_size() // world
+
+    def c_gather(_ctx, send, recv, nbytes):
+        comm.all_gather_into(by_ptr[recv], by_ptr[send])
+    def c_reduce(_ctx, buf, count, op):
+        comm.all_reduce_(by_ptr[buf], "max" if op else "sum")
+    def c_a2a(_ctx, send, recv, nbytes):
+        comm.all_to_all_equal(by_ptr[recv], by_ptr[send])
+    cm = Comm(None, GATHER(guard(c_gather)), REDUCE(guard(c_reduce)), GATHER(guard(c_a2a)))
+    st = Stages()
+    st.layers, st.world = layers, world
+    st.obip_list = STAGE0(guard(lambda _c: bufs["ob_local"].copy_(be.ob_local())))
+    st.close_gathered = STAGE0(guard(lambda _c: be.close_gathered()))
+    st.features = STAGE0(guard(lambda _c: be.features()))
+    st.halo_build = STAGE0(guard(lambda _c: bufs["req"].copy_(be.halo_requests())))
+    st.layer = STAGE1(guard(lambda _c, l: be.layer(l)))
+    st.pack = STAGE1(guard(lambda _c, l: bufs["rows_out"].copy_(be.pack(l))))
+    st.unpack = STAGE1(guard(lambda _c, l: be.unpack(l)))
+    st.score = STAGE0(guard(lambda _c: be.score()))
+    st.ob_local, st.ob_all, st.ob_bytes = reg(bufs["ob_local"]), reg(be.ob_all), per_rank(be.ob_all)
+    st.stats_sum, st.stats_sum_words = reg(be.stats_sum), be.stats_sum.numel()
+    st.stats_max, st.stats_max_words = reg(be.stats_max), be.stats_max.numel()
+    st.req, st.serve, st.list_bytes = reg(bufs["req"]), reg(be.serve), per_rank(be.serve)
+    st.rows_out, st.rows_in, st.rows_bytes = reg(bufs["rows_out"]), reg(be.rows_in), per_rank(be.rows_in)
+    lib.sgh_run_sharded_window.restype = C.c_int
+    lib.sgh_run_sharded_window.argtypes = [C.POINTER(Stages), C.POINTER(Comm)]
+    rc = lib.sgh_run_sharded_window(C.byref(st), C.byref(cm))
+    if errs:
+        raise errs[0]
+    if rc != 0:
+        raise RuntimeError(f"sgh_run_sharded_window returned {rc}")
+
+
+# ------------------------------------------------------------------------------------------------
 # product backend: HIP engine + torch-owned exchange buffers
 # ------------------------------------------------------------------------------------------------
 class HipBackend:
@@ -267,7 +351,16 @@ def bench(a, rank: int, world: int, local: int) -> dict:
     nlab = max(64, len(labels))
     ncap = topo.n_nodes + nlab + 64
     comm = DistComm()
-    engs, bes = [], []
+    # default: the window is ONE C call (sg_window_run_sharded: the library issues its collectives on RCCL itself);
+    # SG_SHARDED_PY=1 keeps the Python-orchestrated driver (run_window: ~15 ctypes calls + 6 torch.distributed calls per window)
+    import os
+    one_call = os.environ.get("SG_SHARDED_PY") != "1"
+
+    def bcast(raw):
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    engs, bes, rcomms, streams = [], [], [], []
     for k in range(2):
         g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(len(view.edge_src) * 1.25) + 4096, layers=L,
                                 max_labels=nlab, max_outbound_ips=64, device=local, rank=rank, world=world, max_batch=1 << 18,
@@ -280,14 +373,22 @@ def bench(a, rank: int, world: int, local: int) -> dict:
             g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
         g.set_label_count(len(labels))
         engs.append(g)
-        bes.append(HipBackend(g, ncap=ncap, layers=L, world=world, rank=rank, device=device, max_obip=64, stream=torch.cuda.Stream(device)))
+        st = torch.cuda.Stream(device)
+        streams.append(st)
+        if one_call:
+            rcomms.append(engine.RcclComm(rank, world, local, bcast))   # one communicator per engine: the two windows in flight do not share a stream
+        else:
+            bes.append(HipBackend(g, ncap=ncap, layers=L, world=world, rank=rank, device=device, max_obip=64, stream=st))
     dev = [torch.from_numpy(ev_all[i * Ev:(i + 1) * Ev].view(np.uint8).reshape(-1)).to(device) for i in range(nb)]
     torch.cuda.synchronize(device)
 
     def step(i):
         k = i & 1
-        engs[k].ingest_device(dev[i % nb].data_ptr(), Ev, bes[k].s)
-        run_window(bes[k], comm, fused_reset=True)
+        engs[k].ingest_device(dev[i % nb].data_ptr(), Ev, streams[k].cuda_stream)
+        if one_call:
+            engs[k].window_run_sharded(rcomms[k], streams[k].cuda_stream)
+        else:
+            run_window(bes[k], comm, fused_reset=True)
 
     for i in range(a.warmup):
         step(i)
@@ -303,10 +404,14 @@ def bench(a, rank: int, world: int, local: int) -> dict:
         g.timing_enable(0)
     k1a = np.mean([g.timing(1)[0] for g in engs]); k1b = np.mean([g.timing(7)[0] for g in engs]); k1n = sum(g.timing(1)[1] for g in engs)
     # edges of one window (untimed)
-    engs[0].ingest_device(dev[0].data_ptr(), Ev, bes[0].s)
-    run_window(bes[0], comm)
-    rows = engs[0].window_read()
-    engs[0].window_reset(bes[0].s)
+    engs[0].ingest_device(dev[0].data_ptr(), Ev, streams[0].cuda_stream)
+    if one_call:
+        engs[0].window_run_sharded(rcomms[0], streams[0].cuda_stream)
+        rows = engs[0].window_read()                               # (the counters and the rows survive the fused reset)
+    else:
+        run_window(bes[0], comm)
+        rows = engs[0].window_read()
+        engs[0].window_reset(bes[0].s)
     st = engs[0].stats()
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -326,11 +431,14 @@ def bench(a, rank: int, world: int, local: int) -> dict:
                    "events_per_window": Ev * world, "edges_per_window": int(agg[0].item()), "layers": L,
                    "dropped_or_misrouted": int(agg[1].item()),
                    "rccl_ranks": dist.get_world_size(),
-                   "parallelism": f"{world} shards, RCCL all-reduce (node stats) + halo all-to-all, 2 windows in flight per GPU"},
-        "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = k1a_partition + k1b_merge (rank 0)", "achieved": ach, "peak": 8000.0,
+                   "parallelism": f"{world} shards, RCCL all-reduce (node stats) + halo all-to-all, 2 windows in flight per GPU",
+                   "window_driver": "sg_window_run_sharded (one C call per window, RCCL from the library)" if one_call else "alaz_amd.sharded.run_window (Python, torch.distributed)"},
+        "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = " + " + ".join(engs[0].k1_kernels()) + " (rank 0)", "achieved": ach, "peak": 8000.0,
                      "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": k1_us,
-                     "k1a_partition_us": float(k1a), "k1b_merge_us": float(k1b), "launches": int(k1n)},
+                     "pass_a_us": float(k1a), "pass_b_us": float(k1b), "launches": int(k1n)},
     }
+    for c in rcomms:
+        c.close()
     for g in engs:
         g.close()
     return res

@@ -317,6 +317,19 @@ int sg_halo_unpack_padded(sg_handle h, uint32_t l, const uint32_t* d_req, uint32
 int sg_halo_pack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, float* d_rows, void* stream);
 int sg_halo_unpack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, const float* d_rows, void* stream);
 
+/* ---- the sharded window in ONE call ------------------------------------------------------------------------------------ *
+ * sg_window_run_sharded = sg_window_obip_list .. sg_window_score_reset above with every exchange in between — all-gather of
+ * the raw outbound IPs, SUM / MAX all-reduce of the integer node statistics, all-to-all of the halo request lists, per layer
+ * an all-to-all of exactly the requested rows — issued by the library itself on RCCL (grouped ncclSend / ncclRecv over the
+ * xGMI full mesh) and enqueued on `stream`: one C call per window, nothing waits for the device, the exchange buffers belong
+ * to the engine.  The communicator: rank 0 calls sg_comm_unique_id, the caller broadcasts the 128 bytes (any transport),
+ * every rank calls sg_comm_create with its sg_config.rank / world.  RCCL is dlopen'ed (SG_ENODEV if it cannot be).      */
+typedef struct sg_comm sg_comm;
+int sg_comm_unique_id(void* id128, size_t bytes);
+int sg_comm_create(const void* id128, size_t bytes, int rank, int world, int device, sg_comm** out);
+int sg_comm_destroy(sg_comm* c);
+int sg_window_run_sharded(sg_handle h, sg_comm* comm, void* stream);
+
 /* Ascending raw IPs of the last read window's OBIP nodes.                                       */
 int sg_window_outbound_ips(sg_handle h, uint32_t* ips, size_t cap, size_t* n);
 /* The latency histograms of the last read window (SG_CFG_EDGE_HISTOGRAM): bins[i * SG_HIST_BINS + b] = requests of row i in

@@ -35,7 +35,7 @@ def _trace(layers):
     return topo, ev, labels
 
 
-def _worker(rank, world, port, layers, q):
+def _worker(rank, world, port, layers, q, c_sequencer=False):
     from tests.np_backend import NumpyBackend
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -48,19 +48,24 @@ def _worker(rank, world, port, layers, q):
         be = NumpyBackend(pod_ip_to_id=pod, svc_ip_to_id=svc, kind=kind, n_labels=len(labels), weights=weights.make_weights(layers),
                           layers=layers, rank=rank, world=world, ncap=topo.n_nodes + len(labels) + 64)
         be.ingest(ev[shard == rank])
-        sharded.run_window(be)
+        if c_sequencer: sharded.run_window_c(be)             # the C function sg_window_run_sharded runs (shard_seq.hpp), collectives = gloo
+        else: sharded.run_window(be)
         q.put((rank, be.rows, be.misrouted, be.N, [int(x) for x in be.ob], [int(x) for x in be.alive_csr]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("c_sequencer", [False, True])
 @pytest.mark.parametrize("layers", [1, 2])
-def test_two_shards_equal_unsharded_oracle(layers):
+def test_two_shards_equal_unsharded_oracle(layers, c_sequencer):
+    """Two gloo processes close a window together — through the Python driver (run_window) and through the C sequencer
+    the engine's one-call entry point sg_window_run_sharded is built on (sgh_run_sharded_window) — and must reproduce the
+    unsharded oracle row for row."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, layers, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, layers, q, c_sequencer)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
