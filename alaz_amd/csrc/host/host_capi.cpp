@@ -374,3 +374,67 @@ uint32_t sgh_mock_label_count(void* g) { auto* c = static_cast<HostCtx*>(g); ret
 // the sequence can be driven without a GPU: tests/test_sharded.py plugs the numpy stand-in backend and gloo collectives in.
 #include "../shard_seq.hpp"
 extern "C" int sgh_run_sharded_window(const sg_shard_stages* stages, const sg_shard_comm* comm) { return sg_run_sharded_window(stages, comm); }
+
+// ---- synthetic capture for the streaming harness (tools/c5_stream.py) ---------------------------------------------------------
+// BASELINE config 5 is a STREAM of raw l7_event records over a 20 M-edge graph.  A ring of distinct 1096-byte records large enough
+// to touch millions of edges per window would be tens of GB; instead the harness keeps a ring of PACKED events (32 bytes each,
+// drawn from the seeded edge list by alaz_amd/replay.py) and this feeder expands every one of them into the wire record the
+// reference's perf reader would have seen — the same fields and payloads replay.to_wire() writes (ebpf/l7_req/l7.go:345-369;
+// "GET /user HTTP1.1" + Host header, a Postgres simple query, count-only Kafka) — in a thread-local buffer, 256 records at a
+// time, and hands them to GraphDS::IngestWire: payload parse, label interning, packing and batching all run as in production.
+// Paced: the caller's share of `rate` events/s since *t0 (steady_clock ns); returns the events fed, stops when *stop != 0.
+#include <atomic>
+#include <chrono>
+#include <thread>
+extern "C" long sgh_graphds_feed_expanded(void* g, const sg_event* ring, size_t ring_n, size_t first, size_t stride_chunks, size_t chunk,
+                                          const char* const* labels, size_t n_labels, double rate_per_s, const int64_t* t0_ns, const volatile int* stop,
+                                          volatile long* fed_out) {
+    auto* ctx = static_cast<HostCtx*>(g);
+    constexpr size_t kRec = l7_req::kWireSize, kBatch = 256;
+    std::vector<uint8_t> buf(kBatch * kRec);
+    static const char kPg[] = "SELECT * FROM users WHERE id = 1";
+    long fed = 0;
+    size_t pos = first;
+    auto now_ns = [] { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    while (!*stop) {
+        const double ahead = (double)fed - rate_per_s * (double)(now_ns() - *t0_ns) * 1e-9;
+        if (ahead > 0) { std::this_thread::sleep_for(std::chrono::microseconds((long)std::min(2000.0, ahead / rate_per_s * 1e6 + 1.0))); continue; }
+        const size_t n_chunk = std::min(chunk, ring_n - pos);
+        for (size_t i0 = 0; i0 < n_chunk; i0 += kBatch) {
+            const size_t nb = std::min(kBatch, n_chunk - i0);
+            for (size_t i = 0; i < nb; i++) {
+                const sg_event& e = ring[pos + i0 + i];
+                uint8_t* r = buf.data() + i * kRec;
+                std::memset(r, 0, 36); std::memset(r + 1060, 0, kRec - 1060);
+                const uint64_t fd = 3 + (pos + i0 + i) % 97; const uint32_t pid = 4242, status = e.status;
+                std::memcpy(r, &fd, 8); std::memcpy(r + 8, &e.write_time_ns, 8); std::memcpy(r + 16, &pid, 4); std::memcpy(r + 20, &status, 4);
+                std::memcpy(r + 24, &e.duration_ns, 8);
+                r[32] = e.protocol;
+                uint32_t pl = 0;
+                char* p = reinterpret_cast<char*>(r + 36);
+                if (e.protocol == SG_PROTO_HTTP) {
+                    r[33] = 1;                                                          // GET (ebpf/l7_req/l7.go method enum)
+                    const bool external = e.daddr >= 0x08080001u && e.daddr < 0x08090001u;
+                    if (e.host_label && e.host_label <= n_labels) pl = (uint32_t)std::snprintf(p, 1024, "GET /user HTTP1.1\r\nHost: %s\r\nAccept: */*\r\n\r\n", labels[e.host_label - 1]);
+                    else if (external) pl = (uint32_t)std::snprintf(p, 1024, "GET /user HTTP1.1\r\nAccept: */*\r\n\r\n");
+                    else pl = (uint32_t)std::snprintf(p, 1024, "GET /user HTTP1.1\r\nHost: svc.cluster.local\r\nAccept: */*\r\n\r\n");
+                } else if (e.protocol == SG_PROTO_POSTGRES) {
+                    r[33] = 2;                                                          // SIMPLE_QUERY
+                    const uint32_t len = (uint32_t)sizeof kPg + 4;                      // query + NUL + the length word
+                    p[0] = 'Q'; p[1] = (char)(len >> 24); p[2] = (char)(len >> 16); p[3] = (char)(len >> 8); p[4] = (char)len;
+                    std::memcpy(p + 5, kPg, sizeof kPg); pl = 5 + (uint32_t)sizeof kPg;
+                } else if (e.protocol == SG_PROTO_KAFKA) r[33] = (e.flags & SG_EV_CONSUME) ? 2 : 1;
+                std::memcpy(r + 1060, &pl, 4); r[1064] = 1; r[1066] = (e.flags & SG_EV_TLS) ? 1 : 0;
+                const uint16_t sport = (uint16_t)(32768 + (pos + i0 + i) % 28232), dport = e.protocol == SG_PROTO_POSTGRES ? 5432 : (e.protocol == SG_PROTO_KAFKA ? 9092 : 80);
+                std::memcpy(r + 1076, &e.saddr, 4); std::memcpy(r + 1080, &sport, 2); std::memcpy(r + 1084, &e.daddr, 4); std::memcpy(r + 1088, &dport, 2);
+            }
+            ctx->ds->IngestWire(buf.data(), nb, nullptr);
+            fed += (long)nb;
+        }
+        if (fed_out) *fed_out = fed;
+        pos += stride_chunks * chunk;
+        if (pos >= ring_n) pos = first;
+    }
+    if (fed_out) *fed_out = fed;
+    return fed;
+}

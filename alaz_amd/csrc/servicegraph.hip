@@ -971,7 +971,9 @@ int sg_window_score_reset(sg_handle e, void* stream) {
 int sg_window_read(sg_handle e, sg_edge_out* out, size_t cap, size_t* n) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    if (!e->closed) { e->err = "sg_window_read before sg_window_close"; return SG_ESTATE; }
+    // (after sg_window_score_reset / sg_window_run_sharded the window is open again, but its rows and counters are still in
+    // place until the next batch is ingested: readable)
+    if (!e->closed && !(e->last_rows == e->d.rows && e->window_events_in == 0)) { e->err = "sg_window_read before sg_window_close"; return SG_ESTATE; }
     return do_read(e, out, cap, n);
 }
 int sg_window_reset(sg_handle e, void* stream) {

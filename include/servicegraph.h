@@ -285,7 +285,8 @@ int sg_window_score(sg_handle h, void* stream);      /* K5 */
 int sg_window_score_reset(sg_handle h, void* stream);/* K5 with the window reset folded in (one launch less): for drivers
                                                         that read the rows through sg_window_rows_buffer(), not
                                                         sg_window_read(); the window is open again afterwards      */
-int sg_window_read(sg_handle h, sg_edge_out* out, size_t cap, size_t* n); /* device-syncs, copies out */
+int sg_window_read(sg_handle h, sg_edge_out* out, size_t cap, size_t* n); /* device-syncs, copies out; also valid after
+                                                        sg_window_score_reset / sg_window_run_sharded until the next ingest */
 int sg_window_reset(sg_handle h, void* stream);      /* clears the window state                  */
 
 /* Device buffers a sharded driver reduces / exchanges (all device pointers, engine-owned):

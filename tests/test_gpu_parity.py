@@ -610,6 +610,22 @@ def test_config5_mixed_protocol_window_on_the_global_table_path_against_the_orac
     pg = ev["protocol"] == replay.PROTO_POSTGRES
     acc = np.isin(ev["saddr"], topo.pod_ips)
     assert int(rows["err_count"].sum()) == int(((ev["status"] >= 500) & acc & (ev["protocol"] == replay.PROTO_HTTP)).sum() + ((ev["status"] == 2) & acc & pg).sum())
+    g.close()
+    # ... and as config 5 actually runs: the graph hash-sharded by source pod over 8 GPUs.  Eight logical shards on this device,
+    # each with the PARTITIONED K1 (variant 0, 8-byte records; 2.75 M-edge capacity per shard, 2048 partitions, join level 2 read
+    # from global memory: 150 k replicated IPs do not fit LDS, 18-bit endpoint indices), halo exchange through the real
+    # driver — the concatenated rows must equal the one-engine (variant 1) rows above bit for bit.
+    from alaz_amd import engine
+    probe = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.1) // 8, layers=2, max_labels=128, max_outbound_ips=128,
+                                rank=0, world=8, max_window_events=len(ev) // 4)
+    geo = probe.geometry(); probe.close()
+    assert geo["k1_variant"] == 0 and geo["k1_narrow"] == 1 and geo["join_l2_in_lds"] == 0 and geo["endpoint_bits"] >= 18
+    got, bad, per = _logical_shards(topo, ev, labels, 2, 8, max_edges=int(c["edges"] * 1.1) // 8)
+    assert bad == 0 and min(per) > 200_000
+    key = lambda a: np.lexsort((a["to_ref"], a["from_ref"]))
+    got = got[key(got)]; exp = rows[key(rows)]
+    assert len(got) == len(exp)
+    assert got.tobytes() == exp.tobytes()
 
 
 def test_windows_in_flight_give_the_same_rows_as_one_window_at_a_time():

@@ -7,11 +7,17 @@ window every second (GraphDS::FlushWindow: window pipeline on the device, rows b
 The reference's shape for the same thing: per-CPU perf readers -> worker goroutines -> PersistRequest
 (aggregator/data.go:222-236, ebpf/collector.go:79-81).
 
-Prints one JSON object: offered / accepted rate, per-window close latency, drops.  The record ring (and the cluster's IP lists)
-are cached in tools/c5_stream_cache.npz (generating C5's topology takes about a minute of CPU); the ring is replayed with
-fresh timestamps, so the window's edge set is the ring's edge set.
+Prints one JSON object: offered / accepted rate, per-window close latency, drops.
 
-usage: c5_stream.py [--rate 5e6] [--windows 10] [--feeders 8] [--ring 262144] [--window-s 1.0]"""
+Two sources of records:
+  --expand N (default, N = 8 M): a ring of N PACKED events drawn from config 5's own 20 M-edge graph (alaz_amd/replay.py; the
+      topology + the ring take ~1.5 min of CPU) which the C++ feeder threads expand into 1096-byte wire records on the fly
+      (sgh_graphds_feed_expanded: same fields and payloads as replay.to_wire) — a window of 5 M events then touches MILLIONS of
+      distinct edges of the graph, which is what config 5 says;
+  --ring N: a ring of N pre-built wire records replayed as they are (cached in tools/c5_stream_cache.npz for N = 262144: the
+      round-2 mode; a window's edge set is the ring's edge set, ~200 k edges).
+
+usage: c5_stream.py [--rate 5e6] [--windows 10] [--feeders 8] [--expand 8000000 | --ring 262144] [--window-s 1.0]"""
 import argparse, ctypes as C, json, os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -39,22 +45,42 @@ def load_or_make(ring: int, pods: int = 0, edges: int = 0):
     return ev, labels, topo.pod_ips, topo.svc_ips
 
 
+def engine_geometry(g):
+    """K1 geometry of the GraphDS's engine (sg_geometry_get through the raw handle)."""
+    from alaz_amd import engine
+    geo = engine.SgGeometry()
+    engine.load_library().sg_geometry_get(g.engine_handle, C.byref(geo))
+    return {"variant": int(geo.k1_variant), "narrow": int(geo.k1_narrow), "partitions": int(geo.partitions)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rate", type=float, default=5e6); ap.add_argument("--windows", type=int, default=10)
-    ap.add_argument("--feeders", type=int, default=8); ap.add_argument("--ring", type=int, default=1 << 18)
+    ap.add_argument("--feeders", type=int, default=8); ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--expand", type=int, default=8_000_000, help="packed events in the ring the C++ feeders expand to wire records (0 with --ring N: pre-built records)")
     ap.add_argument("--window-s", type=float, default=1.0); ap.add_argument("--chunk", type=int, default=4096)
     ap.add_argument("--make-cache-only", action="store_true")
     ap.add_argument("--mock", action="store_true", help="recording stand-in instead of the engine (CPU smoke test of this harness only)")
     ap.add_argument("--pods", type=int, default=0, help="a small synthetic cluster of this many pods instead of config 5's 100 k (smoke tests)")
     ap.add_argument("--edges", type=int, default=0)
     a = ap.parse_args()
-    ev, labels, pod_ips, svc_ips = load_or_make(a.ring, a.pods, a.edges)
+    expand = a.ring == 0
+    if expand and not a.pods:
+        c5 = replay.CONFIGS[5]
+        t_gen = time.perf_counter()
+        topo = replay.make_topology(c5["pods"], c5["edges"], replay.SEED_BASE + 5)
+        ev, labels = replay.make_events(topo, a.expand, replay.SEED_BASE + 5, mixed=True)
+        pod_ips, svc_ips = topo.pod_ips, topo.svc_ips
+        gen_s = time.perf_counter() - t_gen
+        del topo
+    else:
+        ev, labels, pod_ips, svc_ips = load_or_make(a.ring or (1 << 18) if not expand else min(a.expand, 1 << 20), a.pods, a.edges)
+        gen_s = 0.0
     if a.make_cache_only:
         print("cache ready:", len(ev), "records,", len(pod_ips), "pods,", len(svc_ips), "services"); return
     from alaz_amd import engine, hostlib
     c = replay.CONFIGS[5]
-    wire = np.frombuffer(replay.to_wire(ev, labels), dtype=np.uint8).copy()
+    wire = None if expand else np.frombuffer(replay.to_wire(ev, labels), dtype=np.uint8).copy()
     n_nodes = len(pod_ips) + len(svc_ips)
     max_edges = int(c["edges"] * 1.1) if not a.pods else max(1 << 16, 4 * (a.edges or a.pods * 20))
     cfg = engine.make_config(max_known_nodes=n_nodes + 1024, max_edges=max_edges, layers=c["layers"], max_labels=256, max_outbound_ips=256,
@@ -67,28 +93,42 @@ def main():
     for j, ip in enumerate(svc_ips): g.PersistService(f"svc-{j}", replay.ip_str(int(ip)))
     setup_s = time.perf_counter() - t0
     lib = hostlib.load()
-    base = wire.ctypes.data
     nrec = len(ev)
     stop = threading.Event()
     fed = [0] * a.feeders; rcs = [0] * a.feeders
     t_start = [0.0]
+    if expand:
+        ev = np.ascontiguousarray(ev)
+        lab_arr = (C.c_char_p * max(1, len(labels)))(*[s_.encode() for s_ in labels])
+        c_stop = C.c_int(0); c_t0 = C.c_int64(0)
+        c_fed = [C.c_long(0) for _ in range(a.feeders)]
+        lib.sgh_graphds_feed_expanded.restype = C.c_long
+        lib.sgh_graphds_feed_expanded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t,
+                                                  C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_long)]
 
-    def feeder(k):
-        # feeder k owns the ring's records k*chunk, (k+F)*chunk, ...; pacing: it may be at most its share of rate * elapsed ahead
-        per = a.rate / a.feeders
-        pos = k * a.chunk
-        while not stop.is_set():
-            ahead = fed[k] - per * (time.perf_counter() - t_start[0])
-            if ahead > 0:
-                time.sleep(min(ahead / per, 0.002)); continue
-            n = min(a.chunk, nrec - pos)
-            rc = lib.sgh_graphds_ingest_wire(g._g, C.c_void_p(base + pos * replay.L7_WIRE_SIZE), n, None)
-            if rc != 0: rcs[k] += 1
-            fed[k] += n
-            pos += a.feeders * a.chunk
-            if pos >= nrec: pos = k * a.chunk
+        def feeder(k):                                               # the whole paced loop runs in C++ (ctypes drops the GIL for the call)
+            lib.sgh_graphds_feed_expanded(g._g, ev.ctypes.data, nrec, k * a.chunk, a.feeders, a.chunk, lab_arr, len(labels),
+                                          a.rate / a.feeders, C.byref(c_t0), C.byref(c_stop), C.byref(c_fed[k]))
+    else:
+        base = wire.ctypes.data
+
+        def feeder(k):
+            # feeder k owns the ring's records k*chunk, (k+F)*chunk, ...; pacing: it may be at most its share of rate * elapsed ahead
+            per = a.rate / a.feeders
+            pos = k * a.chunk
+            while not stop.is_set():
+                ahead = fed[k] - per * (time.perf_counter() - t_start[0])
+                if ahead > 0:
+                    time.sleep(min(ahead / per, 0.002)); continue
+                n = min(a.chunk, nrec - pos)
+                rc = lib.sgh_graphds_ingest_wire(g._g, C.c_void_p(base + pos * replay.L7_WIRE_SIZE), n, None)
+                if rc != 0: rcs[k] += 1
+                fed[k] += n
+                pos += a.feeders * a.chunk
+                if pos >= nrec: pos = k * a.chunk
     ths = [threading.Thread(target=feeder, args=(k,), daemon=True) for k in range(a.feeders)]
     t_start[0] = time.perf_counter()
+    if expand: c_t0.value = time.monotonic_ns()                     # (std::chrono::steady_clock = CLOCK_MONOTONIC on Linux)
     for t in ths: t.start()
     closes = []; rows = []; offered = []
     prev = 0
@@ -98,15 +138,19 @@ def main():
         t1 = time.perf_counter()
         n = lib.sgh_graphds_flush(g._g, int((w + 1) * a.window_s * 1000), None, 0)      # count only: the rows stay in the C++ sink
         closes.append((time.perf_counter() - t1) * 1e3)
+        if expand: fed = [int(x.value) for x in c_fed]
         tot = sum(fed); offered.append(tot - prev); prev = tot
         rows.append(int(n))
     stop.set()
+    if expand: c_stop.value = 1
     for t in ths: t.join()
+    if expand: fed = [int(x.value) for x in c_fed]
     dt = time.perf_counter() - t_start[0]
     st = engine.SgStats()
     if not a.mock: engine.load_library().sg_stats_get(g.engine_handle, C.byref(st))
     ctr = g.counters()
-    res = {"workload": f"{'C5' if not a.pods else 'small-cluster'} streaming: {len(pod_ips)} pods / {len(svc_ips)} services, raw 1096-B l7_event records (70/15/15 HTTP/Kafka/Postgres) from a {nrec}-record ring, "
+    res = {"workload": f"{'C5' if not a.pods else 'small-cluster'} streaming: {len(pod_ips)} pods / {len(svc_ips)} services, raw 1096-B l7_event records (70/15/15 HTTP/Kafka/Postgres) "
+                       f"{'expanded on the fly by the C++ feeders from a ring of ' + str(nrec) + ' packed events drawn from the 20 M-edge graph' if expand else 'from a ring of ' + str(nrec) + ' pre-built records'}, "
                        f"{a.feeders} feeder threads -> C++ GraphDS::IngestWire -> sg_ingest; one window per {a.window_s:g} s closed by a dispatcher thread",
            "target_events_per_s": a.rate, "offered_events_per_s": sum(fed) / dt, "windows": a.windows,
            "engine_events_in": int(st.events_in), "engine_events_per_s": int(st.events_in) / dt,
@@ -115,7 +159,7 @@ def main():
            "parse_dropped": int(g.dropped_parse), "labels": len(g.labels),
            "window_close_ms": {"min": round(min(closes), 1), "median": round(float(np.median(closes)), 1), "max": round(max(closes), 1)},
            "rows_per_window": {"min": min(rows), "max": max(rows)}, "offered_per_window": {"min": min(offered), "max": max(offered)},
-           "setup_s": round(setup_s, 1), "wire_GBps_offered": sum(fed) / dt * replay.L7_WIRE_SIZE / 1e9}
+           "setup_s": round(setup_s, 1), "generate_s": round(gen_s, 1), "k1": (engine_geometry(g) if not a.mock else None), "wire_GBps_offered": sum(fed) / dt * replay.L7_WIRE_SIZE / 1e9}
     print(json.dumps(res))
     g.close()
 
