@@ -62,6 +62,8 @@ struct sg_engine {
     bool l2_in_lds = false, l2_u16 = false; u32 k1a_ct = 2048, k1a_nsub = 2;
     // staging ring for sg_ingest()
     sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
+    hipStream_t copy_stream = nullptr; hipEvent_t copied_ev[kStageSlots] = {};   // H2D copies run on their own stream: batch i + 1 is copied while K1a folds batch i
+    std::vector<std::pair<const char*, size_t>> registered;          // caller memory page-locked by sg_host_register
     int stage_next = 0;
     sg_edge_out* h_rows = nullptr; sg_edge_out* h_rows_old = nullptr; size_t h_rows_cap = 0;              // page-locked destination of sg_flush_window_view (grown on demand)
     bool stage_busy[kStageSlots] = {};                                   // a feeder thread is copying into the slot (outside the lock)
@@ -581,6 +583,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         d.pb = 0; while ((1u << d.pb) < d.np) d.pb++;
         if (narrow && 2 * nb - d.pb > 31) { d.np = (u32)np; d.pb = 0; while ((1u << d.pb) < d.np) d.pb++; }   // an SG_NP override that would not leave 31 remainder bits
         d.narrow = (narrow && d.variant == 0) ? 1u : 0u;
+        d.k1b_stagger = 0;
+        if (const char* v = std::getenv("SG_K1B_STAGGER")) d.k1b_stagger = (u32)std::min<u64>(std::strtoull(v, nullptr, 0), 10000);   // ticks of 10 ns
         if (!d.narrow) d.k1b_split = 1;
         d.npb = d.np * d.k1b_split;
         d.nb = nb; d.rb = 2 * nb - d.pb;
@@ -726,7 +730,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         CH(hipStreamSynchronize(e->stream));
         d.l1p_tab = tab;
     }
+    CH(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < kStageSlots; i++) {
+        CH(hipEventCreateWithFlags(&e->copied_ev[i], hipEventDisableTiming));
         CH(hipHostMalloc((void**)&e->h_stage[i], (size_t)e->cfg.max_batch * sizeof(sg_event)));
         CR(dev_alloc(e, &e->d_stage[i], e->cfg.max_batch));
         CH(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
@@ -760,7 +766,9 @@ int sg_destroy(sg_handle e) {
     for (int i = 0; i < kUpdSlots; i++) { if (e->h_upd[i]) hipHostFree(e->h_upd[i]); if (e->upd_ev[i]) hipEventDestroy(e->upd_ev[i]); }
     if (e->blob_ev) hipEventDestroy(e->blob_ev);
     if (e->k1_ev) hipEventDestroy(e->k1_ev);
-    for (int i = 0; i < kStageSlots; i++) { if (e->h_stage[i]) hipHostFree(e->h_stage[i]); if (e->stage_ev[i]) hipEventDestroy(e->stage_ev[i]); }
+    for (int i = 0; i < kStageSlots; i++) { if (e->h_stage[i]) hipHostFree(e->h_stage[i]); if (e->stage_ev[i]) hipEventDestroy(e->stage_ev[i]); if (e->copied_ev[i]) hipEventDestroy(e->copied_ev[i]); }
+    for (auto& r : e->registered) hipHostUnregister(const_cast<char*>(r.first));
+    if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     if (e->h_rows) hipHostFree(e->h_rows);
     if (e->h_rows_old) hipHostFree(e->h_rows_old);
     for (auto& r : e->trecs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -829,33 +837,87 @@ int sg_load_weights(sg_handle e, const float* w, size_t n) {
     return SG_OK;
 }
 
+namespace {
+// a free staging slot (neither being filled by another feeder nor still in flight), or -1: the ring is full
+int stage_take(sg_engine* e) {
+    for (int k = 0; k < kStageSlots; k++) {
+        const int c = (e->stage_next + k) % kStageSlots;
+        if (!e->stage_busy[c] && hipEventQuery(e->stage_ev[c]) != hipErrorNotReady) { e->stage_busy[c] = true; e->stage_next = (c + 1) % kStageSlots; e->pending_copies++; return c; }
+    }
+    return -1;
+}
+// host (page-locked) -> device slot on the copy stream, K1 pass A behind it on the window's stream (engine lock held)
+int stage_submit(sg_engine* e, int slot, const sg_event* src, size_t n) {
+    int rc = SG_OK;
+    if (hipMemcpyAsync(e->d_stage[slot], src, n * sizeof(sg_event), hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { e->err = "hipMemcpyAsync (staging ring)"; rc = SG_ENODEV; }
+    if (rc == SG_OK) {
+        hipEventRecord(e->copied_ev[slot], e->copy_stream);
+        hipStreamWaitEvent(e->stream, e->copied_ev[slot], 0);
+        e->st.h2d_bytes += n * sizeof(sg_event);
+        rc = launch_k1(e, e->d_stage[slot], n, e->stream);
+    }
+    hipEventRecord(e->stage_ev[slot], e->stream);                        // the slot is free again when pass A has read it
+    e->stage_busy[slot] = false; e->pending_copies--;
+    e->cv.notify_all();
+    return rc;
+}
+}  // namespace
+
 int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
     if (!e || (!events && n)) return SG_EINVAL;
     std::unique_lock<std::mutex> g(e->mu);
     if (n > e->cfg.max_batch) { e->err = "batch larger than max_batch"; return SG_EINVAL; }
     if (n == 0) return SG_OK;
-    int slot = -1;
-    for (int k = 0; k < kStageSlots; k++) {                              // any slot that is neither being filled by another feeder nor still in flight
-        const int c = (e->stage_next + k) % kStageSlots;
-        if (!e->stage_busy[c] && hipEventQuery(e->stage_ev[c]) != hipErrorNotReady) { slot = c; break; }
-    }
+    const int slot = stage_take(e);
     if (slot < 0) {                                                      // ring full: drop, never block
         e->st.events_dropped_ring += n;
         return SG_EAGAIN;
     }
-    e->stage_busy[slot] = true; e->stage_next = (slot + 1) % kStageSlots; e->pending_copies++;
     g.unlock();
     // the caller's memory is not retained; the copy into the pinned slot runs OUTSIDE the engine lock, so several
     // feeder threads (goroutines on different OS threads) fill different slots at the same time
     std::memcpy(e->h_stage[slot], events, n * sizeof(sg_event));
     g.lock();
-    int rc = SG_OK;
-    if (hipMemcpyAsync(e->d_stage[slot], e->h_stage[slot], n * sizeof(sg_event), hipMemcpyHostToDevice, e->stream) != hipSuccess) { e->err = "hipMemcpyAsync (staging ring)"; rc = SG_ENODEV; }
-    if (rc == SG_OK) { e->st.h2d_bytes += n * sizeof(sg_event); rc = launch_k1(e, e->d_stage[slot], n, e->stream); }
-    hipEventRecord(e->stage_ev[slot], e->stream);
-    e->stage_busy[slot] = false; e->pending_copies--;
-    e->cv.notify_all();
-    return rc;
+    return stage_submit(e, slot, e->h_stage[slot], n);
+}
+
+// The same without the staging copy, for events that already sit in page-locked memory: memory registered with
+// sg_host_register (e.g. the C-allocated buffer a packer writes into), or any hipHostMalloc'd block.  The library reads
+// `events` asynchronously: the n records must stay unchanged until the window they belong to has been closed
+// (sg_flush_window* / sg_window_run returned) — the one entry point that keeps caller memory beyond the call, and therefore
+// not for Go-heap memory (cgo rule); everything else as sg_ingest (non-blocking, SG_EAGAIN when no device slot is free).
+int sg_ingest_pinned(sg_handle e, const sg_event* events, size_t n) {
+    if (!e || (!events && n)) return SG_EINVAL;
+    std::unique_lock<std::mutex> g(e->mu);
+    if (n > e->cfg.max_batch) { e->err = "batch larger than max_batch"; return SG_EINVAL; }
+    if (n == 0) return SG_OK;
+    {
+        const char* p = reinterpret_cast<const char*>(events);
+        bool ok = false;
+        for (auto& r : e->registered) ok |= p >= r.first && p + n * sizeof(sg_event) <= r.first + r.second;
+        if (!ok) { e->err = "sg_ingest_pinned: the events are not inside memory registered with sg_host_register"; return SG_EINVAL; }
+    }
+    const int slot = stage_take(e);
+    if (slot < 0) { e->st.events_dropped_ring += n; return SG_EAGAIN; }
+    return stage_submit(e, slot, events, n);
+}
+int sg_host_register(sg_handle e, void* p, size_t bytes) {
+    if (!e || !p || !bytes) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { e->err = "hipHostRegister failed"; return SG_ENOMEM; }
+    e->registered.push_back({reinterpret_cast<const char*>(p), bytes});
+    return SG_OK;
+}
+int sg_host_unregister(sg_handle e, void* p) {
+    if (!e || !p) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    for (size_t i = 0; i < e->registered.size(); i++) if (e->registered[i].first == reinterpret_cast<const char*>(p)) {
+        hipDeviceSynchronize();                                          // nothing may still be reading it
+        hipHostUnregister(p);
+        e->registered.erase(e->registered.begin() + (long)i);
+        return SG_OK;
+    }
+    return SG_EINVAL;
 }
 
 int sg_ingest_device(sg_handle e, const sg_event* d_events, size_t n, void* stream) {

@@ -33,7 +33,7 @@ EXPORTS = [
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
     "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
-    "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded",
+    "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned",
 ]
 
 
@@ -134,6 +134,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_geometry_get": (C.c_int, [H, C.POINTER(SgGeometry)]),
         "sg_comm_unique_id": (C.c_int, [P, sz]), "sg_comm_create": (C.c_int, [P, sz, C.c_int, C.c_int, C.c_int, C.POINTER(P)]),
         "sg_comm_destroy": (C.c_int, [P]), "sg_window_run_sharded": (C.c_int, [H, P, P]),
+        "sg_host_register": (C.c_int, [H, P, sz]), "sg_host_unregister": (C.c_int, [H, P]), "sg_ingest_pinned": (C.c_int, [H, P, sz]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)          # AttributeError if the library does not export it
@@ -237,6 +238,18 @@ class ServiceGraph:
         ev = np.ascontiguousarray(events)
         assert ev.dtype == EVENT_DTYPE
         return self._ck(self._l.sg_ingest(self._h, ev.ctypes.data, len(ev)), allow=(SG_EAGAIN,))
+
+    def host_register(self, arr: np.ndarray):
+        """Page-lock a (contiguous) numpy array so that ingest_pinned can read slices of it without the staging copy."""
+        assert arr.flags.c_contiguous
+        self._ck(self._l.sg_host_register(self._h, arr.ctypes.data, arr.nbytes))
+
+    def host_unregister(self, arr: np.ndarray): self._ck(self._l.sg_host_unregister(self._h, arr.ctypes.data))
+
+    def ingest_pinned(self, events: np.ndarray) -> int:
+        """events: a slice of a registered array; it must stay unchanged until the window has been closed."""
+        assert events.dtype == EVENT_DTYPE and events.flags.c_contiguous
+        return self._ck(self._l.sg_ingest_pinned(self._h, events.ctypes.data, len(events)), allow=(SG_EAGAIN,))
 
     def ingest_device(self, dev_ptr: int, n: int, stream: int = 0):
         self._ck(self._l.sg_ingest_device(self._h, dev_ptr, n, stream or None))

@@ -431,7 +431,8 @@ def bench_single(a, device):
         g2.close()
     # events accepted by sg_ingest from HOST memory until their window's rows are readable on the host
     if not a.no_end_to_end and not a.profile_mode:
-        res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E)
+        res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E, pinned=True)
+        res["end_to_end"]["pageable"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E)
     if cpu is not None:
         res["cpu_baseline"] = cpu
     g.close()
@@ -444,17 +445,22 @@ def bench_single(a, device):
     return res
 
 
-def end_to_end(g, ev_all, Ev, nb, feeders, E):
-    """`feeders` host threads split every window's events and call sg_ingest (copy into the pinned staging ring, H2D, K1a)
-    concurrently; when all have returned, sg_flush_window closes the window and copies the scored rows to host memory."""
+def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False):
+    """`feeders` host threads split every window's events and call sg_ingest (copy into the pinned staging ring, H2D on the copy
+    stream, K1a behind it) concurrently; when all have returned, sg_flush_window_view closes the window and leaves the scored
+    rows in page-locked host memory.  pinned: the events sit in memory registered with sg_host_register and go in through
+    sg_ingest_pinned — no staging copy, the H2D reads the caller's buffer."""
     import torch
     chunk = 1 << 18
     nwin = 3 if Ev >= 5_000_000 else 10
     retries = [0]
+    if pinned:
+        g.host_register(ev_all)
 
     def feed(part):
+        put = g.ingest_pinned if pinned else g.ingest
         for j in range(0, len(part), chunk):
-            while g.ingest(part[j:j + chunk]) != 0:          # SG_EAGAIN: ring momentarily full -> this harness retries, production drops
+            while put(part[j:j + chunk]) != 0:               # SG_EAGAIN: ring momentarily full -> this harness retries, production drops
                 retries[0] += 1
     torch.cuda.synchronize()
     rows_n = 0
@@ -474,10 +480,13 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E):
         torch.cuda.synchronize(); t1 = time.perf_counter(); dv.copy_(hp, non_blocking=True); torch.cuda.synchronize(); h2d = max(h2d, (256 << 20) / (time.perf_counter() - t1) / 1e9)
         torch.cuda.synchronize(); t1 = time.perf_counter(); hp.copy_(dv, non_blocking=True); torch.cuda.synchronize(); d2h = max(d2h, (256 << 20) / (time.perf_counter() - t1) / 1e9)
     link_ms = (32.0 * Ev / h2d + 64.0 * E / d2h) / 1e6
-    return {"events_per_s": Ev * nwin / dt, "ms_per_window": dt / nwin * 1e3, "windows": nwin, "feeders": feeders,
+    if pinned:
+        g.host_unregister(ev_all)
+    return {"entry_point": "sg_ingest_pinned (events in registered page-locked memory, no staging copy)" if pinned else "sg_ingest (pageable caller memory, copied into the pinned staging ring)",
+            "events_per_s": Ev * nwin / dt, "ms_per_window": dt / nwin * 1e3, "windows": nwin, "feeders": feeders,
             "pcie_measured_GBs": {"h2d": round(h2d, 1), "d2h": round(d2h, 1)}, "pcie_bound_ms_per_window": round(link_ms, 3),
             "frac_of_pcie_bound": round(link_ms / (dt / nwin * 1e3), 3),
-            "includes": ["memcpy into pinned staging ring", "h2d", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows into page-locked host memory (sg_flush_window_view)", "window reset"],
+            "includes": ([] if pinned else ["memcpy into pinned staging ring"]) + ["h2d (own stream, overlapping K1a of the previous batch)", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows into page-locked host memory (sg_flush_window_view)", "window reset"],
             "rows_per_window": rows_n, "ring_full_retries": retries[0],
             "bound": f"PCIe: 32 B/event host->device + 64 B/edge device->host ({(32.0 * Ev + 64.0 * E) / 1e6:.0f} MB per window)"}
 

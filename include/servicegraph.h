@@ -243,6 +243,14 @@ int sg_load_weights(sg_handle h, const float* w, size_t n);
  * and returns SG_EAGAIN (the reference's PersistRequest would block here, backend.go:844).      */
 int sg_ingest(sg_handle h, const sg_event* events, size_t n);
 
+/* The same without the staging copy, for events that already sit in page-locked host memory the caller registered with
+ * sg_host_register (a C-allocated buffer a packer writes into; NOT Go-heap memory): the records are read asynchronously and
+ * must stay unchanged until the window they belong to has been closed.  Non-blocking like sg_ingest (SG_EAGAIN when no device
+ * slot is free); SG_EINVAL when the events are not inside registered memory.                                              */
+int sg_host_register(sg_handle h, void* p, size_t bytes);
+int sg_host_unregister(sg_handle h, void* p);
+int sg_ingest_pinned(sg_handle h, const sg_event* events, size_t n);
+
 /* Same, for events already resident in device memory (bench, sharded feeder).  `stream` is a
  * hipStream_t (NULL = the engine's own stream); K1 is ordered after prior work of that stream. */
 int sg_ingest_device(sg_handle h, const sg_event* d_events, size_t n, void* stream);
