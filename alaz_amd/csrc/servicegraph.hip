@@ -11,7 +11,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -583,8 +585,6 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         d.pb = 0; while ((1u << d.pb) < d.np) d.pb++;
         if (narrow && 2 * nb - d.pb > 31) { d.np = (u32)np; d.pb = 0; while ((1u << d.pb) < d.np) d.pb++; }   // an SG_NP override that would not leave 31 remainder bits
         d.narrow = (narrow && d.variant == 0) ? 1u : 0u;
-        d.k1b_stagger = 0;
-        if (const char* v = std::getenv("SG_K1B_STAGGER")) d.k1b_stagger = (u32)std::min<u64>(std::strtoull(v, nullptr, 0), 10000);   // ticks of 10 ns
         if (!d.narrow) d.k1b_split = 1;
         d.npb = d.np * d.k1b_split;
         d.nb = nb; d.rb = 2 * nb - d.pb;
@@ -900,6 +900,27 @@ int sg_ingest_pinned(sg_handle e, const sg_event* events, size_t n) {
     const int slot = stage_take(e);
     if (slot < 0) { e->st.events_dropped_ring += n; return SG_EAGAIN; }
     return stage_submit(e, slot, events, n);
+}
+// Blocking convenience for loaders that would rather wait than drop (replay tools, the bench's feeders): n events in
+// max_batch-sized pieces through sg_ingest (pinned = 0) or sg_ingest_pinned (pinned = 1); a full ring is waited for (the calling
+// thread sleeps 20 us and retries), never counted as a drop.  *retries (optional) = how often it had to wait.
+int sg_ingest_bulk(sg_handle e, const sg_event* events, size_t n, int pinned, uint64_t* retries) {
+    if (!e || (!events && n)) return SG_EINVAL;
+    const size_t step = e->cfg.max_batch;
+    uint64_t waits = 0;
+    for (size_t o = 0; o < n; o += step) {
+        const size_t m = std::min(step, n - o);
+        for (;;) {
+            const int rc = pinned ? sg_ingest_pinned(e, events + o, m) : sg_ingest(e, events + o, m);
+            if (rc == SG_OK) break;
+            if (rc != SG_EAGAIN) { if (retries) *retries = waits; return rc; }
+            { std::lock_guard<std::mutex> g(e->mu); e->st.events_dropped_ring -= m; }     // (not a drop: it is offered again)
+            waits++;
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    if (retries) *retries = waits;
+    return SG_OK;
 }
 int sg_host_register(sg_handle e, void* p, size_t bytes) {
     if (!e || !p || !bytes) return SG_EINVAL;

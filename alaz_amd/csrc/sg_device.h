@@ -121,7 +121,6 @@ struct Dev {
                                               //   units {mixed key, cnt | err << 32, sum_ns, max_ns, sumsq_us}
     uint2* hdr8;                              // [np][nwg] {narrow records, wide singles | aggregates << 16} in piece (p, w)
     u32 k1b_split;                            // narrow pass B: workgroups (sub-tables) per partition, 1 or 2; output partitions npb = np * k1b_split
-    u32 k1b_stagger;                          // narrow pass B: start offset (100 MHz ticks) of every second workgroup of the first dispatch round (0 = none)
     u32 npb;                                  // partitions of the pass-B OUTPUT (e_from / e_to / acc_src / e_rank / part_n): np, or np * k1b_split
     u32 sn, sw, punits;                       // piece geometry (sa is shared with the 16-byte layout); punits = sn + 2 sw + 5 sa, a multiple of 16
     u32 k1b_ht;                               // pass B: LDS table slots per partition (power of two)

@@ -457,13 +457,6 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     const u32 p = S == 2 ? ((q >> 4) << 3) | (q & 7u) : q, sidx = S == 2 ? (q >> 3) & 1u : 0u;
     const u32 oq = p * S + sidx;                                     // output partition
     const u32 nb = d.nb, nbmask = (1u << nb) - 1u, rbmask = (1u << d.rb) - 1u, sbit = d.rb - 1;
-    // Every workgroup of a dispatch round starts at the same time, so their phases line up chip-wide: all load (HBM busy, LDS
-    // idle), then all merge (LDS atomics busy, HBM idle), then all compact.  Every second workgroup of the FIRST round holds back
-    // for d.k1b_stagger ticks (100 MHz) so that one half's loads run under the other half's merge; later rounds inherit the offset.
-    if (d.k1b_stagger && blockIdx.x < 512u && ((blockIdx.x >> 3) & 1u)) {
-        const u64 t0 = wall_clock64();
-        while (wall_clock64() - t0 < (u64)d.k1b_stagger) __builtin_amdgcn_s_sleep(32);
-    }
     SG_STAMP(d, 1, 0);
     const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
     const u32 LPP = NT > d.nwg ? NT / d.nwg : 1u;                    // lanes per piece

@@ -33,7 +33,7 @@ EXPORTS = [
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
     "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
-    "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned",
+    "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned", "sg_ingest_bulk",
 ]
 
 
@@ -135,6 +135,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_comm_unique_id": (C.c_int, [P, sz]), "sg_comm_create": (C.c_int, [P, sz, C.c_int, C.c_int, C.c_int, C.POINTER(P)]),
         "sg_comm_destroy": (C.c_int, [P]), "sg_window_run_sharded": (C.c_int, [H, P, P]),
         "sg_host_register": (C.c_int, [H, P, sz]), "sg_host_unregister": (C.c_int, [H, P]), "sg_ingest_pinned": (C.c_int, [H, P, sz]),
+        "sg_ingest_bulk": (C.c_int, [H, P, sz, C.c_int, C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)          # AttributeError if the library does not export it
@@ -250,6 +251,13 @@ class ServiceGraph:
         """events: a slice of a registered array; it must stay unchanged until the window has been closed."""
         assert events.dtype == EVENT_DTYPE and events.flags.c_contiguous
         return self._ck(self._l.sg_ingest_pinned(self._h, events.ctypes.data, len(events)), allow=(SG_EAGAIN,))
+
+    def ingest_bulk(self, events: np.ndarray, pinned: bool = False) -> int:
+        """All of `events` in max_batch pieces, waiting for a free staging slot instead of dropping; returns the waits."""
+        assert events.dtype == EVENT_DTYPE and events.flags.c_contiguous
+        w = C.c_uint64(0)
+        self._ck(self._l.sg_ingest_bulk(self._h, events.ctypes.data, len(events), 1 if pinned else 0, C.byref(w)))
+        return int(w.value)
 
     def ingest_device(self, dev_ptr: int, n: int, stream: int = 0):
         self._ck(self._l.sg_ingest_device(self._h, dev_ptr, n, stream or None))

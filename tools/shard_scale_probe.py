@@ -2,7 +2,8 @@
 """Per-shard kernel cost of the multi-GPU weak-scaling workload, measured on ONE GPU: WORLD logical shards
 (one engine each, ThreadComm exchanges through device memory) run the workload of sharded.bench(); the
 per-group HIP-event timings of shard 0's engine are what one GPU of a WORLD-GPU node spends in kernels
-per window (exchanges excluded: those need the real fabric).  usage: shard_scale_probe.py [WORLD] [STEPS] [fixed|scaled]"""
+per window (exchanges excluded: those need the real fabric).  usage: shard_scale_probe.py [WORLD] [STEPS] [fixed|scaled] [CONFIG = 3]
+(CONFIG 3 = BASELINE config 4: config 3's graph hash-sharded over WORLD GPUs, 10 M events per GPU and window)"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,7 +12,8 @@ from alaz_amd import engine, sharded, replay, weights
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 gs = world if (len(sys.argv) > 3 and sys.argv[3] == "scaled") else 1      # graph: fixed (default) or scaled with world
-c = replay.CONFIGS[2]; seed = replay.SEED_BASE + 2
+cfgno = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+c = replay.CONFIGS[cfgno]; seed = replay.SEED_BASE + cfgno
 Ev, L = c["events"], c["layers"]
 topo = replay.make_topology(c["pods"] * gs, c["edges"] * gs, seed)
 dev = torch.device("cuda", 0)
@@ -53,5 +55,7 @@ engs[0].timing_reset(); engs[0].timing_enable(1)
 t0 = time.perf_counter(); run(steps); dt = time.perf_counter() - t0
 engs[0].timing_enable(0)
 print(f"world {world}: N = {topo.n_nodes} known nodes, shard 0 edges ~{len(sharded.shard_view(topo, 0, world).edge_src)}, {Ev} events per shard and window")
-print("shard 0 kernel groups (us):", {f"K{k}": round(engs[0].timing(k)[0], 1) for k in (1, 7, 2, 3, 4, 5, 6)})
+names = {1: "K1a", 7: "K1b", 2: "K2", 8: "K3-in", 3: "K3-feat", 4: "K4", 5: "K5", 6: "K6-halo"}
+per = {names[k]: round(engs[0].timing(k)[0] * engs[0].timing(k)[1] / steps, 1) for k in names}
+print("shard 0 kernel groups, us per window:", per, " sum", round(sum(per.values()), 1))
 print(f"all {world} shards on one GPU: {dt / steps * 1e6:.0f} us per step = {dt / steps / world * 1e6:.0f} us per shard-window")
