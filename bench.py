@@ -431,8 +431,10 @@ def bench_single(a, device):
         g2.close()
     # events accepted by sg_ingest from HOST memory until their window's rows are readable on the host
     if not a.no_end_to_end and not a.profile_mode:
-        res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E, pinned=True)
-        res["end_to_end"]["pageable"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E)
+        res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E)
+        # the same out of caller memory page-locked with sg_host_register (no staging copy).  Measured SLOWER on these boxes: the H2D
+        # engine reads hipHostRegister'ed memory at ~40 GB/s against 57 GB/s for the hipHostMalloc'ed staging ring
+        res["end_to_end"]["registered_memory"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E, pinned=True)
     if cpu is not None:
         res["cpu_baseline"] = cpu
     g.close()

@@ -11,6 +11,7 @@
 #   mfma:TAG:CONFIG          SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES pass -> TAG_mfma_cCONFIG.txt
 #   sq:TAG:CONFIG            SQ / LDS activity counters of the K1 kernels -> TAG_k1_sq_counters_cCONFIG.txt
 #   sharded1:TAG             bench.py under torch.distributed.run at world = 1 with the sharded pipeline forced (RCCL path)
+#   probe:TAG:WORLD[:CFG]    rocprofv3 kernel stats of tools/shard_scale_probe.py WORLD 6 fixed CFG (per-shard kernel time of C4)
 #   c5stream:TAG[:ARGS]      tools/c5_stream.py ARGS -> TAG_c5_stream.json
 #   run:CMD                  any command (',' = blank)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -58,6 +59,10 @@ for step in "$@"; do
     sharded1)
       SG_FORCE_SHARDED=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline > "$O/${a1}_sharded1.json" 2> "$O/${a1}_sharded1.err"
       echo "rc=$?"; tail -n 1 "$O/${a1}_sharded1.json" | cut -c1-900 ;;
+    probe)   # per-shard kernel time of the WORLD-shard workload of config a3 (default 3 = C4) from the profiler, not from event pairs
+      ( cd /tmp && rm -rf "$O/prof_probe" && timeout 900 rocprofv3 --kernel-trace --stats -d "$O/prof_probe" -o kt -- python "$R/tools/shard_scale_probe.py" "$a2" 6 fixed "${a3:-3}" > "$O/${a1}_probe_w$a2.log" 2>&1
+        { grep -v amdgpu.ids "$O/${a1}_probe_w$a2.log" | tail -n 4; python "$R/tools/rocpd_stats.py" "$O/prof_probe/kt_results.db"; } > "$O/${a1}_shard_of_${a2}_kernel_stats.txt"
+        head -n 40 "$O/${a1}_shard_of_${a2}_kernel_stats.txt"; rm -rf "$O/prof_probe" ) ;;
     c5stream) timeout 400 python tools/c5_stream.py $a2 > "$O/${a1}_c5_stream.json" 2> "$O/${a1}_c5_stream.err"; echo "rc=$?"; cut -c1-900 "$O/${a1}_c5_stream.json" ;;
     run) timeout 900 bash -c "$a1" 2>&1 | tail -n 40 ;;
     *) echo "unknown step $name" ;;
