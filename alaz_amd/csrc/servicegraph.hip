@@ -35,6 +35,7 @@ constexpr size_t kLdsBytes = 160 * 1024;  // per workgroup on gfx950
 struct TimingRec { hipEvent_t a, b; int kernel; };
 
 u32 next_pow2(u64 v) { u64 p = 1; while (p < v) p <<= 1; return (u32)p; }
+u64 wg_ev_split(u64 max_window_events) { return next_pow2(std::max<u64>(max_window_events / 12000, 1)); }   // pass-B workgroups a window's records ask for
 
 }  // namespace
 
@@ -396,7 +397,7 @@ int do_layer(sg_engine* e, u32 l, hipStream_t s, bool fuse_proj) {
     Timed t(e, s, 4);
     // two launches per layer: the gather-mean at high occupancy (8 rows per workgroup), then the dense tiles
     // (small graphs keep the fused kernel: at C2 the second launch costs more than the gather gains — 16.6 vs 20.9 us)
-    bool split = e->cfg.max_edges > (1u << 18);
+    bool split = e->cfg.max_edges > (1u << 17);              // (C2's 66 k-edge engine stays fused; a 160 k-edge shard of C4 — with its hub rows — splits)
     if (const char* v = std::getenv("SG_K4_FUSED")) split = std::atoi(v) == 0;
 #define K4_LAUNCH(FI, MF, PJ, HIN, HOUT) do { if (split) { \
             hipLaunchKernelGGL((k4_gather<FI>), dim3(grid_for(d.ncap, K4G_ROWS, 4096)), dim3(512), 0, s, d, HIN); \
@@ -558,6 +559,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             // partitions: ~2700 distinct edges each at the configured capacity at most (pass B's LDS table: 4096 slots of 36
             // bytes, 3072 may fill), at least 256.  Fewer partitions = longer runs per tile in pass A.
             np = next_pow2(std::max<u64>((ME + 2699) / 2700, 256));
+            // ... and few enough RECORDS per pass-B workgroup: a window of many events over few edges (a shard of C4: 10 M events,
+            // 126 k edges) would otherwise leave 256 workgroups, one per CU, with 30 k records each (73 us); ~12 k per workgroup
+            const u64 wg_ev = next_pow2(std::max<u64>(e->cfg.max_window_events / 12000, 1));
+            if (np < 512 && np * 2 < wg_ev) np = std::min<u64>(512, wg_ev / 2);
             u32 pbt = 0; while ((1ull << pbt) < np) pbt++;
             if (np > 2048 || 2 * nb - pbt > 31) narrow = false;          // (one wave scans the run lengths: beyond this the 16-byte kernels / variant 1)
         }
@@ -566,7 +571,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             // pass B: a partition that may hold more than ~1150 edges is merged by TWO workgroups (sub-tables of 2048 slots, two
             // workgroups per CU) rather than by one with a 4096-slot table that owns the CU alone
             if (ME / np > 1150) { d.k1b_split = 2; d.k1b_ht = 2048; }
-            else d.k1b_ht = ME / np > 550 ? 2048 : 1024;
+            else {
+                d.k1b_ht = ME / np > 550 ? 2048 : 1024;
+                if (np * 2 <= wg_ev_split(e->cfg.max_window_events) && ME / (np * 2) > 64) { d.k1b_split = 2; d.k1b_ht = ME / (np * 2) > 550 ? 2048 : 1024; }
+            }
             if (const char* v = std::getenv("SG_SPLIT")) { const int x = std::atoi(v); if (x == 1 || x == 2) { d.k1b_split = (u32)x; d.k1b_ht = ME / (np * x) > 1150 ? 4096 : (ME / (np * x) > 550 ? 2048 : 1024); } }
         } else {
             // 16-byte records: at most ~1250 distinct edges per partition (pass B's LDS table: 2048 slots, 1536 may fill; 1024 slots
