@@ -35,7 +35,6 @@ constexpr size_t kLdsBytes = 160 * 1024;  // per workgroup on gfx950
 struct TimingRec { hipEvent_t a, b; int kernel; };
 
 u32 next_pow2(u64 v) { u64 p = 1; while (p < v) p <<= 1; return (u32)p; }
-u64 wg_ev_split(u64 max_window_events) { return next_pow2(std::max<u64>(max_window_events / 12000, 1)); }   // pass-B workgroups a window's records ask for
 
 }  // namespace
 
@@ -559,10 +558,6 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             // partitions: ~2700 distinct edges each at the configured capacity at most (pass B's LDS table: 4096 slots of 36
             // bytes, 3072 may fill), at least 256.  Fewer partitions = longer runs per tile in pass A.
             np = next_pow2(std::max<u64>((ME + 2699) / 2700, 256));
-            // ... and few enough RECORDS per pass-B workgroup: a window of many events over few edges (a shard of C4: 10 M events,
-            // 126 k edges) would otherwise leave 256 workgroups, one per CU, with 30 k records each (73 us); ~12 k per workgroup
-            const u64 wg_ev = next_pow2(std::max<u64>(e->cfg.max_window_events / 12000, 1));
-            if (np < 512 && np * 2 < wg_ev) np = std::min<u64>(512, wg_ev / 2);
             u32 pbt = 0; while ((1ull << pbt) < np) pbt++;
             if (np > 2048 || 2 * nb - pbt > 31) narrow = false;          // (one wave scans the run lengths: beyond this the 16-byte kernels / variant 1)
         }
@@ -571,10 +566,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             // pass B: a partition that may hold more than ~1150 edges is merged by TWO workgroups (sub-tables of 2048 slots, two
             // workgroups per CU) rather than by one with a 4096-slot table that owns the CU alone
             if (ME / np > 1150) { d.k1b_split = 2; d.k1b_ht = 2048; }
-            else {
-                d.k1b_ht = ME / np > 550 ? 2048 : 1024;
-                if (np * 2 <= wg_ev_split(e->cfg.max_window_events) && ME / (np * 2) > 64) { d.k1b_split = 2; d.k1b_ht = ME / (np * 2) > 550 ? 2048 : 1024; }
-            }
+            else d.k1b_ht = ME / np > 550 ? 2048 : 1024;
+            // (sizing the partitions by the window's RECORDS as well — 512 x 2 workgroups for a shard of C4, 10 M events over 126 k
+            // edges — was measured and bought nothing: 79 vs 73 us)
             if (const char* v = std::getenv("SG_SPLIT")) { const int x = std::atoi(v); if (x == 1 || x == 2) { d.k1b_split = (u32)x; d.k1b_ht = ME / (np * x) > 1150 ? 4096 : (ME / (np * x) > 550 ? 2048 : 1024); } }
         } else {
             // 16-byte records: at most ~1250 distinct edges per partition (pass B's LDS table: 2048 slots, 1536 may fill; 1024 slots
