@@ -2196,24 +2196,41 @@ __device__ __forceinline__ void build_lists(const Dev& d, u32* req, u32 capp, bo
 #pragma unroll
         for (int k = 0; k < 8; k++) c[k] += (o == (u32)k + 1);
     }
-    u32 tl, tp;
-    u32 pl = block_excl_scan<1024>(cl, wsum, &tl);
-    __syncthreads();
-    u32 pp = block_excl_scan<1024>(cp, wsum, &tp);
-    __syncthreads();
-    if (threadIdx.x == 0) { d.ctr[C_ACT_L] = tl; d.ctr[C_ACT_P] = tp; }
+    // TEN exclusive block scans (two list cursors + eight owner cursors) in one go: wave scans of all ten values (DPP), the wave
+    // totals through LDS, ONE barrier pair — ten block_excl_scan calls were thirty barriers and 42 us of a shard's window
+    u32 val[10] = {cl, cp, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]}, pre[10], tot10[10];
+    {
+        const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        u32* ws = wsum;                                              // [10][16] wave totals (the caller provides >= 160 words)
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            u32 incl = val[j];
+            incl += dpp32<0x111>(incl); incl += dpp32<0x112>(incl); incl += dpp32<0x114>(incl); incl += dpp32<0x118>(incl);   // row_shr 1, 2, 4, 8
+            const u32 r0 = rdlane32(incl, 15), r1 = rdlane32(incl, 31), r2 = rdlane32(incl, 47);
+            incl += (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
+            pre[j] = incl - val[j];
+            if (lane == 63) ws[j * 16 + wave] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            u32 before = 0, all = 0;
+#pragma unroll
+            for (u32 w2 = 0; w2 < 16; w2++) { const u32 x = ws[j * 16 + w2]; all += x; before += w2 < wave ? x : 0u; }
+            pre[j] += before; tot10[j] = all;
+        }
+        __syncthreads();
+    }
+    u32 pl = pre[0], pp = pre[1];
+    if (threadIdx.x == 0) { d.ctr[C_ACT_L] = tot10[0]; d.ctr[C_ACT_P] = tot10[1]; }
     u32 pos[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        pos[k] = 0;
-        if (want_req && (u32)k < W) {                                // uniform
-            u32 tot;
-            pos[k] = block_excl_scan<1024>(c[k], wsum, &tot);
-            if (threadIdx.x == 0) {
-                if (tot > capp) { atomicAdd(&d.ctr[C_HALO_OVF], (u64)(tot - capp)); tot = capp; }
-                req[(size_t)k * (capp + 1)] = tot;
-            }
-            __syncthreads();
+        pos[k] = pre[2 + k];
+        if (want_req && (u32)k < W && threadIdx.x == 0) {
+            u32 tot = tot10[2 + k];
+            if (tot > capp) { atomicAdd(&d.ctr[C_HALO_OVF], (u64)(tot - capp)); tot = capp; }
+            req[(size_t)k * (capp + 1)] = tot;
         }
     }
     for (u32 v = beg; v < end; v++) {
@@ -2228,7 +2245,7 @@ __device__ __forceinline__ void build_lists(const Dev& d, u32* req, u32 capp, bo
     }
 }
 __global__ __launch_bounds__(1024) void k6_active_lists(Dev d) {       // for the unpadded halo API
-    __shared__ u32 wsum[17];
+    __shared__ u32 wsum[160];
     __shared__ unsigned char fl[K6_FLAGS_LDS];
     build_lists(d, nullptr, 0, false, fl, wsum);
 }
@@ -2236,7 +2253,7 @@ __global__ __launch_bounds__(1024) void k6_active_lists(Dev d) {       // for th
 // ---- padded halo exchange (no host synchronisation: fixed-size all-to-all) ----------------------------
 // req / serve layout: [world][capp + 1] u32, element 0 = count, ids follow.
 __global__ __launch_bounds__(1024) void k6_halo_build_padded(Dev d, u32* req, u32 capp) {
-    __shared__ u32 wsum[17];
+    __shared__ u32 wsum[160];
     __shared__ unsigned char fl[K6_FLAGS_LDS];
     build_lists(d, req, capp, true, fl, wsum);
 }
