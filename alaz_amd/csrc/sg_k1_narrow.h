@@ -275,6 +275,44 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     // is then one thread per tile position, all of a thread's LDS reads in flight together; otherwise 16 lanes walk a run.
     const bool packb = 2u * nb <= 31u;
     const u32 rb = d.rb;
+    // P4 of a tile: copy its runs to the pieces — adjacent lanes, adjacent addresses.  It runs at the TOP of the next tile, behind
+    // that tile's first eight loads: the loads' HBM latency (the barriers keep the waves in step, so nothing else would hide it)
+    // passes while the previous tile's records leave.  Legal anywhere between the barrier behind P3 and the next barrier behind P1:
+    // the tile, the offsets, this tile's run counters and piece counters are not written before that barrier.
+    auto copy_out = [&](const u32 pc) {
+        u32* bc = bcnt + pc * NP;
+        u32* fcn = fcn2 + pc * NP;
+    if (packb) {
+        const u32 total = boff[NP - 1] + bc[NP - 1];             // records in the tile
+        const u32 strip = ~(((1u << d.pb) - 1u) << rb);         // clears the partition bits (bit 31 = error stays)
+#pragma unroll
+        for (u32 k = 0; k < 4 * NSUB; k++) {
+            const u32 i = t + k * K1T_THREADS;
+            if (i < total) {
+                const u64 rec = tile[i];
+                const u32 hi = (u32)(rec >> 32), b = (hi >> rb) & ((1u << d.pb) - 1u);
+                const u32 pos = fcn[b] + (i - boff[b]);
+                const u64 out = (rec & 0xFFFFFFFFull) | ((u64)(hi & strip) << 32);
+                if (pos < d.sn) { if (!(d.ablate & 0x1u)) piece8(d, b, w)[pos] = out; }
+                else { K1T_LNEW(L); ovf8_single(d, b, ((u64)b << rb) | (hi & rbmask), rec & 0xFFFFFFFFull, hi >> 31, 0u, L); lflush(L); }
+            }
+        }
+    } else {
+        const u32 bpw = NP >> 4;                                 // partitions whose runs a wave writes out (np >= 64): four per step, 16 lanes each
+        for (u32 b4 = 0; b4 < bpw; b4 += 4) {
+            const u32 b = wave * bpw + b4 + (lane >> 4), j0 = lane & 15u;
+            const u32 cnt = bc[b], off = boff[b], pos0 = fcn[b];
+            u64* dst = piece8(d, b, w);
+            for (u32 j = j0; j < cnt; j += 16) {
+                const u64 rec = tile[off + j];
+                const u32 pos = pos0 + j;
+                if (pos < d.sn) { if (!(d.ablate & 0x1u)) dst[pos] = rec; }
+                else { K1T_LNEW(L); ovf8_single(d, b, ((u64)b << rb) | ((u32)(rec >> 32) & rbmask), rec & 0xFFFFFFFFull, (u32)(rec >> 63), 0u, L); lflush(L); }
+            }
+        }
+    }
+    };
+    bool havep = false; u32 pcur = 0;
     u32 cur = 0;
     u64 tk_p1 = 0, tk_wait = 0, tk_scan = 0, tk_p3 = 0, tk_b3 = 0, tk_p4 = 0;   // SG_ABLATE & 0x100: wave 0's clock ticks per phase
     for (u64 c0 = w; c0 < nchunk; c0 += (u64)NSUB * d.nwg, cur ^= 1u) {
@@ -287,6 +325,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
             const u64 cb0 = c0 * chunk, ce0 = cb0 + chunk < end ? cb0 + chunk : end;
             const u64 i0 = cb0 + t;
             K1T_ISSUE(i0, ce0, cb0);
+            if (havep && !(d.ablate & 0x800u)) { const u64 tq = (d.ablate & 0x100u) ? wall_clock64() : 0ull; copy_out(pcur); if (d.ablate & 0x100u) tk_p4 += wall_clock64() - tq; }
             K1T_FOLD(0, i0, ce0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
             if constexpr (NSUB == 2) {
                 const u64 c1 = c0 + d.nwg;
@@ -355,38 +394,11 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         const u64 tk4 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         LDS_BARRIER();
         const u64 tk5 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
-        // P4: copy the runs to the pieces — adjacent lanes, adjacent addresses
-        if (packb) {
-            const u32 total = boff[NP - 1] + bc[NP - 1];             // records in the tile
-            const u32 strip = ~(((1u << d.pb) - 1u) << rb);         // clears the partition bits (bit 31 = error stays)
-#pragma unroll
-            for (u32 k = 0; k < 4 * NSUB; k++) {
-                const u32 i = t + k * K1T_THREADS;
-                if (i < total) {
-                    const u64 rec = tile[i];
-                    const u32 hi = (u32)(rec >> 32), b = (hi >> rb) & ((1u << d.pb) - 1u);
-                    const u32 pos = fcn[b] + (i - boff[b]);
-                    const u64 out = (rec & 0xFFFFFFFFull) | ((u64)(hi & strip) << 32);
-                    if (pos < d.sn) { if (!(d.ablate & 0x1u)) piece8(d, b, w)[pos] = out; }
-                    else { K1T_LNEW(L); ovf8_single(d, b, ((u64)b << rb) | (hi & rbmask), rec & 0xFFFFFFFFull, hi >> 31, 0u, L); lflush(L); }
-                }
-            }
-        } else {
-            const u32 bpw = NP >> 4;                                 // partitions whose runs a wave writes out (np >= 64): four per step, 16 lanes each
-            for (u32 b4 = 0; b4 < bpw; b4 += 4) {
-                const u32 b = wave * bpw + b4 + (lane >> 4), j0 = lane & 15u;
-                const u32 cnt = bc[b], off = boff[b], pos0 = fcn[b];
-                u64* dst = piece8(d, b, w);
-                for (u32 j = j0; j < cnt; j += 16) {
-                    const u64 rec = tile[off + j];
-                    const u32 pos = pos0 + j;
-                    if (pos < d.sn) { if (!(d.ablate & 0x1u)) dst[pos] = rec; }
-                    else { K1T_LNEW(L); ovf8_single(d, b, ((u64)b << rb) | ((u32)(rec >> 32) & rbmask), rec & 0xFFFFFFFFull, (u32)(rec >> 63), 0u, L); lflush(L); }
-                }
-            }
-        }
-        if (d.ablate & 0x100u) { const u64 tk6 = wall_clock64(); tk_scan += tk3 - tk2; tk_p3 += tk4 - tk3; tk_b3 += tk5 - tk4; tk_p4 += tk6 - tk5; }
+        havep = true; pcur = cur;
+        if (d.ablate & 0x800u) copy_out(pcur);                       // (A/B: the copy-out right behind its barrier, as before)
+        if (d.ablate & 0x100u) { tk_scan += tk3 - tk2; tk_p3 += tk4 - tk3; tk_b3 += tk5 - tk4; }
     }
+    if (havep && !(d.ablate & 0x800u)) copy_out(pcur);                // the last tile's runs
     u32* fcn = fcn2 + cur * NP;                                      // the counts behind the last tile (written by its scan)
     SG_STAMP(d, 0, 3);
     if ((d.ablate & 0x100u) && t == 0 && blockIdx.x < 4096) { u64* g = d.dbg + ((size_t)2 * 4096 + blockIdx.x) * 8; g[0] = tk_p1; g[1] = tk_wait; g[2] = tk_scan; g[3] = tk_p3; g[4] = tk_b3; g[5] = tk_p4; }
