@@ -75,7 +75,7 @@ __device__ __forceinline__ void emit_agg8(const Dev& d, u32* fcw, u32 w, u32 p, 
 //   P1  join + setFromToV2 as selects + key mix + cache probe (the r02 fast path); a record that is not folded into the
 //       cache takes a rank in its partition's run (returning LDS add) and stays in registers
 //   P2  every wave turns the run lengths into offsets       P3  every thread drops its records at offset + rank
-//   P4  16 lanes per partition copy its run to the piece: adjacent lanes, adjacent addresses
+//   P4  thread i copies tile position i to its piece: adjacent lanes, adjacent addresses (at the top of the NEXT tile, behind its first loads)
 // Two LDS-only barriers per tile (behind P1 and P3); the run counters alternate so that P4 of tile k may overlap P1 of tile k + 1.
 // L2M: level 2 of the join 0 = read from global memory, 1 = staged in LDS as it is (u32 entries), 2 = staged in LDS as u16
 // entries kind << 14 | id (engines whose id space fits 14 bits: half the LDS, which goes to the edge cache).
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
             const u64 cb0 = c0 * chunk, ce0 = cb0 + chunk < end ? cb0 + chunk : end;
             const u64 i0 = cb0 + t;
             K1T_ISSUE(i0, ce0, cb0);
-            if (havep && !(d.ablate & 0x800u)) { const u64 tq = (d.ablate & 0x100u) ? wall_clock64() : 0ull; copy_out(pcur); if (d.ablate & 0x100u) tk_p4 += wall_clock64() - tq; }
+            if (havep) { const u64 tq = (d.ablate & 0x100u) ? wall_clock64() : 0ull; copy_out(pcur); if (d.ablate & 0x100u) tk_p4 += wall_clock64() - tq; }
             K1T_FOLD(0, i0, ce0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
             if constexpr (NSUB == 2) {
                 const u64 c1 = c0 + d.nwg;
@@ -395,10 +395,9 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         LDS_BARRIER();
         const u64 tk5 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
         havep = true; pcur = cur;
-        if (d.ablate & 0x800u) copy_out(pcur);                       // (A/B: the copy-out right behind its barrier, as before)
         if (d.ablate & 0x100u) { tk_scan += tk3 - tk2; tk_p3 += tk4 - tk3; tk_b3 += tk5 - tk4; }
     }
-    if (havep && !(d.ablate & 0x800u)) copy_out(pcur);                // the last tile's runs
+    if (havep) copy_out(pcur);                                       // the last tile's runs
     u32* fcn = fcn2 + cur * NP;                                      // the counts behind the last tile (written by its scan)
     SG_STAMP(d, 0, 3);
     if ((d.ablate & 0x100u) && t == 0 && blockIdx.x < 4096) { u64* g = d.dbg + ((size_t)2 * 4096 + blockIdx.x) * 8; g[0] = tk_p1; g[1] = tk_wait; g[2] = tk_scan; g[3] = tk_p3; g[4] = tk_b3; g[5] = tk_p4; }
