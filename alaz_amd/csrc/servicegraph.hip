@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int kStageSlots = 16;
+constexpr int kStageSlots = 32;                      // staging ring slots at most (sg_engine::n_stage of them are allocated)
 constexpr int kUpdSlots = 4;             // pinned ring for join-table word updates
 constexpr u32 kUpdCap = 1u << 15;         // (word offset, value) pairs per slot = sgjoin::Table::max_dirty
 constexpr size_t kLdsBytes = 160 * 1024;  // per workgroup on gfx950
@@ -64,12 +64,17 @@ struct sg_engine {
     bool l2_in_lds = false, l2_u16 = false; u32 k1a_ct = 2048, k1a_nsub = 2;
     // staging ring for sg_ingest()
     sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
-    hipStream_t copy_stream = nullptr; hipEvent_t copied_ev[kStageSlots] = {};   // H2D copies run on their own stream: batch i + 1 is copied while K1a folds batch i
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr; int n_copy = 1, copy_rr = 0; hipEvent_t copied_ev[kStageSlots] = {};   // H2D copies run on their own stream: batch i + 1 is copied while K1a folds batch i
     std::vector<std::pair<const char*, size_t>> registered;          // caller memory page-locked by sg_host_register
-    int stage_next = 0;
+    int stage_next = 0, n_stage = 16;
     sg_edge_out* h_rows = nullptr; sg_edge_out* h_rows_old = nullptr; size_t h_rows_cap = 0;              // page-locked destination of sg_flush_window_view (grown on demand)
     bool stage_busy[kStageSlots] = {};                                   // a feeder thread is copying into the slot (outside the lock)
     int pending_copies = 0; std::condition_variable cv;                 // window closes wait for the copies that began before them
+    // sg_flush_begin .. sg_flush_end: the window is closed and its pipeline enqueued under the lock (feeders that arrive meanwhile wait
+    // on `closing`); the rows are fetched WITHOUT it, on rd_stream, while the feeders already fill the next window
+    bool closing = false, flush_open = false, flush_async = false;
+    hipStream_t rd_stream = nullptr; hipEvent_t score_ev = nullptr; u64* h_ctr_pin = nullptr;
+    const sg_edge_out* fl_rows = nullptr; const u32* fl_ob = nullptr;    // device rows / outbound list of the window being flushed
 
     u64 first_kernel = 0, first_user = 0;
     float* d_W = nullptr; bool have_w = false;
@@ -441,30 +446,9 @@ int do_reset(sg_engine* e, hipStream_t s) {
     return SG_OK;
 }
 
-// view != nullptr: the rows go to the engine's page-locked buffer and *view points at them (out / cap unused)
-int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n, const sg_edge_out** view = nullptr) {
-    HIP_TRY(e, hipDeviceSynchronize());
-    HIP_TRY(e, hipMemcpy(e->h_ctr, e->d.ctr, sizeof(e->h_ctr), hipMemcpyDeviceToHost));
+// the window counters in e->h_ctr -> running statistics (engine lock held)
+void account_window(sg_engine* e) {
     const size_t E = (size_t)e->h_ctr[C_N_EDGES];
-    if (n) *n = E;
-    if (view) {
-        if (E > e->h_rows_cap) {
-            // the buffer the previous view pointed into stays alive for one more generation: a caller that still holds the
-            // last view (a numpy array over it, a Go slice) reads stale rows, not freed memory
-            if (e->h_rows_old) { hipHostFree(e->h_rows_old); e->h_rows_old = nullptr; }
-            e->h_rows_old = e->h_rows; e->h_rows = nullptr; e->h_rows_cap = 0;
-            const size_t want = std::min<size_t>(next_pow2(std::max<size_t>(E, 1024)), std::max<size_t>(e->cfg.max_edges, E));
-            HIP_TRY(e, hipHostMalloc((void**)&e->h_rows, want * sizeof(sg_edge_out)));
-            e->h_rows_cap = want;
-        }
-        if (E) HIP_TRY(e, hipMemcpy(e->h_rows, e->d.rows, E * sizeof(sg_edge_out), hipMemcpyDeviceToHost));
-        *view = e->h_rows;
-    }
-    const size_t take = view ? 0 : std::min(E, cap);
-    if (out && take) HIP_TRY(e, hipMemcpy(out, e->d.rows, take * sizeof(sg_edge_out), hipMemcpyDeviceToHost));
-    const size_t nob = (size_t)e->h_ctr[C_N_OBIP];
-    e->last_obips.resize(nob);
-    if (nob) HIP_TRY(e, hipMemcpy(e->last_obips.data(), e->d.ob_sorted, nob * sizeof(u32), hipMemcpyDeviceToHost));
     sg_stats& st = e->st;
     st.windows++;
     st.last_window_events = e->h_ctr[C_N_EVENTS];
@@ -481,6 +465,36 @@ int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n, const sg_edge
         st.last_window_tmin_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMIN_NS])) / 1000000ull);
         st.last_window_tmax_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMAX_NS])) / 1000000ull);
     } else { st.last_window_tmin_ms = st.last_window_tmax_ms = 0; }
+}
+
+// the page-locked view buffer holds at least E rows (the buffer the previous view pointed into stays alive for one more
+// generation: a caller that still holds the last view — a numpy array over it, a Go slice — reads stale rows, not freed memory)
+int view_reserve(sg_engine* e, size_t E) {
+    if (E <= e->h_rows_cap) return SG_OK;
+    if (e->h_rows_old) { hipHostFree(e->h_rows_old); e->h_rows_old = nullptr; }
+    e->h_rows_old = e->h_rows; e->h_rows = nullptr; e->h_rows_cap = 0;
+    const size_t want = std::min<size_t>(next_pow2(std::max<size_t>(E, 1024)), std::max<size_t>(e->cfg.max_edges, E));
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_rows, want * sizeof(sg_edge_out)));
+    e->h_rows_cap = want;
+    return SG_OK;
+}
+// view != nullptr: the rows go to the engine's page-locked buffer and *view points at them (out / cap unused)
+int do_read(sg_engine* e, sg_edge_out* out, size_t cap, size_t* n, const sg_edge_out** view = nullptr) {
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpy(e->h_ctr, e->d.ctr, sizeof(e->h_ctr), hipMemcpyDeviceToHost));
+    const size_t E = (size_t)e->h_ctr[C_N_EDGES];
+    if (n) *n = E;
+    if (view) {
+        { const int rc = view_reserve(e, E); if (rc) return rc; }
+        if (E) HIP_TRY(e, hipMemcpy(e->h_rows, e->d.rows, E * sizeof(sg_edge_out), hipMemcpyDeviceToHost));
+        *view = e->h_rows;
+    }
+    const size_t take = view ? 0 : std::min(E, cap);
+    if (out && take) HIP_TRY(e, hipMemcpy(out, e->d.rows, take * sizeof(sg_edge_out), hipMemcpyDeviceToHost));
+    const size_t nob = (size_t)e->h_ctr[C_N_OBIP];
+    e->last_obips.resize(nob);
+    if (nob) HIP_TRY(e, hipMemcpy(e->last_obips.data(), e->d.ob_sorted, nob * sizeof(u32), hipMemcpyDeviceToHost));
+    account_window(e);
     return SG_OK;
 }
 
@@ -732,8 +746,12 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         CH(hipStreamSynchronize(e->stream));
         d.l1p_tab = tab;
     }
-    CH(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < kStageSlots; i++) {
+    CH(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking)); CH(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
+    if (const char* v = std::getenv("SG_COPY_STREAMS")) e->n_copy = std::atoi(v) == 2 ? 2 : 1;
+    CH(hipStreamCreateWithFlags(&e->rd_stream, hipStreamNonBlocking)); CH(hipEventCreateWithFlags(&e->score_ev, hipEventDisableTiming));
+    CH(hipHostMalloc((void**)&e->h_ctr_pin, sizeof(e->h_ctr)));
+    if (const char* v = std::getenv("SG_STAGE_SLOTS")) e->n_stage = std::min(kStageSlots, std::max(2, std::atoi(v)));
+    for (int i = 0; i < e->n_stage; i++) {
         CH(hipEventCreateWithFlags(&e->copied_ev[i], hipEventDisableTiming));
         CH(hipHostMalloc((void**)&e->h_stage[i], (size_t)e->cfg.max_batch * sizeof(sg_event)));
         CR(dev_alloc(e, &e->d_stage[i], e->cfg.max_batch));
@@ -771,6 +789,10 @@ int sg_destroy(sg_handle e) {
     for (int i = 0; i < kStageSlots; i++) { if (e->h_stage[i]) hipHostFree(e->h_stage[i]); if (e->stage_ev[i]) hipEventDestroy(e->stage_ev[i]); if (e->copied_ev[i]) hipEventDestroy(e->copied_ev[i]); }
     for (auto& r : e->registered) hipHostUnregister(const_cast<char*>(r.first));
     if (e->copy_stream) hipStreamDestroy(e->copy_stream);
+    if (e->copy_stream2) hipStreamDestroy(e->copy_stream2);
+    if (e->rd_stream) hipStreamDestroy(e->rd_stream);
+    if (e->score_ev) hipEventDestroy(e->score_ev);
+    if (e->h_ctr_pin) hipHostFree(e->h_ctr_pin);
     if (e->h_rows) hipHostFree(e->h_rows);
     if (e->h_rows_old) hipHostFree(e->h_rows_old);
     for (auto& r : e->trecs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -842,18 +864,19 @@ int sg_load_weights(sg_handle e, const float* w, size_t n) {
 namespace {
 // a free staging slot (neither being filled by another feeder nor still in flight), or -1: the ring is full
 int stage_take(sg_engine* e) {
-    for (int k = 0; k < kStageSlots; k++) {
-        const int c = (e->stage_next + k) % kStageSlots;
-        if (!e->stage_busy[c] && hipEventQuery(e->stage_ev[c]) != hipErrorNotReady) { e->stage_busy[c] = true; e->stage_next = (c + 1) % kStageSlots; e->pending_copies++; return c; }
+    for (int k = 0; k < e->n_stage; k++) {
+        const int c = (e->stage_next + k) % e->n_stage;
+        if (!e->stage_busy[c] && hipEventQuery(e->stage_ev[c]) != hipErrorNotReady) { e->stage_busy[c] = true; e->stage_next = (c + 1) % e->n_stage; e->pending_copies++; return c; }
     }
     return -1;
 }
 // host (page-locked) -> device slot on the copy stream, K1 pass A behind it on the window's stream (engine lock held)
 int stage_submit(sg_engine* e, int slot, const sg_event* src, size_t n) {
     int rc = SG_OK;
-    if (hipMemcpyAsync(e->d_stage[slot], src, n * sizeof(sg_event), hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { e->err = "hipMemcpyAsync (staging ring)"; rc = SG_ENODEV; }
+    hipStream_t cs = (e->n_copy == 2 && (e->copy_rr++ & 1)) ? e->copy_stream2 : e->copy_stream;
+    if (hipMemcpyAsync(e->d_stage[slot], src, n * sizeof(sg_event), hipMemcpyHostToDevice, cs) != hipSuccess) { e->err = "hipMemcpyAsync (staging ring)"; rc = SG_ENODEV; }
     if (rc == SG_OK) {
-        hipEventRecord(e->copied_ev[slot], e->copy_stream);
+        hipEventRecord(e->copied_ev[slot], cs);
         hipStreamWaitEvent(e->stream, e->copied_ev[slot], 0);
         e->st.h2d_bytes += n * sizeof(sg_event);
         rc = launch_k1(e, e->d_stage[slot], n, e->stream);
@@ -870,6 +893,7 @@ int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
     std::unique_lock<std::mutex> g(e->mu);
     if (n > e->cfg.max_batch) { e->err = "batch larger than max_batch"; return SG_EINVAL; }
     if (n == 0) return SG_OK;
+    e->cv.wait(g, [&] { return !e->closing; });                          // a window is being closed (microseconds): this batch belongs to the next one
     const int slot = stage_take(e);
     if (slot < 0) {                                                      // ring full: drop, never block
         e->st.events_dropped_ring += n;
@@ -899,6 +923,7 @@ int sg_ingest_pinned(sg_handle e, const sg_event* events, size_t n) {
         for (auto& r : e->registered) ok |= p >= r.first && p + n * sizeof(sg_event) <= r.first + r.second;
         if (!ok) { e->err = "sg_ingest_pinned: the events are not inside memory registered with sg_host_register"; return SG_EINVAL; }
     }
+    e->cv.wait(g, [&] { return !e->closing; });
     const int slot = stage_take(e);
     if (slot < 0) { e->st.events_dropped_ring += n; return SG_EAGAIN; }
     return stage_submit(e, slot, events, n);
@@ -1067,38 +1092,112 @@ int sg_window_reset(sg_handle e, void* stream) {
     return do_reset(e, pick(e, stream));
 }
 
+// ---- closing a window from the host side, in two halves ------------------------------------------------------------------------
+// sg_flush_begin  marks the window boundary: waits for the staging copies that began before it, enqueues K1 pass B .. K5 (with the
+//                 window reset folded into K5) and an asynchronous read of the window counters, and returns.  From here on sg_ingest
+//                 fills the NEXT window: its copies run on the copy stream at once, its pass-A launches queue behind K5.
+// sg_flush_end*   waits for K5 and fetches the rows on the read stream WITHOUT the engine lock — PCIe is full duplex, the rows go
+//                 out while the next window's events come in.  (One call doing both held the lock for ~0.55 ms of kernels + 1.1 ms
+//                 of copy per C3 window: every feeder thread stood still for a quarter of the window period.)
+// sg_flush_window / sg_flush_window_view = begin + end, for callers with one thread.
+namespace {
+int flush_begin_locked(sg_engine* e, std::unique_lock<std::mutex>& g) {
+    if (e->flush_open) { e->err = "sg_flush_begin: the previous window has not been fetched (sg_flush_end)"; return SG_ESTATE; }
+    e->closing = true;                                                   // later feeders wait instead of slipping batches into the closing window
+    e->cv.wait(g, [&] { return e->pending_copies == 0; });
+    struct Open { sg_engine* e; ~Open() { e->closing = false; e->cv.notify_all(); } } open{e};
+    hipStream_t s = e->stream;
+    int rc;
+    if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
+    if ((rc = do_features(e, s))) return rc;
+    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
+    bool did = false;
+    if ((rc = do_score(e, s, true, true, &did))) return rc;
+    e->fl_rows = e->d.rows; e->fl_ob = e->d.ob_sorted;
+    if (did) {                                                           // the window is open again in stream order: fetch later, unlocked
+        HIP_TRY(e, hipMemcpyAsync(e->h_ctr_pin, e->d.ctr, sizeof(e->h_ctr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipEventRecord(e->score_ev, s));
+        e->closed = false;
+        e->flush_async = true;
+    } else {                                                             // (variant 1: the reset is its own launch and must follow the read)
+        size_t n = 0; const sg_edge_out* v = nullptr;
+        if ((rc = do_read(e, nullptr, 0, &n, &v))) return rc;
+        if ((rc = do_reset(e, s))) return rc;
+        e->flush_async = false;
+    }
+    e->flush_open = true;
+    return SG_OK;
+}
+// out != nullptr: up to cap rows into caller memory; view != nullptr: all rows into the page-locked view buffer
+int flush_end_unlocked(sg_engine* e, std::unique_lock<std::mutex>& g, sg_edge_out* out, size_t cap, size_t* n, const sg_edge_out** view) {
+    if (!e->flush_open) { e->err = "sg_flush_end without sg_flush_begin"; return SG_ESTATE; }
+    if (!e->flush_async) {                                               // already read (under the lock, by begin) into the view buffer
+        const size_t E = (size_t)e->h_ctr[C_N_EDGES];
+        if (n) *n = E;
+        if (view) *view = e->h_rows;
+        if (out && E && cap) std::memcpy(out, e->h_rows, std::min(E, cap) * sizeof(sg_edge_out));
+        e->flush_open = false; e->cv.notify_all();
+        return SG_OK;
+    }
+    const sg_edge_out* d_rows = e->fl_rows; const u32* d_ob = e->fl_ob;
+    g.unlock();
+    int rc = SG_OK; std::string err;
+    std::vector<u32> obips;
+    size_t E = 0;
+    do {
+        if (hipEventSynchronize(e->score_ev) != hipSuccess) { err = "hipEventSynchronize (window pipeline)"; rc = SG_ENODEV; break; }
+        E = (size_t)e->h_ctr_pin[C_N_EDGES];
+        const size_t nob = (size_t)e->h_ctr_pin[C_N_OBIP];
+        sg_edge_out* dst = out; size_t take = std::min(E, cap);
+        if (view) { g.lock(); rc = view_reserve(e, E); g.unlock(); if (rc) break; dst = e->h_rows; take = E; }
+        if (dst && take && hipMemcpyAsync(dst, d_rows, take * sizeof(sg_edge_out), hipMemcpyDeviceToHost, e->rd_stream) != hipSuccess) { err = "hipMemcpyAsync (rows)"; rc = SG_ENODEV; break; }
+        obips.resize(nob);
+        if (nob && hipMemcpyAsync(obips.data(), d_ob, nob * sizeof(u32), hipMemcpyDeviceToHost, e->rd_stream) != hipSuccess) { err = "hipMemcpyAsync (outbound ips)"; rc = SG_ENODEV; break; }
+        if (hipStreamSynchronize(e->rd_stream) != hipSuccess) { err = "hipStreamSynchronize (read stream)"; rc = SG_ENODEV; break; }
+    } while (0);
+    g.lock();
+    e->flush_open = false; e->cv.notify_all();
+    if (rc) { if (!err.empty()) e->err = err; return rc; }
+    std::memcpy(e->h_ctr, e->h_ctr_pin, sizeof(e->h_ctr));
+    e->last_obips.swap(obips);
+    account_window(e);
+    if (n) *n = E;
+    if (view) *view = e->h_rows;
+    return SG_OK;
+}
+}  // namespace
+
+int sg_flush_begin(sg_handle e, uint64_t window_end_ms) {
+    (void)window_end_ms;
+    if (!e) return SG_EINVAL;
+    std::unique_lock<std::mutex> g(e->mu);
+    return flush_begin_locked(e, g);
+}
+int sg_flush_end(sg_handle e, sg_edge_out* out, size_t cap, size_t* n) {
+    if (!e) return SG_EINVAL;
+    std::unique_lock<std::mutex> g(e->mu);
+    return flush_end_unlocked(e, g, out, cap, n, nullptr);
+}
+int sg_flush_end_view(sg_handle e, const sg_edge_out** rows, size_t* n) {
+    if (!e || !rows) return SG_EINVAL;
+    std::unique_lock<std::mutex> g(e->mu);
+    return flush_end_unlocked(e, g, nullptr, 0, n, rows);
+}
 int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_t cap, size_t* n) {
     (void)window_end_ms;
     if (!e) return SG_EINVAL;
     std::unique_lock<std::mutex> g(e->mu);
-    e->cv.wait(g, [&] { return e->pending_copies == 0; });
-    hipStream_t s = e->stream;
-    int rc;
-    if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
-    if ((rc = do_features(e, s))) return rc;
-    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
-    bool did = false;
-    if ((rc = do_score(e, s, true, true, &did))) return rc;
-    if ((rc = do_read(e, out, cap, n))) return rc;
-    if (did) { e->closed = false; return SG_OK; }
-    return do_reset(e, s);
+    e->cv.wait(g, [&] { return !e->flush_open; });                       // (another thread's begin .. end pair)
+    if (const int rc = flush_begin_locked(e, g)) return rc;
+    return flush_end_unlocked(e, g, out, cap, n, nullptr);
 }
-
 int sg_flush_window_view(sg_handle e, uint64_t window_end_ms, const sg_edge_out** rows, size_t* n) {
     (void)window_end_ms;
     if (!e || !rows) return SG_EINVAL;
     std::unique_lock<std::mutex> g(e->mu);
-    e->cv.wait(g, [&] { return e->pending_copies == 0; });
-    hipStream_t s = e->stream;
-    int rc;
-    if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
-    if ((rc = do_features(e, s))) return rc;
-    for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
-    bool did = false;
-    if ((rc = do_score(e, s, true, true, &did))) return rc;
-    if ((rc = do_read(e, nullptr, 0, n, rows))) return rc;
-    if (did) { e->closed = false; return SG_OK; }
-    return do_reset(e, s);
+    e->cv.wait(g, [&] { return !e->flush_open; });
+    if (const int rc = flush_begin_locked(e, g)) return rc;
+    return flush_end_unlocked(e, g, nullptr, 0, n, rows);
 }
 
 // enqueue-only variant of the whole window pipeline (no read-back, no host sync): what bench.py times.

@@ -56,6 +56,8 @@ __device__ __forceinline__ bool table_slot(u64* keys, u32 mask, u64 key, u64 emp
 // (A __shfl_xor chain is six dependent ds_bpermute round trips per value: seven values per wave at
 // the end of k1a_partition cost ~1.5 us that way.)
 template <int CTRL> __device__ __forceinline__ u32 dpp32(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+// (bound_ctrl:1 — no lane of these controls reads out of bounds, but it tells the compiler the old value is dead: no v_mov 0 + hazard nops per use)
+template <int CTRL> __device__ __forceinline__ u32 dpp32b(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
 template <int CTRL> __device__ __forceinline__ u64 dpp64(u64 v) { return (u64)dpp32<CTRL>((u32)v) | ((u64)dpp32<CTRL>((u32)(v >> 32)) << 32); }
 __device__ __forceinline__ u32 rdlane32(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ u64 rdlane64(u64 v, int l) { return (u64)rdlane32((u32)v, l) | ((u64)rdlane32((u32)(v >> 32), l) << 32); }
@@ -1289,6 +1291,100 @@ __device__ __forceinline__ void k2_row_wg(const Dev& d, const EdgeEmitArgs& ea, 
     }
     __syncthreads();
 }
+// One SG_MEAN_BLOCK-edge block of a row of more than K2_SPLIT_ROW edges (the hub work items k2_rowptr lists for k4_gather serve the
+// row sort too): the workgroup builds the row's whole node bitmap (the keys are 8 bytes an edge, eight loads per thread in
+// flight), but gathers, ranks and emits only its own block — a 3 750-edge row is eight workgroups x ~3 round trips instead of
+// one workgroup x ~12 (such rows were the tail of the launch: ~20 us each, two or three in a row for an unlucky workgroup).
+// The row's out-statistics are integer sums: every block adds its share with device atomics (st_sum / st_max are zero since
+// the window reset); k3_in_reduce, two launches later, turns the totals into ST_OUT_DEG / row_mu / row_sd (k2_split_finish).
+// (A "last block finishes the row" ticket needs a release / acquire fence per block: on this chip that is an L2 write-back —
+// buffer_wbl2 — and ~600 of them made the launch 40 us SLOWER than the unsplit row sort.)
+#define K2_SPLIT_ROW 1024
+// how many hub work items the row sort may use: all of them, when the whole list was recorded and a node bitmap fits the LDS arrays
+__device__ __forceinline__ u32 k2_split_items(const Dev& d) {
+    const u32 BW = ((u32)d.ctr[C_N_NODES] + 31) >> 5;
+    return (d.ctr[C_HUB_ITEMS] <= d.hub_cap && BW <= K2_SORT_LDS && !(d.ablate & 0x800u)) ? (u32)d.ctr[C_HUB_ITEMS] : 0u;
+}
+__device__ __forceinline__ void k2_split_finish(const Dev& d, u32 tid, u32 nt) {
+    const u32 H = k2_split_items(d);
+    for (u32 it = tid; it < H; it += nt) {
+        const uint2 x = d.hub_items[it];
+        if (x.y != 0) continue;
+        const u32 b = d.rowptr[x.x]; u32 m = d.rowptr[x.x + 1] - b;
+        if (m <= K2_SPLIT_ROW) continue;
+        if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
+        u64* t = d.st_sum + (size_t)x.x * SG_NODE_STAT_SUM_WORDS;
+        const u64 tc = t[ST_OUT_CNT], ts = t[ST_OUT_SUM], tq = t[ST_OUT_SSQ];
+        t[ST_OUT_DEG] = m;
+        d.row_mu[x.x] = mean_us(ts, tc); d.row_sd[x.x] = std_us(ts, tq, tc);
+    }
+}
+__device__ __forceinline__ void k2_row_block(const Dev& d, const EdgeEmitArgs& ea, const u32 rr, const u32 blk, u32* sk, u32* sv, u64 (*red)[4], u32* bsum, const u32 BW) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 b = d.rowptr[rr];
+    u32 m = d.rowptr[rr + 1] - b;
+    if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
+    const uint2* in = d.cs + b; u32* key = d.col + b;
+    u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
+    const u32 e0 = blk * SG_MEAN_BLOCK;
+    if (e0 < m) {                                                    // (uniform)
+        for (u32 w = threadIdx.x; w < BW; w += 256) sk[w] = 0;
+        __syncthreads();
+        for (u32 i0 = 0; i0 < m; i0 += 2048) {
+            u32 k8[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const u32 i = i0 + threadIdx.x + q * 256; k8[q] = in[i < m ? i : m - 1].x; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (i0 + threadIdx.x + q * 256 < m) atomicOr(&sk[k8[q] >> 5], 1u << (k8[q] & 31));
+        }
+        constexpr int QB = SG_MEAN_BLOCK / 256;
+        u32 mk[QB], mv[QB]; ulonglong2 ax[QB], ay[QB];
+#pragma unroll
+        for (int q = 0; q < QB; q++) {                               // this block's elements and their accumulators: in flight across the scan
+            const u32 i = e0 + threadIdx.x + q * 256;
+            const uint2 kv = in[i < m ? i : m - 1]; mk[q] = kv.x; mv[q] = kv.y;
+        }
+#pragma unroll
+        for (int q = 0; q < QB; q++) {
+            if (e0 + threadIdx.x + q * 256 < m) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q] * 4); ax[q] = a[0]; ay[q] = a[1]; }
+            else { ax[q] = make_ulonglong2(0, 0); ay[q] = make_ulonglong2(0, 0); }
+        }
+        __syncthreads();
+        {   // sv[w] = number of set bits in words [0, w)
+            const u32 per = (BW + 255) / 256, w0 = threadIdx.x * per < BW ? threadIdx.x * per : BW, w1 = w0 + per < BW ? w0 + per : BW;
+            u32 c = 0;
+            for (u32 w = w0; w < w1; w++) c += __popc(sk[w]);
+            u32 tot;
+            u32 run = block_excl_scan<256>(c, bsum, &tot);
+            for (u32 w = w0; w < w1; w++) { sv[w] = run; run += __popc(sk[w]); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < QB; q++) if (e0 + threadIdx.x + q * 256 < m) {
+            const u32 k = mk[q], r = sv[k >> 5] + __popc(sk[k >> 5] & ((1u << (k & 31)) - 1u));
+            key[r] = k;
+            edge_emit(ea, b + r, rr, mv[q], 0, 0, 0, ax[q], ay[q]);
+            cnt += ax[q].x & 0xFFFFFFFFull; err += ax[q].x >> 32; sum += ax[q].y; ssq += ay[q].y; mx = ay[q].x > mx ? ay[q].x : mx;
+        }
+        cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+        if (lane == 0) { red[0][wave] = cnt; red[1][wave] = err; red[2][wave] = sum; red[3][wave] = ssq; red[4][wave] = mx; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
+        if (e0 < m) {
+            cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+            mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
+            if (cnt) atomicAdd(&t[ST_OUT_CNT], cnt);
+            if (err) atomicAdd(&t[ST_OUT_ERR], err);
+            if (sum) atomicAdd(&t[ST_OUT_SUM], sum);
+            if (ssq) atomicAdd(&t[ST_OUT_SSQ], ssq);
+            if (mx) atomicMax(&d.st_max[(size_t)rr * 2], mx);
+        }
+    }
+    __syncthreads();
+}
 // One row of 65 .. K2_WAVE_ROW edges sorted by one wave, no barrier: the destinations of a row are distinct node ids < N, so
 // setting bit `to` in an N-bit bitmap and counting the bits below it IS the sorted position.  bm / pf: the wave's private
 // BW-word bitmap and word-prefix arrays (LDS operations of one wave execute in order).
@@ -1354,6 +1450,12 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 nlw = gridDim.x > 2 * K2_LONG_WGS ? K2_LONG_WGS : (gridDim.x / 2 ? gridDim.x / 2 : 1);   // host launches >= 2 workgroups
     if (blockIdx.x < nlw) {
         const bool wave_ok = BW <= K2_WAVE_BW && !(d.ablate & 0x400u);
+        // rows of more than K2_SPLIT_ROW edges first, a workgroup per 512-edge block (when the whole list was recorded and the bitmap fits)
+        const u32 H = k2_split_items(d);
+        for (u32 it = blockIdx.x; it < H; it += nlw) {
+            const uint2 x = d.hub_items[it];
+            if (d.rowptr[x.x + 1] - d.rowptr[x.x] > K2_SPLIT_ROW) k2_row_block(d, ea, x.x, x.y, sk, sv, red, bsum, BW);   // (uniform)
+        }
         for (u32 l0 = blockIdx.x * 4; l0 < nlong; l0 += nlw * 4) {
             const u32 li = l0 + wave;
             u32 big = SG_NONE;
@@ -1361,7 +1463,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                 const u32 rr = d.longrows[li];
                 const u32 m = d.rowptr[rr + 1] - d.rowptr[rr];
                 if (wave_ok && m <= K2_WAVE_ROW) k2_row_wave(d, ea, rr, sk + wave * K2_WAVE_BW, sv + wave * K2_WAVE_BW, BW);
-                else big = rr;
+                else if (!(H && m > K2_SPLIT_ROW)) big = rr;
             }
             if (lane == 0) bigrow[wave] = big;
             __syncthreads();
@@ -1450,15 +1552,25 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
     for (u32 i = t; i < nr * 6; i += 1024) acc[i] = 0;
     __syncthreads();
     const u32 per = (E + S - 1) / S, p0 = sl * per < E ? sl * per : E, p1 = p0 + per < E ? p0 + per : E;
-    for (u32 pb = p0 + t; pb < p1; pb += 1024 * 4) {              // 4 edges per thread in flight
-        u32 to[4];
+    // Eight edges per thread and trip; the destinations of the NEXT trip are fetched behind this trip's accumulator loads, so a
+    // trip costs one round trip, not two (a slice of C3 is 31 k edges: four trips; at four edges per trip and no lookahead the
+    // sixteen dependent round trips were most of this kernel's 22 us).
+    constexpr int K3Q = 8;
+    u32 nxt[K3Q];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const u32 p = pb + q * 1024; to[q] = p < p1 ? d.col[p] - n0 : 0xFFFFFFFFu; }
-        ulonglong2 x[4], y[4];
+    for (int q = 0; q < K3Q; q++) { const u32 p = p0 + t + q * 1024; nxt[q] = p < p1 ? d.col[p] - n0 : 0xFFFFFFFFu; }
+    for (u32 pb = p0 + t; pb < p1; pb += 1024 * K3Q) {
+        u32 to[K3Q];
+        ulonglong2 x[K3Q], y[K3Q];
 #pragma unroll
-        for (int q = 0; q < 4; q++) if (to[q] < nr) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)(pb + q * 1024) * 4); x[q] = a[0]; y[q] = a[1]; }
+        for (int q = 0; q < K3Q; q++) {
+            to[q] = nxt[q];
+            if (to[q] < nr) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)(pb + q * 1024) * 4); x[q] = a[0]; y[q] = a[1]; }
+        }
 #pragma unroll
-        for (int q = 0; q < 4; q++) if (to[q] < nr) {
+        for (int q = 0; q < K3Q; q++) { const u32 p = pb + 1024 * K3Q + q * 1024; nxt[q] = p < p1 ? d.col[p] - n0 : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int q = 0; q < K3Q; q++) if (to[q] < nr) {
             u64* o = acc + (size_t)to[q] * 6;
             atomicAdd(&o[0], 1ull); atomicAdd(&o[1], x[q].x & 0xFFFFFFFFull); if (x[q].x >> 32) atomicAdd(&o[2], x[q].x >> 32);
             atomicAdd(&o[3], x[q].y); atomicAdd(&o[4], y[q].y); atomicMax(&o[5], y[q].x);
@@ -1470,13 +1582,32 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
 }
 __global__ __launch_bounds__(256) void k3_in_reduce(Dev d, u32 S) {
     const u32 N = (u32)d.ctr[C_N_NODES];
+    k2_split_finish(d, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);   // the out-statistics of the rows the row sort took block by block
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < (u64)N * 6; i += (u64)gridDim.x * 256) {
         const u32 v = (u32)(i / 6), k = (u32)(i % 6), r = v / K3_IN_NR;
         const u64* p = d.in_part + ((size_t)r * S * K3_IN_NR + (v - r * K3_IN_NR)) * 6 + k;
+        const size_t st = (size_t)K3_IN_NR * 6;
         u64 a = 0;
-        if (k == 5) { for (u32 sl = 0; sl < S; sl++) { const u64 x = p[(size_t)sl * K3_IN_NR * 6]; a = x > a ? x : a; } d.st_max[(size_t)v * 2 + 1] = a; }
-        else {
-            for (u32 sl = 0; sl < S; sl++) a += p[(size_t)sl * K3_IN_NR * 6];
+        u32 sl = 0;
+        if (k == 5) {
+            for (; sl + 8 <= S; sl += 8) {                           // eight independent loads in flight
+                u64 x[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) x[q] = p[(size_t)(sl + q) * st];
+#pragma unroll
+                for (int q = 0; q < 8; q++) a = x[q] > a ? x[q] : a;
+            }
+            for (; sl < S; sl++) { const u64 x = p[(size_t)sl * st]; a = x > a ? x : a; }
+            d.st_max[(size_t)v * 2 + 1] = a;
+        } else {
+            for (; sl + 8 <= S; sl += 8) {
+                u64 x[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) x[q] = p[(size_t)(sl + q) * st];
+#pragma unroll
+                for (int q = 0; q < 8; q++) a += x[q];
+            }
+            for (; sl < S; sl++) a += p[(size_t)sl * st];
             d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + (k == 0 ? ST_IN_DEG : k == 1 ? ST_IN_CNT : k == 2 ? ST_IN_ERR : k == 3 ? ST_IN_SUM : ST_IN_SSQ)] = a;
         }
     }
@@ -1995,10 +2126,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         for (int k = 0; k < (int)SG_F_EDGE; k++) we[k][m] = We[k * SG_F_HID + q + 16 * m];
     }
     // Two steps of four edges per iteration, and the endpoints of the NEXT iteration's edges are fetched while this one's
-    // rows are gathered: the dependent chain per iteration is one round trip (the gathers), not two (ids, then gathers),
-    // with four 16-byte gathers per lane in flight instead of two.
-    auto step = [&](const float4 P4, const float4 Q4, const float4 e0, const float4 e1) -> float {
-        const float ek[SG_F_EDGE] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    // rows are gathered: the dependent chain per iteration is one round trip (the gathers), not two (ids, then gathers).
+    // What the 16 lanes of a group need in common is loaded ONCE per group and spread with DPP row_newbcast (a v_mov per value):
+    // the two edges' feature vectors are one dword per lane (lanes 0..7 edge A's e_0..e_7, lanes 8..15 edge B's) instead of four
+    // 16-byte loads that return the same 32 bytes to all sixteen lanes, the four endpoint ids one dword in lanes 0..3 instead of
+    // four loads — 9 memory instructions and 5.5 KiB returned per wave and iteration instead of 15 and 10 KiB (the kernel is
+    // bound by the vector-memory pipe, not by HBM: P and Q are L2-resident).
+    auto step = [&](const float4 P4, const float4 Q4, const float (&ek)[SG_F_EDGE]) -> float {
         const float pq[4] = {P4.x + Q4.x, P4.y + Q4.y, P4.z + Q4.z, P4.w + Q4.w};
         float r[4];
 #pragma unroll
@@ -2014,6 +2148,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         sum = sum + xor_partner_f32(sum, 2); sum = sum + xor_partner_f32(sum, 1);
         return sum;                                                  // (every lane of the 16 holds it)
     };
+    static_assert(SG_F_EDGE == 8, "k5_edge_score spreads two 8-float edge feature vectors over a DPP row of 16 lanes");
+    const u32* __restrict__ idsrc = (q & 1u) ? d.col : d.csr_from;   // lane q & 3 of a group: from(A), to(A), from(B), to(B)
     // The ROWS of an iteration's eight edges are written by the whole wave: 8 x 64 bytes = 64 lanes x 8 bytes, lane l holds
     // 8-byte word l % 8 of edge l / 8 — one fully coalesced store per iteration instead of four 16-byte stores from one lane in
     // sixteen per step (whose ~100 instructions of row assembly ran with 4 of 64 lanes active).
@@ -2028,22 +2164,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     if (E) {
         const u32 stride = nw * 8, last = E - 1;
         u32 pa = wave * 8 + g, pb = pa + 4;                          // this iteration's two edges of the lane group (clamped when beyond E)
-        u32 ua = d.csr_from[pa < E ? pa : last], va = d.col[pa < E ? pa : last], ub = d.csr_from[pb < E ? pb : last], vb = d.col[pb < E ? pb : last];
+        u32 idw;
+        { const u32 px = (q & 2u) ? pb : pa; idw = idsrc[px < E ? px : last]; }
         for (u32 p0 = wave * 8; p0 < E; p0 += stride) {
+            u32 ua = dpp32b<0x150>(idw), va = dpp32b<0x151>(idw), ub = dpp32b<0x152>(idw), vb = dpp32b<0x153>(idw);
+            if (d.ablate & 0x1000u) { ua &= 15u; va &= 15u; ub &= 15u; vb &= 15u; }   // (diagnostic: gathers that hit the L1)
             const u32 ca = pa < E ? pa : last, cb = pb < E ? pb : last;
             const float4 PA = reinterpret_cast<const float4*>(d.P + (size_t)ua * SG_F_HID)[q], QA = reinterpret_cast<const float4*>(d.Q + (size_t)va * SG_F_HID)[q];
             const float4 PB = reinterpret_cast<const float4*>(d.P + (size_t)ub * SG_F_HID)[q], QB = reinterpret_cast<const float4*>(d.Q + (size_t)vb * SG_F_HID)[q];
-            const float4 ea0 = reinterpret_cast<const float4*>(d.efeat + (size_t)ca * SG_F_EDGE)[0], ea1 = reinterpret_cast<const float4*>(d.efeat + (size_t)ca * SG_F_EDGE)[1];
-            const float4 eb0 = reinterpret_cast<const float4*>(d.efeat + (size_t)cb * SG_F_EDGE)[0], eb1 = reinterpret_cast<const float4*>(d.efeat + (size_t)cb * SG_F_EDGE)[1];
+            const u32 ew = __float_as_uint(d.efeat[(size_t)(q < 8 ? ca : cb) * SG_F_EDGE + (q & 7u)]);
             // what this lane's row word is made of: fetched now, beside the gathers
             const u32 er = p0 + we8, ec = er < E ? er : last;
             const u64 wacc = d.acc_csr[(size_t)ec * 4 + accj];
             const u32 wa = srcA[ec], wb = srcB[ec];
             // next iteration's endpoints: behind the gathers in issue order, so waiting for the gathers does not wait for them
             const u32 na = pa + stride, nb = pb + stride;
-            const u32 ua_n = d.csr_from[na < E ? na : last], va_n = d.col[na < E ? na : last], ub_n = d.csr_from[nb < E ? nb : last], vb_n = d.col[nb < E ? nb : last];
-            const float sa = step(PA, QA, ea0, ea1);
-            const float sb = step(PB, QB, eb0, eb1);
+            { const u32 px = (q & 2u) ? nb : na; idw = idsrc[px < E ? px : last]; }
+            const float eka[SG_F_EDGE] = {__uint_as_float(dpp32b<0x150>(ew)), __uint_as_float(dpp32b<0x151>(ew)), __uint_as_float(dpp32b<0x152>(ew)), __uint_as_float(dpp32b<0x153>(ew)),
+                                          __uint_as_float(dpp32b<0x154>(ew)), __uint_as_float(dpp32b<0x155>(ew)), __uint_as_float(dpp32b<0x156>(ew)), __uint_as_float(dpp32b<0x157>(ew))};
+            const float ekb[SG_F_EDGE] = {__uint_as_float(dpp32b<0x158>(ew)), __uint_as_float(dpp32b<0x159>(ew)), __uint_as_float(dpp32b<0x15A>(ew)), __uint_as_float(dpp32b<0x15B>(ew)),
+                                          __uint_as_float(dpp32b<0x15C>(ew)), __uint_as_float(dpp32b<0x15D>(ew)), __uint_as_float(dpp32b<0x15E>(ew)), __uint_as_float(dpp32b<0x15F>(ew))};
+            const float sa = step(PA, QA, eka);
+            const float sb = step(PB, QB, ekb);
             const float mysum = __shfl(q < 8 ? sa : sb, srcl, 64);     // ONE shuffle executed by all lanes (two under a select were sunk into exec-masked
                                                                        // branches by the compiler: ds_bpermute returns 0 for an inactive source lane)
             u64 val = wacc;                                          // words 0..2 and 4
@@ -2071,8 +2213,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                     }
                 }
             }
-            if (er < E) reinterpret_cast<u64*>(d.rows)[(size_t)er * 8 + wk] = val;
-            pa = na; pb = nb; ua = ua_n; va = va_n; ub = ub_n; vb = vb_n;
+            if (er < E && !(d.ablate & 0x2000u)) reinterpret_cast<u64*>(d.rows)[(size_t)er * 8 + wk] = val;
+            pa = na; pb = nb;
         }
     }
     if (RESET) {

@@ -26,7 +26,7 @@ REF_KNOWN, REF_LABEL, REF_OBIP = 0, 1, 2
 EXPORTS = [
     "sg_abi_version", "sg_weights_count", "sg_hash32", "sg_last_error", "sg_create", "sg_destroy",
     "sg_upsert_pod", "sg_delete_pod", "sg_upsert_service", "sg_delete_service", "sg_set_clock",
-    "sg_set_label_count", "sg_load_weights", "sg_ingest", "sg_ingest_device", "sg_flush_window", "sg_flush_window_view",
+    "sg_set_label_count", "sg_load_weights", "sg_ingest", "sg_ingest_device", "sg_flush_window", "sg_flush_window_view", "sg_flush_begin", "sg_flush_end", "sg_flush_end_view",
     "sg_window_run", "sg_window_rows_buffer", "sg_window_close", "sg_window_obip_list",
     "sg_window_close_sharded", "sg_bind_buffers", "sg_window_features", "sg_window_layer", "sg_window_score", "sg_window_score_reset",
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
@@ -109,6 +109,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_ingest": (C.c_int, [H, P, sz]), "sg_ingest_device": (C.c_int, [H, P, sz, P]),
         "sg_flush_window": (C.c_int, [H, u64, P, sz, C.POINTER(sz)]),
         "sg_flush_window_view": (C.c_int, [H, u64, C.POINTER(C.c_void_p), C.POINTER(sz)]),
+        "sg_flush_begin": (C.c_int, [H, u64]),
+        "sg_flush_end": (C.c_int, [H, C.c_void_p, sz, C.POINTER(sz)]),
+        "sg_flush_end_view": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(sz)]),
         "sg_window_run": (C.c_int, [H, P]), "sg_window_rows_buffer": (C.c_int, [H, C.POINTER(P)]),
         "sg_window_close": (C.c_int, [H, P]),
         "sg_window_obip_list": (C.c_int, [H, P, u32, P, P]),
@@ -192,6 +195,7 @@ class ServiceGraph:
         self._h = h
         self.layers = layers
         self.max_edges = max_edges
+        self.max_batch = max_batch
         self.rank, self.world = rank, world
 
     # ---- plumbing ----
@@ -275,6 +279,27 @@ class ServiceGraph:
         flush_window / flush_window_view / window_read on this engine."""
         ptr = C.c_void_p(); n = C.c_size_t(0)
         self._ck(self._l.sg_flush_window_view(self._h, window_end_ms, C.byref(ptr), C.byref(n)))
+        return self._rows_view(ptr, n)
+
+    def flush_begin(self, window_end_ms: int = 0):
+        """Close the window and enqueue its pipeline (sg_flush_begin); ingest calls from here on fill the next window."""
+        self._ck(self._l.sg_flush_begin(self._h, window_end_ms))
+
+    def flush_end_view(self) -> np.ndarray:
+        """The rows of the window flush_begin closed, as flush_window_view returns them (any thread; the engine lock is not held
+        while the rows are fetched)."""
+        ptr = C.c_void_p(); n = C.c_size_t(0)
+        self._ck(self._l.sg_flush_end_view(self._h, C.byref(ptr), C.byref(n)))
+        return self._rows_view(ptr, n)
+
+    def flush_end(self, cap: int | None = None) -> np.ndarray:
+        cap = self.max_edges if cap is None else cap
+        out = np.zeros(cap, dtype=EDGE_OUT_DTYPE); n = C.c_size_t(0)
+        self._ck(self._l.sg_flush_end(self._h, out.ctypes.data, cap, C.byref(n)))
+        return out[: min(n.value, cap)]
+
+    @staticmethod
+    def _rows_view(ptr, n) -> np.ndarray:
         if n.value == 0:
             z = np.zeros(0, dtype=EDGE_OUT_DTYPE); z.flags.writeable = False
             return z

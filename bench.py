@@ -302,7 +302,7 @@ def _engine_for(a, topo, labels, c, device, windows, engine, weights):
     L = c["layers"]
     big = a.config == 5
     g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * (1.1 if big else 1.25)) + 4096, layers=L,
-                            max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=1 << 18,
+                            max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=int(os.environ.get("SG_BENCH_MAX_BATCH", 1 << 18)),
                             max_window_events=c["events"], windows_in_flight=windows)
     g.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
     g.load_weights(weights.make_weights(L))
@@ -447,47 +447,78 @@ def bench_single(a, device):
     return res
 
 
-def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False):
-    """`feeders` host threads split every window's events and call sg_ingest (copy into the pinned staging ring, H2D on the copy
-    stream, K1a behind it) concurrently; when all have returned, sg_flush_window_view closes the window and leaves the scored
-    rows in page-locked host memory.  pinned: the events sit in memory registered with sg_host_register and go in through
-    sg_ingest_pinned — no staging copy, the H2D reads the caller's buffer."""
+def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False, serial=False):
+    """The host feed as the aggregator drives it: `feeders` threads push ONE continuous stream of events through sg_ingest (copy into
+    the pinned staging ring, H2D on the copy stream, K1a behind it) while the closer marks a window boundary every Ev events
+    (sg_flush_begin: K1b..K5 enqueued) and a fetcher brings the scored rows back (sg_flush_end_view) — beside the next window's
+    feed, over the other direction of the link.  A boundary falls wherever the stream is when the closer looks (within `feeders`
+    batches of Ev events): every event lands in exactly one window, every window's rows are fetched, and the clock stops when the
+    last rows are readable on the host.  pinned: the events sit in memory registered with sg_host_register and go in through
+    sg_ingest_pinned.  serial: every feeder stops at the boundary and sg_flush_window_view does the close in one call (round 2)."""
     import torch
-    chunk = 1 << 18
-    nwin = 3 if Ev >= 5_000_000 else 10
-    retries = [0]
+    chunk = g.max_batch
+    nwin = 4 if Ev >= 5_000_000 else 10
+    retries = [0] * feeders
     if pinned:
         g.host_register(ev_all)
-
-    def feed(part):                                          # sg_ingest_bulk: the feeder's whole share in one C call (the GIL is released);
-        retries[0] += g.ingest_bulk(part, pinned=pinned)     # a full ring is waited for here — production (sg_ingest) would drop and count
+    nchunks_w = -(-Ev // chunk)                              # batches per window
+    total_chunks = nchunks_w * nwin
+    def chunk_of(j):                                         # batch j of the stream: windows cycle through the nb host-resident traces
+        w, c = divmod(j, nchunks_w)
+        base = (w % nb) * Ev
+        return ev_all[base + c * chunk: base + min(Ev, (c + 1) * chunk)]
+    done = [0] * feeders                                     # events each feeder has handed over
+    rows_seen, ev_seen = [], []
     torch.cuda.synchronize()
-    rows_n = 0
     t0 = time.perf_counter()
-    for wdx in range(nwin):
-        b = ev_all[(wdx % nb) * Ev:((wdx % nb) + 1) * Ev]
-        per = -(-Ev // feeders); per = -(-per // chunk) * chunk
-        ths = [threading.Thread(target=feed, args=(b[k * per:(k + 1) * per],)) for k in range(feeders) if k * per < Ev]
+    if serial:
+        for wdx in range(nwin):
+            def feed(k, wdx=wdx):
+                for c in range(k, nchunks_w, feeders): retries[k] += g.ingest_bulk(chunk_of(wdx * nchunks_w + c), pinned=pinned)
+            ths = [threading.Thread(target=feed, args=(k,)) for k in range(feeders)]
+            for t in ths: t.start()
+            for t in ths: t.join()
+            rows_seen.append(len(g.flush_window_view()))
+    else:
+        def feed(k):                                         # sg_ingest_bulk waits for a staging slot instead of dropping (production: drop + count)
+            for j in range(k, total_chunks, feeders):
+                p = chunk_of(j)
+                retries[k] += g.ingest_bulk(p, pinned=pinned)
+                done[k] += len(p)
+        ths = [threading.Thread(target=feed, args=(k,)) for k in range(feeders)]
         for t in ths: t.start()
-        for t in ths: t.join()
-        rows_n = len(g.flush_window_view())              # rows readable in the engine's page-locked host buffer (no copy into pageable memory)
+        fetch = None
+        def fetch_rows(): rows_seen.append(len(g.flush_end_view()))   # rows readable in the engine's page-locked host buffer
+        for wdx in range(nwin):
+            goal = Ev * (wdx + 1)
+            while sum(done) < goal and any(t.is_alive() for t in ths): time.sleep(0.0001)
+            if wdx == nwin - 1:
+                for t in ths: t.join()
+            if fetch: fetch.join()
+            g.flush_begin()                                  # the boundary: what has been handed over so far is this window
+            fetch = threading.Thread(target=fetch_rows); fetch.start()
+        fetch.join()
     dt = time.perf_counter() - t0
+    rows_n = int(sum(rows_seen) / max(1, len(rows_seen)))
+    assert int(g.stats().events_dropped_ring) == 0
     # what the link itself does on this box: pinned 256 MiB copies, best of 3 (the bound the figure above is held against)
     hp = torch.empty(256 << 20, dtype=torch.uint8).pin_memory(); dv = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     h2d = d2h = 0.0
     for _ in range(3):
         torch.cuda.synchronize(); t1 = time.perf_counter(); dv.copy_(hp, non_blocking=True); torch.cuda.synchronize(); h2d = max(h2d, (256 << 20) / (time.perf_counter() - t1) / 1e9)
         torch.cuda.synchronize(); t1 = time.perf_counter(); hp.copy_(dv, non_blocking=True); torch.cuda.synchronize(); d2h = max(d2h, (256 << 20) / (time.perf_counter() - t1) / 1e9)
-    link_ms = (32.0 * Ev / h2d + 64.0 * E / d2h) / 1e6
+    link_ms = (32.0 * Ev / h2d + 64.0 * E / d2h) / 1e6       # the bound of rounds 1-2: both transfers of a window, one after the other
+    duplex_ms = max(32.0 * Ev / h2d, 64.0 * E / d2h) / 1e6   # if the two directions of the link did not disturb each other at all
     if pinned:
         g.host_unregister(ev_all)
     return {"entry_point": "sg_ingest_pinned (events in registered page-locked memory, no staging copy)" if pinned else "sg_ingest (pageable caller memory, copied into the pinned staging ring)",
             "events_per_s": Ev * nwin / dt, "ms_per_window": dt / nwin * 1e3, "windows": nwin, "feeders": feeders,
             "pcie_measured_GBs": {"h2d": round(h2d, 1), "d2h": round(d2h, 1)}, "pcie_bound_ms_per_window": round(link_ms, 3),
             "frac_of_pcie_bound": round(link_ms / (dt / nwin * 1e3), 3),
-            "includes": ([] if pinned else ["memcpy into pinned staging ring"]) + ["h2d (own stream, overlapping K1a of the previous batch)", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows into page-locked host memory (sg_flush_window_view)", "window reset"],
-            "rows_per_window": rows_n, "ring_full_retries": retries[0],
-            "bound": f"PCIe: 32 B/event host->device + 64 B/edge device->host ({(32.0 * Ev + 64.0 * E) / 1e6:.0f} MB per window)"}
+            "pcie_duplex_ms_per_window": round(duplex_ms, 3), "frac_of_duplex_bound": round(duplex_ms / (dt / nwin * 1e3), 3),
+            "includes": ([] if pinned else ["memcpy into pinned staging ring"]) + ["h2d (own stream, overlapping K1a of the previous batch)", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows into page-locked host memory (sg_flush_begin / sg_flush_end_view: beside the next window's feed)", "window reset"],
+            "rows_per_window": rows_n, "rows_by_window": rows_seen, "ring_full_retries": int(sum(retries)),
+            "bound": f"PCIe: 32 B/event host->device + 64 B/edge device->host ({(32.0 * Ev + 64.0 * E) / 1e6:.0f} MB per window) at the measured one-direction rates; duplex = the larger of the two alone (measured: the H2D slows down while the D2H runs)"}
 
 
 if __name__ == "__main__":

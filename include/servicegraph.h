@@ -270,6 +270,17 @@ int sg_flush_window(sg_handle h, uint64_t window_end_ms, sg_edge_out* out, size_
  * (a Go shim building its payload, GraphDS::FlushWindow): a pageable 64 MB destination costs more than the transfer. */
 int sg_flush_window_view(sg_handle h, uint64_t window_end_ms, const sg_edge_out** rows, size_t* n);
 
+/* The window close in two halves, for hosts whose feeders keep running (the aggregator's worker goroutines do): sg_flush_begin
+ * marks the window boundary — it waits for the staging copies that began before it (at most one batch copy per feeder; sg_ingest
+ * calls that arrive meanwhile wait that long too, then belong to the NEXT window), enqueues K1 pass B .. K5 and returns.
+ * sg_flush_end / sg_flush_end_view wait for the pipeline and fetch the rows without holding the engine lock, on a stream of
+ * their own: the rows leave over PCIe while the next window's events arrive (full duplex), and no feeder stands still for the
+ * ~1.7 ms a C3 window's kernels + copy-out take.  One begin may be open at a time (SG_ESTATE otherwise); any thread may call
+ * the end.  sg_flush_window / sg_flush_window_view are exactly begin + end.                                                   */
+int sg_flush_begin(sg_handle h, uint64_t window_end_ms);
+int sg_flush_end(sg_handle h, sg_edge_out* out, size_t cap, size_t* n);
+int sg_flush_end_view(sg_handle h, const sg_edge_out** rows, size_t* n);
+
 /* Enqueue-only form of the same pipeline (K2..K5 + reset, no copy-out, no host sync) for
  * callers that keep results on the device (sg_window_rows_buffer) or time the pipeline.         */
 int sg_window_run(sg_handle h, void* stream);

@@ -210,6 +210,43 @@ def test_k4_gather_launch_equals_the_fused_layer_bitwise():
     assert out[0].tobytes() == out[1].tobytes()
 
 
+def test_row_sort_by_blocks_equals_the_one_workgroup_row_sort_and_the_oracle():
+    """Rows of more than 1024 edges are sorted a 512-edge block per workgroup (k2_row_block: every block ranks against the whole
+    row's node bitmap, the row's out-statistics are summed with atomics and the last block derives row_mu / row_sd).  Against
+    the single-workgroup row sort (SG_ABLATE bit 0x800) every row must be bit-identical, and against the oracle exact /
+    within tolerance — on rows of 3599, 2100, 1025 and 1024 edges next to short ones, with error and duration tails."""
+    topo = replay.make_topology(2400, 30_000, seed=71)
+    ev, labels = replay.make_events(topo, 300_000, seed=72)
+    ev = ev.copy()
+    everyone = np.concatenate([topo.svc_ips, topo.pod_ips])
+    at = 0
+    for hub, n in ((5, 3599), (6, 2100), (7, 1025), (8, 1024)):
+        dst = everyone[everyone != topo.pod_ips[hub]][:n]
+        ev["saddr"][at:at + n] = topo.pod_ips[hub]; ev["daddr"][at:at + n] = dst; ev["host_label"][at:at + n] = 0; ev["flags"][at:at + n] = 0
+        at += n
+    out = []
+    for ablate in ("0x800", None):
+        if ablate: os.environ["SG_ABLATE"] = ablate
+        try:
+            g = _engine(topo.n_nodes + 8, 1 << 16, 2, max_window_events=len(ev))
+            shim = HostShim(); shim.apply(g, topo.k8s_ops())
+            for i in range(0, len(ev), 1 << 17):
+                assert g.ingest(ev[i:i + (1 << 17)]) == 0
+            g.set_label_count(len(labels))
+            out.append(g.flush_window().copy())
+            obips = g.outbound_ips()
+            g.close()
+        finally:
+            os.environ.pop("SG_ABLATE", None)
+    from collections import Counter
+    deg = Counter(out[1]["from_ref"].tolist())
+    top = sorted(deg.values())[-4:]
+    assert top[-1] >= 3599 and top[-2] >= 2100 and top[0] >= 1024 and min(deg.values()) < 64, top
+    assert out[0].tobytes() == out[1].tobytes()
+    o = _oracle(topo.k8s_ops(), 2); o.packed(ev, labels); o.window_close(weights.make_weights(2), 2)
+    compare_edge_dicts(engine_edge_dict(out[1], shim, labels, obips), o.edge_dict())
+
+
 def test_flush_window_view_returns_the_same_rows_without_the_copy():
     """sg_flush_window_view: the rows of the window in the engine's page-locked buffer must be the rows sg_flush_window
     copies out — for a window, an empty window, and a larger one after it (the buffer grows); many feeder threads at once
@@ -237,6 +274,61 @@ def test_flush_window_view_returns_the_same_rows_without_the_copy():
         assert len(v) == len(c) and v.tobytes() == c.tobytes()
         assert not v.flags.writeable
     assert a.stats().events_dropped_cap == 0
+
+
+def test_flush_begin_end_overlaps_the_next_windows_feed_without_mixing_windows():
+    """sg_flush_begin marks the window boundary and returns with the pipeline enqueued; sg_flush_end_view fetches the rows
+    without the engine lock while feeder threads already fill the next window.  Three windows fed that way (the fetch of
+    window i running beside the feed of window i + 1, six feeder threads) must be byte for byte the rows of an engine that
+    closes one window at a time — no batch slips across a boundary, no row is fetched late; also: the copy-out form
+    (sg_flush_end), begin twice = SG_ESTATE, end without begin = SG_ESTATE, and sg_flush_window still works afterwards."""
+    import threading
+    from alaz_amd import engine
+    topo = replay.make_topology(400, 20_000, seed=91)
+    ev, labels = replay.make_events(topo, 900_000, seed=92, mixed=True, with_raw_outbound=True)
+    a = _engine(topo.n_nodes + 8, 1 << 15, 2, max_window_events=400_000, max_batch=1 << 14)
+    b = _engine(topo.n_nodes + 8, 1 << 15, 2, max_window_events=400_000, max_batch=1 << 14)
+    for g in (a, b):
+        HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
+    with pytest.raises(engine.ServiceGraphError) as ei:
+        a.flush_end_view()
+    assert ei.value.rc == engine.SG_ESTATE
+
+    def feed(g, e, threads):
+        parts = np.array_split(np.arange(0, len(e), 1 << 14), threads)
+        def run(idx):
+            for i in idx:
+                while g.ingest(e[i:i + (1 << 14)]) != 0:
+                    pass
+        ths = [threading.Thread(target=run, args=(p,)) for p in parts]
+        for t in ths: t.start()
+        for t in ths: t.join()
+    wins = [ev[0:300_000], ev[300_000:650_000], ev[650_000:900_000]]
+    want = []
+    for w in wins:
+        feed(b, w, 1); want.append(b.flush_window().copy())
+    got = []
+    fetch = None
+    def fetch_rows(): got.append(a.flush_end_view().copy())
+    for w in wins:
+        feed(a, w, 6)
+        if fetch: fetch.join()
+        a.flush_begin()
+        with pytest.raises(engine.ServiceGraphError) as ei:
+            a.flush_begin()
+        assert ei.value.rc == engine.SG_ESTATE
+        fetch = threading.Thread(target=fetch_rows); fetch.start()
+    fetch.join()
+    assert len(got) == 3
+    for x, y in zip(got, want):
+        assert len(x) == len(y) > 10_000 and x.tobytes() == y.tobytes()
+    assert a.stats().windows == 3 and a.stats().events_dropped_cap == 0
+    # the copying end, then the one-call close: same rows again
+    feed(a, wins[0], 3); a.flush_begin(); r = a.flush_end()
+    assert r.tobytes() == want[0].tobytes()
+    feed(a, wins[1], 3)
+    assert a.flush_window_view().tobytes() == want[1].tobytes()
+    a.close(); b.close()
 
 
 def test_device_resident_ingest_and_staged_pipeline():
@@ -1018,4 +1110,32 @@ def test_ingest_pinned_reads_registered_caller_memory_without_the_staging_copy()
     o = _oracle(topo.k8s_ops(), 2); o.packed(ev, labels); o.window_close(weights.make_weights(2), 2)
     compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
     assert g.stats().last_window_events == o.window_events
+    g.close()
+
+
+def test_histogram_engine_at_config3_geometry_with_many_ip_blocks():
+    """with SG_CFG_EDGE_HISTOGRAM the 16-byte pass A has 72-byte cache slots; at a C3-sized edge capacity
+    (4096 partitions) and more than ~90 populated /24 blocks, level 2 of the join no longer fits LDS and the fallback used to ask
+    for more than a CU's 160 KiB — every sg_ingest failed with SG_ENODEV.  The geometry now takes the largest cache that fits:
+    ingest works, nothing is dropped, rows and bins equal the oracle."""
+    topo = replay.make_topology(600, 9000, seed=5151)
+    # one /24 block per pod and per service: 900 level-2 blocks (900 KiB of level 2: far beyond LDS)
+    pod_ips = (0x0A000000 + np.arange(topo.n_pods) * 256 + 7).astype(np.uint32)
+    svc_ips = (0xAC100000 + np.arange(topo.n_svcs) * 256 + 9).astype(np.uint32)
+    topo = replay.Topology(topo.n_pods, topo.n_svcs, pod_ips, svc_ips, topo.edge_src, topo.edge_dst, topo.seed)
+    ev, labels = replay.make_events(topo, 200_000, seed=5152, mixed=True)
+    g = _engine(topo.n_nodes + 8, 1_300_000, 1, max_window_events=len(ev) + 1, edge_histogram=True, max_batch=1 << 16,
+                max_ips=32_768)                                         # room for 1024 /24 blocks (the engine allows max_ips / 32)
+    geo = g.geometry()
+    assert geo["k1_narrow"] == 0 and geo["partitions"] >= 2048          # the histogram rides the 16-byte kernels
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    for i in range(0, len(ev), 1 << 16):
+        assert g.ingest(ev[i:i + (1 << 16)]) == 0, g.geometry()
+    assert g.geometry()["join_l2_in_lds"] == 0                          # 900 blocks: level 2 is read from global memory
+    g.set_label_count(len(labels))
+    rows = g.flush_window()
+    hist = g.window_hist()
+    o = _oracle(topo.k8s_ops(), 1); o.packed(ev, labels); o.window_close(weights.make_weights(1), 1)
+    compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict(), percentiles=True)
+    assert np.array_equal(hist, o.edge_hist()) and g.stats().events_dropped_cap == 0
     g.close()
