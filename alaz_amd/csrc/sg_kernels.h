@@ -1057,11 +1057,24 @@ __global__ __launch_bounds__(256) void k2_scatter_table(Dev d) {
 }
 __global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
     const u32 p = blockIdx.x, n = d.part_n[p];
-    for (u32 i = threadIdx.x; i < n; i += 256) {
-        const u32 slot = p * d.pcap + i;
-        const u32 f = d.e_from[slot];
-        const u64 pos = (u64)d.rowptr[f] + d.deg[SG_DEG_IDX(f, p & (SG_DEG_REP - 1))] + d.e_rank[slot];   // row + replica offset + arrival order
-        if (pos < d.max_edges) d.cs[pos] = make_uint2(d.e_to[slot], slot);     // (one scattered 8-byte write: the cost is per write request, not per byte)
+    // four edges per thread and trip: their loads (source, then row start + replica offset) are in flight together — one edge per
+    // trip was two dependent round trips for each of a partition's ~4 edges per thread
+    for (u32 i0 = threadIdx.x; i0 < n; i0 += 1024) {
+        u32 f[4], to[4], rk[4], slot[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 i = i0 + 256u * q;
+            slot[q] = p * d.pcap + (i < n ? i : i0);
+            f[q] = d.e_from[slot[q]]; to[q] = d.e_to[slot[q]]; rk[q] = d.e_rank[slot[q]];
+        }
+        u32 rp[4], dg[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { rp[q] = d.rowptr[f[q]]; dg[q] = d.deg[SG_DEG_IDX(f[q], p & (SG_DEG_REP - 1))]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 pos = (u64)rp[q] + dg[q] + rk[q];              // row + replica offset + arrival order
+            if (i0 + 256u * q < n && pos < d.max_edges) d.cs[pos] = make_uint2(to[q], slot[q]);   // (one scattered 8-byte write: the cost is per write request, not per byte)
+        }
     }
 }
 

@@ -247,6 +247,31 @@ def test_row_sort_by_blocks_equals_the_one_workgroup_row_sort_and_the_oracle():
     compare_edge_dicts(engine_edge_dict(out[1], shim, labels, obips), o.edge_dict())
 
 
+def test_pass_b_second_long_requests_beside_ordinary_ones():
+    """K1 pass B merges the 8-byte records with 32-bit LDS atomics on the low words of count / max and 64-bit ones on the sums, the
+    wide records (durations beyond 2^32 ns) afterwards with 64-bit ones into the same slots.  A quarter of the requests take
+    seconds (0xDC000000 ns: 1.36e13 us^2 each, sums far beyond 2^32), a few are beyond 2^32 ns, fed in 18 batches so that cache
+    aggregates, single records and wide records meet in one table: every accumulator must equal the oracle's."""
+    topo = replay.make_topology(200, 3000, seed=301)
+    ev, labels = replay.make_events(topo, 120_000, seed=302)
+    ev = ev.copy()
+    rng = np.random.default_rng(303)
+    hot = rng.choice(len(ev), 30_000, replace=False)
+    ev["duration_ns"][hot] = rng.choice(np.array([0xDC000000, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 65_537_000], dtype=np.uint64), len(hot))
+    ev["duration_ns"][rng.choice(len(ev), 300, replace=False)] = (1 << 33) + 12345
+    g = _engine(topo.n_nodes + 8, 8192, 1, max_window_events=len(ev))
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    for i in range(0, len(ev), 7001):
+        assert g.ingest(ev[i:i + 7001]) == 0
+    g.set_label_count(len(labels))
+    assert g.geometry()["k1_narrow"] == 1
+    rows = g.flush_window()
+    assert int(rows["sum_ns"].max()) > (1 << 36) and int(rows["sumsq_us"].max()) > (1 << 46)
+    o = _oracle(topo.k8s_ops(), 1); o.packed(ev, labels); o.window_close(weights.make_weights(1), 1)
+    compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
+    g.close()
+
+
 def test_flush_window_view_returns_the_same_rows_without_the_copy():
     """sg_flush_window_view: the rows of the window in the engine's page-locked buffer must be the rows sg_flush_window
     copies out — for a window, an empty window, and a larger one after it (the buffer grows); many feeder threads at once

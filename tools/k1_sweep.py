@@ -50,7 +50,7 @@ for var in variants:
     for i in range(4):
         g.ingest_device(dev[i % nb].data_ptr(), Ev, 0); g.window_run(0)
     torch.cuda.synchronize(); g.timing_enable(0)
-    grp = {k: round(g.timing(k)[0], 1) for k in range(2, 6)}
+    grp = {k: round(g.timing(k)[0] * g.timing(k)[1] / 4, 1) for k in (2, 8, 3, 4, 5)}      # us per window (a group may have several records)
     g.ingest_device(dev[0].data_ptr(), Ev, 0); torch.cuda.synchronize()
     rows = g.flush_window(); st = g.stats()
     E = int(st.last_window_edges)

@@ -40,6 +40,10 @@ for kid, kname in zip((0, 1), g.k1_kernels()):
         if nm == "-": continue
         col = (a[:, k] - t0) / 100.0
         print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
+    st_, en_ = (a[:, 0] - t0) / 100.0, (a[:, len(names[kid]) - 1] - t0) / 100.0
+    print("  start percentiles 10/25/50/75/90:", np.round(np.percentile(st_, [10, 25, 50, 75, 90]), 1), " duration percentiles:", np.round(np.percentile(en_ - st_, [10, 50, 90]), 1))
+    ts = np.arange(0, en_.max(), 10.0)
+    print("  workgroups running at t =", {int(t): int(((st_ <= t) & (en_ > t)).sum()) for t in ts})
 if st[2][:, 0].max() > 0:                                            # narrow pass A: wave 0's accumulated clock ticks per phase (kernel slot 2)
     a = st[2].astype(np.int64); a = a[a[:, 0] != 0]
     for k, nm in enumerate(("P1 fold", "barrier-1 wait", "P2 scan", "P3 drop", "barrier-3 wait", "P4 copy-out")):
