@@ -1005,12 +1005,19 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     }
     __syncthreads();
     const u32 base = pre;
-    // 4. publish
+    // 4. publish.  Row starts are CLAMPED to the edge capacity: when a window holds more distinct edges than max_edges (counted:
+    // C_DROPPED_CAP below), the rows behind the capacity are empty and the row across it is cut — every consumer of rowptr
+    // (row sort, gather, in-statistics, alive marks) then stays inside the max_edges-sized arrays without clamping of its own.
+    // (Unclamped, K4's gather walked d.col up to E_found: with 10 M events of ten different traces in one C2-sized window that
+    // was a GPU memory fault.)
+    const u64 s0u = (u64)base + run, s1u = s0u + (t < K2_RP_ROWS ? rdeg[t] : 0u);
+    const u32 s0 = (u32)(s0u < d.max_edges ? s0u : d.max_edges), s1 = (u32)(s1u < d.max_edges ? s1u : d.max_edges);
+    const u32 dgc = s1 - s0;                                         // the row's edges inside the capacity
     if (t < K2_RP_ROWS && r0 + t < N) {
-        d.rowptr[r0 + t] = base + run;
-        if (dg > 64) atomicAdd(&nlong, 1u);
-        if (dg > SG_MEAN_BLOCK) {                                    // a hub row: one work item per 512-neighbour block (k4_gather spreads them over the chip)
-            const u32 nblk = (dg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
+        d.rowptr[r0 + t] = s0;
+        if (dgc > 64) atomicAdd(&nlong, 1u);
+        if (dgc > SG_MEAN_BLOCK) {                                   // a hub row: one work item per 512-neighbour block (k4_gather spreads them over the chip)
+            const u32 nblk = (dgc + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
             const u32 ib = (u32)atomicAdd(&d.ctr[C_HUB_ITEMS], (u64)nblk);   // C_HUB_ITEMS is zeroed by kc_prepare
             d.hub_base[r0 + t] = ib;
             for (u32 j = 0; j < nblk; j++) if (ib + j < d.hub_cap) d.hub_items[ib + j] = make_uint2(r0 + t, j);
@@ -1023,7 +1030,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
         __shared__ u32 lpos;
         if (t == 0) lpos = 0;
         __syncthreads();
-        if (t < K2_RP_ROWS && r0 + t < N && dg > 64) d.longrows[lbase + atomicAdd(&lpos, 1u)] = r0 + t;
+        if (t < K2_RP_ROWS && r0 + t < N && dgc > 64) d.longrows[lbase + atomicAdd(&lpos, 1u)] = r0 + t;
     }
     if (t == 0) {
         if (b == 0) {
@@ -1032,7 +1039,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
         }
         if (r0 + K2_RP_ROWS >= N) {                                    // the workgroup of the last row knows E
             const u32 E = base + total;
-            d.rowptr[N] = E;
+            d.rowptr[N] = (u64)E < d.max_edges ? E : (u32)d.max_edges;
             d.ctr[C_N_EDGES] = (u64)E < d.max_edges ? E : d.max_edges;
             if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = E; if ((u64)E > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)E - d.max_edges; }
         }

@@ -431,10 +431,11 @@ def bench_single(a, device):
         g2.close()
     # events accepted by sg_ingest from HOST memory until their window's rows are readable on the host
     if not a.no_end_to_end and not a.profile_mode:
-        res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E)
+        which = os.environ.get("SG_BENCH_E2E", "both")
+        res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E) if which != "pinned" else {}
         # the same out of caller memory page-locked with sg_host_register (no staging copy).  Measured SLOWER on these boxes: the H2D
         # engine reads hipHostRegister'ed memory at ~40 GB/s against 57 GB/s for the hipHostMalloc'ed staging ring
-        res["end_to_end"]["registered_memory"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E, pinned=True)
+        if which != "pageable": res["end_to_end"]["registered_memory"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E, pinned=True)
     if cpu is not None:
         res["cpu_baseline"] = cpu
     g.close()
@@ -448,12 +449,11 @@ def bench_single(a, device):
 
 
 def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False, serial=False):
-    """The host feed as the aggregator drives it: `feeders` threads push ONE continuous stream of events through sg_ingest (copy into
-    the pinned staging ring, H2D on the copy stream, K1a behind it) while the closer marks a window boundary every Ev events
-    (sg_flush_begin: K1b..K5 enqueued) and a fetcher brings the scored rows back (sg_flush_end_view) — beside the next window's
-    feed, over the other direction of the link.  A boundary falls wherever the stream is when the closer looks (within `feeders`
-    batches of Ev events): every event lands in exactly one window, every window's rows are fetched, and the clock stops when the
-    last rows are readable on the host.  pinned: the events sit in memory registered with sg_host_register and go in through
+    """The host feed as the aggregator drives it: `feeders` threads push the events of window after window through sg_ingest (copy into
+    the pinned staging ring, H2D on the copy stream, K1a behind it); when a window's Ev events are in, the closer marks the
+    boundary (sg_flush_begin: K1b..K5 enqueued), the feeders go on with the next window at once and a fetcher brings the scored
+    rows back (sg_flush_end_view) beside that feed, over the other direction of the link.  Every window holds exactly its own
+    events; the clock stops when the last window's rows are readable on the host.  pinned: the events sit in memory registered with sg_host_register and go in through
     sg_ingest_pinned.  serial: every feeder stops at the boundary and sg_flush_window_view does the close in one call (round 2)."""
     import torch
     chunk = g.max_batch
@@ -480,23 +480,26 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False, serial=False):
             for t in ths: t.join()
             rows_seen.append(len(g.flush_window_view()))
     else:
+        closed = [0]                                         # windows whose boundary has been marked (sg_flush_begin returned)
+        done_w = [[0] * feeders for _ in range(nwin)]        # events handed over, per window and feeder
         def feed(k):                                         # sg_ingest_bulk waits for a staging slot instead of dropping (production: drop + count)
             for j in range(k, total_chunks, feeders):
+                wj = j // nchunks_w
+                while closed[0] < wj: time.sleep(0.00005)    # a window's events go in after the previous boundary, never before
                 p = chunk_of(j)
                 retries[k] += g.ingest_bulk(p, pinned=pinned)
-                done[k] += len(p)
+                done_w[wj][k] += len(p)
         ths = [threading.Thread(target=feed, args=(k,)) for k in range(feeders)]
         for t in ths: t.start()
         fetch = None
         def fetch_rows(): rows_seen.append(len(g.flush_end_view()))   # rows readable in the engine's page-locked host buffer
         for wdx in range(nwin):
-            goal = Ev * (wdx + 1)
-            while sum(done) < goal and any(t.is_alive() for t in ths): time.sleep(0.0001)
-            if wdx == nwin - 1:
-                for t in ths: t.join()
+            while sum(done_w[wdx]) < Ev: time.sleep(0.00005)
             if fetch: fetch.join()
-            g.flush_begin()                                  # the boundary: what has been handed over so far is this window
-            fetch = threading.Thread(target=fetch_rows); fetch.start()
+            g.flush_begin()                                  # the boundary; the feeders go on with the next window at once,
+            closed[0] = wdx + 1
+            fetch = threading.Thread(target=fetch_rows); fetch.start()   # its rows come back over the other direction of the link meanwhile
+        for t in ths: t.join()
         fetch.join()
     dt = time.perf_counter() - t0
     rows_n = int(sum(rows_seen) / max(1, len(rows_seen)))

@@ -415,6 +415,40 @@ def test_capacity_overflow_is_counted_not_silent():
     assert len(g.flush_window()) <= 10
 
 
+@pytest.mark.parametrize("pods,edges,events,cap", [(1000, 50_000, 600_000, 8192), (2000, 300_000, 1_500_000, 140_000)])
+def test_edge_capacity_overflow_many_times_over_is_counted_and_stays_in_bounds(pods, edges, events, cap):
+    """A window with several times more distinct edges than max_edges (variant 0: pass B finds them all, the CSR holds max_edges):
+    k2_rowptr publishes row starts clamped to the capacity, so the rows behind it are empty for every later kernel.  (Unclamped,
+    the SAGE gather walked the column array up to the number of edges FOUND — a GPU memory fault when bench.py's feeders put ten
+    traces into one C2-sized window.)  Both K4 forms (fused below 2^17 edge slots, gather + dense above) and a hub row across
+    the boundary; the engine must report max_edges rows, count the rest, keep every row a distinct edge with its own events,
+    and start the next window clean (checked against the oracle)."""
+    topo = replay.make_topology(pods, edges, seed=401)
+    ev, labels = replay.make_events(topo, events, seed=402)
+    ev = ev.copy()
+    hub = topo.pod_ips[pods // 2]                                   # a row of N - 1 edges somewhere in the middle of the id space
+    dst = np.concatenate([topo.svc_ips, topo.pod_ips[topo.pod_ips != hub]])
+    ev["saddr"][:len(dst)] = hub; ev["daddr"][:len(dst)] = dst; ev["host_label"][:len(dst)] = 0; ev["flags"][:len(dst)] = 0
+    g = _engine(topo.n_nodes + 8, cap, 2, max_window_events=len(ev), max_batch=1 << 18)
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    for i in range(0, len(ev), 1 << 18):
+        assert g.ingest(ev[i:i + (1 << 18)]) == 0
+    g.set_label_count(len(labels))
+    rows = g.flush_window()
+    st = g.stats()
+    assert len(rows) == cap and st.events_dropped_cap > 0 and st.last_window_edges == cap
+    pairs = rows["from_ref"].astype(np.uint64) << np.uint64(32) | rows["to_ref"].astype(np.uint64)
+    assert len(np.unique(pairs)) == cap                                                       # every row a distinct edge
+    assert int(rows["count"].sum()) + int(st.events_dropped_cap) <= len(ev) and np.isfinite(rows["score"]).all()
+    # the next window is an ordinary one
+    small = ev[len(dst):len(dst) + 3000]
+    assert g.ingest(small) == 0
+    rows2 = g.flush_window()
+    o = _oracle(topo.k8s_ops(), 2); o.packed(small, labels); o.window_close(weights.make_weights(2), 2)
+    compare_edge_dicts(engine_edge_dict(rows2, shim, labels, g.outbound_ips()), o.edge_dict())
+    g.close()
+
+
 def test_partitioned_k1_overflow_paths_are_exact_or_counted():
     """Variant 0 with deliberately tiny slab pieces (max_window_events far below the real load):
     records spill into the overflow list and the result must still be bit-exact; when even that

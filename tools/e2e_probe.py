@@ -10,7 +10,7 @@ from alaz_amd import engine, replay, weights
 
 cfgno = int(sys.argv[1]); variants = sys.argv[2:] or ["8/pageable/overlap"]
 c = replay.CONFIGS[cfgno]; seed = replay.SEED_BASE + cfgno
-Ev = c["events"]; nb = 2
+Ev = c["events"]; nb = int(os.environ.get("PROBE_NB", "2"))
 topo = replay.make_topology(c["pods"], c["edges"], seed)
 ev_all, labels = replay.make_events(topo, Ev * nb, seed)
 a = types.SimpleNamespace(config=cfgno)
