@@ -1027,7 +1027,8 @@ int sg_halo_build_padded(sg_handle e, uint32_t* d_req, uint32_t capp, void* stre
     hipStream_t s = pick(e, stream);
     Timed t(e, s, 6);
     hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
-    hipLaunchKernelGGL(k6_halo_build_padded, dim3(1), dim3(1024), 0, s, e->d, d_req, capp);
+    if (e->d.ncap <= K6_FLAGS_LDS) hipLaunchKernelGGL(k6_halo_build_padded<true>, dim3(1), dim3(1024), 0, s, e->d, d_req, capp);
+    else hipLaunchKernelGGL(k6_halo_build_padded<false>, dim3(1), dim3(1024), 0, s, e->d, d_req, capp);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
@@ -1245,7 +1246,8 @@ int st_features(void* p) { SCX; return do_features(e, s); }
 int st_halo_build(void* p) {
     SCX; Timed t(e, s, 6);
     hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
-    hipLaunchKernelGGL(k6_halo_build_padded, dim3(1), dim3(1024), 0, s, e->d, e->xc.req, e->xc.capp);
+    if (e->d.ncap <= K6_FLAGS_LDS) hipLaunchKernelGGL(k6_halo_build_padded<true>, dim3(1), dim3(1024), 0, s, e->d, e->xc.req, e->xc.capp);
+    else hipLaunchKernelGGL(k6_halo_build_padded<false>, dim3(1), dim3(1024), 0, s, e->d, e->xc.req, e->xc.capp);
     return hipGetLastError() == hipSuccess ? SG_OK : SG_ENODEV;
 }
 int st_layer(void* p, uint32_t l) { SCX; return do_layer(e, l, s, false); }
@@ -1370,7 +1372,8 @@ int sg_halo_build(sg_handle e, uint32_t* d_ids, uint32_t cap, uint32_t* d_counts
     hipStream_t s = pick(e, stream);
     Timed t(e, s, 6);
     hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
-    hipLaunchKernelGGL(k6_active_lists, dim3(1), dim3(1024), 0, s, e->d);
+    if (e->d.ncap <= K6_FLAGS_LDS) hipLaunchKernelGGL(k6_active_lists<true>, dim3(1), dim3(1024), 0, s, e->d);
+    else hipLaunchKernelGGL(k6_active_lists<false>, dim3(1), dim3(1024), 0, s, e->d);
     hipLaunchKernelGGL(k6_halo_build, dim3(1), dim3(256), 0, s, e->d, d_ids, cap, d_counts);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;

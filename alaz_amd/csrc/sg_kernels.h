@@ -2334,9 +2334,119 @@ __device__ __forceinline__ u32 node_flags(const Dev& d, u32 v, u32 nk, u32 nl) {
 //   req[k]: halo nodes owned by shard k (k < 8), ascending — every shard builds the same lists
 // Flags are first staged in LDS with coalesced loads (thread t, nodes t, t + 1024, ...); the ordered passes
 // then give thread t the contiguous chunk [beg, end) so that thread order is ascending node order.
+// The staged form (N <= K6_FLAGS_LDS, every map so far): ordered compaction by WAVES, not by threads.  Wave w owns the contiguous node
+// block [w * per_w, (w + 1) * per_w) and walks it 64 nodes a step; a list's position of node v = the wave's base (one exchange of
+// the sixteen waves' totals through LDS) + the members in the wave's earlier steps + the members among the lower lanes of this
+// step (ballot + popcount) — ascending by construction, the 64 lanes of a step write adjacent entries, and the only barriers are
+// the one behind the flag staging and the pair around the totals.  (A thread per contiguous 15-node chunk — the form below, kept
+// for maps beyond the LDS staging — was fifteen serial rounds of scattered 4-byte stores per list: 53 us of a C4 shard's window.)
+template <bool REQ>
+__device__ __forceinline__ void build_lists_staged(const Dev& d, u32* req, u32 capp, unsigned char* fl, u32* wsum) {
+    constexpr bool want_req = REQ;
+    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    const u32 W = d.world < 8 ? d.world : 8;
+    // the flags of eight nodes per thread and trip, every load of the trip issued before any of them is used: node_flags() has a
+    // branch (the owner is only computed for halo candidates) behind which the compiler parks the next node's loads — one node
+    // after the other was two dependent round trips x 15 nodes per thread, most of this kernel's 45-50 us
+    const u32 nkl = nk + nl, nobs = N > nkl ? N - nkl : 0u;
+    for (u32 v0 = threadIdx.x; v0 < N; v0 += 8192) {
+        u32 cur[8], r0[8], r1[8], obi[8]; u64 od[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const u32 v = v0 + q * 1024 < N ? v0 + q * 1024 : N - 1;
+            cur[q] = d.cursor[v]; r0[q] = d.rowptr[v]; r1[q] = d.rowptr[v + 1];
+            od[q] = d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG];
+            obi[q] = nobs ? d.ob_sorted[v >= nkl ? v - nkl : 0u] : 0u;         // (only used for an outbound-ip node)
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const u32 v = v0 + q * 1024;
+            if (v >= N) continue;
+            const bool dst = cur[q] == 0xFFFFFFFFu, src = r1[q] != r0[q], has_out = od[q] != 0;
+            u32 f = (dst ? 1u : 0u) | (src ? 2u : 0u) | (has_out ? 4u : 0u);
+            const u32 o = (v < nkl ? owner_hash_ref(ref_of_dense(v, nk, nl)) : owner_hash_obip(obi[q])) % d.world;   // = owner_of_dense(v)
+            if (dst && has_out && o != d.rank) f |= (o + 1) << 3;
+            fl[v] = (unsigned char)f;
+        }
+    }
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 lt = (1ull << lane) - 1ull;
+    const u32 per_w = ((N + 1023) / 1024) * 64;                      // nodes per wave: a multiple of 64
+    const u32 wb = wave * per_w < N ? wave * per_w : N, we = wb + per_w < N ? wb + per_w : N;
+    constexpr int NL = REQ ? 10 : 2;                                 // (compile-time everywhere: a runtime bound would put the arrays into scratch)
+    u32 cnt[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) cnt[j] = 0;
+    for (u32 b = wb; b < we; b += 64) {                              // (uniform per wave)
+        const u32 v = b + lane;
+        const u32 f = v < we ? fl[v] : 0u;
+        cnt[0] += (u32)__popcll(__ballot(((f & 2u) || ((f & 1u) && !(f & 4u))) ? 1 : 0));
+        cnt[1] += (u32)__popcll(__ballot((f & 3u) ? 1 : 0));
+        if (REQ) {
+            const u32 o = f >> 3;
+#pragma unroll
+            for (int k = 0; k < 8; k++) cnt[(REQ ? 2 : 0) + (REQ ? k : 0)] += (u32)__popcll(__ballot(o == (u32)k + 1 ? 1 : 0));
+        }
+    }
+    // wave totals -> LDS; thread j < NL turns list j's sixteen totals into exclusive prefixes (in place) and the list total
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) wsum[j * 16 + wave] = cnt[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < (u32)NL) {
+        u32 acc = 0;
+        for (u32 w2 = 0; w2 < 16; w2++) { const u32 x = wsum[threadIdx.x * 16 + w2]; wsum[threadIdx.x * 16 + w2] = acc; acc += x; }
+        wsum[160 + threadIdx.x] = acc;
+    }
+    __syncthreads();
+    u32 run[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) run[j] = wsum[j * 16 + wave];
+    if (threadIdx.x == 0) {
+        d.ctr[C_ACT_L] = wsum[160]; d.ctr[C_ACT_P] = wsum[161];
+        if (REQ) for (u32 k = 0; k < W; k++) {
+            u32 t = wsum[162 + k];
+            if (t > capp) { atomicAdd(&d.ctr[C_HALO_OVF], (u64)(t - capp)); t = capp; }
+            req[(size_t)k * (capp + 1)] = t;
+        }
+    }
+    for (u32 b = wb; b < we; b += 64) {
+        const u32 v = b + lane;
+        const u32 f = v < we ? fl[v] : 0u;
+        {
+            const bool in = (f & 2u) || ((f & 1u) && !(f & 4u));
+            const u64 m = __ballot(in ? 1 : 0);
+            if (in) d.act_l[run[0] + (u32)__popcll(m & lt)] = v;
+            run[0] += (u32)__popcll(m);
+        }
+        {
+            const bool in = (f & 3u) != 0;
+            const u64 m = __ballot(in ? 1 : 0);
+            if (in) d.act_p[run[1] + (u32)__popcll(m & lt)] = v;
+            run[1] += (u32)__popcll(m);
+        }
+        if (REQ) {
+            const u32 o = f >> 3;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                constexpr int J = REQ ? 2 : 0;
+                const bool in = o == (u32)k + 1;
+                const u64 m = __ballot(in ? 1 : 0);
+                if (m) {                                             // (uniform)
+                    const u32 pos = run[J + (REQ ? k : 0)] + (u32)__popcll(m & lt);
+                    if (in && pos < capp) req[(size_t)k * (capp + 1) + 1 + pos] = v;
+                    run[J + (REQ ? k : 0)] += (u32)__popcll(m);
+                }
+            }
+        }
+    }
+}
 __device__ __forceinline__ void build_lists(const Dev& d, u32* req, u32 capp, bool want_req, unsigned char* fl, u32* wsum) {
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const u32 W = d.world < 8 ? d.world : 8;
+    if (N <= K6_FLAGS_LDS && !(d.ablate & 0x20000u)) { if (want_req) build_lists_staged<true>(d, req, capp, fl, wsum); else build_lists_staged<false>(d, req, capp, fl, wsum); return; }   // (uniform)
     const bool staged = N <= K6_FLAGS_LDS;
     if (staged) {
         for (u32 v0 = threadIdx.x; v0 < N; v0 += 4096) {             // four nodes per thread in flight
@@ -2406,18 +2516,23 @@ __device__ __forceinline__ void build_lists(const Dev& d, u32* req, u32 capp, bo
         }
     }
 }
+// SMALL (host: ncap <= K6_FLAGS_LDS, so every window's N is): only the staged, wave-ordered builder is compiled in — the general
+// form keeps ten-element arrays in scratch, and a kernel that one workgroup runs once per window pays for every cold
+// instruction-cache line and for the scratch set-up.
+template <bool SMALL>
 __global__ __launch_bounds__(1024) void k6_active_lists(Dev d) {       // for the unpadded halo API
-    __shared__ u32 wsum[160];
+    __shared__ u32 wsum[176];
     __shared__ unsigned char fl[K6_FLAGS_LDS];
-    build_lists(d, nullptr, 0, false, fl, wsum);
+    if (SMALL) build_lists_staged<false>(d, nullptr, 0, fl, wsum); else build_lists(d, nullptr, 0, false, fl, wsum);
 }
 
 // ---- padded halo exchange (no host synchronisation: fixed-size all-to-all) ----------------------------
 // req / serve layout: [world][capp + 1] u32, element 0 = count, ids follow.
+template <bool SMALL>
 __global__ __launch_bounds__(1024) void k6_halo_build_padded(Dev d, u32* req, u32 capp) {
-    __shared__ u32 wsum[160];
+    __shared__ u32 wsum[176];
     __shared__ unsigned char fl[K6_FLAGS_LDS];
-    build_lists(d, req, capp, true, fl, wsum);
+    if (SMALL) build_lists_staged<true>(d, req, capp, fl, wsum); else build_lists(d, req, capp, true, fl, wsum);
 }
 // rows[r][i][:] = feat[lists[r][1 + i]][:] for i < lists[r][0]   (pack: lists = what shard r asked of me)
 __global__ __launch_bounds__(256) void k6_pack_padded(const float* __restrict__ feat, const u32* __restrict__ lists, u32 capp, u32 world, float* __restrict__ rows) {
