@@ -529,7 +529,7 @@ func (g *GraphDS) IngestHttp2(d *l7_req.L7Event, req *datastore.Request, authori
 // ---- window close ----------------------------------------------------------------------------------------------------
 
 // FlushWindow closes the window: K1 pass B .. K5 on the GPU, rows left in the engine's page-locked host buffer
-// (sg_flush_window_view: valid until the next flush, so they are converted before this returns).
+// (sg_flush_begin + sg_flush_end_view: valid until the next flush, so they are converted before this returns).
 func (g *GraphDS) FlushWindow(windowEndMs int64) ([]EdgeRow, error) {
 	g.flushMu.Lock()
 	defer g.flushMu.Unlock()
@@ -548,10 +548,16 @@ func (g *GraphDS) FlushWindow(windowEndMs int64) ([]EdgeRow, error) {
 	g.retired = nil
 	g.idMu.Unlock()
 
+	// The close in two halves (ABI 3): sg_flush_begin marks the window boundary and returns with K1 pass B .. K5 enqueued;
+	// sg_flush_end_view waits for them and fetches the rows WITHOUT the engine lock, so the worker goroutines' sg_ingest calls
+	// (add -> flushShard) go on while the rows come back — they belong to the next window.
 	var rows *C.sg_edge_out
 	var n C.size_t
-	if rc := C.sg_flush_window_view(g.h, C.uint64_t(windowEndMs), &rows, &n); rc != 0 {
-		return nil, fmt.Errorf("servicegraph: sg_flush_window_view = %d: %s", int(rc), C.GoString(C.sg_last_error(g.h)))
+	if rc := C.sg_flush_begin(g.h, C.uint64_t(windowEndMs)); rc != 0 {
+		return nil, fmt.Errorf("servicegraph: sg_flush_begin = %d: %s", int(rc), C.GoString(C.sg_last_error(g.h)))
+	}
+	if rc := C.sg_flush_end_view(g.h, &rows, &n); rc != 0 {
+		return nil, fmt.Errorf("servicegraph: sg_flush_end_view = %d: %s", int(rc), C.GoString(C.sg_last_error(g.h)))
 	}
 	var nob C.size_t
 	C.sg_window_outbound_ips(g.h, nil, 0, &nob)

@@ -74,6 +74,15 @@ int main(void) {
     CHECK(sg_ingest(h, ev, 3) == SG_OK);
     const sg_edge_out* view = NULL;
     CHECK(sg_flush_window_view(h, 1000, &view, &n) == SG_OK && n == 2 && view != NULL && view[0].count == 2);
+    /* the close in two halves: begin marks the boundary, what is ingested afterwards is the next window's */
+    CHECK(sg_flush_end_view(h, &view, &n) == SG_ESTATE);
+    CHECK(sg_ingest(h, ev, 3) == SG_OK);
+    CHECK(sg_flush_begin(h, 2000) == SG_OK);
+    CHECK(sg_flush_begin(h, 2000) == SG_ESTATE);
+    CHECK(sg_ingest(h, ev + 4, 1) == SG_OK);                                            /* arrives while the window closes: the next one's */
+    CHECK(sg_flush_end_view(h, &view, &n) == SG_OK && n == 2 && view[0].count == 2);
+    CHECK(sg_flush_begin(h, 3000) == SG_OK);
+    CHECK(sg_flush_end(h, rows, 8, &n) == SG_OK && n == 1 && rows[0].count == 1);
     CHECK(sg_destroy(h) == SG_OK);
     printf("abi_client ok\n");
     return 0;
