@@ -1564,6 +1564,7 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 E = (u32)d.ctr[C_N_EDGES], N = (u32)d.ctr[C_N_NODES];
     const u32 G = gridDim.x, g = blockIdx.x, t = threadIdx.x;
+    SG_STAMP(d, 3, 0);
     alive_mark(d, g, G, t);
     const u32 r = g / S, sl = g % S, n0 = r * K3_IN_NR;
     if (n0 >= N) return;
@@ -1571,6 +1572,7 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
     u64* acc = reinterpret_cast<u64*>(smem);                         // [nr][6]: deg, cnt, err, sum, ssq, max
     for (u32 i = t; i < nr * 6; i += 1024) acc[i] = 0;
     __syncthreads();
+    SG_STAMP(d, 3, 1);
     const u32 per = (E + S - 1) / S, p0 = sl * per < E ? sl * per : E, p1 = p0 + per < E ? p0 + per : E;
     // Eight edges per thread and trip; the destinations of the NEXT trip are fetched behind this trip's accumulator loads, so a
     // trip costs one round trip, not two (a slice of C3 is 31 k edges: four trips; at four edges per trip and no lookahead the
@@ -1596,9 +1598,12 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
             atomicAdd(&o[3], x[q].y); atomicAdd(&o[4], y[q].y); atomicMax(&o[5], y[q].x);
         }
     }
+    SG_STAMP(d, 3, 2);
     __syncthreads();
+    SG_STAMP(d, 3, 3);
     u64* out = d.in_part + ((size_t)r * S + sl) * K3_IN_NR * 6;
     for (u32 i = t; i < nr * 6; i += 1024) out[i] = acc[i];
+    SG_STAMP(d, 3, 4);
 }
 __global__ __launch_bounds__(256) void k3_in_reduce(Dev d, u32 S) {
     const u32 N = (u32)d.ctr[C_N_NODES];

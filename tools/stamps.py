@@ -44,6 +44,12 @@ for kid, kname in zip((0, 1), g.k1_kernels()):
     print("  start percentiles 10/25/50/75/90:", np.round(np.percentile(st_, [10, 25, 50, 75, 90]), 1), " duration percentiles:", np.round(np.percentile(en_ - st_, [10, 50, 90]), 1))
     ts = np.arange(0, en_.max(), 10.0)
     print("  workgroups running at t =", {int(t): int(((st_ <= t) & (en_ > t)).sum()) for t in ts})
+if st[3][:, 0].max() > 0:                                            # k3_in_part: start, LDS zeroed + barrier, slice scanned (thread 0), barrier passed, partials written
+    a = st[3].astype(np.int64); a = a[a[:, 0] != 0]; t0 = a[:, 0].min()
+    print(f"k3_in_part: {len(a)} workgroups")
+    for k, nm in enumerate(("start", "zeroed+barrier", "scanned (thread 0)", "barrier", "written")):
+        col = (a[:, k] - t0) / 100.0
+        print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
 if st[2][:, 0].max() > 0:                                            # narrow pass A: wave 0's accumulated clock ticks per phase (kernel slot 2)
     a = st[2].astype(np.int64); a = a[a[:, 0] != 0]
     for k, nm in enumerate(("P1 fold", "barrier-1 wait", "P2 scan", "P3 drop", "barrier-3 wait", "P4 copy-out")):
