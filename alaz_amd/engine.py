@@ -154,11 +154,10 @@ class RcclComm:
     def __init__(self, rank: int, world: int, device: int, bcast):
         l = load_library()
         buf = (C.c_char * 128)()
-        if rank == 0:
-            rc = l.sg_comm_unique_id(buf, 128)
-            if rc != SG_OK:
-                raise ServiceGraphError(rc, "sg_comm_unique_id: librccl could not be loaded")
-        raw = bcast(bytes(buf.raw))
+        rc = l.sg_comm_unique_id(buf, 128) if rank == 0 else SG_OK
+        raw = bcast(bytes(buf.raw) if rc == SG_OK else b"")      # an empty id tells every rank that rank 0 has no RCCL: all of them raise
+        if not raw:
+            raise ServiceGraphError(rc if rc != SG_OK else SG_ENODEV, "sg_comm_unique_id: librccl could not be loaded on rank 0")
         idb = (C.c_char * 128).from_buffer_copy(raw)
         p = C.c_void_p()
         rc = l.sg_comm_create(idb, 128, rank, world, device, C.byref(p))

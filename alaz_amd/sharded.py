@@ -21,6 +21,7 @@ exercise the same exchange logic with gloo.
 """
 from __future__ import annotations
 
+import sys
 import time
 from typing import List, Sequence
 
@@ -376,7 +377,22 @@ def bench(a, rank: int, world: int, local: int) -> dict:
         st = torch.cuda.Stream(device)
         streams.append(st)
         if one_call:
-            rcomms.append(engine.RcclComm(rank, world, local, bcast))   # one communicator per engine: the two windows in flight do not share a stream
+            # one communicator per engine: the two windows in flight do not share a stream.  If the library cannot reach RCCL on
+            # some rank (no librccl to dlopen, ncclCommInitRank refused), every rank falls back to the Python-orchestrated
+            # driver with torch.distributed's collectives — decided together, so that no rank waits in a collective alone
+            ok = 1
+            try:
+                rcomms.append(engine.RcclComm(rank, world, local, bcast))
+            except engine.ServiceGraphError as ex:
+                ok = 0
+                print(f"[rank {rank}] sg_comm_create failed ({ex}); falling back to the Python driver", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                for c in rcomms: c.close()
+                rcomms.clear(); one_call = False
+                for g0, st0 in zip(engs, streams):
+                    bes.append(HipBackend(g0, ncap=ncap, layers=L, world=world, rank=rank, device=device, max_obip=64, stream=st0))
         else:
             bes.append(HipBackend(g, ncap=ncap, layers=L, world=world, rank=rank, device=device, max_obip=64, stream=st))
     dev = [torch.from_numpy(ev_all[i * Ev:(i + 1) * Ev].view(np.uint8).reshape(-1)).to(device) for i in range(nb)]
