@@ -467,7 +467,6 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False, serial=False):
         w, c = divmod(j, nchunks_w)
         base = (w % nb) * Ev
         return ev_all[base + c * chunk: base + min(Ev, (c + 1) * chunk)]
-    done = [0] * feeders                                     # events each feeder has handed over
     rows_seen, ev_seen = [], []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
