@@ -417,25 +417,36 @@ def bench_single(a, device):
     }
     # diagnostic (never `value`): the same steps with several windows in flight inside one engine — the
     # latency-bound close of window w overlaps the ingest of window w+1; no timing events in this pass
+    # (the diagnostic passes below must never cost the line above: an exception in one of them is reported in its object)
     if a.overlap_windows > 1 and not a.profile_mode and cfgno != 5:
-        g2 = _engine_for(a, topo, labels, c, device, a.overlap_windows, engine, weights)
-        for i in range(a.warmup):
-            g2.ingest_device(dev[i % nb].data_ptr(), Ev, 0); g2.window_run(0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(a.steps):
-            g2.ingest_device(dev[(a.warmup + i) % nb].data_ptr(), Ev, 0); g2.window_run(0)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        res["overlapped"] = {"windows_in_flight": a.overlap_windows, "events_per_s": Ev * a.steps / dt2, "ms_per_step": dt2 / a.steps * 1e3}
-        g2.close()
+        try:
+            g2 = _engine_for(a, topo, labels, c, device, a.overlap_windows, engine, weights)
+            for i in range(a.warmup):
+                g2.ingest_device(dev[i % nb].data_ptr(), Ev, 0); g2.window_run(0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(a.steps):
+                g2.ingest_device(dev[(a.warmup + i) % nb].data_ptr(), Ev, 0); g2.window_run(0)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            res["overlapped"] = {"windows_in_flight": a.overlap_windows, "events_per_s": Ev * a.steps / dt2, "ms_per_step": dt2 / a.steps * 1e3}
+            g2.close()
+        except Exception as ex:                              # noqa: BLE001
+            res["overlapped"] = {"error": repr(ex)[:300]}
     # events accepted by sg_ingest from HOST memory until their window's rows are readable on the host
     if not a.no_end_to_end and not a.profile_mode:
-        which = os.environ.get("SG_BENCH_E2E", "both")
-        res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E) if which != "pinned" else {}
-        # the same out of caller memory page-locked with sg_host_register (no staging copy).  Measured SLOWER on these boxes: the H2D
-        # engine reads hipHostRegister'ed memory at ~40 GB/s against 57 GB/s for the hipHostMalloc'ed staging ring
-        if which != "pageable": res["end_to_end"]["registered_memory"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E, pinned=True)
+        which = os.environ.get("SG_BENCH_E2E", "both")       # (pageable | pinned | both: to look at one of them alone)
+        try:
+            res["end_to_end"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E) if which != "pinned" else {}
+        except Exception as ex:                              # noqa: BLE001
+            res["end_to_end"] = {"error": repr(ex)[:300]}
+        # the same out of caller memory page-locked with sg_host_register (no staging copy): the copy engine reads hipHostRegister'ed
+        # memory at ~47 GB/s against 57 GB/s for the hipHostMalloc'ed staging ring, but the feeders' memcpy is gone
+        if which != "pageable":
+            try:
+                res["end_to_end"]["registered_memory"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E, pinned=True)
+            except Exception as ex:                          # noqa: BLE001
+                res["end_to_end"]["registered_memory"] = {"error": repr(ex)[:300]}
     if cpu is not None:
         res["cpu_baseline"] = cpu
     g.close()
@@ -481,28 +492,42 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False, serial=False):
     else:
         closed = [0]                                         # windows whose boundary has been marked (sg_flush_begin returned)
         done_w = [[0] * feeders for _ in range(nwin)]        # events handed over, per window and feeder
+        errs = []
         def feed(k):                                         # sg_ingest_bulk waits for a staging slot instead of dropping (production: drop + count)
-            for j in range(k, total_chunks, feeders):
-                wj = j // nchunks_w
-                while closed[0] < wj: time.sleep(0.00005)    # a window's events go in after the previous boundary, never before
-                p = chunk_of(j)
-                retries[k] += g.ingest_bulk(p, pinned=pinned)
-                done_w[wj][k] += len(p)
+            try:
+                for j in range(k, total_chunks, feeders):
+                    wj = j // nchunks_w
+                    while closed[0] < wj and not errs: time.sleep(0.00005)   # a window's events go in after the previous boundary, never before
+                    if errs: return
+                    p = chunk_of(j)
+                    retries[k] += g.ingest_bulk(p, pinned=pinned)
+                    done_w[wj][k] += len(p)
+            except Exception as ex:                          # noqa: BLE001  (reported by the closer: no thread may wait for a dead one)
+                errs.append(ex)
         ths = [threading.Thread(target=feed, args=(k,)) for k in range(feeders)]
         for t in ths: t.start()
         fetch = None
-        def fetch_rows(): rows_seen.append(len(g.flush_end_view()))   # rows readable in the engine's page-locked host buffer
-        for wdx in range(nwin):
-            while sum(done_w[wdx]) < Ev: time.sleep(0.00005)
-            if fetch: fetch.join()
-            g.flush_begin()                                  # the boundary; the feeders go on with the next window at once,
-            closed[0] = wdx + 1
-            fetch = threading.Thread(target=fetch_rows); fetch.start()   # its rows come back over the other direction of the link meanwhile
+        def fetch_rows():                                    # rows readable in the engine's page-locked host buffer
+            try: rows_seen.append(len(g.flush_end_view()))
+            except Exception as ex: errs.append(ex)          # noqa: BLE001
+        try:
+            for wdx in range(nwin):
+                while sum(done_w[wdx]) < Ev and not errs: time.sleep(0.00005)
+                if fetch: fetch.join()
+                if errs: break
+                g.flush_begin()                              # the boundary; the feeders go on with the next window at once,
+                closed[0] = wdx + 1
+                fetch = threading.Thread(target=fetch_rows); fetch.start()   # its rows come back over the other direction of the link meanwhile
+        except Exception as ex:                              # noqa: BLE001
+            errs.append(ex)
         for t in ths: t.join()
-        fetch.join()
+        if fetch: fetch.join()
+        if errs:
+            if pinned: g.host_unregister(ev_all)
+            raise errs[0]
     dt = time.perf_counter() - t0
     rows_n = int(sum(rows_seen) / max(1, len(rows_seen)))
-    assert int(g.stats().events_dropped_ring) == 0
+    dropped_ring = int(g.stats().events_dropped_ring)       # (sg_ingest_bulk waits instead of dropping: stays 0)
     # what the link itself does on this box: pinned 256 MiB copies, best of 3 (the bound the figure above is held against)
     hp = torch.empty(256 << 20, dtype=torch.uint8).pin_memory(); dv = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     h2d = d2h = 0.0
@@ -519,7 +544,7 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False, serial=False):
             "frac_of_pcie_bound": round(link_ms / (dt / nwin * 1e3), 3),
             "pcie_duplex_ms_per_window": round(duplex_ms, 3), "frac_of_duplex_bound": round(duplex_ms / (dt / nwin * 1e3), 3),
             "includes": ([] if pinned else ["memcpy into pinned staging ring"]) + ["h2d (own stream, overlapping K1a of the previous batch)", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows into page-locked host memory (sg_flush_begin / sg_flush_end_view: beside the next window's feed)", "window reset"],
-            "rows_per_window": rows_n, "rows_by_window": rows_seen, "ring_full_retries": int(sum(retries)),
+            "rows_per_window": rows_n, "rows_by_window": rows_seen, "ring_full_retries": int(sum(retries)), "events_dropped_ring": dropped_ring,
             "bound": f"PCIe: 32 B/event host->device + 64 B/edge device->host ({(32.0 * Ev + 64.0 * E) / 1e6:.0f} MB per window) at the measured one-direction rates; duplex = the larger of the two alone (measured: the H2D slows down while the D2H runs)"}
 
 
