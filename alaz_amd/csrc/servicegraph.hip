@@ -683,6 +683,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
     CR(dev_alloc(e, &d.dbg, (size_t)4 * 4096 * 8));
+    CR(dev_alloc(e, &d.clk, (size_t)4));
     // everything a window owns; allocated once per slot
     auto alloc_window = [&](Dev& w, u32*& ob_list, u32*& ob_n) -> int {
 #define LR(call) do { int _rc = (call); if (_rc) return _rc; } while (0)
@@ -1443,6 +1444,24 @@ int sg_debug_stamps(sg_handle e, uint64_t* out, size_t n) {
     std::lock_guard<std::mutex> g(e->mu);
     HIP_TRY(e, hipDeviceSynchronize());
     HIP_TRY(e, hipMemcpy(out, e->d.dbg, std::min<size_t>(n, (size_t)4 * 4096 * 8) * sizeof(u64), hipMemcpyDeviceToHost));
+    return SG_OK;
+}
+// The shader clock the chip sustains ("fast box / slow box"): spin_mhz from an all-CU integer spin of about
+// spin_us microseconds launched now; k1a_mhz from the cycle / 100 MHz tick counts pass A's workgroup 0 has accumulated over
+// its launches since the last call (0 when there was none).  Device-syncs.
+int sg_clock_probe(sg_handle e, uint32_t spin_us, double* spin_mhz, double* k1a_mhz) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(e, hipDeviceSynchronize());
+    const u32 iters = std::max<u32>(1000u, spin_us * 120u);           // ~20 cycles per trip of the dependent chain at ~2.4 GHz
+    hipLaunchKernelGGL(k_clock_spin, dim3(1024), dim3(256), 0, e->stream, e->d.clk, iters);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    u64 h[4] = {};
+    HIP_TRY(e, hipMemcpy(h, e->d.clk, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemset(e->d.clk, 0, sizeof(h)));
+    if (spin_mhz) *spin_mhz = h[3] ? 100.0 * (double)h[2] / (double)h[3] : 0.0;
+    if (k1a_mhz) *k1a_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
     return SG_OK;
 }
 int sg_timing_get(sg_handle e, int kernel, double* avg_us, uint64_t* launches) {

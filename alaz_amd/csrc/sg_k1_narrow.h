@@ -114,6 +114,9 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         return;
     }
     SG_STAMP(d, 0, 0);
+    // the shader clock this launch ran at (sg_clock_probe): cycles / 100 MHz ticks of workgroup 0, thread 0
+    const bool clk_me = w == 0 && t == 0;
+    const u64 clk_c0 = clk_me ? __builtin_readcyclecounter() : 0ull, clk_r0 = clk_me ? wall_clock64() : 0ull;
     // statistics: accepted events and their time-stamp range stay in registers; everything rare (drops, labels, misrouted events, what
     // the general path and the overflow paths count) is added to the workgroup's LDS line where it happens — six registers less
     // across the fold
@@ -438,6 +441,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         if (red[WS_MISROUTED]) atomicAdd(&g[WS_MISROUTED], red[WS_MISROUTED]);
     }
     SG_STAMP(d, 0, 6);
+    if (clk_me) { atomicAdd(&d.clk[0], __builtin_readcyclecounter() - clk_c0); atomicAdd(&d.clk[1], wall_clock64() - clk_r0); }
 #undef LDS_BARRIER
 #undef K1T_LNEW
 }

@@ -1120,6 +1120,16 @@ __device__ __forceinline__ void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row
 }
 // (float)log1p((double)c) for an integer count: from the table the device itself filled with the same expression (bit-identical
 // by construction), the fp64 log1p only beyond it
+// sg_clock_probe: every CU spins on dependent integer VALU work for `iters` trips; workgroup 0 reports shader cycles and
+// 100 MHz ticks of the same interval (their ratio x 100 = the shader clock in MHz the chip sustains under an all-CU load)
+__global__ __launch_bounds__(256) void k_clock_spin(u64* clk, u32 iters) {
+    u32 a = threadIdx.x, b = a * 3u + 1u, c = a * 5u + 7u;
+    const u64 c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    for (u32 i = 0; i < iters; i++) { a = a * 1664525u + b; b = b * 22695477u + c; c ^= a >> 3; }
+    const u64 c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[2] = c1 - c0; clk[3] = r1 - r0; }
+    if ((a ^ b ^ c) == 0x12345678u) clk[3] = a;                      // (keeps the loop)
+}
 __global__ void k_l1p_table(float* tab) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < SG_L1P_TAB) tab[i] = (float)log1p((double)i); }
 __device__ __forceinline__ float log1p_count(const Dev& d, u64 c) { return c < SG_L1P_TAB ? d.l1p_tab[c] : (float)log1p((double)c); }
 // e_uv, lat_z, err_ratio of edge `pos` from its accumulators and its row's out-statistics

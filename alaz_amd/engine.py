@@ -33,7 +33,7 @@ EXPORTS = [
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
     "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
-    "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned", "sg_ingest_bulk",
+    "sg_clock_probe", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned", "sg_ingest_bulk",
 ]
 
 
@@ -132,6 +132,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_timing_enable": (C.c_int, [H, C.c_int]), "sg_timing_reset": (C.c_int, [H]),
         "sg_timing_get": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
         "sg_debug_stamps": (C.c_int, [H, P, sz]),
+        "sg_clock_probe": (C.c_int, [H, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sg_route": (C.c_int, [H, P, sz, u32, P]),
         "sg_window_hist": (C.c_int, [H, P, sz, C.POINTER(sz)]),
         "sg_geometry_get": (C.c_int, [H, C.POINTER(SgGeometry)]),
@@ -392,6 +393,12 @@ class ServiceGraph:
         us, n = C.c_double(), C.c_uint64()
         self._ck(self._l.sg_timing_get(self._h, kernel, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def clock_probe(self, spin_us: int = 200) -> Tuple[float, float]:
+        """(MHz under an all-CU spin launched now, MHz averaged over the pass-A launches since the last call)."""
+        a, b = C.c_double(), C.c_double()
+        self._ck(self._l.sg_clock_probe(self._h, int(spin_us), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def debug_stamps(self) -> np.ndarray:
         """[kernel 0..3][workgroup][8] phase stamps (100 MHz ticks); zeros unless SG_ABLATE & 0x100."""

@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--graph", choices=["fixed", "scaled"], default="fixed",
                     help="N > 1: 'fixed' shards the configuration's own graph over the N GPUs (what BASELINE's multi-GPU configurations "
                          "do with theirs); 'scaled' also grows the graph N-fold")
+    ap.add_argument("--settle-ms", type=float, default=400.0, help="untimed real windows run for at least this long before the warm-up steps, so that the "
+                                                                   "GPU's power management has left its idle state when the clock starts (0 = none)")
     ap.add_argument("--profile-mode", action="store_true", help="only warm-up + the timed steps (no diagnostic passes, no CPU baseline): "
                                                                   "the run rocprofv3 wraps, so its per-kernel averages are those of the timed region")
     a = ap.parse_args()
@@ -348,9 +350,19 @@ def bench_single(a, device):
         g.ingest_device(dev[i % nb].data_ptr(), Ev, s)
         g.window_run(s)
 
+    # Settle: the CPU-baseline leg leaves the GPU idle for tens of seconds and the timed region is only a few milliseconds long —
+    # whatever DPM state the chip is in would be what gets timed.  Untimed real windows until the clock is up.
+    settle_windows = 0
+    if a.settle_ms > 0 and not a.profile_mode:
+        ts = time.perf_counter()
+        while (time.perf_counter() - ts) * 1e3 < a.settle_ms:
+            for _ in range(8):
+                step(settle_windows); settle_windows += 1
+            torch.cuda.synchronize()
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    clk_before = g.clock_probe(200)                          # (all-CU spin now, pass A of the settle + warm-up windows)
     g.timing_reset(); g.timing_enable((1 << 1) | (1 << 7))  # dispatch stamps of every K1 launch (pass A + pass B), on their stream
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -359,6 +371,7 @@ def bench_single(a, device):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     g.timing_enable(0)
+    clk_after = g.clock_probe(200)                           # (spin right after the timed steps, pass A of exactly the timed steps)
     k1a, k1b = g.timing(1), g.timing(7)
     # untimed diagnostic pass: per-group durations of the rest of the window pipeline (hipEvent pairs cost a few us each)
     grp = {}
@@ -414,6 +427,11 @@ def bench_single(a, device):
         "kernels": kernels,
         "window_algorithmic_bytes": b_total, "window_algorithmic_bytes_per_event": b_total / Ev,
         "window_algorithmic_GBs": b_total / (ms_step * 1e-3) / 1e9,
+        # shader clock the chip held (MHz = shader cycles per 100 MHz reference tick x 100): under an all-CU integer spin before /
+        # after the timed steps, and inside pass A itself, averaged over the launches of the timed steps
+        "effective_sclk_mhz": {"spin_before": round(clk_before[0], 1), "spin_after": round(clk_after[0], 1),
+                               "pass_a_timed_steps": round(clk_after[1], 1), "pass_a_settle_and_warmup": round(clk_before[1], 1)},
+        "settle": {"ms": a.settle_ms if not a.profile_mode else 0.0, "windows": settle_windows},
     }
     # diagnostic (never `value`): the same steps with several windows in flight inside one engine — the
     # latency-bound close of window w overlaps the ingest of window w+1; no timing events in this pass
@@ -447,6 +465,8 @@ def bench_single(a, device):
                 res["end_to_end"]["registered_memory"] = end_to_end(g, ev_all, Ev, nb, a.feeders, E, pinned=True)
             except Exception as ex:                          # noqa: BLE001
                 res["end_to_end"]["registered_memory"] = {"error": repr(ex)[:300]}
+    e2e = res.get("end_to_end") or {}
+    res["value_end_to_end"] = e2e.get("events_per_s")        # host memory -> scored rows on the host (pageable caller memory)
     if cpu is not None:
         res["cpu_baseline"] = cpu
     g.close()

@@ -387,6 +387,11 @@ int sg_geometry_get(sg_handle h, sg_geometry* out);
 int sg_timing_enable(sg_handle h, int on);   /* 0 = off, 1 = every group, else bitmask: bit k = group Kk */
 int sg_timing_reset(sg_handle h);
 int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
+/* The shader clock the chip sustains, in MHz (shader cycles per 100 MHz reference tick x 100): *spin_mhz from an all-CU integer
+ * spin of about spin_us microseconds launched by this call, *k1a_mhz averaged over the K1 pass-A launches since the previous
+ * call (0 if none; narrow-record kernels only).  Diagnostic for bench.py: the boxes of a pool differ in the clock they hold
+ * under load.  Device-syncs.                                                                                               */
+int sg_clock_probe(sg_handle h, uint32_t spin_us, double* spin_mhz, double* k1a_mhz);
 /* Tuning aid: with SG_ABLATE & 0x100 in the environment at sg_create, the K1 kernels record 100 MHz
  * wall-clock stamps at their phase boundaries, [kernel 0..3][4096 workgroups][8 stamps] u64; this
  * copies the first n words out.  All zero otherwise.                                                */
