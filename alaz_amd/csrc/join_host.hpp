@@ -148,9 +148,13 @@ public:
             const u32 take = (u32)std::min<size_t>(order.size(), L.max_blocks - 1);
             l1_entries = std::min<u32>(L.l1_cap, next_pow2_u32(std::max<u64>((u64)4 * (take + take / 4 + 8), 16)));   // load <= 0.25 with room to grow
             for (;;) {
+                // below the cap one failed placement restarts with twice the slots; AT the cap a /24 that finds no slot is skipped and
+                // the less populated ones behind it are still tried (stopping at the first failure left every remaining /24
+                // in the cuckoo table, i.e. on K1's out-of-line general path, although most of them would fit)
+                const bool at_cap = l1_entries >= L.l1_cap;
                 bool placed = true;
-                for (u32 i = 0; i < take && placed; i++) placed = alloc_block(order[i].second);
-                if (placed || l1_entries >= L.l1_cap) break;        // (at the cap the /24s that found no slot stay in the cuckoo table)
+                for (u32 i = 0; i < take && (placed || at_cap); i++) placed = alloc_block(order[i].second) && placed;
+                if (placed || at_cap) break;                        // (at the cap the /24s that found no slot stay in the cuckoo table)
                 // an insert walked 512 kicks at load <= 1/3: start over with twice the slots
                 const u32 grown = l1_entries * 2;
                 std::memset(blob + L.off_l1, 0xFF, (size_t)L.l1_cap * 8);

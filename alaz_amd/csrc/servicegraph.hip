@@ -61,7 +61,7 @@ struct sg_engine {
     hipStream_t tab_stream = nullptr;
     u32 n_known = 0;
     // pass-A launch geometry, follows the table state
-    bool l2_in_lds = false, l2_u16 = false; u32 k1a_ct = 2048, k1a_nsub = 2;
+    bool l2_in_lds = false, l2_u16 = false, k1a_team = false; u32 k1a_ct = 2048, k1a_nsub = 2, k1a_teams = 2, k1a_nt = 1024;
     // staging ring for sg_ingest()
     sg_event* h_stage[kStageSlots] = {}; sg_event* d_stage[kStageSlots] = {}; hipEvent_t stage_ev[kStageSlots] = {};
     hipStream_t copy_stream = nullptr, copy_stream2 = nullptr; int n_copy = 1, copy_rr = 0; hipEvent_t copied_ev[kStageSlots] = {};   // H2D copies run on their own stream: batch i + 1 is copied while K1a folds batch i
@@ -72,7 +72,7 @@ struct sg_engine {
     int pending_copies = 0; std::condition_variable cv;                 // window closes wait for the copies that began before them
     // sg_flush_begin .. sg_flush_end: the window is closed and its pipeline enqueued under the lock (feeders that arrive meanwhile wait
     // on `closing`); the rows are fetched WITHOUT it, on rd_stream, while the feeders already fill the next window
-    bool closing = false, flush_open = false, flush_async = false;
+    bool closing = false, flush_open = false, flush_async = false, fetching = false;
     hipStream_t rd_stream = nullptr; hipEvent_t score_ev = nullptr; u64* h_ctr_pin = nullptr;
     const sg_edge_out* fl_rows = nullptr; const u32* fl_ob = nullptr;    // device rows / outbound list of the window being flushed
 
@@ -139,7 +139,7 @@ hipEvent_t get_event(sg_engine* e) {
 
 struct Timed {
     sg_engine* e; hipStream_t s; TimingRec r; bool on;
-    Timed(sg_engine* e_, hipStream_t s_, int kernel) : e(e_), s(s_), on((e_->timing >> kernel) & 1u) {
+    Timed(sg_engine* e_, hipStream_t s_, int kernel) : e(e_), s(s_), on(e_ && ((e_->timing >> kernel) & 1u)) {
         if (on) { r.kernel = kernel; r.a = get_event(e); r.b = get_event(e); hipEventRecord(r.a, s); }
     }
     ~Timed() { if (on) { hipEventRecord(r.b, s); e->trecs.push_back(r); } }
@@ -162,11 +162,29 @@ bool k1a_geometry(sg_engine* e) {
         e->l2_u16 = e->cfg.max_known_nodes <= 16384 && !std::getenv("SG_L2_U32");
         const size_t l2lds = e->l2_u16 ? l2b / 2 : l2b;
         if (const char* v = std::getenv("SG_NSUB")) { const int x = std::atoi(v); if (x == 1 || x == 2) e->k1a_nsub = (u32)x; }
-        const size_t fixed = (size_t)d.np * 24 + 64 + (size_t)K1T_TS(e->k1a_nsub) * 8 + l1b;
-        u32 ct = 0;
-        // (the cache flattens the hottest keys; beyond 1024 slots it costs more aggregates than it saves records)
-        for (u32 c : {1024u, 512u, 256u, 128u}) if ((size_t)c * 40 + fixed + l2lds <= kLdsBytes && l1b + l2b <= stage_max) { e->l2_in_lds = true; ct = c; break; }
-        if (!ct) for (u32 c : {1024u, 512u, 256u, 128u, 64u}) if ((size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
+        // round 4: two teams per workgroup (k1a_team_partition) when their two tiles and counter sets fit beside a cache of 256 slots or
+        // more; SG_K1A=tile keeps the one-team kernel (k1a_tile_partition), SG_K1A=team takes the two-team kernel whenever it fits at all
+        const char* kv = std::getenv("SG_K1A");
+        const bool want_tile = kv && !std::strcmp(kv, "tile"), force_team = kv && !std::strcmp(kv, "team");
+        const size_t fixed_tile = (size_t)d.np * 24 + 64 + (size_t)K1T_TS(e->k1a_nsub) * 8 + l1b;
+        // the two-team kernel is instantiated for 256 / 512 / 1024 partitions, 768 threads, the one-thread-per-position copy-out (2 nb <= 31)
+        // and a join blob its prologue can stage; everything else keeps the one-team kernel
+        const int teams = 2, nt = 768;
+        const bool team_ok = (d.np == 256 || d.np == 512 || d.np == 1024) && 2 * d.nb <= 31 && l1b + (e->l2_u16 || true ? l2b : l2b) <= (size_t)K1A_NJ * 768 * 16;
+        e->k1a_teams = (u32)teams; e->k1a_nt = (u32)nt;
+        const size_t fixed_team = K1M_LDS_FIXED(d.np, teams, nt) + l1b;
+        auto pick = [&](size_t fixed, u32 ct_min, u32& ct, bool& in_lds) {
+            ct = 0; in_lds = false;
+            // (the cache flattens the hottest keys; beyond 1024 slots it costs more aggregates than it saves records)
+            for (u32 c : {1024u, 512u, 256u, 128u}) if (c >= ct_min && (size_t)c * 40 + fixed + l2lds <= kLdsBytes && l1b + l2b <= stage_max) { in_lds = true; ct = c; break; }
+            if (!ct) for (u32 c : {1024u, 512u, 256u, 128u, 64u}) if (c >= ct_min && (size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
+        };
+        u32 ct = 0; bool in_lds = false;
+        e->k1a_team = false;
+        if (!want_tile && team_ok) { pick(fixed_team, force_team ? 64u : 256u, ct, in_lds); e->k1a_team = ct != 0; }
+        if (!ct) pick(fixed_tile, 64u, ct, in_lds);
+        const size_t fixed = e->k1a_team ? fixed_team : fixed_tile;
+        e->l2_in_lds = in_lds;
         if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2lds : 0) <= kLdsBytes) ct = x; }
         if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
         if (!ct || l1b > stage_max) return false;
@@ -278,13 +296,22 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
 #define K1A_GO2(L2, SH) do { if (e->d.hist) K1A_GO(L2, SH, true); else K1A_GO(L2, SH, false); } while (0)
 #define K1T_GO(L2, SH, NS) hipExtLaunchKernelGGL((k1a_tile_partition<L2, SH, NS>), dim3(e->d.nwg), dim3(K1T_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
 #define K1T_GO2(L2, SH) do { if (e->k1a_nsub == 2) K1T_GO(L2, SH, 2); else K1T_GO(L2, SH, 1); } while (0)
-        if (e->d.narrow) {
+#define K1M_GO(L2, SH) do { if (e->d.np == 256) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 8>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
+                            else if (e->d.np == 512) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 9>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
+                            else hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 10>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); } while (0)
+        if (e->d.narrow && e->k1a_team) {
+            if (e->l2_in_lds && e->l2_u16) { if (sh) K1M_GO(2, true); else K1M_GO(2, false); }
+            else if (e->l2_in_lds) { if (sh) K1M_GO(1, true); else K1M_GO(1, false); }
+            else { if (sh) K1M_GO(0, true); else K1M_GO(0, false); }
+        }
+        else if (e->d.narrow) {
             if (e->l2_in_lds && e->l2_u16) { if (sh) K1T_GO2(2, true); else K1T_GO2(2, false); }
             else if (e->l2_in_lds) { if (sh) K1T_GO2(1, true); else K1T_GO2(1, false); }
             else { if (sh) K1T_GO2(0, true); else K1T_GO2(0, false); }
         }
         else if (e->l2_in_lds) { if (sh) K1A_GO2(true, true); else K1A_GO2(true, false); }
         else { if (sh) K1A_GO2(false, true); else K1A_GO2(false, false); }
+#undef K1M_GO
 #undef K1T_GO2
 #undef K1T_GO
 #undef K1A_GO2
@@ -663,7 +690,16 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
                               reinterpret_cast<const void*>(k1a_tile_partition<0, true, 2>), reinterpret_cast<const void*>(k1a_tile_partition<0, false, 2>),
                               reinterpret_cast<const void*>(k1a_tile_partition<2, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<2, false, 1>),
                               reinterpret_cast<const void*>(k1a_tile_partition<1, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<1, false, 1>),
-                              reinterpret_cast<const void*>(k1a_tile_partition<0, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<0, false, 1>)})
+                              reinterpret_cast<const void*>(k1a_tile_partition<0, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<0, false, 1>),
+                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 768, 8>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 768, 8>),
+                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 768, 9>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 768, 9>),
+                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 768, 10>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 768, 10>),
+                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 768, 8>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 768, 8>),
+                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 768, 9>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 768, 9>),
+                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 768, 10>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 768, 10>),
+                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 768, 8>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 768, 8>),
+                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 768, 9>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 768, 9>),
+                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 768, 10>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 768, 10>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
         for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>),
                               reinterpret_cast<const void*>(k1b_merge_wide<4, false>), reinterpret_cast<const void*>(k1b_merge_wide<8, false>), reinterpret_cast<const void*>(k1b_merge_wide<4, true>),
@@ -810,7 +846,7 @@ int sg_geometry_get(sg_handle e, sg_geometry* out) {
     const Dev& d = e->d;
     out->k1_variant = d.variant; out->k1_narrow = d.narrow; out->partitions = d.np; out->table_slots = d.k1b_ht; out->pass_b_split = d.k1b_split;
     out->pass_a_workgroups = d.nwg; out->cache_slots = e->k1a_ct; out->join_l2_in_lds = e->l2_in_lds ? (e->d.narrow && e->l2_u16 ? 2u : 1u) : 0u;
-    out->tile_records = d.narrow ? K1T_TS(e->k1a_nsub) : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
+    out->tile_records = d.narrow ? (e->k1a_team ? 8u * e->k1a_nt / e->k1a_teams : K1T_TS(e->k1a_nsub)) : 0u; out->pass_a_teams = d.narrow && e->k1a_team ? e->k1a_teams : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
     out->piece_bytes = d.variant != 0 ? 0u : (d.narrow ? d.punits * 8u : d.pslots * 16u);
     return SG_OK;
 }
@@ -894,7 +930,7 @@ int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
     std::unique_lock<std::mutex> g(e->mu);
     if (n > e->cfg.max_batch) { e->err = "batch larger than max_batch"; return SG_EINVAL; }
     if (n == 0) return SG_OK;
-    e->cv.wait(g, [&] { return !e->closing; });                          // a window is being closed (microseconds): this batch belongs to the next one
+    if (e->closing) { e->st.ingest_waits++; e->cv.wait(g, [&] { return !e->closing; }); }   // a window boundary is being marked (microseconds): this batch belongs to the next window
     const int slot = stage_take(e);
     if (slot < 0) {                                                      // ring full: drop, never block
         e->st.events_dropped_ring += n;
@@ -910,8 +946,9 @@ int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
 
 // The same without the staging copy, for events that already sit in page-locked memory: memory registered with
 // sg_host_register (e.g. the C-allocated buffer a packer writes into), or any hipHostMalloc'd block.  The library reads
-// `events` asynchronously: the n records must stay unchanged until the window they belong to has been closed
-// (sg_flush_window* / sg_window_run returned) — the one entry point that keeps caller memory beyond the call, and therefore
+// `events` asynchronously (the H2D copy on the copy stream, then K1 pass A): the n records must stay unchanged until
+// sg_flush_end* / sg_flush_window* of the window they belong to has RETURNED — sg_flush_begin and sg_window_run only enqueue,
+// the copy may still be reading caller memory when they return (after sg_window_run: synchronise its stream first) — the one entry point that keeps caller memory beyond the call, and therefore
 // not for Go-heap memory (cgo rule); everything else as sg_ingest (non-blocking, SG_EAGAIN when no device slot is free).
 int sg_ingest_pinned(sg_handle e, const sg_event* events, size_t n) {
     if (!e || (!events && n)) return SG_EINVAL;
@@ -924,7 +961,7 @@ int sg_ingest_pinned(sg_handle e, const sg_event* events, size_t n) {
         for (auto& r : e->registered) ok |= p >= r.first && p + n * sizeof(sg_event) <= r.first + r.second;
         if (!ok) { e->err = "sg_ingest_pinned: the events are not inside memory registered with sg_host_register"; return SG_EINVAL; }
     }
-    e->cv.wait(g, [&] { return !e->closing; });
+    if (e->closing) { e->st.ingest_waits++; e->cv.wait(g, [&] { return !e->closing; }); }
     const int slot = stage_take(e);
     if (slot < 0) { e->st.events_dropped_ring += n; return SG_EAGAIN; }
     return stage_submit(e, slot, events, n);
@@ -1104,6 +1141,10 @@ int sg_window_reset(sg_handle e, void* stream) {
 // sg_flush_window / sg_flush_window_view = begin + end, for callers with one thread.
 namespace {
 int flush_begin_locked(sg_engine* e, std::unique_lock<std::mutex>& g) {
+    // One boundary at a time: `closing` is also the "a begin is in progress" flag — the wait for the staging copies below releases the
+    // engine lock, and a second flusher that got in there used to pass the flush_open test too, close the NEXT window and rewrite the
+    // rows / counters the first one's unlocked fetch was reading.  It waits here instead and then sees flush_open.
+    e->cv.wait(g, [&] { return !e->closing; });
     if (e->flush_open) { e->err = "sg_flush_begin: the previous window has not been fetched (sg_flush_end)"; return SG_ESTATE; }
     e->closing = true;                                                   // later feeders wait instead of slipping batches into the closing window
     e->cv.wait(g, [&] { return e->pending_copies == 0; });
@@ -1132,6 +1173,7 @@ int flush_begin_locked(sg_engine* e, std::unique_lock<std::mutex>& g) {
 }
 // out != nullptr: up to cap rows into caller memory; view != nullptr: all rows into the page-locked view buffer
 int flush_end_unlocked(sg_engine* e, std::unique_lock<std::mutex>& g, sg_edge_out* out, size_t cap, size_t* n, const sg_edge_out** view) {
+    e->cv.wait(g, [&] { return !e->fetching; });                         // another thread's sg_flush_end of the same window: one fetch, the loser sees the window gone
     if (!e->flush_open) { e->err = "sg_flush_end without sg_flush_begin"; return SG_ESTATE; }
     if (!e->flush_async) {                                               // already read (under the lock, by begin) into the view buffer
         const size_t E = (size_t)e->h_ctr[C_N_EDGES];
@@ -1142,6 +1184,7 @@ int flush_end_unlocked(sg_engine* e, std::unique_lock<std::mutex>& g, sg_edge_ou
         return SG_OK;
     }
     const sg_edge_out* d_rows = e->fl_rows; const u32* d_ob = e->fl_ob;
+    e->fetching = true;                                                  // claimed: the fetch below runs without the engine lock
     g.unlock();
     int rc = SG_OK; std::string err;
     std::vector<u32> obips;
@@ -1158,7 +1201,7 @@ int flush_end_unlocked(sg_engine* e, std::unique_lock<std::mutex>& g, sg_edge_ou
         if (hipStreamSynchronize(e->rd_stream) != hipSuccess) { err = "hipStreamSynchronize (read stream)"; rc = SG_ENODEV; break; }
     } while (0);
     g.lock();
-    e->flush_open = false; e->cv.notify_all();
+    e->fetching = false; e->flush_open = false; e->cv.notify_all();
     if (rc) { if (!err.empty()) e->err = err; return rc; }
     std::memcpy(e->h_ctr, e->h_ctr_pin, sizeof(e->h_ctr));
     e->last_obips.swap(obips);
@@ -1189,7 +1232,7 @@ int sg_flush_window(sg_handle e, uint64_t window_end_ms, sg_edge_out* out, size_
     (void)window_end_ms;
     if (!e) return SG_EINVAL;
     std::unique_lock<std::mutex> g(e->mu);
-    e->cv.wait(g, [&] { return !e->flush_open; });                       // (another thread's begin .. end pair)
+    e->cv.wait(g, [&] { return !e->closing && !e->flush_open; });        // (another thread's begin .. end pair)
     if (const int rc = flush_begin_locked(e, g)) return rc;
     return flush_end_unlocked(e, g, out, cap, n, nullptr);
 }
@@ -1197,7 +1240,7 @@ int sg_flush_window_view(sg_handle e, uint64_t window_end_ms, const sg_edge_out*
     (void)window_end_ms;
     if (!e || !rows) return SG_EINVAL;
     std::unique_lock<std::mutex> g(e->mu);
-    e->cv.wait(g, [&] { return !e->flush_open; });
+    e->cv.wait(g, [&] { return !e->closing && !e->flush_open; });
     if (const int rc = flush_begin_locked(e, g)) return rc;
     return flush_end_unlocked(e, g, nullptr, 0, n, rows);
 }
@@ -1207,7 +1250,7 @@ int sg_flush_window_view(sg_handle e, uint64_t window_end_ms, const sg_edge_out*
 // RCCL is reached through dlopen (the copy already in the process, e.g. torch's, else /opt/rocm/lib/librccl.so): the engine
 // library itself does not link it, a single-GPU deployment never loads it.
 struct sg_comm {
-    void* lib = nullptr; void* comm = nullptr; int rank = 0, world = 1; hipStream_t stream = nullptr;
+    void* lib = nullptr; void* comm = nullptr; int rank = 0, world = 1; hipStream_t stream = nullptr; sg_engine* eng = nullptr;   // eng: whose timing records the collectives go to (group 9)
     struct Id { char b[128]; };
     int (*GetUniqueId)(Id*) = nullptr; int (*CommInitRank)(void**, int, Id, int) = nullptr; int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
@@ -1227,10 +1270,11 @@ bool rccl_load(sg_comm* c) {
     return true;
 }
 // rccl.h: ncclUint8 = 1, ncclUint64 = 5; ncclSum = 0, ncclMax = 2
-int rc_all_gather(void* x, const void* send, void* recv, size_t bytes) { sg_comm* c = (sg_comm*)x; return c->AllGather(send, recv, bytes, 1, c->comm, c->stream) ? SG_ENODEV : SG_OK; }
-int rc_all_reduce(void* x, void* buf, size_t n, int op) { sg_comm* c = (sg_comm*)x; return c->AllReduce(buf, buf, n, 5, op ? 2 : 0, c->comm, c->stream) ? SG_ENODEV : SG_OK; }
+int rc_all_gather(void* x, const void* send, void* recv, size_t bytes) { sg_comm* c = (sg_comm*)x; Timed t(c->eng, c->stream, 9); return c->AllGather(send, recv, bytes, 1, c->comm, c->stream) ? SG_ENODEV : SG_OK; }
+int rc_all_reduce(void* x, void* buf, size_t n, int op) { sg_comm* c = (sg_comm*)x; Timed t(c->eng, c->stream, 9); return c->AllReduce(buf, buf, n, 5, op ? 2 : 0, c->comm, c->stream) ? SG_ENODEV : SG_OK; }
 int rc_all_to_all(void* x, const void* send, void* recv, size_t bytes) {            // full mesh over xGMI: grouped point-to-point, every link busy at once
     sg_comm* c = (sg_comm*)x;
+    Timed t(c->eng, c->stream, 9);
     int bad = c->GroupStart();
     for (int r = 0; r < c->world; r++) {
         bad |= c->Send((const char*)send + (size_t)r * bytes, bytes, 1, r, c->comm, c->stream);
@@ -1264,6 +1308,9 @@ int st_score(void* p) {
 #undef SCX
 }  // namespace
 
+// Can this process reach RCCL at all (dlopen + every symbol)?  For drivers that must agree on a fallback BEFORE any rank enters
+// ncclCommInitRank (a rank that cannot load librccl would otherwise leave the others waiting in it: ADVICE r3).
+int sg_comm_probe(void) { sg_comm c; return rccl_load(&c) ? SG_OK : SG_ENODEV; }
 int sg_comm_unique_id(void* id, size_t bytes) {
     if (!id || bytes < 128) return SG_EINVAL;
     sg_comm c;
@@ -1311,7 +1358,7 @@ int sg_window_run_sharded(sg_handle e, sg_comm* c, void* stream) {
             (rc = dev_alloc(e, &x.rows_out, (size_t)W * x.capp * SG_F_HID)) || (rc = dev_alloc(e, &x.rows_in, (size_t)W * x.capp * SG_F_HID))) return rc;
         HIP_TRY(e, hipStreamSynchronize(e->stream));                 // (dev_alloc clears on the engine's own stream)
     }
-    c->stream = s;
+    c->stream = s; c->eng = e;
     ShardCtx cx{e, s};
     sg_shard_stages st{};
     st.ctx = &cx; st.layers = e->cfg.layers; st.world = W;
@@ -1329,6 +1376,15 @@ int sg_window_run_sharded(sg_handle e, sg_comm* c, void* stream) {
     return SG_OK;
 }
 
+// Rows this shard asked each owner for in its last sharded window (element r = requests to rank r; device-syncs).  Diagnostic.
+int sg_window_halo_counts(sg_handle e, uint32_t* counts, size_t world) {
+    if (!e || !counts || world != e->cfg.world) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->xc.req) { for (size_t r = 0; r < world; r++) counts[r] = 0; return SG_OK; }
+    HIP_TRY(e, hipDeviceSynchronize());
+    for (size_t r = 0; r < world; r++) HIP_TRY(e, hipMemcpy(&counts[r], e->xc.req + r * (e->xc.capp + 1), 4, hipMemcpyDeviceToHost));
+    return SG_OK;
+}
 int sg_window_run(sg_handle e, void* stream) {
     if (!e) return SG_EINVAL;
     std::unique_lock<std::mutex> g(e->mu);

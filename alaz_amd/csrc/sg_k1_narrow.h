@@ -530,7 +530,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         atomicAdd(&hacc[h], a0); atomicAdd(&hacc[HT + h], a1); atomicMax(&hacc[2 * HT + h], a2); atomicAdd(&hacc[3 * HT + h], a3);
     };
     for (u32 w = w0; w < d.nwg; w += NT / LPP) {
-        const uint2 h = w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w];
+        const uint2 h = empty ? make_uint2(0u, 0u) : (w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w]);   // (no batch this window: the headers are the previous window's)
         const u32 nn = h.x < d.sn ? h.x : d.sn;
         if (!nn) continue;
         const uint4* pairs = reinterpret_cast<const uint4*>(piece8(d, p, w));
@@ -554,7 +554,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     __syncthreads();                                                 // every 32-bit max is in: 64-bit updates may follow
     SG_STAMP(d, 1, 3);
     for (u32 w = w0; w < d.nwg; w += NT / LPP) {
-        const uint2 h = w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w];
+        const uint2 h = empty ? make_uint2(0u, 0u) : (w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w]);
         const u32 nw = (h.y & 0xFFFFu) < d.sw ? (h.y & 0xFFFFu) : d.sw, na = (h.y >> 16) < d.sa ? (h.y >> 16) : d.sa;
         if (!(nw | na)) continue;
         const u64* piece = piece8(d, p, w);

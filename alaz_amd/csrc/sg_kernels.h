@@ -788,6 +788,7 @@ template <int K1B_U, bool HIST> __global__ __launch_bounds__(1024) __attribute__
 template <int K1B_U, bool HIST> __global__ __launch_bounds__(1024) void k1b_merge_wide(Dev d) { k1b_body<K1B_U, HIST>(d); }
 
 #include "sg_k1_narrow.h"   // the narrow-record form of both passes (default of variant 0)
+#include "sg_k1_team.h"     // round 4: pass A with two teams per workgroup and a batched join
 
 // ------------------------------------------------------------------------------------------------
 // K2  csr_build: canonical node numbering, CSR with sorted rows.

@@ -33,7 +33,7 @@ EXPORTS = [
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
     "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
-    "sg_clock_probe", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned", "sg_ingest_bulk",
+    "sg_clock_probe", "sg_comm_probe", "sg_window_halo_counts", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned", "sg_ingest_bulk",
 ]
 
 
@@ -46,7 +46,7 @@ class SgConfig(C.Structure):
 
 
 CFG_EDGE_HISTOGRAM = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def make_config(*, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 256, max_outbound_ips: int = 64,
@@ -59,7 +59,7 @@ def make_config(*, max_known_nodes: int, max_edges: int, layers: int = 1, max_la
 
 class SgGeometry(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("k1_variant", "k1_narrow", "partitions", "table_slots", "pass_a_workgroups", "cache_slots",
-                                          "join_l2_in_lds", "tile_records", "endpoint_bits", "piece_bytes", "pass_b_split", "reserved")]
+                                          "join_l2_in_lds", "tile_records", "endpoint_bits", "piece_bytes", "pass_b_split", "pass_a_teams")]
 
 
 class SgStats(C.Structure):
@@ -69,7 +69,7 @@ class SgStats(C.Structure):
                 ("last_window_tmin_ms", C.c_int64), ("last_window_tmax_ms", C.c_int64), ("h2d_bytes", C.c_uint64),
                 ("events_misrouted", C.c_uint64), ("halo_overflow", C.c_uint64),
                 ("alive_in", C.c_uint64), ("alive_dropped", C.c_uint64),
-                ("join_word_updates", C.c_uint64), ("join_full_uploads", C.c_uint64)]
+                ("join_word_updates", C.c_uint64), ("join_full_uploads", C.c_uint64), ("ingest_waits", C.c_uint64)]
 
 
 class ServiceGraphError(RuntimeError):
@@ -88,6 +88,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get("SG_LIB", path)          # tuning builds (tools/): another build of the same sources, e.g. with phase stamps compiled in
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `python -m alaz_amd.build` "
                            "(hipcc, gfx950). The ServiceGraph engine has no CPU fallback.")
@@ -133,6 +134,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_timing_get": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
         "sg_debug_stamps": (C.c_int, [H, P, sz]),
         "sg_clock_probe": (C.c_int, [H, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "sg_comm_probe": (C.c_int, []), "sg_window_halo_counts": (C.c_int, [H, P, sz]),
         "sg_route": (C.c_int, [H, P, sz, u32, P]),
         "sg_window_hist": (C.c_int, [H, P, sz, C.POINTER(sz)]),
         "sg_geometry_get": (C.c_int, [H, C.POINTER(SgGeometry)]),
@@ -151,6 +153,12 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
 class RcclComm:
     """The engine library's own RCCL communicator (sg_comm_*): rank 0 draws the unique id, `bcast(bytes) -> bytes` hands it to
     every rank (torch.distributed.broadcast_object_list, MPI, a file ...), every rank joins."""
+
+    @staticmethod
+    def probe() -> bool:
+        """Can the library reach RCCL in this process?  (Agree on a fallback with every rank BEFORE constructing: a rank that fails
+        inside the constructor leaves the others waiting in ncclCommInitRank.)"""
+        return load_library().sg_comm_probe() == SG_OK
 
     def __init__(self, rank: int, world: int, device: int, bcast):
         l = load_library()
@@ -224,7 +232,8 @@ class ServiceGraph:
         """Names of the two K1 kernels this engine launches (as rocprofv3 lists them), or the single global-table kernel."""
         g = self.geometry()
         if g["k1_variant"] == 1: return ("k1_resolve_aggregate",)
-        return ("k1a_tile_partition", "k1b_stream_merge") if g["k1_narrow"] else ("k1a_partition", "k1b_merge")
+        if not g["k1_narrow"]: return ("k1a_partition", "k1b_merge")
+        return ("k1a_team_partition" if g["pass_a_teams"] else "k1a_tile_partition", "k1b_stream_merge")
 
     # ---- join tables (aggregator/persist.go:55-71,114-130) ----
     def upsert_pod(self, ip: int, node_id: int): self._ck(self._l.sg_upsert_pod(self._h, ip, node_id))
@@ -320,6 +329,11 @@ class ServiceGraph:
         """K1 pass B .. K5 of this shard's window with every exchange, ONE C call (sg_window_run_sharded); rows stay on the device."""
         self._ck(self._l.sg_window_run_sharded(self._h, comm.ptr, stream or None))
     def window_reset(self, stream: int = 0): self._ck(self._l.sg_window_reset(self._h, stream or None))
+
+    def halo_counts(self, world: int) -> np.ndarray:
+        out = np.zeros(world, dtype=np.uint32)
+        self._ck(self._l.sg_window_halo_counts(self._h, out.ctypes.data, world))
+        return out
 
     def window_close_sharded(self, d_union_ips: int, d_union_n: int, stream: int = 0):
         self._ck(self._l.sg_window_close_sharded(self._h, d_union_ips, d_union_n, stream or None))

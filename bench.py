@@ -62,6 +62,15 @@ def parse():
     ap.add_argument("--graph", choices=["fixed", "scaled"], default="fixed",
                     help="N > 1: 'fixed' shards the configuration's own graph over the N GPUs (what BASELINE's multi-GPU configurations "
                          "do with theirs); 'scaled' also grows the graph N-fold")
+    ap.add_argument("--shard-of", type=int, default=1, help="one GPU: time ONE shard of the configuration hash-sharded over this many GPUs (BASELINE config 5 is "
+                                                              "specified for 8): the shard's sub-graph (edges whose source pod it owns) with every IP replicated, "
+                                                              "its routed share of every window's events, in an engine sized for the shard — the shape a rank of "
+                                                              "the 8-GPU job has, without the exchanges")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: 'weak' = Ev events per GPU and window (the event volume grows with N); 'strong' = ONE replay, the same Ev-event "
+                         "windows routed over the N GPUs by the owner of each event's source")
+    ap.add_argument("--verify", action="store_true", help="N > 1 (or SG_FORCE_SHARDED): one untimed window of a global trace through the sharded engines, rows "
+                                                            "gathered on rank 0 and compared byte for byte with an unsharded engine -> rows_verified in the line")
     ap.add_argument("--settle-ms", type=float, default=400.0, help="untimed real windows run for at least this long before the warm-up steps, so that the "
                                                                    "GPU's power management has left its idle state when the clock starts (0 = none)")
     ap.add_argument("--profile-mode", action="store_true", help="only warm-up + the timed steps (no diagnostic passes, no CPU baseline): "
@@ -303,9 +312,10 @@ def main():
 def _engine_for(a, topo, labels, c, device, windows, engine, weights):
     L = c["layers"]
     big = a.config == 5
-    g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(c["edges"] * (1.1 if big else 1.25)) + 4096, layers=L,
+    n_edges = len(topo.edge_src)                                     # (a shard view holds its own edges only)
+    g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(n_edges * (1.1 if big and a.shard_of == 1 else 1.25)) + 4096, layers=L,
                             max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=int(os.environ.get("SG_BENCH_MAX_BATCH", 1 << 18)),
-                            max_window_events=c["events"], windows_in_flight=windows)
+                            max_window_events=max(1, c["events"] // a.shard_of), windows_in_flight=windows)
     g.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
     g.load_weights(weights.make_weights(L))
     for i in range(topo.n_pods):
@@ -325,8 +335,14 @@ def bench_single(a, device):
     Ev, L = c["events"], c["layers"]
     nb = a.batches or max(2, -(-(320 << 20) // (Ev * 32)))          # ring >= 320 MB > 256 MiB Infinity Cache
     topo = replay.make_topology(c["pods"], c["edges"], seed)
+    full_topo = topo
+    if a.shard_of > 1:                                               # shard 0 of `shard_of`: its edges, every node (the join tables are replicated)
+        from alaz_amd import sharded
+        topo = sharded.shard_view(full_topo, 0, a.shard_of)
+        Ev = Ev // a.shard_of                                        # its routed share of a window (events are drawn from the shard's own edges)
+        nb = a.batches or max(2, -(-(320 << 20) // (Ev * 32)))
     cache = os.environ.get("SG_BENCH_CACHE")                         # tools/gpu.sh: several profiler passes over the same trace on one box
-    cpath = os.path.join(cache, f"bench_ev_c{cfgno}_{nb}.npy") if cache else None
+    cpath = os.path.join(cache, f"bench_ev_c{cfgno}_{nb}_s{a.shard_of}.npy") if cache else None
     if cpath and os.path.exists(cpath):
         ev_all = np.load(cpath); labels = list(replay.EXTERNAL_HOSTS)
         labels = labels[: int(ev_all["host_label"].max())]
@@ -412,11 +428,12 @@ def bench_single(a, device):
         "metric": "L7 edge-events/s ingested->scored service-map", "value": Ev * a.steps / dt, "unit": "events/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"C{cfgno} device-resident replay: {c['pods']} pods / {topo.n_svcs} services / {c['edges']} edges, "
+        "config": {"workload": (f"ONE SHARD OF {a.shard_of} of " if a.shard_of > 1 else "") + f"C{cfgno} device-resident replay: {c['pods']} pods / {topo.n_svcs} services / {len(topo.edge_src)} edges, "
                                f"{Ev} {'mixed HTTP/Kafka/Postgres' if cfgno == 5 else 'HTTP'} l7 events per window already in HBM, {L}-layer SAGE + MLP score, "
                                f"{variant}; {nb}-batch HBM ring (value excludes PCIe: see end_to_end)",
                    "events_per_window": Ev, "edges_per_window": E, "nodes": N, "layers": L,
-                   "events_dropped_cap": int(st.events_dropped_cap), "windows_in_flight": a.windows, "parallelism": "1 GPU"},
+                   "events_dropped_cap": int(st.events_dropped_cap), "windows_in_flight": a.windows, "shard_of": a.shard_of,
+                   "parallelism": "1 GPU" if a.shard_of == 1 else f"1 GPU standing in for one rank of {a.shard_of} (no exchanges: K1 and the local window close of the shard's shape)"},
         "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = " + " + ".join(kn), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src, "traffic_measured_in_run": False, "traffic_build_matches": traffic_match,

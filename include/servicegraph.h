@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 3u   /* 3: sg_config begins with its own size (a binding compiled against an older, shorter sg_config is
+#define SG_ABI_VERSION 4u   /* 4: sg_stats.ingest_waits, sg_geometry.pass_a_teams, sg_clock_probe;
+                               3: sg_config begins with its own size (a binding compiled against an older, shorter sg_config is
                                detected instead of read past its end; members added later are zero for it), sg_geometry_get;
                                2: sg_edge_out carries p50_us / p99_us, sg_config.flags, sg_window_hist, sg_flush_window_view */
 
@@ -206,6 +207,9 @@ typedef struct sg_stats {
     uint64_t alive_dropped;        /* ... of which beyond max_alive, or with an endpoint that was dropped */
     uint64_t join_word_updates;    /* join-table words changed in place on the device (incremental upserts/deletes) */
     uint64_t join_full_uploads;    /* whole join-table images uploaded (first build, rebuilds)        */
+    uint64_t ingest_waits;         /* sg_ingest / sg_ingest_pinned calls that found a window boundary being marked (sg_flush_begin) and
+                                      waited for it — bounded by the staging copies in flight; the reference's PersistRequest blocks on a
+                                      full channel instead (datastore/backend.go:844), this is the only wait on the aggregator's thread */
 } sg_stats;
 
 typedef struct sg_engine* sg_handle;
@@ -244,8 +248,9 @@ int sg_load_weights(sg_handle h, const float* w, size_t n);
 int sg_ingest(sg_handle h, const sg_event* events, size_t n);
 
 /* The same without the staging copy, for events that already sit in page-locked host memory the caller registered with
- * sg_host_register (a C-allocated buffer a packer writes into; NOT Go-heap memory): the records are read asynchronously and
- * must stay unchanged until the window they belong to has been closed.  Non-blocking like sg_ingest (SG_EAGAIN when no device
+ * sg_host_register (a C-allocated buffer a packer writes into; NOT Go-heap memory): the records are read asynchronously (H2D copy,
+ * then K1 pass A) and must stay unchanged until sg_flush_end* / sg_flush_window* of their window has RETURNED (sg_flush_begin and
+ * sg_window_run only enqueue: after sg_window_run synchronise its stream first).  Non-blocking like sg_ingest (SG_EAGAIN when no device
  * slot is free); SG_EINVAL when the events are not inside registered memory.                                              */
 int sg_host_register(sg_handle h, void* p, size_t bytes);
 int sg_host_unregister(sg_handle h, void* p);
@@ -349,10 +354,14 @@ int sg_halo_unpack(sg_handle h, uint32_t l, const uint32_t* d_ids, uint32_t n, c
  * to the engine.  The communicator: rank 0 calls sg_comm_unique_id, the caller broadcasts the 128 bytes (any transport),
  * every rank calls sg_comm_create with its sg_config.rank / world.  RCCL is dlopen'ed (SG_ENODEV if it cannot be).      */
 typedef struct sg_comm sg_comm;
+int sg_comm_probe(void);                         /* SG_OK when librccl can be loaded with every symbol the library uses: lets all ranks agree
+                                                    on a fallback BEFORE any of them enters ncclCommInitRank (which would wait for the others) */
 int sg_comm_unique_id(void* id128, size_t bytes);
 int sg_comm_create(const void* id128, size_t bytes, int rank, int world, int device, sg_comm** out);
 int sg_comm_destroy(sg_comm* c);
 int sg_window_run_sharded(sg_handle h, sg_comm* comm, void* stream);
+/* Rows this shard asked each owner rank for in its last sharded window (counts[r], r < world).  Diagnostic; device-syncs. */
+int sg_window_halo_counts(sg_handle h, uint32_t* counts, size_t world);
 
 /* Ascending raw IPs of the last read window's OBIP nodes.                                       */
 int sg_window_outbound_ips(sg_handle h, uint32_t* ips, size_t cap, size_t* n);
@@ -375,14 +384,15 @@ typedef struct sg_geometry {
     uint32_t endpoint_bits;     /* narrow: nb; remainder bits = 2 nb - log2(partitions)                                      */
     uint32_t piece_bytes;       /* record slab bytes per (partition, workgroup) piece                                        */
     uint32_t pass_b_split;      /* narrow: pass-B workgroups (sub-tables) per partition                                      */
-    uint32_t reserved;
+    uint32_t pass_a_teams;      /* narrow: k1a_team_partition with 2 teams of eight waves per workgroup or 1 team of sixteen; 0 = k1a_tile_partition */
 } sg_geometry;
 int sg_geometry_get(sg_handle h, sg_geometry* out);
 
 /* Per-kernel timing, measured on the launch stream.  Groups: 1 = K1 pass A (k1a_partition / k1_resolve_aggregate, one record
  * per batch), 7 = K1 pass B (k1b_merge) — both by the dispatch's own begin/end stamps; 2 = K2 csr_build (two records per window:
  * window bookkeeping, then row pointers + scatter + row sort), 8 = K3 in-statistics, 3 = K3 node + edge features, 4 = K4 (one
- * record per SAGE layer), 5 = K5, 6 = K6 halo kernels — by hipEvent pairs around the launches.  sg_timing_get returns the
+ * record per SAGE layer), 5 = K5, 6 = K6 halo kernels, 9 = the collectives of sg_window_run_sharded (one record per RCCL call) — by hipEvent
+ * pairs around the launches.  sg_timing_get returns the
  * average duration in microseconds per record since sg_timing_reset(), and the number of records.                          */
 int sg_timing_enable(sg_handle h, int on);   /* 0 = off, 1 = every group, else bitmask: bit k = group Kk */
 int sg_timing_reset(sg_handle h);

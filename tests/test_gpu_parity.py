@@ -1198,3 +1198,84 @@ def test_histogram_engine_at_config3_geometry_with_many_ip_blocks():
     compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict(), percentiles=True)
     assert np.array_equal(hist, o.edge_hist()) and g.stats().events_dropped_cap == 0
     g.close()
+
+
+# ---- the RCCL entry point (sg_window_run_sharded): rows checked, not just timed -------------------------------
+def _rccl_rank(rank, world, idfile, outdir, layers):
+    """One rank of the sharded window through the library's own RCCL communicator (also the body of the world = 1 test).
+    The unique id travels through a file (no torch.distributed in the picture: the C ABI is all a Go / C++ host has)."""
+    import time
+    import torch
+    from alaz_amd import engine
+    topo = replay.make_topology(300, 6000, seed=171)
+    ev, labels = replay.make_events(topo, 200_000, seed=172, mixed=True, with_raw_outbound=True, with_reverse=True, fixed_labels=True)
+    torch.cuda.set_device(rank)
+
+    def bcast(raw):
+        if rank == 0:
+            with open(idfile + ".tmp", "wb") as f: f.write(raw)
+            os.replace(idfile + ".tmp", idfile)
+            return raw
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            if time.time() - t0 > 120: raise RuntimeError("no unique id from rank 0")
+            time.sleep(0.01)
+        return open(idfile, "rb").read()
+    comm = engine.RcclComm(rank, world, rank, bcast)
+    g = engine.ServiceGraph(max_known_nodes=topo.n_nodes + 8, max_edges=16384, layers=layers, max_labels=128, max_outbound_ips=512,
+                            device=rank, rank=rank, world=world, max_window_events=len(ev))
+    g.set_clock(*CLOCK); g.load_weights(weights.make_weights(layers))
+    shim = HostShim(); shim.apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
+    mine = ev[g.route(ev, world) == rank] if world > 1 else ev
+    st = torch.cuda.Stream(torch.device("cuda", rank))
+    dev = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy()).to(torch.device("cuda", rank))
+    outs = []
+    for _ in range(2):                                               # two windows through the same engine and communicator
+        g.ingest_device(dev.data_ptr(), len(mine), st.cuda_stream)
+        g.window_run_sharded(comm, st.cuda_stream)
+        outs.append(g.window_read().copy())
+    assert outs[0].tobytes() == outs[1].tobytes()
+    s = g.stats()
+    assert s.events_dropped_cap + s.events_misrouted + s.halo_overflow == 0
+    np.save(os.path.join(outdir, f"rows_{rank}.npy"), outs[0]); np.save(os.path.join(outdir, f"obips_{rank}.npy"), g.outbound_ips())
+    comm.close(); g.close()
+
+
+def _rccl_check(outdir, world, layers):
+    from oracle import pyoracle
+    topo = replay.make_topology(300, 6000, seed=171)
+    ev, labels = replay.make_events(topo, 200_000, seed=172, mixed=True, with_raw_outbound=True, with_reverse=True, fixed_labels=True)
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(layers), layers)
+    rows = np.concatenate([np.load(os.path.join(outdir, f"rows_{r}.npy")) for r in range(world)])
+    obips = np.load(os.path.join(outdir, "obips_0.npy"))
+    assert all(np.array_equal(obips, np.load(os.path.join(outdir, f"obips_{r}.npy"))) for r in range(world))   # identical node numbering everywhere
+    shim = HostShim()
+    for kind, et, uid, ip in topo.k8s_ops():
+        if not (kind == "pod" and ip == ""): shim.intern(uid, "pod" if kind == "pod" else "service")
+    got = engine_edge_dict(rows, shim, labels, obips)
+    assert len(got) == len(rows)                                     # no edge on two shards
+    assert compare_edge_dicts(got, o.edge_dict()) <= 1e-5
+    assert np.array_equal(obips, o.outbound_ips())
+
+
+@pytest.mark.parametrize("layers", [2])
+def test_rccl_entry_point_world1_rows_against_the_oracle(layers, tmp_path):
+    """sg_comm_create + sg_window_run_sharded at world = 1 (what `bench.py` under SG_FORCE_SHARDED times): the staged pipeline with the
+    collectives issued on RCCL from inside the library — rows row for row against the oracle, two windows."""
+    _rccl_rank(0, 1, str(tmp_path / "id"), str(tmp_path), layers)
+    _rccl_check(str(tmp_path), 1, layers)
+
+
+def test_rccl_entry_point_two_ranks_rows_against_the_oracle(tmp_path):
+    """The same with two processes on two GPUs (grouped ncclSend / ncclRecv all-to-all, all-gather, all-reduce over xGMI): the
+    concatenated rows of the two shards against the oracle.  Skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_rccl_rank, args=(r, 2, str(tmp_path / "id"), str(tmp_path), 2)) for r in range(2)]
+    for p in ps: p.start()
+    for p in ps: p.join(timeout=600)
+    assert all(p.exitcode == 0 for p in ps)
+    _rccl_check(str(tmp_path), 2, 2)

@@ -52,7 +52,7 @@ if st[3][:, 0].max() > 0:                                            # k3_in_par
         print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
 if st[2][:, 0].max() > 0:                                            # narrow pass A: wave 0's accumulated clock ticks per phase (kernel slot 2)
     a = st[2].astype(np.int64); a = a[a[:, 0] != 0]
-    for k, nm in enumerate(("P1 fold", "barrier-1 wait", "P2 scan", "P3 drop", "barrier-3 wait", "P4 copy-out")):
+    for k, nm in enumerate(("P1 fold", "barrier-1 wait", "P2 scan", "P3 drop", "barrier-3 wait", "P4 copy-out", "(P1: load waits)", "(P1: group-0 join)")):
         col = a[:, k] / 100.0
         print(f"  sum {nm:<16} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
 g.close()
