@@ -170,7 +170,7 @@ bool k1a_geometry(sg_engine* e) {
         // the two-team kernel is instantiated for 256 / 512 / 1024 partitions, 768 threads, the one-thread-per-position copy-out (2 nb <= 31)
         // and a join blob its prologue can stage; everything else keeps the one-team kernel
         const int teams = 2, nt = 768;
-        const bool team_ok = (d.np == 256 || d.np == 512 || d.np == 1024) && 2 * d.nb <= 31 && l1b + (e->l2_u16 || true ? l2b : l2b) <= (size_t)K1A_NJ * 768 * 16;
+        const bool team_ok = (d.np == 256 || d.np == 512 || d.np == 1024) && 2 * d.nb <= 31 && (size_t)d.np * d.nwg * d.punits * 8 < ((size_t)1 << 31) && l1b + (e->l2_u16 || true ? l2b : l2b) <= (size_t)K1A_NJ * 768 * 16;
         e->k1a_teams = (u32)teams; e->k1a_nt = (u32)nt;
         const size_t fixed_team = K1M_LDS_FIXED(d.np, teams, nt) + l1b;
         auto pick = [&](size_t fixed, u32 ct_min, u32& ct, bool& in_lds) {
@@ -278,6 +278,11 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     const size_t kMaxHist = (size_t)65535 * 256;
     if (e->d.hist && e->d.variant == 0 && n > kMaxHist) {
         for (size_t o = 0; o < n; o += kMaxHist) { const int rc = launch_k1(e, d_ev + o, std::min(kMaxHist, n - o), s); if (rc) return rc; }
+        return SG_OK;
+    }
+    const size_t kMaxTeam = (size_t)1 << 25;                             // k1a_team_partition addresses a launch's events with byte offsets below 2 GiB
+    if (e->d.variant == 0 && e->d.narrow && e->k1a_team && n > kMaxTeam) {
+        for (size_t o = 0; o < n; o += kMaxTeam) { const int rc = launch_k1(e, d_ev + o, std::min(kMaxTeam, n - o), s); if (rc) return rc; }
         return SG_OK;
     }
     int rc = sync_tables(e, s);

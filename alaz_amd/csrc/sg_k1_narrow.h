@@ -601,6 +601,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             live[k2] = true;
             if (!(d.ablate & 0x20u)) rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], oq & (SG_DEG_REP - 1))], 1u);   // arrival order inside the row's replica
         }
+        // (everything that does not need the returned rank first: the device atomics' round trip passes under these stores)
 #pragma unroll
         for (int k2 = 0; k2 < SPT; k2++) {
             if (!live[k2]) continue;
@@ -609,8 +610,9 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             d.e_from[slot] = f[k2]; d.e_to[slot] = to[k2];
             ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
             o[0] = make_ulonglong2(hacc[sl], hacc[HT + sl]); o[1] = make_ulonglong2(hacc[2 * HT + sl], hacc[3 * HT + sl]);
-            d.e_rank[slot] = rk[k2];
         }
+#pragma unroll
+        for (int k2 = 0; k2 < SPT; k2++) if (live[k2]) d.e_rank[(size_t)oq * d.pcap + oi[k2]] = rk[k2];
     }
     __syncthreads();
     SG_STAMP(d, 1, 5);

@@ -21,6 +21,7 @@
 // Integer adds / max only: bit-exact whatever the order (the three pass-A kernels run the same parity tests).
 #pragma once
 
+#define K1M_OOB     0x80000000u   // buffer offset of a lane without work (out of range of every buffer the kernel addresses)
 #define K1M_RARE    0xFFFFFFFEu   // parked-record tag: a rare event, joined by the general path at the end of its tile
 // LDS besides the cache and the join tables: piece counters + per team 4 counter arrays, statistics + barrier words, tile(s) of 8 records per thread (+ trash words)
 #define K1M_LDS_FIXED(np, teams, nt) ((size_t)(np) * 4 * (2 + 4 * (teams)) + 128 + ((size_t)(nt) * 8 + 4) * 8)
@@ -114,13 +115,25 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
         asm volatile("" : : : "memory");
     };
 
-    // events (base) + k * 512, k = 0..3, below `cend`; out-of-range lanes re-read the group's first event and ignore it
-#define K1M_ISSUE(S, base, cend, cfirst)                                                                                \
-        { const u64 j0 = (base), j1 = j0 + K1M_TT, j2 = j1 + K1M_TT, j3 = j2 + K1M_TT;                                      \
-          const uint4* q0 = pe + 2 * (j0 < (cend) ? j0 : (cfirst)); const uint4* q1 = pe + 2 * (j1 < (cend) ? j1 : (cfirst)); \
-          const uint4* q2 = pe + 2 * (j2 < (cend) ? j2 : (cfirst)); const uint4* q3 = pe + 2 * (j3 < (cend) ? j3 : (cfirst)); \
-          gload16_issue(ea##S##0, q0); gload16_issue(eb##S##0, q0 + 1); gload16_issue(ea##S##1, q1); gload16_issue(eb##S##1, q1 + 1);   \
-          gload16_issue(ea##S##2, q2); gload16_issue(eb##S##2, q2 + 1); gload16_issue(ea##S##3, q3); gload16_issue(eb##S##3, q3 + 1); }
+    // The events of a group: (first) + tq + k * TT, k = 0..3, for the thread index tq, while below the group's count.  Buffer loads: a lane
+    // beyond the count gets an out-of-range offset and the hardware returns zeros without touching memory — no 64-bit address select per load, no
+    // re-read of a dummy event (it is ignored by its in-range flag anyway).  Two 16-byte halves per event, one offset register.
+    // (K1M_OOB, the offset of a lane without work: 2 GiB — every buffer here is shorter (the host sees to it).  NOT ~0: the range check adds
+    // the access size with 32-bit wrap-around, 0xFFFFFFFF + 8 = 7 is "in range" and the store lands 4 GiB behind the base: a memory fault.)
+    typedef u32 v4u32_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t ev_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<sg_event*>(ev), 0, (int)(u32)(n * 32u), 0x00020000);
+#ifdef SG_K1M_BUFFER_LOADS
+#define K1M_LD(A, B, vo) asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16" : "=&v"(A), "=&v"(B) : "v"(vo), "s"(ev_rsrc) : "memory")
+#else
+    // (measured: the same loads as buffer_load ... offen made the launch 178 us instead of ~120 on one box; plain global loads, the
+    // address of a lane without work = the batch's first event, ignored by its in-range flag)
+#define K1M_LD(A, B, vo) { const uint4* q_ = pe + ((vo) == K1M_OOB ? 0u : ((vo) >> 4)); gload16_issue(A, q_); gload16_issue(B, q_ + 1); }
+#endif
+#define K1M_ISSUE(S, tq, first, count)                                                                                  \
+        { const u32 x0 = (tq), x1 = x0 + K1M_TT, x2 = x1 + K1M_TT, x3 = x2 + K1M_TT, fb = (first) * 32u;                  \
+          const u32 o0 = x0 < (count) ? fb + x0 * 32u : K1M_OOB, o1 = x1 < (count) ? fb + x1 * 32u : K1M_OOB;               \
+          const u32 o2 = x2 < (count) ? fb + x2 * 32u : K1M_OOB, o3 = x3 < (count) ? fb + x3 * 32u : K1M_OOB;               \
+          K1M_LD(ea##S##0, eb##S##0, o0); K1M_LD(ea##S##1, eb##S##1, o1); K1M_LD(ea##S##2, eb##S##2, o2); K1M_LD(ea##S##3, eb##S##3, o3); }
     // cache fold of one accepted event into a slot it owns
     auto cache_add = [&](u32 slot, u64 dur, u32 err) {
         u64 ssq;
@@ -291,6 +304,8 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     const u32 rb = d.rb;
     u64* const slab_w = d.slab8 + (size_t)w * d.punits;                  // piece (p, this workgroup) = slab_w + p * nwpun
     const u32 nwpun = d.nwg * d.punits;
+    // (the slab as a buffer: the host takes this kernel only when the whole slab is below 4 GiB)
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(slab_w, 0, (int)(u32)(((size_t)NP * d.nwg - w) * d.punits * 8u), 0x00020000);
     // P4 of a tile: copy its runs to the pieces — adjacent lanes, adjacent addresses.  It runs at the TOP of the team's next tile, behind
     // that tile's first loads.  Legal anywhere between the team barrier behind P3 and the next one behind P1: the tile, the offsets, the
     // piece bases and this tile's run counters are not written before that.
@@ -318,7 +333,9 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
                 const u32 i = tq + k * K1M_TT, h = (u32)(rec[k] >> 32), b = (h >> rb) & pbm;
                 const u32 pos = pb_[k] + (i - bo_[k]);
                 const bool valid = i < total;
-                if (valid & (pos < sn)) slab_w[(u64)b * nwpun + pos] = (rec[k] & 0xFFFFFFFFull) | ((u64)(h & strip) << 32);
+                if (d.ablate & 0x2u) { if (valid & (pos < sn)) slab_w[(u64)b * nwpun + pos] = (rec[k] & 0xFFFFFFFFull) | ((u64)(h & strip) << 32); }
+                else { v2u_t dv; dv.x = (u32)rec[k]; dv.y = h & strip;           // (a lane without a record, or beyond the piece: out-of-range offset, dropped by the hardware)
+                  __builtin_amdgcn_raw_buffer_store_b64(dv, slab_rsrc, (valid & (pos < sn)) ? (b * nwpun + pos) * 8u : K1M_OOB, 0, 0); }
                 ovm |= (valid & (pos >= sn)) ? (1u << k) : 0u;
             }
             if (__builtin_amdgcn_ballot_w64(ovm != 0)) {
@@ -353,8 +370,11 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
 #else
     constexpr bool stamp = false;                                    // (phase clocks of wave 0: build with -DSG_K1_PHASE_STAMPS; they cost a dozen registers)
 #endif
-    auto gbounds = [&](const u64 g, const u64 fallback, u64& cb, u64& ce) {     // events [cb, ce) of group g; an absent group: an empty range at `fallback`
-        if (g < ngroup) { cb = g * grp; ce = cb + grp < end ? cb + grp : end; } else { cb = fallback; ce = fallback; }
+    // events [first, first + count) of group g (count 0: no such group).  A launch has fewer than 2^27 events (the host splits larger
+    // batches): event indices and byte offsets fit 32 bits
+    const u32 n32 = (u32)n, ngroup32 = (u32)ngroup;
+    auto gbounds = [&](const u32 g, u32& first, u32& count) {
+        first = g * grp; count = g < ngroup32 ? (first + grp < n32 ? grp : n32 - first) : 0u;
     };
     for (u64 j = unit; j < ntile; j += units, cur ^= 1u) {
         u32* bc = bcnt + cur * NP;
@@ -369,18 +389,17 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
             // ~25 % duty — 32 KB in flight per CU on average with one group of a 1024-thread workgroup, i.e. ~12 GB/s per CU at 3 us of loaded
             // latency, which is what it ran at.  (Keeping a set in flight ACROSS the tile loop's back edge was tried: the compiler spills the
             // in-flight registers there — tools/check_asm_loads.py — so the loads stay inside one straight stretch of the tile.)
-            u64 cb0, ce0, cb1, ce1;
-            gbounds(2 * j, 0, cb0, ce0); gbounds(2 * j + 1, cb0, cb1, ce1);
-            const u64 i0 = cb0 + ttl, i1 = cb1 + ttl;
+            u32 f0, c0, f1, c1;
+            gbounds(2u * (u32)j, f0, c0); gbounds(2u * (u32)j + 1u, f1, c1);
             u32 Lm[4], Rm[4], du[4], fl[4];
             v4u_t eaa0, eba0, eaa1, eba1, eaa2, eba2, eaa3, eba3, eab0, ebb0, eab1, ebb1, eab2, ebb2, eab3, ebb3;
-            K1M_ISSUE(a, i0, ce0, cb0);
-            K1M_ISSUE(b, i1, ce1, cb1);
+            K1M_ISSUE(a, ttl, f0, c0);
+            K1M_ISSUE(b, ttl, f1, c1);
             if (havep) { const u64 tq = stamp ? wall_clock64() : 0ull; copy_out(pcur); if (stamp) tk_p4 += wall_clock64() - tq; }
             const u64 tl0 = stamp ? wall_clock64() : 0ull;
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(eaa0), "+v"(eba0), "+v"(eaa1), "+v"(eba1), "+v"(eaa2), "+v"(eba2), "+v"(eaa3), "+v"(eba3) : : "memory");
             const u64 tl1 = stamp ? wall_clock64() : 0ull;
-            front4(ttl, (u32)(ce0 - cb0), eaa0, eba0, eaa1, eba1, eaa2, eba2, eaa3, eba3, Lm, Rm, du, fl);
+            front4(ttl, c0, eaa0, eba0, eaa1, eba1, eaa2, eba2, eaa3, eba3, Lm, Rm, du, fl);
             {
                 u32 l4[4], h4[4], p4[4];
                 back4(Lm, Rm, du, fl, bc, l4, h4, p4);
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(eab0), "+v"(ebb0), "+v"(eab1), "+v"(ebb1), "+v"(eab2), "+v"(ebb2), "+v"(eab3), "+v"(ebb3) : : "memory");
             const u64 tl3 = stamp ? wall_clock64() : 0ull;
             if (stamp) { tk_ld += (tl1 - tl0) + (tl3 - tl2); tk_fa += tl2 - tl1; }
-            front4(ttl, (u32)(ce1 - cb1), eab0, ebb0, eab1, ebb1, eab2, ebb2, eab3, ebb3, Lm, Rm, du, fl);
+            front4(ttl, c1, eab0, ebb0, eab1, ebb1, eab2, ebb2, eab3, ebb3, Lm, Rm, du, fl);
             {
                 u32 l4[4], h4[4], p4[4];
                 back4(Lm, Rm, du, fl, bc, l4, h4, p4);
@@ -478,8 +497,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
 #pragma unroll
             for (int i = 0; i < 8; i++) rmask |= (pr[i] == K1M_RARE) ? (1u << i) : 0u;
             if (__builtin_amdgcn_ballot_w64(rmask != 0)) {
-                const u64 g0 = 2 * j, g1 = g0 + 1;
-                const u64 e0 = g0 * grp + ttl, e1 = (g1 < ngroup ? g1 * grp : g0 * grp) + ttl;
+                const u64 e0 = (u64)(2u * (u32)j) * grp + ttl, e1 = (u64)(2u * (u32)j + 1u) * grp + ttl;   // (a rare event is in range: its group exists)
 #pragma unroll 1
                 for (u32 k = 0; k < 8; k++) if ((rmask >> k) & 1u) general((k < 4 ? e0 : e1) + (u64)(k & 3u) * K1M_TT);
             }
