@@ -94,6 +94,7 @@ struct sg_engine {
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
+    u32 k6_epoch = 0;          // k6_halo_lists launch counter (same use)
     u32 rp_epoch = 0;          // k2_rowptr launch counter (tags the per-workgroup totals, so they need no reset)
 
     // windows in flight: every slot has its own window buffers and stream; the members above (d, stream,
@@ -360,6 +361,16 @@ int grid_for(u64 items, int per_block, int cap = 2048) {
     return (int)std::max<u64>(1, std::min<u64>(g, (u64)cap));
 }
 
+// the halo request lists and the active node lists of a sharded window: many workgroups, one launch (SG_K6_ONE_WG=1: the round-3 builder)
+void launch_halo_lists(sg_engine* e, hipStream_t s, u32* req, u32 capp) {
+    static const bool one_wg = std::getenv("SG_K6_ONE_WG") != nullptr;
+    if (one_wg) {
+        if (e->d.ncap <= K6_FLAGS_LDS) hipLaunchKernelGGL(k6_halo_build_padded<true>, dim3(1), dim3(1024), 0, s, e->d, req, capp);
+        else hipLaunchKernelGGL(k6_halo_build_padded<false>, dim3(1), dim3(1024), 0, s, e->d, req, capp);
+        return;
+    }
+    hipLaunchKernelGGL(k6_halo_lists, dim3(((size_t)e->d.ncap + 1023) / 1024), dim3(1024), 0, s, e->d, req, capp, ++e->k6_epoch, 1u);
+}
 // ob_mode 1: collect this engine's own raw outbound IPs; 0: caller's union list (d_union, *d_union_n);
 // 2: all-gathered per-shard lists (d_union = [world][stride], element 0 of a row = count)
 int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union_n, u32 ob_mode = 1, u32 stride = 0, u32 gworld = 0) {
@@ -752,7 +763,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.tile_off, e->ecap / K2_TILE));
         LR(dev_alloc(e, &w.e_slot, ME)); LR(dev_alloc(e, &w.e_from, eslots)); LR(dev_alloc(e, &w.e_to, eslots));
         LR(dev_alloc(e, &w.longrows, (size_t)w.ncap + 1));
-        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS) / K2_RP_ROWS + 1)); LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
+        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS) / K2_RP_ROWS + 1)); LR(dev_alloc(e, &w.k6_tot, (((size_t)w.ncap + 1023) / 1024 + 1) * 16)); LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cs, ME)); LR(dev_alloc(e, &w.csr_from, ME));
         LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));
@@ -1070,8 +1081,7 @@ int sg_halo_build_padded(sg_handle e, uint32_t* d_req, uint32_t capp, void* stre
     hipStream_t s = pick(e, stream);
     Timed t(e, s, 6);
     hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
-    if (e->d.ncap <= K6_FLAGS_LDS) hipLaunchKernelGGL(k6_halo_build_padded<true>, dim3(1), dim3(1024), 0, s, e->d, d_req, capp);
-    else hipLaunchKernelGGL(k6_halo_build_padded<false>, dim3(1), dim3(1024), 0, s, e->d, d_req, capp);
+    launch_halo_lists(e, s, d_req, capp);
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
@@ -1296,8 +1306,7 @@ int st_features(void* p) { SCX; return do_features(e, s); }
 int st_halo_build(void* p) {
     SCX; Timed t(e, s, 6);
     hipLaunchKernelGGL(k6_halo_mark, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, e->d);
-    if (e->d.ncap <= K6_FLAGS_LDS) hipLaunchKernelGGL(k6_halo_build_padded<true>, dim3(1), dim3(1024), 0, s, e->d, e->xc.req, e->xc.capp);
-    else hipLaunchKernelGGL(k6_halo_build_padded<false>, dim3(1), dim3(1024), 0, s, e->d, e->xc.req, e->xc.capp);
+    launch_halo_lists(e, s, e->xc.req, e->xc.capp);
     return hipGetLastError() == hipSuccess ? SG_OK : SG_ENODEV;
 }
 int st_layer(void* p, uint32_t l) { SCX; return do_layer(e, l, s, false); }

@@ -147,6 +147,7 @@ struct Dev {
     u32* alive_csr;                           // [max_edges] CSR order: open connections per edge
     u32* act_l; u32* act_p;                   // [ncap] world > 1: active node lists (ascending), built with the halo requests
     u64* rp_tot;                              // [ceil((ncap+1)/K2_RP_ROWS)] k2_rowptr: (epoch << 32 | rows' edge total) per workgroup
+    u64* k6_tot;                              // [ceil(ncap/1024) + 1][16] k6_halo_lists: (epoch << 32 | members) per workgroup and list
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs
     u32* tile_cnt;  u32* tile_off;            // compaction scratch

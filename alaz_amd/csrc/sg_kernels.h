@@ -2550,6 +2550,78 @@ __global__ __launch_bounds__(1024) void k6_halo_build_padded(Dev d, u32* req, u3
     __shared__ unsigned char fl[K6_FLAGS_LDS];
     if (SMALL) build_lists_staged<true>(d, req, capp, fl, wsum); else build_lists(d, req, capp, true, fl, wsum);
 }
+// Round 4: the same lists by MANY workgroups in one launch (the one-workgroup builder above was 36 us of a C4 shard's window: a single
+// CU walking every node).  Workgroup b owns the 1024 nodes from 1024 b, a thread per node: the node's flags (five loads, in flight
+// together), the membership of the ten lists by wave ballots, the wave's counts through LDS; then the workgroup publishes its ten
+// totals tagged with the launch epoch, sums those of the workgroups before it (they are resident: the grid is ncap / 1024 workgroups,
+// dispatched in order — the assumption k2_rowptr makes) and writes its members at base + wave offset + rank among the lower lanes:
+// ascending by construction, adjacent lanes write adjacent entries.  No reset, no second kernel, no flag array in memory.
+#define K6M_LISTS 10
+__global__ __launch_bounds__(1024) void k6_halo_lists(Dev d, u32* req, u32 capp, u32 epoch, u32 want_req) {
+    const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
+    const u32 W = d.world < 8 ? d.world : 8;
+    const u32 b = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6, v = b * 1024u + t;
+    if (b * 1024u >= N && b != 0) return;                            // beyond the last node (grid sized for ncap)
+    __shared__ u32 wcnt[K6M_LISTS][16];
+    __shared__ u32 base[K6M_LISTS], tot[K6M_LISTS];
+    const u32 nkl = nk + nl;
+    u32 f = 0;
+    if (v < N) {
+        const u32 cur = d.cursor[v], r0 = d.rowptr[v], r1 = d.rowptr[v + 1];
+        const u64 od = d.st_sum[(size_t)v * SG_NODE_STAT_SUM_WORDS + ST_OUT_DEG];
+        const u32 obi = v >= nkl ? d.ob_sorted[v - nkl] : 0u;
+        const bool dst = cur == 0xFFFFFFFFu, src = r1 != r0, has_out = od != 0;
+        f = (dst ? 1u : 0u) | (src ? 2u : 0u) | (has_out ? 4u : 0u);
+        const u32 o = (v < nkl ? owner_hash_ref(ref_of_dense(v, nk, nl)) : owner_hash_obip(obi)) % d.world;   // = owner_of_dense(v)
+        if (dst && has_out && o != d.rank) f |= (o + 1) << 3;
+    }
+    // list j: 0 = act_l (layer output computed here), 1 = act_p (score projections needed here), 2 + k = halo nodes owned by shard k
+    const u64 lt = (1ull << lane) - 1ull;
+    const bool in0 = (f & 2u) || ((f & 1u) && !(f & 4u)), in1 = (f & 3u) != 0;
+    const u32 own1 = f >> 3;                                         // owner + 1 of a halo node, else 0
+    const u64 m0 = __ballot(in0 ? 1 : 0), m1 = __ballot(in1 ? 1 : 0);
+    u64 mk[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) mk[k] = want_req ? __ballot(own1 == (u32)k + 1 ? 1 : 0) : 0ull;
+    if (lane == 0) {
+        wcnt[0][wave] = (u32)__popcll(m0); wcnt[1][wave] = (u32)__popcll(m1);
+#pragma unroll
+        for (int k = 0; k < 8; k++) wcnt[2 + k][wave] = (u32)__popcll(mk[k]);
+    }
+    __syncthreads();
+    if (t < K6M_LISTS) {                                             // thread j: list j's wave counts -> exclusive prefixes, the workgroup's total published,
+        u32 acc = 0;                                                 // the totals of the workgroups before it summed
+        for (u32 w2 = 0; w2 < 16; w2++) { const u32 x = wcnt[t][w2]; wcnt[t][w2] = acc; acc += x; }
+        tot[t] = acc;
+        __atomic_store_n(&d.k6_tot[(size_t)b * 16 + t], ((u64)epoch << 32) | acc, __ATOMIC_RELEASE);
+        u32 pre = 0;
+        for (u32 j = 0; j < b; j++) {
+            u64 x;
+            do { x = __atomic_load_n(&d.k6_tot[(size_t)j * 16 + t], __ATOMIC_ACQUIRE); } while ((u32)(x >> 32) != epoch);
+            pre += (u32)x;
+        }
+        base[t] = pre;
+    }
+    __syncthreads();
+    if (in0) d.act_l[base[0] + wcnt[0][wave] + (u32)__popcll(m0 & lt)] = v;
+    if (in1) d.act_p[base[1] + wcnt[1][wave] + (u32)__popcll(m1 & lt)] = v;
+    if (want_req && own1) {
+        const u32 k = own1 - 1;
+        u64 m = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) m = k == (u32)q ? mk[q] : m;
+        const u32 pos = base[2 + k] + wcnt[2 + k][wave] + (u32)__popcll(m & lt);
+        if (pos < capp) req[(size_t)k * (capp + 1) + 1 + pos] = v;
+    }
+    if (t == 0 && (b + 1) * 1024u >= N) {                            // the workgroup of the last node knows the list lengths
+        d.ctr[C_ACT_L] = base[0] + tot[0]; d.ctr[C_ACT_P] = base[1] + tot[1];
+        if (want_req) for (u32 k = 0; k < W; k++) {
+            u32 c = base[2 + k] + tot[2 + k];
+            if (c > capp) { atomicAdd(&d.ctr[C_HALO_OVF], (u64)(c - capp)); c = capp; }
+            req[(size_t)k * (capp + 1)] = c;
+        }
+    }
+}
 // rows[r][i][:] = feat[lists[r][1 + i]][:] for i < lists[r][0]   (pack: lists = what shard r asked of me)
 __global__ __launch_bounds__(256) void k6_pack_padded(const float* __restrict__ feat, const u32* __restrict__ lists, u32 capp, u32 world, float* __restrict__ rows) {
     const u64 total = (u64)world * capp * 16;

@@ -214,9 +214,9 @@ def pmc_traffic(config):
         with open(path) as f:
             j = json.load(f)
         src = f"profiles/pmc_k1_c{config}.json ({j.get('round', '?')}, git {j.get('git_head', '?')})"
-        return float(j["k1_total_hbm_bytes"]), src, j.get("kernel_src_sha") == kernel_src_sha()
+        return float(j["k1_total_hbm_bytes"]), src, j.get("kernel_src_sha") == kernel_src_sha(), j.get("k1_total_hbm_bytes_calibrated")
     except Exception:
-        return None, None, None
+        return None, None, None, None
 
 
 def measured_copy_gbs(torch):
@@ -412,7 +412,7 @@ def bench_single(a, device):
     alg = algorithmic_bytes(Ev, E, N, L)
     alg_k1 = alg["K1a"] + alg["K1b"]
     achieved = alg_k1 / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
-    traffic, traffic_src, traffic_match = pmc_traffic(cfgno)
+    traffic, traffic_src, traffic_match, traffic_cal = pmc_traffic(cfgno)
     kn = g.k1_kernels(); geo = g.geometry()
     copy_gbs = None if a.profile_mode else measured_copy_gbs(torch)
     kern_us = {"K1a": k1a[0], "K1b": k1b[0], **grp}
@@ -436,6 +436,7 @@ def bench_single(a, device):
                    "parallelism": "1 GPU" if a.shard_of == 1 else f"1 GPU standing in for one rank of {a.shard_of} (no exchanges: K1 and the local window close of the shard's shape)"},
         "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = " + " + ".join(kn), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_calibrated": traffic_cal,   # the same counters divided by their reading for known byte counts in K1's access patterns (profiles/*_pmc_calibration.json)
                      "traffic_source": traffic_src, "traffic_measured_in_run": False, "traffic_build_matches": traffic_match,
                      "measured_copy_GBs": copy_gbs,
                      "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,

@@ -13,6 +13,7 @@
 #   sharded1:TAG             bench.py under torch.distributed.run at world = 1 with the sharded pipeline forced (RCCL path)
 #   probe:TAG:WORLD[:CFG]    rocprofv3 kernel stats of tools/shard_scale_probe.py WORLD 6 fixed CFG (per-shard kernel time of C4)
 #   c5stream:TAG[:ARGS]      tools/c5_stream.py ARGS -> TAG_c5_stream.json
+#   calib:TAG                tools/pmc_calib under FETCH_SIZE / WRITE_SIZE -> TAG_pmc_calibration.json (factors reported / real bytes)
 #   box:TAG                  what this box is: clocks, power cap, memory / compute partition mode -> TAG_box.txt (the pool's boxes differ by up to 30 % on pass A)
 #   run:CMD                  any command (',' = blank)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -65,6 +66,10 @@ for step in "$@"; do
         { grep -v amdgpu.ids "$O/${a1}_probe_w$a2.log" | tail -n 4; python "$R/tools/rocpd_stats.py" "$O/prof_probe/kt_results.db"; } > "$O/${a1}_shard_of_${a2}_kernel_stats.txt"
         head -n 40 "$O/${a1}_shard_of_${a2}_kernel_stats.txt"; rm -rf "$O/prof_probe" ) ;;
     c5stream) timeout 400 python tools/c5_stream.py $a2 > "$O/${a1}_c5_stream.json" 2> "$O/${a1}_c5_stream.err"; echo "rc=$?"; cut -c1-900 "$O/${a1}_c5_stream.json" ;;
+    calib)   # known-byte-count kernels in K1's access patterns under FETCH_SIZE / WRITE_SIZE -> TAG_pmc_calibration.json
+      ( cd /tmp
+        for c in FETCH_SIZE WRITE_SIZE; do rm -rf "$O/cal_$c"; timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/cal_$c" -o pmc -- "$R/tools/pmc_calib" > "$O/cal_$c.log" 2>&1; done
+        python "$R/tools/pmc_calib_json.py" "$O/cal_FETCH_SIZE" "$O/cal_WRITE_SIZE" "$a1" "$HEAD_ID" > "$O/${a1}_pmc_calibration.json"; cat "$O/${a1}_pmc_calibration.json"; rm -rf "$O/cal_FETCH_SIZE" "$O/cal_WRITE_SIZE" ) ;;
     box) { echo "# head $HEAD_ID"; rocm-smi --showclocks --showpower --showmaxpower --showperflevel --showmemorypartition --showcomputepartition 2>&1 | grep -v "^$\|====="; } > "$O/${a1}_box.txt" 2>&1; grep -i "sclk\|mclk\|fclk\|power\|partition" "$O/${a1}_box.txt" | head -n 14 ;;
     run) timeout 900 bash -c "$a1" 2>&1 | tail -n 40 ;;
     *) echo "unknown step $name" ;;
