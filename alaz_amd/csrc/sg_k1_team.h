@@ -26,6 +26,13 @@
 // LDS besides the cache and the join tables: piece counters + per team 4 counter arrays, statistics + barrier words, tile(s) of 8 records per thread (+ trash words)
 #define K1M_LDS_FIXED(np, teams, nt) ((size_t)(np) * 4 * (2 + 4 * (teams)) + 128 + ((size_t)(nt) * 8 + 4) * 8)
 
+// tiles of a launch of n events (the kernel's own arithmetic, for the host's ticket accounting)
+static inline unsigned long long k1m_tiles(unsigned long long n, unsigned nwg, unsigned teams, unsigned nt) {
+    const unsigned long long units = (unsigned long long)teams * nwg, tt = nt / teams, per = (n + units - 1) / units;
+    const unsigned long long grp = per >= 4 * tt ? 4 * tt : (per + tt - 1) / tt * tt;
+    const unsigned long long ngroup = (n + grp - 1) / grp;
+    return (ngroup + 1) >> 1;
+}
 // L2M: level 2 of the join 0 = read from global memory, 1 = staged in LDS as u32, 2 = staged as u16 entries kind << 14 | id
 // TEAMS: 2 = two teams (software team barriers), 1 = one team (the hardware barrier; same code otherwise: the A/B).
 // NT: threads per workgroup, 1024 (four waves per SIMD: 128 registers per lane) or 768 (three waves per SIMD: 168 registers — the batched
@@ -376,7 +383,15 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     auto gbounds = [&](const u32 g, u32& first, u32& count) {
         first = g * grp; count = g < ngroup32 ? (first + grp < n32 ? grp : n32 - first) : 0u;
     };
-    for (u64 j = unit; j < ntile; j += units, cur ^= 1u) {
+    // Tiles are handed out DYNAMICALLY: a team's first tile is its unit number, every further one a ticket from the window slot's device
+    // counter (tile = units + ticket - base; the host advances the base by what a launch consumes: one ticket per tile beyond the first
+    // round + one failing ticket per active team).  On static shares the teams of a launch ended 110 .. 140 us apart.  The ticket is drawn
+    // by one lane at the top of the tile before (a returning device atomic issued by hand: its round trip passes under the joins) and
+    // handed to the team through LDS across the tile's barriers.  (SG_ABLATE & 0x4: static shares.)
+    const bool dyn = !(d.ablate & 0x4u);
+    u32* nxt = bar + 8 * team + 4;
+    const u32 ntile32 = (u32)ntile;
+    for (u32 j = unit; j < ntile32; cur ^= 1u) {
         u32* bc = bcnt + cur * NP;
         u32 lo[8], hi[8], pr[8];
         // the thread's indices, opaque per tile: whatever is derived from them (tile / counter / event addresses) is then computed where it is
@@ -390,11 +405,14 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
             // latency, which is what it ran at.  (Keeping a set in flight ACROSS the tile loop's back edge was tried: the compiler spills the
             // in-flight registers there — tools/check_asm_loads.py — so the loads stay inside one straight stretch of the tile.)
             u32 f0, c0, f1, c1;
-            gbounds(2u * (u32)j, f0, c0); gbounds(2u * (u32)j + 1u, f1, c1);
+            gbounds(2u * j, f0, c0); gbounds(2u * j + 1u, f1, c1);
             u32 Lm[4], Rm[4], du[4], fl[4];
             v4u_t eaa0, eba0, eaa1, eba1, eaa2, eba2, eaa3, eba3, eab0, ebb0, eab1, ebb1, eab2, ebb2, eab3, ebb3;
             K1M_ISSUE(a, ttl, f0, c0);
             K1M_ISSUE(b, ttl, f1, c1);
+            u32 tkv = 0;
+            const bool drawer = dyn && wv == 0 && lanel == 0;
+            if (drawer) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(tkv) : "v"(d.k1a_ticket), "v"(1u) : "memory");
             if (havep) { const u64 tq = stamp ? wall_clock64() : 0ull; copy_out(pcur); if (stamp) tk_p4 += wall_clock64() - tq; }
             const u64 tl0 = stamp ? wall_clock64() : 0ull;
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(eaa0), "+v"(eba0), "+v"(eaa1), "+v"(eba1), "+v"(eaa2), "+v"(eba2), "+v"(eaa3), "+v"(eba3) : : "memory");
@@ -407,9 +425,10 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
                 for (int i = 0; i < 4; i++) { lo[i] = l4[i]; hi[i] = h4[i]; pr[i] = p4[i]; }
             }
             const u64 tl2 = stamp ? wall_clock64() : 0ull;
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(eab0), "+v"(ebb0), "+v"(eab1), "+v"(ebb1), "+v"(eab2), "+v"(ebb2), "+v"(eab3), "+v"(ebb3) : : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(eab0), "+v"(ebb0), "+v"(eab1), "+v"(ebb1), "+v"(eab2), "+v"(ebb2), "+v"(eab3), "+v"(ebb3), "+v"(tkv) : : "memory");
             const u64 tl3 = stamp ? wall_clock64() : 0ull;
             if (stamp) { tk_ld += (tl1 - tl0) + (tl3 - tl2); tk_fa += tl2 - tl1; }
+            if (drawer) { asm volatile("" : "+v"(tkv)); *nxt = tkv - d.k1a_ticket_base + units; }   // (the wait above covered the atomic: it is the youngest operation)
             front4(ttl, c1, eab0, ebb0, eab1, ebb1, eab2, ebb2, eab3, ebb3, Lm, Rm, du, fl);
             {
                 u32 l4[4], h4[4], p4[4];
@@ -497,13 +516,14 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
 #pragma unroll
             for (int i = 0; i < 8; i++) rmask |= (pr[i] == K1M_RARE) ? (1u << i) : 0u;
             if (__builtin_amdgcn_ballot_w64(rmask != 0)) {
-                const u64 e0 = (u64)(2u * (u32)j) * grp + ttl, e1 = (u64)(2u * (u32)j + 1u) * grp + ttl;   // (a rare event is in range: its group exists)
+                const u64 e0 = (u64)(2u * j) * grp + ttl, e1 = (u64)(2u * j + 1u) * grp + ttl;   // (a rare event is in range: its group exists)
 #pragma unroll 1
                 for (u32 k = 0; k < 8; k++) if ((rmask >> k) & 1u) general((k < 4 ? e0 : e1) + (u64)(k & 3u) * K1M_TT);
             }
         }
         havep = true; pcur = cur;
         if (stamp) { tk_scan += tk3 - tk2; tk_p3 += tk4 - tk3; tk_b3 += tk5 - tk4; }
+        j = dyn ? (u32)__builtin_amdgcn_readfirstlane((int)lds_fresh_u32(nxt)) : j + units;   // (written before this tile's first barrier, read behind its second)
     }
     if (havep) copy_out(pcur);                                       // the last tile's runs
     SG_STAMP(d, 0, 3);

@@ -39,7 +39,7 @@ def check(asm_text):
             j = i + 1                    # an asm statement may hold several instructions (issues + their wait)
             while j < len(lines) and not lines[j].strip().startswith(";;#ASMEND"):
                 body = lines[j].strip()
-                if body.startswith(("global_load", "buffer_load")):
+                if body.startswith(("global_load", "buffer_load", "global_atomic")):
                     ops = [o.strip() for o in body.split(None, 1)[1].split(",")]
                     # the address operand must not be an in-flight register either
                     for o in ops[1:]:
