@@ -63,12 +63,20 @@ def main():
     ap.add_argument("--mock", action="store_true", help="recording stand-in instead of the engine (CPU smoke test of this harness only)")
     ap.add_argument("--pods", type=int, default=0, help="a small synthetic cluster of this many pods instead of config 5's 100 k (smoke tests)")
     ap.add_argument("--edges", type=int, default=0)
+    ap.add_argument("--shard-of", type=int, default=1, help="config 5 as SPECIFIED is hash-sharded over 8 GPUs: stream ONE shard's share (rate / N, the events of the "
+                                                              "sources shard 0 owns) into an engine of the shard's shape (its edges x 1.25, every IP replicated: "
+                                                              "the narrow-record variant 0) instead of the whole stream into one variant-1 engine")
     a = ap.parse_args()
+    shard_edges = 0
+    if a.shard_of > 1: a.rate = a.rate / a.shard_of
     expand = a.ring == 0
     if expand and not a.pods:
         c5 = replay.CONFIGS[5]
         t_gen = time.perf_counter()
         topo = replay.make_topology(c5["pods"], c5["edges"], replay.SEED_BASE + 5)
+        if a.shard_of > 1:
+            from alaz_amd import sharded
+            topo = sharded.shard_view(topo, 0, a.shard_of); shard_edges = len(topo.edge_src)
         ev, labels = replay.make_events(topo, a.expand, replay.SEED_BASE + 5, mixed=True)
         pod_ips, svc_ips = topo.pod_ips, topo.svc_ips
         gen_s = time.perf_counter() - t_gen
@@ -83,6 +91,7 @@ def main():
     wire = None if expand else np.frombuffer(replay.to_wire(ev, labels), dtype=np.uint8).copy()
     n_nodes = len(pod_ips) + len(svc_ips)
     max_edges = int(c["edges"] * 1.1) if not a.pods else max(1 << 16, 4 * (a.edges or a.pods * 20))
+    if shard_edges: max_edges = int(shard_edges * 1.25) + 4096
     cfg = engine.make_config(max_known_nodes=n_nodes + 1024, max_edges=max_edges, layers=c["layers"], max_labels=256, max_outbound_ips=256,
                              max_batch=1 << 18, max_window_events=int(a.rate * a.window_s * 1.5), windows_in_flight=3)
     t0 = time.perf_counter()
@@ -149,7 +158,8 @@ def main():
     st = engine.SgStats()
     if not a.mock: engine.load_library().sg_stats_get(g.engine_handle, C.byref(st))
     ctr = g.counters()
-    res = {"workload": f"{'C5' if not a.pods else 'small-cluster'} streaming: {len(pod_ips)} pods / {len(svc_ips)} services, raw 1096-B l7_event records (70/15/15 HTTP/Kafka/Postgres) "
+    res = {"shard_of": a.shard_of, "shard_edges": shard_edges,
+           "workload": f"{'C5' if not a.pods else 'small-cluster'}{' (ONE SHARD OF ' + str(a.shard_of) + ')' if a.shard_of > 1 else ''} streaming: {len(pod_ips)} pods / {len(svc_ips)} services, raw 1096-B l7_event records (70/15/15 HTTP/Kafka/Postgres) "
                        f"{'expanded on the fly by the C++ feeders from a ring of ' + str(nrec) + ' packed events drawn from the 20 M-edge graph' if expand else 'from a ring of ' + str(nrec) + ' pre-built records'}, "
                        f"{a.feeders} feeder threads -> C++ GraphDS::IngestWire -> sg_ingest; one window per {a.window_s:g} s closed by a dispatcher thread",
            "target_events_per_s": a.rate, "offered_events_per_s": sum(fed) / dt, "windows": a.windows,
