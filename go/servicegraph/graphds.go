@@ -162,6 +162,20 @@ func New(inner datastore.DataStore, c Config) (*GraphDS, error) {
 // Close flushes nothing and frees the engine; no call may be in flight.
 func (g *GraphDS) Close() { C.sg_destroy(g.h) }
 
+// Stats: what the engine dropped or waited for since New (sg_stats, ABI 4).  DroppedRing are batches the staging ring had no room
+// for (sg_ingest never blocks: the reference's PersistRequest would, datastore/backend.go:844); IngestWaits the sg_ingest calls that
+// met a window boundary being marked and waited for it — the only wait the library ever imposes on an aggregator goroutine.
+type Stats struct {
+	EventsIn, DroppedSrc, DroppedRing, DroppedCap, Windows, IngestWaits uint64
+}
+
+func (g *GraphDS) Stats() Stats {
+	var st C.sg_stats
+	C.sg_stats_get(g.h, &st)
+	return Stats{EventsIn: uint64(st.events_in), DroppedSrc: uint64(st.events_dropped_src), DroppedRing: uint64(st.events_dropped_ring),
+		DroppedCap: uint64(st.events_dropped_cap), Windows: uint64(st.windows), IngestWaits: uint64(st.ingest_waits)}
+}
+
 // SetClock hands over FirstKernelTime / FirstUserspaceTime (ebpf/l7_req/l7.go:707-710) for the early tap's StartTime.
 func (g *GraphDS) SetClock(firstKernelNs, firstUserNs uint64) {
 	C.sg_set_clock(g.h, C.uint64_t(firstKernelNs), C.uint64_t(firstUserNs))
