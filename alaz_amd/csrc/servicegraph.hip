@@ -305,7 +305,13 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
 #define K1M_GO(L2, SH) do { if (e->d.np == 256) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 8>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
                             else if (e->d.np == 512) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 9>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
                             else hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 10>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); } while (0)
+        da.k1a_rot = e->d.k1a_rot;
+        if (e->d.narrow && !e->k1a_team) {                           // the next launch's first chunk goes to the workgroup behind this launch's last one
+            const u64 per = (n + e->d.nwg - 1) / e->d.nwg, chunk = per >= 4096 ? 4096 : (per + 1023) / 1024 * 1024;
+            e->d.k1a_rot = (u32)((e->d.k1a_rot + (n + chunk - 1) / chunk) % e->d.nwg);
+        }
         if (e->d.narrow && e->k1a_team) {
+            e->d.k1a_rot = (u32)((e->d.k1a_rot + k1m_tiles(n, e->d.nwg, e->k1a_teams, e->k1a_nt)) % ((u64)e->k1a_teams * e->d.nwg));
             da.k1a_ticket_base = e->d.k1a_ticket_base;
             {   // what this launch draws from the slot's ticket counter: one per tile beyond every team's first, one failing draw per active team
                 const unsigned long long nt_ = k1m_tiles(n, e->d.nwg, e->k1a_teams, e->k1a_nt), units_ = (unsigned long long)e->k1a_teams * e->d.nwg;
@@ -768,7 +774,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.tile_off, e->ecap / K2_TILE));
         LR(dev_alloc(e, &w.e_slot, ME)); LR(dev_alloc(e, &w.e_from, eslots)); LR(dev_alloc(e, &w.e_to, eslots));
         LR(dev_alloc(e, &w.longrows, (size_t)w.ncap + 1));
-        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS) / K2_RP_ROWS + 1)); LR(dev_alloc(e, &w.k6_tot, (((size_t)w.ncap + 1023) / 1024 + 1) * 16)); LR(dev_alloc(e, &w.k1a_ticket, 4)); w.k1a_ticket_base = 0; LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
+        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS) / K2_RP_ROWS + 1)); LR(dev_alloc(e, &w.k6_tot, (((size_t)w.ncap + 1023) / 1024 + 1) * 16)); LR(dev_alloc(e, &w.k1a_ticket, 4)); w.k1a_ticket_base = 0; w.k1a_rot = 0; LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cs, ME)); LR(dev_alloc(e, &w.csr_from, ME));
         LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));

@@ -109,7 +109,12 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     const u64 nchunk = (n + chunk - 1) / chunk;
     const u64 end = n;
     const bool first = d.batch_state == 1u;                          // first batch of the window: the headers are zero by definition
-    if ((u64)w >= nchunk) {                                          // no share of this batch: pieces and statistics stay as they are,
+    // chunk c belongs to workgroup (c + rot) % nwg: the host advances `rot` by the chunks of every launch, so that a window fed by many
+    // SMALL batches (a launch of 4 096 events has four chunks) does not put all of its records into the pieces of workgroups 0..3
+    // (round 4: a paced stream of 4 096-event batches into a 2 048-partition engine overflowed exactly those pieces: a third of the
+    // events counted as dropped)
+    const u32 wr = (w + d.nwg - d.k1a_rot % d.nwg) % d.nwg;
+    if ((u64)wr >= nchunk) {                                         // no share of this batch: pieces and statistics stay as they are,
         if (first) for (u32 p = t; p < NP; p += K1T_THREADS) d.hdr8[(size_t)p * d.nwg + w] = make_uint2(0u, 0u);   // but stale headers must go
         return;
     }
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
     bool havep = false; u32 pcur = 0;
     u32 cur = 0;
     u64 tk_p1 = 0, tk_wait = 0, tk_scan = 0, tk_p3 = 0, tk_b3 = 0, tk_p4 = 0;   // SG_ABLATE & 0x100: wave 0's clock ticks per phase
-    for (u64 c0 = w; c0 < nchunk; c0 += (u64)NSUB * d.nwg, cur ^= 1u) {
+    for (u64 c0 = wr; c0 < nchunk; c0 += (u64)NSUB * d.nwg, cur ^= 1u) {
         u32* bc = bcnt + cur * NP;
         u32* fcn = fcn2 + cur * NP;                                  // counts before this tile; the scan writes fcn2[cur ^ 1] = counts behind it
         u32 lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7;

@@ -85,9 +85,11 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     const u32 grp = per >= K1M_GROUP ? K1M_GROUP : (u32)((per + K1M_TT - 1) / K1M_TT * K1M_TT);
     const u64 ngroup = (n + grp - 1) / grp, ntile = (ngroup + 1) >> 1;
     const u64 end = n;
-    const u32 unit = team * d.nwg + w;
+    // (rotated by the tiles of the window's earlier launches: many small batches must not all land on the pieces of the first workgroups)
+    const u32 rot = d.k1a_rot % units;
+    const u32 unit = (team * d.nwg + w + units - rot) % units, unit_other = ((1u - team) * d.nwg + w + units - rot) % units;
     const bool first = d.batch_state == 1u;                          // first batch of the window: the headers are zero by definition
-    if ((u64)w >= ntile) {                                           // no share of this batch (neither team): pieces and statistics stay as they are,
+    if ((u64)unit >= ntile && (TEAMS == 1 || (u64)unit_other >= ntile)) {   // no share of this batch (neither team): pieces and statistics stay as they are,
         if (first) for (u32 p = t; p < NP; p += K1M_THREADS) d.hdr8[(size_t)p * d.nwg + w] = make_uint2(0u, 0u);   // but stale headers must go
         return;
     }

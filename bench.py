@@ -312,7 +312,12 @@ def main():
 def _engine_for(a, topo, labels, c, device, windows, engine, weights):
     L = c["layers"]
     big = a.config == 5
-    n_edges = len(topo.edge_src)                                     # (a shard view holds its own edges only)
+    # edge capacity: the graph's edges (a shard view holds its own only), but never more than a window has events — a window cannot touch
+    # more distinct edges than it has events, and the partition count / table sizes follow the capacity (config 5: 20 M edges in the graph,
+    # 5 M events per window: the partitioned K1 instead of the global-table variant; SG_BENCH_FULL_EDGE_CAP=1 sizes for the whole graph)
+    n_edges = len(topo.edge_src)
+    if not os.environ.get("SG_BENCH_FULL_EDGE_CAP"):
+        n_edges = min(n_edges, max(1, c["events"] // a.shard_of))
     g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(n_edges * (1.1 if big and a.shard_of == 1 else 1.25)) + 4096, layers=L,
                             max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=int(os.environ.get("SG_BENCH_MAX_BATCH", 1 << 18)),
                             max_window_events=max(1, c["events"] // a.shard_of), windows_in_flight=windows)

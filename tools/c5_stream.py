@@ -91,7 +91,7 @@ def main():
     wire = None if expand else np.frombuffer(replay.to_wire(ev, labels), dtype=np.uint8).copy()
     n_nodes = len(pod_ips) + len(svc_ips)
     max_edges = int(c["edges"] * 1.1) if not a.pods else max(1 << 16, 4 * (a.edges or a.pods * 20))
-    if shard_edges: max_edges = int(shard_edges * 1.25) + 4096
+    if shard_edges: max_edges = int(min(shard_edges, a.rate * a.window_s * 1.5) * 1.25) + 4096     # (a window cannot touch more edges than it has events)
     cfg = engine.make_config(max_known_nodes=n_nodes + 1024, max_edges=max_edges, layers=c["layers"], max_labels=256, max_outbound_ips=256,
                              max_batch=1 << 18, max_window_events=int(a.rate * a.window_s * 1.5), windows_in_flight=3)
     t0 = time.perf_counter()
