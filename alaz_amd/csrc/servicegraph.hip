@@ -422,7 +422,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         hipLaunchKernelGGL(k2_rowptr, dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, d, ++e->rp_epoch);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 2 * (size_t)d.k2_sortw * sizeof(u32), s, d);
     }
     {
         Timed t3(e, s, 8);                                   // group 8 = in-statistics (group 3 = node + edge features)
@@ -743,6 +743,11 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     e->k3_slices = (u32)std::min<u64>(K3_IN_SMAX, std::max<u64>(8, ME / 8192));
     if (const char* v = std::getenv("SG_K3_SLICES")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= 256) e->k3_slices = (u32)x; }
     e->k3in_lds = (size_t)K3_IN_NR * 48;
+    {   // the row sort's two LDS arrays: large enough for a bitmap of the node capacity when that fits (a config-5 shard: 150 k nodes = 4.7 k words)
+        const u64 bw = ((u64)d.ncap + 31) / 32;
+        d.k2_sortw = bw <= K2_SORT_LDS ? K2_SORT_LDS : (u32)std::min<u64>(K2_SORT_LDS_MAX, (bw + 255) / 256 * 256);
+        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k2_rowsort_gather), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (size_t)d.k2_sortw * sizeof(u32))));
+    }
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
     CR(dev_alloc(e, &d.dbg, (size_t)4 * 4096 * 8));

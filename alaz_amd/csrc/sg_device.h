@@ -142,6 +142,7 @@ struct Dev {
                                               // window had no batch (pieces hold the previous window: ignore them)
     u32 ablate;                               // SG_ABLATE: 0x100 = record phase stamps (SG_STAMP); 0 in production
     u64* dbg;                                 // phase time stamps (SG_ABLATE & 0x100): [kernel 0..3][4096 workgroups][8]
+    u32 k2_sortw;                             // k2_rowsort_gather: words of each of its two LDS arrays (>= K2_SORT_LDS)
     u32 k1a_rot;                              // pass A: the workgroup (unit) that takes this launch's first chunk (tile): successive small batches must not all land on workgroup 0's pieces
     u32* k1a_ticket; u32 k1a_ticket_base;     // k1a_team_partition: the window slot's tile-ticket counter (never reset) and its value before this launch's first ticket
     u64* clk;                                 // [4] shader clock under load: {shader cycles, 100 MHz ticks} summed over pass-A launches (workgroup 0), then the spin probe's pair

@@ -1151,7 +1151,8 @@ __device__ __forceinline__ void edge_features(const Dev& d, u32 pos) {
     d.latz[pos] = lat_z; d.errr[pos] = err_ratio;
 }
 
-#define K2_SORT_LDS 4096
+#define K2_SORT_LDS 4096         // words of each of the row sort's two LDS arrays — at least: the host sizes them (Dev::k2_sortw) so that a node bitmap fits, up to K2_SORT_LDS_MAX
+#define K2_SORT_LDS_MAX 16384
 #define K2_LONG_WGS 1024
 #define K2_WAVE_ROW 512          // rows of up to this many edges are sorted by ONE wave (bitmap rank in a wave-private slice of the LDS arrays)
 #define K2_WAVE_BW  1024         // ... when the node bitmap fits this many words (N <= 32768)
@@ -1164,7 +1165,7 @@ __device__ __forceinline__ void k2_row_wg(const Dev& d, const EdgeEmitArgs& ea, 
     if (m == 0) return;
     const uint2* in = d.cs + b; u32* key = d.col + b;              // in: {destination, slot} as scattered; key: the row's sorted destinations (output only)
     u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
-    if (BW <= K2_SORT_LDS && m <= 1024) {
+    if (BW <= d.k2_sortw && m <= 1024) {
         // The common long row (65..1024 edges): bitmap rank as below, but every thread keeps its (<= 4) elements
         // and their accumulators in registers — one global round trip (the accumulator gather, issued before the
         // rank is known), no scratch arrays, three barriers.
@@ -1206,7 +1207,7 @@ __device__ __forceinline__ void k2_row_wg(const Dev& d, const EdgeEmitArgs& ea, 
         cnt = red[0][0] + red[0][1] + red[0][2] + red[0][3]; err = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         sum = red[2][0] + red[2][1] + red[2][2] + red[2][3]; ssq = red[3][0] + red[3][1] + red[3][2] + red[3][3];
         mx = red[4][0]; for (int w = 1; w < 4; w++) mx = red[4][w] > mx ? red[4][w] : mx;
-    } else if (BW <= K2_SORT_LDS) {
+    } else if (BW <= d.k2_sortw) {
         // Bitmap rank: the destinations of one row are distinct node ids < N, so setting bit `to` in an
         // N-bit LDS bitmap and counting the bits below it IS the sorted position — O(m + N/32) per row
         // instead of a comparison sort (a 3000-edge hub row cost ~100 us in the bitonic network).
@@ -1281,7 +1282,7 @@ __device__ __forceinline__ void k2_row_wg(const Dev& d, const EdgeEmitArgs& ea, 
     } else {
         u32 np2 = 1; while (np2 < m) np2 <<= 1;
         u32* gk = sk; u32* gv = sv;
-        if (m > K2_SORT_LDS) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
+        if (m > d.k2_sortw) { gk = d.sort_k + 2 * (size_t)b; gv = d.sort_v + 2 * (size_t)b; }   // private padded slice of the global scratch
         for (u32 i = threadIdx.x; i < np2; i += 256) { const uint2 kv = in[i < m ? i : m - 1]; gk[i] = i < m ? kv.x : 0xFFFFFFFFu; gv[i] = i < m ? kv.y : 0; }
         __syncthreads();
         for (u32 k = 2; k <= np2; k <<= 1)
@@ -1334,7 +1335,7 @@ __device__ __forceinline__ void k2_row_wg(const Dev& d, const EdgeEmitArgs& ea, 
 // how many hub work items the row sort may use: all of them, when the whole list was recorded and a node bitmap fits the LDS arrays
 __device__ __forceinline__ u32 k2_split_items(const Dev& d) {
     const u32 BW = ((u32)d.ctr[C_N_NODES] + 31) >> 5;
-    return (d.ctr[C_HUB_ITEMS] <= d.hub_cap && BW <= K2_SORT_LDS && !(d.ablate & 0x800u)) ? (u32)d.ctr[C_HUB_ITEMS] : 0u;
+    return (d.ctr[C_HUB_ITEMS] <= d.hub_cap && BW <= d.k2_sortw && !(d.ablate & 0x800u)) ? (u32)d.ctr[C_HUB_ITEMS] : 0u;
 }
 __device__ __forceinline__ void k2_split_finish(const Dev& d, u32 tid, u32 nt) {
     const u32 H = k2_split_items(d);
@@ -1466,10 +1467,57 @@ __device__ __forceinline__ void k2_row_wave(const Dev& d, const EdgeEmitArgs& ea
         d.row_mu[rr] = mean_us(sum, cnt); d.row_sd[rr] = std_us(sum, ssq, cnt);
     }
 }
+// The same rows when the node space is too large for wave-private bitmaps (N > 32 768: a shard of config 5 has 150 k nodes, and
+// every one of its ~200-edge rows took the whole workgroup, three barriers and a 256-thread rank loop — 0.85 ms of a 1.6 ms close):
+// a rank sort inside the wave, independent of N.  Lane l keeps elements l, l + 64, ...; element j is broadcast with v_readlane (j is
+// uniform) and every lane counts the keys below its own: m (1 + ceil(m / 64)) instructions per row, ~1 000 for a 200-edge row.
+__device__ __forceinline__ void k2_row_wave_rank(const Dev& d, const EdgeEmitArgs& ea, const u32 rr) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 b = d.rowptr[rr];
+    u32 m = d.rowptr[rr + 1] - b;
+    if ((u64)b + m > d.max_edges) m = b < d.max_edges ? (u32)(d.max_edges - b) : 0;
+    if (m == 0) return;
+    const uint2* in = d.cs + b; u32* key = d.col + b;
+    constexpr int Q = K2_WAVE_ROW / 64;
+    u32 mk[Q], mv[Q], rk[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) { const u32 i = lane + 64u * q; const uint2 kv = in[i < m ? i : m - 1]; mk[q] = i < m ? kv.x : 0xFFFFFFFFu; mv[q] = kv.y; rk[q] = 0; }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const u32 nq = m > 64u * q ? (m - 64u * q < 64u ? m - 64u * q : 64u) : 0u;   // uniform
+        for (u32 j = 0; j < nq; j++) {
+            const u32 kj = rdlane32(mk[q], (int)j);
+#pragma unroll
+            for (int q2 = 0; q2 < Q; q2++) rk[q2] += kj < mk[q2];
+        }
+    }
+    u64 cnt = 0, err = 0, sum = 0, ssq = 0, mx = 0;
+#pragma unroll
+    for (int q0 = 0; q0 < Q; q0 += 4) {                              // four accumulator gathers in flight
+        if (64u * q0 >= m) break;                                    // uniform
+        ulonglong2 x4[4], y4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_src + (size_t)mv[q0 + q] * 4); x4[q] = a[0]; y4[q] = a[1]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (lane + 64u * (q0 + q) < m) {
+            key[rk[q0 + q]] = mk[q0 + q];
+            edge_emit(ea, b + rk[q0 + q], rr, mv[q0 + q], 0, 0, 0, x4[q], y4[q]);
+            cnt += x4[q].x & 0xFFFFFFFFull; err += x4[q].x >> 32; sum += x4[q].y; ssq += y4[q].y; mx = y4[q].x > mx ? y4[q].x : mx;
+        }
+    }
+    cnt = wave_sum_u64(cnt); err = wave_sum_u64(err); sum = wave_sum_u64(sum); ssq = wave_sum_u64(ssq); mx = wave_max_u64(mx);
+    if (lane == 0) {
+        u64* t = d.st_sum + (size_t)rr * SG_NODE_STAT_SUM_WORDS;
+        t[ST_OUT_DEG] = m; t[ST_OUT_CNT] = cnt; t[ST_OUT_ERR] = err; t[ST_OUT_SUM] = sum; t[ST_OUT_SSQ] = ssq;
+        d.st_max[(size_t)rr * 2] = mx;
+        d.row_mu[rr] = mean_us(sum, cnt); d.row_sd[rr] = std_us(sum, ssq, cnt);
+    }
+}
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
     const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant, d.hist_src, d.hist_csr, d.hist};
-    __shared__ u32 sk[K2_SORT_LDS], sv[K2_SORT_LDS];
+    extern __shared__ u32 k2_lds[];                                  // 2 x k2_sortw words (dynamic: a node bitmap of the engine's node capacity fits when it can)
+    u32* sk = k2_lds; u32* sv = k2_lds + d.k2_sortw;
     __shared__ u64 red[5][4];
     __shared__ u32 bsum[5];
     __shared__ u32 bigrow[4];
@@ -1494,6 +1542,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
                 const u32 rr = d.longrows[li];
                 const u32 m = d.rowptr[rr + 1] - d.rowptr[rr];
                 if (wave_ok && m <= K2_WAVE_ROW) k2_row_wave(d, ea, rr, sk + wave * K2_WAVE_BW, sv + wave * K2_WAVE_BW, BW);
+                else if (BW > K2_WAVE_BW && m <= K2_WAVE_ROW && !(d.ablate & 0x400u)) k2_row_wave_rank(d, ea, rr);
                 else if (!(H && m > K2_SPLIT_ROW)) big = rr;
             }
             if (lane == 0) bigrow[wave] = big;
