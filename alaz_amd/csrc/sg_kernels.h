@@ -2196,7 +2196,7 @@ static_assert(sizeof(sg_edge_out) == 64 && offsetof(sg_edge_out, sum_ns) == 0 &&
               offsetof(sg_edge_out, score) == 40 && offsetof(sg_edge_out, lat_z) == 44 && offsetof(sg_edge_out, err_ratio) == 48 && offsetof(sg_edge_out, alive) == 52 &&
               offsetof(sg_edge_out, p50_us) == 56 && offsetof(sg_edge_out, p99_us) == 60, "k5_edge_score writes a row as eight 8-byte words");
 template <bool RESET>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k5_edge_score(Dev d, const float* __restrict__ Wh) {
     const u32 E = (u32)d.ctr[C_N_EDGES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const float* __restrict__ We = Wh + 2 * SG_F_HID * SG_F_HID;
     const float* __restrict__ w2 = We + SG_F_EDGE * SG_F_HID + SG_F_HID;
@@ -2249,22 +2249,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     if (E) {
         const u32 stride = nw * 8, last = E - 1;
         u32 pa = wave * 8 + g, pb = pa + 4;                          // this iteration's two edges of the lane group (clamped when beyond E)
-        u32 idw;
-        { const u32 px = (q & 2u) ? pb : pa; idw = idsrc[px < E ? px : last]; }
-        for (u32 p0 = wave * 8; p0 < E; p0 += stride) {
-            u32 ua = dpp32b<0x150>(idw), va = dpp32b<0x151>(idw), ub = dpp32b<0x152>(idw), vb = dpp32b<0x153>(idw);
+        // Round 4: TWO iterations in flight.  A wave runs ~30 iterations at C3 and an iteration was one exposed round trip (the gathers:
+        // ~2 us) beside ~0.4 us of arithmetic — 73 us of which 60 were latency at four waves per SIMD.  Now the gathers, the feature
+        // dword and the row words of iteration i + 1 are issued BEFORE iteration i is computed (a second register set: 21 dwords), its
+        // endpoint ids having been fetched an iteration earlier still; loads return in order, so waiting for set i does not wait for
+        // set i + 1.  (The set beyond the last iteration is loaded from clamped addresses and dropped.)
+        struct K5Set { float4 PA, QA, PB, QB; u32 ew, wa, wb; u64 wacc; };
+        auto ids_of = [&](u32 xa, u32 xb) -> u32 { const u32 px = (q & 2u) ? xb : xa; return idsrc[px < E ? px : last]; };
+        auto issue = [&](u32 idw_, u32 xa, u32 xb, u32 x0, K5Set& S) {
+            u32 ua = dpp32b<0x150>(idw_), va = dpp32b<0x151>(idw_), ub = dpp32b<0x152>(idw_), vb = dpp32b<0x153>(idw_);
             if (d.ablate & 0x1000u) { ua &= 15u; va &= 15u; ub &= 15u; vb &= 15u; }   // (diagnostic: gathers that hit the L1)
-            const u32 ca = pa < E ? pa : last, cb = pb < E ? pb : last;
-            const float4 PA = reinterpret_cast<const float4*>(d.P + (size_t)ua * SG_F_HID)[q], QA = reinterpret_cast<const float4*>(d.Q + (size_t)va * SG_F_HID)[q];
-            const float4 PB = reinterpret_cast<const float4*>(d.P + (size_t)ub * SG_F_HID)[q], QB = reinterpret_cast<const float4*>(d.Q + (size_t)vb * SG_F_HID)[q];
-            const u32 ew = __float_as_uint(d.efeat[(size_t)(q < 8 ? ca : cb) * SG_F_EDGE + (q & 7u)]);
-            // what this lane's row word is made of: fetched now, beside the gathers
-            const u32 er = p0 + we8, ec = er < E ? er : last;
-            const u64 wacc = d.acc_csr[(size_t)ec * 4 + accj];
-            const u32 wa = srcA[ec], wb = srcB[ec];
-            // next iteration's endpoints: behind the gathers in issue order, so waiting for the gathers does not wait for them
+            const u32 ca = xa < E ? xa : last, cb = xb < E ? xb : last;
+            S.PA = reinterpret_cast<const float4*>(d.P + (size_t)ua * SG_F_HID)[q]; S.QA = reinterpret_cast<const float4*>(d.Q + (size_t)va * SG_F_HID)[q];
+            S.PB = reinterpret_cast<const float4*>(d.P + (size_t)ub * SG_F_HID)[q]; S.QB = reinterpret_cast<const float4*>(d.Q + (size_t)vb * SG_F_HID)[q];
+            S.ew = __float_as_uint(d.efeat[(size_t)(q < 8 ? ca : cb) * SG_F_EDGE + (q & 7u)]);
+            // what this lane's row word is made of: fetched beside the gathers
+            const u32 er_ = x0 + we8, ec_ = er_ < E ? er_ : last;
+            S.wacc = d.acc_csr[(size_t)ec_ * 4 + accj];
+            S.wa = srcA[ec_]; S.wb = srcB[ec_];
+        };
+        // One iteration: `cur` is computed and stored, `nxt` issued; the two sets ALTERNATE between the two calls of the loop body — rotating
+        // them through copies at the back edge made the compiler wait for the set in flight there (a v_mov needs its source loaded).
+        auto iter = [&](K5Set& cur, K5Set& nxt, const u32 idw_next, u32& idw_after, const u32 p0) {
             const u32 na = pa + stride, nb = pb + stride;
-            { const u32 px = (q & 2u) ? nb : na; idw = idsrc[px < E ? px : last]; }
+            // the endpoints of the iteration after the next go out FIRST: they are then older than the gathers issued below, and the next
+            // iteration's wait for them does not wait for those gathers (issued the other way round, it was a vmcnt(0) at the loop top)
+            idw_after = ids_of(na + stride, nb + stride);
+            issue(idw_next, na, nb, p0 + stride, nxt);
+            __builtin_amdgcn_sched_barrier(0);                       // (the scheduler moved the arithmetic of `cur` above these loads)
+            const float4 PA = cur.PA, QA = cur.QA, PB = cur.PB, QB = cur.QB;
+            const u32 ew = cur.ew, wa = cur.wa, wb = cur.wb; const u64 wacc = cur.wacc;
+            const u32 er = p0 + we8, ec = er < E ? er : last;
             const float eka[SG_F_EDGE] = {__uint_as_float(dpp32b<0x150>(ew)), __uint_as_float(dpp32b<0x151>(ew)), __uint_as_float(dpp32b<0x152>(ew)), __uint_as_float(dpp32b<0x153>(ew)),
                                           __uint_as_float(dpp32b<0x154>(ew)), __uint_as_float(dpp32b<0x155>(ew)), __uint_as_float(dpp32b<0x156>(ew)), __uint_as_float(dpp32b<0x157>(ew))};
             const float ekb[SG_F_EDGE] = {__uint_as_float(dpp32b<0x158>(ew)), __uint_as_float(dpp32b<0x159>(ew)), __uint_as_float(dpp32b<0x15A>(ew)), __uint_as_float(dpp32b<0x15B>(ew)),
@@ -2298,8 +2313,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                     }
                 }
             }
-            if (er < E && !(d.ablate & 0x2000u)) reinterpret_cast<u64*>(d.rows)[(size_t)er * 8 + wk] = val;
+            // The store as a BUFFER store on the wave's 512 bytes of this iteration (p0 is wave-uniform): rows beyond E are dropped by
+            // the resource's range check, not by a branch — a branch around the store is a join for the compiler's vmcnt bookkeeping,
+            // and the next half-iteration's wait for its endpoint ids then also waited for the first gather of the set in flight.
+            {
+                const u32 p0u = (u32)__builtin_amdgcn_readfirstlane((int)p0);
+                const u32 nrow = (d.ablate & 0x2000u) ? 0u : (E - p0u < 8u ? E - p0u : 8u);
+                const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u64*>(d.rows) + (size_t)p0u * 8, 0, (int)(nrow * 64u), 0x00020000);
+                v2u_t dv; dv.x = (u32)val; dv.y = (u32)(val >> 32);
+                __builtin_amdgcn_raw_buffer_store_b64(dv, rr_, lane * 8u, 0, 0);
+            }
             pa = na; pb = nb;
+        };
+        K5Set A, B;
+        u32 i1 = ids_of(pa + stride, pb + stride), i2;               // the endpoints of iteration 1 ...
+        { const u32 id0 = ids_of(pa, pb); issue(id0, pa, pb, wave * 8, A); }   // ... in flight before iteration 0's gathers
+        for (u32 p0 = wave * 8; p0 < E; p0 += 2 * stride) {
+            iter(A, B, i1, i2, p0);
+            if (p0 + stride >= E) break;                             // (uniform)
+            iter(B, A, i2, i1, p0 + stride);
         }
     }
     if (RESET) {
