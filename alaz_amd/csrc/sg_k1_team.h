@@ -241,7 +241,14 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     auto back4 = [&](const u32 (&Lm)[4], const u32 (&Rm)[4], const u32 (&dur)[4], const u32 (&fl)[4], u32* bc, u32 (&lo)[4], u32 (&hi)[4], u32 (&pr)[4]) {
         ulonglong2 kk[4]; u64 mk[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { mk[i] = ((u64)Lm[i] << nb) | Rm[i]; kk[i] = reinterpret_cast<const ulonglong2*>(ckey)[Rm[i] & bmask]; }
+        for (int i = 0; i < 4; i++) mk[i] = ((u64)Lm[i] << nb) | Rm[i];
+        if (d.ablate & 0x8u) {                                       // (diagnostic: no edge cache — every accepted record travels)
+#pragma unroll
+            for (int i = 0; i < 4; i++) kk[i] = make_ulonglong2(~1ull, ~1ull);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) kk[i] = reinterpret_cast<const ulonglong2*>(ckey)[Rm[i] & bmask];
+        }
         // cache: a key that owns a slot folds; an empty slot may be claimed (rare once the cache is full: one ballot for the four events)
         int slot[4]; bool claim = false;
 #pragma unroll
