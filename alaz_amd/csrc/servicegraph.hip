@@ -458,7 +458,7 @@ int do_layer(sg_engine* e, u32 l, hipStream_t s, bool fuse_proj) {
     bool split = e->cfg.max_edges > (1u << 17);              // (C2's 66 k-edge engine stays fused; a 160 k-edge shard of C4 — with its hub rows — splits)
     if (const char* v = std::getenv("SG_K4_FUSED")) split = std::atoi(v) == 0;
 #define K4_LAUNCH(FI, MF, PJ, HIN, HOUT) do { if (split) { \
-            hipLaunchKernelGGL((k4_gather<FI>), dim3(grid_for(d.ncap, K4G_ROWS, 4096)), dim3(512), 0, s, d, HIN); \
+            hipLaunchKernelGGL((k4_gather<FI>), dim3(grid_for(d.ncap, K4G_ROWS, 4096 * 8 / K4G_ROWS)), dim3(K4G_ROWS * 64), 0, s, d, HIN); \
             hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ, (PJ ? 512 : 256), true>), dim3(grid), dim3(PJ ? 512 : 256), 0, s, d, HIN, HOUT, Wl, Wh); \
         } else hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ, (FI == 32 ? 1024 : 512), false>), dim3(grid), dim3(FI == 32 ? 1024 : 512), 0, s, d, HIN, HOUT, Wl, Wh); } while (0)
     if (l == 0) {

@@ -1934,12 +1934,15 @@ __device__ __forceinline__ void gather_block_sum2(const float* __restrict__ hin,
 // waited for its longest row and a CU held one tile (C3: 57 + 99 us for the two layers).  Rows of more than one block: the
 // blocks of the row are spread over the workgroup's 8 waves and added in block order, as before.  The result, mean[v][0..FI),
 // is bit-identical to the fused version's (same gather_block_sum, same order of the block sums, one division).
-#define K4G_ROWS 8              // rows per workgroup tile of k4_gather: one per wave.  (32 rows handed out by an LDS counter balanced the
-                                // one-block rows better — 33 -> 28 us at C3 — but put several multi-block rows into one workgroup: 53 -> 62 us.)
+#define K4G_ROWS 4              // rows per workgroup tile of k4_gather: one per wave.  (32 rows handed out by an LDS counter balanced the
+                                // one-block rows better — 33 -> 28 us at C3 — but put several multi-block rows into one workgroup: 53 -> 62 us.
+                                // Round 4, same box: 8 waves per workgroup 81-84 us for the two layers' K4, 4 waves 78.5; the 64-neighbour batch
+                                // gathered in two / four parts — fewer registers, more waves — 83-87 / 94: the gather is bound by the bytes a
+                                // wave keeps in flight, not by the waves.)
 template <int FI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k4_gather(Dev d, const float* __restrict__ hin) {
-    __shared__ __attribute__((aligned(16))) float scr_all[8 * 16 * FI];
-    __shared__ __attribute__((aligned(16))) float part[8 * FI];
+__global__ __launch_bounds__(K4G_ROWS * 64) __attribute__((amdgpu_waves_per_eu(4))) void k4_gather(Dev d, const float* __restrict__ hin) {
+    __shared__ __attribute__((aligned(16))) float scr_all[K4G_ROWS * 16 * FI];
+    __shared__ __attribute__((aligned(16))) float part[K4G_ROWS * FI];
     const bool listed = d.world > 1 && d.ctr[C_ACT_L] != SG_ACT_NONE;
     const u32 N = listed ? (u32)d.ctr[C_ACT_L] : (u32)d.ctr[C_N_NODES];
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
@@ -1951,7 +1954,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     // dense kernel adds a row's block sums in block order and divides — the same sums in the same order as before.
     {
         const u32 H = (u32)(d.ctr[C_HUB_ITEMS] < d.hub_cap ? d.ctr[C_HUB_ITEMS] : d.hub_cap);
-        const u32 gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+        const u32 gw = blockIdx.x * K4G_ROWS + wave, nw = gridDim.x * K4G_ROWS;
         for (u32 it = gw; it < H; it += nw) {
             const uint2 x = d.hub_items[it];
             bool sk = false;
