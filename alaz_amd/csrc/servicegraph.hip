@@ -419,7 +419,9 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
             hipLaunchKernelGGL(k2_scan_tiles, dim3(1), dim3(1024), 0, s, d, ntiles);
             hipLaunchKernelGGL(k2_edge_compact, dim3(ntiles), dim3(256), 0, s, d);
         }
-        hipLaunchKernelGGL(k2_rowptr, dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, d, ++e->rp_epoch);
+        if (d.dh_g) hipLaunchKernelGGL(k2_deg_hist, dim3(d.dh_g), dim3(K2_DH_THREADS), ((size_t)d.ncap + 1) * sizeof(u32), s, d);
+        if (d.dh_g) hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS_DH, true>), dim3(((size_t)d.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH), dim3(1024), 0, s, d, ++e->rp_epoch);
+        else hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS, false>), dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, d, ++e->rp_epoch);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
         else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, s, d);
         hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 2 * (size_t)d.k2_sortw * sizeof(u32), s, d);
@@ -748,6 +750,16 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         d.k2_sortw = bw <= K2_SORT_LDS ? K2_SORT_LDS : (u32)std::min<u64>(K2_SORT_LDS_MAX, (bw + 255) / 256 * 256);
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k2_rowsort_gather), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (size_t)d.k2_sortw * sizeof(u32))));
     }
+    {   // row degrees / in-row ranks by LDS histograms instead of one returning device atomic per edge (k2_deg_hist): when a u32 counter
+        // per node fits one workgroup's LDS.  G workgroups of npb / G consecutive output partitions each (G a power of two, 16 .. K2_DH_GMAX).
+        d.dh_g = d.dh_ppw = d.dh_ns = 0;
+        u32 g = std::min<u32>(K2_DH_GMAX, d.variant == 0 ? d.npb : 0u);            // (k2_rowptr: a multiple of 16)
+        if (const char* v = std::getenv("SG_DH_G")) { const u64 x = std::strtoull(v, nullptr, 0); g = (x >= 16 && x <= K2_DH_GMAX && (x & (x - 1)) == 0 && d.variant == 0 && x <= d.npb) ? (u32)x : 0u; }
+        if (g >= 16 && (g & (g - 1)) == 0 && d.npb % g == 0 && ((size_t)d.ncap + 1) * sizeof(u32) <= 128u * 1024u && (u64)d.npb * d.pcap < (1ull << 32)) {
+            d.dh_g = g; d.dh_ppw = d.npb / g; d.dh_ns = (d.ncap + 1 + 63u) & ~63u;
+            CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k2_deg_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)d.ncap + 1) * sizeof(u32))));
+        }
+    }
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
     { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
     CR(dev_alloc(e, &d.dbg, (size_t)4 * 4096 * 8));
@@ -765,6 +777,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             LR(dev_alloc(e, &w.part_n, w.npb));
             LR(dev_alloc(e, &w.acc_src, (size_t)w.npb * w.pcap * 4));
             LR(dev_alloc(e, &w.e_rank, (size_t)w.npb * w.pcap));
+            if (w.dh_g) LR(dev_alloc(e, &w.dh_hist, (size_t)w.dh_g * w.dh_ns));
         }
         LR(dev_alloc(e, &w.ekeys, e->ecap, 0xFF));
         LR(dev_alloc(e, &w.eacc, (size_t)e->ecap * 4));
@@ -779,7 +792,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.tile_off, e->ecap / K2_TILE));
         LR(dev_alloc(e, &w.e_slot, ME)); LR(dev_alloc(e, &w.e_from, eslots)); LR(dev_alloc(e, &w.e_to, eslots));
         LR(dev_alloc(e, &w.longrows, (size_t)w.ncap + 1));
-        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS) / K2_RP_ROWS + 1)); LR(dev_alloc(e, &w.k6_tot, (((size_t)w.ncap + 1023) / 1024 + 1) * 16)); LR(dev_alloc(e, &w.k1a_ticket, 4)); w.k1a_ticket_base = 0; w.k1a_rot = 0; LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
+        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH + 1)); LR(dev_alloc(e, &w.k6_tot, (((size_t)w.ncap + 1023) / 1024 + 1) * 16)); LR(dev_alloc(e, &w.k1a_ticket, 4)); w.k1a_ticket_base = 0; w.k1a_rot = 0; LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cs, ME)); LR(dev_alloc(e, &w.csr_from, ME));
         LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));

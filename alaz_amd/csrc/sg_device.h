@@ -156,6 +156,13 @@ struct Dev {
     u32* tile_cnt;  u32* tile_off;            // compaction scratch
     u32* e_slot;    u32* e_from;  u32* e_to;  // [max_edges] compacted (table order)
     u32* deg;       u32* rowptr;  u32* cursor;// [ncap+1]
+    // Row degrees and in-row positions WITHOUT device atomics (variant 0, node spaces whose u32 counters fit one workgroup's LDS):
+    // k2_deg_hist — workgroup g of dh_g counts the sources of dh_ppw consecutive output partitions in LDS (the returning LDS add is the
+    // edge's rank among the (g, source) edges -> e_rank) and writes its counts to dh_hist[g][.]; k2_rowptr turns every row's column of
+    // counts into offsets inside the row; the scatter adds rowptr + offset(g, source) + rank.  dh_g = 0: pass B takes the rank with
+    // one returning device atomic per edge on deg[source][replica] (1 M of them at C3: 23-38 us of pass B).
+    u32 dh_g, dh_ppw, dh_ns;                  // histogram workgroups (0 = off), output partitions per workgroup, row stride of dh_hist (>= ncap + 1, a multiple of 64)
+    u32* dh_hist;                             // [dh_g][dh_ns]
     u32* col;                                 // [max_edges] CSR order: destination (written by the row sort, sorted inside every row)
     uint2* cs;                                // [max_edges] {destination, table slot} in row order, unsorted: ONE 8-byte scattered write per edge (scatter -> row sort)
     u32* csr_from;                            // [max_edges] CSR order: source (row id per edge)

@@ -604,7 +604,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             oi[k2] = atomicAdd(out_n, 1u);
             if (oi[k2] >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[sl] & 0xFFFFFFFFull)); continue; }
             live[k2] = true;
-            if (!(d.ablate & 0x20u)) rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], oq & (SG_DEG_REP - 1))], 1u);   // arrival order inside the row's replica
+            if (!d.dh_g && !(d.ablate & 0x20u)) rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], oq & (SG_DEG_REP - 1))], 1u);   // arrival order inside the row's replica (dh_g: k2_deg_hist ranks the edges instead, no device atomic)
         }
         // (everything that does not need the returned rank first: the device atomics' round trip passes under these stores)
 #pragma unroll
@@ -617,7 +617,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             o[0] = make_ulonglong2(hacc[sl], hacc[HT + sl]); o[1] = make_ulonglong2(hacc[2 * HT + sl], hacc[3 * HT + sl]);
         }
 #pragma unroll
-        for (int k2 = 0; k2 < SPT; k2++) if (live[k2]) d.e_rank[(size_t)oq * d.pcap + oi[k2]] = rk[k2];
+        for (int k2 = 0; k2 < SPT; k2++) if (live[k2] && !d.dh_g) d.e_rank[(size_t)oq * d.pcap + oi[k2]] = rk[k2];
     }
     __syncthreads();
     SG_STAMP(d, 1, 5);

@@ -754,7 +754,7 @@ __device__ __forceinline__ void k1b_body(const Dev& d) {
             oi[k2] = atomicAdd(out_n, 1u);
             if (oi[k2] >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[s] & 0xFFFFFFFFull)); continue; }
             live[k2] = true;
-            rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], p & (SG_DEG_REP - 1))], 1u);     // arrival order inside the row's replica
+            if (!d.dh_g) rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], p & (SG_DEG_REP - 1))], 1u);     // arrival order inside the row's replica (dh_g: k2_deg_hist ranks the edges)
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; k2++) {
@@ -769,7 +769,7 @@ __device__ __forceinline__ void k1b_body(const Dev& d) {
                 ho[0] = make_uint4(hs[0], hs[1], hs[2], hs[3]); ho[1] = make_uint4(hs[4], hs[5], hs[6], hs[7]);
                 ho[2] = make_uint4(hs[8], hs[9], hs[10], hs[11]); ho[3] = make_uint4(hs[12], hs[13], hs[14], hs[15]);
             }
-            d.e_rank[slot] = rk[k2];
+            if (!d.dh_g) d.e_rank[slot] = rk[k2];
         }
     }
     __syncthreads();
@@ -966,16 +966,84 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
 // give the row's degree; a block scan makes local row offsets; the sum of the preceding workgroups' totals
 // comes from rp_tot[] (each workgroup publishes (epoch, total) as soon as it knows it and the later ones
 // wait for it — all workgroups are resident, at most one per CU, so the wait cannot deadlock).
+// Row degrees and the edges' positions inside their rows without device atomics (Dev::dh_g workgroups; see sg_device.h).  Workgroup g
+// owns the output partitions [g * dh_ppw, (g + 1) * dh_ppw): it counts their sources in an LDS array indexed by node — the value a
+// returning LDS add hands back is the edge's rank among the edges (g, source), stored to e_rank with a coalesced write — and publishes
+// the array as row g of dh_hist.  K2_DH_FLIGHT source loads per thread are in flight together (a partition's ~1000 sources are one
+// round trip for a 1024-thread workgroup: taken one partition at a time the kernel would be dh_ppw dependent round trips).
+#define K2_DH_THREADS 1024
+#define K2_DH_FLIGHT 16
+#define K2_DH_GMAX 128           // k2_rowptr keeps a row's column of counts in registers: GMAX / 8 per lane
+__global__ __launch_bounds__(K2_DH_THREADS) void k2_deg_hist(Dev d) {
+    extern __shared__ u32 dh_cnt[];                                  // [N]
+    const u32 N = (u32)d.ctr[C_N_NODES], g = blockIdx.x, t = threadIdx.x;
+    const u32 CH = (d.pcap + K2_DH_THREADS - 1) / K2_DH_THREADS, items = d.dh_ppw * CH;   // work item = 1024 consecutive slots of one partition
+    // (the first round's loads are issued before the counters are cleared: they fly while the LDS is zeroed)
+    u32 fv[K2_DH_FLIGHT], sl[K2_DH_FLIGHT], okm = 0;
+    auto issue = [&](const u32 it0) {
+        okm = 0;
+#pragma unroll
+        for (int q = 0; q < K2_DH_FLIGHT; q++) {
+            const u32 it = it0 + (u32)q < items ? it0 + (u32)q : items - 1;   // (uniform)
+            const u32 k = it / CH, c = it - k * CH, oq = g * d.dh_ppw + k, i = c * K2_DH_THREADS + t;
+            const bool ok = it0 + (u32)q < items && i < d.part_n[oq];
+            okm |= ok ? (1u << q) : 0u;
+            sl[q] = oq * d.pcap + (ok ? i : 0u);                     // (slots: npb * pcap < 2^32 — the host sees to it)
+            fv[q] = d.e_from[sl[q]];
+        }
+    };
+    issue(0);
+    for (u32 i = t; i < N; i += K2_DH_THREADS) dh_cnt[i] = 0;
+    __syncthreads();
+    for (u32 it0 = 0; it0 < items; it0 += K2_DH_FLIGHT) {
+        if (it0) issue(it0);
+#pragma unroll
+        for (int q = 0; q < K2_DH_FLIGHT; q++) if (((okm >> q) & 1u) && fv[q] < N) d.e_rank[sl[q]] = atomicAdd(&dh_cnt[fv[q]], 1u);
+    }
+    __syncthreads();
+    u32* out = d.dh_hist + (size_t)g * d.dh_ns;
+    for (u32 i = t; i < N; i += K2_DH_THREADS) out[i] = dh_cnt[i];
+}
+
+// (RPR rows per workgroup.  DH — Dev::dh_g: the degrees come from k2_deg_hist's counts, 64 rows per workgroup so that the whole chip
+// pulls the [dh_g][N] table; otherwise from the replica counters pass B's device atomics left, 256 rows per workgroup.)
+#define K2_RP_ROWS_DH 64
+template <u32 RPR, bool DH>
 __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     const u32 N = (u32)d.ctr[C_N_NODES];
     __shared__ u32 wsum[17];
-    __shared__ u32 rdeg[K2_RP_ROWS];
+    __shared__ u32 rdeg[RPR];
     __shared__ u32 nlong, lbase, pre;
-    const u32 b = blockIdx.x, t = threadIdx.x, r0 = b * K2_RP_ROWS;
+    const u32 b = blockIdx.x, t = threadIdx.x, r0 = b * RPR;
     if (r0 >= N && b != 0) return;                                   // beyond the last row (grid sized for ncap)
     if (t == 0) nlong = 0;
     // 1. replicas -> in-row offsets, row degrees
-    for (u32 pass = 0; pass < K2_RP_ROWS / 128; pass++) {
+    if constexpr (DH) {
+        // k2_deg_hist's counts: row r's column dh_hist[0 .. dh_g)[r] becomes its exclusive prefix (the offset of the edges (g, r) inside
+        // row r), the total the row's degree.  Lane = (row, sixteenth of the column): a wave = 64 adjacent rows (coalesced reads and
+        // writes), the sixteenths are the workgroup's sixteen waves — their totals meet in LDS.  The offsets are stored at once: the
+        // stores fly under the scan and the wait for the preceding workgroups' totals.
+        static_assert(RPR == 64, "one row per lane of a wave");
+        constexpr u32 GL = K2_DH_GMAX / 16;
+        __shared__ u32 dtot[16][RPR];
+        const u32 GG = d.dh_g >> 4, rep = t >> 6, rl = t & 63u, row = r0 + rl;   // (dh_g: a multiple of 16, <= K2_DH_GMAX)
+        u32 v[GL];
+#pragma unroll
+        for (u32 j = 0; j < GL; j++) v[j] = (j < GG && row < N) ? d.dh_hist[(size_t)(rep * GG + j) * d.dh_ns + row] : 0u;
+        u32 run = 0;
+#pragma unroll
+        for (u32 j = 0; j < GL; j++) { const u32 x = v[j]; v[j] = run; run += x; }
+        dtot[rep][rl] = run;
+        __syncthreads();
+        u32 before = 0, tot = 0;
+#pragma unroll
+        for (u32 r = 0; r < 16; r++) { const u32 x = dtot[r][rl]; before += r < rep ? x : 0u; tot += x; }
+#pragma unroll
+        for (u32 j = 0; j < GL; j++) if (j < GG && row < N) d.dh_hist[(size_t)(rep * GG + j) * d.dh_ns + row] = v[j] + before;
+        if (rep == 0) rdeg[rl] = tot;
+    } else {
+    static_assert(DH || RPR % 128 == 0, "eight lanes per row, 128 rows per pass");
+    for (u32 pass = 0; pass < RPR / 128; pass++) {
         const u32 rl = pass * 128 + (t >> 3), row = r0 + rl, rep = t & 7;
         u32 v = row < N ? d.deg[SG_DEG_IDX(row, rep)] : 0u;
         u32 incl = v;                                                // inclusive prefix over the 8 lanes of the row
@@ -984,9 +1052,10 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
         if (row < N) d.deg[SG_DEG_IDX(row, rep)] = incl - v;
         if (rep == 7) rdeg[rl] = incl;
     }
+    }
     __syncthreads();
     // 2. local scan
-    const u32 dg = t < K2_RP_ROWS ? rdeg[t] : 0u;
+    const u32 dg = t < RPR ? rdeg[t] : 0u;
     u32 total;
     const u32 run = block_excl_scan<1024>(dg, wsum, &total);
     // 3. totals of the preceding workgroups
@@ -1011,10 +1080,10 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     // (row sort, gather, in-statistics, alive marks) then stays inside the max_edges-sized arrays without clamping of its own.
     // (Unclamped, K4's gather walked d.col up to E_found: with 10 M events of ten different traces in one C2-sized window that
     // was a GPU memory fault.)
-    const u64 s0u = (u64)base + run, s1u = s0u + (t < K2_RP_ROWS ? rdeg[t] : 0u);
+    const u64 s0u = (u64)base + run, s1u = s0u + (t < RPR ? rdeg[t] : 0u);
     const u32 s0 = (u32)(s0u < d.max_edges ? s0u : d.max_edges), s1 = (u32)(s1u < d.max_edges ? s1u : d.max_edges);
     const u32 dgc = s1 - s0;                                         // the row's edges inside the capacity
-    if (t < K2_RP_ROWS && r0 + t < N) {
+    if (t < RPR && r0 + t < N) {
         d.rowptr[r0 + t] = s0;
         if (dgc > 64) atomicAdd(&nlong, 1u);
         if (dgc > SG_MEAN_BLOCK) {                                   // a hub row: one work item per 512-neighbour block (k4_gather spreads them over the chip)
@@ -1031,14 +1100,14 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
         __shared__ u32 lpos;
         if (t == 0) lpos = 0;
         __syncthreads();
-        if (t < K2_RP_ROWS && r0 + t < N && dgc > 64) d.longrows[lbase + atomicAdd(&lpos, 1u)] = r0 + t;
+        if (t < RPR && r0 + t < N && dgc > 64) d.longrows[lbase + atomicAdd(&lpos, 1u)] = r0 + t;
     }
     if (t == 0) {
         if (b == 0) {
             d.ctr[C_OVF_N] = 0;                                        // K1b has consumed the overflow list
             d.ctr[C_ACT_L] = SG_ACT_NONE; d.ctr[C_ACT_P] = 0;          // no active lists yet for this window (see k6_active_lists)
         }
-        if (r0 + K2_RP_ROWS >= N) {                                    // the workgroup of the last row knows E
+        if (r0 + RPR >= N) {                                    // the workgroup of the last row knows E
             const u32 E = base + total;
             d.rowptr[N] = (u64)E < d.max_edges ? E : (u32)d.max_edges;
             d.ctr[C_N_EDGES] = (u64)E < d.max_edges ? E : d.max_edges;
@@ -1077,7 +1146,10 @@ __global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
         }
         u32 rp[4], dg[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { rp[q] = d.rowptr[f[q]]; dg[q] = d.deg[SG_DEG_IDX(f[q], p & (SG_DEG_REP - 1))]; }
+        for (int q = 0; q < 4; q++) {
+            rp[q] = d.rowptr[f[q]];
+            dg[q] = d.dh_g ? d.dh_hist[(size_t)(p / d.dh_ppw) * d.dh_ns + f[q]] : d.deg[SG_DEG_IDX(f[q], p & (SG_DEG_REP - 1))];   // offset of (p's group | replica, source) inside the row
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const u64 pos = (u64)rp[q] + dg[q] + rk[q];              // row + replica offset + arrival order
@@ -1760,8 +1832,8 @@ __global__ __launch_bounds__(256) void k_reset_window(Dev d) {
     const u64 nc = (u64)d.ncap + 1;
     // (obkeys must be cleared here, not in K5: k5's rows reference OBIP ranks only, but a K1a of the next
     // window may already be enqueued behind this kernel — same stream, so ordering is by launch order)
-    for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) d.deg[i * SG_DEG_STRIDE] = 0;
-        for (u64 i = tid; i < nc; i += nt) d.cursor[i] = 0;
+    if (!d.dh_g) for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) d.deg[i * SG_DEG_STRIDE] = 0;    // (dh_g: no degree counters — k2_deg_hist rewrites every count it uses)
+    for (u64 i = tid; i < nc; i += nt) d.cursor[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
     for (u64 i = tid; i <= d.obmask; i += nt) d.obkeys[i] = 0;
@@ -2342,7 +2414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
         // the counters stay: sg_window_read / the next kc_prepare consume them).
         const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
         const u64 nc = (u64)d.ncap + 1;
-        for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) d.deg[i * SG_DEG_STRIDE] = 0;
+        if (!d.dh_g) for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) d.deg[i * SG_DEG_STRIDE] = 0;
         for (u64 i = tid; i < nc; i += nt) d.cursor[i] = 0;
         for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
         for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
