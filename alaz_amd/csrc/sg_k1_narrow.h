@@ -478,6 +478,8 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     const u32 oq = p * S + sidx;                                     // output partition
     const u32 nb = d.nb, nbmask = (1u << nb) - 1u, rbmask = (1u << d.rb) - 1u, sbit = d.rb - 1;
     SG_STAMP(d, 1, 0);
+    if ((d.ablate & 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096)   // where the workgroup runs: HW_ID (CU 8..11, SH 12, SE 13..15) | XCC_ID << 32
+        d.dbg[((size_t)1 * 4096 + blockIdx.x) * 8 + 7] = (u64)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
     const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
     const u32 LPP = NT > d.nwg ? NT / d.nwg : 1u;                    // lanes per piece
     const u32 sub = t % LPP, w0 = t / LPP;

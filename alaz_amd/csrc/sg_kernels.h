@@ -1205,20 +1205,58 @@ __global__ __launch_bounds__(256) void k_clock_spin(u64* clk, u32 iters) {
 }
 __global__ void k_l1p_table(float* tab) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < SG_L1P_TAB) tab[i] = (float)log1p((double)i); }
 __device__ __forceinline__ float log1p_count(const Dev& d, u64 c) { return c < SG_L1P_TAB ? d.l1p_tab[c] : (float)log1p((double)c); }
+// fp64 arithmetic for the per-edge features, where one result per edge is wanted to fp32 accuracy and the chip's fp64 rate is the bound
+// (k3_node_features' edge workgroups: seven IEEE divisions and three libm log1p per edge were ~700 fp64 instructions, 18 of the
+// kernel's 25 us at C3).  sg_div: v_rcp_f64 + two Newton steps + one correction, <= 2 ulp (operands here are finite, positive and far from
+// the exponent range's ends).  sg_log1p_pos (x >= 0, finite): log(1 + x) = e ln 2 + 2 atanh(s), s = (m - 1) / (m + 1) for 1 + x = m 2^e,
+// m in [sqrt(1/2), sqrt(2)) — nine odd terms (|s| < 0.172: the tenth is below 3e-17) — plus the rounding of 1 + x put back, a short series
+// below 1e-4; <= 2 ulp of the fp64 result against long-double log1p over 1e-12 .. 1e14 (tools/log1p_check.py: no fp32 result differs
+// from (float)log1p(x) in six million samples).  The oracle's libm values are matched to the last fp32 bit except where the fp64
+// value sits within ~1e-15 of a rounding boundary.
+__device__ __forceinline__ double sg_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0); r = fma(r, e, r);
+    e = fma(-d, r, 1.0); return fma(r, e, r);
+}
+__device__ __forceinline__ double sg_div(double n, double d) { const double r = sg_rcp(d), q = n * r; return fma(fma(-d, q, n), r, q); }
+__device__ __forceinline__ double sg_log1p_pos(double x) {
+    const double y = 1.0 + x;
+    double m = __builtin_amdgcn_frexp_mant(y);                       // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(y);
+    const bool lo = m < 0.70710678118654752;
+    m = lo ? m + m : m; e = lo ? e - 1 : e;
+    const double s = sg_div(m - 1.0, m + 1.0), s2 = s * s;
+    double p = 1.0 / 19.0;
+    p = fma(p, s2, 1.0 / 17.0); p = fma(p, s2, 1.0 / 15.0); p = fma(p, s2, 1.0 / 13.0); p = fma(p, s2, 1.0 / 11.0);
+    p = fma(p, s2, 1.0 / 9.0); p = fma(p, s2, 1.0 / 7.0); p = fma(p, s2, 1.0 / 5.0); p = fma(p, s2, 1.0 / 3.0);
+    const double logm = fma(2.0 * s * s2, p, 2.0 * s);
+    const double c = (x - (y - 1.0)) * sg_rcp(y);                    // what 1 + x lost
+    const double ed = (double)e;
+    const double r = fma(ed, 6.93147180369123816490e-01, logm + fma(ed, 1.90821492927058770002e-10, c));
+    const double sm = x * (1.0 - x * (0.5 - x * (1.0 / 3.0 - 0.25 * x)));
+    return x < 1e-4 ? sm : r;
+}
 // e_uv, lat_z, err_ratio of edge `pos` from its accumulators and its row's out-statistics
 __device__ __forceinline__ void edge_features(const Dev& d, u32 pos) {
     const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.acc_csr + (size_t)pos * 4);
     const ulonglong2 x = a[0], y = a[1];
     const u32 from = d.csr_from[pos];
     const u64 cnt = x.x & 0xFFFFFFFFull, err = x.x >> 32, sum = x.y, mx = y.x, ssq = y.y;
-    const double m_e = mean_us(sum, cnt), s_e = std_us(sum, ssq, cnt);
+    const double rc = cnt ? sg_rcp((double)cnt) : 0.0, dc = (double)cnt;
+    // mean and standard deviation in us (mean_us / std_us with the division above: the features and lat_z take them to fp32)
+    const double sum_us = (double)sum * 1e-3;
+    double m_e = sum_us * rc; m_e = cnt ? fma(fma(-dc, m_e, sum_us), rc, m_e) : 0.0;
+    double q_e = (double)ssq * rc; q_e = cnt ? fma(fma(-dc, q_e, (double)ssq), rc, q_e) : 0.0;
+    const double var = q_e - m_e * m_e, s_e = var > 0.0 ? sqrt(var) : 0.0;
     const double mu = d.row_mu[from], sd = d.row_sd[from];           // mean_us / std_us of the row's out-statistics: computed once per row by the row sort
-    const double z = (m_e - mu) / (sd > 1.0 ? sd : 1.0);
+    const double z = sd > 1.0 ? sg_div(m_e - mu, sd) : m_e - mu;
     const float lat_z = (float)z;
-    const float err_ratio = cnt ? (float)((double)err / (double)cnt) : 0.0f;
+    // err / cnt correctly rounded to fp32: for integers below 2^24 the fp32 division IS (float)((double) err / (double) cnt) (rounding
+    // twice through a format of at least 2 x 24 + 2 bits is innocuous for a quotient); the fp64 division beyond
+    const float err_ratio = !cnt ? 0.0f : ((cnt | err) < (1ull << 24) ? (float)(u32)err / (float)(u32)cnt : (float)((double)err / (double)cnt));
     const float zc = lat_z < -8.0f ? -8.0f : (lat_z > 8.0f ? 8.0f : lat_z);
     float4* e = reinterpret_cast<float4*>(d.efeat + (size_t)pos * SG_F_EDGE);
-    e[0] = make_float4(log1p_count(d, cnt), (float)log1p(m_e / 1000.0), (float)log1p(s_e / 1000.0), (float)log1p((double)mx / 1e6));
+    e[0] = make_float4(log1p_count(d, cnt), (float)sg_log1p_pos(m_e * 1e-3), (float)sg_log1p_pos(s_e * 1e-3), (float)sg_log1p_pos((double)mx * 1e-6));
     e[1] = make_float4(err_ratio, log1p_count(d, err), zc * 0.125f, 1.0f);
     d.latz[pos] = lat_z; d.errr[pos] = err_ratio;
 }

@@ -42,6 +42,16 @@ for kid, kname in zip((0, 1), g.k1_kernels()):
         print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
     st_, en_ = (a[:, 0] - t0) / 100.0, (a[:, len(names[kid]) - 1] - t0) / 100.0
     print("  start percentiles 10/25/50/75/90:", np.round(np.percentile(st_, [10, 25, 50, 75, 90]), 1), " duration percentiles:", np.round(np.percentile(en_ - st_, [10, 50, 90]), 1))
+    if kid == 1 and a[:, 7].max() > 0:                              # where and when the workgroups of pass B start: (XCC, SE, SH, CU) of every workgroup
+        hw = a[:, 7]; cu = ((hw >> 32) & 15) * 1024 + ((hw >> 13) & 7) * 32 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15)
+        idx = np.flatnonzero(live)
+        print("  distinct CUs:", len(np.unique(cu)), " start by block-index quarter (mean us):", [round(float(st_[(idx >= q * len(idx) // 4) & (idx < (q + 1) * len(idx) // 4)].mean()), 1) for q in range(4)])
+        order = np.argsort(st_); first = {}
+        for i in order: first.setdefault(int(cu[i]), []).append(round(float(st_[i]), 1))
+        ks = sorted(first)[:6]
+        print("  starts on six CUs:", {k: first[k] for k in ks})
+        nth = np.array([[v[j] if len(v) > j else np.nan for j in range(4)] for v in first.values()])
+        print("  n-th workgroup on its CU starts at (mean us):", np.round(np.nanmean(nth, axis=0), 1), " workgroups per CU min/max:", min(len(v) for v in first.values()), max(len(v) for v in first.values()))
     ts = np.arange(0, en_.max(), 10.0)
     print("  workgroups running at t =", {int(t): int(((st_ <= t) & (en_ > t)).sum()) for t in ts})
 if st[3][:, 0].max() > 0:                                            # k3_in_part: start, LDS zeroed + barrier, slice scanned (thread 0), barrier passed, partials written
