@@ -803,7 +803,11 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
     __shared__ u64 red[7][16];
     __shared__ u32 wsum[17];
     __shared__ u32 cnt;
+    __shared__ u64 nkl;                                              // N_KNOWN + N_LABELS as thread 0 wrote them (no second trip to memory for step (c))
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // (the first stretch of the outbound-IP table travels together with the statistics: one round trip to memory, not two — this
+    // kernel is one workgroup, the chip waits for it, and it is nothing but dependent round trips)
+    const u64 ob0 = (collect == 1 && t <= d.obmask) ? d.obkeys[t] : 0ull;
     // (a)
     {
         u64 tmin = ~0ull, tmax = 0, ml = 0, ds = 0, dc = 0, mr = 0, ac = 0;
@@ -829,7 +833,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
             d.ctr[C_TMIN_NS] = red[0][0]; d.ctr[C_TMAX_NS] = red[1][0];
             u64 nl = d.ctr[C_N_LABELS];                              // labels are cumulative across windows
             nl = red[2][0] > nl ? red[2][0] : nl; nl = n_labels_decl > nl ? n_labels_decl : nl;
-            d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known;
+            d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known; nkl = nl + n_known;
             d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
             d.ctr[C_DROPPED_CAP] = red[4][0];                        // K1b / K2 add their own drops afterwards
             d.ctr[C_N_LONG] = 0;                                     // k2_rowptr's workgroups append to the long-row list
@@ -840,7 +844,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
     u32 n;
     if (collect == 1) {
         for (u32 i = t; i <= d.obmask; i += 1024) {
-            const u64 k = d.obkeys[i];
+            const u64 k = i == t ? ob0 : d.obkeys[i];
             if (k) { const u32 pos = atomicAdd(&cnt, 1u); if (pos < list_cap) list[pos] = (u32)k; }
         }
         __syncthreads();
@@ -858,6 +862,10 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
         n = off < list_cap ? off : list_cap;
     } else {
         n = *n_in < list_cap ? *n_in : list_cap;
+    }
+    if (n == 0) {                                                    // (uniform) no raw outbound IP this window: nothing to sort or to number
+        if (t == 0) { d.ctr[C_N_OBIP] = 0; d.ctr[C_N_NODES] = nkl; }
+        return;
     }
     u32 np2 = 1; while (np2 < n) np2 <<= 1;
     for (u32 i = n + t; i < np2; i += 1024) list[i] = 0xFFFFFFFFu;
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
     if (t == 0) {
         const u64 nob = total < d.max_obip ? total : d.max_obip;
         d.ctr[C_N_OBIP] = nob;
-        d.ctr[C_N_NODES] = d.ctr[C_N_KNOWN] + d.ctr[C_N_LABELS] + nob;   // thread 0 wrote both above
+        d.ctr[C_N_NODES] = nkl + nob;
     }
 }
 
@@ -986,10 +994,12 @@ __global__ __launch_bounds__(K2_DH_THREADS) void k2_deg_hist(Dev d) {
         for (int q = 0; q < K2_DH_FLIGHT; q++) {
             const u32 it = it0 + (u32)q < items ? it0 + (u32)q : items - 1;   // (uniform)
             const u32 k = it / CH, c = it - k * CH, oq = g * d.dh_ppw + k, i = c * K2_DH_THREADS + t;
+            // (the source is loaded whether or not the slot holds an edge of this window — what lies beyond the partition's count is an
+            // older window's node id, ignored below: the loads do not wait for the counts' round trip)
+            sl[q] = oq * d.pcap + (i < d.pcap ? i : 0u);             // (slots: npb * pcap < 2^32 — the host sees to it)
+            fv[q] = d.e_from[sl[q]];
             const bool ok = it0 + (u32)q < items && i < d.part_n[oq];
             okm |= ok ? (1u << q) : 0u;
-            sl[q] = oq * d.pcap + (ok ? i : 0u);                     // (slots: npb * pcap < 2^32 — the host sees to it)
-            fv[q] = d.e_from[sl[q]];
         }
     };
     issue(0);
@@ -1010,11 +1020,20 @@ __global__ __launch_bounds__(K2_DH_THREADS) void k2_deg_hist(Dev d) {
 #define K2_RP_ROWS_DH 64
 template <u32 RPR, bool DH>
 __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
-    const u32 N = (u32)d.ctr[C_N_NODES];
     __shared__ u32 wsum[17];
     __shared__ u32 rdeg[RPR];
     __shared__ u32 nlong, lbase, pre;
     const u32 b = blockIdx.x, t = threadIdx.x, r0 = b * RPR;
+    // (DH: the counts are loaded before N is known — rows beyond it read stale words inside the table (its rows are ncap + 1 rounded up
+    // to 64 words) and are zeroed below: one dependent round trip less)
+    constexpr u32 GLd = DH ? K2_DH_GMAX / 16 : 1;
+    u32 v[GLd];
+    if constexpr (DH) {
+        const u32 GG = d.dh_g >> 4, rep = t >> 6, row = r0 + (t & 63u);
+#pragma unroll
+        for (u32 j = 0; j < GLd; j++) v[j] = j < GG ? d.dh_hist[(size_t)(rep * GG + j) * d.dh_ns + row] : 0u;
+    }
+    const u32 N = (u32)d.ctr[C_N_NODES];
     if (r0 >= N && b != 0) return;                                   // beyond the last row (grid sized for ncap)
     if (t == 0) nlong = 0;
     // 1. replicas -> in-row offsets, row degrees
@@ -1027,9 +1046,8 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
         constexpr u32 GL = K2_DH_GMAX / 16;
         __shared__ u32 dtot[16][RPR];
         const u32 GG = d.dh_g >> 4, rep = t >> 6, rl = t & 63u, row = r0 + rl;   // (dh_g: a multiple of 16, <= K2_DH_GMAX)
-        u32 v[GL];
 #pragma unroll
-        for (u32 j = 0; j < GL; j++) v[j] = (j < GG && row < N) ? d.dh_hist[(size_t)(rep * GG + j) * d.dh_ns + row] : 0u;
+        for (u32 j = 0; j < GL; j++) v[j] = row < N ? v[j] : 0u;
         u32 run = 0;
 #pragma unroll
         for (u32 j = 0; j < GL; j++) { const u32 x = v[j]; v[j] = run; run += x; }
@@ -1045,11 +1063,11 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     static_assert(DH || RPR % 128 == 0, "eight lanes per row, 128 rows per pass");
     for (u32 pass = 0; pass < RPR / 128; pass++) {
         const u32 rl = pass * 128 + (t >> 3), row = r0 + rl, rep = t & 7;
-        u32 v = row < N ? d.deg[SG_DEG_IDX(row, rep)] : 0u;
-        u32 incl = v;                                                // inclusive prefix over the 8 lanes of the row
+        const u32 dv = row < N ? d.deg[SG_DEG_IDX(row, rep)] : 0u;
+        u32 incl = dv;                                               // inclusive prefix over the 8 lanes of the row
 #pragma unroll
         for (int s2 = 1; s2 < 8; s2 <<= 1) { const u32 o = __shfl_up(incl, s2, 8); if ((int)rep >= s2) incl += o; }
-        if (row < N) d.deg[SG_DEG_IDX(row, rep)] = incl - v;
+        if (row < N) d.deg[SG_DEG_IDX(row, rep)] = incl - dv;
         if (rep == 7) rdeg[rl] = incl;
     }
     }
@@ -1060,7 +1078,10 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     const u32 run = block_excl_scan<1024>(dg, wsum, &total);
     // 3. totals of the preceding workgroups
     if (t == 0) {
-        __atomic_store_n(&d.rp_tot[b], ((u64)epoch << 32) | total, __ATOMIC_RELEASE);
+        // (relaxed, device scope: the word carries everything its readers want — (epoch, total) — so nothing has to be ordered before
+        // it; a release store here waited for the workgroup's own stores and wrote the L2 back, and every acquire load of the poll loop
+        // below invalidated it: per workgroup, 236 times)
+        __hip_atomic_store(&d.rp_tot[b], ((u64)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pre = 0;
     }
     __syncthreads();
@@ -1068,7 +1089,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
         u32 mine = 0;
         for (u32 j = t; j < b; j += 1024) {
             u64 x;
-            do { x = __atomic_load_n(&d.rp_tot[j], __ATOMIC_ACQUIRE); } while ((u32)(x >> 32) != epoch);
+            do { x = __hip_atomic_load(&d.rp_tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((u32)(x >> 32) != epoch);
             mine += (u32)x;
         }
         if (b) { mine = wave_sum_u32(mine); if ((t & 63) == 0 && mine) atomicAdd(&pre, mine); }
@@ -1135,13 +1156,16 @@ __global__ __launch_bounds__(256) void k2_scatter_table(Dev d) {
 __global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
     const u32 p = blockIdx.x, n = d.part_n[p];
     // four edges per thread and trip: their loads (source, then row start + replica offset) are in flight together — one edge per
-    // trip was two dependent round trips for each of a partition's ~4 edges per thread
-    for (u32 i0 = threadIdx.x; i0 < n; i0 += 1024) {
+    // trip was two dependent round trips for each of a partition's ~4 edges per thread.  The slots are read whether or not they hold an
+    // edge of this window (beyond the count: an older window's node ids — valid indices, ignored at the store): the first trip's loads
+    // do not wait for the count.
+    const u32 pc = d.pcap;
+    for (u32 i0 = threadIdx.x; i0 < pc && (i0 < 1024u || i0 < n); i0 += 1024) {
         u32 f[4], to[4], rk[4], slot[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const u32 i = i0 + 256u * q;
-            slot[q] = p * d.pcap + (i < n ? i : i0);
+            slot[q] = p * pc + (i < pc ? i : i0);
             f[q] = d.e_from[slot[q]]; to[q] = d.e_to[slot[q]]; rk[q] = d.e_rank[slot[q]];
         }
         u32 rp[4], dg[4];
@@ -1777,13 +1801,17 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
 }
 __global__ __launch_bounds__(256) void k3_in_reduce(Dev d, u32 S) {
     const u32 N = (u32)d.ctr[C_N_NODES];
-    k2_split_finish(d, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);   // the out-statistics of the rows the row sort took block by block
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < (u64)N * 6; i += (u64)gridDim.x * 256) {
+    // the out-statistics of the rows the row sort took block by block: the launch's LAST workgroup, and nothing else there (three
+    // dependent round trips — in front of the reduction they were on the path of the threads that ran both)
+    if (blockIdx.x == gridDim.x - 1) { k2_split_finish(d, threadIdx.x, 256); return; }
+    const u32 GW = gridDim.x - 1;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < (u64)N * 6; i += (u64)GW * 256) {
         const u32 v = (u32)(i / 6), k = (u32)(i % 6), r = v / K3_IN_NR;
         const u64* p = d.in_part + ((size_t)r * S * K3_IN_NR + (v - r * K3_IN_NR)) * 6 + k;
         const size_t st = (size_t)K3_IN_NR * 6;
         u64 a = 0;
         u32 sl = 0;
+        // (measured: all 32 slices in one batch of loads instead of four batches of eight — 10.1 -> 12.1 us on one kind of box)
         if (k == 5) {
             for (; sl + 8 <= S; sl += 8) {                           // eight independent loads in flight
                 u64 x[8];
@@ -2787,11 +2815,11 @@ __global__ __launch_bounds__(1024) void k6_halo_lists(Dev d, u32* req, u32 capp,
         u32 acc = 0;                                                 // the totals of the workgroups before it summed
         for (u32 w2 = 0; w2 < 16; w2++) { const u32 x = wcnt[t][w2]; wcnt[t][w2] = acc; acc += x; }
         tot[t] = acc;
-        __atomic_store_n(&d.k6_tot[(size_t)b * 16 + t], ((u64)epoch << 32) | acc, __ATOMIC_RELEASE);
+        __hip_atomic_store(&d.k6_tot[(size_t)b * 16 + t], ((u64)epoch << 32) | acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (relaxed: see k2_rowptr)
         u32 pre = 0;
         for (u32 j = 0; j < b; j++) {
             u64 x;
-            do { x = __atomic_load_n(&d.k6_tot[(size_t)j * 16 + t], __ATOMIC_ACQUIRE); } while ((u32)(x >> 32) != epoch);
+            do { x = __hip_atomic_load(&d.k6_tot[(size_t)j * 16 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((u32)(x >> 32) != epoch);
             pre += (u32)x;
         }
         base[t] = pre;
