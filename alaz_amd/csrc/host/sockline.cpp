@@ -2,7 +2,11 @@
 #include "sockline.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cstring>
+#include <ctime>
+#include <fstream>
+#include <unistd.h>
 
 #include "graph_ds.hpp"   // FormatIPv4
 
@@ -99,27 +103,127 @@ TcpConnectEvent DecodeWire(const uint8_t* r) {
 }
 }  // namespace tcp_state
 
-ConnTracker::~ConnTracker() { for (auto* l : all_) delete l; }
+namespace procfs {
 
-SocketLine* ConnTracker::Line(uint32_t pid, uint64_t fd) {
+bool InodeOfLink(const std::string& link, std::string* inode) {
+    static const std::string lead = "socket:[";
+    for (size_t at = link.find(lead); at != std::string::npos; at = link.find(lead, at + 1)) {
+        size_t b = at + lead.size(), e = b;
+        while (e < link.size() && link[e] >= '0' && link[e] <= '9') e++;
+        if (e > b && e < link.size() && link[e] == ']') { *inode = link.substr(b, e - b); return true; }
+    }
+    return false;
+}
+
+// Go's strconv.ParseInt(text, 16, 64) with the error dropped: 0 for anything that is not [+-]hexdigits, the extreme
+// value on overflow (callers clamp or truncate afterwards)
+static int64_t HexInt(const std::string& t) {
+    size_t i = 0; bool neg = false;
+    if (!t.empty() && (t[0] == '+' || t[0] == '-')) { neg = t[0] == '-'; i = 1; }
+    if (i == t.size()) return 0;
+    uint64_t v = 0; bool big = false;
+    for (; i < t.size(); i++) {
+        const char c = t[i]; unsigned d;
+        if (c >= '0' && c <= '9') d = (unsigned)(c - '0'); else if (c >= 'a' && c <= 'f') d = (unsigned)(c - 'a') + 10; else if (c >= 'A' && c <= 'F') d = (unsigned)(c - 'A') + 10; else return 0;
+        big = big || (v >> 60) != 0;
+        v = v * 16 + d;
+    }
+    const uint64_t lim = neg ? (1ull << 63) : (1ull << 63) - 1;
+    if (big || v > lim) return neg ? INT64_MIN : INT64_MAX;
+    return neg ? (int64_t)(0 - v) : (int64_t)v;
+}
+
+static bool IsGoSpace(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+bool ParseTcpLine(const std::string& line, uint32_t* laddr, uint16_t* lport, uint32_t* raddr, uint16_t* rport) {
+    std::string col[3]; int n = 0; size_t i = 0;
+    while (n < 3) {
+        while (i < line.size() && IsGoSpace(line[i])) i++;
+        if (i == line.size()) break;
+        const size_t b = i; while (i < line.size() && !IsGoSpace(line[i])) i++;
+        col[n++] = line.substr(b, i - b);
+    }
+    if (n < 3 || col[1].size() < 9 || col[2].size() < 9) return false;
+    auto addr = [](const std::string& c) {                     // byte k of the text is the k-th LOWEST byte of the address
+        uint32_t a = 0;
+        for (int k = 0; k < 4; k++) a |= ((uint32_t)HexInt(c.substr(2 * k, 2)) & 0xFFu) << (8 * k);
+        return a;
+    };
+    auto port = [](const std::string& c) { const int64_t p = HexInt(c.substr(9)); return (uint16_t)((p < 0 || p > 65535) ? 0 : p); };
+    *laddr = addr(col[1]); *lport = port(col[1]); *raddr = addr(col[2]); *rport = port(col[2]);
+    return true;
+}
+
+}  // namespace procfs
+
+SocketLine::Seed SocketLine::SeedFromProc(const std::string& root, uint64_t now_kernel_ns) {
+    char target[256];
+    const std::string fdpath = root + "/" + std::to_string(pid_) + "/fd/" + std::to_string(fd_);
+    const ssize_t got = ::readlink(fdpath.c_str(), target, sizeof target - 1);
+    if (got < 0) return Seed::NoLink;
+    std::string inode;
+    if (!procfs::InodeOfLink(std::string(target, (size_t)got), &inode)) return Seed::NoInode;
+    std::ifstream tcp(root + "/" + std::to_string(pid_) + "/net/tcp");
+    if (!tcp.is_open()) return Seed::NoTcpFile;
+    std::string row; bool hit = false;
+    while (std::getline(tcp, row)) {
+        if (row.size() >= 65536) break;                          // the reference's line scanner stops at a 64 KiB token
+        if (!row.empty() && row.back() == '\r') row.pop_back();
+        if (row.find(inode) != std::string::npos) { hit = true; break; }     // substring of the WHOLE line, whichever column
+    }
+    if (!hit) return Seed::NoLineFound;
+    SockInfo si; si.Pid = pid_; si.Fd = fd_;
+    if (!procfs::ParseTcpLine(row, &si.Saddr, &si.Sport, &si.Daddr, &si.Dport)) return Seed::ShortLine;
+    { std::lock_guard<std::mutex> g(mu_); values_.clear(); }
+    AddValue(now_kernel_ns, &si);
+    return Seed::Ok;
+}
+
+std::shared_ptr<SocketLine> ConnTracker::Find(uint32_t pid, uint64_t fd) const {
     std::lock_guard<std::mutex> g(mu_);
     auto p = maps_.find(pid);
     if (p == maps_.end()) return nullptr;
     auto f = p->second.find(fd);
     return f == p->second.end() ? nullptr : f->second;
 }
+SocketLine* ConnTracker::Line(uint32_t pid, uint64_t fd) { return Find(pid, fd).get(); }
 size_t ConnTracker::Lines() const { std::lock_guard<std::mutex> g(mu_); return all_.size(); }
+
+void ConnTracker::SetProcRoot(const std::string& root, uint64_t first_kernel_ns, uint64_t first_user_ns, uint64_t now_user_ns) {
+    std::lock_guard<std::mutex> g(mu_);
+    proc_root_ = root; first_kernel_ = first_kernel_ns; first_user_ = first_user_ns; now_user_ = now_user_ns;
+}
+
+size_t ConnTracker::ClearProc(uint32_t pid) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto p = maps_.find(pid);
+    if (p == maps_.end()) return 0;
+    const size_t n = p->second.size();
+    maps_.erase(p);
+    all_.erase(std::remove_if(all_.begin(), all_.end(), [pid](const std::shared_ptr<SocketLine>& l) { return l->Pid() == pid; }), all_.end());
+    return n;
+}
 
 bool ConnTracker::ProcessTcpConnect(const tcp_state::TcpConnectEvent& e) {
     if (e.Type != tcp_state::kEstablished && e.Type != tcp_state::kClosed) return false;
     const uint32_t localhost = 0x7F000001u;
     if (e.SAddr == localhost || e.DAddr == localhost) return false;
-    SocketLine* line = Line(e.Pid, e.Fd);
+    std::shared_ptr<SocketLine> line = Find(e.Pid, e.Fd);
     if (e.Type == tcp_state::kEstablished) {
         if (!line) {
+            // seeded outside the tracker's lock (file system reads) and published afterwards, like the reference's
+            // creation worker (socket.go:44-82); of two racing creators one line wins, the other is dropped unpublished
+            auto fresh = std::make_shared<SocketLine>(e.Pid, e.Fd);
+            std::string root; uint64_t fk, fu, now;
+            { std::lock_guard<std::mutex> g(mu_); root = proc_root_; fk = first_kernel_; fu = first_user_; now = now_user_; }
+            bool seeded = false, tried = false;
+            if (!root.empty()) {
+                if (now == 0) { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); now = (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
+                tried = true; seeded = fresh->SeedFromProc(root, fk - (fu - now)) == SocketLine::Seed::Ok;
+            }
             std::lock_guard<std::mutex> g(mu_);
-            SocketLine*& slot = maps_[e.Pid][e.Fd];
-            if (!slot) { slot = new SocketLine(e.Pid, e.Fd); all_.push_back(slot); }
+            std::shared_ptr<SocketLine>& slot = maps_[e.Pid][e.Fd];
+            if (!slot) { slot = fresh; all_.push_back(fresh); if (tried) (seeded ? seeds_ok_ : seeds_failed_)++; }
             line = slot;
         }
         SockInfo si; si.Pid = e.Pid; si.Fd = e.Fd; si.Saddr = e.SAddr; si.Sport = e.SPort; si.Daddr = e.DAddr; si.Dport = e.DPort;
@@ -132,10 +236,10 @@ bool ConnTracker::ProcessTcpConnect(const tcp_state::TcpConnectEvent& e) {
 }
 
 size_t ConnTracker::Sweep(int64_t now_ms, bool send_alive, datastore::DataStore* ds) {
-    std::vector<SocketLine*> lines;
+    std::vector<std::shared_ptr<SocketLine>> lines;
     { std::lock_guard<std::mutex> g(mu_); lines = all_; }
     size_t sent = 0;
-    for (SocketLine* l : lines) {
+    for (const auto& l : lines) {
         SockInfo si;
         if (send_alive && ds && l->LastOpen(&si)) {
             datastore::AliveConnection ac;

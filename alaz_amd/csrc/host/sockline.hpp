@@ -9,11 +9,16 @@
 //   sendOpenConnection / sweep         aggregator/data.go:1628-1716
 // Addresses are numeric IPv4 here (a<<24|b<<16|c<<8|d, like L7Event.Saddr); the reference keeps dotted
 // strings, the oracle (oracle/sockline.c) does too, and tests/test_sockline.py compares the two.
+//   NewSocketLine(fetch) / getConnectionInfo   aggregator/sock_num_line.go:38-54, 351-429 (SeedFromProc)
+//   clearProc / processExit            aggregator/cluster.go:97-110, data.go:363-398 (ClearProc)
 // Differences by design: the reference creates a process' socket map and an fd's socket line
-// asynchronously (and may seed the line from /proc/<pid>/net/tcp) and re-queues the event meanwhile;
-// here the line is created on demand and starts empty.  time.Now() is a parameter.
+// asynchronously and re-queues the event meanwhile; here the line is created on demand — seeded from
+// <proc root>/<pid>/fd/<fd> and <proc root>/<pid>/net/tcp first when the tracker was given a proc root, as
+// NewSocketLine(fetch = true) does — and the event applied right after, which is the state the reference
+// reaches when its re-queue loop has settled.  time.Now() is a parameter.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -45,6 +50,12 @@ public:
     SockErr GetValue(uint64_t timestamp, uint64_t now_ns, SockInfo* out);
     void DeleteUnused();
     bool LastOpen(SockInfo* out) const;                                  // what sendOpenConnection looks at
+    // getConnectionInfo: the fd's link names a socket inode; the first line of net/tcp that contains the inode's
+    // digits is taken for the connection; all values are dropped and one open value stamped now_kernel_ns is added
+    enum class Seed { Ok = 0, NoLink = 1, NoInode = 2, NoTcpFile = 3, NoLineFound = 4, ShortLine = 5 };
+    Seed SeedFromProc(const std::string& proc_root, uint64_t now_kernel_ns);
+    uint32_t Pid() const { return pid_; }
+    uint64_t Fd() const { return fd_; }
     size_t Size() const;
     TimestampedSocket At(size_t i) const;
 private:
@@ -63,6 +74,14 @@ struct TcpConnectEvent {                                                   // tc
 TcpConnectEvent DecodeWire(const uint8_t* rec);                            // BpfTcpEvent, tcp.go:63-72
 }  // namespace tcp_state
 
+namespace procfs {
+// the digits of the first `socket:[<digits>]` in a /proc/<pid>/fd/<fd> link text (sock_num_line.go:358-363); false if none
+bool InodeOfLink(const std::string& link, std::string* inode);
+// columns 1 and 2 of a /proc/net/tcp line: little-endian hex IPv4 + ':' + hex port (sock_num_line.go:332-349, 384-397).
+// Out-of-syntax hex pairs read as 0, ports beyond 65535 as 0, as the reference's ignored ParseInt errors leave them.
+bool ParseTcpLine(const std::string& line, uint32_t* laddr, uint16_t* lport, uint32_t* raddr, uint16_t* rport);
+}  // namespace procfs
+
 // clusterInfo.SocketMaps + the two aggregator routines that touch them
 class ConnTracker {
 public:
@@ -72,14 +91,24 @@ public:
     // ds->PersistAliveConnection (resolution of UIDs is left to the data store — GraphDS does it on the
     // GPU from the IPs; FromType/ToType/UIDs stay empty here), then DeleteUnused.  Returns lines reported.
     size_t Sweep(int64_t now_ms, bool send_alive, datastore::DataStore* ds);
-    SocketLine* Line(uint32_t pid, uint64_t fd);
+    SocketLine* Line(uint32_t pid, uint64_t fd);                       // borrowed; dies with ClearProc(pid)
     size_t Lines() const;
+    // NewSocketLine(fetch = true): lines created from now on are seeded from `root` ("" = off, the default: a library
+    // must not read /proc of whatever pids a replay happens to carry).  The seeded value's stamp is
+    // convertUserTimeToKernelTime(now) = first_kernel − (first_user − now) (data.go:1745-1747); now_user_ns = 0 means
+    // the wall clock.
+    void SetProcRoot(const std::string& root, uint64_t first_kernel_ns, uint64_t first_user_ns, uint64_t now_user_ns = 0);
+    // clearProc: every line of the process is gone (process exit)
+    size_t ClearProc(uint32_t pid);
+    uint64_t SeedsOk() const { return seeds_ok_; }
+    uint64_t SeedsFailed() const { return seeds_failed_; }
 private:
+    std::shared_ptr<SocketLine> Find(uint32_t pid, uint64_t fd) const;
     mutable std::mutex mu_;
-    std::unordered_map<uint32_t, std::unordered_map<uint64_t, SocketLine*>> maps_;   // pid -> fd -> line
-    std::vector<SocketLine*> all_;
-public:
-    ~ConnTracker();
+    std::unordered_map<uint32_t, std::unordered_map<uint64_t, std::shared_ptr<SocketLine>>> maps_;   // pid -> fd -> line
+    std::vector<std::shared_ptr<SocketLine>> all_;                                                    // in order of creation
+    std::string proc_root_;
+    uint64_t first_kernel_ = 0, first_user_ = 0, now_user_ = 0, seeds_ok_ = 0, seeds_failed_ = 0;
 };
 
 }  // namespace alaz

@@ -113,6 +113,10 @@ def _load():
         "or_sl_get": (C.c_int, [P, C.c_uint64, C.c_uint64, C.POINTER(SockInfo)]),
         "or_sl_delete_unused": (None, [P]), "or_sl_len": (C.c_size_t, [P]),
         "or_sl_at": (C.c_int, [P, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(SockInfo)]),
+        "or_sl_seed_from_proc": (C.c_int, [P, C.c_char_p, C.c_uint64]),
+        "or_sl_inode_from_link": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
+        "or_sl_parse_tcp_line": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_int)]),
+        "or_set_proc_root": (None, [P, C.c_char_p, C.c_uint64]), "or_process_exit": (None, [P, C.c_uint32]),
         "or_process_tcp": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint16, C.c_char_p, C.c_uint16]),
         "or_process_tcp_wire": (C.c_size_t, [P, C.c_void_p, C.c_size_t]),
         "or_sockline_of": (P, [P, C.c_uint32, C.c_uint64]), "or_sockline_count": (C.c_size_t, [P]), "or_pg_stmt_count": (C.c_size_t, [P]),
@@ -157,6 +161,20 @@ def lib():
     return _lib
 
 
+def inode_from_link(link: str) -> Optional[str]:
+    """getInodeFromFD's regexp (sock_num_line.go:358-363) on a link text."""
+    buf = C.create_string_buffer(32)
+    return buf.value.decode() if lib().or_sl_inode_from_link(link.encode(), buf, 32) == 0 else None
+
+
+def parse_tcp_line(line: str):
+    """parseTcpLine (sock_num_line.go:384-397) -> (local ip, local port, remote ip, remote port) or None."""
+    a, b, lp, rp = C.create_string_buffer(16), C.create_string_buffer(16), C.c_int(), C.c_int()
+    if lib().or_sl_parse_tcp_line(line.encode(), a, C.byref(lp), b, C.byref(rp)) != 0:
+        return None
+    return a.value.decode(), lp.value, b.value.decode(), rp.value
+
+
 def sockinfo(saddr="", sport=0, daddr="", dport=0, pid=0, fd=0) -> SockInfo:
     return SockInfo(pid, fd, saddr.encode(), sport, daddr.encode(), dport)
 
@@ -185,6 +203,10 @@ class SockLine:
         return (out, None) if rc == 0 else (None, SL_ERRORS[rc])
 
     def delete_unused(self): self._l.or_sl_delete_unused(self._s)
+
+    def seed_from_proc(self, proc_root: str, now_kernel_ns: int) -> int:
+        """getConnectionInfo (sock_num_line.go:399-429) against `proc_root` instead of /proc; 0 = seeded."""
+        return self._l.or_sl_seed_from_proc(self._s, proc_root.encode(), now_kernel_ns)
 
     def __len__(self): return self._l.or_sl_len(self._s)
 
@@ -366,6 +388,11 @@ class Oracle:
         return SockLine(_borrowed=p) if p else None
 
     def sockline_count(self) -> int: return self._l.or_sockline_count(self._o)
+
+    def set_proc_root(self, root: Optional[str], now_user_ns: int = 0):
+        self._l.or_set_proc_root(self._o, root.encode() if root is not None else None, now_user_ns)
+
+    def process_exit(self, pid: int): self._l.or_process_exit(self._o, pid)
 
     def pg_stmt_count(self) -> int: return self._l.or_pg_stmt_count(self._o)
 

@@ -107,7 +107,8 @@ struct oracle {
     uint64_t dropped_src, dropped_parse;
 
     /* f-2: clusterInfo.SocketMaps (pid -> fd -> SocketLine), flattened to "pid:fd" -> index */
-    strmap sock_index; or_sockline** socklines; size_t n_socklines, cap_socklines;
+    strmap sock_index; or_sockline** socklines; size_t n_socklines, cap_socklines;   /* a cleared process leaves NULL slots */
+    char* proc_root; uint64_t now_user_ns;            /* set: a new line is seeded from <proc_root>/<pid>/... (NewSocketLine fetch = true) */
     or_alive* alive_log; size_t alive_n, alive_cap; size_t alive_persisted;
     or_h2* h2;                /* f-4: HTTP/2 request assembly (http2.c) */
     int kafka_decode;         /* f-4: decode Kafka payloads (kafka.c) instead of taking the message count as a side input */
@@ -156,7 +157,7 @@ void or_destroy(oracle_t* o) {
     free(o->labels); free(o->log); free(o->wedges);
     sm_free(&o->sock_index);
     for (size_t i = 0; i < o->n_socklines; i++) or_sl_destroy(o->socklines[i]);
-    free(o->socklines); free(o->alive_log);
+    free(o->socklines); free(o->alive_log); free(o->proc_root);
     or_h2_destroy(o->h2);
     free_closed(o);
     free(o);
@@ -629,7 +630,30 @@ or_sockline* or_sockline_of(oracle_t* o, uint32_t pid, uint64_t fd) {
     sm_ent* e = sm_find(&o->sock_index, key);
     return e ? o->socklines[e->uval] : NULL;
 }
-size_t or_sockline_count(const oracle_t* o) { return o->n_socklines; }
+size_t or_sockline_count(const oracle_t* o) { size_t n = 0; for (size_t i = 0; i < o->n_socklines; i++) n += o->socklines[i] != NULL; return n; }
+
+/* "/proc" for NewSocketLine's fetch (NULL: lines start empty) and the time.Now() it stamps the seeded value with */
+void or_set_proc_root(oracle_t* o, const char* root, uint64_t now_user_ns) {
+    free(o->proc_root); o->proc_root = root ? strdup(root) : NULL; o->now_user_ns = now_user_ns;
+}
+
+/* processExit — aggregator/data.go:363-398: clearProc (cluster.go:97-110: the process' socket map, i.e. every line
+ * of the pid, is gone), the pid's HTTP/2 parsers and Postgres statements by STRING PREFIX of the decimal pid
+ * (pid 12 also clears 123's), rate limiter (not on this path).  The MySQL loop :391-397 ranges over pgStmts —
+ * whose keys with this prefix were deleted just above — so no MySQL statement is ever removed here. */
+void or_process_exit(oracle_t* o, uint32_t pid) {
+    for (size_t i = 0; i < o->n_socklines; i++) {
+        or_sockline* sl = o->socklines[i];
+        uint64_t fd;
+        if (!sl || or_sl_owner(sl, &fd) != pid) continue;
+        char key[48]; snprintf(key, sizeof key, "%u:%llu", pid, (unsigned long long)fd);
+        sm_del(&o->sock_index, key);
+        or_sl_destroy(sl); o->socklines[i] = NULL;
+    }
+    or_h2_proc_exit(o->h2, pid);
+    char pfx[16]; snprintf(pfx, sizeof pfx, "%u", pid);
+    sm_del_prefix(&o->pg_stmts, pfx);
+}
 size_t or_pg_stmt_count(const oracle_t* o) { return o->pg_stmts.used; }
 
 /* processTcpConnect — aggregator/data.go:404-506 */
@@ -645,6 +669,8 @@ int or_process_tcp(oracle_t* o, uint32_t type, uint32_t pid, uint64_t fd, uint64
             char key[48]; snprintf(key, sizeof key, "%u:%llu", pid, (unsigned long long)fd);
             sm_put(&o->sock_index, key, NULL, (uint32_t)o->n_socklines);
             o->socklines[o->n_socklines++] = sl;
+            /* sock_num_line.go:38-54: populated from /proc BEFORE the re-queued event finds the line */
+            if (o->proc_root) (void)or_sl_seed_from_proc(sl, o->proc_root, o->first_kernel - (o->first_user - o->now_user_ns));   /* data.go:1745-1747 */
         }
         or_sockinfo si; memset(&si, 0, sizeof si);
         si.pid = pid; si.fd = fd; si.sport = sport; si.dport = dport;
@@ -677,6 +703,7 @@ size_t or_sweep_socket_lines(oracle_t* o, int64_t now_ms, int send_alive) {
     size_t sent = 0;
     for (size_t i = 0; i < o->n_socklines; i++) {
         or_sockline* sl = o->socklines[i];
+        if (!sl) continue;
         size_t len = or_sl_len(sl);
         if (send_alive && len > 0) {
             or_sockinfo si; uint64_t ts, lm;

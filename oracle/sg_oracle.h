@@ -141,6 +141,15 @@ int    or_sl_get(or_sockline* s, uint64_t ts, uint64_t now_ns, or_sockinfo* out)
 void   or_sl_delete_unused(or_sockline* s);
 size_t or_sl_len(const or_sockline* s);
 int    or_sl_at(const or_sockline* s, size_t i, uint64_t* ts, uint64_t* last_match, or_sockinfo* si); /* 1 open, 0 close, -1 out of range */
+uint32_t or_sl_owner(const or_sockline* s, uint64_t* fd);                                             /* pid (and fd) of the line */
+/* NewSocketLine(fetch = true) -> getConnectionInfo (sock_num_line.go:38-54, 351-429): fd link -> inode -> first line of
+ * <proc_root>/<pid>/net/tcp containing it -> ClearAll + one open value at now_kernel_ns.  0 seeded; 1 readlink, 2 no inode
+ * in the link, 3 net/tcp unreadable, 4 no line, 5 line too short to index (the reference would panic).  Pinned by the
+ * reference's own example in the source (sock_num_line.go:244-246: "7038A8C0:A24A C28D640A:0050" = 192.168.56.112:41546 ->
+ * 10.100.141.194:80); the reference has no test of this function. */
+int    or_sl_seed_from_proc(or_sockline* s, const char* proc_root, uint64_t now_kernel_ns);
+int    or_sl_inode_from_link(const char* link, char* inode, size_t cap);
+int    or_sl_parse_tcp_line(const char* line, char lip[16], int* lport, char rip[16], int* rport);
 
 /* BpfTcpEvent (ebpf/tcp_state/tcp.go:63-72): fd u64@0, timestamp u64@8, type u32@16, pid u32@20,
  * sport u16@24, dport u16@26, saddr[16]@28, daddr[16]@44 (first 4 bytes = a.b.c.d), padded to 64. */
@@ -148,10 +157,18 @@ int    or_sl_at(const or_sockline* s, size_t i, uint64_t* ts, uint64_t* last_mat
 enum { OR_TCP_ESTABLISHED = 1, OR_TCP_CONNECT_FAILED = 2, OR_TCP_LISTEN = 3, OR_TCP_LISTEN_CLOSED = 4, OR_TCP_CLOSED = 5 };
 /* processTcpConnect (aggregator/data.go:404-506).  The reference re-queues an event until the
  * process' socket map / the fd's socket line exists (created asynchronously, optionally from /proc);
- * here the line is created on demand and starts empty.  Returns 1 if a value was added. */
+ * here the line is created on demand — empty, or seeded from the proc file system when or_set_proc_root was given
+ * one — and the event applied right after: the state the reference reaches once its re-queue loop has settled (a line
+ * is published to the map only after its seeding, socket.go:77-82, so the seed is always the older arrival; an event whose
+ * address pair equals the seed's is then dropped by AddValue's last-equal rule).  Returns 1 if a value was added. */
 int    or_process_tcp(oracle_t* o, uint32_t type, uint32_t pid, uint64_t fd, uint64_t ts,
                       const char* saddr, uint16_t sport, const char* daddr, uint16_t dport);
 size_t or_process_tcp_wire(oracle_t* o, const uint8_t* recs, size_t n);
+/* root != NULL: a line created by or_process_tcp is first seeded from <root>/<pid>/fd/<fd> + <root>/<pid>/net/tcp, stamped
+ * convertUserTimeToKernelTime(now_user_ns) (or_set_clock's pair); the event that caused it is applied afterwards, as the
+ * reference's re-queue does (data.go:430-450) */
+void   or_set_proc_root(oracle_t* o, const char* root, uint64_t now_user_ns);
+void   or_process_exit(oracle_t* o, uint32_t pid);                         /* processExit, data.go:363-398 */
 or_sockline* or_sockline_of(oracle_t* o, uint32_t pid, uint64_t fd);     /* NULL if none */
 size_t or_pg_stmt_count(const oracle_t* o);                                /* prepared statements remembered (pgStmts) */
 size_t or_sockline_count(const oracle_t* o);

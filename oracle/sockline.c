@@ -36,6 +36,7 @@ or_sockline* or_sl_create(uint32_t pid, uint64_t fd) {
 }
 void or_sl_destroy(or_sockline* s) { if (s) { free(s->v); free(s); } }
 size_t or_sl_len(const or_sockline* s) { return s->n; }
+uint32_t or_sl_owner(const or_sockline* s, uint64_t* fd) { if (fd) *fd = s->fd; return s->pid; }
 int or_sl_at(const or_sockline* s, size_t i, uint64_t* ts, uint64_t* last_match, or_sockinfo* si) {
     if (i >= s->n) return -1;
     if (ts) *ts = s->v[i].ts;
@@ -122,4 +123,106 @@ void or_sl_delete_unused(or_sockline* s) {
             k--;
         }
     }
+}
+
+/* ---------------------------------------------------------------------------------------------- *
+ * A new line seeded from the proc file system — NewSocketLine(fetch = true) :38-54 →
+ * getConnectionInfo :399-429.  `proc_root` stands for "/proc" (the tests point it at a directory they
+ * built), `now_kernel_ns` for convertUserTimeToKernelTime(time.Now()) (data.go:1745-1747).
+ * ---------------------------------------------------------------------------------------------- */
+#include <stdio.h>
+#include <unistd.h>
+
+/* getInodeFromFD :351-366 — regexp `socket:\[(\d+)\]`, FindStringSubmatch: the FIRST match anywhere in
+ * the link text, at least one digit.  Returns 0 and the digits, or -1 ("no inode found in link"). */
+int or_sl_inode_from_link(const char* link, char* inode, size_t cap) {
+    static const char lead[] = "socket:[";
+    for (const char* p = strstr(link, lead); p; p = strstr(p + 1, lead)) {
+        const char* d = p + sizeof lead - 1; size_t n = 0;
+        while (d[n] >= '0' && d[n] <= '9') n++;
+        if (n > 0 && d[n] == ']') {
+            if (n + 1 > cap) return -1;
+            memcpy(inode, d, n); inode[n] = 0;
+            return 0;
+        }
+    }
+    return -1;
+}
+
+/* strconv.ParseInt(s, 16, 64) as the callers below use it (error ignored): the value on success; 0 on a
+ * syntax error (empty, a non-hex digit, a lone sign); the clamped extreme on overflow. */
+static long long parse_hex_i64(const char* s, size_t n) {
+    if (n == 0) return 0;
+    int neg = 0; size_t i = 0;
+    if (s[0] == '+' || s[0] == '-') { neg = s[0] == '-'; i = 1; if (n == 1) return 0; }
+    unsigned long long v = 0; int over = 0;
+    for (; i < n; i++) {
+        int c = (unsigned char)s[i], d;
+        if (c >= '0' && c <= '9') d = c - '0'; else if (c >= 'a' && c <= 'f') d = c - 'a' + 10; else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+        else return 0;                                  /* (an underscore is a syntax error with an explicit base) */
+        if (v >> 60) over = 1;
+        v = (v << 4) | (unsigned)d;
+    }
+    if (over || v > (neg ? 1ull << 63 : (1ull << 63) - 1)) return neg ? (long long)(1ull << 63) : (long long)((1ull << 63) - 1);
+    return neg ? -(long long)v : (long long)v;
+}
+
+/* convertHexToIP :332-340: one "%d" per two hex characters, order reversed, joined by dots */
+static void hex_to_ip(const char* hex8, char out[16]) {
+    long long part[4];
+    for (int i = 0; i < 4; i++) part[i] = parse_hex_i64(hex8 + 2 * i, 2);
+    snprintf(out, 16, "%lld.%lld.%lld.%lld", part[3], part[2], part[1], part[0]);
+}
+
+/* parseTcpLine :384-397 — strings.Fields, fields[1] / fields[2], address = [:8], port = [9:].
+ * The reference indexes without checking (a short line would panic; /proc never produces one): -1 here. */
+int or_sl_parse_tcp_line(const char* line, char lip[16], int* lport, char rip[16], int* rport) {
+    const char* f[3]; size_t fl[3]; int nf = 0;
+    const char* p = line;
+    while (*p && nf < 3) {
+        while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r') p++;
+        if (!*p) break;
+        f[nf] = p; while (*p && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r')) p++;
+        fl[nf] = (size_t)(p - f[nf]); nf++;
+    }
+    if (nf < 3 || fl[1] < 9 || fl[2] < 9) return -1;
+    hex_to_ip(f[1], lip); hex_to_ip(f[2], rip);
+    long long lp = parse_hex_i64(f[1] + 9, fl[1] - 9), rp = parse_hex_i64(f[2] + 9, fl[2] - 9);   /* convertHexToPort :343-349 */
+    *lport = (lp < 0 || lp > 65535) ? 0 : (int)lp;
+    *rport = (rp < 0 || rp > 65535) ? 0 : (int)rp;
+    return 0;
+}
+
+/* getConnectionInfo :399-429.  0 = seeded (all previous values cleared, one open value at now_kernel_ns);
+ * 1 readlink failed, 2 no inode in the link, 3 net/tcp not readable, 4 no line contains the inode
+ * (findTCPConnection :368-382: the first line of the file that CONTAINS the inode's digits anywhere —
+ * header line included, and an address or queue column may match before the inode column does). */
+int or_sl_seed_from_proc(or_sockline* s, const char* proc_root, uint64_t now_kernel_ns) {
+    char path[512], link[256], inode[32];
+    snprintf(path, sizeof path, "%s/%u/fd/%llu", proc_root, s->pid, (unsigned long long)s->fd);
+    ssize_t ln = readlink(path, link, sizeof link - 1);
+    if (ln < 0) return 1;
+    link[ln] = 0;
+    if (or_sl_inode_from_link(link, inode, sizeof inode) != 0) return 2;
+    snprintf(path, sizeof path, "%s/%u/net/tcp", proc_root, s->pid);
+    FILE* f = fopen(path, "r");
+    if (!f) return 3;
+    char* line = NULL; size_t cap = 0; int found = 0;
+    while (getline(&line, &cap, f) >= 0) {
+        size_t l = strlen(line);
+        if (l > 65536) break;                                   /* bufio.Scanner gives up on a token above 64 KiB: the scan ends */
+        if (l && line[l - 1] == '\n') line[--l] = 0;
+        if (l && line[l - 1] == '\r') line[--l] = 0;            /* ScanLines drops one trailing \r */
+        if (strstr(line, inode)) { found = 1; break; }
+    }
+    fclose(f);
+    if (!found) { free(line); return 4; }
+    or_sockinfo si; memset(&si, 0, sizeof si);
+    int lp = 0, rp = 0;
+    if (or_sl_parse_tcp_line(line, si.saddr, &lp, si.daddr, &rp) != 0) { free(line); return 5; }
+    free(line);
+    si.pid = s->pid; si.fd = s->fd; si.sport = (uint16_t)lp; si.dport = (uint16_t)rp;
+    s->n = 0;                                                   /* ClearAll :56-60 */
+    or_sl_add(s, now_kernel_ns, &si);
+    return 0;
 }
