@@ -168,6 +168,17 @@ int sgh_sockline_get(void* l, uint64_t ts, uint64_t now_ns, sgh_sockinfo* out) {
     if (e == SockErr::Ok && out) { out->pid = s.Pid; out->fd = s.Fd; out->saddr = s.Saddr; out->sport = s.Sport; out->daddr = s.Daddr; out->dport = s.Dport; }
     return (int)e;
 }
+// getConnectionInfo against `proc_root` (sock_num_line.go:399-429): 0 = seeded, else SocketLine::Seed
+int sgh_sockline_seed(void* l, const char* proc_root, uint64_t now_kernel_ns) { return (int)static_cast<SocketLine*>(l)->SeedFromProc(proc_root, now_kernel_ns); }
+int sgh_proc_inode_of_link(const char* link, char* inode, size_t cap) {
+    std::string v;
+    if (!procfs::InodeOfLink(link, &v) || v.size() + 1 > cap) return -1;
+    std::memcpy(inode, v.c_str(), v.size() + 1);
+    return 0;
+}
+int sgh_proc_parse_tcp_line(const char* line, uint32_t* laddr, uint16_t* lport, uint32_t* raddr, uint16_t* rport) {
+    return procfs::ParseTcpLine(line, laddr, lport, raddr, rport) ? 0 : -1;
+}
 void sgh_sockline_delete_unused(void* l) { static_cast<SocketLine*>(l)->DeleteUnused(); }
 size_t sgh_sockline_len(void* l) { return static_cast<SocketLine*>(l)->Size(); }
 int sgh_sockline_at(void* l, size_t i, uint64_t* ts, uint64_t* last_match, sgh_sockinfo* out) {
@@ -192,7 +203,13 @@ size_t sgh_graphds_tcp_wire(void* g, const uint8_t* recs, size_t n) {
 }
 // process exec / exit (proc events, data.go:354-377) and the HTTP/2 minute sweep (:553-567)
 void sgh_graphds_proc_exec(void* g, uint32_t pid) { static_cast<HostCtx*>(g)->ds->ProcExec(pid); }
-void sgh_graphds_proc_exit(void* g, uint32_t pid) { static_cast<HostCtx*>(g)->ds->ProcExit(pid); }
+void sgh_graphds_proc_exit(void* g, uint32_t pid) { auto* c = static_cast<HostCtx*>(g); c->conns.ClearProc(pid); c->ds->ProcExit(pid); }   // clearProc first, data.go:364
+// new socket lines are seeded from `root` (NULL or "" = off); the seeded value is stamped first_kernel − (first_user − now_user)
+void sgh_graphds_set_proc_root(void* g, const char* root, uint64_t first_kernel_ns, uint64_t first_user_ns, uint64_t now_user_ns) {
+    static_cast<HostCtx*>(g)->conns.SetProcRoot(root ? root : "", first_kernel_ns, first_user_ns, now_user_ns);
+}
+size_t sgh_graphds_pg_statements(void* g) { return static_cast<HostCtx*>(g)->ds->Packer().PgStatements(); }
+void sgh_graphds_seed_stats(void* g, uint64_t out[2]) { auto* c = static_cast<HostCtx*>(g); out[0] = c->conns.SeedsOk(); out[1] = c->conns.SeedsFailed(); }
 void sgh_graphds_sweep_http2(void* g) { static_cast<HostCtx*>(g)->ds->SweepHttp2(); }
 // counters of the assembler: [0] streams pending, [1] parsers, [2] dropped: pid not live, [3] dropped: method/path unparsed, [4] dropped: time
 void sgh_graphds_http2_stats(void* g, uint64_t out[5]) {

@@ -59,6 +59,11 @@ def load() -> C.CDLL:
             "sgh_graphds_flush": (C.c_long, [P, C.c_int64, C.POINTER(EdgeRowC), sz]),
             "sgh_sockline_create": (P, [u32, u64]), "sgh_sockline_destroy": (None, [P]),
             "sgh_sockline_add": (None, [P, u64, C.POINTER(SockInfoC)]), "sgh_sockline_get": (C.c_int, [P, u64, u64, C.POINTER(SockInfoC)]),
+            "sgh_sockline_seed": (C.c_int, [P, C.c_char_p, u64]),
+            "sgh_proc_inode_of_link": (C.c_int, [C.c_char_p, C.c_char_p, sz]),
+            "sgh_proc_parse_tcp_line": (C.c_int, [C.c_char_p, C.POINTER(u32), C.POINTER(C.c_uint16), C.POINTER(u32), C.POINTER(C.c_uint16)]),
+            "sgh_graphds_pg_statements": (sz, [P]),
+            "sgh_graphds_set_proc_root": (None, [P, C.c_char_p, u64, u64, u64]), "sgh_graphds_seed_stats": (None, [P, C.POINTER(u64)]),
             "sgh_sockline_delete_unused": (None, [P]), "sgh_sockline_len": (sz, [P]),
             "sgh_sockline_at": (C.c_int, [P, sz, C.POINTER(u64), C.POINTER(u64), C.POINTER(SockInfoC)]),
             "sgh_graphds_tcp_wire": (sz, [P, P, sz]), "sgh_graphds_socklines": (sz, [P]), "sgh_graphds_sockline": (P, [P, u32, u64]),
@@ -105,6 +110,19 @@ def parse_http(req: bytes):
     return tuple(x.value.decode("latin-1") for x in (m, p, v, h))
 
 
+def proc_inode_of_link(link: str):
+    buf = C.create_string_buffer(32)
+    return buf.value.decode() if load().sgh_proc_inode_of_link(link.encode(), buf, 32) == 0 else None
+
+
+def proc_parse_tcp_line(line: str):
+    """-> (local addr u32, local port, remote addr u32, remote port) or None"""
+    la, ra, lp, rp = C.c_uint32(), C.c_uint32(), C.c_uint16(), C.c_uint16()
+    if load().sgh_proc_parse_tcp_line(line.encode(), C.byref(la), C.byref(lp), C.byref(ra), C.byref(rp)) != 0:
+        return None
+    return la.value, lp.value, ra.value, rp.value
+
+
 SL_ERRORS = {1: "sock line is empty", 2: "closed socket on last entry", 3: "no smaller value found", 4: "closed socket"}
 
 
@@ -134,6 +152,10 @@ class SocketLine:
         return ((out.saddr, out.sport, out.daddr, out.dport), None) if rc == 0 else (None, SL_ERRORS[rc])
 
     def delete_unused(self): self._l.sgh_sockline_delete_unused(self._p)
+
+    def seed_from_proc(self, proc_root: str, now_kernel_ns: int) -> int:
+        """getConnectionInfo against `proc_root` (aggregator/sock_num_line.go:399-429); 0 = seeded"""
+        return self._l.sgh_sockline_seed(self._p, proc_root.encode(), now_kernel_ns)
 
     def __len__(self): return self._l.sgh_sockline_len(self._p)
 
@@ -365,6 +387,15 @@ class GraphDS:
         return SocketLine(_borrowed=p) if p else None
 
     def sweep(self, now_ms: int, send_alive: bool = True) -> int: return self._l.sgh_graphds_sweep(self._g, now_ms, int(send_alive))
+
+    def set_proc_root(self, root, first_kernel_ns: int = 0, first_user_ns: int = 0, now_user_ns: int = 0):
+        """NewSocketLine(fetch = true): lines created from now on are seeded from `root`/<pid>/... (None = off)"""
+        self._l.sgh_graphds_set_proc_root(self._g, root.encode() if root else None, first_kernel_ns, first_user_ns, now_user_ns)
+
+    def pg_statements(self) -> int: return self._l.sgh_graphds_pg_statements(self._g)
+
+    def seed_stats(self):
+        out = (C.c_uint64 * 2)(); self._l.sgh_graphds_seed_stats(self._g, out); return out[0], out[1]
 
     def edges_json(self, monitoring_id="", idempotency_key="", node_id="", version="", batch=1000) -> List[str]:
         """The rows of the last FlushWindow as "/edges/" payloads (edges_payload.hpp), one JSON document per batch."""

@@ -11,5 +11,5 @@ gcc $SAN -std=gnu99 -fPIC -shared -ffp-contract=off -Wno-format-truncation -o "$
 export SG_HOST_LIB_PATH="$OUT/libsgdatastore.so" SG_ORACLE_LIB_PATH="$OUT/libsgoracle.so"
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1
-python -m pytest tests/test_http2.py tests/test_kafka.py tests/test_sockline.py tests/test_host.py tests/test_oracle_golden.py -x -q -p no:cacheprovider "$@"
+python -m pytest tests/test_http2.py tests/test_kafka.py tests/test_sockline.py tests/test_sockline_proc.py tests/test_host.py tests/test_oracle_golden.py -x -q -p no:cacheprovider "$@"
 python tools/fuzz_host_parsers.py ${FUZZ_ITERS:-20000} ${FUZZ_SEED:-1}
