@@ -771,6 +771,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // per node fits one workgroup's LDS.  G workgroups of npb / G consecutive output partitions each (G a power of two, 16 .. K2_DH_GMAX).
         d.dh_g = d.dh_ppw = d.dh_ns = 0;
         u32 g = std::min<u32>(K2_DH_GMAX, d.variant == 0 ? d.npb : 0u);            // (k2_rowptr: a multiple of 16)
+        // small graphs keep the degree atomics: their cost grows with the edges (1 M: 23 us of pass B), the histogram launch and the wider
+        // row scan cost 6-7 us whatever the size — C2 (66 k-edge capacity), same box: window 128.5 / 130.2 us with it, 124.4 / 125.3 without
+        if (ME < (1ull << 19)) g = 0;
         if (const char* v = std::getenv("SG_DH_G")) { const u64 x = std::strtoull(v, nullptr, 0); g = (x >= 16 && x <= K2_DH_GMAX && (x & (x - 1)) == 0 && d.variant == 0 && x <= d.npb) ? (u32)x : 0u; }
         if (g >= 16 && (g & (g - 1)) == 0 && d.npb % g == 0 && ((size_t)d.ncap + 1) * sizeof(u32) <= 128u * 1024u && (u64)d.npb * d.pcap < (1ull << 32)) {
             d.dh_g = g; d.dh_ppw = d.npb / g; d.dh_ns = (d.ncap + 1 + 63u) & ~63u;

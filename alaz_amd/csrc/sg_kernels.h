@@ -808,6 +808,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
     // (the first stretch of the outbound-IP table travels together with the statistics: one round trip to memory, not two — this
     // kernel is one workgroup, the chip waits for it, and it is nothing but dependent round trips)
     const u64 ob0 = (collect == 1 && t <= d.obmask) ? d.obkeys[t] : 0ull;
+    const u64 nl_prev = t == 0 ? d.ctr[C_N_LABELS] : 0ull;           // (so does the label count of the windows before: it was a third trip, behind the barrier)
     // (a)
     {
         u64 tmin = ~0ull, tmax = 0, ml = 0, ds = 0, dc = 0, mr = 0, ac = 0;
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
                 red[3][0] += red[3][k]; red[4][0] += red[4][k]; red[5][0] += red[5][k]; red[6][0] += red[6][k];
             }
             d.ctr[C_TMIN_NS] = red[0][0]; d.ctr[C_TMAX_NS] = red[1][0];
-            u64 nl = d.ctr[C_N_LABELS];                              // labels are cumulative across windows
+            u64 nl = nl_prev;                                        // labels are cumulative across windows
             nl = red[2][0] > nl ? red[2][0] : nl; nl = n_labels_decl > nl ? n_labels_decl : nl;
             d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known; nkl = nl + n_known;
             d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];

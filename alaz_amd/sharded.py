@@ -424,6 +424,13 @@ def bench(a, rank: int, world: int, local: int) -> dict:
     dev = [torch.from_numpy(b.view(np.uint8).reshape(-1)).to(device) for b in batches]
     cnt = [len(b) for b in batches]
     torch.cuda.synchronize(device)
+    # A collective that never completes (a rank missing, a link down) would hold the launcher until ITS caller gives up, with nothing to
+    # read afterwards: from here on a watchdog dumps every thread's Python stack to stderr and ends the process (torch.distributed.run
+    # then ends the other ranks) when the GPU part of the run takes longer than SG_BENCH_WATCHDOG_S seconds (default 600; 0 = off).
+    import faulthandler
+    wd = float(os.environ.get("SG_BENCH_WATCHDOG_S", "600"))
+    if wd > 0:
+        faulthandler.dump_traceback_later(wd, exit=True)
 
     def window(k, d_ptr, n):
         engs[k].ingest_device(d_ptr, n, streams[k].cuda_stream)
@@ -521,6 +528,7 @@ def bench(a, rank: int, world: int, local: int) -> dict:
         cm.close()
     for g in engs:
         g.close()
+    faulthandler.cancel_dump_traceback_later()
     return res
 
 

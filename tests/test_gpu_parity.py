@@ -247,6 +247,40 @@ def test_row_sort_by_blocks_equals_the_one_workgroup_row_sort_and_the_oracle():
     compare_edge_dicts(engine_edge_dict(out[1], shim, labels, obips), o.edge_dict())
 
 
+def test_row_degrees_by_lds_histograms_equal_the_degree_atomics_and_the_oracle():
+    """k2_deg_hist + k2_rowptr<64, DH> (row degrees and in-row ranks from LDS histograms, the default above 2^19 edges of capacity) forced
+    on a small graph with SG_DH_G = 16 / 64 / 128 against the path with pass B's returning degree atomics (SG_DH_G=0, the default at this
+    size): bit-identical rows — hub rows, rows of one edge, sources without any — and exact against the oracle.  (Config 3 at full size
+    runs the histogram path by default; this keeps it covered where a failure is cheap to read.)"""
+    topo = replay.make_topology(1800, 40_000, seed=81)
+    ev, labels = replay.make_events(topo, 400_000, seed=82)
+    ev = ev.copy()
+    everyone = np.concatenate([topo.svc_ips, topo.pod_ips])
+    n = 2500
+    ev["saddr"][:n] = topo.pod_ips[3]; ev["daddr"][:n] = everyone[everyone != topo.pod_ips[3]][:n]; ev["host_label"][:n] = 0; ev["flags"][:n] = 0
+    out = {}
+    for dh in ("0", "16", "64", "128"):
+        os.environ["SG_DH_G"] = dh
+        try:
+            g = _engine(topo.n_nodes + 8, 1 << 16, 2, max_window_events=len(ev))
+            shim = HostShim(); shim.apply(g, topo.k8s_ops())
+            for w in range(2):                                   # two windows: the histograms and the look-back epochs are re-armed
+                for i in range(0, len(ev), 1 << 17):
+                    assert g.ingest(ev[i:i + (1 << 17)]) == 0
+                g.set_label_count(len(labels))
+                out[(dh, w)] = g.flush_window().copy()
+            obips = g.outbound_ips()
+            g.close()
+        finally:
+            os.environ.pop("SG_DH_G", None)
+    for dh in ("16", "64", "128"):
+        for w in range(2):
+            assert out[(dh, w)].tobytes() == out[("0", w)].tobytes(), (dh, w)
+    assert out[("0", 0)].tobytes() == out[("0", 1)].tobytes()
+    o = _oracle(topo.k8s_ops(), 2); o.packed(ev, labels); o.window_close(weights.make_weights(2), 2)
+    compare_edge_dicts(engine_edge_dict(out[("64", 1)], shim, labels, obips), o.edge_dict())
+
+
 def test_pass_b_second_long_requests_beside_ordinary_ones():
     """K1 pass B merges the 8-byte records with 32-bit LDS atomics on the low words of count / max and 64-bit ones on the sums, the
     wide records (durations beyond 2^32 ns) afterwards with 64-bit ones into the same slots.  A quarter of the requests take
