@@ -21,6 +21,7 @@ size_t sgh_graphds_tcp_wire(void* g, const uint8_t* recs, size_t n);
 size_t sgh_graphds_sweep(void* g, int64_t now_ms, int send_alive);
 void sgh_graphds_proc_exec(void* g, uint32_t pid);
 void sgh_graphds_proc_exit(void* g, uint32_t pid);
+void sgh_graphds_set_proc_root(void* g, const char* root, uint64_t first_kernel_ns, uint64_t first_user_ns, uint64_t now_user_ns);
 void sgh_graphds_sweep_http2(void* g);
 size_t sgh_mock_events(void* g, sg_event* out, size_t cap);
 }
@@ -41,6 +42,7 @@ int main() {
     if (!g) { std::fprintf(stderr, "create failed\n"); return 2; }
     for (int i = 0; i < 32; i++) { char uid[16], ip[16]; std::snprintf(uid, sizeof uid, "p%d", i); std::snprintf(ip, sizeof ip, "10.0.0.%d", i + 1); sgh_graphds_persist_pod(g, "ADD", uid, ip); }
     sgh_graphds_persist_service(g, "ADD", "s0", "10.96.0.1");
+    sgh_graphds_set_proc_root(g, "/proc", 1000, 2000, 0);          // new socket lines try the proc file system first (whatever pid 77 is here)
     constexpr int kThreads = 8, kPer = 4000;
     std::atomic<bool> stop{false};
     std::vector<std::thread> ts;
@@ -56,7 +58,7 @@ int main() {
             sgh_graphds_ingest_wire(g, buf.data(), 50, nullptr);
         }
     });
-    std::thread churn([&] { int k = 0; while (!stop) { char ip[20]; std::snprintf(ip, sizeof ip, "10.9.0.%d", k % 9 + 1); sgh_graphds_persist_pod(g, k & 1 ? "UPDATE" : "DELETE", "churn", ip); sgh_graphds_proc_exec(g, 1000 + k % 5); sgh_graphds_proc_exit(g, 1000 + (k + 2) % 5); k++; } });
+    std::thread churn([&] { int k = 0; while (!stop) { char ip[20]; std::snprintf(ip, sizeof ip, "10.9.0.%d", k % 9 + 1); sgh_graphds_persist_pod(g, k & 1 ? "UPDATE" : "DELETE", "churn", ip); sgh_graphds_proc_exec(g, 1000 + k % 5); sgh_graphds_proc_exit(g, 1000 + (k + 2) % 5); if (k % 16 == 0) sgh_graphds_proc_exit(g, 77); k++; } });   // (77: the tcp thread's process — its lines go while it adds to them and the sweep walks them)
     std::thread tcp([&] {
         uint8_t r[64]; uint64_t ts_ = 1; 
         while (!stop) {
