@@ -95,6 +95,7 @@ struct sg_engine {
     size_t k1a_lds = 0, k1b_lds = 0, k3in_lds = 0;
     u32 k3_ranges = 1, k3_slices = 8;
     u32 k1b_threads = 512, k1b_u = 4, k1b_cus = 256;
+    bool k1b_pack = false;                    // narrow pass B: count + duration sum of a record in one 64-bit LDS add (sn x nwg < 2^16)
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
@@ -417,13 +418,15 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         const bool share = d.npb > e->k1b_cus && 2 * e->k1b_lds <= kLdsBytes;   // several partitions per CU and room for two tables: the SGPR-capped build lets two workgroups share a CU
 #define K1B_GO(U_, H_) do { if (share) hipExtLaunchKernelGGL((k1b_merge<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
                             else hipExtLaunchKernelGGL((k1b_merge_wide<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
-#define K1B8_GO(U_, SPT_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
-                               else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
+#define K1B8_GOP(U_, SPT_, P_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_, P_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
+                               else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_, P_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
+#define K1B8_GO(U_, SPT_) do { if (e->k1b_pack) K1B8_GOP(U_, SPT_, true); else K1B8_GOP(U_, SPT_, false); } while (0)
 #define K1B8_GO2(U_) do { const u32 spt = d.k1b_ht / e->k1b_threads; if (spt >= 4) K1B8_GO(U_, 4); else if (spt == 2) K1B8_GO(U_, 2); else K1B8_GO(U_, 1); } while (0)
         if (d.narrow) { if (e->k1b_u == 8) K1B8_GO2(8); else K1B8_GO2(4); }
         else if (d.hist) K1B_GO(4, true); else if (e->k1b_u == 8) K1B_GO(8, false); else K1B_GO(4, false);
 #undef K1B8_GO2
 #undef K1B8_GO
+#undef K1B8_GOP
 #undef K1B_GO
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
     }
@@ -699,6 +702,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // narrow pass B: 8 x 16 bytes per lane in flight where a CU holds one table anyway; two workgroups per CU need <= 64 VGPRs
         if (d.narrow) e->k1b_u = ((size_t)d.k1b_ht * 36 + 8) * 2 > kLdsBytes && m > 24.0 ? 8 : 4;
         if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; if (std::atoi(v) == 4) e->k1b_u = 4; }
+        // the packed add of pass B is exact while a workgroup merges fewer than 2^16 narrow records: a partition's pieces hold sn each
+        e->k1b_pack = d.narrow && (u64)d.sn * d.nwg < 65536ull;
+        if (const char* v = std::getenv("SG_K1B_PACK")) { if (std::atoi(v) == 0) e->k1b_pack = false; }
         if (const char* v = std::getenv("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if ((x == 256 && !d.narrow) || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
         if (d.narrow && d.k1b_ht / e->k1b_threads > 4) e->k1b_threads = 1024u;    // (the compaction takes at most four table slots per thread)
     }
@@ -749,10 +755,14 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
         for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>),
                               reinterpret_cast<const void*>(k1b_merge_wide<4, false>), reinterpret_cast<const void*>(k1b_merge_wide<8, false>), reinterpret_cast<const void*>(k1b_merge_wide<4, true>),
-                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4>),
-                              reinterpret_cast<const void*>(k1b_stream_merge<8, 1>), reinterpret_cast<const void*>(k1b_stream_merge<8, 2>), reinterpret_cast<const void*>(k1b_stream_merge<8, 4>),
-                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4>),
-                              reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 4>)})
+                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1, false>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, false>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, false>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<8, 1, false>), reinterpret_cast<const void*>(k1b_stream_merge<8, 2, false>), reinterpret_cast<const void*>(k1b_stream_merge<8, 4, false>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, false>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, false>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, false>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 1, false>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 2, false>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 4, false>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1, true>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, true>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, true>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<8, 1, true>), reinterpret_cast<const void*>(k1b_stream_merge<8, 2, true>), reinterpret_cast<const void*>(k1b_stream_merge<8, 4, true>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, true>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 1, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 2, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 4, true>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }

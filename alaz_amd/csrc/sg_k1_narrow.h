@@ -464,7 +464,13 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
 // words of the accumulators —, then, behind a barrier, the wide singles, aggregates and overflow records with 64-bit ones.
 // LDS: hacc[4][HT] u64 | hkey[HT] u32 | two counters: 36 bytes per slot.  SPT = table slots per thread in the compaction
 // (HT / threads): one round, all returning `deg` atomics of a thread in flight together.
-template <int U, int SPT>
+// PACK (round 4): a narrow record's count and duration travel in ONE 64-bit LDS add — count in bits 48.., the duration sum below —
+// instead of a 32-bit add and a 64-bit add.  The merge runs at the rate of the LDS atomic unit (§3 K1: ~1.5 lane-operations per clock and
+// CU, 5.45 per record), so an operation less per record is time.  Exact as long as a workgroup merges fewer than 2^16 narrow records —
+// every one is below 2^32 ns, so the sum stays below 2^48 and cannot carry into the count —, which the host guarantees from the geometry
+// (sn x nwg < 65 536: a piece holds at most sn narrow records) before it picks this build; behind the narrow phase's barrier every slot's
+// owner thread moves the count into accumulator 0, where the wide records (64-bit adds) expect it.
+template <int U, int SPT, bool PACK>
 __device__ __forceinline__ void k1b8_body(const Dev& d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 HT = d.k1b_ht, hmask = HT - 1;
@@ -521,9 +527,9 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         const u32 h = slot_of(rem);
         if (h == HT) { atomicAdd(n_drop, 1u); return; }
         const u32 us = div1000_u32(lo);
-        atomicAdd(&hacc32[2 * h], 1u);                               // count (low word of accumulator 0)
-        if (hi >> 31) atomicAdd(&hacc32[2 * h + 1], 1u);             // errors (high word)
-        atomicAdd(&hacc[HT + h], (u64)lo);
+        if constexpr (PACK) atomicAdd(&hacc[HT + h], (u64)lo | (1ull << 48));   // count (bits 48..) and duration sum in one operation
+        else { atomicAdd(&hacc32[2 * h], 1u); atomicAdd(&hacc[HT + h], (u64)lo); }   // count (low word of accumulator 0); duration sum
+        if (hi >> 31) atomicAdd(&hacc32[2 * h + 1], 1u);             // errors (high word of accumulator 0)
         atomicMax(&hacc32[2 * (2 * HT + h)], lo);                    // max: no wide record has touched the table yet
         // (measured on one box each: both sums as 32-bit words with a carry, 125.6-130.0 vs 121.3-129.3 us; reading the maximum first and
         //  sending the atomic only when it would rise, 128.0-129.2 vs 122.6-123.5 us: the merge is not bound by the number or width of
@@ -560,6 +566,10 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     }
     __syncthreads();                                                 // every 32-bit max is in: 64-bit updates may follow
     SG_STAMP(d, 1, 3);
+    if constexpr (PACK) {                                            // unpack: a slot by one thread, nobody else touches the table here
+        for (u32 i = t; i < HT; i += NT) { const u64 w = hacc[HT + i]; hacc[i] += w >> 48; hacc[HT + i] = w & ((1ull << 48) - 1ull); }
+        __syncthreads();
+    }
     for (u32 w = w0; w < d.nwg; w += NT / LPP) {
         const uint2 h = empty ? make_uint2(0u, 0u) : (w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w]);
         const u32 nw = (h.y & 0xFFFFu) < d.sw ? (h.y & 0xFFFFu) : d.sw, na = (h.y >> 16) < d.sa ? (h.y >> 16) : d.sa;
@@ -634,5 +644,5 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
 }
 // (the SGPR cap lets two 1024-thread workgroups share a CU — tools/occupancy_probe.hip; the uncapped build for geometries
 // where a CU holds one workgroup anyway)
-template <int U, int SPT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_stream_merge(Dev d) { k1b8_body<U, SPT>(d); }
-template <int U, int SPT> __global__ __launch_bounds__(1024) void k1b_stream_merge_wide(Dev d) { k1b8_body<U, SPT>(d); }
+template <int U, int SPT, bool PACK> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_stream_merge(Dev d) { k1b8_body<U, SPT, PACK>(d); }
+template <int U, int SPT, bool PACK> __global__ __launch_bounds__(1024) void k1b_stream_merge_wide(Dev d) { k1b8_body<U, SPT, PACK>(d); }
