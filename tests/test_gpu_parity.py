@@ -281,6 +281,38 @@ def test_row_degrees_by_lds_histograms_equal_the_degree_atomics_and_the_oracle()
     compare_edge_dicts(engine_edge_dict(out[("64", 1)], shim, labels, obips), o.edge_dict())
 
 
+def test_pass_b_packed_add_equals_the_two_add_form_and_the_oracle():
+    """Pass B adds a narrow record's count and duration in one 64-bit LDS operation (count in bits 48.., k1b_stream_merge<.., PACK>: the
+    default wherever a workgroup merges fewer than 2^16 narrow records) or, with SG_K1B_PACK=0 and on larger geometries, as a 32-bit and a
+    64-bit add.  Both forms must give bit-identical rows — a hot key the pass-A cache cannot hold (many records in one slot), second-long
+    requests (sums far beyond 2^32), errors — and equal the oracle."""
+    topo = replay.make_topology(1500, 30_000, seed=91)
+    ev, labels = replay.make_events(topo, 500_000, seed=92)
+    ev = ev.copy()
+    ev["duration_ns"][::4] = 0xDC000000                                # 3.69 s: 2^16 of them would be 2^47.8 ns in one slot
+    ev["status"][::9] = 503
+    hot = slice(0, 120_000)                                             # one edge takes a quarter of the window
+    ev["saddr"][hot] = topo.pod_ips[11]; ev["daddr"][hot] = topo.svc_ips[2]; ev["host_label"][hot] = 0; ev["flags"][hot] = 0
+    out = {}
+    for pack in ("0", None):
+        if pack is not None: os.environ["SG_K1B_PACK"] = pack
+        try:
+            g = _engine(topo.n_nodes + 8, 1 << 16, 2, max_window_events=len(ev))
+            shim = HostShim(); shim.apply(g, topo.k8s_ops())
+            for i in range(0, len(ev), 1 << 16):
+                assert g.ingest(ev[i:i + (1 << 16)]) == 0
+            g.set_label_count(len(labels))
+            out[pack] = g.flush_window().copy()
+            obips = g.outbound_ips()
+            g.close()
+        finally:
+            os.environ.pop("SG_K1B_PACK", None)
+    assert out["0"].tobytes() == out[None].tobytes()
+    assert int(out[None]["count"].max()) >= 100_000
+    o = _oracle(topo.k8s_ops(), 2); o.packed(ev, labels); o.window_close(weights.make_weights(2), 2)
+    compare_edge_dicts(engine_edge_dict(out[None], shim, labels, obips), o.edge_dict())
+
+
 def test_pass_b_second_long_requests_beside_ordinary_ones():
     """K1 pass B merges the 8-byte records with 32-bit LDS atomics on the low words of count / max and 64-bit ones on the sums, the
     wide records (durations beyond 2^32 ns) afterwards with 64-bit ones into the same slots.  A quarter of the requests take
