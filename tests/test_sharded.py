@@ -56,13 +56,14 @@ def _worker(rank, world, port, layers, q, c_sequencer=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("c_sequencer", [False, True])
-@pytest.mark.parametrize("layers", [1, 2])
-def test_two_shards_equal_unsharded_oracle(layers, c_sequencer):
-    """Two gloo processes close a window together — through the Python driver (run_window) and through the C sequencer
-    the engine's one-call entry point sg_window_run_sharded is built on (sgh_run_sharded_window) — and must reproduce the
-    unsharded oracle row for row."""
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world,layers,c_sequencer", [(2, 1, False), (2, 1, True), (2, 2, False), (2, 2, True),
+                                                      (3, 2, True), (4, 2, True), (4, 1, False)])
+def test_shards_equal_unsharded_oracle(world, layers, c_sequencer):
+    """Two, three and four gloo processes close a window together — through the Python driver (run_window) and through the C
+    sequencer the engine's one-call entry point sg_window_run_sharded is built on (sgh_run_sharded_window) — and must reproduce
+    the unsharded oracle row for row.  (Three: ownership modulo a number that is not a power of two; four: every shard serves
+    halo rows to several peers in one all-to-all.)"""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, layers, q, c_sequencer)) for r in range(world)]
