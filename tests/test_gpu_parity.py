@@ -299,8 +299,8 @@ def test_pass_b_packed_add_equals_the_two_add_form_and_the_oracle():
         try:
             g = _engine(topo.n_nodes + 8, 1 << 16, 2, max_window_events=len(ev))
             shim = HostShim(); shim.apply(g, topo.k8s_ops())
-            for i in range(0, len(ev), 1 << 16):
-                assert g.ingest(ev[i:i + (1 << 16)]) == 0
+            for i in range(0, len(ev), 1 << 17):
+                assert g.ingest(ev[i:i + (1 << 17)]) == 0
             g.set_label_count(len(labels))
             out[pack] = g.flush_window().copy()
             obips = g.outbound_ips()
