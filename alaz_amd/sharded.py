@@ -512,6 +512,9 @@ def bench(a, rank: int, world: int, local: int) -> dict:
                    "largest_shard_edges": int(gmax[len(names)].item()), "largest_shard_events": int(gmax[len(names) + 1].item()),
                    "rccl_ranks": dist.get_world_size(),
                    "parallelism": f"{world} shards, RCCL all-reduce (node stats) + halo all-to-all, 2 windows in flight per GPU",
+                   # (for whoever divides this line by the 1-GPU line: that one times ONE window in flight — clean per-kernel durations for its
+                   # roofline — and carries the pipelined rate as `overlapped.events_per_s`; this one needs two in flight to overlap its collectives)
+                   "value_basis": "2 windows in flight per GPU; the like-for-like 1-GPU figure is that line's overlapped.events_per_s, not its value",
                    "window_driver": "sg_window_run_sharded (one C call per window, RCCL from the library)" if one_call else "alaz_amd.sharded.run_window (Python, torch.distributed)"},
         "roofline": {"bound": "hbm", "kernel": "K1 resolve_aggregate = " + " + ".join(engs[0].k1_kernels()) + " (rank 0)", "achieved": ach, "peak": 8000.0,
                      "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": k1_us,
