@@ -78,7 +78,8 @@ namespace procfs {
 // the digits of the first `socket:[<digits>]` in a /proc/<pid>/fd/<fd> link text (sock_num_line.go:358-363); false if none
 bool InodeOfLink(const std::string& link, std::string* inode);
 // columns 1 and 2 of a /proc/net/tcp line: little-endian hex IPv4 + ':' + hex port (sock_num_line.go:332-349, 384-397).
-// Out-of-syntax hex pairs read as 0, ports beyond 65535 as 0, as the reference's ignored ParseInt errors leave them.
+// Out-of-syntax hex pairs read as 0, ports beyond 65535 as 0, as the reference's ignored ParseInt errors leave them; a signed
+// one-digit pair ("-8": the reference prints the text "-8") keeps its low byte.  /proc never writes either.
 bool ParseTcpLine(const std::string& line, uint32_t* laddr, uint16_t* lport, uint32_t* raddr, uint16_t* rport);
 }  // namespace procfs
 

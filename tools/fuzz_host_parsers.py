@@ -49,7 +49,9 @@ def kafka_seed():
 
 
 def main():
-    stats = {"kafka": 0, "kafka_ok": 0, "codec": 0, "hpack": 0, "huffman": 0, "h2": 0, "wire": 0}
+    stats = {"kafka": 0, "kafka_ok": 0, "codec": 0, "hpack": 0, "huffman": 0, "h2": 0, "wire": 0, "procline": 0}
+    # (the reference prints "%d" of a signed parse: a pair like "-8" gives the text "-8"; the numeric product keeps its low byte)
+    ipn = lambda s_: sum((int(x) & 255) << (24 - 8 * i) for i, x in enumerate(s_.split(".")))
     for it in range(N):
         # Kafka payloads
         m, v, p = kafka_seed()
@@ -90,6 +92,14 @@ def main():
             pk = hostlib.Packer(); pk.proc_exec(5); pk.kafka_decode(True); pk.pack_wire(bytes(rec)); pk.pack_wire(bytes(rec), full_copy=True)
             o = pyoracle.Oracle(0, 0); o.pod("ADD", "p", "10.0.0.1"); o.set_kafka_decode(True); o.h2().proc_exec(5); o.l7_wire(bytes(rec))
             stats["wire"] += 1
+        # /proc/<pid>/net/tcp lines and fd link texts (the socket-line seeding, sock_num_line.go:351-397): ASCII-ish mutations
+        line = mutate(b"   3: 7038A8C0:A24A C28D640A:0050 01 00000000:00000000 02:000002E0 00000000  1000        0 5276530 2 ffff8e8be7a0bd40 20 4 24 10 -1")
+        line = bytes(c for c in line if c not in (0,) and c < 128).decode("ascii")
+        a, b = pyoracle.parse_tcp_line(line), hostlib.proc_parse_tcp_line(line)
+        assert (a is None) == (b is None) and (a is None or (ipn(a[0]), a[1], ipn(a[2]), a[3]) == b), ("procline", line)
+        link = bytes(c for c in mutate(b"socket:[5276530]") if c != 0 and c < 128).decode("ascii")
+        assert pyoracle.inode_from_link(link) == hostlib.proc_inode_of_link(link), ("link", link)
+        stats["procline"] += 1
     print("fuzz ok:", stats)
 
 
