@@ -153,3 +153,27 @@ def test_thread_comm_runs_the_same_pipeline_without_processes():
     rows = [r for b in bes for r in b.rows]
     assert len(rows) == len(o.edge_rows())
     assert sorted(r[2] for r in rows) == sorted((int(w["count"]), int(w["err_count"]), int(w["sum_ns"]), int(w["max_ns"]), int(w["sumsq_us"])) for w in o.edge_rows())
+
+
+def test_halo_capacity_holds_for_the_bench_graph_at_2_4_8_shards():
+    """The sharded bench refuses to report a number when a shard asks one owner for more rows than the fixed-size exchange holds
+    (halo_overflow).  The capacity both drivers derive — 2 x ceil(ncap / world) + 1024 rows per (shard, owner) pair — against what
+    BASELINE config 3's graph (= config 4 sharded) really asks for: the distinct destinations of a shard's edges that another shard owns
+    AND that have out-edges themselves (only those rows are needed: a node without out-edges is nobody's neighbour source)."""
+    c = replay.CONFIGS[3]
+    topo = replay.make_topology(c["pods"], c["edges"], replay.SEED_BASE + 3)
+    src, dst = topo.edge_src.astype(np.uint32), topo.edge_dst.astype(np.uint32)
+    has_out = np.zeros(topo.n_nodes, dtype=bool); has_out[src] = True
+    ncap = topo.n_nodes + 64 + 64                                          # as sharded.bench sizes it
+    for world in (2, 4, 8):
+        capp = max(1, min(ncap, 2 * -(-ncap // world) + 1024))
+        so, do = sharded.owner_of_known(src, world), sharded.owner_of_known(dst, world)
+        need = (so != do) & has_out[dst]
+        worst = 0
+        for s in range(world):
+            m = need & (so == s)
+            pair = np.unique(dst[m].astype(np.uint64) * world + do[m])       # distinct (destination, its owner) of shard s
+            worst = max(worst, int(np.bincount((pair % world).astype(np.int64), minlength=world).max()))
+        own = np.bincount(sharded.owner_of_known(np.arange(topo.n_nodes, dtype=np.uint32), world), minlength=world)
+        assert worst <= own.max() <= capp, (world, worst, int(own.max()), capp)
+        assert worst > 0
