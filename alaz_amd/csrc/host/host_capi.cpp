@@ -355,7 +355,15 @@ void sgh_packer_proc_exit(void* p, uint32_t pid) { static_cast<L7Packer*>(p)->Pr
 void sgh_packer_conn_closed(void* p, uint32_t pid, uint64_t fd) { static_cast<L7Packer*>(p)->ConnClosed(pid, fd); }
 size_t sgh_packer_pg_statements(void* p) { return static_cast<L7Packer*>(p)->PgStatements(); }
 size_t sgh_graphds_socklines(void* g) { return static_cast<HostCtx*>(g)->conns.Lines(); }
-void* sgh_graphds_sockline(void* g, uint32_t pid, uint64_t fd) { return static_cast<HostCtx*>(g)->conns.Line(pid, fd); }
+// An OWNING reference to the line of (pid, fd), or null: sgh_graphds_proc_exit -> ClearProc(pid) drops the tracker's reference, and a
+// wrapper that still looks at the line must not be left with freed memory.  sgh_sockline_ref_get is the SocketLine* the
+// sgh_sockline_* calls take, valid until sgh_sockline_ref_release.
+void* sgh_graphds_sockline(void* g, uint32_t pid, uint64_t fd) {
+    auto sp = static_cast<HostCtx*>(g)->conns.Share(pid, fd);
+    return sp ? new std::shared_ptr<SocketLine>(std::move(sp)) : nullptr;
+}
+void* sgh_sockline_ref_get(void* ref) { return ref ? static_cast<std::shared_ptr<SocketLine>*>(ref)->get() : nullptr; }
+void sgh_sockline_ref_release(void* ref) { delete static_cast<std::shared_ptr<SocketLine>*>(ref); }
 // one clearSocketLines tick: open connections -> GraphDS::PersistAliveConnection (-> SG_EV_ALIVE records)
 size_t sgh_graphds_sweep(void* g, int64_t now_ms, int send_alive) { auto* c = static_cast<HostCtx*>(g); return c->conns.Sweep(now_ms, send_alive != 0, c->ds.get()); }
 

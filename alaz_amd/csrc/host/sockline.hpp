@@ -92,7 +92,8 @@ public:
     // ds->PersistAliveConnection (resolution of UIDs is left to the data store — GraphDS does it on the
     // GPU from the IPs; FromType/ToType/UIDs stay empty here), then DeleteUnused.  Returns lines reported.
     size_t Sweep(int64_t now_ms, bool send_alive, datastore::DataStore* ds);
-    SocketLine* Line(uint32_t pid, uint64_t fd);                       // borrowed; dies with ClearProc(pid)
+    SocketLine* Line(uint32_t pid, uint64_t fd);                       // borrowed; dies with ClearProc(pid) — in-process callers that hold mu_'s owner still
+    std::shared_ptr<SocketLine> Share(uint32_t pid, uint64_t fd) const { return Find(pid, fd); }   // owning: survives ClearProc(pid) (what the C API hands out)
     size_t Lines() const;
     // NewSocketLine(fetch = true): lines created from now on are seeded from `root` ("" = off, the default: a library
     // must not read /proc of whatever pids a replay happens to carry).  The seeded value's stamp is
@@ -101,8 +102,8 @@ public:
     void SetProcRoot(const std::string& root, uint64_t first_kernel_ns, uint64_t first_user_ns, uint64_t now_user_ns = 0);
     // clearProc: every line of the process is gone (process exit)
     size_t ClearProc(uint32_t pid);
-    uint64_t SeedsOk() const { return seeds_ok_; }
-    uint64_t SeedsFailed() const { return seeds_failed_; }
+    uint64_t SeedsOk() const { std::lock_guard<std::mutex> g(mu_); return seeds_ok_; }       // (ProcessTcpConnect counts them under mu_)
+    uint64_t SeedsFailed() const { std::lock_guard<std::mutex> g(mu_); return seeds_failed_; }
 private:
     std::shared_ptr<SocketLine> Find(uint32_t pid, uint64_t fd) const;
     mutable std::mutex mu_;

@@ -99,6 +99,7 @@ struct sg_engine {
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
+    hipEvent_t win_ta = nullptr;   // timing group 10: the open window's begin event (recorded in front of its first pass-A launch)
     u32 k6_epoch = 0;          // k6_halo_lists launch counter (same use)
     u32 rp_epoch = 0;          // k2_rowptr launch counter (tags the per-workgroup totals, so they need no reset)
 
@@ -188,19 +189,22 @@ bool k1a_geometry(sg_engine* e) {
         // the two-team kernel is instantiated for 256 / 512 / 1024 partitions, 768 threads, the one-thread-per-position copy-out (2 nb <= 31)
         // and a join blob its prologue can stage; everything else keeps the one-team kernel
         const int teams = 2, nt = 768;
-        const bool team_ok = (d.np == 256 || d.np == 512 || d.np == 1024) && 2 * d.nb <= 31 && (size_t)d.np * d.nwg * d.punits * 8 < ((size_t)1 << 31) && l1b + (e->l2_u16 || true ? l2b : l2b) <= (size_t)K1A_NJ * 768 * 16;
+        // (what the team kernel's prologue can stage: six 16-byte words per lane of ITS 768 threads.  Level 1 always goes through it, level 2
+        // only when it is staged — an engine whose level 2 stays in global memory needs room for level 1 alone)
+        const size_t stage_team = (size_t)K1A_NJ * nt * 16;
+        const bool team_ok = (d.np == 256 || d.np == 512 || d.np == 1024) && 2 * d.nb <= 31 && (size_t)d.np * d.nwg * d.punits * 8 < ((size_t)1 << 31) && l1b <= stage_team;
         e->k1a_teams = (u32)teams; e->k1a_nt = (u32)nt;
         const size_t fixed_team = K1M_LDS_FIXED(d.np, teams, nt) + l1b;
-        auto pick = [&](size_t fixed, u32 ct_min, u32& ct, bool& in_lds) {
+        auto pick = [&](size_t fixed, u32 ct_min, size_t stage_cap, u32& ct, bool& in_lds) {
             ct = 0; in_lds = false;
             // (the cache flattens the hottest keys; beyond 1024 slots it costs more aggregates than it saves records)
-            for (u32 c : {1024u, 512u, 256u, 128u}) if (c >= ct_min && (size_t)c * 40 + fixed + l2lds <= kLdsBytes && l1b + l2b <= stage_max) { in_lds = true; ct = c; break; }
+            for (u32 c : {1024u, 512u, 256u, 128u}) if (c >= ct_min && (size_t)c * 40 + fixed + l2lds <= kLdsBytes && l1b + l2b <= stage_cap) { in_lds = true; ct = c; break; }
             if (!ct) for (u32 c : {1024u, 512u, 256u, 128u, 64u}) if (c >= ct_min && (size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
         };
         u32 ct = 0; bool in_lds = false;
         e->k1a_team = false;
-        if (!want_tile && team_ok) { pick(fixed_team, force_team ? 64u : 256u, ct, in_lds); e->k1a_team = ct != 0; }
-        if (!ct) pick(fixed_tile, 64u, ct, in_lds);
+        if (!want_tile && team_ok) { pick(fixed_team, force_team ? 64u : 256u, stage_team, ct, in_lds); e->k1a_team = ct != 0; }
+        if (!ct) pick(fixed_tile, 64u, stage_max, ct, in_lds);
         const size_t fixed = e->k1a_team ? fixed_team : fixed_tile;
         e->l2_in_lds = in_lds;
         if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2lds : 0) <= kLdsBytes) ct = x; }
@@ -306,8 +310,10 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     int rc = sync_tables(e, s);
     if (rc) return rc;
     if ((rc = order_after_tables(e, s))) return rc;
+    if (((e->timing >> 10) & 1u) && e->window_events_in == 0 && !e->win_ta) { e->win_ta = get_event(e); hipEventRecord(e->win_ta, s); }   // group 10: the whole window
     Dev da = e->d;
     join_view(e, da);
+    u32 rot0 = e->d.k1a_rot, tb0 = e->d.k1a_ticket_base;
     if (e->d.variant == 0) {
         // single-kernel groups are timed by the dispatch's own begin/end stamps (hipExtLaunchKernel start/stop
         // events): the kernel's duration as rocprofv3 reports it, without the event-record round trip
@@ -323,6 +329,7 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
                             else if (e->d.np == 512) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 9>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
                             else hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 10>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); } while (0)
         da.k1a_rot = e->d.k1a_rot;
+        rot0 = e->d.k1a_rot; tb0 = e->d.k1a_ticket_base;           // (restored below when the launch is refused: the device counter only moves if the kernel runs)
         if (e->d.narrow && !e->k1a_team) {                           // the next launch's first chunk goes to the workgroup behind this launch's last one
             const u64 per = (n + e->d.nwg - 1) / e->d.nwg, chunk = per >= 4096 ? 4096 : (per + 1023) / 1024 * 1024;
             e->d.k1a_rot = (u32)((e->d.k1a_rot + (n + chunk - 1) / chunk) % e->d.nwg);
@@ -357,7 +364,16 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
         int grid = (int)std::min<u64>(want, (u64)e->k1_grid);
         hipLaunchKernelGGL(k1_resolve_aggregate, dim3(grid), dim3(256), 0, s, da, d_ev, (u64)n);
     }
-    HIP_TRY(e, hipGetLastError());
+    {
+        // the host predicts what the launch draws from the slot's ticket counter and where its last tile lands: both only hold if the
+        // kernel actually runs — a refused launch must leave them where the device still is
+        const hipError_t lr = hipGetLastError();
+        if (lr != hipSuccess) {
+            e->d.k1a_rot = rot0; e->d.k1a_ticket_base = tb0;
+            e->err = std::string("K1 pass A launch: ") + hipGetErrorString(lr);
+            return lr == hipErrorOutOfMemory ? SG_ENOMEM : SG_ENODEV;
+        }
+    }
     e->st.events_in += n;
     e->window_events_in += n;
     return SG_OK;
@@ -519,6 +535,15 @@ int do_reset(sg_engine* e, hipStream_t s) {
     e->closed = false;
     e->window_events_in = 0;            // (an open window that is reset is discarded: the next batch is a first batch again)
     return SG_OK;
+}
+
+// group 10 = one record per window: from in front of its first pass-A launch to behind its score kernel, on the window's stream
+void window_timed_end(sg_engine* e, hipStream_t s) {
+    if (!e->win_ta) return;
+    TimingRec r; r.kernel = 10; r.a = e->win_ta; r.b = get_event(e);
+    hipEventRecord(r.b, s);
+    e->trecs.push_back(r);
+    e->win_ta = nullptr;
 }
 
 // the window counters in e->h_ctr -> running statistics (engine lock held)
@@ -822,7 +847,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.tile_off, e->ecap / K2_TILE));
         LR(dev_alloc(e, &w.e_slot, ME)); LR(dev_alloc(e, &w.e_from, eslots)); LR(dev_alloc(e, &w.e_to, eslots));
         LR(dev_alloc(e, &w.longrows, (size_t)w.ncap + 1));
-        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH + 1)); LR(dev_alloc(e, &w.k6_tot, (((size_t)w.ncap + 1023) / 1024 + 1) * 16)); LR(dev_alloc(e, &w.k1a_ticket, 4)); w.k1a_ticket_base = 0; w.k1a_rot = 0; LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
+        LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH + 1)); LR(dev_alloc(e, &w.k6_tot, (((size_t)w.ncap + 1023) / 1024 + 1) * 16)); LR(dev_alloc(e, &w.k1a_ticket, 4)); LR(dev_alloc(e, &w.lb_ticket, 4)); w.k1a_ticket_base = 0; w.k1a_rot = 0; LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cs, ME)); LR(dev_alloc(e, &w.csr_from, ME));
         LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));
@@ -1445,6 +1470,7 @@ int sg_window_run_sharded(sg_handle e, sg_comm* c, void* stream) {
     sg_shard_comm sc{c, rc_all_gather, rc_all_reduce, rc_all_to_all};
     const int rc = sg_run_sharded_window(&st, &sc);
     if (rc) { if (e->err.empty()) e->err = "sg_window_run_sharded: a stage or a collective failed"; return rc; }
+    window_timed_end(e, s);
     e->last_rows = e->d.rows;
     return SG_OK;
 }
@@ -1470,6 +1496,7 @@ int sg_window_run(sg_handle e, void* stream) {
     bool did = false;
     if ((rc = do_score(e, s, true, true, &did))) return rc;
     if (did) e->closed = false; else if ((rc = do_reset(e, s))) return rc;
+    window_timed_end(e, s);
     e->last_rows = e->d.rows;
     rotate_window(e);                                    // the next sg_ingest* goes to the next slot (if any)
     return SG_OK;
@@ -1604,6 +1631,46 @@ int sg_timing_get(sg_handle e, int kernel, double* avg_us, uint64_t* launches) {
     }
     if (avg_us) *avg_us = cnt ? tot / (double)cnt : 0.0;
     if (launches) *launches = cnt;
+    return SG_OK;
+}
+
+// every record of one group since sg_timing_reset, in launch order (bench.py: median and minimum, SURVEY 8(d) run protocol)
+int sg_timing_samples(sg_handle e, int kernel, double* us, size_t cap, size_t* n) {
+    if (!e || (!us && cap)) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    size_t cnt = 0;
+    for (auto& r : e->trecs) if (r.kernel == kernel) {
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        if (cnt < cap) us[cnt] = (double)ms * 1000.0;
+        cnt++;
+    }
+    if (n) *n = cnt;
+    return SG_OK;
+}
+// What kind of box this is (the pool's boxes differ in memory latency, not in clock): ONE lane follows a chain of
+// dependent loads through `bytes` of device memory (one 128-byte line per step, the order an odd-multiplier walk over all lines)
+// and reports the average nanoseconds per load by the 100 MHz reference clock.  bytes >> Infinity Cache = HBM latency; 2 MiB,
+// walked once before the clock starts = L2 latency.  Allocates and frees its own buffer; device-syncs.
+int sg_latency_probe(sg_handle e, uint64_t bytes, uint32_t steps, int warm, double* ns_per_load) {
+    if (!e || !ns_per_load || bytes < 4096 || steps == 0) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    u64 lines = 1; while (lines * 2 * 128 <= bytes) lines *= 2;         // a power of two: x -> a x + c (a % 4 == 1, c odd) visits every line
+    if (lines > (1ull << 31)) lines = 1ull << 31;
+    u32* buf = nullptr; u64* out = nullptr;
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMalloc((void**)&buf, lines * 128));
+    if (hipMalloc((void**)&out, 2 * sizeof(u64)) != hipSuccess) { hipFree(buf); e->err = "sg_latency_probe: hipMalloc"; return SG_ENOMEM; }
+    hipLaunchKernelGGL(k_chase_init, dim3((unsigned)std::min<u64>((lines + 255) / 256, 65535)), dim3(256), 0, e->stream, buf, (u32)(lines - 1));
+    if (warm) hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, e->stream, (const u32*)buf, (u32)lines, out);   // one whole round: every line is in the cache level it fits
+    hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, e->stream, (const u32*)buf, steps, out);
+    u64 h[2] = {};
+    hipError_t r = hipStreamSynchronize(e->stream);
+    if (r == hipSuccess) r = hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    hipFree(buf); hipFree(out);
+    if (r != hipSuccess) { e->err = std::string("sg_latency_probe: ") + hipGetErrorString(r); return SG_ENODEV; }
+    *ns_per_load = 10.0 * (double)h[0] / (double)steps;
     return SG_OK;
 }
 

@@ -79,6 +79,7 @@ enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, 
 // into offsets inside the row.
 #define SG_DEG_REP 8
 #define SG_DEG_IDX(f, r) (((size_t)(f) * SG_DEG_REP + (r)) * SG_DEG_STRIDE)
+#define SG_LB_RESIDENT 256       // workgroups of a look-back kernel that are certainly all resident (one per CU); above it the workgroups order themselves by ticket
 #define K2_RP_ROWS 256           // rows per workgroup of k2_rowptr (a multiple of 128; 1024 threads: 8 lanes per row, 2 passes)
 
 // phase stamps for kernel tuning (off unless SG_ABLATE & 0x100): 100 MHz wall clock, thread 0 of a workgroup
@@ -150,6 +151,7 @@ struct Dev {
     u32* alive_csr;                           // [max_edges] CSR order: open connections per edge
     u32* act_l; u32* act_p;                   // [ncap] world > 1: active node lists (ascending), built with the halo requests
     u64* rp_tot;                              // [ceil((ncap+1)/K2_RP_ROWS)] k2_rowptr: (epoch << 32 | rows' edge total) per workgroup
+    u32* lb_ticket;                           // [4] self-resetting workgroup tickets of the look-back kernels whose grid exceeds SG_LB_RESIDENT ([0] k2_rowptr, [1] kw_compact)
     u64* k6_tot;                              // [ceil(ncap/1024) + 1][16] k6_halo_lists: (epoch << 32 | members) per workgroup and list
     // ---- closed window ----
     u32* ob_sorted;                           // [max_obip] ascending distinct raw IPs

@@ -974,7 +974,7 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
 // (one sector each, consecutive lanes -> consecutive sectors), turn them into offsets inside the row and
 // give the row's degree; a block scan makes local row offsets; the sum of the preceding workgroups' totals
 // comes from rp_tot[] (each workgroup publishes (epoch, total) as soon as it knows it and the later ones
-// wait for it — all workgroups are resident, at most one per CU, so the wait cannot deadlock).
+// wait for it — up to SG_LB_RESIDENT workgroups all are resident; larger grids order themselves by ticket, see below).
 // Row degrees and the edges' positions inside their rows without device atomics (Dev::dh_g workgroups; see sg_device.h).  Workgroup g
 // owns the output partitions [g * dh_ppw, (g + 1) * dh_ppw): it counts their sources in an LDS array indexed by node — the value a
 // returning LDS add hands back is the edge's rank among the edges (g, source), stored to e_rank with a coalesced write — and publishes
@@ -1023,8 +1023,20 @@ template <u32 RPR, bool DH>
 __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     __shared__ u32 wsum[17];
     __shared__ u32 rdeg[RPR];
-    __shared__ u32 nlong, lbase, pre;
-    const u32 b = blockIdx.x, t = threadIdx.x, r0 = b * RPR;
+    __shared__ u32 nlong, lbase, pre, bdyn;
+    const u32 t = threadIdx.x;
+    // Which rows this workgroup owns.  The look-back below waits for the workgroups of the rows before it.  Up to SG_LB_RESIDENT
+    // workgroups (one per CU) every workgroup of the launch is resident and the block index serves.  Beyond that (C5: 150 k rows) a
+    // workgroup takes its index from a ticket counter instead, so that it only ever waits for workgroups that have already STARTED —
+    // HIP does not promise that blocks are dispatched in index order.  The counter resets itself: the workgroup that draws
+    // the launch's last ticket is the last one to draw.
+    u32 b = blockIdx.x;
+    if (gridDim.x > SG_LB_RESIDENT) {                                // (uniform)
+        if (t == 0) { const u32 tk = atomicAdd(&d.lb_ticket[0], 1u); if (tk == gridDim.x - 1) atomicExch(&d.lb_ticket[0], 0u); bdyn = tk; }
+        __syncthreads();
+        b = bdyn;
+    }
+    const u32 r0 = b * RPR;
     // (DH: the counts are loaded before N is known — rows beyond it read stale words inside the table (its rows are ncap + 1 rounded up
     // to 64 words) and are zeroed below: one dependent round trip less)
     constexpr u32 GLd = DH ? K2_DH_GMAX / 16 : 1;
@@ -1227,6 +1239,19 @@ __global__ __launch_bounds__(256) void k_clock_spin(u64* clk, u32 iters) {
     const u64 c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[2] = c1 - c0; clk[3] = r1 - r0; }
     if ((a ^ b ^ c) == 0x12345678u) clk[3] = a;                      // (keeps the loop)
+}
+// latency probe (sg_latency_probe): word 0 of line x holds the next line, (A x + C) mod lines — a full-period walk for lines = 2^k
+#define SG_CHASE_A 0x9E3779B5u
+#define SG_CHASE_C 0x7F4A7C15u
+__global__ __launch_bounds__(256) void k_chase_init(u32* buf, u32 mask) {
+    for (u64 x = (u64)blockIdx.x * 256 + threadIdx.x; x <= mask; x += (u64)gridDim.x * 256) buf[x * 32] = ((u32)x * SG_CHASE_A + SG_CHASE_C) & mask;
+}
+__global__ void k_chase(const u32* buf, u32 steps, u64* out) {
+    u32 x = 0;
+    const u64 t0 = wall_clock64();
+    for (u32 i = 0; i < steps; i++) x = __builtin_nontemporal_load(buf + (size_t)x * 32);   // (each address comes out of the load before it)
+    const u64 t1 = wall_clock64();
+    out[0] = t1 - t0; out[1] = x;
 }
 __global__ void k_l1p_table(float* tab) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < SG_L1P_TAB) tab[i] = (float)log1p((double)i); }
 __device__ __forceinline__ float log1p_count(const Dev& d, u64 c) { return c < SG_L1P_TAB ? d.l1p_tab[c] : (float)log1p((double)c); }

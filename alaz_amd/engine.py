@@ -32,7 +32,7 @@ EXPORTS = [
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
-    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
+    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_timing_samples", "sg_latency_probe", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
     "sg_clock_probe", "sg_comm_probe", "sg_window_halo_counts", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned", "sg_ingest_bulk",
 ]
 
@@ -132,6 +132,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_stats_get": (C.c_int, [H, C.POINTER(SgStats)]),
         "sg_timing_enable": (C.c_int, [H, C.c_int]), "sg_timing_reset": (C.c_int, [H]),
         "sg_timing_get": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "sg_timing_samples": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), sz, C.POINTER(sz)]),
+        "sg_latency_probe": (C.c_int, [H, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
         "sg_debug_stamps": (C.c_int, [H, P, sz]),
         "sg_clock_probe": (C.c_int, [H, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sg_comm_probe": (C.c_int, []), "sg_window_halo_counts": (C.c_int, [H, P, sz]),
@@ -407,6 +409,18 @@ class ServiceGraph:
         us, n = C.c_double(), C.c_uint64()
         self._ck(self._l.sg_timing_get(self._h, kernel, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def timing_samples(self, kernel: int, cap: int = 4096) -> np.ndarray:
+        """every record of a timing group since timing_reset(), microseconds, in launch order"""
+        out = np.zeros(cap, dtype=np.float64); n = C.c_size_t()
+        self._ck(self._l.sg_timing_samples(self._h, kernel, out.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(n)))
+        return out[: min(cap, n.value)]
+
+    def latency_probe(self, nbytes: int, steps: int, warm: bool = False) -> float:
+        """ns per dependent load through `nbytes` of device memory (HBM: far beyond the Infinity Cache, cold; L2: 2 MiB, warm)"""
+        ns = C.c_double()
+        self._ck(self._l.sg_latency_probe(self._h, int(nbytes), int(steps), 1 if warm else 0, C.byref(ns)))
+        return ns.value
 
     def clock_probe(self, spin_us: int = 200) -> Tuple[float, float]:
         """(MHz under an all-CU spin launched now, MHz averaged over the pass-A launches since the last call)."""

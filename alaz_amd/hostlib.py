@@ -67,6 +67,7 @@ def load() -> C.CDLL:
             "sgh_sockline_delete_unused": (None, [P]), "sgh_sockline_len": (sz, [P]),
             "sgh_sockline_at": (C.c_int, [P, sz, C.POINTER(u64), C.POINTER(u64), C.POINTER(SockInfoC)]),
             "sgh_graphds_tcp_wire": (sz, [P, P, sz]), "sgh_graphds_socklines": (sz, [P]), "sgh_graphds_sockline": (P, [P, u32, u64]),
+            "sgh_sockline_ref_get": (P, [P]), "sgh_sockline_ref_release": (None, [P]),
             "sgh_graphds_sweep": (sz, [P, C.c_int64, C.c_int]),
             "sgh_graphds_labels": (sz, [P, C.c_char_p, sz]), "sgh_graphds_dropped_parse": (u64, [P]), "sgh_graphds_engine": (P, [P]),
             "sgh_graphds_proc_exec": (None, [P, u32]), "sgh_graphds_proc_exit": (None, [P, u32]), "sgh_graphds_sweep_http2": (None, [P]),
@@ -128,14 +129,18 @@ SL_ERRORS = {1: "sock line is empty", 2: "closed socket on last entry", 3: "no s
 
 class SocketLine:
     """alaz::SocketLine (csrc/host/sockline.hpp); addresses are numeric IPv4."""
-    def __init__(self, pid: int = 0, fd: int = 0, _borrowed=None):
-        self._l = load(); self._own = _borrowed is None
-        self._p = self._l.sgh_sockline_create(pid, fd) if self._own else _borrowed
+    def __init__(self, pid: int = 0, fd: int = 0, _ref=None):
+        # _ref: an owning reference handed out by sgh_graphds_sockline (a line of a GraphDS's tracker: it stays alive here after the
+        # tracker dropped it at process exit)
+        self._l = load(); self._own = _ref is None; self._ref = _ref
+        self._p = self._l.sgh_sockline_create(pid, fd) if self._own else self._l.sgh_sockline_ref_get(_ref)
 
     def __del__(self):
         try:
             if self._own and self._p:
                 self._l.sgh_sockline_destroy(self._p); self._p = None
+            elif self._ref:
+                self._l.sgh_sockline_ref_release(self._ref); self._ref = None; self._p = None
         except Exception:
             pass
 
@@ -384,7 +389,7 @@ class GraphDS:
 
     def sockline(self, pid: int, fd: int):
         p = self._l.sgh_graphds_sockline(self._g, pid, fd)
-        return SocketLine(_borrowed=p) if p else None
+        return SocketLine(_ref=p) if p else None
 
     def sweep(self, now_ms: int, send_alive: bool = True) -> int: return self._l.sgh_graphds_sweep(self._g, now_ms, int(send_alive))
 

@@ -397,6 +397,15 @@ int sg_geometry_get(sg_handle h, sg_geometry* out);
 int sg_timing_enable(sg_handle h, int on);   /* 0 = off, 1 = every group, else bitmask: bit k = group Kk */
 int sg_timing_reset(sg_handle h);
 int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
+/* Every record of a group since sg_timing_reset, in launch order: min(*n, cap) durations in microseconds go to us[], *n = how many
+ * there are.  Group 10 (only when its bit is set explicitly or with on = 1) = one record per window of sg_window_run /
+ * sg_window_run_sharded, from in front of the window's first pass-A launch to behind its score kernel.                      */
+int sg_timing_samples(sg_handle h, int kernel, double* us, size_t cap, size_t* n);
+/* Memory latency of this box: one lane follows `steps` dependent loads (one 128-byte line each, an odd-multiplier walk over all
+ * lines) through `bytes` of device memory it allocates for the call; *ns_per_load by the 100 MHz reference clock.  warm != 0
+ * walks every line once before the clock starts (a 2 MiB buffer then measures the L2, a buffer far beyond the 256 MiB Infinity
+ * Cache without it measures HBM).  Diagnostic for bench.py ("which kind of box did this line come from"); device-syncs.       */
+int sg_latency_probe(sg_handle h, uint64_t bytes, uint32_t steps, int warm, double* ns_per_load);
 /* The shader clock the chip sustains, in MHz (shader cycles per 100 MHz reference tick x 100): *spin_mhz from an all-CU integer
  * spin of about spin_us microseconds launched by this call, *k1a_mhz averaged over the K1 pass-A launches since the previous
  * call (0 if none; narrow-record kernels only).  Diagnostic for bench.py: the boxes of a pool differ in the clock they hold

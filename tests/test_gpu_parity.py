@@ -987,6 +987,93 @@ def test_sg_ingest_from_many_threads_into_one_engine():
     assert st.last_window_events == o.window_events and st.events_dropped_cap == 0
 
 
+def test_two_concurrent_flushers_beside_eight_feeders_every_window_equals_a_single_flusher():
+    """servicegraph.hip flush_begin_locked / flush_end_unlocked: TWO threads close windows at the same time —
+    one with sg_flush_window, one with sg_flush_begin + sg_flush_end — while eight feeder threads call sg_ingest, until at least 50
+    windows have been closed.  Where a boundary falls is up to the race, so the trace is built to tell afterwards: it is cut into
+    chunks with DISJOINT sources (chunk k holds the edges whose source pod is k mod K), each handed over in ONE sg_ingest call,
+    which lands in exactly one window.  Then: every chunk appears in exactly one window, whole; every window is byte for byte what a
+    single-flusher engine returns for the same chunks; sg_stats.windows counts every close once (no double account_window)."""
+    import threading
+    import time
+    from alaz_amd import engine, sharded
+    K, per = 160, 2500
+    topo = replay.make_topology(800, 40_000, seed=131)
+    nlab = len(replay.EXTERNAL_HOSTS)
+    chunks = []
+    for k in range(K):
+        keep = (topo.edge_src % K) == k
+        sub = replay.Topology(topo.n_pods, topo.n_svcs, topo.pod_ips, topo.svc_ips, topo.edge_src[keep], topo.edge_dst[keep], topo.seed)
+        ev, _ = replay.make_events(sub, per, seed=500 + k, fixed_labels=True)
+        chunks.append(np.ascontiguousarray(ev))
+    def mk():
+        g = _engine(topo.n_nodes + 8, 1 << 16, 2, max_labels=max(64, nlab), max_window_events=K * per + 1, max_batch=4096)
+        HostShim().apply(g, topo.k8s_ops()); g.set_label_count(nlab)
+        return g
+    a, b = mk(), mk()
+    errs, wins, lock = [], [], threading.Lock()
+    fed = [0]
+    def feed(idx):
+        try:
+            for k in idx:
+                while a.ingest(chunks[k]) != 0:              # SG_EAGAIN: the staging ring is momentarily full
+                    pass
+                with lock: fed[0] += 1
+                time.sleep(0.0005)
+        except Exception as ex:                              # noqa: BLE001
+            errs.append(ex)
+    def done():
+        with lock: return fed[0] == K and len(wins) >= 50
+    def flusher_one_call():
+        try:
+            while not done() and not errs:
+                r = a.flush_window().copy()
+                with lock: wins.append(r)
+        except Exception as ex:                              # noqa: BLE001
+            errs.append(ex)
+    def flusher_two_halves():
+        try:
+            while not done() and not errs:
+                try:
+                    a.flush_begin()
+                except engine.ServiceGraphError as ex:       # the other flusher's window has not been fetched yet: legitimate, try again
+                    if ex.rc != engine.SG_ESTATE: raise
+                    continue
+                try:
+                    r = a.flush_end().copy()
+                except engine.ServiceGraphError as ex:       # ... or it fetched ours (one fetch per window, the loser sees the window gone)
+                    if ex.rc != engine.SG_ESTATE: raise
+                    continue
+                with lock: wins.append(r)
+        except Exception as ex:                              # noqa: BLE001
+            errs.append(ex)
+    ths = [threading.Thread(target=feed, args=(list(range(j, K, 8)),)) for j in range(8)]
+    ths += [threading.Thread(target=flusher_one_call), threading.Thread(target=flusher_two_halves)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errs, errs
+    wins.append(a.flush_window().copy())                     # whatever the last boundary left open
+    st = a.stats()
+    assert st.windows == len(wins) >= 51 and st.events_in == K * per and st.events_dropped_cap == 0 and st.events_dropped_ring == 0
+    seen = np.zeros(K, dtype=np.int64)
+    nonempty = 0
+    for r in wins:
+        if not len(r):
+            continue
+        nonempty += 1
+        assert np.all((r["from_ref"] >> 30) == 0)            # sources are pods (known nodes): the id is the pod index
+        ks = np.unique((r["from_ref"] & 0x3FFFFFFF) % K)
+        seen[ks] += 1
+        for k in ks:                                         # the single-flusher engine, the same chunks in one window
+            while b.ingest(chunks[int(k)]) != 0:
+                pass
+        want = b.flush_window()
+        assert len(want) == len(r) and want.tobytes() == r.tobytes()
+    assert np.all(seen == 1), "a chunk (one sg_ingest call) was split over windows, lost or counted twice"
+    assert nonempty >= 5                                     # (the race did cut the stream into several windows)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_edge_latency_histogram_and_percentiles(variant):
     """f-3: with SG_CFG_EDGE_HISTOGRAM every edge carries a 16-bin log2 latency histogram and p50 / p99 read off
