@@ -96,6 +96,12 @@ struct sg_engine {
     u32 k3_ranges = 1, k3_slices = 8;
     u32 k1b_threads = 512, k1b_u = 4, k1b_cus = 256;
     bool k1b_pack = false;                    // narrow pass B: count + duration sum of a record in one 64-bit LDS add (sn x nwg < 2^16)
+    // warm windows (sg_device.h): the host only decides whether a window TRIES the warm path; whether it may is decided on the device
+    bool warm_on = true;                      // sg_set_warm
+    u32 cold_streak = 0;                      // consecutive windows the host has seen fall back to the full rebuild
+    u64 warm_skip = 0;                        // windows left of a back-off (the warm attempt is not launched at all)
+    u32 kw_epoch = 0;                         // kw_compact launch counter (tags its look-back words)
+    std::vector<u64*> scr_sum, scr_max; std::vector<double*> scr_mu;   // per window slot: the node statistics the kept-CSR rebuild writes (scratch; row_mu | row_sd in one array)
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
@@ -421,17 +427,35 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
     int rc = sync_tables(e, s);
     if (rc) return rc;
     const Dev& d = e->d;
+    // warm windows: try unless switched off or backing off after a run of cold windows (the device decides whether the try holds)
+    bool warm_try = d.warm && e->warm_on;
+    if (warm_try && e->warm_skip) { e->warm_skip--; warm_try = false; }
+    const u32 wt = warm_try ? 1u : 0u;
     {
         Timed tp(e, s, 2);
-        if (ob_mode == 1) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u, (const u32*)nullptr, 0u, 0u);
-        else if (ob_mode == 0) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap, 0u, (const u32*)nullptr, 0u, 0u);
-        else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 2u, d_union, stride, gworld);
+        if (ob_mode == 1) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u, (const u32*)nullptr, 0u, 0u, wt);
+        else if (ob_mode == 0) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, const_cast<u32*>(d_union), d_union_n, e->ob_list_cap, 0u, (const u32*)nullptr, 0u, 0u, wt);
+        else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 2u, d_union, stride, gworld, wt);
     }
     if (d.variant == 0) {                                    // group 7 = K1 pass B (k1b_merge), kernel-exact timing as for pass A
         const bool tk = (e->timing >> 7) & 1u;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
         const bool share = d.npb > e->k1b_cus && 2 * e->k1b_lds <= kLdsBytes;   // several partitions per CU and room for two tables: the SGPR-capped build lets two workgroups share a CU
+        // warm engines: the warm attempt (WM 1: seeded tables, accumulators straight to their kept positions; returns at once when
+        // kc_prepare has already called the window cold), then the cold merge (WM 2: returns at once on a warm window).  Both are records
+        // of group 7: a window's pass B is the SUM of its group-7 records.
+#define K1B8W_GOP(U_, SPT_, P_, WM_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
+                                     else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
+#define K1B8W_GO(SPT_, WM_) do { if (e->k1b_pack) K1B8W_GOP(4, SPT_, true, WM_); else K1B8W_GOP(4, SPT_, false, WM_); } while (0)
+#define K1B8W_GO2(WM_) do { const u32 spt = d.k1b_ht / e->k1b_threads; if (spt >= 4) K1B8W_GO(4, WM_); else if (spt == 2) K1B8W_GO(2, WM_); else K1B8W_GO(1, WM_); } while (0)
+        if (d.warm) {
+            if (warm_try) {
+                K1B8W_GO2(1);
+                if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); ta = get_event(e); tb = get_event(e); }
+            }
+            K1B8W_GO2(2);
+        } else {
 #define K1B_GO(U_, H_) do { if (share) hipExtLaunchKernelGGL((k1b_merge<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
                             else hipExtLaunchKernelGGL((k1b_merge_wide<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
 #define K1B8_GOP(U_, SPT_, P_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_, P_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
@@ -440,31 +464,51 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
 #define K1B8_GO2(U_) do { const u32 spt = d.k1b_ht / e->k1b_threads; if (spt >= 4) K1B8_GO(U_, 4); else if (spt == 2) K1B8_GO(U_, 2); else K1B8_GO(U_, 1); } while (0)
         if (d.narrow) { if (e->k1b_u == 8) K1B8_GO2(8); else K1B8_GO2(4); }
         else if (d.hist) K1B_GO(4, true); else if (e->k1b_u == 8) K1B_GO(8, false); else K1B_GO(4, false);
+        }
 #undef K1B8_GO2
 #undef K1B8_GO
 #undef K1B8_GOP
 #undef K1B_GO
+#undef K1B8W_GO2
+#undef K1B8W_GO
+#undef K1B8W_GOP
         if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); }
     }
     {
         Timed t(e, s, 2);
+        // An engine that keeps warm-window state rebuilds the KEPT CSR, not the window's: the same kernels on a Dev whose CSR pointers
+        // are the kept arrays (capacity npb x pcap: whatever pass B's tables can emit fits, nothing is cut) and whose node statistics
+        // are scratch (the row sort reduces every row it sorts; the window's statistics come from kw_compact).  On a warm window each
+        // of them returns at once.
+        Dev dk = d;
+        if (d.warm) {
+            dk.rowptr = d.k_rowptr; dk.col = d.k_col; dk.csr_from = d.k_from; dk.acc_csr = d.k_acc; dk.max_edges = (u64)d.npb * d.pcap;
+            dk.st_sum = e->scr_sum[e->cur]; dk.st_max = e->scr_max[e->cur]; dk.row_mu = e->scr_mu[e->cur]; dk.row_sd = e->scr_mu[e->cur] + d.ncap + 1;
+        }
         if (d.variant == 1) {
             const u32 ntiles = e->ecap / K2_TILE;
             hipLaunchKernelGGL(k2_edge_count, dim3(ntiles), dim3(256), 0, s, d);
             hipLaunchKernelGGL(k2_scan_tiles, dim3(1), dim3(1024), 0, s, d, ntiles);
             hipLaunchKernelGGL(k2_edge_compact, dim3(ntiles), dim3(256), 0, s, d);
         }
-        if (d.dh_g) hipLaunchKernelGGL(k2_deg_hist, dim3(d.dh_g), dim3(K2_DH_THREADS), ((size_t)d.ncap + 1) * sizeof(u32), s, d);
-        if (d.dh_g) hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS_DH, true>), dim3(((size_t)d.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH), dim3(1024), 0, s, d, ++e->rp_epoch);
-        else hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS, false>), dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, d, ++e->rp_epoch);
+        if (d.dh_g) hipLaunchKernelGGL(k2_deg_hist, dim3(d.dh_g), dim3(K2_DH_THREADS), ((size_t)d.ncap + 1) * sizeof(u32), s, dk);
+        if (d.dh_g) hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS_DH, true>), dim3(((size_t)d.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH), dim3(1024), 0, s, dk, ++e->rp_epoch);
+        else hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS, false>), dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, dk, ++e->rp_epoch);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
-        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 2 * (size_t)d.k2_sortw * sizeof(u32), s, d);
+        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, s, dk);
+        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 2 * (size_t)d.k2_sortw * sizeof(u32), s, dk);
+        if (d.warm) {
+            // behind a rebuild: the positions the next windows' pass B writes to (returns at once on a warm window); then, every window,
+            // the window's CSR out of the kept one
+            hipLaunchKernelGGL(kw_capture, dim3(grid_for(std::max<u64>((u64)d.ncap * SG_NODE_STAT_SUM_WORDS, (u64)d.npb * d.k1b_ht), 256 * 8, 1024)), dim3(256), 0, s, d, dk.st_sum, dk.st_max);
+            hipLaunchKernelGGL(kw_compact, dim3((unsigned)(((u64)d.npb * d.pcap + KW_CH - 1) / KW_CH)), dim3(KW_THREADS), (size_t)KW_ROWS * 5 * sizeof(u64), s, d, ++e->kw_epoch);
+        }
     }
     {
         Timed t3(e, s, 8);                                   // group 8 = in-statistics (group 3 = node + edge features)
+        const u32 fin = d.warm ? (u32)std::min<u64>(64, ((u64)d.ncap + 255) / 256) : 1u;   // finishing workgroups: the block-sorted rows (1), every row of a warm window
         hipLaunchKernelGGL(k3_in_part, dim3(e->k3_ranges * e->k3_slices), dim3(1024), e->k3in_lds, s, d, e->k3_slices);
-        hipLaunchKernelGGL(k3_in_reduce, dim3(grid_for((u64)d.ncap * 6, 256, 1024) + 1), dim3(256), 0, s, d, e->k3_slices);   // (+ 1: the last workgroup finishes the block-sorted rows)
+        hipLaunchKernelGGL(k3_in_reduce, dim3(grid_for((u64)d.ncap * 6, 256, 1024) + fin), dim3(256), 0, s, d, e->k3_slices, fin);
     }
     HIP_TRY(e, hipGetLastError());
     e->closed = true;
@@ -560,6 +604,17 @@ void account_window(sg_engine* e) {
     st.halo_overflow += e->h_ctr[C_HALO_OVF];
     st.alive_in += e->h_ctr[C_ALIVE_SEEN];
     st.alive_dropped += e->h_ctr[C_ALIVE_DROPPED];
+    if (e->d.warm) {
+        // (counters of the slot that was read: with several windows in flight every slot keeps its own state and its own counts)
+        const bool cold = e->h_ctr[C_COLD] != 0;
+        if (cold) st.windows_cold++; else st.windows_warm++;
+        // a stream whose windows keep touching edges the kept set lacks pays for the warm attempt every time: after four cold windows
+        // in a row the attempt is left out for eight windows (they rebuild and re-capture as before), then tried again
+        // (only the windows whose warm attempt ran its merge and THEN met an unknown key count — C_COLD = 2 —: a window kc_prepare
+        // calls cold costs nothing extra)
+        e->cold_streak = e->h_ctr[C_COLD] == 2 ? e->cold_streak + 1 : (cold ? e->cold_streak : 0);
+        if (e->cold_streak >= 4) { e->warm_skip = 8; e->cold_streak = 0; }
+    }
     if (e->h_ctr[C_N_EVENTS]) {
         // convertKernelTimeToUserspaceTime()/1e6 — aggregator/data.go:1740-1743, :1219 (u64 wrap arithmetic)
         st.last_window_tmin_ms = (int64_t)((e->first_user - (e->first_kernel - e->h_ctr[C_TMIN_NS])) / 1000000ull);
@@ -703,6 +758,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         if (narrow && 2 * nb - d.pb > 31) { d.np = (u32)np; d.pb = 0; while ((1u << d.pb) < d.np) d.pb++; }   // an SG_NP override that would not leave 31 remainder bits
         d.narrow = (narrow && d.variant == 0) ? 1u : 0u;
         if (!d.narrow) d.k1b_split = 1;
+        // warm windows: the 8-byte-record path without the per-edge histogram (whose bins would have to follow the kept order too);
+        // SG_CFG_NO_WARM / SG_WARM=0 keep every window on the full rebuild.  (k1b_u = 8, the one-table-per-CU build, has no warm instantiation.)
+        d.warm = (d.narrow && !d.hist && !(cfg->flags & SG_CFG_NO_WARM)) ? 1u : 0u;
+        if (const char* v = std::getenv("SG_WARM")) { if (std::atoi(v) == 0) d.warm = 0; }
         d.npb = d.np * d.k1b_split;
         d.nb = nb; d.rb = 2 * nb - d.pb;
         d.pcap = d.narrow ? d.k1b_ht * 13 / 16 : d.k1b_ht * 3 / 4;       // (u32 keys probe cheaply: the narrow tables may fill to 0.81)
@@ -727,6 +786,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // narrow pass B: 8 x 16 bytes per lane in flight where a CU holds one table anyway; two workgroups per CU need <= 64 VGPRs
         if (d.narrow) e->k1b_u = ((size_t)d.k1b_ht * 36 + 8) * 2 > kLdsBytes && m > 24.0 ? 8 : 4;
         if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; if (std::atoi(v) == 4) e->k1b_u = 4; }
+        if (e->k1b_u == 8) d.warm = 0;
         // the packed add of pass B is exact while a workgroup merges fewer than 2^16 narrow records: a partition's pieces hold sn each
         e->k1b_pack = d.narrow && (u64)d.sn * d.nwg < 65536ull;
         if (const char* v = std::getenv("SG_K1B_PACK")) { if (std::atoi(v) == 0) e->k1b_pack = false; }
@@ -757,7 +817,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     }
     if (d.variant == 0) {
         if (!k1a_geometry(e)) { e->err = "K1 pass A: piece counters and join level 1 do not fit a CU's LDS"; return fail(SG_ENOSPC); }
-        e->k1b_lds = d.narrow ? ((size_t)d.k1b_ht * 36 + 8 + 15) / 16 * 16 : (size_t)d.k1b_ht * (8 + 32 + (d.hist ? 4 * SG_HIST_BINS : 0));
+        // (narrow: accumulators, keys, two counters, then the warm path's touch bits — one per slot — and its "key inserted" word)
+        e->k1b_lds = d.narrow ? ((size_t)d.k1b_ht * 36 + 8 + (size_t)d.k1b_ht / 8 + 4 + 15) / 16 * 16 : (size_t)d.k1b_ht * (8 + 32 + (d.hist ? 4 * SG_HIST_BINS : 0));
         for (const void* f : {reinterpret_cast<const void*>(k1a_partition<true, true, false>), reinterpret_cast<const void*>(k1a_partition<true, false, false>),
                               reinterpret_cast<const void*>(k1a_partition<false, true, false>), reinterpret_cast<const void*>(k1a_partition<false, false, false>),
                               reinterpret_cast<const void*>(k1a_partition<true, true, true>), reinterpret_cast<const void*>(k1a_partition<true, false, true>),
@@ -789,6 +850,16 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
                               reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, true>),
                               reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 1, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 2, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 4, true>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
+        for (const void* f : {reinterpret_cast<const void*>(k1b_stream_merge<4, 1, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, false, 1>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, true, 1>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, false, 1>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, true, 1>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, false, 2>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, true, 2>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, false, 2>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, true, 2>)})
+            CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
+        CH(hipFuncSetAttribute(reinterpret_cast<const void*>(kw_compact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)KW_ROWS * 5 * sizeof(u64))));
         e->ecap = K2_TILE;                                              // the global edge table is not used
     }
     d.emask = e->ecap - 1;
@@ -833,7 +904,18 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             LR(dev_alloc(e, &w.acc_src, (size_t)w.npb * w.pcap * 4));
             LR(dev_alloc(e, &w.e_rank, (size_t)w.npb * w.pcap));
             if (w.dh_g) LR(dev_alloc(e, &w.dh_hist, (size_t)w.dh_g * w.dh_ns));
+            if (w.warm) {
+                const size_t KC = (size_t)w.npb * w.pcap;              // the kept CSR holds whatever pass B's tables can emit
+                LR(dev_alloc(e, &w.wk_keys, (size_t)w.npb * w.k1b_ht, 0xFF)); LR(dev_alloc(e, &w.wk_pos, (size_t)w.npb * w.k1b_ht, 0xFF));
+                LR(dev_alloc(e, &w.pos_of_slot, KC, 0xFF));
+                LR(dev_alloc(e, &w.k_acc, KC * 4)); LR(dev_alloc(e, &w.k_col, KC)); LR(dev_alloc(e, &w.k_from, KC)); LR(dev_alloc(e, &w.k_rowptr, (size_t)w.ncap + 2));
+                LR(dev_alloc(e, &w.kw_tot, (KC + KW_CH - 1) / KW_CH + 2));
+                u64* a = nullptr; u64* b = nullptr; double* c = nullptr;
+                LR(dev_alloc(e, &a, (size_t)w.ncap * SG_NODE_STAT_SUM_WORDS)); LR(dev_alloc(e, &b, (size_t)w.ncap * SG_NODE_STAT_MAX_WORDS)); LR(dev_alloc(e, &c, 2 * ((size_t)w.ncap + 1)));
+                e->scr_sum.push_back(a); e->scr_max.push_back(b); e->scr_mu.push_back(c);
+            }
         }
+        const size_t KE = w.warm ? std::max<size_t>(ME, (size_t)w.npb * w.pcap) : ME;   // arrays the rebuild indexes by KEPT position on a warm engine
         LR(dev_alloc(e, &w.ekeys, e->ecap, 0xFF));
         LR(dev_alloc(e, &w.eacc, (size_t)e->ecap * 4));
         if (w.variant == 1) w.acc_src = w.eacc;
@@ -848,8 +930,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         LR(dev_alloc(e, &w.e_slot, ME)); LR(dev_alloc(e, &w.e_from, eslots)); LR(dev_alloc(e, &w.e_to, eslots));
         LR(dev_alloc(e, &w.longrows, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.deg, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE)); LR(dev_alloc(e, &w.rp_tot, ((size_t)w.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH + 1)); LR(dev_alloc(e, &w.k6_tot, (((size_t)w.ncap + 1023) / 1024 + 1) * 16)); LR(dev_alloc(e, &w.k1a_ticket, 4)); LR(dev_alloc(e, &w.lb_ticket, 4)); w.k1a_ticket_base = 0; w.k1a_rot = 0; LR(dev_alloc(e, &w.rowptr, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.cursor, (size_t)w.ncap + 1));
-        LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cs, ME)); LR(dev_alloc(e, &w.csr_from, ME));
-        LR(dev_alloc(e, &w.sort_k, 2 * ME)); LR(dev_alloc(e, &w.sort_v, 2 * ME));
+        LR(dev_alloc(e, &w.col, ME)); LR(dev_alloc(e, &w.cs, KE)); LR(dev_alloc(e, &w.csr_from, ME));
+        LR(dev_alloc(e, &w.sort_k, 2 * KE)); LR(dev_alloc(e, &w.sort_v, 2 * KE));
         LR(dev_alloc(e, &w.acc_csr, ME * 4));
         if (w.hist) { LR(dev_alloc(e, &w.hist_src, (w.variant == 0 ? (size_t)w.npb * w.pcap : (size_t)e->ecap) * SG_HIST_BINS)); LR(dev_alloc(e, &w.hist_csr, ME * SG_HIST_BINS)); }
         LR(dev_alloc(e, &w.st_sum, (size_t)w.ncap * SG_NODE_STAT_SUM_WORDS)); LR(dev_alloc(e, &w.st_max, (size_t)w.ncap * SG_NODE_STAT_MAX_WORDS));
@@ -857,13 +939,13 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         for (u32 l = 1; l <= cfg->layers; l++) LR(dev_alloc(e, &w.h[l], (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.P, (size_t)w.ncap * SG_F_HID)); LR(dev_alloc(e, &w.Q, (size_t)w.ncap * SG_F_HID));
         LR(dev_alloc(e, &w.nmean, (size_t)w.ncap * SG_F_HID));
-        w.hub_cap = (u32)std::min<u64>(ME / 256 + 16, 1u << 24);         // blocks of the rows longer than one block: at most E / 512 + one per such row
+        w.hub_cap = (u32)std::min<u64>(KE / 256 + 16, 1u << 24);         // blocks of the rows longer than one block: at most E / 512 + one per such row
         LR(dev_alloc(e, &w.hub_items, w.hub_cap)); LR(dev_alloc(e, &w.hub_base, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.hub_part, (size_t)w.hub_cap * SG_F_HID));
         LR(dev_alloc(e, &w.efeat, ME * SG_F_EDGE)); LR(dev_alloc(e, &w.latz, ME)); LR(dev_alloc(e, &w.errr, ME));
         LR(dev_alloc(e, &w.row_mu, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.row_sd, (size_t)w.ncap + 1));
         LR(dev_alloc(e, &w.rows, ME));
         LR(dev_alloc(e, &w.in_part, (size_t)e->k3_ranges * e->k3_slices * K3_IN_NR * 6));
-        LR(dev_alloc(e, &w.alive_keys, w.alive_cap)); LR(dev_alloc(e, &w.alive_csr, ME));
+        LR(dev_alloc(e, &w.alive_keys, w.alive_cap)); LR(dev_alloc(e, &w.alive_csr, KE));
         LR(dev_alloc(e, &w.act_l, (size_t)w.ncap + 1)); LR(dev_alloc(e, &w.act_p, (size_t)w.ncap + 1));
         // arm the per-workgroup statistic slots (tmin = ~0)
         std::vector<u64> init((size_t)SG_MAX_K1_WGS * WS_WORDS, 0);
@@ -948,6 +1030,7 @@ int sg_geometry_get(sg_handle e, sg_geometry* out) {
     out->pass_a_workgroups = d.nwg; out->cache_slots = e->k1a_ct; out->join_l2_in_lds = e->l2_in_lds ? (e->d.narrow && e->l2_u16 ? 2u : 1u) : 0u;
     out->tile_records = d.narrow ? (e->k1a_team ? 8u * e->k1a_nt / e->k1a_teams : K1T_TS(e->k1a_nsub)) : 0u; out->pass_a_teams = d.narrow && e->k1a_team ? e->k1a_teams : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
     out->piece_bytes = d.variant != 0 ? 0u : (d.narrow ? d.punits * 8u : d.pslots * 16u);
+    out->warm_windows = d.warm;
     return SG_OK;
 }
 
@@ -1634,6 +1717,12 @@ int sg_timing_get(sg_handle e, int kernel, double* avg_us, uint64_t* launches) {
     return SG_OK;
 }
 
+int sg_set_warm(sg_handle e, int on) {
+    if (!e) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->warm_on = on != 0; e->warm_skip = 0; e->cold_streak = 0;
+    return SG_OK;
+}
 // every record of one group since sg_timing_reset, in launch order (bench.py: median and minimum, SURVEY 8(d) run protocol)
 int sg_timing_samples(sg_handle e, int kernel, double* us, size_t cap, size_t* n) {
     if (!e || (!us && cap)) return SG_EINVAL;

@@ -57,7 +57,15 @@ enum {
     C_ACT_L,          // world > 1: nodes whose layer output this shard computes (local sources + local leaf destinations)
     C_ACT_P,          // world > 1: nodes whose score projections this shard needs (local sources + local destinations)
     C_HUB_ITEMS,      // (row, block) work items of the rows with more than SG_MEAN_BLOCK neighbours (k2_rowptr -> k4_gather)
-    C_COUNT = 24
+    // warm windows (Dev::warm): the edge set and its CSR order kept from the last cold window
+    C_COLD,           // != 0: this window takes the full rebuild — 1 set by kc_prepare (no usable kept state / the host does not try), 2 by the warm pass B (a key the kept set lacks)
+    C_KEPT_VALID,     // the kept state describes a whole window (no capacity drop, no raw outbound IP when it was captured)
+    C_KEPT_E,         // edges of the kept CSR
+    C_KEPT_NK,        // N_KNOWN and
+    C_KEPT_NL,        // N_LABELS when it was captured: the dense node numbering the kept columns are written in
+    C_WARM_WINDOWS,   // windows closed on the warm path / by a full rebuild since create (sg_stats)
+    C_COLD_WINDOWS,
+    C_COUNT = 32
 };
 
 // per-workgroup statistics slots written by K1 (one 64-byte line per workgroup: no cross-WG
@@ -151,6 +159,20 @@ struct Dev {
     u32* alive_csr;                           // [max_edges] CSR order: open connections per edge
     u32* act_l; u32* act_p;                   // [ncap] world > 1: active node lists (ascending), built with the halo requests
     u64* rp_tot;                              // [ceil((ncap+1)/K2_RP_ROWS)] k2_rowptr: (epoch << 32 | rows' edge total) per workgroup
+    // ---- warm windows (variant 0, 8-byte records, no histogram): state carried from one window to the next ----
+    // A service map's edge set hardly changes from window to window.  The last COLD window (full rebuild) leaves behind pass B's table
+    // image — key per slot — and, per slot, the position its edge got in the CSR; its CSR (row pointers, columns, sources) is kept as
+    // the "kept CSR".  A WARM window seeds pass B's LDS tables with the image: every record finds its key where it was, the
+    // accumulators go straight to k_acc[kept position], and kw_compact turns the kept CSR minus the untouched edges into the window's
+    // CSR in one stable pass (no degree histogram, no row scan over partitions, no scatter, no row sort).  Any key the image lacks, a
+    // changed node numbering or a raw outbound IP sends the window down the full rebuild, which captures the state anew.
+    u32 warm;                                 // 1 = this engine keeps the state
+    u32* wk_keys;                             // [npb][k1b_ht] pass B's table image of the last cold window (all ones = empty)
+    u32* wk_pos;                              // [npb][k1b_ht] the slot's edge: partition-output index (cold pass B), then its kept-CSR position (kw_capture); SG_NONE = none
+    u32* pos_of_slot;                         // [npb * pcap] CSR position the row sort gave the edge of a partition-output slot (cold windows)
+    u64* k_acc;                               // [max_edges][4] accumulators by kept position, rewritten by every warm pass B; bit 63 of word 2 (max_ns < 2^62) = touched in this window
+    u32* k_col; u32* k_from; u32* k_rowptr;   // the kept CSR: [max_edges], [max_edges], [ncap + 1]
+    u64* kw_tot;                              // [max_edges / KW_CH + 2] kw_compact: (epoch << 32 | touched edges) per chunk
     u32* lb_ticket;                           // [4] self-resetting workgroup tickets of the look-back kernels whose grid exceeds SG_LB_RESIDENT ([0] k2_rowptr, [1] kw_compact)
     u64* k6_tot;                              // [ceil(ncap/1024) + 1][16] k6_halo_lists: (epoch << 32 | members) per workgroup and list
     // ---- closed window ----

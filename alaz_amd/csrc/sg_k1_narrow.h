@@ -470,13 +470,28 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
 // every one is below 2^32 ns, so the sum stays below 2^48 and cannot carry into the count —, which the host guarantees from the geometry
 // (sn x nwg < 65 536: a piece holds at most sn narrow records) before it picks this build; behind the narrow phase's barrier every slot's
 // owner thread moves the count into accumulator 0, where the wide records (64-bit adds) expect it.
-template <int U, int SPT, bool PACK>
+// WM (warm windows, sg_device.h): 0 = an engine without the kept state: the kernel as it was.  1 = the WARM attempt: the table starts as
+// the image the last cold window left (wk_keys), a record finds its key at the slot it had then, and at the end every seeded slot's
+// accumulators go straight to k_acc[wk_pos[slot]] — zero for a slot no record touched, bit 63 of the max word set for one that was
+// (an SG_EV_ALIVE record touches a key without counting: its own LDS bit map says so).  A key the image lacks is inserted like any
+// other, which makes the window COLD (C_COLD): the full rebuild repeats the merge.  A window already known to be cold is skipped.
+// 2 = the COLD merge of an engine that keeps state: skipped on a warm window.  As WM 0 for the window's records; then, behind them, the
+// keys of the OLD image that no record touched are put into the table too as long as the partition's output has room (they can
+// never displace a key of this window: those are all in by then) — the kept set is the UNION of what the windows have touched, so a
+// stream whose windows each touch another 90 % of the graph settles on the warm path instead of rebuilding for ever.  Every key
+// leaves with its accumulators (bit 63 of the max word = touched in this window, all zero otherwise); the image and, per slot, the
+// edge's index in the partition output are left for kw_capture.  The rebuild (K2) then builds the KEPT CSR from these outputs and
+// kw_compact derives the window's CSR from it, exactly as on a warm window.
+template <int U, int SPT, bool PACK, int WM>
 __device__ __forceinline__ void k1b8_body(const Dev& d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (WM == 1) { if (d.ctr[C_COLD]) return; }             // (uniform: kc_prepare already knows, or another workgroup found a new key)
+    if constexpr (WM == 2) { if (!d.ctr[C_COLD]) return; }
     const u32 HT = d.k1b_ht, hmask = HT - 1;
     u64* hacc = reinterpret_cast<u64*>(smem);                        // [4][HT]: accumulator j of slot h at j*HT + h
     u32* hkey = reinterpret_cast<u32*>(hacc + (size_t)HT * 4);       // [HT] remainders, all ones = empty
     u32* n_drop = hkey + HT; u32* out_n = n_drop + 1;
+    u32* htouch = out_n + 1;                                         // WM 1: [HT / 32] slots a record touched without counting; word HT / 32 = "a key was inserted"
     const u32 t = threadIdx.x, NT = blockDim.x;
     // q -> (partition, sub-table): blocks b and b + 8 run on the same XCD (b % 8) and are dispatched back to back
     const u32 S = d.k1b_split, q = blockIdx.x;
@@ -502,7 +517,14 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     }
     const u64 ovf_n = d.ctr[C_OVF_N];
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
-    for (u32 i = t; i < HT; i += NT) hkey[i] = 0xFFFFFFFFu;
+    if constexpr (WM == 1) {
+        const u32* img = d.wk_keys + (size_t)oq * HT;                 // (coalesced: 4 HT bytes per workgroup, beside the headers' round trip)
+        for (u32 i = t; i < HT; i += NT) hkey[i] = img[i];
+        for (u32 i = t; i <= HT / 32; i += NT) htouch[i] = 0;
+    } else {
+        for (u32 i = t; i < HT; i += NT) hkey[i] = 0xFFFFFFFFu;
+        if constexpr (WM == 2) { for (u32 i = t; i <= HT / 32; i += NT) htouch[i] = 0; }   // bits: slots filled from the old image; word HT / 32: keys in the table
+    }
     for (u32 i = t; i < HT * 4; i += NT) hacc[i] = 0;
     if (t == 0) { *n_drop = 0; *out_n = 0; }
     __syncthreads();
@@ -513,7 +535,14 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         u32 h = rem & hmask;
         for (u32 it = 0; it < HT; it++) {
             u32 k = lds_fresh_u32(&hkey[h]);
-            if (k == 0xFFFFFFFFu) { k = atomicCAS(&hkey[h], 0xFFFFFFFFu, rem); if (k == 0xFFFFFFFFu) k = rem; }
+            if (k == 0xFFFFFFFFu) {
+                k = atomicCAS(&hkey[h], 0xFFFFFFFFu, rem);
+                if (k == 0xFFFFFFFFu) {
+                    k = rem;
+                    if constexpr (WM == 1) htouch[HT / 32] = 1u;     // a key the kept set lacks: the window is cold
+                    if constexpr (WM == 2) atomicAdd(&htouch[HT / 32], 1u);   // keys in the table (the union phase fills what room is left)
+                }
+            }
             if (k == rem) return h;
             h = (h + 1) & hmask;
         }
@@ -541,6 +570,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         const u32 h = slot_of(rem);
         if (h == HT) { atomicAdd(n_drop, (u32)(a0 & 0xFFFFFFFFull)); return; }
         atomicAdd(&hacc[h], a0); atomicAdd(&hacc[HT + h], a1); atomicMax(&hacc[2 * HT + h], a2); atomicAdd(&hacc[3 * HT + h], a3);
+        if constexpr (WM == 1) { if (!(a0 & 0xFFFFFFFFull)) atomicOr(&htouch[h >> 5], 1u << (h & 31u)); }   // an edge-only record: the edge exists in this window with count 0
     };
     for (u32 w = w0; w < d.nwg; w += NT / LPP) {
         const uint2 h = empty ? make_uint2(0u, 0u) : (w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w]);   // (no batch this window: the headers are the previous window's)
@@ -598,6 +628,64 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     }
     __syncthreads();
     SG_STAMP(d, 1, 4);
+    if constexpr (WM == 2) {
+        // the union: keys of the old image that this window did not touch, while the partition's output has room.  (A kept state that
+        // is not whole — it was captured from a window with raw outbound IPs, whose compact indices are table slots of THAT window —
+        // is not carried.)
+        if (d.ctr[C_KEPT_VALID]) {                                   // (uniform)
+            const u32* img = d.wk_keys + (size_t)oq * HT;
+            u32 old[SPT];
+#pragma unroll
+            for (int k2 = 0; k2 < SPT; k2++) { const u32 sl = t + (u32)k2 * NT; old[k2] = sl < HT ? img[sl] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (int k2 = 0; k2 < SPT; k2++) {
+                const u32 rem = old[k2];
+                if (rem == 0xFFFFFFFFu) continue;
+                u32 h = rem & hmask;
+                bool have = false, room = false;
+                for (u32 it = 0; it < HT; it++) {
+                    u32 k = lds_fresh_u32(&hkey[h]);
+                    if (k == 0xFFFFFFFFu) {
+                        if (!room) {                                 // absent so far: take one of the output's free places, or leave the key behind
+                            if (atomicAdd(&htouch[HT / 32], 1u) >= d.pcap) { atomicSub(&htouch[HT / 32], 1u); break; }
+                            room = true;
+                        }
+                        k = atomicCAS(&hkey[h], 0xFFFFFFFFu, rem);
+                        if (k == 0xFFFFFFFFu) { atomicOr(&htouch[h >> 5], 1u << (h & 31u)); have = true; break; }   // in, marked "not of this window"
+                    }
+                    if (k == rem) { have = true; break; }            // (a record of this window has it)
+                    h = (h + 1) & hmask;
+                }
+                if (room && !have) atomicSub(&htouch[HT / 32], 1u);  // (the table itself was full)
+            }
+        }
+        __syncthreads();                                             // the old image has been read: the compaction below writes the new one
+    }
+    if constexpr (WM == 1) {
+        // warm output: slot -> kept position (one coalesced read), 32 bytes to k_acc[position] — untouched slots write zeros, so the
+        // kept array is rewritten whole every window and kw_compact needs no other mark
+        const u32 KE = (u32)d.ctr[C_KEPT_E];
+        const u32* wp = d.wk_pos + (size_t)oq * HT;
+        u32 pos[SPT];
+#pragma unroll
+        for (int k2 = 0; k2 < SPT; k2++) { const u32 sl = t + (u32)k2 * NT; pos[k2] = sl < HT ? wp[sl] : SG_NONE; }
+        bool cold = false;
+#pragma unroll
+        for (int k2 = 0; k2 < SPT; k2++) {
+            const u32 sl = t + (u32)k2 * NT;
+            if (sl >= HT) continue;
+            if (hkey[sl] == 0xFFFFFFFFu) continue;
+            if (pos[k2] >= KE) { cold = true; continue; }             // a key without a kept edge (inserted in this window, or dropped when the image was taken)
+            const u64 a0 = hacc[sl], a1 = hacc[HT + sl], a2 = hacc[2 * HT + sl], a3 = hacc[3 * HT + sl];
+            const bool touched = (a0 & 0xFFFFFFFFull) != 0 || ((htouch[sl >> 5] >> (sl & 31u)) & 1u);
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(d.k_acc + (size_t)pos[k2] * 4);
+            o[0] = make_ulonglong2(touched ? a0 : 0ull, touched ? a1 : 0ull);
+            o[1] = make_ulonglong2(touched ? (a2 | (1ull << 63)) : 0ull, touched ? a3 : 0ull);
+        }
+        if (cold || (t == 0 && (htouch[HT / 32] || *n_drop))) d.ctr[C_COLD] = 2;   // (same value from whoever writes it; 2 = found HERE, after a whole merge: the host backs off when that keeps happening)
+        SG_STAMP(d, 1, 5);
+        return;
+    }
     // compaction: SPT table slots per thread, one round; the returning `deg` atomics of a thread are in flight together
     {
         u32 f[SPT], to[SPT], oi[SPT], rk[SPT]; bool live[SPT];
@@ -607,6 +695,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             live[k2] = false; f[k2] = to[k2] = oi[k2] = rk[k2] = 0;
             if (sl >= HT) continue;
             const u32 rem = hkey[sl];
+            if constexpr (WM == 2) { d.wk_keys[(size_t)oq * HT + sl] = rem; d.wk_pos[(size_t)oq * HT + sl] = SG_NONE; }   // the image; the live slots' index follows below
             if (rem == 0xFFFFFFFFu) continue;
             const u64 mk = ((u64)p << d.rb) | rem;
             u32 cf, ct;
@@ -624,9 +713,16 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             if (!live[k2]) continue;
             const u32 sl = t + (u32)k2 * NT;
             const size_t slot = (size_t)oq * d.pcap + oi[k2];
+            if constexpr (WM == 2) d.wk_pos[(size_t)oq * HT + sl] = oi[k2];
             d.e_from[slot] = f[k2]; d.e_to[slot] = to[k2];
             ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
+            if constexpr (WM == 2) {
+                const bool touched = !((htouch[sl >> 5] >> (sl & 31u)) & 1u);   // (everything the records put in; the union phase marked its own)
+                o[0] = make_ulonglong2(touched ? hacc[sl] : 0ull, touched ? hacc[HT + sl] : 0ull);
+                o[1] = make_ulonglong2(touched ? (hacc[2 * HT + sl] | (1ull << 63)) : 0ull, touched ? hacc[3 * HT + sl] : 0ull);
+            } else {
             o[0] = make_ulonglong2(hacc[sl], hacc[HT + sl]); o[1] = make_ulonglong2(hacc[2 * HT + sl], hacc[3 * HT + sl]);
+            }
         }
 #pragma unroll
         for (int k2 = 0; k2 < SPT; k2++) if (live[k2] && !d.dh_g) d.e_rank[(size_t)oq * d.pcap + oi[k2]] = rk[k2];
@@ -644,5 +740,5 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
 }
 // (the SGPR cap lets two 1024-thread workgroups share a CU — tools/occupancy_probe.hip; the uncapped build for geometries
 // where a CU holds one workgroup anyway)
-template <int U, int SPT, bool PACK> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_stream_merge(Dev d) { k1b8_body<U, SPT, PACK>(d); }
-template <int U, int SPT, bool PACK> __global__ __launch_bounds__(1024) void k1b_stream_merge_wide(Dev d) { k1b8_body<U, SPT, PACK>(d); }
+template <int U, int SPT, bool PACK, int WM = 0> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_stream_merge(Dev d) { k1b8_body<U, SPT, PACK, WM>(d); }
+template <int U, int SPT, bool PACK, int WM = 0> __global__ __launch_bounds__(1024) void k1b_stream_merge_wide(Dev d) { k1b8_body<U, SPT, PACK, WM>(d); }

@@ -798,12 +798,21 @@ template <int K1B_U, bool HIST> __global__ __launch_bounds__(1024) void k1b_merg
 //   (b) collect the window's distinct raw outbound IPs (or take the sharded driver's union list),
 //       sort them (bitonic, global memory), drop duplicates -> ob_sorted, N_OBIP;
 //   (c) N = NK + NL + NOB.
+// Warm windows: thread 0 also decides whether this window may take the warm path at all (C_COLD = 0): the host wants to try
+// (warm_try), the kept state is whole, the node numbering it was written in still holds (same N_KNOWN and N_LABELS — the dense
+// ids of labels follow the known nodes'), and the window has no raw outbound IP (their dense ids are ranks among the window's own).
+__device__ __forceinline__ void kc_warm_decide(const Dev& d, u32 warm_try, u64 n_known, u64 nl, u64 nob) {
+    if (!d.warm) return;
+    const bool ok = warm_try && d.ctr[C_KEPT_VALID] && d.ctr[C_KEPT_E] != 0 && d.ctr[C_KEPT_NK] == n_known && d.ctr[C_KEPT_NL] == nl && nob == 0;
+    d.ctr[C_COLD] = ok ? 0ull : 1ull;
+}
 __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_labels_decl, u32* list, const u32* n_in, u32 list_cap, u32 collect,
-                                                   const u32* seg, u32 seg_stride, u32 seg_world) {
+                                                   const u32* seg, u32 seg_stride, u32 seg_world, u32 warm_try) {
     __shared__ u64 red[7][16];
     __shared__ u32 wsum[17];
     __shared__ u32 cnt;
     __shared__ u64 nkl;                                              // N_KNOWN + N_LABELS as thread 0 wrote them (no second trip to memory for step (c))
+    __shared__ u64 nl_s;
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // (the first stretch of the outbound-IP table travels together with the statistics: one round trip to memory, not two — this
     // kernel is one workgroup, the chip waits for it, and it is nothing but dependent round trips)
@@ -834,7 +843,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
             d.ctr[C_TMIN_NS] = red[0][0]; d.ctr[C_TMAX_NS] = red[1][0];
             u64 nl = nl_prev;                                        // labels are cumulative across windows
             nl = red[2][0] > nl ? red[2][0] : nl; nl = n_labels_decl > nl ? n_labels_decl : nl;
-            d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known; nkl = nl + n_known;
+            d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known; nkl = nl + n_known; nl_s = nl;
             d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
             d.ctr[C_DROPPED_CAP] = red[4][0];                        // K1b / K2 add their own drops afterwards
             d.ctr[C_N_LONG] = 0;                                     // k2_rowptr's workgroups append to the long-row list
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
         n = *n_in < list_cap ? *n_in : list_cap;
     }
     if (n == 0) {                                                    // (uniform) no raw outbound IP this window: nothing to sort or to number
-        if (t == 0) { d.ctr[C_N_OBIP] = 0; d.ctr[C_N_NODES] = nkl; }
+        if (t == 0) { d.ctr[C_N_OBIP] = 0; d.ctr[C_N_NODES] = nkl; kc_warm_decide(d, warm_try, n_known, nl_s, 0); }
         return;
     }
     u32 np2 = 1; while (np2 < n) np2 <<= 1;
@@ -893,6 +902,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
         const u64 nob = total < d.max_obip ? total : d.max_obip;
         d.ctr[C_N_OBIP] = nob;
         d.ctr[C_N_NODES] = nkl + nob;
+        kc_warm_decide(d, warm_try, n_known, nl_s, nob);
     }
 }
 
@@ -983,8 +993,10 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
 #define K2_DH_THREADS 1024
 #define K2_DH_FLIGHT 16
 #define K2_DH_GMAX 128           // k2_rowptr keeps a row's column of counts in registers: GMAX / 8 per lane
+#define SG_WARM_WINDOW(d) ((d).warm && !(d).ctr[C_COLD])             /* (uniform) this window is closed on the warm path: the rebuild kernels return at once */
 __global__ __launch_bounds__(K2_DH_THREADS) void k2_deg_hist(Dev d) {
     extern __shared__ u32 dh_cnt[];                                  // [N]
+    if (SG_WARM_WINDOW(d)) return;
     const u32 N = (u32)d.ctr[C_N_NODES], g = blockIdx.x, t = threadIdx.x;
     const u32 CH = (d.pcap + K2_DH_THREADS - 1) / K2_DH_THREADS, items = d.dh_ppw * CH;   // work item = 1024 consecutive slots of one partition
     // (the first round's loads are issued before the counters are cleared: they fly while the LDS is zeroed)
@@ -1024,6 +1036,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
     __shared__ u32 wsum[17];
     __shared__ u32 rdeg[RPR];
     __shared__ u32 nlong, lbase, pre, bdyn;
+    if (SG_WARM_WINDOW(d)) return;
     const u32 t = threadIdx.x;
     // Which rows this workgroup owns.  The look-back below waits for the workgroups of the rows before it.  Up to SG_LB_RESIDENT
     // workgroups (one per CU) every workgroup of the launch is resident and the block index serves.  Beyond that (C5: 150 k rows) a
@@ -1167,6 +1180,7 @@ __global__ __launch_bounds__(256) void k2_scatter_table(Dev d) {
     }
 }
 __global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
+    if (SG_WARM_WINDOW(d)) return;
     const u32 p = blockIdx.x, n = d.part_n[p];
     // four edges per thread and trip: their loads (source, then row start + replica offset) are in flight together — one edge per
     // trip was two dependent round trips for each of a partition's ~4 edges per thread.  The slots are read whether or not they hold an
@@ -1210,11 +1224,12 @@ __device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
 // The fp32 edge features, lat_z and err_ratio are computed afterwards, one thread per edge, by the edge
 // workgroups of k3_node_features: inside the row sort they were ~1000 fp64-heavy instructions per edge run
 // by the few threads that own a long row (a 3000-edge hub row kept one 256-thread workgroup busy for tens of us).
-struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; u32* hist_src; u32* hist_csr; u32 hist; };
+struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; u32* hist_src; u32* hist_csr; u32 hist; u32* pos_of_slot; };
 __device__ __forceinline__ void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row, u32 slot, u64, u64, u64, const ulonglong2 x, const ulonglong2 y) {
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)pos * 4);
     dst[0] = x; dst[1] = y;
     d.csr_from[pos] = row;
+    if (d.pos_of_slot) d.pos_of_slot[slot] = pos;                    // warm windows: where the edge of this partition-output slot sits in the CSR (kw_capture)
     d.alive_csr[pos] = 0;                                            // k3_in_stats adds the window's open connections
     if (d.hist) {                                                    // f-3: the edge's latency histogram follows it into row order
         uint4* hs = reinterpret_cast<uint4*>(d.hist_src + (size_t)slot * SG_HIST_BINS); uint4* hd = reinterpret_cast<uint4*>(d.hist_csr + (size_t)pos * SG_HIST_BINS);
@@ -1674,8 +1689,9 @@ __device__ __forceinline__ void k2_row_wave_rank(const Dev& d, const EdgeEmitArg
     }
 }
 __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
+    if (SG_WARM_WINDOW(d)) return;
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
-    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant, d.hist_src, d.hist_csr, d.hist};
+    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant, d.hist_src, d.hist_csr, d.hist, d.warm ? d.pos_of_slot : nullptr};
     extern __shared__ u32 k2_lds[];                                  // 2 x k2_sortw words (dynamic: a node bitmap of the engine's node capacity fits when it can)
     u32* sk = k2_lds; u32* sv = k2_lds + d.k2_sortw;
     __shared__ u64 red[5][4];
@@ -1738,6 +1754,193 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
             d.row_mu[r] = mean_us(sum, cnt); d.row_sd[r] = std_us(sum, ssq, cnt);
         }
         if (lane < n) edge_emit(ea, beg + rank, r, v, cnt, sum, ssq, x, y);
+    }
+}
+
+// ---- warm windows (sg_device.h): capture behind a full rebuild, one-pass window CSR on a warm window --------------------------------
+// kw_capture, behind the rebuild of a COLD close.  On an engine that keeps state the rebuild (k2_deg_hist .. k2_rowsort_gather) runs on a
+// Dev whose CSR pointers are the KEPT arrays: it has just built the kept CSR — every key pass B's cold merge left in its tables, the
+// window's own and the ones carried over from the old image — with each edge's accumulators (bit 63 of the max word = touched in this
+// window).  Here every slot of the table image gets the kept position of its edge (image index -> partition-output index -> the
+// position the row sort reported) and the state is declared whole, unless the window holds raw outbound IPs (their compact indices
+// are slots of this window's own outbound-IP table, their node ids ranks among this window's own).  The scratch node statistics the
+// rebuild wrote (it reduces every row it sorts; the window's real ones come from kw_compact) are zeroed for the next rebuild.
+__global__ __launch_bounds__(256) void kw_capture(Dev d, u64* scratch_sum, u64* scratch_max) {
+    if (!d.ctr[C_COLD]) return;                                      // (uniform) a warm window changes nothing
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
+    const bool whole = d.ctr[C_N_OBIP] == 0;
+    if (tid == 0) {
+        d.ctr[C_KEPT_VALID] = whole ? 1ull : 0ull; d.ctr[C_KEPT_E] = d.ctr[C_N_EDGES];   // (k2_rowptr's count on the kept arrays)
+        d.ctr[C_KEPT_NK] = d.ctr[C_N_KNOWN]; d.ctr[C_KEPT_NL] = d.ctr[C_N_LABELS];
+        d.ctr[C_COLD_WINDOWS] += 1;
+    }
+    for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) scratch_sum[i] = 0;
+    for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) scratch_max[i] = 0;
+    const u64 slots = (u64)d.npb * d.k1b_ht;
+    for (u64 i = tid; i < slots; i += nt) {
+        const u32 oi = d.wk_pos[i];
+        if (oi != SG_NONE) d.wk_pos[i] = oi < d.pcap ? d.pos_of_slot[(size_t)(i / d.k1b_ht) * d.pcap + oi] : SG_NONE;
+    }
+}
+
+// kw_compact — every window of an engine that keeps state; the whole of K2 on a WARM one: the kept CSR minus the edges no record
+// touched, in ONE stable pass (on a cold window the rebuild has just refreshed the kept CSR and kw_capture its positions).  Workgroup b owns
+// the kept positions [b KW_CH, (b + 1) KW_CH): it loads their accumulators (written by the warm pass B, bit 63 of the max word =
+// touched), columns and sources, counts the touched ones (wave ballots), publishes the count and sums the counts of the chunks before
+// it (the look-back of k2_rowptr: relaxed (epoch, total) words; beyond SG_LB_RESIDENT chunks the workgroups order themselves by
+// ticket), and writes the survivors at base + rank — adjacent lanes, adjacent addresses, the order inside every row unchanged, so
+// rows stay sorted by destination.  The rows that START in the chunk get their new row pointer from the same ranks.  The out-
+// statistics of a row (integer sums, order-free) are folded in LDS arrays indexed by row − first row of the chunk and leave with plain
+// stores for the rows that lie wholly inside the chunk, with device atomics for the at most two that cross its ends (and for rows
+// beyond the LDS arrays' reach in graphs of very short rows); k3_in_reduce turns the sums into degree, mean and deviation and lists
+// the hub rows' blocks.
+#define KW_THREADS 1024
+#define KW_Q 4
+#define KW_CH (KW_THREADS * KW_Q)
+#define KW_ROWS 1536                                                 // rows per chunk with LDS accumulators (5 x u64 each: 60 KiB)
+__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch) {
+    extern __shared__ u64 kw_racc[];                                 // [KW_ROWS][5]: cnt, err, sum, ssq, max
+    __shared__ u64 bal[KW_Q][16];
+    __shared__ u32 wpre[KW_Q][16];
+    __shared__ u32 qpre[KW_Q + 1];
+    __shared__ u32 pre, bdyn;
+    const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const u32 KE = (u32)d.ctr[C_KEPT_E], N = (u32)d.ctr[C_N_NODES];
+    const u32 nchunk = KE ? (KE + KW_CH - 1) / KW_CH : 1u;
+    u32 b = blockIdx.x;
+    if (gridDim.x > SG_LB_RESIDENT) {                                // (uniform) see k2_rowptr
+        if (t == 0) { const u32 tk = atomicAdd(&d.lb_ticket[1], 1u); if (tk == gridDim.x - 1) atomicExch(&d.lb_ticket[1], 0u); bdyn = tk; }
+        __syncthreads();
+        b = bdyn;
+    }
+    if (b >= nchunk) return;                                         // (nobody waits for a chunk behind its own)
+    if (b == 0 && t == 0) {
+        d.ctr[C_OVF_N] = 0;                                          // pass B has consumed the overflow list
+        d.ctr[C_ACT_L] = SG_ACT_NONE; d.ctr[C_ACT_P] = 0;
+        d.ctr[C_HUB_ITEMS] = 0;                                      // the hub blocks of the WINDOW's rows are listed behind this kernel (kw_finish_rows); a rebuild's were the kept rows'
+        if (!d.ctr[C_COLD]) d.ctr[C_WARM_WINDOWS] += 1;
+    }
+    if (KE == 0) {                                                   // an empty kept set: an empty window
+        for (u32 v = t; v <= N; v += KW_THREADS) d.rowptr[v] = 0;
+        if (t == 0) { d.ctr[C_N_EDGES] = 0; d.ctr[C_EDGES_FOUND] = 0; }
+        return;
+    }
+    const u32 p0 = b * KW_CH, last = (p0 + KW_CH < KE ? p0 + KW_CH : KE) - 1;
+    u32 fr[KW_Q], co[KW_Q]; ulonglong2 x[KW_Q], y[KW_Q]; bool tc[KW_Q];
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) {
+        const u32 i = p0 + (u32)q * KW_THREADS + t, ic = i <= last ? i : last;
+        fr[q] = d.k_from[ic]; co[q] = d.k_col[ic];
+        const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.k_acc + (size_t)ic * 4);
+        x[q] = a[0]; y[q] = a[1];
+    }
+    const u32 v0 = d.k_from[p0], v_hi = d.k_from[last];              // first and last row with an edge in this chunk
+    const u32 v_lo = b == 0 ? 0u : d.k_from[p0 - 1] + 1u;            // rows that START here: (row of the position before the chunk, v_hi]
+    for (u32 i = t; i < KW_ROWS * 5; i += KW_THREADS) kw_racc[i] = 0;
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) {
+        tc[q] = p0 + (u32)q * KW_THREADS + t <= last && (y[q].x >> 63) != 0;
+        const u64 m = __ballot(tc[q] ? 1 : 0);
+        if (lane == 0) { bal[q][wave] = m; wpre[q][wave] = (u32)__popcll(m); }
+    }
+    __syncthreads();
+    if (t < KW_Q) { u32 acc = 0; for (u32 w2 = 0; w2 < 16; w2++) { const u32 c = wpre[t][w2]; wpre[t][w2] = acc; acc += c; } qpre[t + 1] = acc; }
+    __syncthreads();
+    if (t == 0) {
+        u32 run = 0;
+        for (int q = 0; q < KW_Q; q++) { const u32 c = qpre[q + 1]; qpre[q] = run; run += c; }
+        qpre[KW_Q] = run;
+        __hip_atomic_store(&d.kw_tot[b], ((u64)epoch << 32) | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (relaxed: see k2_rowptr)
+        pre = 0;
+    }
+    __syncthreads();
+    {
+        u32 mine = 0;
+        for (u32 j = t; j < b; j += KW_THREADS) {
+            u64 w;
+            do { w = __hip_atomic_load(&d.kw_tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((u32)(w >> 32) != epoch);
+            mine += (u32)w;
+        }
+        if (b) { mine = wave_sum_u32(mine); if (lane == 0 && mine) atomicAdd(&pre, mine); }
+    }
+    __syncthreads();
+    const u32 base = pre, total = qpre[KW_Q];
+    const u64 lt = (1ull << lane) - 1ull;
+    const u32 ME = (u32)d.max_edges;                                 // (the kept arrays hold npb x pcap edges; a WINDOW's rows stop at the configured capacity: cut and counted, as k2_rowptr does)
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) if (tc[q]) {
+        const u32 np = base + qpre[q] + wpre[q][wave] + (u32)__popcll(bal[q][wave] & lt);
+        if (np >= ME) continue;
+        const u64 mx = y[q].x & ~(1ull << 63);
+        d.col[np] = co[q]; d.csr_from[np] = fr[q]; d.alive_csr[np] = 0;
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)np * 4);
+        o[0] = x[q]; o[1] = make_ulonglong2(mx, y[q].y);
+        const u64 cnt = x[q].x & 0xFFFFFFFFull, err = x[q].x >> 32;
+        const u32 r = fr[q] - v0;
+        if (r < KW_ROWS) {
+            u64* a = kw_racc + (size_t)r * 5;
+            if (cnt) atomicAdd(&a[0], cnt);
+            if (err) atomicAdd(&a[1], err);
+            if (x[q].y) atomicAdd(&a[2], x[q].y);
+            if (y[q].y) atomicAdd(&a[3], y[q].y);
+            if (mx) atomicMax(&a[4], mx);
+        } else {
+            u64* g = d.st_sum + (size_t)fr[q] * SG_NODE_STAT_SUM_WORDS;
+            if (cnt) atomicAdd(&g[ST_OUT_CNT], cnt);
+            if (err) atomicAdd(&g[ST_OUT_ERR], err);
+            if (x[q].y) atomicAdd(&g[ST_OUT_SUM], x[q].y);
+            if (y[q].y) atomicAdd(&g[ST_OUT_SSQ], y[q].y);
+            if (mx) atomicMax(&d.st_max[(size_t)fr[q] * 2], mx);
+        }
+    }
+    // new row pointers of the rows that start in this chunk: rank of the row's first kept position among the chunk's touched ones
+    for (u32 v = v_lo + t; v <= v_hi; v += KW_THREADS) {
+        const u32 xl = d.k_rowptr[v] - p0, q = xl / KW_THREADS, tt = xl % KW_THREADS, w2 = tt >> 6, l2 = tt & 63u;
+        const u32 rp = base + qpre[q] + wpre[q][w2] + (u32)__popcll(bal[q][w2] & ((1ull << l2) - 1ull));
+        d.rowptr[v] = rp < ME ? rp : ME;
+    }
+    if (b == nchunk - 1) {                                           // the last chunk knows E; the rows behind the last kept edge are empty
+        const u32 Ef = base + total, E = Ef < ME ? Ef : ME;
+        for (u32 v = v_hi + 1 + t; v <= N; v += KW_THREADS) d.rowptr[v] = E;
+        if (t == 0) { d.ctr[C_N_EDGES] = E; d.ctr[C_EDGES_FOUND] = Ef; if (Ef > ME) d.ctr[C_DROPPED_CAP] += (u64)(Ef - ME); }
+    }
+    __syncthreads();                                                 // every LDS fold is in
+    {
+        const u32 nr = v_hi - v0 + 1 < KW_ROWS ? v_hi - v0 + 1 : KW_ROWS;
+        for (u32 r = t; r < nr; r += KW_THREADS) {
+            const u64* a = kw_racc + (size_t)r * 5;
+            const u64 cnt = a[0], err = a[1], sum = a[2], ssq = a[3], mx = a[4];
+            if (!(cnt | err | sum | ssq | mx)) continue;
+            const u32 v = v0 + r;
+            u64* g = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
+            if (v >= v_lo && v < v_hi) {                             // wholly inside this chunk: nobody else writes the row (the arrays were zeroed by the window reset)
+                g[ST_OUT_CNT] = cnt; g[ST_OUT_ERR] = err; g[ST_OUT_SUM] = sum; g[ST_OUT_SSQ] = ssq; d.st_max[(size_t)v * 2] = mx;
+            } else {
+                if (cnt) atomicAdd(&g[ST_OUT_CNT], cnt);
+                if (err) atomicAdd(&g[ST_OUT_ERR], err);
+                if (sum) atomicAdd(&g[ST_OUT_SUM], sum);
+                if (ssq) atomicAdd(&g[ST_OUT_SSQ], ssq);
+                if (mx) atomicMax(&d.st_max[(size_t)v * 2], mx);
+            }
+        }
+    }
+}
+// behind kw_compact (run by extra workgroups of k3_in_reduce on a warm window): a thread per node — out-degree from the new row pointers,
+// mean / deviation of the row's out-events from its sums (the row sort's own expressions), the hub rows' block work items
+__device__ __forceinline__ void kw_finish_rows(const Dev& d, u32 tid, u32 nt) {
+    const u32 N = (u32)d.ctr[C_N_NODES];
+    for (u32 v = tid; v < N; v += nt) {
+        const u32 s0 = d.rowptr[v], dg = d.rowptr[v + 1] - s0;
+        u64* t = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
+        const u64 tc = t[ST_OUT_CNT], ts = t[ST_OUT_SUM], tq = t[ST_OUT_SSQ];
+        t[ST_OUT_DEG] = dg;
+        d.row_mu[v] = mean_us(ts, tc); d.row_sd[v] = std_us(ts, tq, tc);
+        if (dg > SG_MEAN_BLOCK) {
+            const u32 nblk = (dg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
+            const u32 ib = (u32)atomicAdd(&d.ctr[C_HUB_ITEMS], (u64)nblk);   // (zeroed by kc_prepare)
+            d.hub_base[v] = ib;
+            for (u32 j = 0; j < nblk; j++) if (ib + j < d.hub_cap) d.hub_items[ib + j] = make_uint2(v, j);
+        }
     }
 }
 
@@ -1825,12 +2028,17 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
     for (u32 i = t; i < nr * 6; i += 1024) out[i] = acc[i];
     SG_STAMP(d, 3, 4);
 }
-__global__ __launch_bounds__(256) void k3_in_reduce(Dev d, u32 S) {
+__global__ __launch_bounds__(256) void k3_in_reduce(Dev d, u32 S, u32 fin) {
     const u32 N = (u32)d.ctr[C_N_NODES];
     // the out-statistics of the rows the row sort took block by block: the launch's LAST workgroup, and nothing else there (three
     // dependent round trips — in front of the reduction they were on the path of the threads that ran both)
-    if (blockIdx.x == gridDim.x - 1) { k2_split_finish(d, threadIdx.x, 256); return; }
-    const u32 GW = gridDim.x - 1;
+    // (an engine that keeps state: the last `fin` workgroups finish EVERY row behind kw_compact instead — degree, mean / deviation, hub work items)
+    if (blockIdx.x >= gridDim.x - fin) {
+        if (d.warm) kw_finish_rows(d, (blockIdx.x - (gridDim.x - fin)) * 256 + threadIdx.x, fin * 256);
+        else if (blockIdx.x == gridDim.x - 1) k2_split_finish(d, threadIdx.x, 256);
+        return;
+    }
+    const u32 GW = gridDim.x - fin;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < (u64)N * 6; i += (u64)GW * 256) {
         const u32 v = (u32)(i / 6), k = (u32)(i % 6), r = v / K3_IN_NR;
         const u64* p = d.in_part + ((size_t)r * S * K3_IN_NR + (v - r * K3_IN_NR)) * 6 + k;

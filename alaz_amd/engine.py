@@ -32,7 +32,7 @@ EXPORTS = [
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
-    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_timing_samples", "sg_latency_probe", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
+    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_timing_samples", "sg_latency_probe", "sg_set_warm", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
     "sg_clock_probe", "sg_comm_probe", "sg_window_halo_counts", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned", "sg_ingest_bulk",
 ]
 
@@ -46,7 +46,8 @@ class SgConfig(C.Structure):
 
 
 CFG_EDGE_HISTOGRAM = 1
-ABI_VERSION = 4
+CFG_NO_WARM = 2
+ABI_VERSION = 5
 
 
 def make_config(*, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 256, max_outbound_ips: int = 64,
@@ -59,7 +60,7 @@ def make_config(*, max_known_nodes: int, max_edges: int, layers: int = 1, max_la
 
 class SgGeometry(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("k1_variant", "k1_narrow", "partitions", "table_slots", "pass_a_workgroups", "cache_slots",
-                                          "join_l2_in_lds", "tile_records", "endpoint_bits", "piece_bytes", "pass_b_split", "pass_a_teams")]
+                                          "join_l2_in_lds", "tile_records", "endpoint_bits", "piece_bytes", "pass_b_split", "pass_a_teams", "warm_windows")]
 
 
 class SgStats(C.Structure):
@@ -69,7 +70,8 @@ class SgStats(C.Structure):
                 ("last_window_tmin_ms", C.c_int64), ("last_window_tmax_ms", C.c_int64), ("h2d_bytes", C.c_uint64),
                 ("events_misrouted", C.c_uint64), ("halo_overflow", C.c_uint64),
                 ("alive_in", C.c_uint64), ("alive_dropped", C.c_uint64),
-                ("join_word_updates", C.c_uint64), ("join_full_uploads", C.c_uint64), ("ingest_waits", C.c_uint64)]
+                ("join_word_updates", C.c_uint64), ("join_full_uploads", C.c_uint64), ("ingest_waits", C.c_uint64),
+                ("windows_warm", C.c_uint64), ("windows_cold", C.c_uint64)]
 
 
 class ServiceGraphError(RuntimeError):
@@ -132,6 +134,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_stats_get": (C.c_int, [H, C.POINTER(SgStats)]),
         "sg_timing_enable": (C.c_int, [H, C.c_int]), "sg_timing_reset": (C.c_int, [H]),
         "sg_timing_get": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "sg_set_warm": (C.c_int, [H, C.c_int]),
         "sg_timing_samples": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), sz, C.POINTER(sz)]),
         "sg_latency_probe": (C.c_int, [H, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
         "sg_debug_stamps": (C.c_int, [H, P, sz]),
@@ -192,12 +195,12 @@ class ServiceGraph:
     def __init__(self, *, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 1024,
                  max_outbound_ips: int = 1024, max_ips: int = 0, max_batch: int = 1 << 20, device: int = 0,
                  rank: int = 0, world: int = 1, k1_variant: int = 0, max_window_events: int = 0, windows_in_flight: int = 1,
-                 edge_histogram: bool = False):
+                 edge_histogram: bool = False, warm: bool = True):
         self._l = load_library()
         cfg = make_config(max_known_nodes=max_known_nodes, max_edges=max_edges, layers=layers, max_labels=max_labels,
                           max_outbound_ips=max_outbound_ips, max_ips=max_ips, max_batch=max_batch, device=device, rank=rank, world=world,
                           k1_variant=k1_variant, max_window_events=max_window_events, windows_in_flight=windows_in_flight,
-                          flags=CFG_EDGE_HISTOGRAM if edge_histogram else 0)
+                          flags=(CFG_EDGE_HISTOGRAM if edge_histogram else 0) | (0 if warm else CFG_NO_WARM))
         h = C.c_void_p()
         rc = self._l.sg_create(C.byref(cfg), C.byref(h))
         if rc != SG_OK:
@@ -409,6 +412,10 @@ class ServiceGraph:
         us, n = C.c_double(), C.c_uint64()
         self._ck(self._l.sg_timing_get(self._h, kernel, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def set_warm(self, on: bool = True):
+        """warm windows on / off at run time (off: every window is rebuilt from nothing; the rows are the same either way)"""
+        self._ck(self._l.sg_set_warm(self._h, 1 if on else 0))
 
     def timing_samples(self, kernel: int, cap: int = 4096) -> np.ndarray:
         """every record of a timing group since timing_reset(), microseconds, in launch order"""

@@ -486,7 +486,10 @@ def _bench_mode(a, rank: int, world: int, local: int, strong: bool, brief: bool)
     dt = time.perf_counter() - t0
     for g in engs:
         g.timing_enable(0)
-    k1a = np.mean([g.timing(1)[0] for g in engs]); k1b = np.mean([g.timing(7)[0] for g in engs]); k1n = sum(g.timing(1)[1] for g in engs)
+    # per window: all records of a group over the two engines / the timed windows (an engine that keeps warm-window state launches
+    # pass B twice per window — the warm attempt and the cold merge, one of which returns at once — and a window's pass B is their sum)
+    k1a = sum(g.timing(1)[0] * g.timing(1)[1] for g in engs) / max(1, a.steps); k1b = sum(g.timing(7)[0] * g.timing(7)[1] for g in engs) / max(1, a.steps)
+    k1n = sum(g.timing(1)[1] for g in engs)
     # untimed diagnostic pass: every kernel group and every collective bracketed by events (a few us each), per window of rank 0's engines
     nd = 0 if brief else min(10, a.steps)
     for g in engs:

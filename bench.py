@@ -310,6 +310,14 @@ def main():
         dist.destroy_process_group()
 
 
+def geo_warm(g) -> bool:
+    """does this engine carry the edge set from window to window (sg_geometry.warm_windows)"""
+    try:
+        return bool(g.geometry().get("warm_windows", 0))
+    except Exception:                                        # noqa: BLE001
+        return False
+
+
 def _engine_for(a, topo, labels, c, device, windows, engine, weights):
     L = c["layers"]
     big = a.config == 5
@@ -396,6 +404,13 @@ def bench_single(a, device):
     clk_after = g.clock_probe(200)                           # (spin right after the timed steps, pass A of exactly the timed steps)
     k1a, k1b = g.timing(1), g.timing(7)
     k1a_s, k1b_s = g.timing_samples(1), g.timing_samples(7)  # every launch of the timed steps, by the dispatch's own stamps
+    # an engine that keeps warm-window state launches pass B twice per window (the warm attempt, then the cold merge, which returns at
+    # once on a warm window): a window's pass B is the SUM of its launches
+    per_w = max(1, round(len(k1b_s) / max(1, a.steps)))
+    if per_w > 1 and len(k1b_s) == per_w * a.steps:
+        k1b_s = k1b_s.reshape(a.steps, per_w).sum(axis=1)
+        k1b = (float(k1b_s.mean()), a.steps)
+    st_timed = g.stats()
     # SURVEY 8(d) run protocol (median + min): a separate untimed pass — the event pair around every window costs a few microseconds, so it
     # stays out of the region `value` is taken from — of at least 100 windows (or the driver's --steps if that is more), one record each
     # from in front of the window's pass A to behind its score kernel
@@ -426,6 +441,28 @@ def bench_single(a, device):
             us, n = g.timing(k)
             grp[name] = us * n / nd                                 # per window (a group may have several records per window)
 
+    # the cold path beside the steady state: the same steps with the warm path switched off — every window rebuilt from nothing (what a
+    # window costs when its edge set is not among the kept one: first window, new edge, changed node numbering)
+    cold = None
+    if geo_warm(g) and not a.profile_mode:
+        g.set_warm(False)
+        for i in range(2):
+            step(i)
+        g.timing_reset(); g.timing_enable((1 << 1) | (1 << 7))
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + i)
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - tc0
+        g.timing_enable(0)
+        ca, cb = g.timing(1), g.timing(7)
+        cold = {"ms_per_step": dtc / a.steps * 1e3, "events_per_s": Ev * a.steps / dtc, "pass_a_us": ca[0], "pass_b_us": cb[0] * cb[1] / a.steps,
+                "what": "sg_set_warm(0): every window takes the full rebuild (pass B's cold merge, degree histogram, row scan, scatter, row sort, state capture)"}
+        g.set_warm(True)
+        for i in range(2):                                   # (back on the warm path for the passes below)
+            step(i)
+        torch.cuda.synchronize()
     # one untimed window with copy-out: how many edges / nodes a window of this workload has
     g.ingest_device(dev[0].data_ptr(), Ev, s)
     torch.cuda.synchronize()
@@ -489,6 +526,10 @@ def bench_single(a, device):
                                "pass_a_timed_steps": round(clk_after[1], 1), "pass_a_settle_and_warmup": round(clk_before[1], 1)},
         "settle": {"ms": a.settle_ms if not a.profile_mode else 0.0, "windows": settle_windows},
         "per_step": per_step, "box": box,
+        # `value` / ms_per_step are the STEADY STATE of a replay whose windows touch the same edges: every timed window is closed on the warm
+        # path (windows_warm_in_check_read says what the window read back at the end was); cold = the same steps with the warm path off
+        "warm_windows": {"engine_keeps_state": bool(geo_warm(g)), "cold": cold, "cold_ms_per_step": cold["ms_per_step"] if cold else None,
+                         "windows_read": {"warm": int(st.windows_warm), "cold": int(st.windows_cold)}},
         "value_basis": "mean over the timed steps (wall clock around K back-to-back windows, one window in flight); per_step holds median / min of single windows",
     }
     # diagnostic (never `value`): the same steps with several windows in flight inside one engine — the

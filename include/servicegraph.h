@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 4u   /* 4: sg_stats.ingest_waits, sg_geometry.pass_a_teams, sg_clock_probe;
+#define SG_ABI_VERSION 5u   /* 5: warm windows — sg_stats.windows_warm / windows_cold, SG_CFG_NO_WARM, sg_set_warm; sg_timing_samples,
+                               sg_latency_probe;
+                               4: sg_stats.ingest_waits, sg_geometry.pass_a_teams, sg_clock_probe;
                                3: sg_config begins with its own size (a binding compiled against an older, shorter sg_config is
                                detected instead of read past its end; members added later are zero for it), sg_geometry_get;
                                2: sg_edge_out carries p50_us / p99_us, sg_config.flags, sg_window_hist, sg_flush_window_view */
@@ -182,6 +184,12 @@ typedef struct sg_config {
                                       sg_window_hist).  Costs LDS in both K1 passes (smaller edge cache, half-size partitions) and
                                       64 bytes per edge of extra traffic: off by default.                                          */
 
+#define SG_CFG_NO_WARM 0x2u        /* never carry the edge set from one window to the next: every window is rebuilt from nothing (see
+                                      sg_set_warm).  By default an engine on the 8-byte-record path without the histogram keeps, from
+                                      the last window that was rebuilt, the edge set and its CSR order: a window whose edges are all
+                                      among the kept ones skips the degree count, the row scan, the scatter and the row sort.  The rows
+                                      of a window are the same either way, bit for bit.                                             */
+
 #define SG_MAX_LAYERS 4u
 #define SG_F_IN    32u   /* node feature width                                                  */
 #define SG_F_HID   64u   /* hidden width of every SAGE layer and of the score head               */
@@ -210,6 +218,8 @@ typedef struct sg_stats {
     uint64_t ingest_waits;         /* sg_ingest / sg_ingest_pinned calls that found a window boundary being marked (sg_flush_begin) and
                                       waited for it — bounded by the staging copies in flight; the reference's PersistRequest blocks on a
                                       full channel instead (datastore/backend.go:844), this is the only wait on the aggregator's thread */
+    uint64_t windows_warm;         /* of the windows READ so far (sg_flush_* / sg_window_read): closed on the warm path ...             */
+    uint64_t windows_cold;         /* ... by the full rebuild (always, for an engine that keeps no state: then both stay 0)            */
 } sg_stats;
 
 typedef struct sg_engine* sg_handle;
@@ -385,6 +395,7 @@ typedef struct sg_geometry {
     uint32_t piece_bytes;       /* record slab bytes per (partition, workgroup) piece                                        */
     uint32_t pass_b_split;      /* narrow: pass-B workgroups (sub-tables) per partition                                      */
     uint32_t pass_a_teams;      /* narrow: k1a_team_partition with 2 teams of eight waves per workgroup or 1 team of sixteen; 0 = k1a_tile_partition */
+    uint32_t warm_windows;      /* 1 = the engine carries the edge set and its CSR order from window to window (SG_CFG_NO_WARM)   */
 } sg_geometry;
 int sg_geometry_get(sg_handle h, sg_geometry* out);
 
@@ -393,10 +404,15 @@ int sg_geometry_get(sg_handle h, sg_geometry* out);
  * window bookkeeping, then row pointers + scatter + row sort), 8 = K3 in-statistics, 3 = K3 node + edge features, 4 = K4 (one
  * record per SAGE layer), 5 = K5, 6 = K6 halo kernels, 9 = the collectives of sg_window_run_sharded (one record per RCCL call) — by hipEvent
  * pairs around the launches.  sg_timing_get returns the
- * average duration in microseconds per record since sg_timing_reset(), and the number of records.                          */
+ * average duration in microseconds per record since sg_timing_reset(), and the number of records.  An engine that keeps warm-window
+ * state launches pass B twice per window (the warm attempt and the cold merge; one of them returns at once): group 7 then has two
+ * records per window and a window's pass B is their sum.                                                                    */
 int sg_timing_enable(sg_handle h, int on);   /* 0 = off, 1 = every group, else bitmask: bit k = group Kk */
 int sg_timing_reset(sg_handle h);
 int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
+/* Warm windows on / off at run time (on = 0: no window tries the warm path from now on, each is rebuilt and re-captured; on = 1: back
+ * to the default).  The rows never depend on it; bench.py uses it to time the cold path beside the steady state.                     */
+int sg_set_warm(sg_handle h, int on);
 /* Every record of a group since sg_timing_reset, in launch order: min(*n, cap) durations in microseconds go to us[], *n = how many
  * there are.  Group 10 (only when its bit is set explicitly or with on = 1) = one record per window of sg_window_run /
  * sg_window_run_sharded, from in front of the window's first pass-A launch to behind its score kernel.                      */

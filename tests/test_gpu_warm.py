@@ -1,0 +1,288 @@
+"""Warm windows (sg_device.h "warm windows"): the edge set and its CSR order carried from one window to the next.
+Whatever path a window takes — seeded pass B + one-pass compaction of the kept CSR, or the full rebuild — its rows must be the
+oracle's, and byte for byte the rows of an engine that rebuilds every window (SG_CFG_NO_WARM).  The reference keeps its tables
+across events too (aggregator/cluster.go:13-29, persist.go:55-71); what is carried here is the per-window edge ledger."""
+import numpy as np
+import pytest
+
+from alaz_amd import replay, weights
+from tests.helpers import CLOCK, HostShim, compare_edge_dicts, engine_edge_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(nodes, max_edges, layers, **kw):
+    from alaz_amd import engine
+    g = engine.ServiceGraph(max_known_nodes=nodes, max_edges=max_edges, layers=layers, max_labels=kw.pop("max_labels", 256),
+                            max_outbound_ips=kw.pop("max_outbound_ips", 512), **kw)
+    g.set_clock(*CLOCK)
+    g.load_weights(weights.make_weights(layers))
+    return g
+
+
+class Pair:
+    """a warm engine, an engine that rebuilds every window, and the oracle, fed the same windows"""
+    def __init__(self, topo, layers, max_edges, labels, **kw):
+        from oracle import pyoracle
+        self.layers, self.labels = layers, labels
+        self.warm = _engine(topo.n_nodes + 16, max_edges, layers, **kw)
+        self.cold = _engine(topo.n_nodes + 16, max_edges, layers, warm=False, **kw)
+        assert self.warm.geometry()["warm_windows"] == 1 and self.cold.geometry()["warm_windows"] == 0
+        self.shim = HostShim(); self.shim2 = HostShim()
+        self.o = pyoracle.Oracle(*CLOCK)
+        self.W = weights.make_weights(layers)
+        self.ops(topo.k8s_ops())
+        self.paths = []                                      # "warm" / "cold" per window, as sg_stats counted them
+
+    def ops(self, ops):
+        self.shim.apply(self.warm, ops); self.shim2.apply(self.cold, ops); self.o.apply_ops(ops)
+
+    def window(self, ev, chunk=1 << 16):
+        rows = []
+        before = self.warm.stats()
+        for g in (self.warm, self.cold):
+            for i in range(0, len(ev), chunk):
+                while g.ingest(ev[i:i + chunk]) != 0:
+                    pass
+            g.set_label_count(len(self.labels))
+            rows.append(g.flush_window().copy())
+        st = self.warm.stats()
+        self.paths.append("warm" if st.windows_warm > before.windows_warm else "cold")
+        assert (st.windows_warm - before.windows_warm) + (st.windows_cold - before.windows_cold) == 1
+        self.o.packed(ev, self.labels); self.o.window_close(self.W, self.layers)
+        compare_edge_dicts(engine_edge_dict(rows[0], self.shim, self.labels, self.warm.outbound_ips()), self.o.edge_dict())
+        assert st.last_window_events == self.o.window_events and st.last_window_edges == len(rows[0]) == len(self.o.edge_dict())
+        assert st.last_window_nodes == self.o.n_nodes
+        assert rows[0].tobytes() == rows[1].tobytes(), "the warm engine's rows differ from the rebuilding engine's"
+        orow = self.o.edge_rows()
+        assert np.array_equal(rows[0]["from_ref"], orow["from_ref"]) and np.array_equal(rows[0]["to_ref"], orow["to_ref"])
+        return rows[0]
+
+    def close(self):
+        self.warm.close(); self.cold.close()
+
+
+def _events_on(topo, edge_idx, n, seed):
+    sub = replay.Topology(topo.n_pods, topo.n_svcs, topo.pod_ips, topo.svc_ips, topo.edge_src[edge_idx], topo.edge_dst[edge_idx], topo.seed)
+    ev, _ = replay.make_events(sub, n, seed=seed, fixed_labels=True)
+    return ev
+
+
+def test_edge_appears_disappears_returns_first_window_cold():
+    """window 1 is cold (nothing kept); the same edges again: warm; a subset: warm (the untouched kept edges leave the window's CSR);
+    edges the kept set lacks: cold (rebuild + capture — the kept set becomes the UNION of the old one and the window's); that window
+    again: warm; back to the first set: warm too, the union covers it; an empty window and a window behind it: warm both."""
+    topo = replay.make_topology(300, 9000, seed=21)
+    labels = list(replay.EXTERNAL_HOSTS)
+    ev, _ = replay.make_events(topo, 300_000, seed=31, fixed_labels=True)
+    # every event of one (source, destination, label) triple lands in the same class: three classes, two overlapping sets of them.
+    # A window made of a SUBSET of another window's events can only touch a subset of its edges.
+    cls = ((ev["saddr"].astype(np.uint64) * 2654435761 + ev["daddr"].astype(np.uint64) * 40503 + ev["host_label"].astype(np.uint64)) >> np.uint64(7)) % np.uint64(3)
+    evA, evB = ev[cls != 0], ev[cls != 1]
+    evA2 = evA[::2].copy(); evA2["duration_ns"] += 1000      # half of A's events, other latencies: some of A's edges are not touched
+    evSub = evA[(evA["saddr"] % 8) == 1]
+    p = Pair(topo, 2, 1 << 15, labels)
+    r1 = p.window(evA)
+    r2 = p.window(evA)
+    assert r1.tobytes() == r2.tobytes()
+    p.window(evA2)                                           # same edge set drawn again with other events: mostly the same edges, some untouched -> compaction
+    r4 = p.window(evSub)
+    assert 0 < len(r4) < len(r1)
+    p.window(evA)                                            # the kept set still covers A
+    p.window(evB)                                            # edges outside A: rebuild
+    p.window(evB)
+    p.window(evA)                                            # A is not inside B, but inside what the engine has kept
+    p.window(evA[:0])                                        # an empty window
+    p.window(evA2)
+    assert p.paths == ["cold", "warm", "warm", "warm", "warm", "cold", "warm", "warm", "warm", "warm"], p.paths
+    p.close()
+
+
+def test_pod_gets_a_new_ip_between_windows_stays_warm_and_exact():
+    """the kept state names edges by node ids, not addresses: a pod that comes back under another IP (UPDATE) keeps its edges, a deleted
+    source's events are dropped (its kept edges are simply not touched), a new pod without traffic changes the node count (rebuild)."""
+    from alaz_amd import engine
+    topo = replay.make_topology(120, 2500, seed=41)
+    labels = list(replay.EXTERNAL_HOSTS)
+    ev = _events_on(topo, np.arange(len(topo.edge_src)), 60_000, 43)
+    p = Pair(topo, 1, 1 << 13, labels)
+    p.window(ev)
+    p.window(ev)
+    p.ops([("pod", "UPDATE", topo.pod_uid(3), "10.77.0.9")])                     # pod 3 answers under a second address
+    e2 = ev.copy()
+    m = e2["saddr"] == topo.pod_ips[3]
+    e2["saddr"][m] = engine.ip_u32("10.77.0.9")
+    p.window(e2)
+    # a pod that is a source but nobody's destination goes away (a deleted DESTINATION's address would become a raw outbound IP, whose
+    # node id is a rank among the window's own: such a window is rebuilt — the third test)
+    gone = int(np.setdiff1d(topo.edge_src, topo.edge_dst[topo.edge_dst < topo.n_pods])[0])
+    assert gone != 3
+    p.ops([("pod", "DELETE", topo.pod_uid(gone), replay.ip_str(int(topo.pod_ips[gone])))])
+    r = p.window(ev)                                                             # its requests are dropped: its kept edges stay untouched
+    assert p.warm.stats().events_dropped_src > 0
+    p.ops([("pod", "ADD", "a-new-pod", "10.77.0.10")])                           # N_KNOWN grows: the labels' dense ids move
+    p.window(ev)
+    p.window(ev)
+    assert p.paths == ["cold", "warm", "warm", "warm", "cold", "warm"], p.paths
+    p.close()
+
+
+def test_raw_outbound_ips_alive_connections_and_reversal_across_windows():
+    """mixed protocols with raw-IP destinations (their node ids are ranks among the window's own: such a window is rebuilt), reversed
+    direction, and SG_EV_ALIVE records (an edge a window only sees as an open connection exists there with count 0: touched without
+    counting) — every window against the oracle and the rebuilding engine, whatever path it took."""
+    topo = replay.make_topology(150, 3000, seed=51)
+    ev, labels = replay.make_events(topo, 80_000, seed=52, mixed=True, with_raw_outbound=True, with_reverse=True, fixed_labels=True)
+    labels = list(replay.EXTERNAL_HOSTS)
+    p = Pair(topo, 2, 1 << 14, labels)
+    p.window(ev[:40_000]); p.window(ev[:40_000]); p.window(ev[40_000:])
+    assert "warm" not in p.paths                             # raw outbound IPs in every window
+    # (any protocol without a Host header leaves an unknown destination as a raw IP: the windows below are HTTP, with the direction
+    # of some requests to KNOWN destinations reversed by hand — AMQP DELIVER, data.go:1110-1112)
+    noraw, _ = replay.make_events(topo, 60_000, seed=53, fixed_labels=True)
+    known = np.isin(noraw["daddr"], np.concatenate([topo.pod_ips, topo.svc_ips]))
+    rv = known & (np.arange(len(noraw)) % 37 == 0)
+    noraw["protocol"][rv] = replay.PROTO_AMQP; noraw["flags"][rv] |= replay.EV_REVERSE; noraw["status"][rv] = 1; noraw["host_label"][rv] = 0
+    p.window(noraw); p.window(noraw)
+    # (an alive record is never reversed and carries no Host header: taken from un-reversed requests to known destinations, it names
+    # an edge the window has; an open connection to an unknown address is a raw outbound IP)
+    alive = noraw[~rv & known][:3000].copy()
+    alive["flags"] |= np.uint8(replay.EV_ALIVE)
+    alive["duration_ns"] = 0
+    both = np.concatenate([noraw, alive])
+    p.window(both)
+    only_alive = np.concatenate([noraw[30_000:], alive])     # edges that only the alive records touch stay in the window with count 0
+    r = p.window(only_alive)
+    assert int((r["count"] == 0).sum()) > 0 and int(r["alive"].sum()) > 0
+    assert p.paths[3:] == ["cold", "warm", "warm", "warm"], p.paths
+    p.close()
+
+
+def test_hub_rows_and_a_large_graph_warm_equals_rebuild():
+    """rows of more than 512 and more than 1024 edges (block work items come from the warm finish, not from k2_rowptr), partitions merged by
+    two workgroups, the degree-histogram rebuild (capacity >= 2^19): three windows of a C3-shaped graph at a tenth of its size."""
+    topo = replay.make_topology(3000, 450_000, seed=61)
+    deg = np.bincount(topo.edge_src, minlength=topo.n_pods)
+    assert deg.max() > 1024
+    labels = list(replay.EXTERNAL_HOSTS)
+    ev1, _ = replay.make_events(topo, 2_000_000, seed=62, fixed_labels=True)
+    ev2, _ = replay.make_events(topo, 600_000, seed=63, fixed_labels=True)
+    p = Pair(topo, 2, 1 << 19, labels, max_window_events=2_000_001)
+    p.window(ev1, chunk=1 << 18); p.window(ev1, chunk=1 << 18)
+    r = p.window(ev2, chunk=1 << 18)                         # fewer events: a third of the kept edges untouched, hub rows shrink
+    assert p.paths[:2] == ["cold", "warm"]
+    assert len(r) < p.warm.stats().last_window_edges + 1
+    p.window(ev1, chunk=1 << 18)
+    p.close()
+
+
+def test_three_windows_in_flight_each_slot_keeps_its_own_state():
+    """sg_config.windows_in_flight = 3: every slot has its own kept state (its previous window was three windows ago).  Nine windows
+    enqueued three at a time on the three slots: slot k rebuilds on its first window, is warm on the same events again, and warm with a
+    third of them; all equal to the rows of a single-slot engine that rebuilds every window."""
+    import ctypes
+    import torch
+    topo = replay.make_topology(200, 5000, seed=71)
+    labels = list(replay.EXTERNAL_HOSTS)
+    evs = [replay.make_events(topo, 50_000, seed=80 + k, fixed_labels=True)[0] for k in range(3)]
+    wins = evs + evs + [e[::3].copy() for e in evs]
+    b = _engine(topo.n_nodes + 8, 1 << 14, 2, warm=False)
+    a = _engine(topo.n_nodes + 8, 1 << 14, 2, windows_in_flight=3)
+    for g in (a, b):
+        HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
+    want = []
+    for w in wins:
+        assert b.ingest(w) == 0
+        want.append(b.flush_window().copy())
+    hip = ctypes.CDLL(None); hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    dev = [torch.from_numpy(w.view(np.uint8).reshape(-1)).cuda() for w in wins]
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        ptrs = []
+        for k in range(3):
+            i = rnd * 3 + k
+            a.ingest_device(dev[i].data_ptr(), len(wins[i]), 0)
+            a.window_run(0)
+            ptrs.append(a.rows_buffer())
+        torch.cuda.synchronize()
+        assert len(set(ptrs)) == 3
+        for k in range(3):
+            i = rnd * 3 + k
+            n = len(want[i])
+            buf = np.zeros(n, dtype=replay.EDGE_OUT_DTYPE)
+            assert n and hip.hipMemcpy(buf.ctypes.data, ctypes.c_void_p(ptrs[k]), n * 64, 2) == 0
+            assert buf.tobytes() == want[i].tobytes(), i
+    # the synchronous API on the current slot (slot 0 again: its fourth window), and what path it took
+    assert a.ingest(wins[6]) == 0
+    assert a.flush_window().tobytes() == want[6].tobytes()
+    st = a.stats()
+    assert (st.windows_warm, st.windows_cold) == (1, 0)
+    a.close(); b.close()
+
+
+def test_set_warm_off_and_on_again_same_rows():
+    topo = replay.make_topology(100, 2000, seed=91)
+    ev, labels = replay.make_events(topo, 30_000, seed=92, fixed_labels=True)
+    g = _engine(topo.n_nodes + 8, 1 << 13, 1)
+    HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(replay.EXTERNAL_HOSTS))
+    rows = []
+    for k in range(6):
+        if k == 2: g.set_warm(False)
+        if k == 4: g.set_warm(True)
+        assert g.ingest(ev) == 0
+        rows.append(g.flush_window().copy())
+    assert all(r.tobytes() == rows[0].tobytes() for r in rows)
+    st = g.stats()
+    assert (st.windows_warm, st.windows_cold) == (3, 3)     # cold: the first, the two with the warm path off; the state they captured serves window 4 at once
+    g.close()
+
+
+def test_eight_logical_shards_warm_windows_equal_one_engine():
+    """the sharded window close takes the same two paths: eight logical shards of one graph on this device (exchanges through device memory),
+    three windows — rebuild, warm, warm with fewer edges — equal to the unsharded engine's rows bit for bit."""
+    import threading
+    import torch
+    from alaz_amd import engine, sharded
+    layers, world = 2, 8
+    topo = replay.make_topology(400, 12_000, seed=101)
+    labels = list(replay.EXTERNAL_HOSTS)
+    ev1, _ = replay.make_events(topo, 150_000, seed=102, fixed_labels=True)
+    ev2 = ev1[::4].copy(); ev2["duration_ns"] += 777         # a quarter of the first window's requests: a subset of its edges
+    W = weights.make_weights(layers)
+    one = _engine(topo.n_nodes + 8, 1 << 15, layers, warm=False, max_labels=128)
+    HostShim().apply(one, topo.k8s_ops()); one.set_label_count(len(labels))
+    shared = sharded.ThreadComm.Shared(world)
+    dev = torch.device("cuda", 0)
+    ncap = topo.n_nodes + 8 + 128 + 512
+    engs, bes = [], []
+    for r in range(world):
+        g = engine.ServiceGraph(max_known_nodes=topo.n_nodes + 8, max_edges=8192, layers=layers, max_labels=128, max_outbound_ips=512,
+                                rank=r, world=world, max_window_events=len(ev1))
+        assert g.geometry()["warm_windows"] == 1
+        g.set_clock(*CLOCK); g.load_weights(W); HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
+        engs.append(g)
+        bes.append(sharded.HipBackend(g, ncap=ncap, layers=layers, world=world, rank=r, device=dev, max_obip=512, stream=torch.cuda.Stream(dev)))
+    for w, ev in enumerate((ev1, ev1, ev2, ev1)):
+        assert one.ingest(ev) == 0
+        want = one.flush_window().copy()
+        shard = one.route(ev, world)
+        outs = [None] * world
+        for r in range(world):
+            assert engs[r].ingest(ev[shard == r]) == 0
+
+        def run(r):
+            sharded.run_window(bes[r], sharded.ThreadComm(shared, r))
+            outs[r] = engs[r].window_read().copy()
+            engs[r].window_reset(bes[r].s)
+        ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ths: t.start()
+        for t in ths: t.join(timeout=300)
+        assert all(o is not None for o in outs)
+        got = np.concatenate(outs)
+        key = lambda a: np.lexsort((a["to_ref"], a["from_ref"]))
+        assert len(got) == len(want) and got[key(got)].tobytes() == want[key(want)].tobytes(), w
+    st = [g.stats() for g in engs]
+    assert sum(x.events_dropped_cap + x.events_misrouted for x in st) == 0
+    assert all(x.windows_cold == 1 and x.windows_warm == 3 for x in st), [(x.windows_warm, x.windows_cold) for x in st]
+    for g in engs: g.close()
+    one.close()
