@@ -101,7 +101,16 @@ struct sg_engine {
     u32 cold_streak = 0;                      // consecutive windows the host has seen fall back to the full rebuild
     u64 warm_skip = 0;                        // windows left of a back-off (the warm attempt is not launched at all)
     u32 kw_epoch = 0;                         // kw_compact launch counter (tags its look-back words)
+    u64 closes = 0; u32 timing_stride = 1;    // windows closed so far; the dispatch stamps of K1 (groups 1 and 7) are taken on every timing_stride-th window
+    u32 obip_streak = 0; u64 plain_left = 0;  // windows read in a row that raw outbound IPs kept cold; windows still to be closed without the kept-CSR detour
+    std::vector<char> plain_slot;             // per window slot: its last close was such a plain one (not counted as warm or cold)
     std::vector<u64*> scr_sum, scr_max; std::vector<double*> scr_mu;   // per window slot: the node statistics the kept-CSR rebuild writes (scratch; row_mu | row_sd in one array)
+    // two-stream close (SG_WARM_AUX=1; measured and left OFF): the rebuild kernels — each returns at once on a warm window, but an empty
+    // launch still costs ~4.5 us, and there are five of them — on a second stream beside the warm window's compaction.  Same box, C3:
+    // 506 us per window with it, 490 without — the fork / join events and the two streams' kernels slowing each other cost more than
+    // the empty launches (profiles/r05_c_*)
+    bool warm_aux = false;
+    std::vector<hipStream_t> aux_stream; std::vector<hipEvent_t> ev_fork, ev_join;
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
@@ -323,7 +332,7 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
     if (e->d.variant == 0) {
         // single-kernel groups are timed by the dispatch's own begin/end stamps (hipExtLaunchKernel start/stop
         // events): the kernel's duration as rocprofv3 reports it, without the event-record round trip
-        const bool tk = (e->timing >> 1) & 1u;
+        const bool tk = ((e->timing >> 1) & 1u) && e->closes % e->timing_stride == 0;   // (the window this batch belongs to is the closes-th)
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         da.batch_state = e->window_events_in == 0 ? 1u : 0u;     // first batch of this window?
         const bool sh = e->d.world > 1;
@@ -426,11 +435,21 @@ void launch_halo_lists(sg_engine* e, hipStream_t s, u32* req, u32 capp) {
 int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union_n, u32 ob_mode = 1, u32 stride = 0, u32 gworld = 0) {
     int rc = sync_tables(e, s);
     if (rc) return rc;
-    const Dev& d = e->d;
+    // A stream whose every window carries raw outbound IPs (any protocol without a Host header talking to addresses outside the
+    // cluster: BASELINE config 5's Kafka / Postgres share) can never close warm — the ids of those nodes are ranks among the window's
+    // own — and would pay for the kept-CSR detour (rebuild into the kept arrays, then the compaction) every time.  Once the host has
+    // READ four such windows in a row it closes the next 64 as an engine without the state does (the kept state stays as it is: these
+    // windows do not touch it), then looks again.
+    Dev dloc = e->d;
+    if (dloc.warm && e->plain_left) { e->plain_left--; dloc.warm = 0; }
+    if ((size_t)e->cur < e->plain_slot.size()) e->plain_slot[e->cur] = e->d.warm && !dloc.warm;
+    const Dev& d = dloc;
     // warm windows: try unless switched off or backing off after a run of cold windows (the device decides whether the try holds)
     bool warm_try = d.warm && e->warm_on;
     if (warm_try && e->warm_skip) { e->warm_skip--; warm_try = false; }
     const u32 wt = warm_try ? 1u : 0u;
+    // the stream of the rebuild (pass B's cold merge, K2, kw_compact's cold case): a second one beside the warm path when this window tries it
+    hipStream_t sx = (d.warm && e->warm_aux && warm_try && !e->aux_stream.empty()) ? e->aux_stream[e->cur] : s;
     {
         Timed tp(e, s, 2);
         if (ob_mode == 1) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u, (const u32*)nullptr, 0u, 0u, wt);
@@ -438,22 +457,25 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         else hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 2u, d_union, stride, gworld, wt);
     }
     if (d.variant == 0) {                                    // group 7 = K1 pass B (k1b_merge), kernel-exact timing as for pass A
-        const bool tk = (e->timing >> 7) & 1u;
+        const bool tk = ((e->timing >> 7) & 1u) && e->closes % e->timing_stride == 0;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
         const bool share = d.npb > e->k1b_cus && 2 * e->k1b_lds <= kLdsBytes;   // several partitions per CU and room for two tables: the SGPR-capped build lets two workgroups share a CU
         // warm engines: the warm attempt (WM 1: seeded tables, accumulators straight to their kept positions; returns at once when
         // kc_prepare has already called the window cold), then the cold merge (WM 2: returns at once on a warm window).  Both are records
         // of group 7: a window's pass B is the SUM of its group-7 records.
-#define K1B8W_GOP(U_, SPT_, P_, WM_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
-                                     else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
+#define K1B8W_GOP(U_, SPT_, P_, WM_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, ks, ta, tb, 0u, db); \
+                                     else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, ks, ta, tb, 0u, db); } while (0)
 #define K1B8W_GO(SPT_, WM_) do { if (e->k1b_pack) K1B8W_GOP(4, SPT_, true, WM_); else K1B8W_GOP(4, SPT_, false, WM_); } while (0)
 #define K1B8W_GO2(WM_) do { const u32 spt = d.k1b_ht / e->k1b_threads; if (spt >= 4) K1B8W_GO(4, WM_); else if (spt == 2) K1B8W_GO(2, WM_); else K1B8W_GO(1, WM_); } while (0)
         if (d.warm) {
+            hipStream_t ks = s;
             if (warm_try) {
                 K1B8W_GO2(1);
                 if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); ta = get_event(e); tb = get_event(e); }
             }
+            if (sx != s) { HIP_TRY(e, hipEventRecord(e->ev_fork[e->cur], s)); HIP_TRY(e, hipStreamWaitEvent(sx, e->ev_fork[e->cur], 0)); }   // the rebuild starts behind the warm attempt
+            ks = sx;
             K1B8W_GO2(2);
         } else {
 #define K1B_GO(U_, H_) do { if (share) hipExtLaunchKernelGGL((k1b_merge<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
@@ -491,17 +513,26 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
             hipLaunchKernelGGL(k2_scan_tiles, dim3(1), dim3(1024), 0, s, d, ntiles);
             hipLaunchKernelGGL(k2_edge_compact, dim3(ntiles), dim3(256), 0, s, d);
         }
-        if (d.dh_g) hipLaunchKernelGGL(k2_deg_hist, dim3(d.dh_g), dim3(K2_DH_THREADS), ((size_t)d.ncap + 1) * sizeof(u32), s, dk);
-        if (d.dh_g) hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS_DH, true>), dim3(((size_t)d.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH), dim3(1024), 0, s, dk, ++e->rp_epoch);
-        else hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS, false>), dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, dk, ++e->rp_epoch);
+        if (d.dh_g) hipLaunchKernelGGL(k2_deg_hist, dim3(d.dh_g), dim3(K2_DH_THREADS), ((size_t)d.ncap + 1) * sizeof(u32), sx, dk);
+        if (d.dh_g) hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS_DH, true>), dim3(((size_t)d.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH), dim3(1024), 0, sx, dk, ++e->rp_epoch);
+        else hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS, false>), dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, sx, dk, ++e->rp_epoch);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
-        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, s, dk);
-        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 2 * (size_t)d.k2_sortw * sizeof(u32), s, dk);
+        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, sx, dk);
+        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 2 * (size_t)d.k2_sortw * sizeof(u32), sx, dk);
         if (d.warm) {
-            // behind a rebuild: the positions the next windows' pass B writes to (returns at once on a warm window); then, every window,
-            // the window's CSR out of the kept one
-            hipLaunchKernelGGL(kw_capture, dim3(grid_for(std::max<u64>((u64)d.ncap * SG_NODE_STAT_SUM_WORDS, (u64)d.npb * d.k1b_ht), 256 * 8, 1024)), dim3(256), 0, s, d, dk.st_sum, dk.st_max);
-            hipLaunchKernelGGL(kw_compact, dim3((unsigned)(((u64)d.npb * d.pcap + KW_CH - 1) / KW_CH)), dim3(KW_THREADS), (size_t)KW_ROWS * 5 * sizeof(u64), s, d, ++e->kw_epoch);
+            // the window's CSR out of the kept one — every window; behind a rebuild its first workgroups also take the positions the
+            // next windows' pass B writes to (kw_capture).  Two streams: the cold case at the end of the rebuild's stream, the warm
+            // case on the window's own at once, beside the rebuild's empty launches; the window goes on when both are through.
+            const unsigned kg = (unsigned)(((u64)d.npb * d.pcap + KW_CH - 1) / KW_CH) + KW_CAPW;
+            const size_t kl = (size_t)KW_ROWS * 5 * sizeof(u64);
+            if (sx != s) {
+                hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), kl, sx, d, ++e->kw_epoch, dk.st_sum, dk.st_max, 2u);
+                HIP_TRY(e, hipEventRecord(e->ev_join[e->cur], sx));
+                hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), kl, s, d, ++e->kw_epoch, dk.st_sum, dk.st_max, 1u);
+                HIP_TRY(e, hipStreamWaitEvent(s, e->ev_join[e->cur], 0));
+            } else {
+                hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), kl, s, d, ++e->kw_epoch, dk.st_sum, dk.st_max, 0u);
+            }
         }
     }
     {
@@ -513,6 +544,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
     HIP_TRY(e, hipGetLastError());
     e->closed = true;
     e->window_events_in = 0;
+    e->closes++;
     return SG_OK;
 }
 
@@ -604,9 +636,11 @@ void account_window(sg_engine* e) {
     st.halo_overflow += e->h_ctr[C_HALO_OVF];
     st.alive_in += e->h_ctr[C_ALIVE_SEEN];
     st.alive_dropped += e->h_ctr[C_ALIVE_DROPPED];
-    if (e->d.warm) {
+    if (e->d.warm && !((size_t)e->cur < e->plain_slot.size() && e->plain_slot[e->cur])) {
         // (counters of the slot that was read: with several windows in flight every slot keeps its own state and its own counts)
         const bool cold = e->h_ctr[C_COLD] != 0;
+        e->obip_streak = (e->h_ctr[C_COLD] == 1 && e->h_ctr[C_N_OBIP] != 0) ? e->obip_streak + 1 : 0;
+        if (e->obip_streak >= 4) { e->plain_left = 64; e->obip_streak = 0; }
         if (cold) st.windows_cold++; else st.windows_warm++;
         // a stream whose windows keep touching edges the kept set lacks pays for the warm attempt every time: after four cold windows
         // in a row the attempt is left out for eight windows (they rebuild and re-capture as before), then tried again
@@ -723,6 +757,12 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         const u64 cn = (u64)cfg->max_known_nodes + cfg->max_labels + e->obcap;
         u32 nb = 12; while ((1ull << nb) < cn && nb < 31) nb++;
         bool narrow = d.variant == 0 && !d.hist && cfg->k1_variant != 2 && !std::getenv("SG_K1_LEGACY") && nb <= 24;
+        // k1_variant 0 (auto) picks by the WINDOW, not only by what fits: the 8-byte path pays from a few million events or a quarter
+        // of a million edges per window up; below that (BASELINE config 2: 1 M events, 54 k edges) a window is a dozen launches of
+        // 5-30 us and the 16-byte kernels' shorter prologue and simpler pass B win — same box, C2: 130 us per window against 147-155
+        // (three rounds of tuning for config 3 had been paid for at config 2).  3 asks for the 8-byte path by name.
+        const bool small_window = ME < (1ull << 18) && e->cfg.max_window_events <= (2ull << 20);
+        if (cfg->k1_variant == 0 && small_window && !std::getenv("SG_K1_NARROW")) narrow = false;
         u64 np = 0;
         if (narrow) {
             // partitions: ~2700 distinct edges each at the configured capacity at most (pass B's LDS table: 4096 slots of 36
@@ -760,8 +800,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         if (!d.narrow) d.k1b_split = 1;
         // warm windows: the 8-byte-record path without the per-edge histogram (whose bins would have to follow the kept order too);
         // SG_CFG_NO_WARM / SG_WARM=0 keep every window on the full rebuild.  (k1b_u = 8, the one-table-per-CU build, has no warm instantiation.)
-        d.warm = (d.narrow && !d.hist && !(cfg->flags & SG_CFG_NO_WARM)) ? 1u : 0u;
-        if (const char* v = std::getenv("SG_WARM")) { if (std::atoi(v) == 0) d.warm = 0; }
+        // By default only where it pays: on a graph below a quarter of a million edges the rebuild's four kernels cost about what the
+        // compaction plus their four empty launches do (C2, same box: 147 us per window without, 155 with).  SG_CFG_WARM asks for it anyway.
+        d.warm = (d.narrow && !d.hist && !(cfg->flags & SG_CFG_NO_WARM) && ((cfg->flags & SG_CFG_WARM) || ME >= (1ull << 18))) ? 1u : 0u;
+        if (const char* v = std::getenv("SG_WARM")) { d.warm = (std::atoi(v) != 0 && d.narrow && !d.hist) ? 1u : 0u; }
         d.npb = d.np * d.k1b_split;
         d.nb = nb; d.rb = 2 * nb - d.pb;
         d.pcap = d.narrow ? d.k1b_ht * 13 / 16 : d.k1b_ht * 3 / 4;       // (u32 keys probe cheaply: the narrow tables may fill to 0.81)
@@ -880,6 +922,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // small graphs keep the degree atomics: their cost grows with the edges (1 M: 23 us of pass B), the histogram launch and the wider
         // row scan cost 6-7 us whatever the size — C2 (66 k-edge capacity), same box: window 128.5 / 130.2 us with it, 124.4 / 125.3 without
         if (ME < (1ull << 19)) g = 0;
+        // an engine that keeps warm-window state rebuilds rarely, and every launch of the rebuild chain is ~4.5 us of an EMPTY launch on a
+        // warm window: there the degree atomics (23-30 us more on a cold window at C3, no launch) are the better trade
+        if (d.warm) g = 0;
         if (const char* v = std::getenv("SG_DH_G")) { const u64 x = std::strtoull(v, nullptr, 0); g = (x >= 16 && x <= K2_DH_GMAX && (x & (x - 1)) == 0 && d.variant == 0 && x <= d.npb) ? (u32)x : 0u; }
         if (g >= 16 && (g & (g - 1)) == 0 && d.npb % g == 0 && ((size_t)d.ncap + 1) * sizeof(u32) <= 128u * 1024u && (u64)d.npb * d.pcap < (1ull << 32)) {
             d.dh_g = g; d.dh_ppw = d.npb / g; d.dh_ns = (d.ncap + 1 + 63u) & ~63u;
@@ -980,13 +1025,22 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     // further windows in flight: same tables and weights, own window buffers and stream
     {
         const u32 nw = std::min<u32>(std::max<u32>(cfg->windows_in_flight, 1), 8);
-        e->slots.resize(nw);
+        e->slots.resize(nw); e->plain_slot.assign(nw, 0);
         e->slots[0] = sg_engine::WinSlot{e->d, e->stream, e->d_ob_list, e->d_ob_n, false, 0};
         for (u32 k = 1; k < nw; k++) {
             sg_engine::WinSlot& w = e->slots[k];
             w.d = e->d; w.closed = false; w.events_in = 0; w.ob_list = nullptr; w.ob_n = nullptr; w.stream = nullptr;
             CH(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
             CR(alloc_window(w.d, w.ob_list, w.ob_n));
+        }
+        if (e->d.warm) {
+            if (const char* v = std::getenv("SG_WARM_AUX")) e->warm_aux = std::atoi(v) != 0;
+            for (u32 k = 0; k < nw && e->warm_aux; k++) {
+                hipStream_t a = nullptr; hipEvent_t f = nullptr, j = nullptr;
+                CH(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+                CH(hipEventCreateWithFlags(&f, hipEventDisableTiming)); CH(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+                e->aux_stream.push_back(a); e->ev_fork.push_back(f); e->ev_join.push_back(j);
+            }
         }
         CH(hipDeviceSynchronize());
     }
@@ -1000,6 +1054,9 @@ int sg_destroy(sg_handle e) {
     if (!e) return SG_EINVAL;
     hipDeviceSynchronize();
     for (size_t k = 0; k < e->slots.size(); k++) if ((int)k != e->cur && e->slots[k].stream) hipStreamDestroy(e->slots[k].stream);
+    for (hipStream_t a : e->aux_stream) hipStreamDestroy(a);
+    for (hipEvent_t v : e->ev_fork) hipEventDestroy(v);
+    for (hipEvent_t v : e->ev_join) hipEventDestroy(v);
     for (void* p : e->allocs) hipFree(p);
     if (e->h_blob) hipHostFree(e->h_blob);
     for (int i = 0; i < kUpdSlots; i++) { if (e->h_upd[i]) hipHostFree(e->h_upd[i]); if (e->upd_ev[i]) hipEventDestroy(e->upd_ev[i]); }
@@ -1671,6 +1728,15 @@ int sg_timing_enable(sg_handle e, int on) {
     e->timing = on == 0 ? 0u : (on == 1 ? ~0u : (unsigned)on);
     return SG_OK;
 }
+// The dispatch stamps of groups 1 and 7 cost a few microseconds per launch (the runtime brackets the kernel with its own signal packets):
+// with stride n they are taken on every n-th window only — the averages are still over launches of the timed region, which they then
+// disturb n times less (bench.py: 3).
+int sg_timing_stride(sg_handle e, uint32_t n) {
+    if (!e || n == 0) return SG_EINVAL;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->timing_stride = n;
+    return SG_OK;
+}
 int sg_timing_reset(sg_handle e) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
@@ -1720,7 +1786,7 @@ int sg_timing_get(sg_handle e, int kernel, double* avg_us, uint64_t* launches) {
 int sg_set_warm(sg_handle e, int on) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    e->warm_on = on != 0; e->warm_skip = 0; e->cold_streak = 0;
+    e->warm_on = on != 0; e->warm_skip = 0; e->cold_streak = 0; e->plain_left = 0; e->obip_streak = 0;
     return SG_OK;
 }
 // every record of one group since sg_timing_reset, in launch order (bench.py: median and minimum, SURVEY 8(d) run protocol)
@@ -1752,8 +1818,9 @@ int sg_latency_probe(sg_handle e, uint64_t bytes, uint32_t steps, int warm, doub
     HIP_TRY(e, hipMalloc((void**)&buf, lines * 128));
     if (hipMalloc((void**)&out, 2 * sizeof(u64)) != hipSuccess) { hipFree(buf); e->err = "sg_latency_probe: hipMalloc"; return SG_ENOMEM; }
     hipLaunchKernelGGL(k_chase_init, dim3((unsigned)std::min<u64>((lines + 255) / 256, 65535)), dim3(256), 0, e->stream, buf, (u32)(lines - 1));
-    if (warm) hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, e->stream, (const u32*)buf, (u32)lines, out);   // one whole round: every line is in the cache level it fits
-    hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, e->stream, (const u32*)buf, steps, out);
+    if (warm & 1) hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, e->stream, (const u32*)buf, (u32)lines, out);   // one whole round: every line is in the cache level it fits
+    if (warm & 2) hipLaunchKernelGGL(k_chase, dim3(1024), dim3(64), 0, e->stream, (const u32*)buf, steps, out);    // 65 536 chains in flight: the latency under load
+    else hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, e->stream, (const u32*)buf, steps, out);
     u64 h[2] = {};
     hipError_t r = hipStreamSynchronize(e->stream);
     if (r == hipSuccess) r = hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);

@@ -1159,6 +1159,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
             d.rowptr[N] = (u64)E < d.max_edges ? E : (u32)d.max_edges;
             d.ctr[C_N_EDGES] = (u64)E < d.max_edges ? E : d.max_edges;
             if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = E; if ((u64)E > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)E - d.max_edges; }
+            if (d.warm) d.ctr[C_KEPT_E] = (u64)E < d.max_edges ? E : d.max_edges;   // (this launch rebuilt the KEPT CSR: kw_compact, next, walks that many positions)
         }
     }
 }
@@ -1260,13 +1261,20 @@ __global__ __launch_bounds__(256) void k_clock_spin(u64* clk, u32 iters) {
 #define SG_CHASE_C 0x7F4A7C15u
 __global__ __launch_bounds__(256) void k_chase_init(u32* buf, u32 mask) {
     for (u64 x = (u64)blockIdx.x * 256 + threadIdx.x; x <= mask; x += (u64)gridDim.x * 256) buf[x * 32] = ((u32)x * SG_CHASE_A + SG_CHASE_C) & mask;
+    if (blockIdx.x == 0 && threadIdx.x == 0) buf[1] = mask;          // (word 1 of line 0: the walk's mask, for the many-chain launch's starting points)
 }
+__device__ __forceinline__ u32 out_mask(const u32* buf) { return buf[1]; }
 __global__ void k_chase(const u32* buf, u32 steps, u64* out) {
-    u32 x = 0;
+    // one chain per LANE: a launch of 1 x 1 measures the unloaded latency; 1024 x 64 lanes keep 65 536 dependent chains in flight (every
+    // lane starts somewhere else on the same full-period walk) — the latency of a random 128-byte line while the memory system is busy,
+    // which is where the boxes of the pool differ
+    const u32 mask_start = (blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B1u;
+    u32 x = (gridDim.x * blockDim.x) == 1 ? 0u : (mask_start & out_mask(buf));
     const u64 t0 = wall_clock64();
     for (u32 i = 0; i < steps; i++) x = __builtin_nontemporal_load(buf + (size_t)x * 32);   // (each address comes out of the load before it)
     const u64 t1 = wall_clock64();
-    out[0] = t1 - t0; out[1] = x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = t1 - t0;
+    if (x == 0xFFFFFFFFu) out[1] = x;                                // (keeps the chain)
 }
 __global__ void k_l1p_table(float* tab) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < SG_L1P_TAB) tab[i] = (float)log1p((double)i); }
 __device__ __forceinline__ float log1p_count(const Dev& d, u64 c) { return c < SG_L1P_TAB ? d.l1p_tab[c] : (float)log1p((double)c); }
@@ -1758,19 +1766,20 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 }
 
 // ---- warm windows (sg_device.h): capture behind a full rebuild, one-pass window CSR on a warm window --------------------------------
-// kw_capture, behind the rebuild of a COLD close.  On an engine that keeps state the rebuild (k2_deg_hist .. k2_rowsort_gather) runs on a
+// kw_capture, behind the rebuild of a COLD close (the first KW_CAPW workgroups of the kw_compact launch).  On an engine that keeps state the rebuild (k2_deg_hist .. k2_rowsort_gather) runs on a
 // Dev whose CSR pointers are the KEPT arrays: it has just built the kept CSR — every key pass B's cold merge left in its tables, the
 // window's own and the ones carried over from the old image — with each edge's accumulators (bit 63 of the max word = touched in this
 // window).  Here every slot of the table image gets the kept position of its edge (image index -> partition-output index -> the
 // position the row sort reported) and the state is declared whole, unless the window holds raw outbound IPs (their compact indices
 // are slots of this window's own outbound-IP table, their node ids ranks among this window's own).  The scratch node statistics the
 // rebuild wrote (it reduces every row it sorts; the window's real ones come from kw_compact) are zeroed for the next rebuild.
-__global__ __launch_bounds__(256) void kw_capture(Dev d, u64* scratch_sum, u64* scratch_max) {
+#define KW_CAPW 48                                                   // workgroups of the kw_compact launch that do this instead of a chunk (nothing in a chunk's work depends on it)
+__device__ __forceinline__ void kw_capture(const Dev& d, u64* scratch_sum, u64* scratch_max, u32 wg, u32 nwg, u32 nthreads) {
     if (!d.ctr[C_COLD]) return;                                      // (uniform) a warm window changes nothing
-    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
+    const u64 tid = (u64)wg * nthreads + threadIdx.x, nt = (u64)nwg * nthreads;
     const bool whole = d.ctr[C_N_OBIP] == 0;
     if (tid == 0) {
-        d.ctr[C_KEPT_VALID] = whole ? 1ull : 0ull; d.ctr[C_KEPT_E] = d.ctr[C_N_EDGES];   // (k2_rowptr's count on the kept arrays)
+        d.ctr[C_KEPT_VALID] = whole ? 1ull : 0ull;                   // (C_KEPT_E: k2_rowptr's count on the kept arrays)
         d.ctr[C_KEPT_NK] = d.ctr[C_N_KNOWN]; d.ctr[C_KEPT_NL] = d.ctr[C_N_LABELS];
         d.ctr[C_COLD_WINDOWS] += 1;
     }
@@ -1794,26 +1803,45 @@ __global__ __launch_bounds__(256) void kw_capture(Dev d, u64* scratch_sum, u64* 
 // stores for the rows that lie wholly inside the chunk, with device atomics for the at most two that cross its ends (and for rows
 // beyond the LDS arrays' reach in graphs of very short rows); k3_in_reduce turns the sums into degree, mean and deviation and lists
 // the hub rows' blocks.
-#define KW_THREADS 1024
+// Geometry (measured, C3, phase stamps: a chunk's workgroup lives ~12 us whatever its size — loads 3.7, scan + look-back 2.1, stores +
+// folds 3.3, row pointers 2.1 — so the launch costs one such life per ROUND of workgroups): 512 threads x 4 positions = 2048 per
+// chunk, 20 KiB of LDS, three workgroups per CU — C3's 565 working chunks are resident at once (1024 threads x 2048 positions:
+// two per CU, 53 chunks in a second round, 40 us; 1024 x 4096 with 60 KiB: one per CU, 44 us).
+#define KW_THREADS 512
+#define KW_NW (KW_THREADS / 64)
 #define KW_Q 4
 #define KW_CH (KW_THREADS * KW_Q)
-#define KW_ROWS 1536                                                 // rows per chunk with LDS accumulators (5 x u64 each: 60 KiB)
-__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch) {
+#define KW_ROWS 512                                                  // rows per chunk with LDS accumulators (5 x u64 each: 20 KiB)
+#define KW_RESIDENT (3 * SG_LB_RESIDENT)                             // working chunks that are certainly resident together (<= 80 VGPRs, 21 KiB of LDS)
+// `only`: 0 = every window; 1 = only a warm window, 2 = only a cold one (the two launches of the two-stream close: the warm window's
+// compaction runs beside the empty rebuild kernels, the cold window's behind the rebuild).
+__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* scratch_sum, u64* scratch_max, u32 only) {
     extern __shared__ u64 kw_racc[];                                 // [KW_ROWS][5]: cnt, err, sum, ssq, max
-    __shared__ u64 bal[KW_Q][16];
-    __shared__ u32 wpre[KW_Q][16];
+    __shared__ u64 bal[KW_Q][KW_NW];
+    __shared__ u32 wpre[KW_Q][KW_NW];
     __shared__ u32 qpre[KW_Q + 1];
     __shared__ u32 pre, bdyn;
+    {
+        const bool cold = d.ctr[C_COLD] != 0;
+        if ((only == 1 && cold) || (only == 2 && !cold)) return;     // (uniform)
+    }
+    if (blockIdx.x < KW_CAPW) { kw_capture(d, scratch_sum, scratch_max, blockIdx.x, KW_CAPW, KW_THREADS); return; }
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u32 KE = (u32)d.ctr[C_KEPT_E], N = (u32)d.ctr[C_N_NODES];
     const u32 nchunk = KE ? (KE + KW_CH - 1) / KW_CH : 1u;
-    u32 b = blockIdx.x;
-    if (gridDim.x > SG_LB_RESIDENT) {                                // (uniform) see k2_rowptr
-        if (t == 0) { const u32 tk = atomicAdd(&d.lb_ticket[1], 1u); if (tk == gridDim.x - 1) atomicExch(&d.lb_ticket[1], 0u); bdyn = tk; }
+    const u32 G = gridDim.x - KW_CAPW;                               // chunk workgroups of the launch
+    u32 b = blockIdx.x - KW_CAPW;
+    // Order by ticket (see k2_rowptr) only when the chunks that DO something cannot all be resident at once — three workgroups per CU.
+    // The grid is sized for the kept arrays' capacity; the chunks behind the last kept edge
+    // return at once and free their place, so up to KW_RESIDENT working chunks never wait for one that cannot start,
+    // whatever the dispatch order.  (586 same-address ticket draws were ~7 us at the head of every launch.)
+    if (nchunk > KW_RESIDENT) {                                      // (uniform: every workgroup reads the same count)
+        if (t == 0) { const u32 tk = atomicAdd(&d.lb_ticket[1], 1u); if (tk == G - 1) atomicExch(&d.lb_ticket[1], 0u); bdyn = tk; }
         __syncthreads();
         b = bdyn;
     }
     if (b >= nchunk) return;                                         // (nobody waits for a chunk behind its own)
+    SG_STAMP(d, 2, 0);
     if (b == 0 && t == 0) {
         d.ctr[C_OVF_N] = 0;                                          // pass B has consumed the overflow list
         d.ctr[C_ACT_L] = SG_ACT_NONE; d.ctr[C_ACT_P] = 0;
@@ -1844,7 +1872,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch) {
         if (lane == 0) { bal[q][wave] = m; wpre[q][wave] = (u32)__popcll(m); }
     }
     __syncthreads();
-    if (t < KW_Q) { u32 acc = 0; for (u32 w2 = 0; w2 < 16; w2++) { const u32 c = wpre[t][w2]; wpre[t][w2] = acc; acc += c; } qpre[t + 1] = acc; }
+    SG_STAMP(d, 2, 1);
+    if (t < KW_Q) { u32 acc = 0; for (u32 w2 = 0; w2 < KW_NW; w2++) { const u32 c = wpre[t][w2]; wpre[t][w2] = acc; acc += c; } qpre[t + 1] = acc; }
     __syncthreads();
     if (t == 0) {
         u32 run = 0;
@@ -1864,8 +1893,17 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch) {
         if (b) { mine = wave_sum_u32(mine); if (lane == 0 && mine) atomicAdd(&pre, mine); }
     }
     __syncthreads();
+    SG_STAMP(d, 2, 2);
     const u32 base = pre, total = qpre[KW_Q];
     const u64 lt = (1ull << lane) - 1ull;
+    // (row statistics: 64 lanes adding to the same five LDS words serialise in the LDS unit — a wave whose positions all lie in one row
+    // sums in registers first and sends one set of atomics)
+    bool wsame[KW_Q];
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) {
+        const u32 f0 = rdlane32(fr[q], 0);
+        wsame[q] = __ballot(fr[q] == f0 ? 1 : 0) == ~0ull && f0 - v0 < KW_ROWS;
+    }
     const u32 ME = (u32)d.max_edges;                                 // (the kept arrays hold npb x pcap edges; a WINDOW's rows stop at the configured capacity: cut and counted, as k2_rowptr does)
 #pragma unroll
     for (int q = 0; q < KW_Q; q++) if (tc[q]) {
@@ -1877,7 +1915,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch) {
         o[0] = x[q]; o[1] = make_ulonglong2(mx, y[q].y);
         const u64 cnt = x[q].x & 0xFFFFFFFFull, err = x[q].x >> 32;
         const u32 r = fr[q] - v0;
-        if (r < KW_ROWS) {
+        if (r < KW_ROWS && wsame[q]) {                               // the wave's 64 positions lie in ONE row (hub rows: half of C3's edges): reduced in the wave below
+        } else if (r < KW_ROWS) {
             u64* a = kw_racc + (size_t)r * 5;
             if (cnt) atomicAdd(&a[0], cnt);
             if (err) atomicAdd(&a[1], err);
@@ -1893,6 +1932,21 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch) {
             if (mx) atomicMax(&d.st_max[(size_t)fr[q] * 2], mx);
         }
     }
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) if (wsame[q]) {                   // (uniform per wave)
+        const bool in = tc[q] && base + qpre[q] + wpre[q][wave] + (u32)__popcll(bal[q][wave] & lt) < ME;
+        const u64 cnt = wave_sum_u64(in ? x[q].x & 0xFFFFFFFFull : 0ull), err = wave_sum_u64(in ? x[q].x >> 32 : 0ull);
+        const u64 sum = wave_sum_u64(in ? x[q].y : 0ull), ssq = wave_sum_u64(in ? y[q].y : 0ull), mx = wave_max_u64(in ? y[q].x & ~(1ull << 63) : 0ull);
+        if (lane == 0) {
+            u64* a = kw_racc + (size_t)(rdlane32(fr[q], 0) - v0) * 5;
+            if (cnt) atomicAdd(&a[0], cnt);
+            if (err) atomicAdd(&a[1], err);
+            if (sum) atomicAdd(&a[2], sum);
+            if (ssq) atomicAdd(&a[3], ssq);
+            if (mx) atomicMax(&a[4], mx);
+        }
+    }
+    SG_STAMP(d, 2, 3);
     // new row pointers of the rows that start in this chunk: rank of the row's first kept position among the chunk's touched ones
     for (u32 v = v_lo + t; v <= v_hi; v += KW_THREADS) {
         const u32 xl = d.k_rowptr[v] - p0, q = xl / KW_THREADS, tt = xl % KW_THREADS, w2 = tt >> 6, l2 = tt & 63u;
@@ -1905,6 +1959,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch) {
         if (t == 0) { d.ctr[C_N_EDGES] = E; d.ctr[C_EDGES_FOUND] = Ef; if (Ef > ME) d.ctr[C_DROPPED_CAP] += (u64)(Ef - ME); }
     }
     __syncthreads();                                                 // every LDS fold is in
+    SG_STAMP(d, 2, 4);
     {
         const u32 nr = v_hi - v0 + 1 < KW_ROWS ? v_hi - v0 + 1 : KW_ROWS;
         for (u32 r = t; r < nr; r += KW_THREADS) {
@@ -1924,6 +1979,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch) {
             }
         }
     }
+    SG_STAMP(d, 2, 5);
 }
 // behind kw_compact (run by extra workgroups of k3_in_reduce on a warm window): a thread per node — out-degree from the new row pointers,
 // mean / deviation of the row's out-events from its sums (the row sort's own expressions), the hub rows' block work items

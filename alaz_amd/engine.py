@@ -32,7 +32,7 @@ EXPORTS = [
     "sg_window_read", "sg_window_reset", "sg_window_buffers", "sg_window_feat_buffer",
     "sg_halo_build", "sg_halo_pack", "sg_halo_unpack", "sg_window_close_gathered", "sg_halo_build_padded",
     "sg_halo_pack_padded", "sg_halo_unpack_padded", "sg_window_outbound_ips", "sg_stats_get",
-    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_timing_samples", "sg_latency_probe", "sg_set_warm", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
+    "sg_timing_enable", "sg_timing_reset", "sg_timing_get", "sg_timing_samples", "sg_timing_stride", "sg_latency_probe", "sg_set_warm", "sg_debug_stamps", "sg_route", "sg_window_hist", "sg_geometry_get",
     "sg_clock_probe", "sg_comm_probe", "sg_window_halo_counts", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy", "sg_window_run_sharded", "sg_host_register", "sg_host_unregister", "sg_ingest_pinned", "sg_ingest_bulk",
 ]
 
@@ -47,6 +47,7 @@ class SgConfig(C.Structure):
 
 CFG_EDGE_HISTOGRAM = 1
 CFG_NO_WARM = 2
+CFG_WARM = 4
 ABI_VERSION = 5
 
 
@@ -134,7 +135,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "sg_stats_get": (C.c_int, [H, C.POINTER(SgStats)]),
         "sg_timing_enable": (C.c_int, [H, C.c_int]), "sg_timing_reset": (C.c_int, [H]),
         "sg_timing_get": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
-        "sg_set_warm": (C.c_int, [H, C.c_int]),
+        "sg_set_warm": (C.c_int, [H, C.c_int]), "sg_timing_stride": (C.c_int, [H, C.c_uint32]),
         "sg_timing_samples": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), sz, C.POINTER(sz)]),
         "sg_latency_probe": (C.c_int, [H, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
         "sg_debug_stamps": (C.c_int, [H, P, sz]),
@@ -195,12 +196,12 @@ class ServiceGraph:
     def __init__(self, *, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 1024,
                  max_outbound_ips: int = 1024, max_ips: int = 0, max_batch: int = 1 << 20, device: int = 0,
                  rank: int = 0, world: int = 1, k1_variant: int = 0, max_window_events: int = 0, windows_in_flight: int = 1,
-                 edge_histogram: bool = False, warm: bool = True):
+                 edge_histogram: bool = False, warm: Optional[bool] = None):
         self._l = load_library()
         cfg = make_config(max_known_nodes=max_known_nodes, max_edges=max_edges, layers=layers, max_labels=max_labels,
                           max_outbound_ips=max_outbound_ips, max_ips=max_ips, max_batch=max_batch, device=device, rank=rank, world=world,
                           k1_variant=k1_variant, max_window_events=max_window_events, windows_in_flight=windows_in_flight,
-                          flags=(CFG_EDGE_HISTOGRAM if edge_histogram else 0) | (0 if warm else CFG_NO_WARM))
+                          flags=(CFG_EDGE_HISTOGRAM if edge_histogram else 0) | (0 if warm is None else (CFG_WARM if warm else CFG_NO_WARM)))   # warm: None = the engine's own rule
         h = C.c_void_p()
         rc = self._l.sg_create(C.byref(cfg), C.byref(h))
         if rc != SG_OK:
@@ -407,6 +408,7 @@ class ServiceGraph:
 
     def timing_enable(self, mask: int = 1): self._ck(self._l.sg_timing_enable(self._h, int(mask)))
     def timing_reset(self): self._ck(self._l.sg_timing_reset(self._h))
+    def timing_stride(self, n: int): self._ck(self._l.sg_timing_stride(self._h, int(n)))
 
     def timing(self, kernel: int) -> Tuple[float, int]:
         us, n = C.c_double(), C.c_uint64()
@@ -423,10 +425,11 @@ class ServiceGraph:
         self._ck(self._l.sg_timing_samples(self._h, kernel, out.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(n)))
         return out[: min(cap, n.value)]
 
-    def latency_probe(self, nbytes: int, steps: int, warm: bool = False) -> float:
-        """ns per dependent load through `nbytes` of device memory (HBM: far beyond the Infinity Cache, cold; L2: 2 MiB, warm)"""
+    def latency_probe(self, nbytes: int, steps: int, warm: bool = False, loaded: bool = False) -> float:
+        """ns per dependent load through `nbytes` of device memory (HBM: far beyond the Infinity Cache, cold; L2: 2 MiB, warm);
+        loaded: 65 536 chains in flight at once, one of them timed"""
         ns = C.c_double()
-        self._ck(self._l.sg_latency_probe(self._h, int(nbytes), int(steps), 1 if warm else 0, C.byref(ns)))
+        self._ck(self._l.sg_latency_probe(self._h, int(nbytes), int(steps), (1 if warm else 0) | (2 if loaded else 0), C.byref(ns)))
         return ns.value
 
     def clock_probe(self, spin_us: int = 200) -> Tuple[float, float]:

@@ -166,10 +166,12 @@ typedef struct sg_config {
     uint32_t rank;              /* this shard                                                   */
     uint32_t world;             /* number of shards (1 = unsharded)                             */
     uint32_t k1_variant;        /* 0 = auto: partitioned LDS aggregation when the graph fits it — 8-byte records sorted by
-                                       partition in LDS before they are written; with SG_CFG_EDGE_HISTOGRAM or a node space
-                                       beyond 2^24 the 16-byte-record form of 2,
+                                       partition in LDS before they are written, from max_edges >= 2^18 or max_window_events
+                                       > 2^21 up; the 16-byte-record form of 2 for smaller windows, with SG_CFG_EDGE_HISTOGRAM
+                                       and for node spaces beyond 2^24,
                                    1 = global edge table + device-scope atomics (any size),
-                                   2 = partitioned aggregation with 16-byte records (the round-2 kernels)      */
+                                   2 = partitioned aggregation with 16-byte records (the round-2 kernels),
+                                   3 = as 0, but the 8-byte form whatever the window's size (where the graph fits it)  */
     uint64_t max_window_events; /* most events one window may carry (sizes the K1 record slabs;
                                    0 = max_batch)                                               */
     uint32_t windows_in_flight; /* 1..8 window slots, each with its own buffers and HIP stream:
@@ -185,10 +187,11 @@ typedef struct sg_config {
                                       64 bytes per edge of extra traffic: off by default.                                          */
 
 #define SG_CFG_NO_WARM 0x2u        /* never carry the edge set from one window to the next: every window is rebuilt from nothing (see
-                                      sg_set_warm).  By default an engine on the 8-byte-record path without the histogram keeps, from
-                                      the last window that was rebuilt, the edge set and its CSR order: a window whose edges are all
-                                      among the kept ones skips the degree count, the row scan, the scatter and the row sort.  The rows
-                                      of a window are the same either way, bit for bit.                                             */
+                                      sg_set_warm).  By default an engine on the 8-byte-record path without the histogram and with
+                                      max_edges >= 2^18 keeps the union of the edges its windows have touched, in CSR order: a
+                                      window whose edges are all among the kept ones skips the degree count, the row scan, the
+                                      scatter and the row sort.  The rows of a window are the same either way, bit for bit.         */
+#define SG_CFG_WARM    0x4u        /* keep that state below 2^18 edges too (where it does not pay: for tests)                       */
 
 #define SG_MAX_LAYERS 4u
 #define SG_F_IN    32u   /* node feature width                                                  */
@@ -409,6 +412,7 @@ int sg_geometry_get(sg_handle h, sg_geometry* out);
  * records per window and a window's pass B is their sum.                                                                    */
 int sg_timing_enable(sg_handle h, int on);   /* 0 = off, 1 = every group, else bitmask: bit k = group Kk */
 int sg_timing_reset(sg_handle h);
+int sg_timing_stride(sg_handle h, uint32_t n);   /* groups 1 and 7 (dispatch stamps, a few us per launch): on every n-th window only; 1 = every window */
 int sg_timing_get(sg_handle h, int kernel, double* avg_us, uint64_t* launches);
 /* Warm windows on / off at run time (on = 0: no window tries the warm path from now on, each is rebuilt and re-captured; on = 1: back
  * to the default).  The rows never depend on it; bench.py uses it to time the cold path beside the steady state.                     */
@@ -418,9 +422,10 @@ int sg_set_warm(sg_handle h, int on);
  * sg_window_run_sharded, from in front of the window's first pass-A launch to behind its score kernel.                      */
 int sg_timing_samples(sg_handle h, int kernel, double* us, size_t cap, size_t* n);
 /* Memory latency of this box: one lane follows `steps` dependent loads (one 128-byte line each, an odd-multiplier walk over all
- * lines) through `bytes` of device memory it allocates for the call; *ns_per_load by the 100 MHz reference clock.  warm != 0
+ * lines) through `bytes` of device memory it allocates for the call; *ns_per_load by the 100 MHz reference clock.  warm & 1
  * walks every line once before the clock starts (a 2 MiB buffer then measures the L2, a buffer far beyond the 256 MiB Infinity
- * Cache without it measures HBM).  Diagnostic for bench.py ("which kind of box did this line come from"); device-syncs.       */
+ * Cache without it measures HBM); warm & 2: 65 536 lanes follow a chain each at the same time and one of them is timed — the
+ * latency of a random line under load.  Diagnostic for bench.py ("which kind of box did this line come from"); device-syncs.  */
 int sg_latency_probe(sg_handle h, uint64_t bytes, uint32_t steps, int warm, double* ns_per_load);
 /* The shader clock the chip sustains, in MHz (shader cycles per 100 MHz reference tick x 100): *spin_mhz from an all-CU integer
  * spin of about spin_us microseconds launched by this call, *k1a_mhz averaged over the K1 pass-A launches since the previous

@@ -13,6 +13,11 @@ pytestmark = pytest.mark.gpu
 
 def _engine(topo_nodes, max_edges, layers, **kw):
     from alaz_amd import engine
+    # variant 0 here = the 8-byte-record path by name (3) with the warm-window state kept: sg_create's own rule would give engines of
+    # these sizes the 16-byte kernels (variant 2 in the parametrised tests) and no kept state (test_k1_path_follows_the_window_size)
+    if kw.get("k1_variant", 0) == 0:
+        kw["k1_variant"] = 3
+        kw.setdefault("warm", True)
     g = engine.ServiceGraph(max_known_nodes=topo_nodes, max_edges=max_edges, layers=layers,
                             max_labels=kw.pop("max_labels", 256), max_outbound_ips=kw.pop("max_outbound_ips", 512), **kw)
     g.set_clock(*CLOCK)
@@ -985,6 +990,21 @@ def test_sg_ingest_from_many_threads_into_one_engine():
     compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
     st = g.stats()
     assert st.last_window_events == o.window_events and st.events_dropped_cap == 0
+
+
+def test_k1_path_follows_the_window_size():
+    """sg_config.k1_variant = 0: a window of BASELINE config 2's size gets the 16-byte kernels and keeps no state, config 3's the 8-byte
+    path with the warm-window state; 3 / SG_CFG_WARM ask for them by name."""
+    from alaz_amd import engine
+    small = engine.ServiceGraph(max_known_nodes=1600, max_edges=66_000, layers=1, max_window_events=1_000_000)
+    g = small.geometry(); small.close()
+    assert (g["k1_variant"], g["k1_narrow"], g["warm_windows"]) == (0, 0, 0)
+    forced = engine.ServiceGraph(max_known_nodes=1600, max_edges=66_000, layers=1, max_window_events=1_000_000, k1_variant=3, warm=True)
+    g = forced.geometry(); forced.close()
+    assert (g["k1_narrow"], g["warm_windows"]) == (1, 1)
+    big = engine.ServiceGraph(max_known_nodes=15_000, max_edges=1_250_000, layers=2, max_window_events=10_000_000)
+    g = big.geometry(); big.close()
+    assert (g["k1_narrow"], g["warm_windows"], g["pass_a_teams"]) == (1, 1, 2)
 
 
 def test_two_concurrent_flushers_beside_eight_feeders_every_window_equals_a_single_flusher():

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def _engine(nodes, max_edges, layers, **kw):
     from alaz_amd import engine
+    kw.setdefault("k1_variant", 3); kw.setdefault("warm", True)     # (by name: sg_create's own rule keeps the state from 2^18 edges up only)
     g = engine.ServiceGraph(max_known_nodes=nodes, max_edges=max_edges, layers=layers, max_labels=kw.pop("max_labels", 256),
                             max_outbound_ips=kw.pop("max_outbound_ips", 512), **kw)
     g.set_clock(*CLOCK)
@@ -257,7 +258,7 @@ def test_eight_logical_shards_warm_windows_equal_one_engine():
     engs, bes = [], []
     for r in range(world):
         g = engine.ServiceGraph(max_known_nodes=topo.n_nodes + 8, max_edges=8192, layers=layers, max_labels=128, max_outbound_ips=512,
-                                rank=r, world=world, max_window_events=len(ev1))
+                                rank=r, world=world, max_window_events=len(ev1), k1_variant=3, warm=True)
         assert g.geometry()["warm_windows"] == 1
         g.set_clock(*CLOCK); g.load_weights(W); HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
         engs.append(g)
@@ -286,3 +287,32 @@ def test_eight_logical_shards_warm_windows_equal_one_engine():
     assert all(x.windows_cold == 1 and x.windows_warm == 3 for x in st), [(x.windows_warm, x.windows_cold) for x in st]
     for g in engs: g.close()
     one.close()
+
+
+def test_a_stream_of_raw_outbound_ip_windows_stops_paying_for_the_kept_state():
+    """every window carries raw outbound IPs (mixed protocols: no Host header on the Kafka / Postgres requests to outside addresses): none can
+    close warm.  After four such windows have been READ the engine closes the following ones the plain way (no rebuild into the kept
+    arrays, no compaction) — visible as windows that count neither as warm nor as cold — and every window still equals the oracle
+    and the rebuilding engine; a window without raw addresses later finds the kept state where it was left."""
+    topo = replay.make_topology(150, 3000, seed=151)
+    ev, _ = replay.make_events(topo, 120_000, seed=152, mixed=True, with_raw_outbound=True, fixed_labels=True)
+    labels = list(replay.EXTERNAL_HOSTS)
+    p = Pair(topo, 2, 1 << 14, labels)
+    counted = []
+    for k in range(8):
+        p.paths.clear()
+        before = p.warm.stats()
+        # (Pair.window asserts exactly one of warm / cold per window: here a plain window counts as neither)
+        rows = []
+        w = ev[k * 15_000:(k + 1) * 15_000]
+        for g in (p.warm, p.cold):
+            assert g.ingest(w) == 0
+            g.set_label_count(len(labels))
+            rows.append(g.flush_window().copy())
+        st = p.warm.stats()
+        counted.append((st.windows_warm - before.windows_warm, st.windows_cold - before.windows_cold))
+        p.o.packed(w, labels); p.o.window_close(p.W, 2)
+        compare_edge_dicts(engine_edge_dict(rows[0], p.shim, labels, p.warm.outbound_ips()), p.o.edge_dict())
+        assert rows[0].tobytes() == rows[1].tobytes()
+    assert counted[:4] == [(0, 1)] * 4 and counted[4:] == [(0, 0)] * 4, counted
+    p.close()

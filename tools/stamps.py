@@ -54,6 +54,14 @@ for kid, kname in zip((0, 1), g.k1_kernels()):
         print("  n-th workgroup on its CU starts at (mean us):", np.round(np.nanmean(nth, axis=0), 1), " workgroups per CU min/max:", min(len(v) for v in first.values()), max(len(v) for v in first.values()))
     ts = np.arange(0, en_.max(), 10.0)
     print("  workgroups running at t =", {int(t): int(((st_ <= t) & (en_ > t)).sum()) for t in ts})
+if st[2][:, 0].max() > 0:                                            # kw_compact (warm windows): start, loads in + ballots, look-back done, written + folded, row pointers + barrier, flushed
+    a = st[2].astype(np.int64); a = a[a[:, 0] != 0]; t0 = a[:, 0].min()
+    print(f"kw_compact: {len(a)} workgroups")
+    for k, nm in enumerate(("start", "loads in, ballots", "look-back done", "written + folded", "row pointers, barrier", "flushed")):
+        col = (a[:, k] - t0) / 100.0
+        print(f"  {k} {nm:<22} min {col.min():7.2f}  mean {col.mean():7.2f}  max {col.max():7.2f}")
+    dur = (a[:, 5] - a[:, 0]) / 100.0
+    print("  duration percentiles 10/50/90:", np.round(np.percentile(dur, [10, 50, 90]), 1), " phase means:", [round(float(((a[:, k + 1] - a[:, k]) / 100.0).mean()), 2) for k in range(5)])
 if st[3][:, 0].max() > 0:                                            # k3_in_part: start, LDS zeroed + barrier, slice scanned (thread 0), barrier passed, partials written
     a = st[3].astype(np.int64); a = a[a[:, 0] != 0]; t0 = a[:, 0].min()
     print(f"k3_in_part: {len(a)} workgroups")
