@@ -1490,6 +1490,7 @@ int sg_flush_window_view(sg_handle e, uint64_t window_end_ms, const sg_edge_out*
 // library itself does not link it, a single-GPU deployment never loads it.
 struct sg_comm {
     void* lib = nullptr; void* comm = nullptr; int rank = 0, world = 1; hipStream_t stream = nullptr; sg_engine* eng = nullptr;   // eng: whose timing records the collectives go to (group 9)
+    bool in_group = false; void* grp_t = nullptr;                    // between rc_group_begin and rc_group_end (the grouped calls' one timing record)
     struct Id { char b[128]; };
     int (*GetUniqueId)(Id*) = nullptr; int (*CommInitRank)(void**, int, Id, int) = nullptr; int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
@@ -1510,7 +1511,27 @@ bool rccl_load(sg_comm* c) {
 }
 // rccl.h: ncclUint8 = 1, ncclUint64 = 5; ncclSum = 0, ncclMax = 2
 int rc_all_gather(void* x, const void* send, void* recv, size_t bytes) { sg_comm* c = (sg_comm*)x; Timed t(c->eng, c->stream, 9); return c->AllGather(send, recv, bytes, 1, c->comm, c->stream) ? SG_ENODEV : SG_OK; }
-int rc_all_reduce(void* x, void* buf, size_t n, int op) { sg_comm* c = (sg_comm*)x; Timed t(c->eng, c->stream, 9); return c->AllReduce(buf, buf, n, 5, op ? 2 : 0, c->comm, c->stream) ? SG_ENODEV : SG_OK; }
+// (inside a group the two all-reduces are one launch: timed as one record of group 9, opened by the first and closed by rc_group_end)
+int rc_all_reduce(void* x, void* buf, size_t n, int op) {
+    sg_comm* c = (sg_comm*)x;
+    if (c->in_group) return c->AllReduce(buf, buf, n, 5, op ? 2 : 0, c->comm, c->stream) ? SG_ENODEV : SG_OK;
+    Timed t(c->eng, c->stream, 9);
+    return c->AllReduce(buf, buf, n, 5, op ? 2 : 0, c->comm, c->stream) ? SG_ENODEV : SG_OK;
+}
+int rc_group_begin(void* x) {
+    sg_comm* c = (sg_comm*)x;
+    if (!c->GroupStart || !c->GroupEnd) return SG_OK;
+    c->in_group = true;
+    c->grp_t = new Timed(c->eng, c->stream, 9);
+    return c->GroupStart() ? SG_ENODEV : SG_OK;
+}
+int rc_group_end(void* x) {
+    sg_comm* c = (sg_comm*)x;
+    if (!c->in_group) return SG_OK;
+    const int rc = c->GroupEnd();
+    delete static_cast<Timed*>(c->grp_t); c->grp_t = nullptr; c->in_group = false;
+    return rc ? SG_ENODEV : SG_OK;
+}
 int rc_all_to_all(void* x, const void* send, void* recv, size_t bytes) {            // full mesh over xGMI: grouped point-to-point, every link busy at once
     sg_comm* c = (sg_comm*)x;
     Timed t(c->eng, c->stream, 9);
@@ -1607,7 +1628,7 @@ int sg_window_run_sharded(sg_handle e, sg_comm* c, void* stream) {
     st.stats_max = e->d.st_max; st.stats_max_words = (size_t)e->d.ncap * SG_NODE_STAT_MAX_WORDS;
     st.req = e->xc.req; st.serve = e->xc.serve; st.list_bytes = (size_t)(e->xc.capp + 1) * 4;
     st.rows_out = e->xc.rows_out; st.rows_in = e->xc.rows_in; st.rows_bytes = (size_t)e->xc.capp * SG_F_HID * 4;
-    sg_shard_comm sc{c, rc_all_gather, rc_all_reduce, rc_all_to_all};
+    sg_shard_comm sc{c, rc_all_gather, rc_all_reduce, rc_all_to_all, rc_group_begin, rc_group_end};
     const int rc = sg_run_sharded_window(&st, &sc);
     if (rc) { if (e->err.empty()) e->err = "sg_window_run_sharded: a stage or a collective failed"; return rc; }
     window_timed_end(e, s);

@@ -5,7 +5,7 @@
 // enqueues:
 //
 //   obip_list -> all_gather(raw outbound IPs)  -> close (identical node numbering on every shard)
-//             -> all_reduce SUM / MAX of the integer node statistics (exact, order-free) -> features
+//             -> all_reduce SUM / MAX of the integer node statistics (exact, order-free; one grouped launch) -> features
 //             -> halo_build -> all_to_all(request lists)
 //             -> for every layer: layer -> pack -> all_to_all(requested rows: copied, never reduced) -> unpack
 //             -> score (+ window reset)
@@ -25,6 +25,10 @@ typedef struct sg_shard_comm {
     int (*all_gather)(void* ctx, const void* send, void* recv, size_t bytes_per_rank);          // recv = [world][bytes_per_rank]
     int (*all_reduce_u64)(void* ctx, void* buf, size_t count, int op);                           // in place; op 0 = sum, 1 = max
     int (*all_to_all)(void* ctx, const void* send, void* recv, size_t bytes_per_rank);          // both [world][bytes_per_rank]
+    // optional (may be null): the collectives issued between the two calls may be launched as one (RCCL: ncclGroupStart / ncclGroupEnd —
+    // the SUM and the MAX all-reduce of the node statistics leave as ONE launch instead of two)
+    int (*group_begin)(void* ctx);
+    int (*group_end)(void* ctx);
 } sg_shard_comm;
 
 // The local stages of one shard and the exchange buffers they fill / read (device memory for the HIP engine).
@@ -52,8 +56,10 @@ static inline int sg_run_sharded_window(const sg_shard_stages* s, const sg_shard
     SG_SEQ(s->obip_list(s->ctx));
     SG_SEQ(c->all_gather(c->ctx, s->ob_local, s->ob_all, s->ob_bytes));
     SG_SEQ(s->close_gathered(s->ctx));
+    if (c->group_begin && c->group_end) SG_SEQ(c->group_begin(c->ctx));
     SG_SEQ(c->all_reduce_u64(c->ctx, s->stats_sum, s->stats_sum_words, 0));
     SG_SEQ(c->all_reduce_u64(c->ctx, s->stats_max, s->stats_max_words, 1));
+    if (c->group_begin && c->group_end) SG_SEQ(c->group_end(c->ctx));
     SG_SEQ(s->features(s->ctx));
     SG_SEQ(s->halo_build(s->ctx));
     SG_SEQ(c->all_to_all(c->ctx, s->req, s->serve, s->list_bytes));

@@ -208,7 +208,8 @@ def run_window_c(be, comm=None) -> None:
     REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
     class Comm(C.Structure):
-        _fields_ = [("ctx", C.c_void_p), ("all_gather", GATHER), ("all_reduce_u64", REDUCE), ("all_to_all", GATHER)]
+        _fields_ = [("ctx", C.c_void_p), ("all_gather", GATHER), ("all_reduce_u64", REDUCE), ("all_to_all", GATHER),
+                    ("group_begin", C.c_void_p), ("group_end", C.c_void_p)]      # (optional grouping of the two statistics all-reduces: null here)
 
     class Stages(C.Structure):
         _fields_ = [("ctx", C.c_void_p), ("layers", C.c_uint32), ("world", C.c_uint32),
@@ -552,7 +553,7 @@ def _bench_mode(a, rank: int, world: int, local: int, strong: bool, brief: bool)
         # per window, the slowest rank's figure of every group (untimed pass, every group bracketed by events; with two windows in flight the
         # groups of the two engines overlap, so they do not add up to ms_per_step)
         "kernels": [{"name": n_, "us_per_window_max_rank": round(float(gmax[i].item()), 2)} for i, n_ in enumerate(names) if n_ != "collectives"],
-        "comm_us_per_window": round(float(gmax[names.index("collectives")].item()), 2),
+        "comm_us_per_window": None if brief else round(float(gmax[names.index("collectives")].item()), 2),
         "rows_verified": verified,
     }
     if res["config"]["halo_overflow"]:

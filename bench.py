@@ -328,7 +328,7 @@ def _engine_for(a, topo, labels, c, device, windows, engine, weights):
     if not os.environ.get("SG_BENCH_FULL_EDGE_CAP"):
         n_edges = min(n_edges, max(1, c["events"] // a.shard_of))
     g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(n_edges * (1.1 if big and a.shard_of == 1 else 1.25)) + 4096, layers=L,
-                            max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=int(os.environ.get("SG_BENCH_MAX_BATCH", 1 << 18)),
+                            max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=int(os.environ.get("SG_BENCH_MAX_BATCH", 1 << 20)),
                             max_window_events=max(1, c["events"] // a.shard_of), windows_in_flight=windows,
                             # config 5's Kafka / Postgres requests to outside addresses are raw outbound IPs in every window: no window can close warm
                             # (the engine finds that out by itself from the windows it READS; this replay reads none, so it is told)
