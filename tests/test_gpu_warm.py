@@ -316,3 +316,38 @@ def test_a_stream_of_raw_outbound_ip_windows_stops_paying_for_the_kept_state():
         assert rows[0].tobytes() == rows[1].tobytes()
     assert counted[:4] == [(0, 1)] * 4 and counted[4:] == [(0, 0)] * 4, counted
     p.close()
+
+
+def test_config3_graph_three_windows_the_engines_own_rule_warm_equals_cold():
+    """BASELINE config 3's graph (10 k pods, 1 M edges) under sg_create's OWN rule (no flag: the 8-byte path with the kept state from 2^18
+    edges up, degree atomics instead of histograms): window 1 = trace A (rebuild), window 2 = trace B (touches edges A did not: rebuild,
+    the kept set becomes the union), window 3 = trace A again — warm, a tenth of the kept edges untouched — must equal window 1 byte
+    for byte, and all three must equal the engine that rebuilds every window; window 1 is the oracle's (test_config3_full_size_row_for_row)."""
+    topo = replay.make_topology(10_000, 1_000_000, replay.SEED_BASE + 3)
+    A, labels = replay.make_events(topo, 3_000_000, replay.SEED_BASE + 3)
+    B, _ = replay.make_events(topo, 3_000_000, replay.SEED_BASE + 77)
+    from alaz_amd import engine
+    def mk(**kw):
+        g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=1_250_000, layers=2, max_labels=128, max_outbound_ips=128,
+                                max_window_events=len(A), max_batch=1 << 20, **kw)
+        g.set_clock(*CLOCK); g.load_weights(weights.make_weights(2))
+        for i in range(topo.n_pods): g.upsert_pod(int(topo.pod_ips[i]), i)
+        for j in range(topo.n_svcs): g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
+        g.set_label_count(128)
+        return g
+    a, b = mk(), mk(warm=False)
+    assert a.geometry()["warm_windows"] == 1 and a.geometry()["k1_narrow"] == 1 and b.geometry()["warm_windows"] == 0
+    rows = []
+    for ev in (A, B, A):
+        got = []
+        for g in (a, b):
+            for i in range(0, len(ev), 1 << 20):
+                while g.ingest(ev[i:i + (1 << 20)]) != 0:
+                    pass
+            got.append(g.flush_window().copy())
+        assert len(got[0]) > 500_000 and got[0].tobytes() == got[1].tobytes()
+        rows.append(got[0])
+    assert rows[0].tobytes() == rows[2].tobytes()
+    st = a.stats()
+    assert (st.windows_warm, st.windows_cold) == (1, 2) and st.events_dropped_cap == 0
+    a.close(); b.close()

@@ -32,10 +32,13 @@ def avg(d, counter):
 
 
 def pick(m, prefix):
+    """every kernel of the family (an engine that keeps warm-window state launches pass B twice per window — the warm attempt and the cold
+    merge, one of which returns at once): their per-launch averages add up to the family's bytes per window"""
+    tot, n = 0.0, 0
     for k, v in m.items():
         if prefix in k:
-            return v
-    return (0.0, 0)
+            tot += v[0]; n = max(n, v[1])
+    return (tot, n)
 
 
 def main():
