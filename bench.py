@@ -16,8 +16,11 @@ Steps cycle through a ring of distinct batches larger than the 256 MiB Infinity 
 from HBM.  One JSON line on stdout (rank 0):
 
   value        events/s of the timed device-resident steps (never includes PCIe; `end_to_end` does)
-  roofline     the dominant kernel K1 (pass A k1a_tile_partition + pass B k1b_stream_merge): algorithmic bytes 32*Ev + 32*E per window
+  roofline     the dominant kernel K1 (pass A k1a_team_partition + pass B k1b_stream_merge): algorithmic bytes 32*Ev + 32*E per window
                 / their dispatch durations (HIP events on the launch stream), vs 8 TB/s
+  per_step     median / min / p90 / max of >= 100 single windows (SURVEY 8(d) run protocol); box: dependent-load latencies of this box
+  warm_windows the engine keeps the union of the edges its windows touched: value is the steady state of a replay whose
+               windows touch edges it has seen; cold_ms_per_step = the same steps with every window rebuilt from nothing
   kernels      the same for every kernel group of the window (K1a, K1b, K2, K3-in, K3-feat, K4, K5)
   end_to_end   events accepted by sg_ingest from HOST memory (several feeder threads, pinned staging ring, H2D) until the
                window's rows are back in host memory (sg_flush_window): SURVEY §8(d)(i); bounded by PCIe (32 B/event in)
@@ -466,7 +469,7 @@ def bench_single(a, device):
         g.timing_enable(0)
         ca, cb = g.timing(1), g.timing(7)
         cold = {"ms_per_step": dtc / a.steps * 1e3, "events_per_s": Ev * a.steps / dtc, "pass_a_us": ca[0], "pass_b_us": cb[0] * cb[1] / max(1, ca[1]),
-                "what": "sg_set_warm(0): every window takes the full rebuild (pass B's cold merge, degree histogram, row scan, scatter, row sort, state capture)"}
+                "what": "sg_set_warm(0): every window takes the full rebuild (pass B's cold merge with the kept keys carried over, row scan, scatter, row sort of the kept CSR, state capture, then the compaction)"}
         g.set_warm(True)
         for i in range(2):                                   # (back on the warm path for the passes below)
             step(i)
