@@ -332,6 +332,22 @@ def shard_view(topo: replay.Topology, rank: int, world: int) -> replay.Topology:
     return replay.Topology(topo.n_pods, topo.n_svcs, topo.pod_ips, topo.svc_ips, topo.edge_src[keep], topo.edge_dst[keep], topo.seed)
 
 
+def settle_collectively(step, settle_ms: float, device, sync=lambda: None, trip: int = 8) -> int:
+    """Run step(0), step(1), ... in trips of `trip` windows until EVERY rank's clock says settle_ms have passed, and return how many ran:
+    the same number on every rank (each window issues collectives, so no rank may run one the others do not join).  The decision to go
+    on is itself a collective — the MAX over the ranks' "my clock says continue" flags after each trip; `trip` is even, so windows that
+    alternate between two engines / communicators stay aligned across ranks."""
+    ts = time.perf_counter(); i = 0
+    go = torch.ones(1, dtype=torch.int32, device=device)
+    while int(go.item()):
+        for _ in range(trip):
+            step(i); i += 1
+        sync()
+        go.fill_(1 if (time.perf_counter() - ts) * 1e3 < settle_ms else 0)
+        dist.all_reduce(go, op=dist.ReduceOp.MAX)
+    return i
+
+
 def bench(a, rank: int, world: int, local: int) -> dict:
     """bench.py --gpus N: the line's `value` is the STRONG-scaling figure by default (BASELINE config 4 = config 3's replay over the
     GPUs: the total work is fixed, so value(N) / value(1) is the speed-up the north star asks about); the other mode runs right after
@@ -466,14 +482,7 @@ def _bench_mode(a, rank: int, world: int, local: int, strong: bool, brief: bool)
         # collective (MAX over the ranks' "my clock says continue" flags after each trip of 8 windows — an even count, so the
         # engs[k] / rcomms[k] parity stays aligned).  A per-rank wall-clock test let one rank leave for the barrier while another
         # enqueued eight more windows of all-gather / all-to-all nobody joined.
-        ts = time.perf_counter(); i = 0
-        go = torch.ones(1, dtype=torch.int32, device=device)
-        while int(go.item()):
-            for _ in range(8):
-                step(i); i += 1
-            torch.cuda.synchronize(device)
-            go.fill_(1 if (time.perf_counter() - ts) * 1e3 < a.settle_ms else 0)
-            dist.all_reduce(go, op=dist.ReduceOp.MAX)
+        settle_collectively(step, a.settle_ms, device, lambda: torch.cuda.synchronize(device))
         dist.barrier()
     for i in range(a.warmup):
         step(i)

@@ -177,3 +177,42 @@ def test_halo_capacity_holds_for_the_bench_graph_at_2_4_8_shards():
         own = np.bincount(sharded.owner_of_known(np.arange(topo.n_nodes, dtype=np.uint32), world), minlength=world)
         assert worst <= own.max() <= capp, (world, worst, int(own.max()), capp)
         assert worst > 0
+
+
+def _settle_worker(rank, world, port, q):
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        time.sleep(0.12 * rank)                              # the ranks' clocks start apart, as their set-up times do
+        ran = []
+        def step(i):                                         # every "window" is a collective: a rank running one alone would hang here
+            t = torch.tensor([i], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            assert int(t.item()) == i * world                # ... and every rank is at the same window
+            ran.append(i)
+            time.sleep(0.002)
+        n = sharded.settle_collectively(step, 60.0, torch.device("cpu"))
+        q.put((rank, n, len(ran)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_settle_loop_runs_the_same_number_of_windows_on_every_rank():
+    """the bench's settle loop decided from each rank's own wall clock whether to run eight more sharded windows — each a
+    set of collectives — so a rank whose clock started earlier left for the barrier while another enqueued windows nobody joined.  The
+    decision is a collective now: three gloo ranks whose clocks start 120 ms apart run the same number of windows (a multiple of 8), and at
+    least as many as the slowest clock asks for."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_settle_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps: p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps: p.join(timeout=60)
+    counts = {n for _, n, _ in got}
+    assert len(counts) == 1 and all(n == m for _, n, m in got), got
+    n = counts.pop()
+    assert n % 8 == 0 and n >= 8
