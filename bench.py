@@ -497,6 +497,9 @@ def bench_single(a, device):
                    "hbm_loaded_latency_ns": round(g.latency_probe(4 << 30, 2048, loaded=True), 1),
                    "how": "dependent loads one 128-byte line apart (sg_latency_probe), one lane: 4 GiB cold / 2 MiB warm / 64 MiB warm (Infinity Cache); "
                           "loaded: 65 536 lanes each on a chain of its own through 4 GiB, one timed"}
+            pr = torch.cuda.get_device_properties(device)
+            box["device"] = {"name": pr.name, "cus": pr.multi_processor_count, "hbm_GiB": round(pr.total_memory / 2**30, 1),
+                             "l2_MiB": round(getattr(pr, "L2_cache_size", 0) / 2**20, 1), "gcn_arch": getattr(pr, "gcnArchName", "")}
         except Exception as ex:                              # noqa: BLE001
             box = {"error": repr(ex)[:200]}
     kern_us = {"K1a": k1a[0], "K1b": k1b[0], **grp}
@@ -511,7 +514,8 @@ def bench_single(a, device):
     res = {
         "metric": "L7 edge-events/s ingested->scored service-map", "value": Ev * a.steps / dt, "unit": "events/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        # (one GPU: the job of the N > 1 default — BASELINE config 4 = this replay routed over N ranks, total work fixed — at N = 1)
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": (f"ONE SHARD OF {a.shard_of} of " if a.shard_of > 1 else "") + f"C{cfgno} device-resident replay: {c['pods']} pods / {topo.n_svcs} services / {len(topo.edge_src)} edges, "
                                f"{Ev} {'mixed HTTP/Kafka/Postgres' if cfgno == 5 else 'HTTP'} l7 events per window already in HBM, {L}-layer SAGE + MLP score, "
                                f"{variant}; {nb}-batch HBM ring (value excludes PCIe: see end_to_end)",
