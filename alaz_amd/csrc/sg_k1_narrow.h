@@ -539,7 +539,8 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
                 k = atomicCAS(&hkey[h], 0xFFFFFFFFu, rem);
                 if (k == 0xFFFFFFFFu) {
                     k = rem;
-                    if constexpr (WM == 1) htouch[HT / 32] = 1u;     // a key the kept set lacks: the window is cold
+                    if constexpr (WM == 1) { htouch[HT / 32] = 1u; d.ctr[C_COLD] = 2; }   // a key the kept set lacks: the window is cold — said at once, so that the
+                                                                                        // workgroups that have not started yet (half of them run in a second round) return at their first line
                     if constexpr (WM == 2) atomicAdd(&htouch[HT / 32], 1u);   // keys in the table (the union phase fills what room is left)
                 }
             }
@@ -596,6 +597,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     }
     __syncthreads();                                                 // every 32-bit max is in: 64-bit updates may follow
     SG_STAMP(d, 1, 3);
+    if constexpr (WM == 1) { if (d.ctr[C_COLD]) return; }             // (uniform) some workgroup met an unknown key: the rebuild repeats the merge, nothing this one writes is read
     if constexpr (PACK) {                                            // unpack: a slot by one thread, nobody else touches the table here
         for (u32 i = t; i < HT; i += NT) { const u64 w = hacc[HT + i]; hacc[i] += w >> 48; hacc[HT + i] = w & ((1ull << 48) - 1ull); }
         __syncthreads();
