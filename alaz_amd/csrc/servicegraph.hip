@@ -105,12 +105,8 @@ struct sg_engine {
     u32 obip_streak = 0; u64 plain_left = 0;  // windows read in a row that raw outbound IPs kept cold; windows still to be closed without the kept-CSR detour
     std::vector<char> plain_slot;             // per window slot: its last close was such a plain one (not counted as warm or cold)
     std::vector<u64*> scr_sum, scr_max; std::vector<double*> scr_mu;   // per window slot: the node statistics the kept-CSR rebuild writes (scratch; row_mu | row_sd in one array)
-    // two-stream close (SG_WARM_AUX=1; measured and left OFF): the rebuild kernels — each returns at once on a warm window, but an empty
-    // launch still costs ~4.5 us, and there are five of them — on a second stream beside the warm window's compaction.  Same box, C3:
-    // 506 us per window with it, 490 without — the fork / join events and the two streams' kernels slowing each other cost more than
-    // the empty launches (profiles/r05_c_*)
-    bool warm_aux = false;
-    std::vector<hipStream_t> aux_stream; std::vector<hipEvent_t> ev_fork, ev_join;
+    // (Measured and rejected, profiles/r05_c_aux*: the rebuild kernels on a second stream beside the warm window's compaction, so that their
+    // empty launches cost nothing — the fork / join events and the two streams' kernels slowing each other cost more: 506 vs 490 us per window.)
     u64 window_events_in = 0;
 
     unsigned timing = 0;       // bit k set: kernel group k is bracketed by HIP events
@@ -448,8 +444,6 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
     bool warm_try = d.warm && e->warm_on;
     if (warm_try && e->warm_skip) { e->warm_skip--; warm_try = false; }
     const u32 wt = warm_try ? 1u : 0u;
-    // the stream of the rebuild (pass B's cold merge, K2, kw_compact's cold case): a second one beside the warm path when this window tries it
-    hipStream_t sx = (d.warm && e->warm_aux && warm_try && !e->aux_stream.empty()) ? e->aux_stream[e->cur] : s;
     {
         Timed tp(e, s, 2);
         if (ob_mode == 1) hipLaunchKernelGGL(kc_prepare, dim3(1), dim3(1024), 0, s, d, (u64)e->n_known, (u64)e->n_labels_decl, e->d_ob_list, (const u32*)e->d_ob_n, e->ob_list_cap, 1u, (const u32*)nullptr, 0u, 0u, wt);
@@ -464,18 +458,15 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         // warm engines: the warm attempt (WM 1: seeded tables, accumulators straight to their kept positions; returns at once when
         // kc_prepare has already called the window cold), then the cold merge (WM 2: returns at once on a warm window).  Both are records
         // of group 7: a window's pass B is the SUM of its group-7 records.
-#define K1B8W_GOP(U_, SPT_, P_, WM_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, ks, ta, tb, 0u, db); \
-                                     else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, ks, ta, tb, 0u, db); } while (0)
+#define K1B8W_GOP(U_, SPT_, P_, WM_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
+                                     else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
 #define K1B8W_GO(SPT_, WM_) do { if (e->k1b_pack) K1B8W_GOP(4, SPT_, true, WM_); else K1B8W_GOP(4, SPT_, false, WM_); } while (0)
 #define K1B8W_GO2(WM_) do { const u32 spt = d.k1b_ht / e->k1b_threads; if (spt >= 4) K1B8W_GO(4, WM_); else if (spt == 2) K1B8W_GO(2, WM_); else K1B8W_GO(1, WM_); } while (0)
         if (d.warm) {
-            hipStream_t ks = s;
             if (warm_try) {
                 K1B8W_GO2(1);
                 if (tk) { TimingRec r; r.a = ta; r.b = tb; r.kernel = 7; e->trecs.push_back(r); ta = get_event(e); tb = get_event(e); }
             }
-            if (sx != s) { HIP_TRY(e, hipEventRecord(e->ev_fork[e->cur], s)); HIP_TRY(e, hipStreamWaitEvent(sx, e->ev_fork[e->cur], 0)); }   // the rebuild starts behind the warm attempt
-            ks = sx;
             K1B8W_GO2(2);
         } else {
 #define K1B_GO(U_, H_) do { if (share) hipExtLaunchKernelGGL((k1b_merge<U_, H_>), dim3(d.np), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
@@ -513,26 +504,17 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
             hipLaunchKernelGGL(k2_scan_tiles, dim3(1), dim3(1024), 0, s, d, ntiles);
             hipLaunchKernelGGL(k2_edge_compact, dim3(ntiles), dim3(256), 0, s, d);
         }
-        if (d.dh_g) hipLaunchKernelGGL(k2_deg_hist, dim3(d.dh_g), dim3(K2_DH_THREADS), ((size_t)d.ncap + 1) * sizeof(u32), sx, dk);
-        if (d.dh_g) hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS_DH, true>), dim3(((size_t)d.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH), dim3(1024), 0, sx, dk, ++e->rp_epoch);
-        else hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS, false>), dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, sx, dk, ++e->rp_epoch);
+        if (d.dh_g) hipLaunchKernelGGL(k2_deg_hist, dim3(d.dh_g), dim3(K2_DH_THREADS), ((size_t)d.ncap + 1) * sizeof(u32), s, dk);
+        if (d.dh_g) hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS_DH, true>), dim3(((size_t)d.ncap + K2_RP_ROWS_DH) / K2_RP_ROWS_DH), dim3(1024), 0, s, dk, ++e->rp_epoch);
+        else hipLaunchKernelGGL((k2_rowptr<K2_RP_ROWS, false>), dim3(((size_t)d.ncap + K2_RP_ROWS) / K2_RP_ROWS), dim3(1024), 0, s, dk, ++e->rp_epoch);
         if (d.variant == 1) hipLaunchKernelGGL(k2_scatter_table, dim3(grid_for(e->cfg.max_edges, 256)), dim3(256), 0, s, d);
-        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, sx, dk);
-        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 2 * (size_t)d.k2_sortw * sizeof(u32), sx, dk);
+        else hipLaunchKernelGGL(k2_scatter_parts, dim3(d.npb), dim3(256), 0, s, dk);
+        hipLaunchKernelGGL(k2_rowsort_gather, dim3(std::max(2, std::min(4096, 2 * K2_LONG_WGS + grid_for(d.ncap, 8)))), dim3(256), 2 * (size_t)d.k2_sortw * sizeof(u32), s, dk);
         if (d.warm) {
             // the window's CSR out of the kept one — every window; behind a rebuild its first workgroups also take the positions the
-            // next windows' pass B writes to (kw_capture).  Two streams: the cold case at the end of the rebuild's stream, the warm
-            // case on the window's own at once, beside the rebuild's empty launches; the window goes on when both are through.
+            // next windows' pass B writes to (kw_capture)
             const unsigned kg = (unsigned)(((u64)d.npb * d.pcap + KW_CH - 1) / KW_CH) + KW_CAPW;
-            const size_t kl = (size_t)KW_ROWS * 5 * sizeof(u64);
-            if (sx != s) {
-                hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), kl, sx, d, ++e->kw_epoch, dk.st_sum, dk.st_max, 2u);
-                HIP_TRY(e, hipEventRecord(e->ev_join[e->cur], sx));
-                hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), kl, s, d, ++e->kw_epoch, dk.st_sum, dk.st_max, 1u);
-                HIP_TRY(e, hipStreamWaitEvent(s, e->ev_join[e->cur], 0));
-            } else {
-                hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), kl, s, d, ++e->kw_epoch, dk.st_sum, dk.st_max, 0u);
-            }
+            hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), (size_t)KW_ROWS * 5 * sizeof(u64), s, d, ++e->kw_epoch, dk.st_sum, dk.st_max);
         }
     }
     {
@@ -1033,15 +1015,6 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             CH(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
             CR(alloc_window(w.d, w.ob_list, w.ob_n));
         }
-        if (e->d.warm) {
-            if (const char* v = std::getenv("SG_WARM_AUX")) e->warm_aux = std::atoi(v) != 0;
-            for (u32 k = 0; k < nw && e->warm_aux; k++) {
-                hipStream_t a = nullptr; hipEvent_t f = nullptr, j = nullptr;
-                CH(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-                CH(hipEventCreateWithFlags(&f, hipEventDisableTiming)); CH(hipEventCreateWithFlags(&j, hipEventDisableTiming));
-                e->aux_stream.push_back(a); e->ev_fork.push_back(f); e->ev_join.push_back(j);
-            }
-        }
         CH(hipDeviceSynchronize());
     }
 #undef CR
@@ -1054,9 +1027,6 @@ int sg_destroy(sg_handle e) {
     if (!e) return SG_EINVAL;
     hipDeviceSynchronize();
     for (size_t k = 0; k < e->slots.size(); k++) if ((int)k != e->cur && e->slots[k].stream) hipStreamDestroy(e->slots[k].stream);
-    for (hipStream_t a : e->aux_stream) hipStreamDestroy(a);
-    for (hipEvent_t v : e->ev_fork) hipEventDestroy(v);
-    for (hipEvent_t v : e->ev_join) hipEventDestroy(v);
     for (void* p : e->allocs) hipFree(p);
     if (e->h_blob) hipHostFree(e->h_blob);
     for (int i = 0; i < kUpdSlots; i++) { if (e->h_upd[i]) hipHostFree(e->h_upd[i]); if (e->upd_ev[i]) hipEventDestroy(e->upd_ev[i]); }

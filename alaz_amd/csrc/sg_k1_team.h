@@ -84,7 +84,6 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     const u64 per = (n + units - 1) / units;
     const u32 grp = per >= K1M_GROUP ? K1M_GROUP : (u32)((per + K1M_TT - 1) / K1M_TT * K1M_TT);
     const u64 ngroup = (n + grp - 1) / grp, ntile = (ngroup + 1) >> 1;
-    const u64 end = n;
     // (rotated by the tiles of the window's earlier launches: many small batches must not all land on the pieces of the first workgroups)
     const u32 rot = d.k1a_rot % units;
     const u32 unit = (team * d.nwg + w + units - rot) % units, unit_other = ((1u - team) * d.nwg + w + units - rot) % units;
@@ -129,8 +128,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     // re-read of a dummy event (it is ignored by its in-range flag anyway).  Two 16-byte halves per event, one offset register.
     // (K1M_OOB, the offset of a lane without work: 2 GiB — every buffer here is shorter (the host sees to it).  NOT ~0: the range check adds
     // the access size with 32-bit wrap-around, 0xFFFFFFFF + 8 = 7 is "in range" and the store lands 4 GiB behind the base: a memory fault.)
-    typedef u32 v4u32_t __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t ev_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<sg_event*>(ev), 0, (int)(u32)(n * 32u), 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t ev_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<sg_event*>(ev), 0, (int)(u32)(n * 32u), 0x00020000);
 #ifdef SG_K1M_BUFFER_LOADS
 #define K1M_LD(A, B, vo) asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16" : "=&v"(A), "=&v"(B) : "v"(vo), "s"(ev_rsrc) : "memory")
 #else

@@ -1813,18 +1813,12 @@ __device__ __forceinline__ void kw_capture(const Dev& d, u64* scratch_sum, u64* 
 #define KW_CH (KW_THREADS * KW_Q)
 #define KW_ROWS 512                                                  // rows per chunk with LDS accumulators (5 x u64 each: 20 KiB)
 #define KW_RESIDENT (3 * SG_LB_RESIDENT)                             // working chunks that are certainly resident together (<= 80 VGPRs, 21 KiB of LDS)
-// `only`: 0 = every window; 1 = only a warm window, 2 = only a cold one (the two launches of the two-stream close: the warm window's
-// compaction runs beside the empty rebuild kernels, the cold window's behind the rebuild).
-__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* scratch_sum, u64* scratch_max, u32 only) {
+__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* scratch_sum, u64* scratch_max) {
     extern __shared__ u64 kw_racc[];                                 // [KW_ROWS][5]: cnt, err, sum, ssq, max
     __shared__ u64 bal[KW_Q][KW_NW];
     __shared__ u32 wpre[KW_Q][KW_NW];
     __shared__ u32 qpre[KW_Q + 1];
     __shared__ u32 pre, bdyn;
-    {
-        const bool cold = d.ctr[C_COLD] != 0;
-        if ((only == 1 && cold) || (only == 2 && !cold)) return;     // (uniform)
-    }
     if (blockIdx.x < KW_CAPW) { kw_capture(d, scratch_sum, scratch_max, blockIdx.x, KW_CAPW, KW_THREADS); return; }
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u32 KE = (u32)d.ctr[C_KEPT_E], N = (u32)d.ctr[C_N_NODES];
@@ -1993,7 +1987,7 @@ __device__ __forceinline__ void kw_finish_rows(const Dev& d, u32 tid, u32 nt) {
         d.row_mu[v] = mean_us(ts, tc); d.row_sd[v] = std_us(ts, tq, tc);
         if (dg > SG_MEAN_BLOCK) {
             const u32 nblk = (dg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
-            const u32 ib = (u32)atomicAdd(&d.ctr[C_HUB_ITEMS], (u64)nblk);   // (zeroed by kc_prepare)
+            const u32 ib = (u32)atomicAdd(&d.ctr[C_HUB_ITEMS], (u64)nblk);   // (zeroed by kw_compact)
             d.hub_base[v] = ib;
             for (u32 j = 0; j < nblk; j++) if (ib + j < d.hub_cap) d.hub_items[ib + j] = make_uint2(v, j);
         }
@@ -2870,7 +2864,7 @@ __device__ __forceinline__ u32 node_flags(const Dev& d, u32 v, u32 nk, u32 nl) {
 // for maps beyond the LDS staging — was fifteen serial rounds of scattered 4-byte stores per list: 53 us of a C4 shard's window.)
 template <bool REQ>
 __device__ __forceinline__ void build_lists_staged(const Dev& d, u32* req, u32 capp, unsigned char* fl, u32* wsum) {
-    constexpr bool want_req = REQ;
+    [[maybe_unused]] constexpr bool want_req = REQ;
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const u32 W = d.world < 8 ? d.world : 8;
     // the flags of eight nodes per thread and trip, every load of the trip issued before any of them is used: node_flags() has a
