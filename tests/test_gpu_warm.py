@@ -351,3 +351,44 @@ def test_config3_graph_three_windows_the_engines_own_rule_warm_equals_cold():
     st = a.stats()
     assert (st.windows_warm, st.windows_cold) == (1, 2) and st.events_dropped_cap == 0
     a.close(); b.close()
+
+
+def test_kept_set_beyond_the_resident_chunks_compaction_ordered_by_ticket():
+    """2 M kept edges = 977 chunks of `kw_compact`, more than are certainly resident at once (768): its workgroups take their chunk by ticket,
+    so that a chunk only ever waits for chunks that have started (the look-back of k2_rowptr beyond 256 workgroups).  One request per edge of
+    a 2 M-edge graph (every edge touched: rebuild), the same again (warm), every second request (warm, half the kept edges leave), all again —
+    the warm engine against the one that rebuilds every window, byte for byte; counts and row order against the trace itself."""
+    from alaz_amd import engine
+    topo = replay.make_topology(10_000, 2_000_000, seed=171)
+    E = len(topo.edge_src)
+    ev = np.zeros(E, dtype=replay.EVENT_DTYPE)
+    ev["saddr"] = topo.pod_ips[topo.edge_src]; ev["daddr"] = topo.node_ip(topo.edge_dst)
+    ev["status"] = 200; ev["protocol"] = replay.PROTO_HTTP
+    ev["duration_ns"] = 1_000_000 + (np.arange(E, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(9_000_000))
+    ev["write_time_ns"] = 2_000_000_000 + np.arange(E, dtype=np.uint64)
+    def mk(**kw):
+        g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=2_300_000, layers=1, max_labels=64, max_outbound_ips=64,
+                                max_window_events=E, max_batch=1 << 20, **kw)
+        g.set_clock(*CLOCK); g.load_weights(weights.make_weights(1))
+        for i in range(topo.n_pods): g.upsert_pod(int(topo.pod_ips[i]), i)
+        for j in range(topo.n_svcs): g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
+        return g
+    a, b = mk(), mk(warm=False)
+    assert a.geometry()["warm_windows"] == 1
+    rows = []
+    for w in (ev, ev, ev[::2], ev):
+        got = []
+        for g in (a, b):
+            for i in range(0, len(w), 1 << 20):
+                while g.ingest(np.ascontiguousarray(w[i:i + (1 << 20)])) != 0:
+                    pass
+            got.append(g.flush_window().copy())
+        assert got[0].tobytes() == got[1].tobytes()
+        rows.append(got[0])
+    assert len(rows[0]) == E == len(rows[3]) and len(rows[2]) == (E + 1) // 2 and int(rows[0]["count"].sum()) == E
+    assert rows[0].tobytes() == rows[1].tobytes() == rows[3].tobytes()
+    key = (rows[2]["from_ref"].astype(np.uint64) << np.uint64(32)) | rows[2]["to_ref"].astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])
+    st = a.stats()
+    assert (st.windows_warm, st.windows_cold) == (3, 1) and st.events_dropped_cap == 0
+    a.close(); b.close()
