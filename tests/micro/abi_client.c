@@ -84,6 +84,33 @@ int main(void) {
     CHECK(sg_flush_begin(h, 3000) == SG_OK);
     CHECK(sg_flush_end(h, rows, 8, &n) == SG_OK && n == 1 && rows[0].count == 1);
     CHECK(sg_destroy(h) == SG_OK);
+    h = NULL;
+
+    /* ABI 5 — warm windows by name (an engine of this size would not keep the state by itself): the 8-byte-record path (k1_variant 3) with
+     * SG_CFG_WARM.  The first window is rebuilt, the same requests again and a subset of them are closed out of the kept edge set; the rows
+     * are the same either way; sg_set_warm(h, 0) sends every window down the rebuild again. */
+    cfg.k1_variant = 3; cfg.flags = SG_CFG_WARM;
+    CHECK(sg_create(&cfg, &h) == SG_OK && h != NULL);
+    w = (float*)malloc(nw * sizeof *w);
+    CHECK(w != NULL);
+    for (size_t i = 0; i < nw; i++) w[i] = (float)((i * 2654435761u >> 8) & 0xFFFF) / 65536.0f * 0.2f - 0.1f;
+    CHECK(sg_load_weights(h, w, nw) == SG_OK);
+    free(w);
+    CHECK(sg_geometry_get(h, &geo) == SG_OK && geo.k1_narrow == 1 && geo.warm_windows == 1);
+    CHECK(sg_upsert_pod(h, ip(10, 0, 0, 1), 0) == SG_OK && sg_upsert_pod(h, ip(10, 0, 0, 2), 1) == SG_OK && sg_upsert_service(h, ip(172, 16, 0, 1), 2) == SG_OK);
+    CHECK(sg_set_label_count(h, 1) == SG_OK);
+    sg_edge_out first[4];
+    for (int win = 0; win < 4; win++) {
+        if (win == 3) CHECK(sg_set_warm(h, 0) == SG_OK);
+        const size_t feed = win == 2 ? 2 : 3;                                             /* window 2: only pod 0 -> service 2 */
+        CHECK(sg_ingest(h, ev, feed) == SG_OK);
+        CHECK(sg_flush_window(h, 0, rows, 16, &n) == SG_OK);
+        CHECK(n == (win == 2 ? 1u : 2u) && rows[0].count == 2 && rows[0].err_count == 1 && rows[0].sum_ns == 3000000ull);
+        if (win == 0) memcpy(first, rows, 2 * sizeof rows[0]);
+        else if (win != 2) CHECK(memcmp(first, rows, 2 * sizeof rows[0]) == 0);           /* warm or rebuilt: the same bytes */
+    }
+    CHECK(sg_stats_get(h, &st) == SG_OK && st.windows == 4 && st.windows_warm == 2 && st.windows_cold == 2);
+    CHECK(sg_destroy(h) == SG_OK);
     printf("abi_client ok\n");
     return 0;
 }
