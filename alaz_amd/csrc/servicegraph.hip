@@ -99,11 +99,11 @@ struct sg_engine {
     // warm windows (sg_device.h): the host only decides whether a window TRIES the warm path; whether it may is decided on the device
     bool warm_on = true;                      // sg_set_warm
     u32 cold_streak = 0;                      // consecutive windows the host has seen fall back to the full rebuild
-    u64 warm_skip = 0;                        // windows left of a back-off (the warm attempt is not launched at all)
     u32 kw_epoch = 0;                         // kw_compact launch counter (tags its look-back words)
     u64 closes = 0; u32 timing_stride = 1;    // windows closed so far; the dispatch stamps of K1 (groups 1 and 7) are taken on every timing_stride-th window
     u32 obip_streak = 0; u64 plain_left = 0;  // windows read in a row that raw outbound IPs kept cold; windows still to be closed without the kept-CSR detour
     std::vector<char> plain_slot;             // per window slot: its last close was such a plain one (not counted as warm or cold)
+    std::vector<u64*> h_note; std::vector<u64> note_seen;   // per window slot: the device's note (page-locked, mapped) and the sequence number last read from it
     std::vector<u64*> scr_sum, scr_max; std::vector<double*> scr_mu;   // per window slot: the node statistics the kept-CSR rebuild writes (scratch; row_mu | row_sd in one array)
     // (Measured and rejected, profiles/r05_c_aux*: the rebuild kernels on a second stream beside the warm window's compaction, so that their
     // empty launches cost nothing — the fork / join events and the two streams' kernels slowing each other cost more: 506 vs 490 us per window.)
@@ -437,12 +437,28 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
     // READ four such windows in a row it closes the next 64 as an engine without the state does (the kept state stays as it is: these
     // windows do not touch it), then looks again.
     Dev dloc = e->d;
+    if (dloc.warm && (size_t)e->cur < e->note_seen.size()) {
+        // what the device has said since we last looked (this slot's note; page-locked host memory the kw_compact of an earlier window wrote)
+        volatile u64* note = e->h_note[e->cur];
+        const u64 seq = note[0];
+        if (seq != e->note_seen[e->cur]) {
+            e->note_seen[e->cur] = seq;
+            const u64 v = note[1];
+            const u32 cold = (u32)(v & 0xFFu); const bool obip = (v & 0x100ull) != 0;
+            // a warm attempt that ran its merge and THEN met an unknown key is the expensive outcome (the window pays the attempt, the rebuild
+            // with the kept keys carried over and the compaction: +45 % on a stream that brings new edges every window, tools/churn_probe.py):
+            // three of them in a row and the next 32 windows are closed the plain way, then one more try
+            e->cold_streak = cold == 2 ? e->cold_streak + 1 : 0;
+            e->obip_streak = (cold == 1 && obip) ? e->obip_streak + 1 : 0;
+            if (e->cold_streak >= 3) { e->plain_left = 32; e->cold_streak = 0; }
+            if (e->obip_streak >= 4) { e->plain_left = 64; e->obip_streak = 0; }
+        }
+    }
     if (dloc.warm && e->plain_left) { e->plain_left--; dloc.warm = 0; }
     if ((size_t)e->cur < e->plain_slot.size()) e->plain_slot[e->cur] = e->d.warm && !dloc.warm;
     const Dev& d = dloc;
-    // warm windows: try unless switched off or backing off after a run of cold windows (the device decides whether the try holds)
+    // warm windows: try unless switched off (the device decides whether the try holds)
     bool warm_try = d.warm && e->warm_on;
-    if (warm_try && e->warm_skip) { e->warm_skip--; warm_try = false; }
     const u32 wt = warm_try ? 1u : 0u;
     {
         Timed tp(e, s, 2);
@@ -514,7 +530,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
             // the window's CSR out of the kept one — every window; behind a rebuild its first workgroups also take the positions the
             // next windows' pass B writes to (kw_capture)
             const unsigned kg = (unsigned)(((u64)d.npb * d.pcap + KW_CH - 1) / KW_CH) + KW_CAPW;
-            hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), (size_t)KW_ROWS * 5 * sizeof(u64), s, d, ++e->kw_epoch, dk.st_sum, dk.st_max);
+            hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), (size_t)KW_ROWS * 5 * sizeof(u64), s, d, ++e->kw_epoch, dk.st_sum, dk.st_max, (u64)(e->closes + 1));
         }
     }
     {
@@ -621,15 +637,9 @@ void account_window(sg_engine* e) {
     if (e->d.warm && !((size_t)e->cur < e->plain_slot.size() && e->plain_slot[e->cur])) {
         // (counters of the slot that was read: with several windows in flight every slot keeps its own state and its own counts)
         const bool cold = e->h_ctr[C_COLD] != 0;
-        e->obip_streak = (e->h_ctr[C_COLD] == 1 && e->h_ctr[C_N_OBIP] != 0) ? e->obip_streak + 1 : 0;
-        if (e->obip_streak >= 4) { e->plain_left = 64; e->obip_streak = 0; }
+
         if (cold) st.windows_cold++; else st.windows_warm++;
-        // a stream whose windows keep touching edges the kept set lacks pays for the warm attempt every time: after four cold windows
-        // in a row the attempt is left out for eight windows (they rebuild and re-capture as before), then tried again
-        // (only the windows whose warm attempt ran its merge and THEN met an unknown key count — C_COLD = 2 —: a window kc_prepare
-        // calls cold costs nothing extra)
-        e->cold_streak = e->h_ctr[C_COLD] == 2 ? e->cold_streak + 1 : (cold ? e->cold_streak : 0);
-        if (e->cold_streak >= 4) { e->warm_skip = 8; e->cold_streak = 0; }
+        // (the policy — when to stop trying — reads the device's note at the next close: do_close)
     }
     if (e->h_ctr[C_N_EVENTS]) {
         // convertKernelTimeToUserspaceTime()/1e6 — aggregator/data.go:1740-1743, :1219 (u64 wrap arithmetic)
@@ -940,6 +950,12 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
                 u64* a = nullptr; u64* b = nullptr; double* c = nullptr;
                 LR(dev_alloc(e, &a, (size_t)w.ncap * SG_NODE_STAT_SUM_WORDS)); LR(dev_alloc(e, &b, (size_t)w.ncap * SG_NODE_STAT_MAX_WORDS)); LR(dev_alloc(e, &c, 2 * ((size_t)w.ncap + 1)));
                 e->scr_sum.push_back(a); e->scr_max.push_back(b); e->scr_mu.push_back(c);
+                u64* hn = nullptr; void* dn = nullptr;
+                HIP_TRY(e, hipHostMalloc((void**)&hn, 64, hipHostMallocMapped));
+                hn[0] = hn[1] = 0;
+                HIP_TRY(e, hipHostGetDevicePointer(&dn, hn, 0));
+                w.host_note = (u64*)dn;
+                e->h_note.push_back(hn); e->note_seen.push_back(0);
             }
         }
         const size_t KE = w.warm ? std::max<size_t>(ME, (size_t)w.npb * w.pcap) : ME;   // arrays the rebuild indexes by KEPT position on a warm engine
@@ -1027,6 +1043,7 @@ int sg_destroy(sg_handle e) {
     if (!e) return SG_EINVAL;
     hipDeviceSynchronize();
     for (size_t k = 0; k < e->slots.size(); k++) if ((int)k != e->cur && e->slots[k].stream) hipStreamDestroy(e->slots[k].stream);
+    for (u64* hn : e->h_note) hipHostFree(hn);
     for (void* p : e->allocs) hipFree(p);
     if (e->h_blob) hipHostFree(e->h_blob);
     for (int i = 0; i < kUpdSlots; i++) { if (e->h_upd[i]) hipHostFree(e->h_upd[i]); if (e->upd_ev[i]) hipEventDestroy(e->upd_ev[i]); }
@@ -1777,7 +1794,7 @@ int sg_timing_get(sg_handle e, int kernel, double* avg_us, uint64_t* launches) {
 int sg_set_warm(sg_handle e, int on) {
     if (!e) return SG_EINVAL;
     std::lock_guard<std::mutex> g(e->mu);
-    e->warm_on = on != 0; e->warm_skip = 0; e->cold_streak = 0; e->plain_left = 0; e->obip_streak = 0;
+    e->warm_on = on != 0; e->cold_streak = 0; e->plain_left = 0; e->obip_streak = 0;
     return SG_OK;
 }
 // every record of one group since sg_timing_reset, in launch order (bench.py: median and minimum, SURVEY 8(d) run protocol)

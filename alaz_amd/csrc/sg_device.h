@@ -173,6 +173,8 @@ struct Dev {
     u64* k_acc;                               // [max_edges][4] accumulators by kept position, rewritten by every warm pass B; bit 63 of word 2 (max_ns < 2^62) = touched in this window
     u32* k_col; u32* k_from; u32* k_rowptr;   // the kept CSR: [max_edges], [max_edges], [ncap + 1]
     u64* kw_tot;                              // [max_edges / KW_CH + 2] kw_compact: (epoch << 32 | touched edges) per chunk
+    u64* host_note;                           // page-locked HOST memory (mapped): [0] = sequence number of the last window kw_compact closed, [1] = its C_COLD
+                                              // and C_N_OBIP << 8 — how the host learns, without ever waiting for the device, which path its windows take
     u32* lb_ticket;                           // [4] self-resetting workgroup tickets of the look-back kernels whose grid exceeds SG_LB_RESIDENT ([0] k2_rowptr, [1] kw_compact)
     u64* k6_tot;                              // [ceil(ncap/1024) + 1][16] k6_halo_lists: (epoch << 32 | members) per workgroup and list
     // ---- closed window ----

@@ -1813,7 +1813,7 @@ __device__ __forceinline__ void kw_capture(const Dev& d, u64* scratch_sum, u64* 
 #define KW_CH (KW_THREADS * KW_Q)
 #define KW_ROWS 512                                                  // rows per chunk with LDS accumulators (5 x u64 each: 20 KiB)
 #define KW_RESIDENT (3 * SG_LB_RESIDENT)                             // working chunks that are certainly resident together (<= 80 VGPRs, 21 KiB of LDS)
-__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* scratch_sum, u64* scratch_max) {
+__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* scratch_sum, u64* scratch_max, u64 seq) {
     extern __shared__ u64 kw_racc[];                                 // [KW_ROWS][5]: cnt, err, sum, ssq, max
     __shared__ u64 bal[KW_Q][KW_NW];
     __shared__ u32 wpre[KW_Q][KW_NW];
@@ -1841,6 +1841,10 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
         d.ctr[C_ACT_L] = SG_ACT_NONE; d.ctr[C_ACT_P] = 0;
         d.ctr[C_HUB_ITEMS] = 0;                                      // the hub blocks of the WINDOW's rows are listed behind this kernel (kw_finish_rows); a rebuild's were the kept rows'
         if (!d.ctr[C_COLD]) d.ctr[C_WARM_WINDOWS] += 1;
+        // for the host's policy (it never waits for the device: it reads this note, a window or two late, when it closes a later window)
+        d.host_note[1] = d.ctr[C_COLD] | (d.ctr[C_N_OBIP] ? 0x100ull : 0ull);
+        __threadfence_system();
+        d.host_note[0] = seq;
     }
     if (KE == 0) {                                                   // an empty kept set: an empty window
         for (u32 v = t; v <= N; v += KW_THREADS) d.rowptr[v] = 0;
