@@ -98,10 +98,10 @@ struct sg_engine {
     bool k1b_pack = false;                    // narrow pass B: count + duration sum of a record in one 64-bit LDS add (sn x nwg < 2^16)
     // warm windows (sg_device.h): the host only decides whether a window TRIES the warm path; whether it may is decided on the device
     bool warm_on = true;                      // sg_set_warm
-    u32 cold_streak = 0;                      // consecutive windows the host has seen fall back to the full rebuild
+    u32 cold_streak = 0;                      // consecutive windows whose warm attempt met an unknown key (C_COLD = 2), by the device's note
     u32 kw_epoch = 0;                         // kw_compact launch counter (tags its look-back words)
     u64 closes = 0; u32 timing_stride = 1;    // windows closed so far; the dispatch stamps of K1 (groups 1 and 7) are taken on every timing_stride-th window
-    u32 obip_streak = 0; u64 plain_left = 0;  // windows read in a row that raw outbound IPs kept cold; windows still to be closed without the kept-CSR detour
+    u32 obip_streak = 0; u64 plain_left = 0;  // windows in a row that raw outbound IPs kept cold (same note); windows still to be closed without the kept-CSR detour
     std::vector<char> plain_slot;             // per window slot: its last close was such a plain one (not counted as warm or cold)
     std::vector<u64*> h_note; std::vector<u64> note_seen;   // per window slot: the device's note (page-locked, mapped) and the sequence number last read from it
     std::vector<u64*> scr_sum, scr_max; std::vector<double*> scr_mu;   // per window slot: the node statistics the kept-CSR rebuild writes (scratch; row_mu | row_sd in one array)
@@ -431,11 +431,12 @@ void launch_halo_lists(sg_engine* e, hipStream_t s, u32* req, u32 capp) {
 int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union_n, u32 ob_mode = 1, u32 stride = 0, u32 gworld = 0) {
     int rc = sync_tables(e, s);
     if (rc) return rc;
-    // A stream whose every window carries raw outbound IPs (any protocol without a Host header talking to addresses outside the
-    // cluster: BASELINE config 5's Kafka / Postgres share) can never close warm — the ids of those nodes are ranks among the window's
-    // own — and would pay for the kept-CSR detour (rebuild into the kept arrays, then the compaction) every time.  Once the host has
-    // READ four such windows in a row it closes the next 64 as an engine without the state does (the kept state stays as it is: these
-    // windows do not touch it), then looks again.
+    // When the kept state does not pay, the window is closed as an engine without it does ("plain": the kept state stays as it is, these
+    // windows do not touch it), for a while, then the engine looks again.  Two such streams: every window carries raw outbound IPs (any
+    // protocol without a Host header talking to addresses outside the cluster — BASELINE config 5's Kafka / Postgres share: the ids of
+    // those nodes are ranks among the window's own, such a window can never close warm and would pay for the kept-CSR detour every time);
+    // every window brings edges the kept set lacks (the warm attempt is wasted and the rebuild carries the kept keys as well).  The host
+    // learns which path its windows took from the note kw_compact leaves in page-locked memory — it never waits for the device.
     Dev dloc = e->d;
     if (dloc.warm && (size_t)e->cur < e->note_seen.size()) {
         // what the device has said since we last looked (this slot's note; page-locked host memory the kw_compact of an earlier window wrote)
