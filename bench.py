@@ -298,7 +298,14 @@ def main():
             from alaz_amd import sharded
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            res = sharded.bench(a, rank, world, local)
+            try:
+                res = sharded.bench(a, rank, world, local)
+            except Exception as ex:                                  # noqa: BLE001
+                # one line saying what failed, on the real stdout, then the exception itself: a rank that exits non-zero makes
+                # torch.distributed.run end the others (they may be waiting for it in a collective)
+                os.write(saved_stdout, (json.dumps({"metric": "L7 edge-events/s ingested->scored service-map", "value": None, "unit": "events/s",
+                                                    "n_gpus": world, "rank": rank, "error": repr(ex)[:400]}) + "\n").encode())
+                raise
         else:
             res = bench_single(a, local)
     finally:
