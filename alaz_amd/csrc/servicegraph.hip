@@ -1135,11 +1135,12 @@ int stage_take(sg_engine* e) {
     }
     return -1;
 }
-// host (page-locked) -> device slot on the copy stream, K1 pass A behind it on the window's stream (engine lock held)
-int stage_submit(sg_engine* e, int slot, const sg_event* src, size_t n) {
+// the copy stream a batch's host -> device copy goes on (engine lock held; two streams alternate when the engine has two)
+hipStream_t stage_stream(sg_engine* e) { return (e->n_copy == 2 && (e->copy_rr++ & 1)) ? e->copy_stream2 : e->copy_stream; }
+// behind a slot's copy (already enqueued on `cs`, or refused): K1 pass A on the window's stream, the slot handed back (engine lock held)
+int stage_finish(sg_engine* e, int slot, size_t n, hipStream_t cs, bool copy_ok) {
     int rc = SG_OK;
-    hipStream_t cs = (e->n_copy == 2 && (e->copy_rr++ & 1)) ? e->copy_stream2 : e->copy_stream;
-    if (hipMemcpyAsync(e->d_stage[slot], src, n * sizeof(sg_event), hipMemcpyHostToDevice, cs) != hipSuccess) { e->err = "hipMemcpyAsync (staging ring)"; rc = SG_ENODEV; }
+    if (!copy_ok) { e->err = "hipMemcpyAsync (staging ring)"; rc = SG_ENODEV; }
     if (rc == SG_OK) {
         hipEventRecord(e->copied_ev[slot], cs);
         hipStreamWaitEvent(e->stream, e->copied_ev[slot], 0);
@@ -1151,6 +1152,16 @@ int stage_submit(sg_engine* e, int slot, const sg_event* src, size_t n) {
     e->cv.notify_all();
     return rc;
 }
+// host (page-locked) -> device slot on the copy stream in one piece, K1 pass A behind it (engine lock held)
+int stage_submit(sg_engine* e, int slot, const sg_event* src, size_t n) {
+    hipStream_t cs = stage_stream(e);
+    const bool ok = hipMemcpyAsync(e->d_stage[slot], src, n * sizeof(sg_event), hipMemcpyHostToDevice, cs) == hipSuccess;
+    return stage_finish(e, slot, n, cs, ok);
+}
+// sg_ingest moves a batch in pieces of this many events (4 MiB): each piece is on the link while the calling thread copies the next
+// into the pinned slot.  One 32 MiB batch copied whole keeps the link idle for the 3 ms a thread needs for it — at every window
+// boundary, where all feeders start a batch at the same moment, that was a third of the window (bench.py end_to_end)
+constexpr size_t kStagePiece = ((size_t)4 << 20) / sizeof(sg_event);
 }  // namespace
 
 int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
@@ -1164,12 +1175,20 @@ int sg_ingest(sg_handle e, const sg_event* events, size_t n) {
         e->st.events_dropped_ring += n;
         return SG_EAGAIN;
     }
+    hipStream_t cs = stage_stream(e);
     g.unlock();
     // the caller's memory is not retained; the copy into the pinned slot runs OUTSIDE the engine lock, so several
-    // feeder threads (goroutines on different OS threads) fill different slots at the same time
-    std::memcpy(e->h_stage[slot], events, n * sizeof(sg_event));
+    // feeder threads (goroutines on different OS threads) fill different slots at the same time — and piece by piece,
+    // every piece sent on its way as soon as it is in the slot (the slot is this thread's until stage_finish hands it back;
+    // the stream calls need no engine state)
+    bool ok = true;
+    for (size_t o = 0; o < n && ok; o += kStagePiece) {
+        const size_t m = std::min(kStagePiece, n - o);
+        std::memcpy(e->h_stage[slot] + o, events + o, m * sizeof(sg_event));
+        ok = hipMemcpyAsync(e->d_stage[slot] + o, e->h_stage[slot] + o, m * sizeof(sg_event), hipMemcpyHostToDevice, cs) == hipSuccess;
+    }
     g.lock();
-    return stage_submit(e, slot, e->h_stage[slot], n);
+    return stage_finish(e, slot, n, cs, ok);
 }
 
 // The same without the staging copy, for events that already sit in page-locked memory: memory registered with

@@ -686,7 +686,7 @@ def end_to_end(g, ev_all, Ev, nb, feeders, E, pinned=False, serial=False):
             "pcie_measured_GBs": {"h2d": round(h2d, 1), "d2h": round(d2h, 1)}, "pcie_bound_ms_per_window": round(link_ms, 3),
             "frac_of_pcie_bound": round(link_ms / (dt / nwin * 1e3), 3),
             "pcie_duplex_ms_per_window": round(duplex_ms, 3), "frac_of_duplex_bound": round(duplex_ms / (dt / nwin * 1e3), 3),
-            "includes": ([] if pinned else ["memcpy into pinned staging ring"]) + ["h2d (own stream, overlapping K1a of the previous batch)", "K1a per 256k-event batch", "K1b..K5", "d2h of the scored rows into page-locked host memory (sg_flush_begin / sg_flush_end_view: beside the next window's feed)", "window reset"],
+            "includes": ([] if pinned else ["memcpy into pinned staging ring"]) + ["h2d (own stream, overlapping K1a of the previous batch)", f"K1a per staging batch ({chunk} events, copied and sent in 4 MiB pieces)", "K1b..K5", "d2h of the scored rows into page-locked host memory (sg_flush_begin / sg_flush_end_view: beside the next window's feed)", "window reset"],
             "rows_per_window": rows_n, "rows_by_window": rows_seen, "ring_full_retries": int(sum(retries)), "events_dropped_ring": dropped_ring,
             "bound": f"PCIe: 32 B/event host->device + 64 B/edge device->host ({(32.0 * Ev + 64.0 * E) / 1e6:.0f} MB per window) at the measured one-direction rates; duplex = the larger of the two alone (measured: the H2D slows down while the D2H runs)"}
 
