@@ -256,7 +256,8 @@ int sg_load_weights(sg_handle h, const float* w, size_t n);
 
 /* ---- ingest: replaces processL7 .. setFromToV2 .. PersistRequest for the edge fields ------ *
  * sg_ingest copies n events from host memory into the engine's pinned staging ring, uploads
- * them and launches K1 asynchronously.  Non-blocking: a full ring drops the batch, counts it
+ * them (in 4 MiB pieces, each on the link while the caller's thread copies the next) and
+ * launches K1 asynchronously.  Non-blocking: a full ring drops the batch, counts it
  * and returns SG_EAGAIN (the reference's PersistRequest would block here, backend.go:844).      */
 int sg_ingest(sg_handle h, const sg_event* events, size_t n);
 
