@@ -183,11 +183,14 @@ def _run_window(be, comm, fused_reset: bool = False) -> None:
 # ------------------------------------------------------------------------------------------------
 # the same sequence through the C sequencer (alaz_amd/csrc/shard_seq.hpp)
 # ------------------------------------------------------------------------------------------------
-def run_window_c(be, comm=None) -> None:
+def run_window_c(be, comm=None, grouped: bool = False, trace=None) -> None:
     """The window sequence of `_run_window`, but issued by the C function the engine library itself runs inside
     sg_window_run_sharded (sg_run_sharded_window, exported by libsgdatastore.so as sgh_run_sharded_window): the stages are
     callbacks into `be`, the collectives callbacks into `comm`.  The HIP engine does not need this detour (it has
-    sg_window_run_sharded with RCCL inside); it exists so that the C sequence itself is driven by the CPU tests (gloo)."""
+    sg_window_run_sharded with RCCL inside); it exists so that the C sequence itself is driven by the CPU tests (gloo).
+    grouped: hand the sequencer group_begin / group_end callbacks that behave as ncclGroupStart / ncclGroupEnd do — the all-reduces
+    issued between them are only RECORDED and run when the group ends (what the RCCL communicator of sg_window_run_sharded does with
+    the SUM and MAX statistics).  trace (a list): the order of the communicator calls the sequencer made."""
     import ctypes as C
     from . import hostlib
     comm = comm if comm is not None else DistComm()
@@ -209,7 +212,7 @@ def run_window_c(be, comm=None) -> None:
 
     class Comm(C.Structure):
         _fields_ = [("ctx", C.c_void_p), ("all_gather", GATHER), ("all_reduce_u64", REDUCE), ("all_to_all", GATHER),
-                    ("group_begin", C.c_void_p), ("group_end", C.c_void_p)]      # (optional grouping of the two statistics all-reduces: null here)
+                    ("group_begin", STAGE0), ("group_end", STAGE0)]              # (optional grouping of the two statistics all-reduces: null unless `grouped`)
 
     class Stages(C.Structure):
         _fields_ = [("ctx", C.c_void_p), ("layers", C.c_uint32), ("world", C.c_uint32),
@@ -234,13 +237,31 @@ def run_window_c(be, comm=None) -> None:
     def per_rank(t):
         return t.numel() * t.element_size() // world
 
+    note = trace.append if trace is not None else (lambda _x: None)
+    group = {"open": False, "held": []}
+
     def c_gather(_ctx, send, recv, nbytes):
-        comm.all_gather_into(by_ptr[recv], by_ptr[send])
+        note("all_gather"); comm.all_gather_into(by_ptr[recv], by_ptr[send])
     def c_reduce(_ctx, buf, count, op):
-        comm.all_reduce_(by_ptr[buf], "max" if op else "sum")
+        note("all_reduce_max" if op else "all_reduce_sum")
+        if group["open"]: group["held"].append((buf, op))            # (inside a group nothing runs before the group ends)
+        else: comm.all_reduce_(by_ptr[buf], "max" if op else "sum")
     def c_a2a(_ctx, send, recv, nbytes):
-        comm.all_to_all_equal(by_ptr[recv], by_ptr[send])
+        note("all_to_all"); comm.all_to_all_equal(by_ptr[recv], by_ptr[send])
+    def c_group_begin(_ctx):
+        note("group_begin")
+        if group["open"]: raise RuntimeError("group_begin inside a group")
+        group["open"] = True
+    def c_group_end(_ctx):
+        note("group_end")
+        if not group["open"]: raise RuntimeError("group_end without group_begin")
+        group["open"] = False
+        held, group["held"] = group["held"], []
+        for buf, op in held:
+            comm.all_reduce_(by_ptr[buf], "max" if op else "sum")
     cm = Comm(None, GATHER(guard(c_gather)), REDUCE(guard(c_reduce)), GATHER(guard(c_a2a)))
+    if grouped:
+        cm.group_begin, cm.group_end = STAGE0(guard(c_group_begin)), STAGE0(guard(c_group_end))
     st = Stages()
     st.layers, st.world = layers, world
     st.obip_list = STAGE0(guard(lambda _c: bufs["ob_local"].copy_(be.ob_local())))
@@ -263,6 +284,8 @@ def run_window_c(be, comm=None) -> None:
         raise errs[0]
     if rc != 0:
         raise RuntimeError(f"sgh_run_sharded_window returned {rc}")
+    if group["open"] or group["held"]:
+        raise RuntimeError("the sequencer left a collective group open")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -48,21 +48,25 @@ def _worker(rank, world, port, layers, q, c_sequencer=False):
         be = NumpyBackend(pod_ip_to_id=pod, svc_ip_to_id=svc, kind=kind, n_labels=len(labels), weights=weights.make_weights(layers),
                           layers=layers, rank=rank, world=world, ncap=topo.n_nodes + len(labels) + 64)
         be.ingest(ev[shard == rank])
-        if c_sequencer: sharded.run_window_c(be)             # the C function sg_window_run_sharded runs (shard_seq.hpp), collectives = gloo
+        calls = []
+        if c_sequencer:                                      # the C function sg_window_run_sharded runs (shard_seq.hpp), collectives = gloo
+            sharded.run_window_c(be, grouped=c_sequencer == "grouped", trace=calls)
         else: sharded.run_window(be)
-        q.put((rank, be.rows, be.misrouted, be.N, [int(x) for x in be.ob], [int(x) for x in be.alive_csr]))
+        q.put((rank, be.rows, be.misrouted, be.N, [int(x) for x in be.ob], [int(x) for x in be.alive_csr], calls))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,layers,c_sequencer", [(2, 1, False), (2, 1, True), (2, 2, False), (2, 2, True),
-                                                      (3, 2, True), (4, 2, True), (4, 1, False)])
+                                                      (3, 2, True), (4, 2, True), (4, 1, False), (2, 2, "grouped"), (3, 1, "grouped")])
 def test_shards_equal_unsharded_oracle(world, layers, c_sequencer):
     """Two, three and four gloo processes close a window together — through the Python driver (run_window) and through the C
     sequencer the engine's one-call entry point sg_window_run_sharded is built on (sgh_run_sharded_window) — and must reproduce
     the unsharded oracle row for row.  (Three: ownership modulo a number that is not a power of two; four: every shard serves
-    halo rows to several peers in one all-to-all.)"""
+    halo rows to several peers in one all-to-all.  "grouped": the communicator has group_begin / group_end with ncclGroupStart / End
+    semantics — all-reduces issued inside a group run only when it ends — as the RCCL communicator of sg_window_run_sharded has:
+    the sequencer must not read the statistics before the group has ended, and must bracket exactly the SUM and the MAX.)"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -73,6 +77,11 @@ def test_shards_equal_unsharded_oracle(world, layers, c_sequencer):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    if c_sequencer:                                          # the communicator calls of one window, in the order shard_seq.hpp documents
+        grp = c_sequencer == "grouped"
+        seq = ["all_gather"] + (["group_begin"] if grp else []) + ["all_reduce_sum", "all_reduce_max"] + (["group_end"] if grp else []) \
+            + ["all_to_all"] * (1 + layers)
+        assert all(g[6] == seq for g in got)
     topo, ev, labels = _trace(layers)
     o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(weights.make_weights(layers), layers)
     want = o.edge_rows()
