@@ -197,10 +197,12 @@ bool k1a_geometry(sg_engine* e) {
         const char* kv = std::getenv("SG_K1A");
         const bool want_tile = kv && !std::strcmp(kv, "tile"), force_team = kv && !std::strcmp(kv, "team");
         const size_t fixed_tile = (size_t)d.np * 24 + 64 + (size_t)K1T_TS(e->k1a_nsub) * 8 + l1b;
-        // the two-team kernel is instantiated for 256 / 512 / 1024 partitions, 768 threads, the one-thread-per-position copy-out (2 nb <= 31)
-        // and a join blob its prologue can stage; everything else keeps the one-team kernel
-        const int teams = 2, nt = 768;
-        // (what the team kernel's prologue can stage: six 16-byte words per lane of ITS 768 threads.  Level 1 always goes through it, level 2
+        // the two-team kernel is instantiated for 256 / 512 / 1024 partitions, 1024 threads (two teams of eight waves, one group of four events
+        // per thread and tile: round 6; round 4 ran two groups at 768 threads), the one-thread-per-position copy-out (2 nb <= 31) and a join
+        // blob its prologue can stage; everything else keeps the one-team kernel
+        const int teams = 2, nt = 1024;
+        const size_t lds_cap = kLdsBytes;
+        // (what the team kernel's prologue can stage: six 16-byte words per lane of its threads.  Level 1 always goes through it, level 2
         // only when it is staged — an engine whose level 2 stays in global memory needs room for level 1 alone)
         const size_t stage_team = (size_t)K1A_NJ * nt * 16;
         const bool team_ok = (d.np == 256 || d.np == 512 || d.np == 1024) && 2 * d.nb <= 31 && (size_t)d.np * d.nwg * d.punits * 8 < ((size_t)1 << 31) && l1b <= stage_team;
@@ -209,8 +211,8 @@ bool k1a_geometry(sg_engine* e) {
         auto pick = [&](size_t fixed, u32 ct_min, size_t stage_cap, u32& ct, bool& in_lds) {
             ct = 0; in_lds = false;
             // (the cache flattens the hottest keys; beyond 1024 slots it costs more aggregates than it saves records)
-            for (u32 c : {1024u, 512u, 256u, 128u}) if (c >= ct_min && (size_t)c * 40 + fixed + l2lds <= kLdsBytes && l1b + l2b <= stage_cap) { in_lds = true; ct = c; break; }
-            if (!ct) for (u32 c : {1024u, 512u, 256u, 128u, 64u}) if (c >= ct_min && (size_t)c * 40 + fixed <= kLdsBytes) { ct = c; break; }
+            for (u32 c : {1024u, 512u, 256u, 128u}) if (c >= ct_min && (size_t)c * 40 + fixed + l2lds <= lds_cap && l1b + l2b <= stage_cap) { in_lds = true; ct = c; break; }
+            if (!ct) for (u32 c : {1024u, 512u, 256u, 128u, 64u}) if (c >= ct_min && (size_t)c * 40 + fixed <= lds_cap) { ct = c; break; }
         };
         u32 ct = 0; bool in_lds = false;
         e->k1a_team = false;
@@ -218,8 +220,8 @@ bool k1a_geometry(sg_engine* e) {
         if (!ct) pick(fixed_tile, 64u, stage_max, ct, in_lds);
         const size_t fixed = e->k1a_team ? fixed_team : fixed_tile;
         e->l2_in_lds = in_lds;
-        if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2lds : 0) <= kLdsBytes) ct = x; }
         if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
+        if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2lds : 0) <= lds_cap) ct = x; }
         if (!ct || l1b > stage_max) return false;
         e->k1a_ct = ct;
         e->k1a_lds = (size_t)ct * 40 + fixed + (e->l2_in_lds ? l2lds : 0);
@@ -336,9 +338,9 @@ int launch_k1(sg_engine* e, const sg_event* d_ev, size_t n, hipStream_t s) {
 #define K1A_GO2(L2, SH) do { if (e->d.hist) K1A_GO(L2, SH, true); else K1A_GO(L2, SH, false); } while (0)
 #define K1T_GO(L2, SH, NS) hipExtLaunchKernelGGL((k1a_tile_partition<L2, SH, NS>), dim3(e->d.nwg), dim3(K1T_THREADS), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n)
 #define K1T_GO2(L2, SH) do { if (e->k1a_nsub == 2) K1T_GO(L2, SH, 2); else K1T_GO(L2, SH, 1); } while (0)
-#define K1M_GO(L2, SH) do { if (e->d.np == 256) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 8>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
-                            else if (e->d.np == 512) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 9>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
-                            else hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 768, 10>), dim3(e->d.nwg), dim3(768), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); } while (0)
+#define K1M_GO(L2, SH) do { if (e->d.np == 256) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 1024, 8>), dim3(e->d.nwg), dim3(1024), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
+                            else if (e->d.np == 512) hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 1024, 9>), dim3(e->d.nwg), dim3(1024), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); \
+                            else hipExtLaunchKernelGGL((k1a_team_partition<L2, SH, 2, 1024, 10>), dim3(e->d.nwg), dim3(1024), (uint32_t)e->k1a_lds, s, ta, tb, 0u, da, d_ev, (u64)n); } while (0)
         da.k1a_rot = e->d.k1a_rot;
         rot0 = e->d.k1a_rot; tb0 = e->d.k1a_ticket_base;           // (restored below when the launch is refused: the device counter only moves if the kernel runs)
         if (e->d.narrow && !e->k1a_team) {                           // the next launch's first chunk goes to the workgroup behind this launch's last one
@@ -864,15 +866,15 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
                               reinterpret_cast<const void*>(k1a_tile_partition<2, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<2, false, 1>),
                               reinterpret_cast<const void*>(k1a_tile_partition<1, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<1, false, 1>),
                               reinterpret_cast<const void*>(k1a_tile_partition<0, true, 1>), reinterpret_cast<const void*>(k1a_tile_partition<0, false, 1>),
-                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 768, 8>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 768, 8>),
-                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 768, 9>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 768, 9>),
-                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 768, 10>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 768, 10>),
-                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 768, 8>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 768, 8>),
-                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 768, 9>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 768, 9>),
-                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 768, 10>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 768, 10>),
-                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 768, 8>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 768, 8>),
-                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 768, 9>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 768, 9>),
-                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 768, 10>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 768, 10>)})
+                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 1024, 8>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 1024, 8>),
+                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 1024, 9>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 1024, 9>),
+                              reinterpret_cast<const void*>(k1a_team_partition<2, true, 2, 1024, 10>), reinterpret_cast<const void*>(k1a_team_partition<2, false, 2, 1024, 10>),
+                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 1024, 8>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 1024, 8>),
+                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 1024, 9>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 1024, 9>),
+                              reinterpret_cast<const void*>(k1a_team_partition<1, true, 2, 1024, 10>), reinterpret_cast<const void*>(k1a_team_partition<1, false, 2, 1024, 10>),
+                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 1024, 8>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 1024, 8>),
+                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 1024, 9>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 1024, 9>),
+                              reinterpret_cast<const void*>(k1a_team_partition<0, true, 2, 1024, 10>), reinterpret_cast<const void*>(k1a_team_partition<0, false, 2, 1024, 10>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
         for (const void* f : {reinterpret_cast<const void*>(k1b_merge<4, false>), reinterpret_cast<const void*>(k1b_merge<8, false>), reinterpret_cast<const void*>(k1b_merge<4, true>),
                               reinterpret_cast<const void*>(k1b_merge_wide<4, false>), reinterpret_cast<const void*>(k1b_merge_wide<8, false>), reinterpret_cast<const void*>(k1b_merge_wide<4, true>),
@@ -1073,7 +1075,7 @@ int sg_geometry_get(sg_handle e, sg_geometry* out) {
     const Dev& d = e->d;
     out->k1_variant = d.variant; out->k1_narrow = d.narrow; out->partitions = d.np; out->table_slots = d.k1b_ht; out->pass_b_split = d.k1b_split;
     out->pass_a_workgroups = d.nwg; out->cache_slots = e->k1a_ct; out->join_l2_in_lds = e->l2_in_lds ? (e->d.narrow && e->l2_u16 ? 2u : 1u) : 0u;
-    out->tile_records = d.narrow ? (e->k1a_team ? 8u * e->k1a_nt / e->k1a_teams : K1T_TS(e->k1a_nsub)) : 0u; out->pass_a_teams = d.narrow && e->k1a_team ? e->k1a_teams : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
+    out->tile_records = d.narrow ? (e->k1a_team ? 4u * e->k1a_nt / e->k1a_teams : K1T_TS(e->k1a_nsub)) : 0u; out->pass_a_teams = d.narrow && e->k1a_team ? e->k1a_teams : 0u; out->endpoint_bits = d.narrow ? d.nb : 0u;
     out->piece_bytes = d.variant != 0 ? 0u : (d.narrow ? d.punits * 8u : d.pslots * 16u);
     out->warm_windows = d.warm;
     return SG_OK;

@@ -1,54 +1,55 @@
-// sg_k1_team.h — K1 pass A, round 4: k1a_team_partition.  Included by sg_kernels.h behind sg_k1_narrow.h (whose record
-// format, pieces, cache and emit_* helpers it shares; pass B is unchanged).
+// sg_k1_team.h — K1 pass A: k1a_team_partition (round 4; one group per tile and sixteen waves since round 6).  Included by sg_kernels.h
+// behind sg_k1_narrow.h (whose record format, pieces, cache and emit_* helpers it shares).
 //
 // Same job as k1a_tile_partition (extractAddressPair + setFromToV2 + ReverseDirection + the per-request PersistRequest,
-// aggregator/data.go:1760-1767, 827-870; datastore/dto.go:226-231; backend.go:819-847), restructured around what round 3's
-// counters and round 4's issue-rate probe (profiles/r04_a_rate_probe.txt) say about it:
+// aggregator/data.go:1760-1767, 827-870; datastore/dto.go:226-231; backend.go:819-847), built around what the counters and the
+// issue-rate probe (profiles/r04_a_rate_probe.txt) say about it:
 //
-//   * the kernel is LATENCY-bound, not issue-bound: its waves issue in 20 % of their cycles, wait for an issue slot in 24 % and
-//     are parked at s_waitcnt / s_barrier for 56 %; the VALU pipes take a wave64 integer instruction every 1.25 cycles from four
-//     waves per SIMD (one wave alone issues one per 5 cycles), the LDS serves a random ds_read_b64 / returning ds_add_u32 in 4-5
-//     cycles per wave-instruction at 16 waves per CU.  So:
-//   * TWO TEAMS of eight waves per workgroup, each sorting its own tiles (own tile, run counters, offsets; software team barrier
-//     on an LDS counter — gfx950 has one hardware barrier per workgroup).  While one team waits for its events, scans or copies
-//     runs out, the other one joins.  They share the join tables, the edge cache and the piece counters (a tile's runs get
-//     their piece positions by returning LDS adds), so pass B sees the same 256 pieces per partition as before;
-//   * the join / key / cache probe of a group's four events is BATCHED and branch-free: four dependent LDS round trips per
-//     group (level 1, level 2, cache bucket, run rank) instead of four per event, the rank taken by an unconditional returning
-//     add of 0 or 1, drop / label statistics kept in registers; only cache claims (a few hundred per launch), cache folds and
-//     rare events branch, each behind one wave ballot;
-//   * the second group's loads of a tile are in flight while the first group is joined (two register sets).
-// Integer adds / max only: bit-exact whatever the order (the three pass-A kernels run the same parity tests).
+//   * its waves issue in ~20 % of their cycles and are parked at s_waitcnt / s_barrier for more than half; one wave alone issues an integer
+//     VALU instruction per 5 cycles, four waves per SIMD one per 1.25; the LDS serves a random ds_read_b64 / returning ds_add_u32 in
+//     4-5 cycles per wave-instruction.  So:
+//   * TWO TEAMS of eight waves per workgroup, each sorting its own tiles (own tile, run counters, offsets; software team barrier on an
+//     LDS counter — gfx950 has one hardware barrier per workgroup).  While one team waits for its events, scans or copies runs out, the
+//     other one joins.  They share the join tables, the edge cache and the piece counters (a tile's runs get their piece positions by
+//     returning LDS adds), so pass B sees the same 256 pieces per partition;
+//   * the join / key / cache probe of a PAIR of events is batched and branch-free (level 1 of all four addresses, level 2, cache
+//     buckets, run ranks: four dependent LDS round trips per pair), the rank taken by an unconditional returning add of 0 or 1;
+//     only cache claims (a few hundred per launch), cache folds and rare events branch, each behind one wave ballot;
+//   * ONE group of four events per thread and tile.  Round 4 kept two groups in flight (eight parked records per thread: 168
+//     registers, 768 threads = twelve waves per CU, 6144-event tiles — a team drew three or four of them per launch); with one group
+//     the kernel fits 128 registers without a spill, 1024 threads = sixteen waves, and 2048-event tiles are handed out nine or ten
+//     per team (round 6, same box: 134.0 -> 127.2 us at C3).  Measured beside it and rejected: TWO workgroups per CU of 768 / 640 /
+//     512 threads (80 / 96 / 128 registers, 512 pieces per partition: pass A 141-222 us, pass B +35 us for the 512 headers; level 2
+//     of the join read from global memory instead of a second LDS copy: 187 us) — docs/HISTORY.md.
+// Integer adds / max only: bit-exact whatever the order (the pass-A kernels run the same parity tests).
 #pragma once
 
 #define K1M_OOB     0x80000000u   // buffer offset of a lane without work (out of range of every buffer the kernel addresses)
 #define K1M_RARE    0xFFFFFFFEu   // parked-record tag: a rare event, joined by the general path at the end of its tile
-// LDS besides the cache and the join tables: piece counters + per team 4 counter arrays, statistics + barrier words, tile(s) of 8 records per thread (+ trash words)
-#define K1M_LDS_FIXED(np, teams, nt) ((size_t)(np) * 4 * (2 + 4 * (teams)) + 128 + ((size_t)(nt) * 8 + 4) * 8)
+// LDS besides the cache and the join tables: piece counters + per team 4 counter arrays, statistics + barrier words, tile(s) of 4 records per thread (+ trash words)
+#define K1M_LDS_FIXED(np, teams, nt) ((size_t)(np) * 4 * (2 + 4 * (teams)) + 128 + ((size_t)(nt) * 4 + 4) * 8)
 
 // tiles of a launch of n events (the kernel's own arithmetic, for the host's ticket accounting)
 static inline unsigned long long k1m_tiles(unsigned long long n, unsigned nwg, unsigned teams, unsigned nt) {
     const unsigned long long units = (unsigned long long)teams * nwg, tt = nt / teams, per = (n + units - 1) / units;
     const unsigned long long grp = per >= 4 * tt ? 4 * tt : (per + tt - 1) / tt * tt;
-    const unsigned long long ngroup = (n + grp - 1) / grp;
-    return (ngroup + 1) >> 1;
+    return (n + grp - 1) / grp;                                      // a tile = one group
 }
 // L2M: level 2 of the join 0 = read from global memory, 1 = staged in LDS as u32, 2 = staged as u16 entries kind << 14 | id
 // TEAMS: 2 = two teams (software team barriers), 1 = one team (the hardware barrier; same code otherwise: the A/B).
-// NT: threads per workgroup, 1024 (four waves per SIMD: 128 registers per lane) or 768 (three waves per SIMD: 168 registers — the batched
-// join of four events beside eight parked records does not fit 128 without spilling ~60 of them, and a scratch reload's vmcnt(0) also
-// waits for the event loads in flight).
+// NT: threads per workgroup: 1024 (four waves per SIMD, 128 registers per lane; the kernel uses 115, no scratch).
 // NPB: log2 of the partition count, a compile-time constant: every counter array then sits at a constant LDS offset and the scan is
 // straight-line code (with a run-time count the scan's quad loop branched per quad and its piece bases were spilled to scratch — whose
 // reload waits for vmcnt(0), i.e. for the previous tile's copy-out stores to reach memory: 3 us per scan).
 template <int L2M, bool SHARDED, int TEAMS, int NT, int NPB>
 __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* __restrict__ ev, u64 n) {
     constexpr u32 K1M_THREADS = NT;
-    constexpr u32 K1M_TILE_ALL = 8 * NT;                             // records in the workgroup's tile(s)
+    constexpr u32 K1M_TILE_ALL = 4 * NT;                             // records in the workgroup's tile(s)
     constexpr u32 K1M_TT = K1M_THREADS / TEAMS;                      // threads per team
     constexpr u32 K1M_TW = K1M_TT / 64;                              // waves per team
     constexpr u32 K1M_GROUP = 4 * K1M_TT;                            // events per group at most: four per thread of a team
-    constexpr u32 K1M_TS = K1M_TILE_ALL / TEAMS;                     // records per team tile: two groups
+    constexpr u32 K1M_TS = K1M_TILE_ALL / TEAMS;                     // records per team tile: one group
+    constexpr u32 K1M_NR = 4;                                        // records a thread parks per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 CT = d.k1a_ct;
     constexpr u32 NP = 1u << NPB;
@@ -77,13 +78,13 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     u64* tile = tiles + team * (K1M_TS + 2);
     u32* mybar = bar + 8 * team;
     const uint4* __restrict__ pe = reinterpret_cast<const uint4*>(ev);
-    // The batch is cut into groups of g <= 2048 events (a multiple of 512: up to four events per thread of a team); a tile = two
-    // consecutive groups; tile j belongs to unit j % (TEAMS nwg), unit = team * nwg + workgroup — so that at any moment the 512 units read one
+    // The batch is cut into groups of g <= 2048 events (a multiple of 512: up to four events per thread of a team); a tile = one
+    // group; tile j belongs to unit j % (TEAMS nwg), unit = team * nwg + workgroup — so that at any moment the 512 units read one
     // contiguous stretch of the batch and a small batch still reaches every workgroup (the pieces of a window fed by many small batches fill evenly).
     const u32 units = (u32)TEAMS * d.nwg;
     const u64 per = (n + units - 1) / units;
     const u32 grp = per >= K1M_GROUP ? K1M_GROUP : (u32)((per + K1M_TT - 1) / K1M_TT * K1M_TT);
-    const u64 ngroup = (n + grp - 1) / grp, ntile = (ngroup + 1) >> 1;
+    const u64 ngroup = (n + grp - 1) / grp, ntile = ngroup;              // a tile = one group
     // (rotated by the tiles of the window's earlier launches: many small batches must not all land on the pieces of the first workgroups)
     const u32 rot = d.k1a_rot % units;
     const u32 unit = (team * d.nwg + w + units - rot) % units, unit_other = ((1u - team) * d.nwg + w + units - rot) % units;
@@ -93,6 +94,14 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
         return;
     }
     SG_STAMP(d, 0, 0);
+    // Everything rare (the general path, the overflow list, the cache flush) reads its share of the ~100 Dev fields from the kernel
+    // argument segment WHERE it runs (Dev is argument 0; the pointer is made opaque, so the scalar loads cannot be hoisted to the kernel's
+    // entry) — held in SGPRs from the entry on they were most of ~230 live scalars, 120 of them spilled to VGPR lanes inside the tile loop.
+    auto kd = [&]() -> const Dev& {
+        const __attribute__((address_space(4))) Dev* kp = (const __attribute__((address_space(4))) Dev*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return *(const Dev*)kp;
+    };
     const bool clk_me = w == 0 && t == 0;                            // the shader clock this launch ran at (sg_clock_probe)
     const u64 clk_c0 = clk_me ? __builtin_readcyclecounter() : 0ull, clk_r0 = clk_me ? wall_clock64() : 0ull;
     // statistics in registers: accepted events, their time-stamp range, drops for a non-pod source, largest label; what the general path and the
@@ -123,24 +132,6 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
         asm volatile("" : : : "memory");
     };
 
-    // The events of a group: (first) + tq + k * TT, k = 0..3, for the thread index tq, while below the group's count.  Buffer loads: a lane
-    // beyond the count gets an out-of-range offset and the hardware returns zeros without touching memory — no 64-bit address select per load, no
-    // re-read of a dummy event (it is ignored by its in-range flag anyway).  Two 16-byte halves per event, one offset register.
-    // (K1M_OOB, the offset of a lane without work: 2 GiB — every buffer here is shorter (the host sees to it).  NOT ~0: the range check adds
-    // the access size with 32-bit wrap-around, 0xFFFFFFFF + 8 = 7 is "in range" and the store lands 4 GiB behind the base: a memory fault.)
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t ev_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<sg_event*>(ev), 0, (int)(u32)(n * 32u), 0x00020000);
-#ifdef SG_K1M_BUFFER_LOADS
-#define K1M_LD(A, B, vo) asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16" : "=&v"(A), "=&v"(B) : "v"(vo), "s"(ev_rsrc) : "memory")
-#else
-    // (measured: the same loads as buffer_load ... offen made the launch 178 us instead of ~120 on one box; plain global loads, the
-    // address of a lane without work = the batch's first event, ignored by its in-range flag)
-#define K1M_LD(A, B, vo) { const uint4* q_ = pe + ((vo) == K1M_OOB ? 0u : ((vo) >> 4)); gload16_issue(A, q_); gload16_issue(B, q_ + 1); }
-#endif
-#define K1M_ISSUE(S, tq, first, count)                                                                                  \
-        { const u32 x0 = (tq), x1 = x0 + K1M_TT, x2 = x1 + K1M_TT, x3 = x2 + K1M_TT, fb = (first) * 32u;                  \
-          const u32 o0 = x0 < (count) ? fb + x0 * 32u : K1M_OOB, o1 = x1 < (count) ? fb + x1 * 32u : K1M_OOB;               \
-          const u32 o2 = x2 < (count) ? fb + x2 * 32u : K1M_OOB, o3 = x3 < (count) ? fb + x3 * 32u : K1M_OOB;               \
-          K1M_LD(ea##S##0, eb##S##0, o0); K1M_LD(ea##S##1, eb##S##1, o1); K1M_LD(ea##S##2, eb##S##2, o2); K1M_LD(ea##S##3, eb##S##3, o3); }
     // cache fold of one accepted event into a slot it owns
     auto cache_add = [&](u32 slot, u64 dur, u32 err) {
         u64 ssq;
@@ -154,6 +145,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     // (where nothing of the batched fast path is live); the event is read again — it is rare and in L2.  Its record does not join the tile:
     // a narrow record takes its piece position from the shared counter, like the cache flush's.
     auto general = [&](const u64 idx) {
+        const Dev& d = kd();                                         // (shadows the kernel's copy: see kd)
         const uint4* q2 = pe + 2 * idx;
         const uint4 xa = q2[0], xb = q2[1];
         K1Ev e;
@@ -174,45 +166,42 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     };
     constexpr u32 KSH = L2M == 2 ? 14u : 30u, IDM = L2M == 2 ? 0x3FFFu : 0x3FFFFFFFu;   // kind shift / id mask of a level-2 entry as this build reads it
 
-    // ---- one group of four events per thread: the batched fast path, in two halves ------------------------------------
-    // front: both joins (two-level block table in LDS: level 1 of all eight addresses, then level 2), data.go:827-870 as selects, error rule,
-    //        time stamps, key mix.  Leaves per event: the mixed key halves, the duration's low word and three flag bits — the events'
-    //        32 registers are dead behind it (a rare event is re-read from memory by the general path), so the next group's loads can be issued.
-    // back:  cache bucket reads, claims (one ballot), the run ranks (unconditional returning adds of 0 or 1), folds, parked records; rare events.
 #define K1M_F_ACC 1u
 #define K1M_F_RARE 2u
 #define K1M_F_ERR 4u
-    auto front4 = [&](const u32 tq, const u32 gcount, const v4u_t A0, const v4u_t B0, const v4u_t A1, const v4u_t B1, const v4u_t A2, const v4u_t B2,
-                      const v4u_t A3, const v4u_t B3, u32 (&Lm)[4], u32 (&Rm)[4], u32 (&dur)[4], u32 (&fl)[4]) {
-        const v4u_t A[4] = {A0, A1, A2, A3}, B[4] = {B0, B1, B2, B3};
-        u32 vs[4], vd[4];
-        {   // sources: level 1 (two independent ds_read_b64 per address), then level 2 — whose reads fly while the destinations' level 1 is fetched
-            u64 s1[4], s2[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) { const u32 b = A[i].x >> 8; s1[i] = l1[(__umul24(b, SG_JL1_K1) >> 9) & jm]; s2[i] = l1[(__umul24(b, SG_JL1_K2) >> 11) & jm]; }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32 b = A[i].x >> 8;
-                const u32 blk = (u32)s1[i] == b ? (u32)(s1[i] >> 32) : ((u32)s2[i] == b ? (u32)(s2[i] >> 32) : 0u);     // block 0 = the all-zero block
-                const u32 ix = (blk << 8) | (A[i].x & 255u);
-                vs[i] = L2M == 2 ? (u32)l2h[ix] : l2[ix];
-            }
-        }
+    // ---- a PAIR of events: the batched fast path, in two halves -----------------------------------------------------
+    // front: both joins (two-level block table in LDS: level 1 of all four addresses — eight independent ds_read_b64 —, then level 2),
+    //        data.go:827-870 as selects, error rule, time stamps, key mix.  Leaves per event: the mixed key halves, the duration's low word
+    //        and three flag bits (a rare event is re-read from memory by the general path).
+    // back:  cache bucket reads, claims (one ballot), the run ranks (unconditional returning adds of 0 or 1), folds, parked records.
+    // (round 4 batched four events per step — four dependent LDS round trips per group of four — at 168 registers and twelve waves per
+    // CU; two per step fit 128 registers without a spill: sixteen waves, and the round trips a pair leaves exposed are another wave's
+    // issue slots.)  i0: index of the pair's first event in the group (0 or 2).
+    auto front2 = [&](const u32 tq, const u32 i0, const u32 gcount, const v4u_t A0, const v4u_t B0, const v4u_t A1, const v4u_t B1,
+                      u32 (&Lm)[2], u32 (&Rm)[2], u32 (&dur)[2], u32 (&fl)[2]) {
+        const v4u_t A[2] = {A0, A1}, B[2] = {B0, B1};
+        u32 vs[2], vd[2];
         {
-            u64 d1[4], d2[4];
+            u64 s1[2], s2[2], d1[2], d2[2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { const u32 b = A[i].y >> 8; d1[i] = l1[(__umul24(b, SG_JL1_K1) >> 9) & jm]; d2[i] = l1[(__umul24(b, SG_JL1_K2) >> 11) & jm]; }
+            for (int i = 0; i < 2; i++) {
+                const u32 b = A[i].x >> 8, c = A[i].y >> 8;
+                s1[i] = l1[(__umul24(b, SG_JL1_K1) >> 9) & jm]; s2[i] = l1[(__umul24(b, SG_JL1_K2) >> 11) & jm];
+                d1[i] = l1[(__umul24(c, SG_JL1_K1) >> 9) & jm]; d2[i] = l1[(__umul24(c, SG_JL1_K2) >> 11) & jm];
+            }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32 b = A[i].y >> 8;
-                const u32 blk = (u32)d1[i] == b ? (u32)(d1[i] >> 32) : ((u32)d2[i] == b ? (u32)(d2[i] >> 32) : 0u);
-                const u32 ix = (blk << 8) | (A[i].y & 255u);
-                vd[i] = L2M == 2 ? (u32)l2h[ix] : l2[ix];
+            for (int i = 0; i < 2; i++) {
+                const u32 b = A[i].x >> 8, c = A[i].y >> 8;
+                const u32 blk = (u32)s1[i] == b ? (u32)(s1[i] >> 32) : ((u32)s2[i] == b ? (u32)(s2[i] >> 32) : 0u);
+                const u32 blkd = (u32)d1[i] == c ? (u32)(d1[i] >> 32) : ((u32)d2[i] == c ? (u32)(d2[i] >> 32) : 0u);
+                const u32 ix = (blk << 8) | (A[i].x & 255u), ixd = (blkd << 8) | (A[i].y & 255u);
+                vs[i] = L2M == 2 ? (u32)l2h[ix] : l2[ix];
+                vd[i] = L2M == 2 ? (u32)l2h[ixd] : l2[ixd];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool inr = tq + (u32)i * K1M_TT < gcount;       /* gcount: events of the group */
+        for (int i = 0; i < 2; i++) {
+            const bool inr = tq + (i0 + (u32)i) * K1M_TT < gcount;
             const u32 flags = A[i].w >> 24, label = A[i].z;
             const u32 ks = vs[i] >> KSH, kd = vd[i] >> KSH;
             bool r = ((flags & SG_EV_ALIVE) != 0) | (ks == 3u) | (kd == 3u) | (B[i].y != 0u) |
@@ -231,43 +220,34 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
             const u64 wt = (u64)B[i].z | ((u64)B[i].w << 32);
             st_acc += a ? 1u : 0u;
             st_tmin = (a && wt < st_tmin) ? wt : st_tmin; st_tmax = (a && wt > st_tmax) ? wt : st_tmax;
-            sg_kmix(cf & nbmask, ct & nbmask, nbmask, &Lm[i], &Rm[i]);   /* (the masks only matter for events that are not accepted) */
+            sg_kmix(cf & nbmask, ct & nbmask, nbmask, &Lm[i], &Rm[i]);
             dur[i] = B[i].x;
             fl[i] = (a ? K1M_F_ACC : 0u) | (r ? K1M_F_RARE : 0u) | (err ? K1M_F_ERR : 0u);
         }
     };
-    auto back4 = [&](const u32 (&Lm)[4], const u32 (&Rm)[4], const u32 (&dur)[4], const u32 (&fl)[4], u32* bc, u32 (&lo)[4], u32 (&hi)[4], u32 (&pr)[4]) {
-        ulonglong2 kk[4]; u64 mk[4];
+    auto back2 = [&](const u32 (&Lm)[2], const u32 (&Rm)[2], const u32 (&dur)[2], const u32 (&fl)[2], u32* bc, u32* lo, u32* hi, u32* pr) {
+        ulonglong2 kk[2]; u64 mk[2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) mk[i] = ((u64)Lm[i] << nb) | Rm[i];
-        if (d.ablate & 0x8u) {                                       // (diagnostic: no edge cache — every accepted record travels)
+        for (int i = 0; i < 2; i++) { mk[i] = ((u64)Lm[i] << nb) | Rm[i]; kk[i] = reinterpret_cast<const ulonglong2*>(ckey)[Rm[i] & bmask]; }
+        int slot[2]; bool claim = false;
 #pragma unroll
-            for (int i = 0; i < 4; i++) kk[i] = make_ulonglong2(~1ull, ~1ull);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) kk[i] = reinterpret_cast<const ulonglong2*>(ckey)[Rm[i] & bmask];
-        }
-        // cache: a key that owns a slot folds; an empty slot may be claimed (rare once the cache is full: one ballot for the four events)
-        int slot[4]; bool claim = false;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 2; i++) {
             const u32 bk = Rm[i] & bmask;
             slot[i] = kk[i].x == mk[i] ? (int)(2u * bk) : (kk[i].y == mk[i] ? (int)(2u * bk + 1u) : -1);
             claim |= ((fl[i] & K1M_F_ACC) != 0) & (slot[i] < 0) & ((kk[i].x == SG_EKEY_EMPTY) | (kk[i].y == SG_EKEY_EMPTY));
         }
         if (__builtin_amdgcn_ballot_w64(claim)) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 2; i++)
                 if ((fl[i] & K1M_F_ACC) && slot[i] < 0 && (kk[i].x == SG_EKEY_EMPTY || kk[i].y == SG_EKEY_EMPTY)) slot[i] = cache_claim(ckey, Rm[i] & bmask, mk[i], kk[i].x, kk[i].y);
         }
-        // the run rank of every travelling record: a returning add of 1 or 0 (no branch; a lane that does not travel adds 0)
-        u32 rank[4];
+        u32 rank[2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) rank[i] = atomicAdd(&bc[Lm[i] >> pshift], ((fl[i] & K1M_F_ACC) && slot[i] < 0) ? 1u : 0u);
+        for (int i = 0; i < 2; i++) rank[i] = atomicAdd(&bc[Lm[i] >> pshift], ((fl[i] & K1M_F_ACC) && slot[i] < 0) ? 1u : 0u);
 #pragma unroll
-        for (int i = 0; i < 4; i++) if ((fl[i] & K1M_F_ACC) && slot[i] >= 0) cache_add((u32)slot[i], (u64)dur[i], (fl[i] >> 2) & 1u);
+        for (int i = 0; i < 2; i++) if ((fl[i] & K1M_F_ACC) && slot[i] >= 0) cache_add((u32)slot[i], (u64)dur[i], (fl[i] >> 2) & 1u);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 2; i++) {
             const bool travel = (fl[i] & K1M_F_ACC) && slot[i] < 0;
             lo[i] = dur[i]; hi[i] = ((u32)mk[i] & rbmask) | ((fl[i] & K1M_F_ERR) ? 0x80000000u : 0u);
             pr[i] = travel ? ((Lm[i] >> pshift) | (rank[i] << K1T_RANK_SHIFT)) : ((fl[i] & K1M_F_RARE) ? K1M_RARE : K1T_NONE);
@@ -325,7 +305,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     // piece bases and this tile's run counters are not written before that.
     // (a record beyond its piece's capacity goes to the window's overflow list: a rolled loop behind the copy, so that the eight
     // unrolled copies carry one compare each and no call-sized code)
-    auto ovf_record = [&](const u32 b, const u32 remv, const u32 dur, const u32 err) { K1M_LNEW(L); ovf8_single(d, b, ((u64)b << d.rb) | remv, (u64)dur, err, 0u, L); lflush(L); };
+    auto ovf_record = [&](const u32 b, const u32 remv, const u32 dur, const u32 err) { const Dev& d = kd(); K1M_LNEW(L); ovf8_single(d, b, ((u64)b << d.rb) | remv, (u64)dur, err, 0u, L); lflush(L); };
     auto copy_out = [&](const u32 pc) {
         const u32* bc = bcnt + pc * NP;
         if (packb) {
@@ -396,52 +376,56 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     // by one lane at the top of the tile before (a returning device atomic issued by hand: its round trip passes under the joins) and
     // handed to the team through LDS across the tile's barriers.  (SG_ABLATE & 0x4: static shares.)
     const bool dyn = !(d.ablate & 0x4u);
-    u32* nxt = bar + 8 * team + 4;
+    // (the ticket is handed on through TWO words, alternating with the tile: a wave that is late behind a tile's second barrier — rare events,
+    // statistics — reads its word while the drawer, already in the next tile, writes the other one; with one word nothing ordered that read
+    // before that write, and a wave that read the NEXT tile's ticket left its team for good: a hang, seen in round 6 when the write moved
+    // closer to the top of the tile)
+    u32* nxt2 = bar + 8 * team + 4;
     const u32 ntile32 = (u32)ntile;
     for (u32 j = unit; j < ntile32; cur ^= 1u) {
         u32* bc = bcnt + cur * NP;
-        u32 lo[8], hi[8], pr[8];
+        u32 lo[K1M_NR], hi[K1M_NR], pr[K1M_NR];
         // the thread's indices, opaque per tile: whatever is derived from them (tile / counter / event addresses) is then computed where it is
         // used — hoisted out of this loop as loop invariants they were SPILLED (45 dwords) and every reload's vmcnt(0) also waited for the
         // event loads in flight
         u32 ttl = tt, lanel = lane; asm volatile("" : "+v"(ttl), "+v"(lanel));
         const u64 tk0 = stamp ? wall_clock64() : 0ull;
-        {   // P1: two groups of up to four events per thread, BOTH fetched at the top of the tile (two register sets, 256 bytes per lane in flight
-            // behind the previous tile's copy-out).  Pass A's speed is its memory-level parallelism: loads issued in bursts and waited for have
-            // ~25 % duty — 32 KB in flight per CU on average with one group of a 1024-thread workgroup, i.e. ~12 GB/s per CU at 3 us of loaded
-            // latency, which is what it ran at.  (Keeping a set in flight ACROSS the tile loop's back edge was tried: the compiler spills the
-            // in-flight registers there — tools/check_asm_loads.py — so the loads stay inside one straight stretch of the tile.)
-            u32 f0, c0, f1, c1;
-            gbounds(2u * j, f0, c0); gbounds(2u * j + 1u, f1, c1);
-            u32 Lm[4], Rm[4], du[4], fl[4];
-            v4u_t eaa0, eba0, eaa1, eba1, eaa2, eba2, eaa3, eba3, eab0, ebb0, eab1, ebb1, eab2, ebb2, eab3, ebb3;
-            K1M_ISSUE(a, ttl, f0, c0);
-            K1M_ISSUE(b, ttl, f1, c1);
+        {   // P1: one group of up to four events per thread.
+            // The previous tile's records leave FIRST, then the eight loads and the ticket go out and are waited for with vmcnt(0): a
+            // vmcnt(N) that lets the copy's stores fly behind the loads would have to assume that loads and stores retire in order with
+            // each other and that a store whose lanes are all out of range still counts — measured: every tile but a workgroup's first read
+            // its events before they had landed.  The latency this team no longer hides is the other team's issue time.  (Keeping a set of
+            // loads in flight ACROSS the tile loop's back edge was tried in round 4: the compiler spills the in-flight registers there —
+            // tools/check_asm_loads.py.)
+            if (havep) { const u64 tq = stamp ? wall_clock64() : 0ull; copy_out(pcur); if (stamp) tk_p4 += wall_clock64() - tq; }
+            u32 f0, c0;
+            gbounds(j, f0, c0);
+            v4u_t eaa0, eba0, eaa1, eba1, eaa2, eba2, eaa3, eba3;
+            {   // scalar base + one 32-bit offset register per event, both halves from it (a lane without work reads the batch's first event
+                // and ignores it by its in-range flag)
+                const u32 x0 = ttl, x1 = x0 + K1M_TT, x2 = x1 + K1M_TT, x3 = x2 + K1M_TT, fb = f0 * 32u;
+                const u32 o0 = x0 < c0 ? fb + x0 * 32u : 0u, o1 = x1 < c0 ? fb + x1 * 32u : 0u, o2 = x2 < c0 ? fb + x2 * 32u : 0u, o3 = x3 < c0 ? fb + x3 * 32u : 0u;
+#define K1M_LD2(A, B, vo) asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16" : "=&v"(A), "=&v"(B) : "v"(vo), "s"(pe) : "memory")
+                K1M_LD2(eaa0, eba0, o0); K1M_LD2(eaa1, eba1, o1); K1M_LD2(eaa2, eba2, o2); K1M_LD2(eaa3, eba3, o3);
+#undef K1M_LD2
+            }
             u32 tkv = 0;
             const bool drawer = dyn && wv == 0 && lanel == 0;
             if (drawer) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(tkv) : "v"(d.k1a_ticket), "v"(1u) : "memory");
-            if (havep) { const u64 tq = stamp ? wall_clock64() : 0ull; copy_out(pcur); if (stamp) tk_p4 += wall_clock64() - tq; }
             const u64 tl0 = stamp ? wall_clock64() : 0ull;
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(eaa0), "+v"(eba0), "+v"(eaa1), "+v"(eba1), "+v"(eaa2), "+v"(eba2), "+v"(eaa3), "+v"(eba3) : : "memory");
-            const u64 tl1 = stamp ? wall_clock64() : 0ull;
-            front4(ttl, c0, eaa0, eba0, eaa1, eba1, eaa2, eba2, eaa3, eba3, Lm, Rm, du, fl);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(eaa0), "+v"(eba0), "+v"(eaa1), "+v"(eba1), "+v"(eaa2), "+v"(eba2), "+v"(eaa3), "+v"(eba3), "+v"(tkv) : : "memory");
+            if (stamp) tk_ld += wall_clock64() - tl0;
+            if (drawer) { asm volatile("" : "+v"(tkv)); nxt2[cur] = tkv - d.k1a_ticket_base + units; }
             {
-                u32 l4[4], h4[4], p4[4];
-                back4(Lm, Rm, du, fl, bc, l4, h4, p4);
-#pragma unroll
-                for (int i = 0; i < 4; i++) { lo[i] = l4[i]; hi[i] = h4[i]; pr[i] = p4[i]; }
+                u32 Lm[2], Rm[2], du[2], fl[2];
+                front2(ttl, 0u, c0, eaa0, eba0, eaa1, eba1, Lm, Rm, du, fl);
+                back2(Lm, Rm, du, fl, bc, lo, hi, pr);
             }
-            const u64 tl2 = stamp ? wall_clock64() : 0ull;
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(eab0), "+v"(ebb0), "+v"(eab1), "+v"(ebb1), "+v"(eab2), "+v"(ebb2), "+v"(eab3), "+v"(ebb3), "+v"(tkv) : : "memory");
-            const u64 tl3 = stamp ? wall_clock64() : 0ull;
-            if (stamp) { tk_ld += (tl1 - tl0) + (tl3 - tl2); tk_fa += tl2 - tl1; }
-            if (drawer) { asm volatile("" : "+v"(tkv)); *nxt = tkv - d.k1a_ticket_base + units; }   // (the wait above covered the atomic: it is the youngest operation)
-            front4(ttl, c1, eab0, ebb0, eab1, ebb1, eab2, ebb2, eab3, ebb3, Lm, Rm, du, fl);
+            __builtin_amdgcn_sched_barrier(0);
             {
-                u32 l4[4], h4[4], p4[4];
-                back4(Lm, Rm, du, fl, bc, l4, h4, p4);
-#pragma unroll
-                for (int i = 0; i < 4; i++) { lo[4 + i] = l4[i]; hi[4 + i] = h4[i]; pr[4 + i] = p4[i]; }
+                u32 Lm[2], Rm[2], du[2], fl[2];
+                front2(ttl, 2u, c0, eaa2, eba2, eaa3, eba3, Lm, Rm, du, fl);
+                back2(Lm, Rm, du, fl, bc, lo + 2, hi + 2, pr + 2);
             }
         }
         const u64 tk1 = stamp ? wall_clock64() : 0ull;
@@ -505,11 +489,11 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
         // P3: every thread drops its records at offset + rank (PACKB: with the partition number in the free bits of the high word): the eight
         // offset reads together, then eight unconditional stores — a slot without a travelling record writes to the trash word behind the tile
         {
-            u32 of_[8];
+            u32 of_[K1M_NR];
 #pragma unroll
-            for (int i = 0; i < 8; i++) of_[i] = boff[pr[i] < K1M_RARE ? (pr[i] & ((1u << K1T_RANK_SHIFT) - 1u)) : 0u];
+            for (int i = 0; i < (int)K1M_NR; i++) of_[i] = boff[pr[i] < K1M_RARE ? (pr[i] & ((1u << K1T_RANK_SHIFT) - 1u)) : 0u];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < (int)K1M_NR; i++) {
                 const u32 pt_ = pr[i] & ((1u << K1T_RANK_SHIFT) - 1u);
                 const u32 at = pr[i] < K1M_RARE ? of_[i] + (pr[i] >> K1T_RANK_SHIFT) : K1M_TS;
                 tile[at] = (u64)lo[i] | ((u64)(hi[i] | (packb ? pt_ << rb : 0u)) << 32);
@@ -521,24 +505,37 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
         {   // the tile's rare events: the general path, one event at a time (nothing of P1 is live here)
             u32 rmask = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) rmask |= (pr[i] == K1M_RARE) ? (1u << i) : 0u;
+            for (int i = 0; i < (int)K1M_NR; i++) rmask |= (pr[i] == K1M_RARE) ? (1u << i) : 0u;
             if (__builtin_amdgcn_ballot_w64(rmask != 0)) {
-                const u64 e0 = (u64)(2u * j) * grp + ttl, e1 = (u64)(2u * j + 1u) * grp + ttl;   // (a rare event is in range: its group exists)
+                const u64 e0 = (u64)j * grp + ttl;                   // (a rare event is in range: its group exists)
 #pragma unroll 1
-                for (u32 k = 0; k < 8; k++) if ((rmask >> k) & 1u) general((k < 4 ? e0 : e1) + (u64)(k & 3u) * K1M_TT);
+                for (u32 k = 0; k < K1M_NR; k++) if ((rmask >> k) & 1u) general(e0 + (u64)k * K1M_TT);
             }
+        }
+        {
+            // the lanes' statistics leave per tile (wave reduce -> the workgroup's LDS line): eight registers that are not carried around the loop
+            const u64 tmin = wave_min_u64(st_tmin), tmax = wave_max_u64(st_tmax);
+            const u32 ac = wave_sum_u32(st_acc);
+            if (lanel == 0 && ac) { atomicMin(&red[WS_TMIN], tmin); atomicMax(&red[WS_TMAX], tmax); atomicAdd(&red[WS_ACCEPTED], (u64)ac); }
+            if (__builtin_amdgcn_ballot_w64((st_dsrc | st_misr | st_maxlabel) != 0u)) {
+                if (st_dsrc) atomicAdd(&red[WS_DROPPED_SRC], (u64)st_dsrc);
+                if (st_misr) atomicAdd(&red[WS_MISROUTED], (u64)st_misr);
+                if (st_maxlabel) atomicMax(&red[WS_MAXLABEL], (u64)st_maxlabel);
+            }
+            st_acc = st_dsrc = st_maxlabel = st_misr = 0; st_tmin = ~0ull; st_tmax = 0;
         }
         havep = true; pcur = cur;
         if (stamp) { tk_scan += tk3 - tk2; tk_p3 += tk4 - tk3; tk_b3 += tk5 - tk4; }
-        j = dyn ? (u32)__builtin_amdgcn_readfirstlane((int)lds_fresh_u32(nxt)) : j + units;   // (written before this tile's first barrier, read behind its second)
+        j = dyn ? (u32)__builtin_amdgcn_readfirstlane((int)lds_fresh_u32(nxt2 + cur)) : j + units;   // (written before this tile's first barrier, read behind its second)
     }
     if (havep) copy_out(pcur);                                       // the last tile's runs
     SG_STAMP(d, 0, 3);
     if (stamp && tt == 0 && blockIdx.x < 2048) { u64* g = d.dbg + ((size_t)2 * 4096 + blockIdx.x * 2 + team) * 8; g[0] = tk_p1; g[1] = tk_wait; g[2] = tk_scan; g[3] = tk_p3; g[4] = tk_b3; g[5] = tk_p4; g[6] = tk_ld; g[7] = tk_fa; }
-#undef K1M_ISSUE
     K1M_WG_BARRIER();
     SG_STAMP(d, 0, 4);
     // flush the cache: a key seen once leaves as a single record, the others as aggregates
+    {
+    const Dev& d = kd();                                             // (the epilogue's Dev fields are loaded here, not held across the tile loop)
     K1M_LNEW(L);
     for (u32 s = t; s < CT; s += K1M_THREADS) {
         const u64 k = ckey[s];
@@ -578,6 +575,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     }
     SG_STAMP(d, 0, 6);
     if (clk_me) { atomicAdd(&d.clk[0], __builtin_readcyclecounter() - clk_c0); atomicAdd(&d.clk[1], wall_clock64() - clk_r0); }
+    }
 #undef K1M_WG_BARRIER
 #undef K1M_LNEW
 }
