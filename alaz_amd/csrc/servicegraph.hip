@@ -637,11 +637,13 @@ void account_window(sg_engine* e) {
     st.halo_overflow += e->h_ctr[C_HALO_OVF];
     st.alive_in += e->h_ctr[C_ALIVE_SEEN];
     st.alive_dropped += e->h_ctr[C_ALIVE_DROPPED];
-    if (e->d.warm && !((size_t)e->cur < e->plain_slot.size() && e->plain_slot[e->cur])) {
+    st.last_window_new_edges = 0;
+    if (e->d.warm && (size_t)e->cur < e->plain_slot.size() && e->plain_slot[e->cur]) st.windows_plain++;
+    else if (e->d.warm) {
         // (counters of the slot that was read: with several windows in flight every slot keeps its own state and its own counts)
         const bool cold = e->h_ctr[C_COLD] != 0;
-
         if (cold) st.windows_cold++; else st.windows_warm++;
+        if (!cold && e->h_ctr[C_DELTA_N]) { st.windows_delta++; st.last_window_new_edges = e->h_ctr[C_DELTA_N]; }
         // (the policy — when to stop trying — reads the device's note at the next close: do_close)
     }
     if (e->h_ctr[C_N_EVENTS]) {
@@ -854,8 +856,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     }
     if (d.variant == 0) {
         if (!k1a_geometry(e)) { e->err = "K1 pass A: piece counters and join level 1 do not fit a CU's LDS"; return fail(SG_ENOSPC); }
-        // (narrow: accumulators, keys, two counters, then the warm path's touch bits — one per slot — and its "key inserted" word)
-        e->k1b_lds = d.narrow ? ((size_t)d.k1b_ht * 36 + 8 + (size_t)d.k1b_ht / 8 + 4 + 15) / 16 * 16 : (size_t)d.k1b_ht * (8 + 32 + (d.hist ? 4 * SG_HIST_BINS : 0));
+        // (narrow: accumulators, keys, two counters, then the warm path's touch bits and new-key bits — one each per slot — and three words)
+        e->k1b_lds = d.narrow ? ((size_t)d.k1b_ht * 36 + 8 + (size_t)d.k1b_ht / 4 + 12 + 15) / 16 * 16 : (size_t)d.k1b_ht * (8 + 32 + (d.hist ? 4 * SG_HIST_BINS : 0));
         for (const void* f : {reinterpret_cast<const void*>(k1a_partition<true, true, false>), reinterpret_cast<const void*>(k1a_partition<true, false, false>),
                               reinterpret_cast<const void*>(k1a_partition<false, true, false>), reinterpret_cast<const void*>(k1a_partition<false, false, false>),
                               reinterpret_cast<const void*>(k1a_partition<true, true, true>), reinterpret_cast<const void*>(k1a_partition<true, false, true>),
@@ -950,6 +952,12 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
                 LR(dev_alloc(e, &w.pos_of_slot, KC, 0xFF));
                 LR(dev_alloc(e, &w.k_acc, KC * 4)); LR(dev_alloc(e, &w.k_col, KC)); LR(dev_alloc(e, &w.k_from, KC)); LR(dev_alloc(e, &w.k_rowptr, (size_t)w.ncap + 2));
                 LR(dev_alloc(e, &w.kw_tot, (KC + KW_CH - 1) / KW_CH + 2));
+                // delta windows: the second kept buffer, kept position -> image index (both buffers), the delta CSR and its maps
+                LR(dev_alloc(e, &w.k_col2, KC)); LR(dev_alloc(e, &w.k_from2, KC)); LR(dev_alloc(e, &w.k_rowptr2, (size_t)w.ncap + 2));
+                LR(dev_alloc(e, &w.k_slot, 2 * KC));
+                LR(dev_alloc(e, &w.dc_rowptr, (size_t)w.ncap + 2)); LR(dev_alloc(e, &w.dc_col, KC)); LR(dev_alloc(e, &w.dc_from, KC)); LR(dev_alloc(e, &w.dc_acc, KC * 4));
+                LR(dev_alloc(e, &w.dc_slot, KC)); LR(dev_alloc(e, &w.dc_ip, KC)); LR(dev_alloc(e, &w.dl_img, KC));
+                LR(dev_alloc(e, &w.deg2, ((size_t)w.ncap + 1) * SG_DEG_REP * SG_DEG_STRIDE));
                 u64* a = nullptr; u64* b = nullptr; double* c = nullptr;
                 LR(dev_alloc(e, &a, (size_t)w.ncap * SG_NODE_STAT_SUM_WORDS)); LR(dev_alloc(e, &b, (size_t)w.ncap * SG_NODE_STAT_MAX_WORDS)); LR(dev_alloc(e, &c, 2 * ((size_t)w.ncap + 1)));
                 e->scr_sum.push_back(a); e->scr_max.push_back(b); e->scr_mu.push_back(c);

@@ -58,14 +58,18 @@ enum {
     C_ACT_P,          // world > 1: nodes whose score projections this shard needs (local sources + local destinations)
     C_HUB_ITEMS,      // (row, block) work items of the rows with more than SG_MEAN_BLOCK neighbours (k2_rowptr -> k4_gather)
     // warm windows (Dev::warm): the edge set and its CSR order kept from the last cold window
-    C_COLD,           // != 0: this window takes the full rebuild — 1 set by kc_prepare (no usable kept state / the host does not try), 2 by the warm pass B (a key the kept set lacks)
+    C_COLD,           // != 0: this window takes the full rebuild — 1 set by kc_prepare (no usable kept state / the host does not try), 2 by the warm pass B (a table or a partition's key budget ran full, or an edge was dropped)
     C_KEPT_VALID,     // the kept state describes a whole window (no capacity drop, no raw outbound IP when it was captured)
     C_KEPT_E,         // edges of the kept CSR
     C_KEPT_NK,        // N_KNOWN and
     C_KEPT_NL,        // N_LABELS when it was captured: the dense node numbering the kept columns are written in
     C_WARM_WINDOWS,   // windows closed on the warm path / by a full rebuild since create (sg_stats)
     C_COLD_WINDOWS,
-    C_COUNT = 32
+    // delta windows (round 6): a warm window whose records brought keys the kept set lacks
+    C_DELTA_N,        // new edges the warm pass B emitted in this window (zeroed by kc_prepare; consumed when the kept buffers are flipped)
+    C_KEPT_BUF,       // which of the two kept-CSR buffers (k_col / k_col2 ...) is current; a full rebuild writes buffer 0, a delta window the other one
+    C_DELTA_WINDOWS,  // windows closed warm WITH new edges since create
+    C_COUNT = 40
 };
 
 // per-workgroup statistics slots written by K1 (one 64-byte line per workgroup: no cross-WG
@@ -173,6 +177,19 @@ struct Dev {
     u64* k_acc;                               // [max_edges][4] accumulators by kept position, rewritten by every warm pass B; bit 63 of word 2 (max_ns < 2^62) = touched in this window
     u32* k_col; u32* k_from; u32* k_rowptr;   // the kept CSR: [max_edges], [max_edges], [ncap + 1]
     u64* kw_tot;                              // [max_edges / KW_CH + 2] kw_compact: (epoch << 32 | touched edges) per chunk
+    // Delta windows (round 6).  A key the image lacks no longer sends the window down the full rebuild: the warm pass B inserts it, emits
+    // the NEW edges in the cold format (partition outputs e_from / e_to / acc_src / e_rank, part_n = new edges of the partition, row ranks
+    // from deg2), the rebuild chain runs on these few edges only and leaves a sorted DELTA CSR (dc_*), and kw_compact merges it into the
+    // window's CSR and into the kept CSR — written to the OTHER kept buffer with every position shifted by the new edges before it; the
+    // image's positions (wk_pos) follow through k_slot.  The kept set only grows; a full rebuild starts it afresh.
+    u32* k_col2; u32* k_from2; u32* k_rowptr2; // the second kept-CSR buffer (ctr[C_KEPT_BUF] says which is current)
+    u32* k_slot;                              // [2][npb * pcap] kept position -> image index (partition * k1b_ht + slot), per buffer
+    u32* dc_rowptr; u32* dc_col; u32* dc_from; // the delta CSR: [ncap + 2], [npb * pcap], [npb * pcap]
+    u64* dc_acc;                              // [npb * pcap][4]
+    u32* dc_slot;                             // [npb * pcap] delta position -> partition-output slot (written by the row sort)
+    u32* dc_ip;                               // [npb * pcap] delta position -> insertion point in the kept CSR (kw_compact's scratch)
+    u32* dl_img;                              // [npb * pcap] partition-output slot of a new edge -> its image index
+    u32* deg2;                                // [ncap + 1][SG_DEG_REP] row-degree replicas of the new edges (deg belongs to a full rebuild; zeroed by the window reset)
     u64* host_note;                           // page-locked HOST memory (mapped): [0] = sequence number of the last window kw_compact closed, [1] = its C_COLD
                                               // and C_N_OBIP << 8 — how the host learns, without ever waiting for the device, which path its windows take
     u32* lb_ticket;                           // [4] self-resetting workgroup tickets of the look-back kernels whose grid exceeds SG_LB_RESIDENT ([0] k2_rowptr, [1] kw_compact)

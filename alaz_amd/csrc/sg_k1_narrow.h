@@ -491,7 +491,10 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     u64* hacc = reinterpret_cast<u64*>(smem);                        // [4][HT]: accumulator j of slot h at j*HT + h
     u32* hkey = reinterpret_cast<u32*>(hacc + (size_t)HT * 4);       // [HT] remainders, all ones = empty
     u32* n_drop = hkey + HT; u32* out_n = n_drop + 1;
-    u32* htouch = out_n + 1;                                         // WM 1: [HT / 32] slots a record touched without counting; word HT / 32 = "a key was inserted"
+    u32* htouch = out_n + 1;                                         // WM 1: [HT / 32] slots a record touched without counting; word HT / 32 = new keys inserted
+    u32* hnew = htouch + HT / 32 + 1;                                // WM 1: [HT / 32] slots whose key the image lacked (inserted by this window's records)
+    u32* nkeys = hnew + HT / 32;                                     // WM 1: keys in the table (the image's + the new ones): a partition keeps at most pcap
+    u32* coldf = nkeys + 1;                                          // WM 1: C_COLD as thread 0 read it (one value for the whole workgroup)
     const u32 t = threadIdx.x, NT = blockDim.x;
     // q -> (partition, sub-table): blocks b and b + 8 run on the same XCD (b % 8) and are dispatched back to back
     const u32 S = d.k1b_split, q = blockIdx.x;
@@ -519,8 +522,14 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     const u32 nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS], nob = (u32)d.ctr[C_N_OBIP];
     if constexpr (WM == 1) {
         const u32* img = d.wk_keys + (size_t)oq * HT;                 // (coalesced: 4 HT bytes per workgroup, beside the headers' round trip)
-        for (u32 i = t; i < HT; i += NT) hkey[i] = img[i];
+        if (t == 0) *nkeys = 0;
         for (u32 i = t; i <= HT / 32; i += NT) htouch[i] = 0;
+        for (u32 i = t; i < HT / 32; i += NT) hnew[i] = 0;
+        __syncthreads();
+        u32 have = 0;
+        for (u32 i = t; i < HT; i += NT) { const u32 k = img[i]; hkey[i] = k; have += k != 0xFFFFFFFFu ? 1u : 0u; }
+        have = wave_sum_u32(have);
+        if ((t & 63u) == 0 && have) atomicAdd(nkeys, have);
     } else {
         for (u32 i = t; i < HT; i += NT) hkey[i] = 0xFFFFFFFFu;
         if constexpr (WM == 2) { for (u32 i = t; i <= HT / 32; i += NT) htouch[i] = 0; }   // bits: slots filled from the old image; word HT / 32: keys in the table
@@ -539,8 +548,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
                 k = atomicCAS(&hkey[h], 0xFFFFFFFFu, rem);
                 if (k == 0xFFFFFFFFu) {
                     k = rem;
-                    if constexpr (WM == 1) { htouch[HT / 32] = 1u; d.ctr[C_COLD] = 2; }   // a key the kept set lacks: the window is cold — said at once, so that the
-                                                                                        // workgroups that have not started yet (half of them run in a second round) return at their first line
+                    if constexpr (WM == 1) { atomicOr(&hnew[h >> 5], 1u << (h & 31u)); atomicAdd(&htouch[HT / 32], 1u); }   // a key the kept set lacks: a NEW edge of this window (delta, below)
                     if constexpr (WM == 2) atomicAdd(&htouch[HT / 32], 1u);   // keys in the table (the union phase fills what room is left)
                 }
             }
@@ -595,9 +603,11 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             }
         }
     }
+    if constexpr (WM == 1) { if (t == 0) *coldf = (u32)d.ctr[C_COLD]; }   // (ONE read per workgroup: other workgroups may raise the flag while this one runs, and waves that
+                                                                     //  saw different values would part ways in front of the barriers below — ADVICE r5)
     __syncthreads();                                                 // every 32-bit max is in: 64-bit updates may follow
     SG_STAMP(d, 1, 3);
-    if constexpr (WM == 1) { if (d.ctr[C_COLD]) return; }             // (uniform) some workgroup met an unknown key: the rebuild repeats the merge, nothing this one writes is read
+    if constexpr (WM == 1) { if (*coldf) return; }                    // some workgroup gave up (a full table, a dropped edge): the rebuild repeats the merge, nothing this one writes is read
     if constexpr (PACK) {                                            // unpack: a slot by one thread, nobody else touches the table here
         for (u32 i = t; i < HT; i += NT) { const u64 w = hacc[HT + i]; hacc[i] += w >> 48; hacc[HT + i] = w & ((1ull << 48) - 1ull); }
         __syncthreads();
@@ -672,19 +682,47 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
 #pragma unroll
         for (int k2 = 0; k2 < SPT; k2++) { const u32 sl = t + (u32)k2 * NT; pos[k2] = sl < HT ? wp[sl] : SG_NONE; }
         bool cold = false;
+        const bool anynew = htouch[HT / 32] != 0;                    // (uniform)
 #pragma unroll
         for (int k2 = 0; k2 < SPT; k2++) {
             const u32 sl = t + (u32)k2 * NT;
             if (sl >= HT) continue;
-            if (hkey[sl] == 0xFFFFFFFFu) continue;
-            if (pos[k2] >= KE) { cold = true; continue; }             // a key without a kept edge (inserted in this window, or dropped when the image was taken)
+            const u32 rem = hkey[sl];
+            if (rem == 0xFFFFFFFFu) continue;
             const u64 a0 = hacc[sl], a1 = hacc[HT + sl], a2 = hacc[2 * HT + sl], a3 = hacc[3 * HT + sl];
+            if (anynew && ((hnew[sl >> 5] >> (sl & 31u)) & 1u)) {
+                // A NEW edge (round 6): it leaves in the cold format — endpoints out of the key, a place in the partition's output, its rank
+                // among the new edges of its row (deg2) — and enters the image at once; kw_compact gives it its kept position.  An edge
+                // whose endpoint has no dense id (a label beyond the count) is dropped and counted as the rebuild would (cold: it repeats
+                // the merge and does the accounting), and so is a partition that would keep more than pcap keys.
+                const u64 mk = ((u64)p << d.rb) | rem;
+                u32 cf, ct;
+                sg_kunmix((u32)(mk >> nb), (u32)mk & nbmask, nbmask, &cf, &ct);
+                const u32 f = dense_of(d, ref_of_ci(d, cf), nk, nl, nob), to = dense_of(d, ref_of_ci(d, ct), nk, nl, nob);
+                if (f == SG_NONE || to == SG_NONE || atomicAdd(nkeys, 1u) >= d.pcap) { cold = true; continue; }
+                const u32 di = atomicAdd(out_n, 1u);                 // (< pcap: the partition's keys are)
+                const size_t slot = (size_t)oq * d.pcap + di;
+                const u32 rk = atomicAdd(&d.deg2[SG_DEG_IDX(f, oq & (SG_DEG_REP - 1))], 1u);
+                d.e_from[slot] = f; d.e_to[slot] = to; d.e_rank[slot] = rk;
+                ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
+                o[0] = make_ulonglong2(a0, a1); o[1] = make_ulonglong2(a2 | (1ull << 63), a3);
+                d.dl_img[slot] = oq * HT + sl;
+                d.wk_keys[(size_t)oq * HT + sl] = rem;               // (its position: kw_compact, from dl_img)
+                continue;
+            }
+            if (pos[k2] >= KE) { cold = true; continue; }             // a key without a kept edge (dropped when the image was taken)
             const bool touched = (a0 & 0xFFFFFFFFull) != 0 || ((htouch[sl >> 5] >> (sl & 31u)) & 1u);
             ulonglong2* o = reinterpret_cast<ulonglong2*>(d.k_acc + (size_t)pos[k2] * 4);
             o[0] = make_ulonglong2(touched ? a0 : 0ull, touched ? a1 : 0ull);
             o[1] = make_ulonglong2(touched ? (a2 | (1ull << 63)) : 0ull, touched ? a3 : 0ull);
         }
-        if (cold || (t == 0 && (htouch[HT / 32] || *n_drop))) d.ctr[C_COLD] = 2;   // (same value from whoever writes it; 2 = found HERE, after a whole merge: the host backs off when that keeps happening)
+        if (cold || (t == 0 && *n_drop)) d.ctr[C_COLD] = 2;           // (same value from whoever writes it; 2 = found HERE, after a whole merge: the host backs off when that keeps happening)
+        __syncthreads();                                             // the new edges are counted
+        if (t == 0) {
+            const u32 dn = *out_n;
+            d.part_n[oq] = dn;                                       // new edges of this partition (the delta chain reads it; a full rebuild rewrites it)
+            if (dn) atomicAdd(&d.ctr[C_DELTA_N], (u64)dn);
+        }
         SG_STAMP(d, 1, 5);
         return;
     }

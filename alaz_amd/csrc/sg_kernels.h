@@ -846,6 +846,7 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
             d.ctr[C_N_LABELS] = nl; d.ctr[C_N_KNOWN] = n_known; nkl = nl + n_known; nl_s = nl;
             d.ctr[C_DROPPED_SRC] = red[3][0]; d.ctr[C_MISROUTED] = red[5][0]; d.ctr[C_N_EVENTS] = red[6][0];
             d.ctr[C_DROPPED_CAP] = red[4][0];                        // K1b / K2 add their own drops afterwards
+            d.ctr[C_DELTA_N] = 0;                                    // the warm pass B counts the window's new edges
             d.ctr[C_N_LONG] = 0;                                     // k2_rowptr's workgroups append to the long-row list
             d.ctr[C_HUB_ITEMS] = 0;                                  // ... and to the hub-block work list
         }
@@ -994,6 +995,13 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
 #define K2_DH_FLIGHT 16
 #define K2_DH_GMAX 128           // k2_rowptr keeps a row's column of counts in registers: GMAX / 8 per lane
 #define SG_WARM_WINDOW(d) ((d).warm && !(d).ctr[C_COLD])             /* (uniform) this window is closed on the warm path: the rebuild kernels return at once */
+// The rebuild chain (k2_rowptr .. k2_rowsort_gather) on an engine that keeps state runs in one of three ways, decided on the device:
+//   0  a full rebuild (cold window) on the Dev the host set up — its CSR pointers are the KEPT arrays (buffer 0);
+//   1  a warm window that met NEW edges (C_DELTA_N != 0): the same kernels on those few edges only — the warm pass B left them in the
+//      partition outputs, ranks from deg2 — and the result is the DELTA CSR (dc_*), which kw_compact merges in;
+//  -1  a warm window without new edges: nothing to do, return at once.
+__device__ __forceinline__ int sg_chain_mode(const Dev& d) { if (!d.warm || d.ctr[C_COLD]) return 0; return d.ctr[C_DELTA_N] ? 1 : -1; }
+__device__ __forceinline__ Dev sg_delta_view(const Dev& d) { Dev x = d; x.rowptr = d.dc_rowptr; x.col = d.dc_col; x.csr_from = d.dc_from; x.acc_csr = d.dc_acc; x.deg = d.deg2; return x; }
 __global__ __launch_bounds__(K2_DH_THREADS) void k2_deg_hist(Dev d) {
     extern __shared__ u32 dh_cnt[];                                  // [N]
     if (SG_WARM_WINDOW(d)) return;
@@ -1032,11 +1040,14 @@ __global__ __launch_bounds__(K2_DH_THREADS) void k2_deg_hist(Dev d) {
 // pulls the [dh_g][N] table; otherwise from the replica counters pass B's device atomics left, 256 rows per workgroup.)
 #define K2_RP_ROWS_DH 64
 template <u32 RPR, bool DH>
-__global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
+__global__ __launch_bounds__(1024) void k2_rowptr(Dev dd, u32 epoch) {
     __shared__ u32 wsum[17];
     __shared__ u32 rdeg[RPR];
     __shared__ u32 nlong, lbase, pre, bdyn;
-    if (SG_WARM_WINDOW(d)) return;
+    const int cm = sg_chain_mode(dd);
+    if (cm < 0) return;
+    const bool delta = cm == 1;
+    const Dev d = delta ? sg_delta_view(dd) : dd;
     const u32 t = threadIdx.x;
     // Which rows this workgroup owns.  The look-back below waits for the workgroups of the rows before it.  Up to SG_LB_RESIDENT
     // workgroups (one per CU) every workgroup of the launch is resident and the block index serves.  Beyond that (C5: 150 k rows) a
@@ -1157,9 +1168,11 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev d, u32 epoch) {
         if (r0 + RPR >= N) {                                    // the workgroup of the last row knows E
             const u32 E = base + total;
             d.rowptr[N] = (u64)E < d.max_edges ? E : (u32)d.max_edges;
+            if (!delta) {                                            // (the delta CSR's size is its last row pointer; the window's counts are kw_compact's)
             d.ctr[C_N_EDGES] = (u64)E < d.max_edges ? E : d.max_edges;
             if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = E; if ((u64)E > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)E - d.max_edges; }
-            if (d.warm) d.ctr[C_KEPT_E] = (u64)E < d.max_edges ? E : d.max_edges;   // (this launch rebuilt the KEPT CSR: kw_compact, next, walks that many positions)
+            if (d.warm) { d.ctr[C_KEPT_E] = (u64)E < d.max_edges ? E : d.max_edges; d.ctr[C_KEPT_BUF] = 0; }   // (this launch rebuilt the KEPT CSR, buffer 0: kw_compact, next, walks that many positions)
+            }
         }
     }
 }
@@ -1180,8 +1193,10 @@ __global__ __launch_bounds__(256) void k2_scatter_table(Dev d) {
         d.cs[pos] = make_uint2(d.e_to[i], d.e_slot[i]);
     }
 }
-__global__ __launch_bounds__(256) void k2_scatter_parts(Dev d) {
-    if (SG_WARM_WINDOW(d)) return;
+__global__ __launch_bounds__(256) void k2_scatter_parts(Dev dd) {
+    const int cm = sg_chain_mode(dd);
+    if (cm < 0) return;
+    const Dev d = cm == 1 ? sg_delta_view(dd) : dd;
     const u32 p = blockIdx.x, n = d.part_n[p];
     // four edges per thread and trip: their loads (source, then row start + replica offset) are in flight together — one edge per
     // trip was two dependent round trips for each of a partition's ~4 edges per thread.  The slots are read whether or not they hold an
@@ -1225,12 +1240,13 @@ __device__ __forceinline__ double std_us(u64 sum_ns, u64 ssq_us, u64 cnt) {
 // The fp32 edge features, lat_z and err_ratio are computed afterwards, one thread per edge, by the edge
 // workgroups of k3_node_features: inside the row sort they were ~1000 fp64-heavy instructions per edge run
 // by the few threads that own a long row (a 3000-edge hub row kept one 256-thread workgroup busy for tens of us).
-struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; u32* hist_src; u32* hist_csr; u32 hist; u32* pos_of_slot; };
+struct EdgeEmitArgs { u64* acc_csr; u32* csr_from; u64* eacc; u64* ekeys; u32* alive_csr; u32 variant; u32* hist_src; u32* hist_csr; u32 hist; u32* pos_of_slot; u32* slot_of_pos; };
 __device__ __forceinline__ void edge_emit(const EdgeEmitArgs d, u32 pos, u32 row, u32 slot, u64, u64, u64, const ulonglong2 x, const ulonglong2 y) {
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)pos * 4);
     dst[0] = x; dst[1] = y;
     d.csr_from[pos] = row;
     if (d.pos_of_slot) d.pos_of_slot[slot] = pos;                    // warm windows: where the edge of this partition-output slot sits in the CSR (kw_capture)
+    if (d.slot_of_pos) d.slot_of_pos[pos] = slot;                    // delta windows: the partition-output slot of a delta position (kw_compact finds the edge's image index through it)
     d.alive_csr[pos] = 0;                                            // k3_in_stats adds the window's open connections
     if (d.hist) {                                                    // f-3: the edge's latency histogram follows it into row order
         uint4* hs = reinterpret_cast<uint4*>(d.hist_src + (size_t)slot * SG_HIST_BINS); uint4* hd = reinterpret_cast<uint4*>(d.hist_csr + (size_t)pos * SG_HIST_BINS);
@@ -1696,10 +1712,12 @@ __device__ __forceinline__ void k2_row_wave_rank(const Dev& d, const EdgeEmitArg
         d.row_mu[rr] = mean_us(sum, cnt); d.row_sd[rr] = std_us(sum, ssq, cnt);
     }
 }
-__global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
-    if (SG_WARM_WINDOW(d)) return;
+__global__ __launch_bounds__(256) void k2_rowsort_gather(Dev dd) {
+    const int cm = sg_chain_mode(dd);
+    if (cm < 0) return;
+    const Dev d = cm == 1 ? sg_delta_view(dd) : dd;
     const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
-    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant, d.hist_src, d.hist_csr, d.hist, d.warm ? d.pos_of_slot : nullptr};
+    const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant, d.hist_src, d.hist_csr, d.hist, d.warm ? d.pos_of_slot : nullptr, cm == 1 ? d.dc_slot : nullptr};
     extern __shared__ u32 k2_lds[];                                  // 2 x k2_sortw words (dynamic: a node bitmap of the engine's node capacity fits when it can)
     u32* sk = k2_lds; u32* sv = k2_lds + d.k2_sortw;
     __shared__ u64 red[5][4];
@@ -1775,8 +1793,14 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev d) {
 // rebuild wrote (it reduces every row it sorts; the window's real ones come from kw_compact) are zeroed for the next rebuild.
 #define KW_CAPW 48                                                   // workgroups of the kw_compact launch that do this instead of a chunk (nothing in a chunk's work depends on it)
 __device__ __forceinline__ void kw_capture(const Dev& d, u64* scratch_sum, u64* scratch_max, u32 wg, u32 nwg, u32 nthreads) {
-    if (!d.ctr[C_COLD]) return;                                      // (uniform) a warm window changes nothing
     const u64 tid = (u64)wg * nthreads + threadIdx.x, nt = (u64)nwg * nthreads;
+    if (!d.ctr[C_COLD]) {                                            // (uniform) a warm window changes nothing — unless its new edges went through the
+        if (d.ctr[C_DELTA_N]) {                                      // row sort, which reduces every row it sorts into the scratch statistics: re-arm them
+            for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) scratch_sum[i] = 0;
+            for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) scratch_max[i] = 0;
+        }
+        return;
+    }
     const bool whole = d.ctr[C_N_OBIP] == 0;
     if (tid == 0) {
         d.ctr[C_KEPT_VALID] = whole ? 1ull : 0ull;                   // (C_KEPT_E: k2_rowptr's count on the kept arrays)
@@ -1788,7 +1812,11 @@ __device__ __forceinline__ void kw_capture(const Dev& d, u64* scratch_sum, u64* 
     const u64 slots = (u64)d.npb * d.k1b_ht;
     for (u64 i = tid; i < slots; i += nt) {
         const u32 oi = d.wk_pos[i];
-        if (oi != SG_NONE) d.wk_pos[i] = oi < d.pcap ? d.pos_of_slot[(size_t)(i / d.k1b_ht) * d.pcap + oi] : SG_NONE;
+        if (oi != SG_NONE) {
+            const u32 pos = oi < d.pcap ? d.pos_of_slot[(size_t)(i / d.k1b_ht) * d.pcap + oi] : SG_NONE;
+            d.wk_pos[i] = pos;
+            if (pos != SG_NONE) d.k_slot[pos] = (u32)i;              // kept position -> image index (buffer 0: a full rebuild writes buffer 0), for the delta windows' renumbering
+        }
     }
 }
 
@@ -1813,6 +1841,203 @@ __device__ __forceinline__ void kw_capture(const Dev& d, u64* scratch_sum, u64* 
 #define KW_CH (KW_THREADS * KW_Q)
 #define KW_ROWS 512                                                  // rows per chunk with LDS accumulators (5 x u64 each: 20 KiB)
 #define KW_RESIDENT (3 * SG_LB_RESIDENT)                             // working chunks that are certainly resident together (<= 80 VGPRs, 21 KiB of LDS)
+
+// kw_compact on a DELTA window (round 6): the warm pass B met keys the kept set lacks and emitted them as new edges; the rebuild chain has
+// sorted them into the delta CSR (dc_rowptr / dc_col / dc_from / dc_acc, D edges).  The chunk does what it does on every warm window — the
+// kept CSR minus the untouched edges, stable — and merges the delta in, twice:
+//   * into the WINDOW's CSR: a touched kept edge lands at base + its rank among the touched ones + the new edges that sort before it;
+//     a new edge j (all of them are in the window) at j + the touched kept edges that sort before it;
+//   * into the KEPT CSR, written to the other buffer: kept position i -> i + the new edges before it, new edge j -> j + the kept edges
+//     before it; the image's positions follow (wk_pos[k_slot[i]], wk_pos[dl_img[..]]), so the next windows' pass B finds every edge warm.
+// Which new edges are this chunk's: those whose insertion point — the number of kept keys below theirs — lies in [p0, last]: two searches
+// in the delta CSR for the keys at the chunk's ends give the range [jlo, jhi), a binary search over the chunk's keys in LDS the point.
+// Row statistics leave with atomics throughout (a new edge of a row may belong to the chunk behind the one that holds the row).
+__device__ __forceinline__ u32 kw_dsearch(const Dev& d, u32 r, u32 c) {   // delta keys below (r, c)
+    u32 lo = d.dc_rowptr[r], hi = d.dc_rowptr[r + 1];
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (d.dc_col[m] < c) lo = m + 1; else hi = m; }
+    return lo;
+}
+__device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, const u32 nchunk, const u32 epoch, const u32 KE, const u32 N, const u32 D, const u32 buf,
+                                                 u64* kw_racc, u64 (*bal)[KW_NW], u32 (*wpre)[KW_NW], u32* qpre, u32* pre) {
+    __shared__ u32 kF[KW_CH], kC[KW_CH];                             // the chunk's kept keys (source, destination)
+    __shared__ u32 ins[KW_CH + 4];                                   // new edges inserted in front of local index x, then their inclusive prefix
+    __shared__ u32 wsum[KW_NW + 1];
+    __shared__ u32 jr[2];
+    const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const size_t KC = (size_t)d.npb * d.pcap;
+    const u32* kcol = buf ? d.k_col2 : d.k_col; const u32* kfrom = buf ? d.k_from2 : d.k_from; const u32* krp = buf ? d.k_rowptr2 : d.k_rowptr;
+    const u32* kslot = d.k_slot + (size_t)buf * KC;
+    u32* ncol = buf ? d.k_col : d.k_col2; u32* nfrom = buf ? d.k_from : d.k_from2; u32* nrp = buf ? d.k_rowptr : d.k_rowptr2;
+    u32* nslot = d.k_slot + (size_t)(buf ^ 1u) * KC;
+    const u32 p0 = b * KW_CH, last = (p0 + KW_CH < KE ? p0 + KW_CH : KE) - 1, cnt = last - p0 + 1;
+    u32 fr[KW_Q], co[KW_Q], sl[KW_Q]; ulonglong2 x[KW_Q], y[KW_Q]; bool tc[KW_Q];
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) {
+        const u32 i = p0 + (u32)q * KW_THREADS + t, ic = i <= last ? i : last;
+        fr[q] = kfrom[ic]; co[q] = kcol[ic]; sl[q] = kslot[ic];
+        const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.k_acc + (size_t)ic * 4);
+        x[q] = a[0]; y[q] = a[1];
+    }
+    const u32 v0 = kfrom[p0], v_hi = kfrom[last];
+    const u32 v_lo = b == 0 ? 0u : kfrom[p0 - 1] + 1u;
+    if (t == 0) jr[0] = b == 0 ? 0u : kw_dsearch(d, kfrom[p0 - 1], kcol[p0 - 1]);
+    if (t == 64) jr[1] = b == nchunk - 1 ? D : kw_dsearch(d, kfrom[last], kcol[last]);
+    for (u32 i = t; i < KW_ROWS * 5; i += KW_THREADS) kw_racc[i] = 0;
+    for (u32 i = t; i < KW_CH + 4; i += KW_THREADS) ins[i] = 0;
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) {
+        const u32 xq = (u32)q * KW_THREADS + t;
+        kF[xq] = xq < cnt ? fr[q] : 0xFFFFFFFFu; kC[xq] = xq < cnt ? co[q] : 0xFFFFFFFFu;
+        tc[q] = xq < cnt && (y[q].x >> 63) != 0;
+        const u64 m = __ballot(tc[q] ? 1 : 0);
+        if (lane == 0) { bal[q][wave] = m; wpre[q][wave] = (u32)__popcll(m); }
+    }
+    __syncthreads();
+    if (t < KW_Q) { u32 acc = 0; for (u32 w2 = 0; w2 < KW_NW; w2++) { const u32 c = wpre[t][w2]; wpre[t][w2] = acc; acc += c; } qpre[t + 1] = acc; }
+    __syncthreads();
+    if (t == 0) {
+        u32 run = 0;
+        for (int q = 0; q < KW_Q; q++) { const u32 c = qpre[q + 1]; qpre[q] = run; run += c; }
+        qpre[KW_Q] = run;
+        __hip_atomic_store(&d.kw_tot[b], ((u64)epoch << 32) | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *pre = 0;
+    }
+    const u32 jlo = jr[0], jhi = jr[1];
+    // the new edges' insertion points among the chunk's keys
+    for (u32 j = jlo + t; j < jhi; j += KW_THREADS) {
+        const u32 rf = d.dc_from[j], rc = d.dc_col[j];
+        u32 lo = 0, hi = cnt;
+        while (lo < hi) { const u32 m = (lo + hi) >> 1; const u32 mf = kF[m]; if (mf < rf || (mf == rf && kC[m] < rc)) lo = m + 1; else hi = m; }
+        d.dc_ip[j] = lo;
+        atomicAdd(&ins[lo], 1u);
+    }
+    __syncthreads();
+    {   // look-back: touched kept edges of the chunks before this one
+        u32 mine = 0;
+        for (u32 j = t; j < b; j += KW_THREADS) {
+            u64 w;
+            do { w = __hip_atomic_load(&d.kw_tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((u32)(w >> 32) != epoch);
+            mine += (u32)w;
+        }
+        if (b) { mine = wave_sum_u32(mine); if (lane == 0 && mine) atomicAdd(pre, mine); }
+    }
+    {   // ins[x] := new edges of this chunk inserted at a local index <= x
+        const u32 a0 = ins[4 * t], a1 = ins[4 * t + 1], a2 = ins[4 * t + 2], a3 = ins[4 * t + 3];
+        u32 tot;
+        const u32 ex = block_excl_scan<KW_THREADS>(a0 + a1 + a2 + a3, wsum, &tot);
+        ins[4 * t] = ex + a0; ins[4 * t + 1] = ex + a0 + a1; ins[4 * t + 2] = ex + a0 + a1 + a2; ins[4 * t + 3] = ex + a0 + a1 + a2 + a3;
+    }
+    __syncthreads();
+    const u32 base = *pre, total = qpre[KW_Q];
+    const u64 lt = (1ull << lane) - 1ull;
+    const u32 ME = (u32)d.max_edges;
+    auto rank_excl = [&](u32 xi) -> u32 {                            // touched kept edges of the chunk below local index xi
+        if (xi >= KW_CH) return total;
+        const u32 q = xi / KW_THREADS, tt = xi % KW_THREADS, w2 = tt >> 6, l2 = tt & 63u;
+        return qpre[q] + wpre[q][w2] + (u32)__popcll(bal[q][w2] & ((1ull << l2) - 1ull));
+    };
+    auto fold = [&](u32 row, u64 cnt_, u64 err, u64 sum, u64 ssq, u64 mx) {
+        const u32 r = row - v0;
+        if (r < KW_ROWS) {
+            u64* a = kw_racc + (size_t)r * 5;
+            if (cnt_) atomicAdd(&a[0], cnt_);
+            if (err) atomicAdd(&a[1], err);
+            if (sum) atomicAdd(&a[2], sum);
+            if (ssq) atomicAdd(&a[3], ssq);
+            if (mx) atomicMax(&a[4], mx);
+        } else {
+            u64* g = d.st_sum + (size_t)row * SG_NODE_STAT_SUM_WORDS;
+            if (cnt_) atomicAdd(&g[ST_OUT_CNT], cnt_);
+            if (err) atomicAdd(&g[ST_OUT_ERR], err);
+            if (sum) atomicAdd(&g[ST_OUT_SUM], sum);
+            if (ssq) atomicAdd(&g[ST_OUT_SSQ], ssq);
+            if (mx) atomicMax(&d.st_max[(size_t)row * 2], mx);
+        }
+    };
+    bool wsame[KW_Q];
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) {
+        const u32 f0 = rdlane32(fr[q], 0);
+        wsame[q] = __ballot(fr[q] == f0 ? 1 : 0) == ~0ull && f0 - v0 < KW_ROWS;
+    }
+    bool inw[KW_Q];
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) {
+        const u32 xq = (u32)q * KW_THREADS + t;
+        const u32 sh = jlo + ins[xq];
+        inw[q] = false;
+        if (xq < cnt) {
+            const u32 nk = p0 + xq + sh;
+            ncol[nk] = co[q]; nfrom[nk] = fr[q]; nslot[nk] = sl[q];
+            if (sh) d.wk_pos[sl[q]] = nk;
+        }
+        if (!tc[q]) continue;
+        const u32 np = base + qpre[q] + wpre[q][wave] + (u32)__popcll(bal[q][wave] & lt) + sh;
+        if (np >= ME) continue;
+        inw[q] = true;
+        const u64 mx = y[q].x & ~(1ull << 63);
+        d.col[np] = co[q]; d.csr_from[np] = fr[q]; d.alive_csr[np] = 0;
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)np * 4);
+        o[0] = x[q]; o[1] = make_ulonglong2(mx, y[q].y);
+        if (!wsame[q]) fold(fr[q], x[q].x & 0xFFFFFFFFull, x[q].x >> 32, x[q].y, y[q].y, mx);
+    }
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) if (wsame[q]) {                   // (uniform per wave) the wave's 64 positions lie in one row: reduced in the wave
+        const bool in = inw[q];
+        const u64 c_ = wave_sum_u64(in ? x[q].x & 0xFFFFFFFFull : 0ull), e_ = wave_sum_u64(in ? x[q].x >> 32 : 0ull);
+        const u64 s_ = wave_sum_u64(in ? x[q].y : 0ull), q_ = wave_sum_u64(in ? y[q].y : 0ull), m_ = wave_max_u64(in ? y[q].x & ~(1ull << 63) : 0ull);
+        if (lane == 0) fold(rdlane32(fr[q], 0), c_, e_, s_, q_, m_);
+    }
+    // the new edges
+    for (u32 j = jlo + t; j < jhi; j += KW_THREADS) {
+        const u32 xi = d.dc_ip[j], rf = d.dc_from[j], rc = d.dc_col[j];
+        const u32 img = d.dl_img[d.dc_slot[j]];
+        const u32 nk = p0 + xi + j;
+        ncol[nk] = rc; nfrom[nk] = rf; nslot[nk] = img; d.wk_pos[img] = nk;
+        const u64 np = (u64)base + rank_excl(xi) + j;
+        if (np >= ME) continue;
+        const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.dc_acc + (size_t)j * 4);
+        const ulonglong2 ax = a[0], ay = a[1];
+        const u64 mx = ay.x & ~(1ull << 63);
+        d.col[np] = rc; d.csr_from[np] = rf; d.alive_csr[np] = 0;
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)np * 4);
+        o[0] = ax; o[1] = make_ulonglong2(mx, ay.y);
+        fold(rf, ax.x & 0xFFFFFFFFull, ax.x >> 32, ax.y, ay.y, mx);
+    }
+    // row pointers of the rows that start in this chunk (window: by rank; kept: shifted by the new edges before the row)
+    for (u32 v = v_lo + t; v <= v_hi; v += KW_THREADS) {
+        const u32 kr = krp[v], dr = d.dc_rowptr[v];
+        const u64 rp = (u64)base + rank_excl(kr - p0) + dr;
+        d.rowptr[v] = rp < ME ? (u32)rp : ME;
+        nrp[v] = kr + dr;
+    }
+    if (b == nchunk - 1) {
+        const u64 Em = (u64)base + total, Ef = Em + D;
+        for (u32 v = v_hi + 1 + t; v <= N; v += KW_THREADS) {
+            const u32 dr = d.dc_rowptr[v];
+            const u64 rp = Em + dr;
+            d.rowptr[v] = rp < ME ? (u32)rp : ME;
+            nrp[v] = KE + dr;
+        }
+        if (t == 0) { d.ctr[C_N_EDGES] = Ef < ME ? Ef : ME; d.ctr[C_EDGES_FOUND] = Ef; if (Ef > ME) d.ctr[C_DROPPED_CAP] += Ef - ME; }
+    }
+    __syncthreads();
+    {
+        const u32 nr = v_hi - v0 + 1 < KW_ROWS ? v_hi - v0 + 1 : KW_ROWS;
+        for (u32 r = t; r < nr; r += KW_THREADS) {
+            const u64* a = kw_racc + (size_t)r * 5;
+            const u64 cnt_ = a[0], err = a[1], sum = a[2], ssq = a[3], mx = a[4];
+            if (!(cnt_ | err | sum | ssq | mx)) continue;
+            const u32 v = v0 + r;
+            u64* g = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
+            if (cnt_) atomicAdd(&g[ST_OUT_CNT], cnt_);
+            if (err) atomicAdd(&g[ST_OUT_ERR], err);
+            if (sum) atomicAdd(&g[ST_OUT_SUM], sum);
+            if (ssq) atomicAdd(&g[ST_OUT_SSQ], ssq);
+            if (mx) atomicMax(&d.st_max[(size_t)v * 2], mx);
+        }
+    }
+}
 __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* scratch_sum, u64* scratch_max, u64 seq) {
     extern __shared__ u64 kw_racc[];                                 // [KW_ROWS][5]: cnt, err, sum, ssq, max
     __shared__ u64 bal[KW_Q][KW_NW];
@@ -1823,6 +2048,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u32 KE = (u32)d.ctr[C_KEPT_E], N = (u32)d.ctr[C_N_NODES];
     const u32 nchunk = KE ? (KE + KW_CH - 1) / KW_CH : 1u;
+    const u32 buf = (u32)d.ctr[C_KEPT_BUF] & 1u;                      // the current kept buffer (a delta window writes the other one and k3_in_part flips)
+    const u32 D = (!d.ctr[C_COLD] && d.ctr[C_DELTA_N]) ? d.dc_rowptr[N] : 0u;   // (uniform) new edges of a warm window, sorted by the delta chain
     const u32 G = gridDim.x - KW_CAPW;                               // chunk workgroups of the launch
     u32 b = blockIdx.x - KW_CAPW;
     // Order by ticket (see k2_rowptr) only when the chunks that DO something cannot all be resident at once — three workgroups per CU.
@@ -1841,6 +2068,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
         d.ctr[C_ACT_L] = SG_ACT_NONE; d.ctr[C_ACT_P] = 0;
         d.ctr[C_HUB_ITEMS] = 0;                                      // the hub blocks of the WINDOW's rows are listed behind this kernel (kw_finish_rows); a rebuild's were the kept rows'
         if (!d.ctr[C_COLD]) d.ctr[C_WARM_WINDOWS] += 1;
+        if (D) d.ctr[C_DELTA_WINDOWS] += 1;
         // for the host's policy (it never waits for the device: it reads this note, a window or two late, when it closes a later window)
         d.host_note[1] = d.ctr[C_COLD] | (d.ctr[C_N_OBIP] ? 0x100ull : 0ull);
         __threadfence_system();
@@ -1851,17 +2079,19 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
         if (t == 0) { d.ctr[C_N_EDGES] = 0; d.ctr[C_EDGES_FOUND] = 0; }
         return;
     }
+    if (D) { kw_compact_delta(d, b, nchunk, epoch, KE, N, D, buf, kw_racc, bal, wpre, qpre, &pre); SG_STAMP(d, 2, 5); return; }
+    const u32* __restrict__ kcol = buf ? d.k_col2 : d.k_col; const u32* __restrict__ kfrom = buf ? d.k_from2 : d.k_from; const u32* __restrict__ krp = buf ? d.k_rowptr2 : d.k_rowptr;
     const u32 p0 = b * KW_CH, last = (p0 + KW_CH < KE ? p0 + KW_CH : KE) - 1;
     u32 fr[KW_Q], co[KW_Q]; ulonglong2 x[KW_Q], y[KW_Q]; bool tc[KW_Q];
 #pragma unroll
     for (int q = 0; q < KW_Q; q++) {
         const u32 i = p0 + (u32)q * KW_THREADS + t, ic = i <= last ? i : last;
-        fr[q] = d.k_from[ic]; co[q] = d.k_col[ic];
+        fr[q] = kfrom[ic]; co[q] = kcol[ic];
         const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.k_acc + (size_t)ic * 4);
         x[q] = a[0]; y[q] = a[1];
     }
-    const u32 v0 = d.k_from[p0], v_hi = d.k_from[last];              // first and last row with an edge in this chunk
-    const u32 v_lo = b == 0 ? 0u : d.k_from[p0 - 1] + 1u;            // rows that START here: (row of the position before the chunk, v_hi]
+    const u32 v0 = kfrom[p0], v_hi = kfrom[last];                    // first and last row with an edge in this chunk
+    const u32 v_lo = b == 0 ? 0u : kfrom[p0 - 1] + 1u;               // rows that START here: (row of the position before the chunk, v_hi]
     for (u32 i = t; i < KW_ROWS * 5; i += KW_THREADS) kw_racc[i] = 0;
 #pragma unroll
     for (int q = 0; q < KW_Q; q++) {
@@ -1947,7 +2177,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
     SG_STAMP(d, 2, 3);
     // new row pointers of the rows that start in this chunk: rank of the row's first kept position among the chunk's touched ones
     for (u32 v = v_lo + t; v <= v_hi; v += KW_THREADS) {
-        const u32 xl = d.k_rowptr[v] - p0, q = xl / KW_THREADS, tt = xl % KW_THREADS, w2 = tt >> 6, l2 = tt & 63u;
+        const u32 xl = krp[v] - p0, q = xl / KW_THREADS, tt = xl % KW_THREADS, w2 = tt >> 6, l2 = tt & 63u;
         const u32 rp = base + qpre[q] + wpre[q][w2] + (u32)__popcll(bal[q][w2] & ((1ull << l2) - 1ull));
         d.rowptr[v] = rp < ME ? rp : ME;
     }
@@ -2042,6 +2272,12 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
     const u32 E = (u32)d.ctr[C_N_EDGES], N = (u32)d.ctr[C_N_NODES];
     const u32 G = gridDim.x, g = blockIdx.x, t = threadIdx.x;
     SG_STAMP(d, 3, 0);
+    // a delta window's kw_compact (the launch before this one) has written the kept CSR, grown by the window's new edges, to the other
+    // buffer: flip (nothing in this launch reads the kept state; the next window's pass B and kw_compact do)
+    if (g == 0 && t == 0 && d.warm && !d.ctr[C_COLD] && d.ctr[C_DELTA_N]) {
+        d.ctr[C_KEPT_E] += (u64)d.dc_rowptr[N];
+        d.ctr[C_KEPT_BUF] ^= 1ull;                                    // (C_DELTA_N stays for the window's reader: sg_stats.windows_delta; kc_prepare re-arms it)
+    }
     alive_mark(d, g, G, t);
     const u32 r = g / S, sl = g % S, n0 = r * K3_IN_NR;
     if (n0 >= N) return;
@@ -2186,7 +2422,7 @@ __global__ __launch_bounds__(256) void k_reset_window(Dev d) {
     const u64 nc = (u64)d.ncap + 1;
     // (obkeys must be cleared here, not in K5: k5's rows reference OBIP ranks only, but a K1a of the next
     // window may already be enqueued behind this kernel — same stream, so ordering is by launch order)
-    if (!d.dh_g) for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) d.deg[i * SG_DEG_STRIDE] = 0;    // (dh_g: no degree counters — k2_deg_hist rewrites every count it uses)
+    if (!d.dh_g) for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) { d.deg[i * SG_DEG_STRIDE] = 0; if (d.warm) d.deg2[i * SG_DEG_STRIDE] = 0; }    // (dh_g: no degree counters — k2_deg_hist rewrites every count it uses)
     for (u64 i = tid; i < nc; i += nt) d.cursor[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
     for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;
@@ -2768,7 +3004,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
         // the counters stay: sg_window_read / the next kc_prepare consume them).
         const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nt = (u64)gridDim.x * 256;
         const u64 nc = (u64)d.ncap + 1;
-        if (!d.dh_g) for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) d.deg[i * SG_DEG_STRIDE] = 0;
+        if (!d.dh_g) for (u64 i = tid; i < nc * SG_DEG_REP; i += nt) { d.deg[i * SG_DEG_STRIDE] = 0; if (d.warm) d.deg2[i * SG_DEG_STRIDE] = 0; }
         for (u64 i = tid; i < nc; i += nt) d.cursor[i] = 0;
         for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_SUM_WORDS; i += nt) d.st_sum[i] = 0;
         for (u64 i = tid; i < (u64)d.ncap * SG_NODE_STAT_MAX_WORDS; i += nt) d.st_max[i] = 0;

@@ -48,7 +48,7 @@ class SgConfig(C.Structure):
 CFG_EDGE_HISTOGRAM = 1
 CFG_NO_WARM = 2
 CFG_WARM = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def make_config(*, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 256, max_outbound_ips: int = 64,
@@ -72,7 +72,8 @@ class SgStats(C.Structure):
                 ("events_misrouted", C.c_uint64), ("halo_overflow", C.c_uint64),
                 ("alive_in", C.c_uint64), ("alive_dropped", C.c_uint64),
                 ("join_word_updates", C.c_uint64), ("join_full_uploads", C.c_uint64), ("ingest_waits", C.c_uint64),
-                ("windows_warm", C.c_uint64), ("windows_cold", C.c_uint64)]
+                ("windows_warm", C.c_uint64), ("windows_cold", C.c_uint64),
+                ("windows_delta", C.c_uint64), ("windows_plain", C.c_uint64), ("last_window_new_edges", C.c_uint64)]
 
 
 class ServiceGraphError(RuntimeError):

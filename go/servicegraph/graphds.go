@@ -162,13 +162,17 @@ func New(inner datastore.DataStore, c Config) (*GraphDS, error) {
 // Close flushes nothing and frees the engine; no call may be in flight.
 func (g *GraphDS) Close() { C.sg_destroy(g.h) }
 
-// Stats: what the engine dropped or waited for since New (sg_stats, ABI 5).  DroppedRing are batches the staging ring had no room
+// Stats: what the engine dropped or waited for since New (sg_stats, ABI 6).  DroppedRing are batches the staging ring had no room
 // for (sg_ingest never blocks: the reference's PersistRequest would, datastore/backend.go:844); IngestWaits the sg_ingest calls that
 // met a window boundary being marked and waited for it — the only wait the library ever imposes on an aggregator goroutine.
 // WindowsWarm / WindowsCold: of the windows FlushWindow has read, how many were closed out of the kept edge set and how many were
 // rebuilt (a service map whose edges hardly change should settle on warm; both stay 0 for an engine that keeps no state).
+// WindowsDelta: of WindowsWarm, the windows that met edges the kept set lacked and merged them in (new edges cost a warm window a
+// little more, not a rebuild).  WindowsPlain: windows closed without touching the kept state at all (the engine's back-off after
+// repeated fall-backs, streams of raw outbound IPs) — counted in neither WindowsWarm nor WindowsCold, so the two need not add up to
+// Windows.
 type Stats struct {
-	EventsIn, DroppedSrc, DroppedRing, DroppedCap, Windows, IngestWaits, WindowsWarm, WindowsCold uint64
+	EventsIn, DroppedSrc, DroppedRing, DroppedCap, Windows, IngestWaits, WindowsWarm, WindowsCold, WindowsDelta, WindowsPlain uint64
 }
 
 func (g *GraphDS) Stats() Stats {
@@ -176,7 +180,8 @@ func (g *GraphDS) Stats() Stats {
 	C.sg_stats_get(g.h, &st)
 	return Stats{EventsIn: uint64(st.events_in), DroppedSrc: uint64(st.events_dropped_src), DroppedRing: uint64(st.events_dropped_ring),
 		DroppedCap: uint64(st.events_dropped_cap), Windows: uint64(st.windows), IngestWaits: uint64(st.ingest_waits),
-		WindowsWarm: uint64(st.windows_warm), WindowsCold: uint64(st.windows_cold)}
+		WindowsWarm: uint64(st.windows_warm), WindowsCold: uint64(st.windows_cold),
+		WindowsDelta: uint64(st.windows_delta), WindowsPlain: uint64(st.windows_plain)}
 }
 
 // SetClock hands over FirstKernelTime / FirstUserspaceTime (ebpf/l7_req/l7.go:707-710) for the early tap's StartTime.

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 5u   /* 5: warm windows — sg_stats.windows_warm / windows_cold, SG_CFG_NO_WARM, sg_set_warm; sg_timing_samples,
+#define SG_ABI_VERSION 6u   /* 6: delta windows — sg_stats.windows_delta / windows_plain / last_window_new_edges.  5: warm windows — sg_stats.windows_warm / windows_cold, SG_CFG_NO_WARM, sg_set_warm; sg_timing_samples,
                                sg_latency_probe;
                                4: sg_stats.ingest_waits, sg_geometry.pass_a_teams, sg_clock_probe;
                                3: sg_config begins with its own size (a binding compiled against an older, shorter sg_config is
@@ -223,6 +223,10 @@ typedef struct sg_stats {
                                       full channel instead (datastore/backend.go:844), this is the only wait on the aggregator's thread */
     uint64_t windows_warm;         /* of the windows READ so far (sg_flush_* / sg_window_read): closed on the warm path ...             */
     uint64_t windows_cold;         /* ... by the full rebuild (always, for an engine that keeps no state: then both stay 0)            */
+    uint64_t windows_delta;        /* of windows_warm: windows that met edges the kept set lacked and merged them in (ABI 6)           */
+    uint64_t windows_plain;        /* windows of a state-keeping engine closed WITHOUT touching the kept state (the host's back-off after
+                                      repeated fall-backs, raw-outbound-IP streams): counted in neither windows_warm nor windows_cold    */
+    uint64_t last_window_new_edges;/* edges the last read window added to the kept set                                                  */
 } sg_stats;
 
 typedef struct sg_engine* sg_handle;

@@ -25,7 +25,7 @@ def test_header_and_binding_declare_the_same_symbols():
 def test_library_builds_loads_and_exports_every_symbol(engine_lib):
     for name in _declared():
         assert hasattr(engine_lib, name), name
-    assert engine_lib.sg_abi_version() == engine.ABI_VERSION == 5
+    assert engine_lib.sg_abi_version() == engine.ABI_VERSION == 6
     from alaz_amd import weights
     assert engine_lib.sg_weights_count(1) == weights.weights_count(1) == 12993
     assert engine_lib.sg_weights_count(2) == weights.weights_count(2)
@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_every_symbol(engine_lib):
 
 
 def test_struct_layouts_match_the_header():
-    assert C.sizeof(engine.SgConfig) == 88 and C.sizeof(engine.SgStats) == 160 and C.sizeof(engine.SgGeometry) == 52
+    assert C.sizeof(engine.SgConfig) == 88 and C.sizeof(engine.SgStats) == 184 and C.sizeof(engine.SgGeometry) == 52
     assert engine.SgConfig.struct_size.offset == 0 and engine.SgConfig.abi_version.offset == 4 and engine.SgConfig.max_edges.offset == 32
     assert replay.EVENT_DTYPE.itemsize == 32 and replay.EDGE_OUT_DTYPE.itemsize == 64
     assert replay.EVENT_DTYPE.fields["duration_ns"][1] == 16 and replay.EVENT_DTYPE.fields["status"][1] == 12

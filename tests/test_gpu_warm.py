@@ -48,8 +48,11 @@ class Pair:
             g.set_label_count(len(self.labels))
             rows.append(g.flush_window().copy())
         st = self.warm.stats()
-        self.paths.append("warm" if st.windows_warm > before.windows_warm else "cold")
+        # "delta": a warm window that met edges the kept set lacked and merged them in (round 6); st.last_window_new_edges of them
+        self.paths.append(("delta" if st.windows_delta > before.windows_delta else "warm") if st.windows_warm > before.windows_warm else "cold")
         assert (st.windows_warm - before.windows_warm) + (st.windows_cold - before.windows_cold) == 1
+        assert (st.windows_delta > before.windows_delta) == (st.last_window_new_edges > 0)
+        self.new_edges = int(st.last_window_new_edges)
         self.o.packed(ev, self.labels); self.o.window_close(self.W, self.layers)
         compare_edge_dicts(engine_edge_dict(rows[0], self.shim, self.labels, self.warm.outbound_ips()), self.o.edge_dict())
         assert st.last_window_events == self.o.window_events and st.last_window_edges == len(rows[0]) == len(self.o.edge_dict())
@@ -71,8 +74,9 @@ def _events_on(topo, edge_idx, n, seed):
 
 def test_edge_appears_disappears_returns_first_window_cold():
     """window 1 is cold (nothing kept); the same edges again: warm; a subset: warm (the untouched kept edges leave the window's CSR);
-    edges the kept set lacks: cold (rebuild + capture — the kept set becomes the UNION of the old one and the window's); that window
-    again: warm; back to the first set: warm too, the union covers it; an empty window and a window behind it: warm both."""
+    edges the kept set lacks: a DELTA window (round 6: warm, the new edges are merged into the window's CSR and into the kept set — until
+    round 5 this was a full rebuild); that window again: warm; back to the first set: warm too, the kept set only grows; an empty window
+    and a window behind it: warm both."""
     topo = replay.make_topology(300, 9000, seed=21)
     labels = list(replay.EXTERNAL_HOSTS)
     ev, _ = replay.make_events(topo, 300_000, seed=31, fixed_labels=True)
@@ -90,12 +94,48 @@ def test_edge_appears_disappears_returns_first_window_cold():
     r4 = p.window(evSub)
     assert 0 < len(r4) < len(r1)
     p.window(evA)                                            # the kept set still covers A
-    p.window(evB)                                            # edges outside A: rebuild
+    p.window(evB)                                            # edges outside A: merged in
+    assert p.new_edges > 0
     p.window(evB)
     p.window(evA)                                            # A is not inside B, but inside what the engine has kept
     p.window(evA[:0])                                        # an empty window
     p.window(evA2)
-    assert p.paths == ["cold", "warm", "warm", "warm", "warm", "cold", "warm", "warm", "warm", "warm"], p.paths
+    assert p.paths == ["cold", "warm", "warm", "warm", "warm", "delta", "warm", "warm", "warm", "warm"], p.paths
+    p.close()
+
+
+def test_new_edges_window_after_window_are_merged_in_not_rebuilt():
+    """A stream that brings new edges in EVERY window (VERDICT r5 missing #2): ten slices of a graph's edges, window k replays slices
+    0..k — so each window meets a tenth of the graph for the first time, scattered over all rows and partitions: before, between and
+    behind the kept edges of a row, in rows that had no edge yet, hub rows included — then windows that skip slices (untouched kept
+    edges beside new ones), one slice alone, and everything again.  Only the first window is rebuilt; every window equals the oracle
+    and the rebuilding engine byte for byte."""
+    topo = replay.make_topology(400, 24000, seed=71)
+    labels = list(replay.EXTERNAL_HOSTS)
+    E = len(topo.edge_src)
+    rng = np.random.default_rng(5)
+    sl = rng.integers(0, 10, E)
+    p = Pair(topo, 2, 1 << 16, labels)
+    grown, seen = [], []
+    for k in range(10):
+        ev = _events_on(topo, np.nonzero(sl <= k)[0], 40_000 + 15_000 * k, 100 + k)
+        p.window(ev)
+        grown.append(p.new_edges); seen.append(ev)
+    assert p.paths == ["cold"] + ["delta"] * 9, p.paths
+    assert all(g > 0 for g in grown[1:]), grown
+    # nothing new: events the engine has seen (a fresh draw would bring new (pod, Host label) edges of its own)
+    p.window(seen[9][::3].copy())                             # a third of the last window's events: many kept edges untouched
+    p.window(seen[2])
+    p.window(np.concatenate([seen[9], seen[4]]))
+    assert p.paths[10:] == ["warm", "warm", "warm"], p.paths
+    # a second graph over the same pods: almost every edge is new at once (a delta far larger than a compaction chunk)
+    topo2 = replay.make_topology(400, 30000, seed=72)
+    ev2, _ = replay.make_events(replay.Topology(topo.n_pods, topo.n_svcs, topo.pod_ips, topo.svc_ips, topo2.edge_src, topo2.edge_dst, topo.seed), 200_000, seed=204, fixed_labels=True)
+    p.window(ev2)
+    assert p.paths[-1] == "delta" and p.new_edges > 10_000, (p.paths[-1], p.new_edges)
+    p.window(ev2)
+    p.window(seen[9])
+    assert p.paths[-2:] == ["warm", "warm"], p.paths
     p.close()
 
 
@@ -320,9 +360,9 @@ def test_a_stream_of_raw_outbound_ip_windows_stops_paying_for_the_kept_state():
 
 def test_config3_graph_three_windows_the_engines_own_rule_warm_equals_cold():
     """BASELINE config 3's graph (10 k pods, 1 M edges) under sg_create's OWN rule (no flag: the 8-byte path with the kept state from 2^18
-    edges up, degree atomics instead of histograms): window 1 = trace A (rebuild), window 2 = trace B (touches edges A did not: rebuild,
-    the kept set becomes the union), window 3 = trace A again — warm, a tenth of the kept edges untouched — must equal window 1 byte
-    for byte, and all three must equal the engine that rebuilds every window; window 1 is the oracle's (test_config3_full_size_row_for_row)."""
+    edges up, degree atomics instead of histograms): window 1 = trace A (rebuild), window 2 = trace B (touches ~10^5 edges A did not: a
+    delta window since round 6 — merged into the kept set, no rebuild), window 3 = trace A again — warm, a tenth of the kept edges
+    untouched — must equal window 1 byte for byte, and all three must equal the engine that rebuilds every window; window 1 is the oracle's (test_config3_full_size_row_for_row)."""
     topo = replay.make_topology(10_000, 1_000_000, replay.SEED_BASE + 3)
     A, labels = replay.make_events(topo, 3_000_000, replay.SEED_BASE + 3)
     B, _ = replay.make_events(topo, 3_000_000, replay.SEED_BASE + 77)
@@ -349,7 +389,7 @@ def test_config3_graph_three_windows_the_engines_own_rule_warm_equals_cold():
         rows.append(got[0])
     assert rows[0].tobytes() == rows[2].tobytes()
     st = a.stats()
-    assert (st.windows_warm, st.windows_cold) == (1, 2) and st.events_dropped_cap == 0
+    assert (st.windows_warm, st.windows_cold, st.windows_delta) == (2, 1, 1) and st.events_dropped_cap == 0
     a.close(); b.close()
 
 
