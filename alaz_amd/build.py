@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "servicegraph.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("sg_kernels.h", "sg_k1_narrow.h", "sg_k1_team.h", "sg_device.h", "sg_hash.h", "join_host.hpp")] + \
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("sg_kernels.h", "sg_k1_narrow.h", "sg_k1_team.h", "sg_device.h", "sg_hash.h", "join_host.hpp", "shard_seq.hpp")] + \
        [os.path.join(ROOT, "include", "servicegraph.h")]
 LIB = os.path.join(HERE, "lib", "libservicegraph.so")
 HOST_SRC = os.path.join(HERE, "csrc", "host")

@@ -1538,9 +1538,10 @@ int rc_all_reduce(void* x, void* buf, size_t n, int op) {
 int rc_group_begin(void* x) {
     sg_comm* c = (sg_comm*)x;
     if (!c->GroupStart || !c->GroupEnd) return SG_OK;
+    if (c->GroupStart()) return SG_ENODEV;                           // (no group opened: nothing to time, nothing to close)
     c->in_group = true;
     c->grp_t = new Timed(c->eng, c->stream, 9);
-    return c->GroupStart() ? SG_ENODEV : SG_OK;
+    return SG_OK;
 }
 int rc_group_end(void* x) {
     sg_comm* c = (sg_comm*)x;

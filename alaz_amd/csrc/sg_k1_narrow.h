@@ -494,7 +494,6 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     u32* htouch = out_n + 1;                                         // WM 1: [HT / 32] slots a record touched without counting; word HT / 32 = new keys inserted
     u32* hnew = htouch + HT / 32 + 1;                                // WM 1: [HT / 32] slots whose key the image lacked (inserted by this window's records)
     u32* nkeys = hnew + HT / 32;                                     // WM 1: keys in the table (the image's + the new ones): a partition keeps at most pcap
-    u32* coldf = nkeys + 1;                                          // WM 1: C_COLD as thread 0 read it (one value for the whole workgroup)
     const u32 t = threadIdx.x, NT = blockDim.x;
     // q -> (partition, sub-table): blocks b and b + 8 run on the same XCD (b % 8) and are dispatched back to back
     const u32 S = d.k1b_split, q = blockIdx.x;
@@ -603,11 +602,12 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             }
         }
     }
-    if constexpr (WM == 1) { if (t == 0) *coldf = (u32)d.ctr[C_COLD]; }   // (ONE read per workgroup: other workgroups may raise the flag while this one runs, and waves that
-                                                                     //  saw different values would part ways in front of the barriers below — ADVICE r5)
     __syncthreads();                                                 // every 32-bit max is in: 64-bit updates may follow
     SG_STAMP(d, 1, 3);
-    if constexpr (WM == 1) { if (*coldf) return; }                    // some workgroup gave up (a full table, a dropped edge): the rebuild repeats the merge, nothing this one writes is read
+    // (WM 1: until round 5 the workgroup looked at C_COLD again here and left when another one had given up — each wave for itself, so
+    // that waves which saw different values parted ways in front of the barriers below.  Since round 6 an unknown key no
+    // longer makes a window cold; what still does — a full table, a dropped edge — is rare, and a workgroup that finishes a merge nobody
+    // will read costs less than a dependent global load in front of every warm workgroup's barrier.)
     if constexpr (PACK) {                                            // unpack: a slot by one thread, nobody else touches the table here
         for (u32 i = t; i < HT; i += NT) { const u64 w = hacc[HT + i]; hacc[i] += w >> 48; hacc[HT + i] = w & ((1ull << 48) - 1ull); }
         __syncthreads();

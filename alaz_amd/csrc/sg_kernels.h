@@ -1198,12 +1198,13 @@ __global__ __launch_bounds__(256) void k2_scatter_parts(Dev dd) {
     if (cm < 0) return;
     const Dev d = cm == 1 ? sg_delta_view(dd) : dd;
     const u32 p = blockIdx.x, n = d.part_n[p];
+    if (cm == 1 && n == 0) return;                                   // (the new edges of a warm window: most partitions have none)
     // four edges per thread and trip: their loads (source, then row start + replica offset) are in flight together — one edge per
     // trip was two dependent round trips for each of a partition's ~4 edges per thread.  The slots are read whether or not they hold an
     // edge of this window (beyond the count: an older window's node ids — valid indices, ignored at the store): the first trip's loads
     // do not wait for the count.
     const u32 pc = d.pcap;
-    for (u32 i0 = threadIdx.x; i0 < pc && (i0 < 1024u || i0 < n); i0 += 1024) {
+    for (u32 i0 = threadIdx.x; i0 < pc && ((i0 < 1024u && cm != 1) || i0 < n); i0 += 1024) {
         u32 f[4], to[4], rk[4], slot[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -1843,76 +1844,116 @@ __device__ __forceinline__ void kw_capture(const Dev& d, u64* scratch_sum, u64* 
 #define KW_RESIDENT (3 * SG_LB_RESIDENT)                             // working chunks that are certainly resident together (<= 80 VGPRs, 21 KiB of LDS)
 
 // kw_compact on a DELTA window (round 6): the warm pass B met keys the kept set lacks and emitted them as new edges; the rebuild chain has
-// sorted them into the delta CSR (dc_rowptr / dc_col / dc_from / dc_acc, D edges).  The chunk does what it does on every warm window — the
-// kept CSR minus the untouched edges, stable — and merges the delta in, twice:
-//   * into the WINDOW's CSR: a touched kept edge lands at base + its rank among the touched ones + the new edges that sort before it;
-//     a new edge j (all of them are in the window) at j + the touched kept edges that sort before it;
-//   * into the KEPT CSR, written to the other buffer: kept position i -> i + the new edges before it, new edge j -> j + the kept edges
-//     before it; the image's positions follow (wk_pos[k_slot[i]], wk_pos[dl_img[..]]), so the next windows' pass B finds every edge warm.
-// Which new edges are this chunk's: those whose insertion point — the number of kept keys below theirs — lies in [p0, last]: two searches
-// in the delta CSR for the keys at the chunk's ends give the range [jlo, jhi), a binary search over the chunk's keys in LDS the point.
-// Row statistics leave with atomics throughout (a new edge of a row may belong to the chunk behind the one that holds the row).
-__device__ __forceinline__ u32 kw_dsearch(const Dev& d, u32 r, u32 c) {   // delta keys below (r, c)
-    u32 lo = d.dc_rowptr[r], hi = d.dc_rowptr[r + 1];
-    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (d.dc_col[m] < c) lo = m + 1; else hi = m; }
+// sorted them into the delta CSR (dc_rowptr / dc_col / dc_from / dc_acc, D edges).  The kept CSR (KE edges) and the delta CSR are two
+// sorted lists of (source, destination) keys without a common key; their MERGE is the new kept CSR (KE + D positions, written to the
+// other kept buffer: wk_pos follows through k_slot / dl_img), and the window's CSR is the merge minus the untouched kept edges.
+// Workgroup b owns the MERGED positions [b KW_CH, (b + 1) KW_CH) — not kept positions: a window whose new edges all sort into one
+// stretch of the kept order (a new pod's rows) had one chunk place fifty thousand of them, 246 us against 25 for its neighbours.  Two
+// merge-path searches (how many kept keys are among the first m merged ones) give the chunk its kept range [i0, i1) and its delta range
+// [j0, j1); the two short lists meet in LDS, every element finds its merged index by a binary search in the other list, a bit map of
+// the touched elements in merged order gives the ranks, and the look-back over the chunks' touched counts the base — as on any window.
+// Row statistics leave with atomics throughout (a row's elements may lie in two chunks whichever list they come from).
+__device__ __forceinline__ bool kw_key_less(u32 af, u32 ac, u32 bf, u32 bc) { return af < bf || (af == bf && ac < bc); }
+// kept keys among the first m of the merge (0 <= m <= KE + D): the smallest i in [max(0, m - D), min(m, KE)] whose kept key i is NOT below
+// the new key m - i - 1.  Called by a whole WAVE: 64 candidates per step (a one-lane binary search is ~20 dependent trips to memory of
+// four loads each — 15 us in front of every chunk of a delta window; 64-ary it is four).
+__device__ __forceinline__ u32 kw_merge_path(const u32* kfrom, const u32* kcol, const u32* dfrom, const u32* dcol, u32 KE, u32 D, u32 m) {
+    const u32 lane = threadIdx.x & 63u;
+    u32 lo = m > D ? m - D : 0u, hi = m < KE ? m : KE;
+    while (lo < hi) {                                                // (uniform)
+        const u32 span = hi - lo;
+        const u32 c = lo + (u32)(((u64)span * lane) >> 6);           // lo <= c < hi, ascending with the lane (repeats when span < 64)
+        const u32 j = m - c;                                         // >= 1 (c < hi <= m), <= D (c >= lo >= m - D)
+        const bool below = kw_key_less(kfrom[c], kcol[c], dfrom[j - 1], dcol[j - 1]);   // monotone: true up to some candidate, false from there on
+        const u32 nt = (u32)__popcll(__ballot(below ? 1 : 0));
+        const u32 nlo = nt ? (u32)__shfl((int)c, (int)nt - 1, 64) + 1u : lo;
+        const u32 nhi = nt < 64u ? (u32)__shfl((int)c, (int)nt, 64) : hi;
+        lo = nlo; hi = nhi;
+    }
     return lo;
 }
-__device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, const u32 nchunk, const u32 epoch, const u32 KE, const u32 N, const u32 D, const u32 buf,
-                                                 u64* kw_racc, u64 (*bal)[KW_NW], u32 (*wpre)[KW_NW], u32* qpre, u32* pre) {
-    __shared__ u32 kF[KW_CH], kC[KW_CH];                             // the chunk's kept keys (source, destination)
-    __shared__ u32 ins[KW_CH + 4];                                   // new edges inserted in front of local index x, then their inclusive prefix
-    __shared__ u32 wsum[KW_NW + 1];
-    __shared__ u32 jr[2];
-    const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+__device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, const u32 epoch, const u32 KE, const u32 N, const u32 D, const u32 buf,
+                                                 u64* kw_racc, u32* pre) {
+    __shared__ u32 kF[KW_CH], kC[KW_CH];                             // the chunk's keys: its kept ones [0, na), then its new ones [na, na + nd)
+    __shared__ u32 tbits[KW_CH / 32];                                // touched, by merged index
+    __shared__ u32 tpre[KW_CH / 32 + 1];                             // touched elements below word w
+    __shared__ u32 dg[4];                                            // i0, i1 (merge path), then rows
+    const u32 t = threadIdx.x, lane = t & 63u;
     const size_t KC = (size_t)d.npb * d.pcap;
     const u32* kcol = buf ? d.k_col2 : d.k_col; const u32* kfrom = buf ? d.k_from2 : d.k_from; const u32* krp = buf ? d.k_rowptr2 : d.k_rowptr;
     const u32* kslot = d.k_slot + (size_t)buf * KC;
     u32* ncol = buf ? d.k_col : d.k_col2; u32* nfrom = buf ? d.k_from : d.k_from2; u32* nrp = buf ? d.k_rowptr : d.k_rowptr2;
     u32* nslot = d.k_slot + (size_t)(buf ^ 1u) * KC;
-    const u32 p0 = b * KW_CH, last = (p0 + KW_CH < KE ? p0 + KW_CH : KE) - 1, cnt = last - p0 + 1;
-    u32 fr[KW_Q], co[KW_Q], sl[KW_Q]; ulonglong2 x[KW_Q], y[KW_Q]; bool tc[KW_Q];
-#pragma unroll
-    for (int q = 0; q < KW_Q; q++) {
-        const u32 i = p0 + (u32)q * KW_THREADS + t, ic = i <= last ? i : last;
-        fr[q] = kfrom[ic]; co[q] = kcol[ic]; sl[q] = kslot[ic];
-        const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.k_acc + (size_t)ic * 4);
-        x[q] = a[0]; y[q] = a[1];
-    }
-    const u32 v0 = kfrom[p0], v_hi = kfrom[last];
-    const u32 v_lo = b == 0 ? 0u : kfrom[p0 - 1] + 1u;
-    if (t == 0) jr[0] = b == 0 ? 0u : kw_dsearch(d, kfrom[p0 - 1], kcol[p0 - 1]);
-    if (t == 64) jr[1] = b == nchunk - 1 ? D : kw_dsearch(d, kfrom[last], kcol[last]);
+    const u32 M = KE + D, m0 = b * KW_CH, m1 = m0 + KW_CH < M ? m0 + KW_CH : M, cm = m1 - m0;   // (b < ceil(M / KW_CH): the caller saw to it)
+    const bool lastc = m1 == M;
+    if (t < 64) { const u32 r = kw_merge_path(kfrom, kcol, d.dc_from, d.dc_col, KE, D, m0); if (t == 0) dg[0] = r; }
+    else if (t < 128) { const u32 r = kw_merge_path(kfrom, kcol, d.dc_from, d.dc_col, KE, D, m1); if (t == 64) dg[1] = r; }
     for (u32 i = t; i < KW_ROWS * 5; i += KW_THREADS) kw_racc[i] = 0;
-    for (u32 i = t; i < KW_CH + 4; i += KW_THREADS) ins[i] = 0;
+    if (t < KW_CH / 32) tbits[t] = 0;
+    __syncthreads();
+    const u32 i0 = dg[0], i1 = dg[1], j0 = m0 - i0, j1 = m1 - i1, na = i1 - i0, nd = j1 - j0;   // na + nd = cm
+    // element s of the chunk's concatenated list: kept edge i0 + s (s < na) or new edge j0 + s - na
+    u32 fr[KW_Q], co[KW_Q], sl[KW_Q]; ulonglong2 x[KW_Q], y[KW_Q]; bool have[KW_Q], tc[KW_Q];
 #pragma unroll
     for (int q = 0; q < KW_Q; q++) {
-        const u32 xq = (u32)q * KW_THREADS + t;
-        kF[xq] = xq < cnt ? fr[q] : 0xFFFFFFFFu; kC[xq] = xq < cnt ? co[q] : 0xFFFFFFFFu;
-        tc[q] = xq < cnt && (y[q].x >> 63) != 0;
-        const u64 m = __ballot(tc[q] ? 1 : 0);
-        if (lane == 0) { bal[q][wave] = m; wpre[q][wave] = (u32)__popcll(m); }
+        const u32 s = (u32)q * KW_THREADS + t;
+        have[q] = s < cm;
+        if (!(have[q] && s >= na)) {
+            const u32 ic = (have[q] && s < na) ? i0 + s : 0u;        // (a thread without an element: kept position 0 — KE >= 1 on a warm window — ignored)
+            fr[q] = kfrom[ic]; co[q] = kcol[ic]; sl[q] = kslot[ic];
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.k_acc + (size_t)ic * 4);
+            x[q] = a[0]; y[q] = a[1];
+        } else {
+            const u32 j = j0 + (s - na);
+            fr[q] = d.dc_from[j]; co[q] = d.dc_col[j]; sl[q] = d.dl_img[d.dc_slot[j]];
+            const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.dc_acc + (size_t)j * 4);
+            x[q] = a[0]; y[q] = a[1];
+        }
+        if (have[q]) { kF[s] = fr[q]; kC[s] = co[q]; }
+        tc[q] = have[q] && (y[q].x >> 63) != 0;                      // (a new edge is touched by construction: pass B set the bit)
     }
     __syncthreads();
-    if (t < KW_Q) { u32 acc = 0; for (u32 w2 = 0; w2 < KW_NW; w2++) { const u32 c = wpre[t][w2]; wpre[t][w2] = acc; acc += c; } qpre[t + 1] = acc; }
-    __syncthreads();
-    if (t == 0) {
-        u32 run = 0;
-        for (int q = 0; q < KW_Q; q++) { const u32 c = qpre[q + 1]; qpre[q] = run; run += c; }
-        qpre[KW_Q] = run;
-        __hip_atomic_store(&d.kw_tot[b], ((u64)epoch << 32) | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *pre = 0;
-    }
-    const u32 jlo = jr[0], jhi = jr[1];
-    // the new edges' insertion points among the chunk's keys
-    for (u32 j = jlo + t; j < jhi; j += KW_THREADS) {
-        const u32 rf = d.dc_from[j], rc = d.dc_col[j];
-        u32 lo = 0, hi = cnt;
-        while (lo < hi) { const u32 m = (lo + hi) >> 1; const u32 mf = kF[m]; if (mf < rf || (mf == rf && kC[m] < rc)) lo = m + 1; else hi = m; }
-        d.dc_ip[j] = lo;
-        atomicAdd(&ins[lo], 1u);
+    SG_STAMP(d, 2, 1);
+    // merged index: own index in its list + the elements of the OTHER list below its key
+    u32 ml[KW_Q];
+#pragma unroll
+    for (int q = 0; q < KW_Q; q++) {
+        const u32 s = (u32)q * KW_THREADS + t;
+        ml[q] = 0;
+        if (!have[q]) continue;
+        const bool kept = s < na;
+        u32 lo = kept ? na : 0u, hi = kept ? cm : na;
+        while (lo < hi) { const u32 m = (lo + hi) >> 1; if (kw_key_less(kF[m], kC[m], fr[q], co[q])) lo = m + 1; else hi = m; }
+        ml[q] = kept ? s + (lo - na) : (s - na) + lo;
+        if (tc[q]) atomicOr(&tbits[ml[q] >> 5], 1u << (ml[q] & 31u));
     }
     __syncthreads();
-    {   // look-back: touched kept edges of the chunks before this one
+    if (t < 64) {                                                    // one wave: exclusive prefix over the 64 words' popcounts
+        const u32 c = (u32)__popc(tbits[t]);
+        u32 incl = c;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) { const u32 o = __shfl_up(incl, s2, 64); if ((int)lane >= s2) incl += o; }
+        tpre[t] = incl - c;
+        if (t == 63) {
+            tpre[64] = incl;
+            __hip_atomic_store(&d.kw_tot[b], ((u64)epoch << 32) | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *pre = 0;
+        }
+    }
+    // rows of the chunk's first and last element, of the element before the chunk (all uniform; through LDS)
+    if (t == 128) {
+        // the merged element m0 - 1 / m1 - 1 is the larger of the last kept and the last new key before the cut
+        auto row_before = [&](u32 i, u32 j) -> u32 {                 // row of the last of the first i kept + j new keys (i + j >= 1)
+            if (!j) return kfrom[i - 1];
+            if (!i) return d.dc_from[j - 1];
+            const u32 a = kfrom[i - 1], c = d.dc_from[j - 1];
+            return a > c ? a : c;                                    // (keys ascend in both lists: the later row is the later key's)
+        };
+        dg[2] = m0 ? row_before(i0, j0) + 1u : 0u;                   // v_lo: rows that START in this chunk begin behind the row of element m0 - 1
+        dg[3] = row_before(i1, j1);                                  // v_hi: the row of the chunk's last element
+    }
+    __syncthreads();
+    {   // look-back: touched elements of the chunks before this one
         u32 mine = 0;
         for (u32 j = t; j < b; j += KW_THREADS) {
             u64 w;
@@ -1921,20 +1962,15 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
         }
         if (b) { mine = wave_sum_u32(mine); if (lane == 0 && mine) atomicAdd(pre, mine); }
     }
-    {   // ins[x] := new edges of this chunk inserted at a local index <= x
-        const u32 a0 = ins[4 * t], a1 = ins[4 * t + 1], a2 = ins[4 * t + 2], a3 = ins[4 * t + 3];
-        u32 tot;
-        const u32 ex = block_excl_scan<KW_THREADS>(a0 + a1 + a2 + a3, wsum, &tot);
-        ins[4 * t] = ex + a0; ins[4 * t + 1] = ex + a0 + a1; ins[4 * t + 2] = ex + a0 + a1 + a2; ins[4 * t + 3] = ex + a0 + a1 + a2 + a3;
-    }
     __syncthreads();
-    const u32 base = *pre, total = qpre[KW_Q];
-    const u64 lt = (1ull << lane) - 1ull;
+    SG_STAMP(d, 2, 2);
+    const u32 base = *pre, total = tpre[64];
     const u32 ME = (u32)d.max_edges;
-    auto rank_excl = [&](u32 xi) -> u32 {                            // touched kept edges of the chunk below local index xi
-        if (xi >= KW_CH) return total;
-        const u32 q = xi / KW_THREADS, tt = xi % KW_THREADS, w2 = tt >> 6, l2 = tt & 63u;
-        return qpre[q] + wpre[q][w2] + (u32)__popcll(bal[q][w2] & ((1ull << l2) - 1ull));
+    const u32 v_lo = dg[2], v_hi = dg[3];
+    const u32 va = na ? kF[0] : 0xFFFFFFFFu, vb = nd ? kF[na] : 0xFFFFFFFFu, v0 = va < vb ? va : vb;   // the chunk's first row: the smaller of the two lists' first rows
+    auto rank_excl = [&](u32 mi) -> u32 {                            // touched elements of the chunk below merged index mi (mi <= cm)
+        if (mi >= KW_CH) return total;
+        return tpre[mi >> 5] + (u32)__popc(tbits[mi >> 5] & ((1u << (mi & 31u)) - 1u));
     };
     auto fold = [&](u32 row, u64 cnt_, u64 err, u64 sum, u64 ssq, u64 mx) {
         const u32 r = row - v0;
@@ -1954,25 +1990,21 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
             if (mx) atomicMax(&d.st_max[(size_t)row * 2], mx);
         }
     };
-    bool wsame[KW_Q];
+    bool wsame[KW_Q], inw[KW_Q];
 #pragma unroll
     for (int q = 0; q < KW_Q; q++) {
         const u32 f0 = rdlane32(fr[q], 0);
-        wsame[q] = __ballot(fr[q] == f0 ? 1 : 0) == ~0ull && f0 - v0 < KW_ROWS;
+        wsame[q] = __ballot((have[q] && fr[q] == f0) ? 1 : 0) == ~0ull && f0 - v0 < KW_ROWS;
     }
-    bool inw[KW_Q];
 #pragma unroll
     for (int q = 0; q < KW_Q; q++) {
-        const u32 xq = (u32)q * KW_THREADS + t;
-        const u32 sh = jlo + ins[xq];
         inw[q] = false;
-        if (xq < cnt) {
-            const u32 nk = p0 + xq + sh;
-            ncol[nk] = co[q]; nfrom[nk] = fr[q]; nslot[nk] = sl[q];
-            if (sh) d.wk_pos[sl[q]] = nk;
-        }
+        if (!have[q]) continue;
+        const u32 nk = m0 + ml[q];                                   // the element's position in the new kept CSR
+        ncol[nk] = co[q]; nfrom[nk] = fr[q]; nslot[nk] = sl[q];
+        d.wk_pos[sl[q]] = nk;
         if (!tc[q]) continue;
-        const u32 np = base + qpre[q] + wpre[q][wave] + (u32)__popcll(bal[q][wave] & lt) + sh;
+        const u64 np = (u64)base + rank_excl(ml[q]);
         if (np >= ME) continue;
         inw[q] = true;
         const u64 mx = y[q].x & ~(1ull << 63);
@@ -1982,46 +2014,27 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
         if (!wsame[q]) fold(fr[q], x[q].x & 0xFFFFFFFFull, x[q].x >> 32, x[q].y, y[q].y, mx);
     }
 #pragma unroll
-    for (int q = 0; q < KW_Q; q++) if (wsame[q]) {                   // (uniform per wave) the wave's 64 positions lie in one row: reduced in the wave
+    for (int q = 0; q < KW_Q; q++) if (wsame[q]) {                   // (uniform per wave) the wave's 64 elements lie in one row: reduced in the wave
         const bool in = inw[q];
         const u64 c_ = wave_sum_u64(in ? x[q].x & 0xFFFFFFFFull : 0ull), e_ = wave_sum_u64(in ? x[q].x >> 32 : 0ull);
         const u64 s_ = wave_sum_u64(in ? x[q].y : 0ull), q_ = wave_sum_u64(in ? y[q].y : 0ull), m_ = wave_max_u64(in ? y[q].x & ~(1ull << 63) : 0ull);
         if (lane == 0) fold(rdlane32(fr[q], 0), c_, e_, s_, q_, m_);
     }
-    // the new edges
-    for (u32 j = jlo + t; j < jhi; j += KW_THREADS) {
-        const u32 xi = d.dc_ip[j], rf = d.dc_from[j], rc = d.dc_col[j];
-        const u32 img = d.dl_img[d.dc_slot[j]];
-        const u32 nk = p0 + xi + j;
-        ncol[nk] = rc; nfrom[nk] = rf; nslot[nk] = img; d.wk_pos[img] = nk;
-        const u64 np = (u64)base + rank_excl(xi) + j;
-        if (np >= ME) continue;
-        const ulonglong2* a = reinterpret_cast<const ulonglong2*>(d.dc_acc + (size_t)j * 4);
-        const ulonglong2 ax = a[0], ay = a[1];
-        const u64 mx = ay.x & ~(1ull << 63);
-        d.col[np] = rc; d.csr_from[np] = rf; d.alive_csr[np] = 0;
-        ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)np * 4);
-        o[0] = ax; o[1] = make_ulonglong2(mx, ay.y);
-        fold(rf, ax.x & 0xFFFFFFFFull, ax.x >> 32, ax.y, ay.y, mx);
-    }
-    // row pointers of the rows that start in this chunk (window: by rank; kept: shifted by the new edges before the row)
+    SG_STAMP(d, 2, 3);
+    // row pointers of the rows that start in this chunk: a row starts at the merged position krp + dc_rowptr
     for (u32 v = v_lo + t; v <= v_hi; v += KW_THREADS) {
-        const u32 kr = krp[v], dr = d.dc_rowptr[v];
-        const u64 rp = (u64)base + rank_excl(kr - p0) + dr;
+        const u32 ns = krp[v] + d.dc_rowptr[v];
+        nrp[v] = ns;
+        const u64 rp = (u64)base + rank_excl(ns - m0);
         d.rowptr[v] = rp < ME ? (u32)rp : ME;
-        nrp[v] = kr + dr;
     }
-    if (b == nchunk - 1) {
-        const u64 Em = (u64)base + total, Ef = Em + D;
-        for (u32 v = v_hi + 1 + t; v <= N; v += KW_THREADS) {
-            const u32 dr = d.dc_rowptr[v];
-            const u64 rp = Em + dr;
-            d.rowptr[v] = rp < ME ? (u32)rp : ME;
-            nrp[v] = KE + dr;
-        }
+    if (lastc) {
+        const u64 Ef = (u64)base + total;
+        for (u32 v = v_hi + 1 + t; v <= N; v += KW_THREADS) { nrp[v] = M; d.rowptr[v] = Ef < ME ? (u32)Ef : ME; }
         if (t == 0) { d.ctr[C_N_EDGES] = Ef < ME ? Ef : ME; d.ctr[C_EDGES_FOUND] = Ef; if (Ef > ME) d.ctr[C_DROPPED_CAP] += Ef - ME; }
     }
     __syncthreads();
+    SG_STAMP(d, 2, 4);
     {
         const u32 nr = v_hi - v0 + 1 < KW_ROWS ? v_hi - v0 + 1 : KW_ROWS;
         for (u32 r = t; r < nr; r += KW_THREADS) {
@@ -2047,9 +2060,9 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
     if (blockIdx.x < KW_CAPW) { kw_capture(d, scratch_sum, scratch_max, blockIdx.x, KW_CAPW, KW_THREADS); return; }
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u32 KE = (u32)d.ctr[C_KEPT_E], N = (u32)d.ctr[C_N_NODES];
-    const u32 nchunk = KE ? (KE + KW_CH - 1) / KW_CH : 1u;
     const u32 buf = (u32)d.ctr[C_KEPT_BUF] & 1u;                      // the current kept buffer (a delta window writes the other one and k3_in_part flips)
     const u32 D = (!d.ctr[C_COLD] && d.ctr[C_DELTA_N]) ? d.dc_rowptr[N] : 0u;   // (uniform) new edges of a warm window, sorted by the delta chain
+    const u32 nchunk = (KE + D) ? (KE + D + KW_CH - 1) / KW_CH : 1u; // (a delta window's chunks cut the MERGE of the kept and the new edges: kw_compact_delta)
     const u32 G = gridDim.x - KW_CAPW;                               // chunk workgroups of the launch
     u32 b = blockIdx.x - KW_CAPW;
     // Order by ticket (see k2_rowptr) only when the chunks that DO something cannot all be resident at once — three workgroups per CU.
@@ -2079,7 +2092,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
         if (t == 0) { d.ctr[C_N_EDGES] = 0; d.ctr[C_EDGES_FOUND] = 0; }
         return;
     }
-    if (D) { kw_compact_delta(d, b, nchunk, epoch, KE, N, D, buf, kw_racc, bal, wpre, qpre, &pre); SG_STAMP(d, 2, 5); return; }
+    if (D) { kw_compact_delta(d, b, epoch, KE, N, D, buf, kw_racc, &pre); SG_STAMP(d, 2, 5); return; }
     const u32* __restrict__ kcol = buf ? d.k_col2 : d.k_col; const u32* __restrict__ kfrom = buf ? d.k_from2 : d.k_from; const u32* __restrict__ krp = buf ? d.k_rowptr2 : d.k_rowptr;
     const u32 p0 = b * KW_CH, last = (p0 + KW_CH < KE ? p0 + KW_CH : KE) - 1;
     u32 fr[KW_Q], co[KW_Q]; ulonglong2 x[KW_Q], y[KW_Q]; bool tc[KW_Q];

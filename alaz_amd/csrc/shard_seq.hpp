@@ -56,10 +56,15 @@ static inline int sg_run_sharded_window(const sg_shard_stages* s, const sg_shard
     SG_SEQ(s->obip_list(s->ctx));
     SG_SEQ(c->all_gather(c->ctx, s->ob_local, s->ob_all, s->ob_bytes));
     SG_SEQ(s->close_gathered(s->ctx));
-    if (c->group_begin && c->group_end) SG_SEQ(c->group_begin(c->ctx));
-    SG_SEQ(c->all_reduce_u64(c->ctx, s->stats_sum, s->stats_sum_words, 0));
-    SG_SEQ(c->all_reduce_u64(c->ctx, s->stats_max, s->stats_max_words, 1));
-    if (c->group_begin && c->group_end) SG_SEQ(c->group_end(c->ctx));
+    {   // the SUM and the MAX all-reduce as one grouped launch; a failure inside the group still closes it (an open group would swallow
+        // every later collective of this communicator)
+        const bool grp = c->group_begin && c->group_end;
+        if (grp) SG_SEQ(c->group_begin(c->ctx));
+        int rc_ = c->all_reduce_u64(c->ctx, s->stats_sum, s->stats_sum_words, 0);
+        if (!rc_) rc_ = c->all_reduce_u64(c->ctx, s->stats_max, s->stats_max_words, 1);
+        if (grp) { const int re_ = c->group_end(c->ctx); if (!rc_) rc_ = re_; }
+        if (rc_) return rc_;
+    }
     SG_SEQ(s->features(s->ctx));
     SG_SEQ(s->halo_build(s->ctx));
     SG_SEQ(c->all_to_all(c->ctx, s->req, s->serve, s->list_bytes));

@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--batches", type=int, default=0, help="distinct event batches in the HBM ring (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-churn", action="store_true", help="skip the churn leg (windows that bring 0.1 % / 1 % / 4 % new edges)")
     ap.add_argument("--stream", action="store_true", help="config 5 only: add the streaming run (tools/c5_stream.py: raw 1096-byte records at the "
                                                          "nominal 5 M events/s through the C++ host side, a window per second, ten windows)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="seconds per CPU-baseline variant")
@@ -341,7 +342,7 @@ def _engine_for(a, topo, labels, c, device, windows, engine, weights):
                             max_labels=max(64, len(labels)), max_outbound_ips=64, device=device, max_batch=int(os.environ.get("SG_BENCH_MAX_BATCH", 1 << 20)),
                             max_window_events=max(1, c["events"] // a.shard_of), windows_in_flight=windows,
                             # config 5's Kafka / Postgres requests to outside addresses are raw outbound IPs in every window: no window can close warm
-                            # (the engine finds that out by itself from the windows it READS; this replay reads none, so it is told)
+                            # (the engine would find that out from the note its device side leaves at every close, four windows late; the replay is told)
                             warm=False if big else None)
     g.set_clock(1_000_000_000, 1_700_000_000_000_000_000)
     g.load_weights(weights.make_weights(L))
@@ -351,6 +352,78 @@ def _engine_for(a, topo, labels, c, device, windows, engine, weights):
         g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
     g.set_label_count(len(labels))
     return g
+
+
+def churn_leg(a, topo, labels, c, device, dev, Ev, nb, steady_ms):
+    """What a window costs when it meets edges the engine has not seen: a fresh engine is warmed on the ring's traces, then
+    every window = one of those traces + a small batch of requests on NEW (pod, service) pairs — 0.1 %, 1 % and 4 % of the graph's edges per
+    window, drawn at random over all rows, never repeated.  Since round 6 such a window stays warm: the new edges are merged into the
+    window's CSR and into the kept set (delta window).  One hipEvent pair per window (timing group 10), median / min over the windows of a
+    rate; every window is read back, so sg_stats says which path each one took."""
+    import torch
+    from alaz_amd import engine, replay, weights
+    g = _engine_for(a, topo, labels, c, device, 1, engine, weights)
+    P, S, E0 = topo.n_pods, topo.n_svcs, len(topo.edge_src)
+    rng = np.random.default_rng(20260930)
+    have = (topo.edge_src.astype(np.uint64) << np.uint64(32)) | topo.edge_dst.astype(np.uint64)
+    tmpl = np.zeros(1, dtype=replay.EVENT_DTYPE)
+    def batch_of_new_edges(n):
+        nonlocal have
+        src = rng.integers(0, P, size=2 * n + 64).astype(np.uint64); dst = (P + rng.integers(0, S, size=2 * n + 64)).astype(np.uint64)
+        key = (src << np.uint64(32)) | dst
+        key = np.unique(key[~np.isin(key, have)])
+        key = rng.permutation(key)[:n]
+        have = np.concatenate([have, key])
+        ev = np.repeat(tmpl, 4 * len(key))
+        s_ = (key >> np.uint64(32)).astype(np.int64); d_ = (key & np.uint64(0xFFFFFFFF)).astype(np.int64) - P
+        ev["saddr"] = np.repeat(topo.pod_ips[s_], 4); ev["daddr"] = np.repeat(topo.svc_ips[d_], 4)
+        ev["status"] = 200; ev["protocol"] = 1
+        ev["duration_ns"] = rng.integers(1_000_000, 20_000_000, size=len(ev)); ev["write_time_ns"] = 2_000_000_000 + np.arange(len(ev), dtype=np.uint64)
+        return torch.from_numpy(ev.view(np.uint8).reshape(-1)).cuda(), len(ev), len(key)
+    out = []
+    try:
+        for i in range(4):                                           # the ring's traces: everything after this is warm unless a window brings something new
+            g.ingest_device(dev[i % nb].data_ptr(), Ev, 0); g.window_run(0)
+        torch.cuda.synchronize()
+        wi = 0
+        for rate in (0.001, 0.01, 0.04):
+            W = 6
+            extra = [batch_of_new_edges(max(1, int(rate * E0))) for _ in range(W)]
+            torch.cuda.synchronize()
+            before = g.stats()
+            g.timing_reset(); g.timing_enable(1 << 10)
+            new_seen = []
+            for k in range(W):
+                g.ingest_device(dev[wi % nb].data_ptr(), Ev, 0); wi += 1
+                g.ingest_device(extra[k][0].data_ptr(), extra[k][1], 0)
+                g.window_run(0)
+                torch.cuda.synchronize()
+                g.window_read(); new_seen.append(int(g.stats().last_window_new_edges))
+            g.timing_enable(0)
+            w = np.sort(g.timing_samples(10, W + 8))
+            st = g.stats()
+            # the SAME windows once more: their edges are known now — what the window costs without anything new (it has a second,
+            # small pass-A launch for the extra batch, which the replay's steady window has not)
+            g.timing_reset(); g.timing_enable(1 << 10)
+            for k in range(W):
+                g.ingest_device(dev[wi % nb].data_ptr(), Ev, 0); wi += 1
+                g.ingest_device(extra[k][0].data_ptr(), extra[k][1], 0)
+                g.window_run(0)
+                torch.cuda.synchronize()
+            g.timing_enable(0)
+            w2 = np.sort(g.timing_samples(10, W + 8))
+            out.append({"new_edges_per_window": extra[0][2], "share_of_graph": rate, "windows": W,
+                        "ms_per_window_median": round(float(np.median(w)) / 1e3, 5), "ms_per_window_min": round(float(w[0]) / 1e3, 5),
+                        "ms_same_windows_edges_known": round(float(np.median(w2)) / 1e3, 5),
+                        "vs_same_windows_edges_known": round(float(np.median(w)) / float(np.median(w2)), 3),
+                        "vs_steady_window": round(float(np.median(w)) / 1e3 / steady_ms, 3) if steady_ms else None,
+                        "new_edges_merged": new_seen,
+                        "paths": {"warm": int(st.windows_warm - before.windows_warm), "of_them_delta": int(st.windows_delta - before.windows_delta),
+                                  "cold": int(st.windows_cold - before.windows_cold), "plain": int(st.windows_plain - before.windows_plain)}})
+            del extra
+    finally:
+        g.close()
+    return out
 
 
 def bench_single(a, device):
@@ -481,6 +554,13 @@ def bench_single(a, device):
         for i in range(2):                                   # (back on the warm path for the passes below)
             step(i)
         torch.cuda.synchronize()
+    # churn: windows that bring new edges (a fresh engine; this one's kept set stays what the replay made it)
+    churn = None
+    if geo_warm(g) and not a.profile_mode and a.shard_of == 1 and cfgno != 5 and not a.no_churn:
+        try:
+            churn = churn_leg(a, topo, labels, c, device, dev, Ev, nb, per_step["median_ms"] if per_step else None)
+        except Exception as ex:                              # noqa: BLE001  (a diagnostic leg must never cost the line)
+            churn = {"error": repr(ex)[:300]}
     # one untimed window with copy-out: how many edges / nodes a window of this workload has
     g.ingest_device(dev[0].data_ptr(), Ev, s)
     torch.cuda.synchronize()
@@ -553,6 +633,8 @@ def bench_single(a, device):
         # `value` / ms_per_step are the STEADY STATE of a replay whose windows touch the same edges: every timed window is closed on the warm
         # path (windows_warm_in_check_read says what the window read back at the end was); cold = the same steps with the warm path off
         "warm_windows": {"engine_keeps_state": bool(geo_warm(g)), "cold": cold, "cold_ms_per_step": cold["ms_per_step"] if cold else None,
+                         # windows that meet NEW edges (0.1 % / 1 % / 4 % of the graph per window, spread over all rows): merged in, not rebuilt
+                         "churn": churn,
                          "windows_read": {"warm": int(st.windows_warm), "cold": int(st.windows_cold)}},
         "value_basis": "mean over the timed steps (wall clock around K back-to-back windows, one window in flight); per_step holds median / min of single windows",
     }

@@ -28,14 +28,24 @@ def run(warm, steady):
         g.ingest_device(dev[0].data_ptr(), Ev, 0); g.window_run(0)
     torch.cuda.synchronize()
     g.timing_reset(); g.timing_enable(1 << 10)
+    g.window_read(); st = g.stats(); seen = (st.windows_warm, st.windows_cold, st.windows_plain, st.windows_delta); paths = []
     for k in range(W):
         g.ingest_device(dev[0 if steady else k].data_ptr(), Ev, 0); g.window_run(0)
         torch.cuda.synchronize()                             # windows are seconds apart in production: the host closes one knowing how the last one went
+        g.window_read(); st = g.stats()                      # (untimed: group 10 ends behind the score kernel) — which path the window took
+        paths.append("cold" if st.windows_cold > seen[1] else ("plain" if st.windows_plain > seen[2] else (f"delta+{st.last_window_new_edges}" if st.windows_delta > seen[3] else "warm")))
+        seen = (st.windows_warm, st.windows_cold, st.windows_plain, st.windows_delta)
+        if os.environ.get("SG_ABLATE") and k in (0, 3):          # phase stamps of this window's kw_compact (SG_ABLATE=0x100)
+            a = g.debug_stamps()[2].astype(np.int64); a = a[a[:, 0] != 0]; t0 = a[:, 0].min()
+            print(f"   window {k} ({paths[-1]}): kw_compact {len(a)} workgroups; phase ends (us, min / mean / max):",
+                  [(round(float(((a[:, q] - t0) / 100.0).min()), 1), round(float(((a[:, q] - t0) / 100.0).mean()), 1), round(float(((a[:, q] - t0) / 100.0).max()), 1)) for q in range(6)])
     g.timing_enable(0)
     w = g.timing_samples(10)
+    print("   paths:", paths)
     g.close()
     return [round(float(x), 1) for x in w]
 print("new edges every window, warm engine :", run(None, False))
+if os.environ.get("CHURN_ONLY_FIRST"): sys.exit(0)
 print("new edges every window, rebuild only:", run(False, False))
 print("same trace every window, warm engine:", run(None, True))
 print("same trace every window, rebuild only:", run(False, True))
