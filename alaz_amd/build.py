@@ -14,6 +14,9 @@ SRC = os.path.join(HERE, "csrc", "servicegraph.hip")
 DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("sg_kernels.h", "sg_k1_narrow.h", "sg_k1_team.h", "sg_device.h", "sg_hash.h", "join_host.hpp", "shard_seq.hpp")] + \
        [os.path.join(ROOT, "include", "servicegraph.h")]
 LIB = os.path.join(HERE, "lib", "libservicegraph.so")
+# the development build of the same sources (-DSG_DEV_KNOBS: SG_* tuning knobs read from the environment, SG_ABLATE bits and phase
+# stamps compiled into the kernels) — what tools/ and the A/B tests of alternative kernel paths load; the shipped library has none of it
+LIB_DEV = os.path.join(HERE, "lib", "libservicegraph_dev.so")
 HOST_SRC = os.path.join(HERE, "csrc", "host")
 HOST_LIB = os.path.join(HERE, "lib", "libsgdatastore.so")
 
@@ -29,13 +32,14 @@ def _stale(target: str, deps) -> bool:
     return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps if os.path.exists(d))
 
 
-def build_engine(force: bool = False) -> str:
-    if force or _stale(LIB, DEPS):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", "-Wno-unused-value", "-o", LIB, SRC]
+def build_engine(force: bool = False, dev: bool = False) -> str:
+    lib = LIB_DEV if dev else LIB
+    if force or _stale(lib, DEPS):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wl,-Bsymbolic",
+               "-Wno-unused-function", "-Wno-unused-value"] + (["-DSG_DEV_KNOBS"] if dev else []) + ["-o", lib, SRC]
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 def build_host(force: bool = False) -> str | None:
@@ -52,7 +56,11 @@ def build_host(force: bool = False) -> str | None:
 
 
 def build_all(force: bool = False):
-    return build_engine(force), build_host(force)
+    """both engine builds side by side (two hipcc runs of the same translation unit) and the host library"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as ex:
+        a, b = ex.submit(build_engine, force, False), ex.submit(build_engine, force, True)
+        return a.result(), build_host(force), b.result()
 
 
 if __name__ == "__main__":

@@ -36,6 +36,16 @@ struct TimingRec { hipEvent_t a, b; int kernel; };
 
 u32 next_pow2(u64 v) { u64 p = 1; while (p < v) p <<= 1; return (u32)p; }
 
+// Tuning knobs (SG_NP, SG_HT, SG_K1A, SG_ABLATE, ...: tools/k1_sweep.py, the A/B tests of alternative kernel paths) are read from the
+// environment by the DEVELOPMENT build only (-DSG_DEV_KNOBS -> lib/libservicegraph_dev.so); the shipped library reads none.
+inline const char* sg_knob(const char* name) {
+#ifdef SG_DEV_KNOBS
+    return std::getenv(name);
+#else
+    (void)name; return nullptr;
+#endif
+}
+
 }  // namespace
 
 struct sg_engine {
@@ -189,23 +199,25 @@ bool k1a_geometry(sg_engine* e) {
     if (d.narrow) {
         // cache | 6 counters per partition | statistics | tile | join tables.  Level 2 is staged as u16 entries
         // (half the bytes) when every node id fits 14 bits.
-        e->l2_u16 = e->cfg.max_known_nodes <= 16384 && !std::getenv("SG_L2_U32");
+        e->l2_u16 = e->cfg.max_known_nodes <= 16384 && !sg_knob("SG_L2_U32");
         const size_t l2lds = e->l2_u16 ? l2b / 2 : l2b;
-        if (const char* v = std::getenv("SG_NSUB")) { const int x = std::atoi(v); if (x == 1 || x == 2) e->k1a_nsub = (u32)x; }
+        if (const char* v = sg_knob("SG_NSUB")) { const int x = std::atoi(v); if (x == 1 || x == 2) e->k1a_nsub = (u32)x; }
         // round 4: two teams per workgroup (k1a_team_partition) when their two tiles and counter sets fit beside a cache of 256 slots or
         // more; SG_K1A=tile keeps the one-team kernel (k1a_tile_partition), SG_K1A=team takes the two-team kernel whenever it fits at all
-        const char* kv = std::getenv("SG_K1A");
+        const char* kv = sg_knob("SG_K1A");
         const bool want_tile = kv && !std::strcmp(kv, "tile"), force_team = kv && !std::strcmp(kv, "team");
         const size_t fixed_tile = (size_t)d.np * 24 + 64 + (size_t)K1T_TS(e->k1a_nsub) * 8 + l1b;
         // the two-team kernel is instantiated for 256 / 512 / 1024 partitions, 1024 threads (two teams of eight waves, one group of four events
-        // per thread and tile: round 6; round 4 ran two groups at 768 threads), the one-thread-per-position copy-out (2 nb <= 31) and a join
-        // blob its prologue can stage; everything else keeps the one-team kernel
+        // per thread and tile: round 6; round 4 ran two groups at 768 threads) and a join blob its prologue can stage; everything else keeps
+        // the one-team kernel
         const int teams = 2, nt = 1024;
         const size_t lds_cap = kLdsBytes;
         // (what the team kernel's prologue can stage: six 16-byte words per lane of its threads.  Level 1 always goes through it, level 2
         // only when it is staged — an engine whose level 2 stays in global memory needs room for level 1 alone)
         const size_t stage_team = (size_t)K1A_NJ * nt * 16;
-        const bool team_ok = (d.np == 256 || d.np == 512 || d.np == 1024) && 2 * d.nb <= 31 && (size_t)d.np * d.nwg * d.punits * 8 < ((size_t)1 << 31) && l1b <= stage_team;
+        // (endpoint spaces beyond 15 bits — a shard of BASELINE config 5: 18 — leave no room for the partition number in a parked record: the
+        // kernel's 16-lanes-per-run copy-out takes over, the workgroup has the 1024 threads it is written for since round 6)
+        const bool team_ok = (d.np == 256 || d.np == 512 || d.np == 1024) && (size_t)d.np * d.nwg * d.punits * 8 < ((size_t)1 << 31) && l1b <= stage_team;
         e->k1a_teams = (u32)teams; e->k1a_nt = (u32)nt;
         const size_t fixed_team = K1M_LDS_FIXED(d.np, teams, nt) + l1b;
         auto pick = [&](size_t fixed, u32 ct_min, size_t stage_cap, u32& ct, bool& in_lds) {
@@ -220,8 +232,8 @@ bool k1a_geometry(sg_engine* e) {
         if (!ct) pick(fixed_tile, 64u, stage_max, ct, in_lds);
         const size_t fixed = e->k1a_team ? fixed_team : fixed_tile;
         e->l2_in_lds = in_lds;
-        if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
-        if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2lds : 0) <= lds_cap) ct = x; }
+        if (sg_knob("SG_L2_GLOBAL")) e->l2_in_lds = false;
+        if (const char* v = sg_knob("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * 40 + fixed + (e->l2_in_lds ? l2lds : 0) <= lds_cap) ct = x; }
         if (!ct || l1b > stage_max) return false;
         e->k1a_ct = ct;
         e->k1a_lds = (size_t)ct * 40 + fixed + (e->l2_in_lds ? l2lds : 0);
@@ -233,8 +245,8 @@ bool k1a_geometry(sg_engine* e) {
     for (u32 c : {2048u, 1024u, 512u}) if ((size_t)c * slot + fixed + l2b <= kLdsBytes && l1b + l2b <= stage_max) { e->l2_in_lds = true; ct = c; break; }
     // level 2 stays in global memory: the largest cache that fits beside the counters and level 1
     if (!ct) for (u32 c : {2048u, 1024u, 512u, 256u, 128u, 64u}) if ((size_t)c * slot + fixed <= kLdsBytes) { ct = c; break; }
-    if (const char* v = std::getenv("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * slot + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) ct = x; }
-    if (std::getenv("SG_L2_GLOBAL")) e->l2_in_lds = false;
+    if (const char* v = sg_knob("SG_CT")) { const u32 x = (u32)std::strtoul(v, nullptr, 0); if (x >= 64 && x <= 2048 && (x & (x - 1)) == 0 && (size_t)x * slot + fixed + (e->l2_in_lds ? l2b : 0) <= kLdsBytes) ct = x; }
+    if (sg_knob("SG_L2_GLOBAL")) e->l2_in_lds = false;
     if (!ct || l1b > stage_max) return false;
     e->k1a_ct = ct;
     e->k1a_lds = (size_t)ct * slot + fixed + (e->l2_in_lds ? l2b : 0);
@@ -420,7 +432,7 @@ int grid_for(u64 items, int per_block, int cap = 2048) {
 
 // the halo request lists and the active node lists of a sharded window: many workgroups, one launch (SG_K6_ONE_WG=1: the round-3 builder)
 void launch_halo_lists(sg_engine* e, hipStream_t s, u32* req, u32 capp) {
-    static const bool one_wg = std::getenv("SG_K6_ONE_WG") != nullptr;
+    static const bool one_wg = sg_knob("SG_K6_ONE_WG") != nullptr;
     if (one_wg) {
         if (e->d.ncap <= K6_FLAGS_LDS) hipLaunchKernelGGL(k6_halo_build_padded<true>, dim3(1), dim3(1024), 0, s, e->d, req, capp);
         else hipLaunchKernelGGL(k6_halo_build_padded<false>, dim3(1), dim3(1024), 0, s, e->d, req, capp);
@@ -570,7 +582,7 @@ int do_layer(sg_engine* e, u32 l, hipStream_t s, bool fuse_proj) {
     // two launches per layer: the gather-mean at high occupancy (8 rows per workgroup), then the dense tiles
     // (small graphs keep the fused kernel: at C2 the second launch costs more than the gather gains — 16.6 vs 20.9 us)
     bool split = e->cfg.max_edges > (1u << 17);              // (C2's 66 k-edge engine stays fused; a 160 k-edge shard of C4 — with its hub rows — splits)
-    if (const char* v = std::getenv("SG_K4_FUSED")) split = std::atoi(v) == 0;
+    if (const char* v = sg_knob("SG_K4_FUSED")) split = std::atoi(v) == 0;
 #define K4_LAUNCH(FI, MF, PJ, HIN, HOUT) do { if (split) { \
             hipLaunchKernelGGL((k4_gather<FI>), dim3(grid_for(d.ncap, K4G_ROWS, 4096 * 8 / K4G_ROWS)), dim3(K4G_ROWS * 64), 0, s, d, HIN); \
             hipLaunchKernelGGL((k4_sage_layer<FI, MF, PJ, (PJ ? 512 : 256), true>), dim3(grid), dim3(PJ ? 512 : 256), 0, s, d, HIN, HOUT, Wl, Wh); \
@@ -717,7 +729,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SG_ENODEV;   // MI355X only: the kernels are gfx950 code objects
     sg_engine* e = new sg_engine();
     e->cfg = *cfg;
-    if (const char* v = std::getenv("SG_ARENA")) e->arena_on = std::atoi(v) != 0;
+    if (const char* v = sg_knob("SG_ARENA")) e->arena_on = std::atoi(v) != 0;
     if (e->cfg.max_batch == 0) e->cfg.max_batch = 1u << 20;
     if (e->cfg.max_ips == 0) e->cfg.max_ips = e->cfg.max_known_nodes;
     auto fail = [&](int rc) { std::fprintf(stderr, "sg_create: %s\n", e->err.c_str()); sg_destroy(e); return rc; };
@@ -728,7 +740,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     CH(hipEventCreateWithFlags(&e->tab_ev, hipEventDisableTiming));
     e->k1_grid = std::min<int>(SG_MAX_K1_WGS, prop.multiProcessorCount * 8);
     e->k1b_cus = (u32)std::max(1, prop.multiProcessorCount);
-    const char* env = std::getenv("SG_DENSE_VALU");
+    const char* env = sg_knob("SG_DENSE_VALU");
     e->use_mfma = !(env && env[0] == '1');
 
     Dev& d = e->d;
@@ -753,13 +765,13 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // carry the per-edge histogram.
         const u64 cn = (u64)cfg->max_known_nodes + cfg->max_labels + e->obcap;
         u32 nb = 12; while ((1ull << nb) < cn && nb < 31) nb++;
-        bool narrow = d.variant == 0 && !d.hist && cfg->k1_variant != 2 && !std::getenv("SG_K1_LEGACY") && nb <= 24;
+        bool narrow = d.variant == 0 && !d.hist && cfg->k1_variant != 2 && !sg_knob("SG_K1_LEGACY") && nb <= 24;
         // k1_variant 0 (auto) picks by the WINDOW, not only by what fits: the 8-byte path pays from a few million events or a quarter
         // of a million edges per window up; below that (BASELINE config 2: 1 M events, 54 k edges) a window is a dozen launches of
         // 5-30 us and the 16-byte kernels' shorter prologue and simpler pass B win — same box, C2: 130 us per window against 147-155
         // (three rounds of tuning for config 3 had been paid for at config 2).  3 asks for the 8-byte path by name.
         const bool small_window = ME < (1ull << 18) && e->cfg.max_window_events <= (2ull << 20);
-        if (cfg->k1_variant == 0 && small_window && !std::getenv("SG_K1_NARROW")) narrow = false;
+        if (cfg->k1_variant == 0 && small_window && !sg_knob("SG_K1_NARROW")) narrow = false;
         u64 np = 0;
         if (narrow) {
             // partitions: ~2700 distinct edges each at the configured capacity at most (pass B's LDS table: 4096 slots of 36
@@ -776,7 +788,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
             else d.k1b_ht = ME / np > 550 ? 2048 : 1024;
             // (sizing the partitions by the window's RECORDS as well — 512 x 2 workgroups for a shard of C4, 10 M events over 126 k
             // edges — was measured and bought nothing: 79 vs 73 us)
-            if (const char* v = std::getenv("SG_SPLIT")) { const int x = std::atoi(v); if (x == 1 || x == 2) { d.k1b_split = (u32)x; d.k1b_ht = ME / (np * x) > 1150 ? 4096 : (ME / (np * x) > 550 ? 2048 : 1024); } }
+            if (const char* v = sg_knob("SG_SPLIT")) { const int x = std::atoi(v); if (x == 1 || x == 2) { d.k1b_split = (u32)x; d.k1b_ht = ME / (np * x) > 1150 ? 4096 : (ME / (np * x) > 550 ? 2048 : 1024); } }
         } else {
             // 16-byte records: at most ~1250 distinct edges per partition (pass B's LDS table: 2048 slots, 1536 may fill; 1024 slots
             // for small graphs), at least one per CU.  C3 with 1024 partitions 181 us, 2048: 198 us, 4096: 292 us.
@@ -788,9 +800,9 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         }
         d.np = (u32)np; d.nwg = 256;
         // tuning overrides (tools/k1_sweep.py); anything that is not a legal geometry is ignored
-        if (const char* v = std::getenv("SG_NP")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 64 && x <= (narrow ? 2048u : 4096u) && (x & (x - 1)) == 0) d.np = (u32)x; }
-        if (const char* v = std::getenv("SG_HT")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 256 && x <= (narrow ? 4096u : 2048u) && (x & (x - 1)) == 0) d.k1b_ht = (u32)x; }
-        if (const char* v = std::getenv("SG_NWG")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= (u64)SG_MAX_K1_WGS) d.nwg = (u32)x; }
+        if (const char* v = sg_knob("SG_NP")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 64 && x <= (narrow ? 2048u : 4096u) && (x & (x - 1)) == 0) d.np = (u32)x; }
+        if (const char* v = sg_knob("SG_HT")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 256 && x <= (narrow ? 4096u : 2048u) && (x & (x - 1)) == 0) d.k1b_ht = (u32)x; }
+        if (const char* v = sg_knob("SG_NWG")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= (u64)SG_MAX_K1_WGS) d.nwg = (u32)x; }
         d.pb = 0; while ((1u << d.pb) < d.np) d.pb++;
         if (narrow && 2 * nb - d.pb > 31) { d.np = (u32)np; d.pb = 0; while ((1u << d.pb) < d.np) d.pb++; }   // an SG_NP override that would not leave 31 remainder bits
         d.narrow = (narrow && d.variant == 0) ? 1u : 0u;
@@ -800,7 +812,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // By default only where it pays: on a graph below a quarter of a million edges the rebuild's four kernels cost about what the
         // compaction plus their four empty launches do (C2, same box: 147 us per window without, 155 with).  SG_CFG_WARM asks for it anyway.
         d.warm = (d.narrow && !d.hist && !(cfg->flags & SG_CFG_NO_WARM) && ((cfg->flags & SG_CFG_WARM) || ME >= (1ull << 18))) ? 1u : 0u;
-        if (const char* v = std::getenv("SG_WARM")) { d.warm = (std::atoi(v) != 0 && d.narrow && !d.hist) ? 1u : 0u; }
+        if (const char* v = sg_knob("SG_WARM")) { d.warm = (std::atoi(v) != 0 && d.narrow && !d.hist) ? 1u : 0u; }
         d.npb = d.np * d.k1b_split;
         d.nb = nb; d.rb = 2 * nb - d.pb;
         d.pcap = d.narrow ? d.k1b_ht * 13 / 16 : d.k1b_ht * 3 / 4;       // (u32 keys probe cheaply: the narrow tables may fill to 0.81)
@@ -824,12 +836,12 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         e->k1b_threads = 1024u;                                          // measured: 1024 threads beat 2 x 512 (C3 135 vs 153 us, C2 15.5 vs 22.9 us)
         // narrow pass B: 8 x 16 bytes per lane in flight where a CU holds one table anyway; two workgroups per CU need <= 64 VGPRs
         if (d.narrow) e->k1b_u = ((size_t)d.k1b_ht * 36 + 8) * 2 > kLdsBytes && m > 24.0 ? 8 : 4;
-        if (const char* v = std::getenv("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; if (std::atoi(v) == 4) e->k1b_u = 4; }
+        if (const char* v = sg_knob("SG_K1B_U")) { if (std::atoi(v) == 8) e->k1b_u = 8; if (std::atoi(v) == 4) e->k1b_u = 4; }
         if (e->k1b_u == 8) d.warm = 0;
         // the packed add of pass B is exact while a workgroup merges fewer than 2^16 narrow records: a partition's pieces hold sn each
         e->k1b_pack = d.narrow && (u64)d.sn * d.nwg < 65536ull;
-        if (const char* v = std::getenv("SG_K1B_PACK")) { if (std::atoi(v) == 0) e->k1b_pack = false; }
-        if (const char* v = std::getenv("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if ((x == 256 && !d.narrow) || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
+        if (const char* v = sg_knob("SG_K1B_PACK")) { if (std::atoi(v) == 0) e->k1b_pack = false; }
+        if (const char* v = sg_knob("SG_K1B_THREADS")) { const u64 x = std::strtoull(v, nullptr, 0); if ((x == 256 && !d.narrow) || x == 512 || x == 1024) e->k1b_threads = (u32)x; }
         if (d.narrow && d.k1b_ht / e->k1b_threads > 4) e->k1b_threads = 1024u;    // (the compaction takes at most four table slots per thread)
     }
     // join tables: word image (join_host.hpp) on the host, one device copy, a pinned ring for word updates
@@ -905,7 +917,7 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     d.alive_cap = cfg->max_alive ? cfg->max_alive : 65536u;
     e->k3_ranges = (d.ncap + K3_IN_NR - 1) / K3_IN_NR;
     e->k3_slices = (u32)std::min<u64>(K3_IN_SMAX, std::max<u64>(8, ME / 8192));
-    if (const char* v = std::getenv("SG_K3_SLICES")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= 256) e->k3_slices = (u32)x; }
+    if (const char* v = sg_knob("SG_K3_SLICES")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= 256) e->k3_slices = (u32)x; }
     e->k3in_lds = (size_t)K3_IN_NR * 48;
     {   // the row sort's two LDS arrays: large enough for a bitmap of the node capacity when that fits (a config-5 shard: 150 k nodes = 4.7 k words)
         const u64 bw = ((u64)d.ncap + 31) / 32;
@@ -922,14 +934,14 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         // an engine that keeps warm-window state rebuilds rarely, and every launch of the rebuild chain is ~4.5 us of an EMPTY launch on a
         // warm window: there the degree atomics (23-30 us more on a cold window at C3, no launch) are the better trade
         if (d.warm) g = 0;
-        if (const char* v = std::getenv("SG_DH_G")) { const u64 x = std::strtoull(v, nullptr, 0); g = (x >= 16 && x <= K2_DH_GMAX && (x & (x - 1)) == 0 && d.variant == 0 && x <= d.npb) ? (u32)x : 0u; }
+        if (const char* v = sg_knob("SG_DH_G")) { const u64 x = std::strtoull(v, nullptr, 0); g = (x >= 16 && x <= K2_DH_GMAX && (x & (x - 1)) == 0 && d.variant == 0 && x <= d.npb) ? (u32)x : 0u; }
         if (g >= 16 && (g & (g - 1)) == 0 && d.npb % g == 0 && ((size_t)d.ncap + 1) * sizeof(u32) <= 128u * 1024u && (u64)d.npb * d.pcap < (1ull << 32)) {
             d.dh_g = g; d.dh_ppw = d.npb / g; d.dh_ns = (d.ncap + 1 + 63u) & ~63u;
             CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k2_deg_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)d.ncap + 1) * sizeof(u32))));
         }
     }
     CH(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_in_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k3in_lds));
-    { const char* ab = std::getenv("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
+    { const char* ab = sg_knob("SG_ABLATE"); d.ablate = ab ? (u32)std::strtoul(ab, nullptr, 0) : 0u; }
     CR(dev_alloc(e, &d.dbg, (size_t)4 * 4096 * 8));
     CR(dev_alloc(e, &d.clk, (size_t)4));
     // everything a window owns; allocated once per slot
@@ -1020,10 +1032,10 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         d.l1p_tab = tab;
     }
     CH(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking)); CH(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
-    if (const char* v = std::getenv("SG_COPY_STREAMS")) e->n_copy = std::atoi(v) == 2 ? 2 : 1;
+    if (const char* v = sg_knob("SG_COPY_STREAMS")) e->n_copy = std::atoi(v) == 2 ? 2 : 1;
     CH(hipStreamCreateWithFlags(&e->rd_stream, hipStreamNonBlocking)); CH(hipEventCreateWithFlags(&e->score_ev, hipEventDisableTiming));
     CH(hipHostMalloc((void**)&e->h_ctr_pin, sizeof(e->h_ctr)));
-    if (const char* v = std::getenv("SG_STAGE_SLOTS")) e->n_stage = std::min(kStageSlots, std::max(2, std::atoi(v)));
+    if (const char* v = sg_knob("SG_STAGE_SLOTS")) e->n_stage = std::min(kStageSlots, std::max(2, std::atoi(v)));
     for (int i = 0; i < e->n_stage; i++) {
         CH(hipEventCreateWithFlags(&e->copied_ev[i], hipEventDisableTiming));
         CH(hipHostMalloc((void**)&e->h_stage[i], (size_t)e->cfg.max_batch * sizeof(sg_event)));

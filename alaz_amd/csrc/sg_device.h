@@ -96,7 +96,15 @@ enum { ST_OUT_DEG = 0, ST_IN_DEG, ST_OUT_CNT, ST_IN_CNT, ST_OUT_ERR, ST_IN_ERR, 
 
 // phase stamps for kernel tuning (off unless SG_ABLATE & 0x100): 100 MHz wall clock, thread 0 of a workgroup
 #define SG_L1P_TAB 4096u
-#define SG_STAMP(d, kid, k) do { if (((d).ablate & 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096) (d).dbg[((size_t)(kid) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+// Tuning / ablation hooks (SG_ABLATE bits, phase stamps) exist in the DEVELOPMENT build only (-DSG_DEV_KNOBS: alaz_amd/build.py writes it to
+// lib/libservicegraph_dev.so, which the tools and the A/B tests of alternative kernel paths load); in the shipped library they are
+// compiled out of the kernels and the host reads no SG_* environment variable.
+#ifdef SG_DEV_KNOBS
+#define SG_ABL(d, bits) (((d).ablate & (bits)) != 0)
+#else
+#define SG_ABL(d, bits) (false)
+#endif
+#define SG_STAMP(d, kid, k) do { if (SG_ABL(d, 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096) (d).dbg[((size_t)(kid) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
 
 // Everything the kernels need, passed by value as one kernel argument.
 struct Dev {

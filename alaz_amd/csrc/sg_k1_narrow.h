@@ -301,7 +301,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
                 const u32 hi = (u32)(rec >> 32), b = (hi >> rb) & ((1u << d.pb) - 1u);
                 const u32 pos = fcn[b] + (i - boff[b]);
                 const u64 out = (rec & 0xFFFFFFFFull) | ((u64)(hi & strip) << 32);
-                if (pos < d.sn) { if (!(d.ablate & 0x1u)) piece8(d, b, w)[pos] = out; }
+                if (pos < d.sn) { if (!SG_ABL(d, 0x1u)) piece8(d, b, w)[pos] = out; }
                 else { K1T_LNEW(L); ovf8_single(d, b, ((u64)b << rb) | (hi & rbmask), rec & 0xFFFFFFFFull, hi >> 31, 0u, L); lflush(L); }
             }
         }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
             for (u32 j = j0; j < cnt; j += 16) {
                 const u64 rec = tile[off + j];
                 const u32 pos = pos0 + j;
-                if (pos < d.sn) { if (!(d.ablate & 0x1u)) dst[pos] = rec; }
+                if (pos < d.sn) { if (!SG_ABL(d, 0x1u)) dst[pos] = rec; }
                 else { K1T_LNEW(L); ovf8_single(d, b, ((u64)b << rb) | ((u32)(rec >> 32) & rbmask), rec & 0xFFFFFFFFull, (u32)(rec >> 63), 0u, L); lflush(L); }
             }
         }
@@ -327,13 +327,13 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
         u32* bc = bcnt + cur * NP;
         u32* fcn = fcn2 + cur * NP;                                  // counts before this tile; the scan writes fcn2[cur ^ 1] = counts behind it
         u32 lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7;
-        const u64 tk0 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
+        const u64 tk0 = SG_ABL(d, 0x100u) ? wall_clock64() : 0ull;
         {   // P1: NSUB chunks of up to four events per thread
             v4u_t ea0, eb0, ea1, eb1, ea2, eb2, ea3, eb3;
             const u64 cb0 = c0 * chunk, ce0 = cb0 + chunk < end ? cb0 + chunk : end;
             const u64 i0 = cb0 + t;
             K1T_ISSUE(i0, ce0, cb0);
-            if (havep) { const u64 tq = (d.ablate & 0x100u) ? wall_clock64() : 0ull; copy_out(pcur); if (d.ablate & 0x100u) tk_p4 += wall_clock64() - tq; }
+            if (havep) { const u64 tq = SG_ABL(d, 0x100u) ? wall_clock64() : 0ull; copy_out(pcur); if SG_ABL(d, 0x100u) tk_p4 += wall_clock64() - tq; }
             K1T_FOLD(0, i0, ce0, bc, lo0, hi0, pr0, lo1, hi1, pr1, lo2, hi2, pr2, lo3, hi3, pr3);
             if constexpr (NSUB == 2) {
                 const u64 c1 = c0 + d.nwg;
@@ -343,9 +343,9 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
                 K1T_FOLD(0, i1, ce1, bc, lo4, hi4, pr4, lo5, hi5, pr5, lo6, hi6, pr6, lo7, hi7, pr7);
             } else { pr4 = pr5 = pr6 = pr7 = K1T_NONE; lo4 = hi4 = lo5 = hi5 = lo6 = hi6 = lo7 = hi7 = 0; }
         }
-        const u64 tk1 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
+        const u64 tk1 = SG_ABL(d, 0x100u) ? wall_clock64() : 0ull;
         LDS_BARRIER();
-        const u64 tk2 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
+        const u64 tk2 = SG_ABL(d, 0x100u) ? wall_clock64() : 0ull;
         tk_p1 += tk1 - tk0; tk_wait += tk2 - tk1;
         {   // P2: exclusive scan of the run lengths by EVERY wave (sixteen identical scans cost less than a barrier behind one: the
             // offsets a wave needs in P3 are its own writes, every wave writes the same values).  Lane l owns the np / 64 consecutive
@@ -392,23 +392,23 @@ __global__ __launch_bounds__(K1T_THREADS) void k1a_tile_partition(Dev d, const s
                 }
             }
         }
-        const u64 tk3 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
+        const u64 tk3 = SG_ABL(d, 0x100u) ? wall_clock64() : 0ull;
         // P3: every thread drops its records at offset + rank (PACKB: with the partition number in the free bits of the high word)
 #define K1T_DROP(lo, hi, pr) if ((pr) != K1T_NONE) { const u32 pt_ = (pr) & ((1u << K1T_RANK_SHIFT) - 1u);                                  \
             tile[boff[pt_] + ((pr) >> K1T_RANK_SHIFT)] = (u64)(lo) | ((u64)((hi) | (packb ? pt_ << rb : 0u)) << 32); }
         K1T_DROP(lo0, hi0, pr0); K1T_DROP(lo1, hi1, pr1); K1T_DROP(lo2, hi2, pr2); K1T_DROP(lo3, hi3, pr3);
         if constexpr (NSUB == 2) { K1T_DROP(lo4, hi4, pr4); K1T_DROP(lo5, hi5, pr5); K1T_DROP(lo6, hi6, pr6); K1T_DROP(lo7, hi7, pr7); }
 #undef K1T_DROP
-        const u64 tk4 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
+        const u64 tk4 = SG_ABL(d, 0x100u) ? wall_clock64() : 0ull;
         LDS_BARRIER();
-        const u64 tk5 = (d.ablate & 0x100u) ? wall_clock64() : 0ull;
+        const u64 tk5 = SG_ABL(d, 0x100u) ? wall_clock64() : 0ull;
         havep = true; pcur = cur;
-        if (d.ablate & 0x100u) { tk_scan += tk3 - tk2; tk_p3 += tk4 - tk3; tk_b3 += tk5 - tk4; }
+        if SG_ABL(d, 0x100u) { tk_scan += tk3 - tk2; tk_p3 += tk4 - tk3; tk_b3 += tk5 - tk4; }
     }
     if (havep) copy_out(pcur);                                       // the last tile's runs
     u32* fcn = fcn2 + cur * NP;                                      // the counts behind the last tile (written by its scan)
     SG_STAMP(d, 0, 3);
-    if ((d.ablate & 0x100u) && t == 0 && blockIdx.x < 4096) { u64* g = d.dbg + ((size_t)2 * 4096 + blockIdx.x) * 8; g[0] = tk_p1; g[1] = tk_wait; g[2] = tk_scan; g[3] = tk_p3; g[4] = tk_b3; g[5] = tk_p4; }
+    if (SG_ABL(d, 0x100u) && t == 0 && blockIdx.x < 4096) { u64* g = d.dbg + ((size_t)2 * 4096 + blockIdx.x) * 8; g[0] = tk_p1; g[1] = tk_wait; g[2] = tk_scan; g[3] = tk_p3; g[4] = tk_b3; g[5] = tk_p4; }
 #undef K1T_ISSUE
 #undef K1T_FOLD
     LDS_BARRIER();
@@ -501,12 +501,13 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     const u32 oq = p * S + sidx;                                     // output partition
     const u32 nb = d.nb, nbmask = (1u << nb) - 1u, rbmask = (1u << d.rb) - 1u, sbit = d.rb - 1;
     SG_STAMP(d, 1, 0);
-    if ((d.ablate & 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096)   // where the workgroup runs: HW_ID (CU 8..11, SH 12, SE 13..15) | XCC_ID << 32
+    if (SG_ABL(d, 0x100u) && threadIdx.x == 0 && blockIdx.x < 4096)   // where the workgroup runs: HW_ID (CU 8..11, SH 12, SE 13..15) | XCC_ID << 32
         d.dbg[((size_t)1 * 4096 + blockIdx.x) * 8 + 7] = (u64)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((u64)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
     const bool empty = d.batch_state == 2u;                          // no batch this window: the pieces are the previous window's
     const u32 LPP = NT > d.nwg ? NT / d.nwg : 1u;                    // lanes per piece
     const u32 sub = t % LPP, w0 = t / LPP;
     uint2 h0 = make_uint2(0u, 0u);
+    u32 have_keys = 0;                                               // WM 1: keys of the image this thread seeded
     if (!empty && w0 < d.nwg) h0 = d.hdr8[(size_t)p * d.nwg + w0];
     // the first U record pairs of the lane's first piece go out together with the header (index clamped to the narrow region;
     // what lies beyond the count is ignored): one round trip instead of two, hidden behind the table set-up
@@ -524,11 +525,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         if (t == 0) *nkeys = 0;
         for (u32 i = t; i <= HT / 32; i += NT) htouch[i] = 0;
         for (u32 i = t; i < HT / 32; i += NT) hnew[i] = 0;
-        __syncthreads();
-        u32 have = 0;
-        for (u32 i = t; i < HT; i += NT) { const u32 k = img[i]; hkey[i] = k; have += k != 0xFFFFFFFFu ? 1u : 0u; }
-        have = wave_sum_u32(have);
-        if ((t & 63u) == 0 && have) atomicAdd(nkeys, have);
+        for (u32 i = t; i < HT; i += NT) { const u32 k = img[i]; hkey[i] = k; have_keys += k != 0xFFFFFFFFu ? 1u : 0u; }
     } else {
         for (u32 i = t; i < HT; i += NT) hkey[i] = 0xFFFFFFFFu;
         if constexpr (WM == 2) { for (u32 i = t; i <= HT / 32; i += NT) htouch[i] = 0; }   // bits: slots filled from the old image; word HT / 32: keys in the table
@@ -536,6 +533,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     for (u32 i = t; i < HT * 4; i += NT) hacc[i] = 0;
     if (t == 0) { *n_drop = 0; *out_n = 0; }
     __syncthreads();
+    if constexpr (WM == 1) { have_keys = wave_sum_u32(have_keys); if ((t & 63u) == 0 && have_keys) atomicAdd(nkeys, have_keys); }   // (read at the end, behind barriers)
     SG_STAMP(d, 1, 1);
 
     // slot of a key (find or insert), or HT when the table is full
@@ -560,7 +558,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     u32* hacc32 = reinterpret_cast<u32*>(hacc);                       // low word of accumulator j of slot h: 2 * (j*HT + h)
     auto add_narrow = [&](u32 lo, u32 hi) {
         const u32 rem = hi & rbmask;
-        if (!mine(rem) || (d.ablate & 0x10u)) return;
+        if (!mine(rem) || SG_ABL(d, 0x10u)) return;
         const u32 h = slot_of(rem);
         if (h == HT) { atomicAdd(n_drop, 1u); return; }
         const u32 us = div1000_u32(lo);
@@ -717,12 +715,10 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             o[1] = make_ulonglong2(touched ? (a2 | (1ull << 63)) : 0ull, touched ? a3 : 0ull);
         }
         if (cold || (t == 0 && *n_drop)) d.ctr[C_COLD] = 2;           // (same value from whoever writes it; 2 = found HERE, after a whole merge: the host backs off when that keeps happening)
-        __syncthreads();                                             // the new edges are counted
-        if (t == 0) {
-            const u32 dn = *out_n;
-            d.part_n[oq] = dn;                                       // new edges of this partition (the delta chain reads it; a full rebuild rewrites it)
-            if (dn) atomicAdd(&d.ctr[C_DELTA_N], (u64)dn);
-        }
+        if (anynew) {                                                // (uniform)
+            __syncthreads();                                         // the new edges are counted
+            if (t == 0) { const u32 dn = *out_n; d.part_n[oq] = dn; if (dn) atomicAdd(&d.ctr[C_DELTA_N], (u64)dn); }   // new edges of this partition (the delta chain reads it)
+        } else if (t == 0) d.part_n[oq] = 0;
         SG_STAMP(d, 1, 5);
         return;
     }
@@ -745,7 +741,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             oi[k2] = atomicAdd(out_n, 1u);
             if (oi[k2] >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[sl] & 0xFFFFFFFFull)); continue; }
             live[k2] = true;
-            if (!d.dh_g && !(d.ablate & 0x20u)) rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], oq & (SG_DEG_REP - 1))], 1u);   // arrival order inside the row's replica (dh_g: k2_deg_hist ranks the edges instead, no device atomic)
+            if (!d.dh_g && !SG_ABL(d, 0x20u)) rk[k2] = atomicAdd(&d.deg[SG_DEG_IDX(f[k2], oq & (SG_DEG_REP - 1))], 1u);   // arrival order inside the row's replica (dh_g: k2_deg_hist ranks the edges instead, no device atomic)
         }
         // (everything that does not need the returned rank first: the device atomics' round trip passes under these stores)
 #pragma unroll

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
                 const u32 i = tq + k * K1M_TT, h = (u32)(rec[k] >> 32), b = (h >> rb) & pbm;
                 const u32 pos = pb_[k] + (i - bo_[k]);
                 const bool valid = i < total;
-                if (d.ablate & 0x2u) { if (valid & (pos < sn)) slab_w[(u64)b * nwpun + pos] = (rec[k] & 0xFFFFFFFFull) | ((u64)(h & strip) << 32); }
+                if SG_ABL(d, 0x2u) { if (valid & (pos < sn)) slab_w[(u64)b * nwpun + pos] = (rec[k] & 0xFFFFFFFFull) | ((u64)(h & strip) << 32); }
                 else { v2u_t dv; dv.x = (u32)rec[k]; dv.y = h & strip;           // (a lane without a record, or beyond the piece: out-of-range offset, dropped by the hardware)
                   __builtin_amdgcn_raw_buffer_store_b64(dv, slab_rsrc, (valid & (pos < sn)) ? (b * nwpun + pos) * 8u : K1M_OOB, 0, 0); }
                 ovm |= (valid & (pos >= sn)) ? (1u << k) : 0u;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     bool havep = false; u32 pcur = 0, cur = 0;
     u64 tk_p1 = 0, tk_wait = 0, tk_scan = 0, tk_p3 = 0, tk_b3 = 0, tk_p4 = 0, tk_ld = 0, tk_fa = 0;   // SG_K1_PHASE_STAMPS: wave 0's clock ticks per phase (tk_ld: inside P1, waiting for the event loads; tk_fa: joining the first group)
 #ifdef SG_K1_PHASE_STAMPS
-    const bool stamp = (d.ablate & 0x100u) != 0;
+    const bool stamp = SG_ABL(d, 0x100u) != 0;
 #else
     constexpr bool stamp = false;                                    // (phase clocks of wave 0: build with -DSG_K1_PHASE_STAMPS; they cost a dozen registers)
 #endif
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NT) void k1a_team_partition(Dev d, const sg_event* 
     // round + one failing ticket per active team).  On static shares the teams of a launch ended 110 .. 140 us apart.  The ticket is drawn
     // by one lane at the top of the tile before (a returning device atomic issued by hand: its round trip passes under the joins) and
     // handed to the team through LDS across the tile's barriers.  (SG_ABLATE & 0x4: static shares.)
-    const bool dyn = !(d.ablate & 0x4u);
+    const bool dyn = !SG_ABL(d, 0x4u);
     // (the ticket is handed on through TWO words, alternating with the tile: a wave that is late behind a tile's second barrier — rare events,
     // statistics — reads its word while the drawer, already in the next tile, writes the other one; with one word nothing ordered that read
     // before that write, and a wave that read the NEXT tile's ticket left its team for good: a hang, seen in round 6 when the write moved

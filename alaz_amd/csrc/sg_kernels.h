@@ -348,7 +348,7 @@ __device__ __forceinline__ uint4* piece_of(const Dev& d, u32 p, u32 w) { return 
 // zero = 1: a record that only creates the edge (SG_EV_ALIVE): count 0, all accumulators 0
 __device__ __forceinline__ void emit_single(const Dev& d, u32* fc, u32 w, u32 p, u64 key, u64 dur, u32 err, K1Local& L, u32 zero = 0) {
     const u32 pos = K1_NS(atomicAdd(&fc[p], 1u));
-    if (pos < d.ss) { if (!(d.ablate & 0x1u)) piece_of(d, (d.ablate & 0x40u) ? (p & 63u) : p, w)[pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31) | (zero << 30)); }
+    if (pos < d.ss) { if (!SG_ABL(d, 0x1u)) piece_of(d, SG_ABL(d, 0x40u) ? (p & 63u) : p, w)[pos] = make_uint4((u32)key, (u32)(key >> 32), (u32)dur, (u32)(dur >> 32) | (err << 31) | (zero << 30)); }
     else {
         atomicSub(&fc[p], 1u);                                       // the count stays exact (and below 2^20)
         if (zero) ovf_append(d, p, key, 0ull, 0ull, 0ull, 0ull, L);
@@ -497,9 +497,9 @@ __global__ __launch_bounds__(K1A_THREADS) void k1a_partition(Dev d, const sg_eve
             const ulonglong2 kk = reinterpret_cast<const ulonglong2*>(ckey)[bucket];                                \
             int slot = kk.x == key ? (int)(2u * bucket) : (kk.y == key ? (int)(2u * bucket + 1u) : -1);             \
             if (acc && slot < 0 && (kk.x == SG_EKEY_EMPTY || kk.y == SG_EKEY_EMPTY)) slot = cache_claim(ckey, bucket, key, kk.x, kk.y); \
-            if (d.ablate & 0x2u) slot = -1;                                                                         \
-            if (acc && !(d.ablate & 0x8u)) {                                                                        \
-                if (slot >= 0 && !(d.ablate & 0x4u)) {                                                              \
+            if SG_ABL(d, 0x2u) slot = -1;                                                                         \
+            if (acc && !SG_ABL(d, 0x8u)) {                                                                        \
+                if (slot >= 0 && !SG_ABL(d, 0x4u)) {                                                              \
                     const u32 us = div1000_u32(dur);                                                                \
                     const u64 ssq = (u64)us * (u64)us;                        /* us < 2^23: 24-bit multiplies */             \
                     atomicAdd(&cacc[slot * 4], 1ull | ((u64)err << 32)); atomicAdd(&cacc[slot * 4 + 1], (u64)dur);  \
@@ -710,7 +710,7 @@ __device__ __forceinline__ void k1b_body(const Dev& d) {
                 if (dhi == 0) { const u32 us = div1000_u32(x[u].z); ssq = (u64)us * (u64)us; }
                 else { const u64 us = dur / 1000ull; ssq = us * us; }
                 const u64 one = ((x[u].w >> 30) & 1u) ? 0ull : 1ull;             // bit 62: edge-only record (SG_EV_ALIVE)
-                if (!(d.ablate & 0x10u)) add(key, one | ((u64)(x[u].w >> 31) << 32), dur, dur, ssq, nullptr);
+                if (!SG_ABL(d, 0x10u)) add(key, one | ((u64)(x[u].w >> 31) << 32), dur, dur, ssq, nullptr);
             }
         }
         for (u32 r = sub; r < na; r += LPP) {
@@ -1535,7 +1535,7 @@ __device__ __forceinline__ void k2_row_wg(const Dev& d, const EdgeEmitArgs& ea, 
 // how many hub work items the row sort may use: all of them, when the whole list was recorded and a node bitmap fits the LDS arrays
 __device__ __forceinline__ u32 k2_split_items(const Dev& d) {
     const u32 BW = ((u32)d.ctr[C_N_NODES] + 31) >> 5;
-    return (d.ctr[C_HUB_ITEMS] <= d.hub_cap && BW <= d.k2_sortw && !(d.ablate & 0x800u)) ? (u32)d.ctr[C_HUB_ITEMS] : 0u;
+    return (d.ctr[C_HUB_ITEMS] <= d.hub_cap && BW <= d.k2_sortw && !SG_ABL(d, 0x800u)) ? (u32)d.ctr[C_HUB_ITEMS] : 0u;
 }
 __device__ __forceinline__ void k2_split_finish(const Dev& d, u32 tid, u32 nt) {
     const u32 H = k2_split_items(d);
@@ -1731,7 +1731,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev dd) {
     // afterwards (rows of 65..1024 edges used to cost a workgroup three barriers and a 256-thread scan of the bitmap EACH) ----
     const u32 nlw = gridDim.x > 2 * K2_LONG_WGS ? K2_LONG_WGS : (gridDim.x / 2 ? gridDim.x / 2 : 1);   // host launches >= 2 workgroups
     if (blockIdx.x < nlw) {
-        const bool wave_ok = BW <= K2_WAVE_BW && !(d.ablate & 0x400u);
+        const bool wave_ok = BW <= K2_WAVE_BW && !SG_ABL(d, 0x400u);
         // rows of more than K2_SPLIT_ROW edges first, a workgroup per 512-edge block (when the whole list was recorded and the bitmap fits)
         const u32 H = k2_split_items(d);
         for (u32 it = blockIdx.x; it < H; it += nlw) {
@@ -1745,7 +1745,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev dd) {
                 const u32 rr = d.longrows[li];
                 const u32 m = d.rowptr[rr + 1] - d.rowptr[rr];
                 if (wave_ok && m <= K2_WAVE_ROW) k2_row_wave(d, ea, rr, sk + wave * K2_WAVE_BW, sv + wave * K2_WAVE_BW, BW);
-                else if (BW > K2_WAVE_BW && m <= K2_WAVE_ROW && !(d.ablate & 0x400u)) k2_row_wave_rank(d, ea, rr);
+                else if (BW > K2_WAVE_BW && m <= K2_WAVE_ROW && !SG_ABL(d, 0x400u)) k2_row_wave_rank(d, ea, rr);
                 else if (!(H && m > K2_SPLIT_ROW)) big = rr;
             }
             if (lane == 0) bigrow[wave] = big;
@@ -2936,7 +2936,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
         auto ids_of = [&](u32 xa, u32 xb) -> u32 { const u32 px = (q & 2u) ? xb : xa; return idsrc[px < E ? px : last]; };
         auto issue = [&](u32 idw_, u32 xa, u32 xb, u32 x0, K5Set& S) {
             u32 ua = dpp32b<0x150>(idw_), va = dpp32b<0x151>(idw_), ub = dpp32b<0x152>(idw_), vb = dpp32b<0x153>(idw_);
-            if (d.ablate & 0x1000u) { ua &= 15u; va &= 15u; ub &= 15u; vb &= 15u; }   // (diagnostic: gathers that hit the L1)
+            if SG_ABL(d, 0x1000u) { ua &= 15u; va &= 15u; ub &= 15u; vb &= 15u; }   // (diagnostic: gathers that hit the L1)
             const u32 ca = xa < E ? xa : last, cb = xb < E ? xb : last;
             S.PA = reinterpret_cast<const float4*>(d.P + (size_t)ua * SG_F_HID)[q]; S.QA = reinterpret_cast<const float4*>(d.Q + (size_t)va * SG_F_HID)[q];
             S.PB = reinterpret_cast<const float4*>(d.P + (size_t)ub * SG_F_HID)[q]; S.QB = reinterpret_cast<const float4*>(d.Q + (size_t)vb * SG_F_HID)[q];
@@ -2996,7 +2996,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
             // and the next half-iteration's wait for its endpoint ids then also waited for the first gather of the set in flight.
             {
                 const u32 p0u = (u32)__builtin_amdgcn_readfirstlane((int)p0);
-                const u32 nrow = (d.ablate & 0x2000u) ? 0u : (E - p0u < 8u ? E - p0u : 8u);
+                const u32 nrow = SG_ABL(d, 0x2000u) ? 0u : (E - p0u < 8u ? E - p0u : 8u);
                 const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u64*>(d.rows) + (size_t)p0u * 8, 0, (int)(nrow * 64u), 0x00020000);
                 v2u_t dv; dv.x = (u32)val; dv.y = (u32)(val >> 32);
                 __builtin_amdgcn_raw_buffer_store_b64(dv, rr_, lane * 8u, 0, 0);
@@ -3221,7 +3221,7 @@ __device__ __forceinline__ void build_lists_staged(const Dev& d, u32* req, u32 c
 __device__ __forceinline__ void build_lists(const Dev& d, u32* req, u32 capp, bool want_req, unsigned char* fl, u32* wsum) {
     const u32 N = (u32)d.ctr[C_N_NODES], nk = (u32)d.ctr[C_N_KNOWN], nl = (u32)d.ctr[C_N_LABELS];
     const u32 W = d.world < 8 ? d.world : 8;
-    if (N <= K6_FLAGS_LDS && !(d.ablate & 0x20000u)) { if (want_req) build_lists_staged<true>(d, req, capp, fl, wsum); else build_lists_staged<false>(d, req, capp, fl, wsum); return; }   // (uniform)
+    if (N <= K6_FLAGS_LDS && !SG_ABL(d, 0x20000u)) { if (want_req) build_lists_staged<true>(d, req, capp, fl, wsum); else build_lists_staged<false>(d, req, capp, fl, wsum); return; }   // (uniform)
     const bool staged = N <= K6_FLAGS_LDS;
     if (staged) {
         for (u32 v0 = threadIdx.x; v0 < N; v0 += 4096) {             // four nodes per thread in flight

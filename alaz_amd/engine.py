@@ -16,6 +16,13 @@ from .replay import EDGE_OUT_DTYPE, EVENT_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SG_LIB_PATH") or os.path.join(_HERE, "lib", "libservicegraph.so")   # SG_LIB_PATH: A/B runs of two builds on one box
+# the development build (-DSG_DEV_KNOBS, alaz_amd/build.py): the only one that reads SG_* tuning knobs from the environment and has the
+# SG_ABLATE bits / phase stamps compiled in.  ServiceGraph(dev_knobs=True) — tools/, the A/B tests of alternative kernel paths — loads it.
+LIB_DEV_PATH = os.path.join(_HERE, "lib", "libservicegraph_dev.so")
+#: the knobs the development build reads (servicegraph.hip sg_knob); ServiceGraph(dev_knobs=None) picks that build when one of them is set
+DEV_KNOBS = ("SG_ABLATE", "SG_NP", "SG_HT", "SG_CT", "SG_NWG", "SG_NSUB", "SG_SPLIT", "SG_WARM", "SG_K1A", "SG_K1_NARROW", "SG_K1_LEGACY", "SG_K1B_U",
+             "SG_K1B_THREADS", "SG_K1B_PACK", "SG_L2_GLOBAL", "SG_L2_U32", "SG_DH_G", "SG_K3_SLICES", "SG_K4_FUSED", "SG_K6_ONE_WG", "SG_DENSE_VALU",
+             "SG_COPY_STREAMS", "SG_STAGE_SLOTS", "SG_ARENA")
 
 SG_OK, SG_EINVAL, SG_ENOMEM, SG_ENODEV, SG_ENOSPC, SG_EAGAIN, SG_ESTATE = 0, -22, -12, -19, -28, -11, -71
 F_IN, F_HID, F_EDGE = 32, 64, 8
@@ -83,16 +90,22 @@ class ServiceGraphError(RuntimeError):
 
 
 _lib = None
+_lib_dev = None
 
 
-def load_library(path: str = LIB_PATH) -> C.CDLL:
+def load_library(path: str = LIB_PATH, dev: bool = False) -> C.CDLL:
     """dlopen the engine.  torch is imported first so that the HIP runtime torch ships is the one
     both share (same soname, one copy per process): device pointers of torch tensors are then
     valid arguments of sg_ingest_device / the halo calls."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("SG_LIB", path)          # tuning builds (tools/): another build of the same sources, e.g. with phase stamps compiled in
+    global _lib, _lib_dev
+    if dev:
+        if _lib_dev is not None:
+            return _lib_dev
+        path = LIB_DEV_PATH
+    else:
+        if _lib is not None:
+            return _lib
+        path = os.environ.get("SG_LIB", path)          # another build of the same sources
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `python -m alaz_amd.build` "
                            "(hipcc, gfx950). The ServiceGraph engine has no CPU fallback.")
@@ -100,7 +113,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         import torch  # noqa: F401  (loads libamdhip64 with RTLD_GLOBAL semantics first)
     except Exception:
         pass
-    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)          # (local: the shipped and the development build export the same names and may both be loaded)
     H, P = C.c_void_p, C.c_void_p
     u32, u64, sz = C.c_uint32, C.c_uint64, C.c_size_t
     sig = {
@@ -153,7 +166,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     for name, (res, args) in sig.items():
         f = getattr(lib, name)          # AttributeError if the library does not export it
         f.restype = res; f.argtypes = args
-    _lib = lib
+    if dev:
+        _lib_dev = lib
+    else:
+        _lib = lib
     return lib
 
 
@@ -197,8 +213,12 @@ class ServiceGraph:
     def __init__(self, *, max_known_nodes: int, max_edges: int, layers: int = 1, max_labels: int = 1024,
                  max_outbound_ips: int = 1024, max_ips: int = 0, max_batch: int = 1 << 20, device: int = 0,
                  rank: int = 0, world: int = 1, k1_variant: int = 0, max_window_events: int = 0, windows_in_flight: int = 1,
-                 edge_histogram: bool = False, warm: Optional[bool] = None):
-        self._l = load_library()
+                 edge_histogram: bool = False, warm: Optional[bool] = None, dev_knobs: Optional[bool] = None):
+        # dev_knobs: the development build (SG_* environment knobs, SG_ABLATE, phase stamps).  None = that build when a knob is set in the
+        # environment (tools/k1_sweep.py, tools/stamps.py, the A/B tests of alternative kernel paths), the shipped library otherwise.
+        if dev_knobs is None:
+            dev_knobs = any(k in os.environ for k in DEV_KNOBS)
+        self._l = load_library(dev=dev_knobs)
         cfg = make_config(max_known_nodes=max_known_nodes, max_edges=max_edges, layers=layers, max_labels=max_labels,
                           max_outbound_ips=max_outbound_ips, max_ips=max_ips, max_batch=max_batch, device=device, rank=rank, world=world,
                           k1_variant=k1_variant, max_window_events=max_window_events, windows_in_flight=windows_in_flight,

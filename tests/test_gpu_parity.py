@@ -1452,3 +1452,37 @@ def test_rccl_entry_point_two_ranks_rows_against_the_oracle(tmp_path):
     for p in ps: p.join(timeout=600)
     assert all(p.exitcode == 0 for p in ps)
     _rccl_check(str(tmp_path), 2, 2)
+
+
+def test_config5_one_shard_of_eight_the_bench_engine_row_for_row():
+    """BASELINE config 5 as it is specified — hash-sharded over 8 GPUs — seen from ONE shard, with the engine exactly as
+    `bench.py --config 5 --shard-of 8` builds it (sg_create's own K1 rule for a 150 k-node, ~440 k-edge shard: the 8-byte records with
+    18-bit endpoints, 1024 partitions, level 2 of the join read from global memory, and — round 6 — pass A as k1a_team_partition with the
+    16-lanes-per-run copy-out): one 625 k-event window of the mixed HTTP / Kafka / Postgres stream against the oracle row for row (until
+    round 5 a tool, tools/c5_shard_check.py)."""
+    from alaz_amd import engine, sharded
+    from oracle import pyoracle
+    c = replay.CONFIGS[5]; seed = replay.SEED_BASE + 5
+    full = replay.make_topology(c["pods"], c["edges"], seed)
+    topo = sharded.shard_view(full, 0, 8)
+    Ev = c["events"] // 8
+    ev, labels = replay.make_events(topo, Ev, seed, mixed=True)
+    L = c["layers"]
+    g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=int(min(len(topo.edge_src), Ev) * 1.25) + 4096, layers=L,
+                            max_labels=max(64, len(labels)), max_outbound_ips=64, max_batch=1 << 20, max_window_events=Ev, warm=False)
+    geo = g.geometry()
+    assert geo["k1_narrow"] == 1 and geo["endpoint_bits"] >= 18 and geo["pass_a_teams"] == 2, geo
+    g.set_clock(*CLOCK); W = weights.make_weights(L); g.load_weights(W)
+    shim = HostShim(); shim.apply(g, topo.k8s_ops())
+    g.set_label_count(len(labels))
+    for _ in range(2):                                               # (a second window over the first one's pieces: the headers carry over)
+        for i in range(0, len(ev), 1 << 18):
+            while g.ingest(ev[i:i + (1 << 18)]) != 0:
+                pass
+        rows = g.flush_window().copy()
+    o = pyoracle.Oracle(*CLOCK); o.apply_ops(topo.k8s_ops()); o.packed(ev, labels); o.window_close(W, L)
+    compare_edge_dicts(engine_edge_dict(rows, shim, labels, g.outbound_ips()), o.edge_dict())
+    orow = o.edge_rows()
+    assert np.array_equal(rows["from_ref"], orow["from_ref"]) and np.array_equal(rows["to_ref"], orow["to_ref"])
+    assert g.stats().events_dropped_cap == 0
+    g.close()
