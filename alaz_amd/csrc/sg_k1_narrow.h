@@ -556,7 +556,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     };
     auto mine = [&](u32 rem) -> bool { return S == 1 || ((rem >> sbit) & 1u) == sidx; };
     u32* hacc32 = reinterpret_cast<u32*>(hacc);                       // low word of accumulator j of slot h: 2 * (j*HT + h)
-    auto add_narrow = [&](u32 lo, u32 hi) {
+    [[maybe_unused]] auto add_narrow = [&](u32 lo, u32 hi) {
         const u32 rem = hi & rbmask;
         if (!mine(rem) || SG_ABL(d, 0x10u)) return;
         const u32 h = slot_of(rem);
@@ -570,6 +570,25 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         //  sending the atomic only when it would rise, 128.0-129.2 vs 122.6-123.5 us: the merge is not bound by the number or width of
         //  its LDS atomics.  Without the returning `deg` atomics of the compaction the launch is 91 us instead of 114; without any merge 48.)
         atomicAdd(&hacc[3 * HT + h], (u64)us * (u64)us);
+    };
+    // the two records of one 16-byte load together: their first probes are in flight at once (a hit at the home slot — seven in ten at this
+    // load — then costs the pair one LDS round trip instead of two); whatever the first probe does not settle walks the probe loop as before
+    auto apply_narrow = [&](u32 lo, u32 hi, u32 h) {
+        if (h == HT) { atomicAdd(n_drop, 1u); return; }
+        const u32 us = div1000_u32(lo);
+        if constexpr (PACK) atomicAdd(&hacc[HT + h], (u64)lo | (1ull << 48));
+        else { atomicAdd(&hacc32[2 * h], 1u); atomicAdd(&hacc[HT + h], (u64)lo); }
+        if (hi >> 31) atomicAdd(&hacc32[2 * h + 1], 1u);
+        atomicMax(&hacc32[2 * (2 * HT + h)], lo);
+        atomicAdd(&hacc[3 * HT + h], (u64)us * (u64)us);
+    };
+    auto add_narrow2 = [&](u32 lo0, u32 hi0, u32 lo1, u32 hi1, bool second) {
+        const u32 rem0 = hi0 & rbmask, rem1 = hi1 & rbmask;
+        const bool a0 = mine(rem0) && !SG_ABL(d, 0x10u), a1 = second && mine(rem1) && !SG_ABL(d, 0x10u);
+        const u32 h0 = rem0 & hmask, h1 = rem1 & hmask;
+        const u32 k0 = lds_fresh_u32(&hkey[h0]), k1 = lds_fresh_u32(&hkey[h1]);
+        if (a0) apply_narrow(lo0, hi0, k0 == rem0 ? h0 : slot_of(rem0));
+        if (a1) apply_narrow(lo1, hi1, k1 == rem1 ? h1 : slot_of(rem1));
     };
     auto add_wide = [&](u32 rem, u64 a0, u64 a1, u64 a2, u64 a3) {
         if (!mine(rem)) return;
@@ -596,7 +615,11 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const u32 r = r0 + u * LPP;
+#ifdef SG_K1B_ONE_PROBE                                                  /* (the one-record-at-a-time form, for a same-box A/B of two builds) */
                 if (r < npair) { add_narrow(x[u].x, x[u].y); if (2 * r + 1 < nn) add_narrow(x[u].z, x[u].w); }
+#else
+                if (r < npair) add_narrow2(x[u].x, x[u].y, x[u].z, x[u].w, 2 * r + 1 < nn);
+#endif
             }
         }
     }

@@ -113,7 +113,9 @@ def load_library(path: str = LIB_PATH, dev: bool = False) -> C.CDLL:
         import torch  # noqa: F401  (loads libamdhip64 with RTLD_GLOBAL semantics first)
     except Exception:
         pass
-    lib = C.CDLL(path, mode=C.RTLD_LOCAL)          # (local: the shipped and the development build export the same names and may both be loaded)
+    # (the development build is loaded locally: it exports the same names as the shipped library and both may be loaded in one process;
+    # both are linked -Bsymbolic, so neither's own calls can land in the other)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL if dev else C.RTLD_GLOBAL)
     H, P = C.c_void_p, C.c_void_p
     u32, u64, sz = C.c_uint32, C.c_uint64, C.c_size_t
     sig = {

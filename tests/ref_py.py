@@ -77,3 +77,26 @@ class Aggregator:
         if proto == "HTTP" and tls:
             proto = "HTTPS"                            # :1240-1242
         self.rows.append((start_ms, duration_ns, ft, fu, tt, tu, proto, status, tls))
+
+
+# ---- the per-window edge ledger (round 6: a second definition of what a window's rows are) ------------------------------------------
+# The reference ships one row per request (datastore/backend.go:819-847) and keeps no per-edge state; a window's edge rows are the
+# builder's aggregation of exactly the requests PersistRequest received in that window: an edge is in a window's
+# rows if and only if a request on it arrived in THAT window — whatever the engine keeps from earlier windows (the warm-window state) must
+# not show.  "error": HTTP / HTTPS / HTTP2 status >= 500; POSTGRES / REDIS / MYSQL status 2 (ebpf/c/postgres.c:91, redis.c:10, mysql.c:36).
+def is_error(proto: str, status: int) -> bool:
+    if proto in ("HTTP", "HTTPS", "HTTP2"):
+        return status >= 500
+    if proto in ("POSTGRES", "REDIS", "MYSQL"):
+        return status == 2
+    return False
+
+
+def window_ledger(rows):
+    """rows: Aggregator.rows of ONE window -> {(from_type, from_uid, to_type, to_uid): (count, errors, sum_ns, max_ns, sumsq_us)}"""
+    d = {}
+    for (_start, lat, ft, fu, tt, tu, proto, status, _tls) in rows:
+        c, e, s, m, q = d.get((ft, fu, tt, tu), (0, 0, 0, 0, 0))
+        us = lat // 1000
+        d[(ft, fu, tt, tu)] = (c + 1, e + (1 if is_error(proto, status) else 0), s + lat, max(m, lat), (q + us * us) & U64)
+    return d

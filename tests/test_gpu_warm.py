@@ -220,13 +220,14 @@ def test_hub_rows_and_a_large_graph_warm_equals_rebuild():
 def test_three_windows_in_flight_each_slot_keeps_its_own_state():
     """sg_config.windows_in_flight = 3: every slot has its own kept state (its previous window was three windows ago).  Nine windows
     enqueued three at a time on the three slots: slot k rebuilds on its first window, is warm on the same events again, and warm with a
-    third of them; all equal to the rows of a single-slot engine that rebuilds every window."""
+    third of them; then three windows in which every slot meets ANOTHER slot's events — edges its own kept set lacks: delta windows, each
+    slot merging into its own state; all equal to the rows of a single-slot engine that rebuilds every window."""
     import ctypes
     import torch
     topo = replay.make_topology(200, 5000, seed=71)
     labels = list(replay.EXTERNAL_HOSTS)
     evs = [replay.make_events(topo, 50_000, seed=80 + k, fixed_labels=True)[0] for k in range(3)]
-    wins = evs + evs + [e[::3].copy() for e in evs]
+    wins = evs + evs + [e[::3].copy() for e in evs] + [evs[1], evs[2], evs[0]]
     b = _engine(topo.n_nodes + 8, 1 << 14, 2, warm=False)
     a = _engine(topo.n_nodes + 8, 1 << 14, 2, windows_in_flight=3)
     for g in (a, b):
@@ -238,7 +239,7 @@ def test_three_windows_in_flight_each_slot_keeps_its_own_state():
     hip = ctypes.CDLL(None); hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     dev = [torch.from_numpy(w.view(np.uint8).reshape(-1)).cuda() for w in wins]
     torch.cuda.synchronize()
-    for rnd in range(3):
+    for rnd in range(4):
         ptrs = []
         for k in range(3):
             i = rnd * 3 + k
@@ -253,11 +254,19 @@ def test_three_windows_in_flight_each_slot_keeps_its_own_state():
             buf = np.zeros(n, dtype=replay.EDGE_OUT_DTYPE)
             assert n and hip.hipMemcpy(buf.ctypes.data, ctypes.c_void_p(ptrs[k]), n * 64, 2) == 0
             assert buf.tobytes() == want[i].tobytes(), i
-    # the synchronous API on the current slot (slot 0 again: its fourth window), and what path it took
+    # the synchronous API on the current slot (slot 0 again: its fifth window), and what path it took
     assert a.ingest(wins[6]) == 0
     assert a.flush_window().tobytes() == want[6].tobytes()
     st = a.stats()
-    assert (st.windows_warm, st.windows_cold) == (1, 0)
+    assert (st.windows_warm, st.windows_cold, st.windows_delta) == (1, 0, 0)
+    # ... and the next slot with a draw it has never seen
+    fresh = replay.make_events(topo, 50_000, seed=99, fixed_labels=True)[0]
+    assert b.ingest(fresh) == 0
+    wantf = b.flush_window().copy()
+    assert a.ingest(fresh) == 0
+    assert a.flush_window().tobytes() == wantf.tobytes()
+    st = a.stats()
+    assert (st.windows_warm, st.windows_cold, st.windows_delta) == (2, 0, 1) and st.last_window_new_edges > 0
     a.close(); b.close()
 
 
@@ -280,7 +289,8 @@ def test_set_warm_off_and_on_again_same_rows():
 
 def test_eight_logical_shards_warm_windows_equal_one_engine():
     """the sharded window close takes the same two paths: eight logical shards of one graph on this device (exchanges through device memory),
-    three windows — rebuild, warm, warm with fewer edges — equal to the unsharded engine's rows bit for bit."""
+    windows that rebuild, close warm, close warm with fewer edges, and — round 6 — meet new edges (every shard merges its own new edges into
+    its own kept set) — equal to the unsharded engine's rows bit for bit."""
     import threading
     import torch
     from alaz_amd import engine, sharded
@@ -289,6 +299,7 @@ def test_eight_logical_shards_warm_windows_equal_one_engine():
     labels = list(replay.EXTERNAL_HOSTS)
     ev1, _ = replay.make_events(topo, 150_000, seed=102, fixed_labels=True)
     ev2 = ev1[::4].copy(); ev2["duration_ns"] += 777         # a quarter of the first window's requests: a subset of its edges
+    ev3, _ = replay.make_events(topo, 150_000, seed=103, fixed_labels=True)   # another draw: edges the first one missed, other (pod, Host label) pairs
     W = weights.make_weights(layers)
     one = _engine(topo.n_nodes + 8, 1 << 15, layers, warm=False, max_labels=128)
     HostShim().apply(one, topo.k8s_ops()); one.set_label_count(len(labels))
@@ -303,7 +314,7 @@ def test_eight_logical_shards_warm_windows_equal_one_engine():
         g.set_clock(*CLOCK); g.load_weights(W); HostShim().apply(g, topo.k8s_ops()); g.set_label_count(len(labels))
         engs.append(g)
         bes.append(sharded.HipBackend(g, ncap=ncap, layers=layers, world=world, rank=r, device=dev, max_obip=512, stream=torch.cuda.Stream(dev)))
-    for w, ev in enumerate((ev1, ev1, ev2, ev1)):
+    for w, ev in enumerate((ev1, ev1, ev2, ev1, ev3, ev1, ev3)):
         assert one.ingest(ev) == 0
         want = one.flush_window().copy()
         shard = one.route(ev, world)
@@ -324,7 +335,8 @@ def test_eight_logical_shards_warm_windows_equal_one_engine():
         assert len(got) == len(want) and got[key(got)].tobytes() == want[key(want)].tobytes(), w
     st = [g.stats() for g in engs]
     assert sum(x.events_dropped_cap + x.events_misrouted for x in st) == 0
-    assert all(x.windows_cold == 1 and x.windows_warm == 3 for x in st), [(x.windows_warm, x.windows_cold) for x in st]
+    assert all(x.windows_cold == 1 and x.windows_warm == 6 for x in st), [(x.windows_warm, x.windows_cold) for x in st]
+    assert sum(x.windows_delta for x in st) >= world // 2, [x.windows_delta for x in st]
     for g in engs: g.close()
     one.close()
 
