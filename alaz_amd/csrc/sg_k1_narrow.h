@@ -799,5 +799,12 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
 }
 // (the SGPR cap lets two 1024-thread workgroups share a CU — tools/occupancy_probe.hip; the uncapped build for geometries
 // where a CU holds one workgroup anyway)
-template <int U, int SPT, bool PACK, int WM = 0> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void k1b_stream_merge(Dev d) { k1b8_body<U, SPT, PACK, WM>(d); }
+// (the development build's stamp / ablation code costs two registers more than the 64 that let two workgroups share a CU: there the
+// allocator is told to stay within them, so that what the tools measure is the shipped kernel's occupancy)
+#ifdef SG_DEV_KNOBS
+#define SG_K1B_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define SG_K1B_OCC
+#endif
+template <int U, int SPT, bool PACK, int WM = 0> __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) SG_K1B_OCC void k1b_stream_merge(Dev d) { k1b8_body<U, SPT, PACK, WM>(d); }
 template <int U, int SPT, bool PACK, int WM = 0> __global__ __launch_bounds__(1024) void k1b_stream_merge_wide(Dev d) { k1b8_body<U, SPT, PACK, WM>(d); }
