@@ -444,3 +444,27 @@ def test_kept_set_beyond_the_resident_chunks_compaction_ordered_by_ticket():
     st = a.stats()
     assert (st.windows_warm, st.windows_cold) == (3, 1) and st.events_dropped_cap == 0
     a.close(); b.close()
+
+
+def test_new_edges_beyond_a_partitions_key_budget_fall_back_to_the_rebuild_exactly():
+    """The one way a window with new edges still ends in the full rebuild: a partition's table would keep more than pcap keys (kept ones,
+    touched or not, + new ones).  Window 1 fills the partitions to ~60 % with edge set A; window 2 brings set B, ~47 % more and none of
+    A: the warm pass B gives up (C_COLD = 2), the cold merge repeats the window — B's keys first, A's untouched ones only while there is
+    room — and nothing is dropped; window 3 = B again is warm.  Every window equals the oracle and the rebuilding engine."""
+    topo = replay.make_topology(3000, 455_000, seed=171)
+    labels = list(replay.EXTERNAL_HOSTS)
+    E = len(topo.edge_src)
+    rng = np.random.default_rng(9)
+    perm = rng.permutation(E)
+    A, B = perm[:255_000], perm[255_000:]
+    evA = _events_on(topo, A, 1_500_000, 172); evA = evA[evA["host_label"] == 0]     # (no Host-label edges: the windows' edge sets are exactly A and B)
+    evB = _events_on(topo, B, 1_200_000, 173); evB = evB[evB["host_label"] == 0]
+    p = Pair(topo, 1, 1 << 18, labels, max_window_events=1_600_000)
+    geo = p.warm.geometry()
+    assert geo["partitions"] * geo["pass_b_split"] * (geo["table_slots"] * 13 // 16) < 255_000 + 200_000, geo   # the tables cannot hold A and B together
+    p.window(evA, chunk=1 << 18)
+    p.window(evB, chunk=1 << 18)
+    p.window(evB, chunk=1 << 18)
+    assert p.paths == ["cold", "cold", "warm"], p.paths
+    assert p.warm.stats().events_dropped_cap == 0
+    p.close()
