@@ -485,6 +485,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         const bool tk = ((e->timing >> 7) & 1u) && e->closes % e->timing_stride == 0;
         hipEvent_t ta = tk ? get_event(e) : nullptr, tb = tk ? get_event(e) : nullptr;
         Dev db = d; db.batch_state = e->window_events_in == 0 ? 2u : 0u;          // a window without any batch: nothing to merge
+        db.kept_compact = d.warm;                                                 // (a warm engine's pass B builds / feeds the kept state: compact node ids, sg_kernels.h sg_kept_compact)
         const bool share = d.npb > e->k1b_cus && 2 * e->k1b_lds <= kLdsBytes;   // several partitions per CU and room for two tables: the SGPR-capped build lets two workgroups share a CU
         // warm engines: the warm attempt (WM 1: seeded tables, accumulators straight to their kept positions; returns at once when
         // kc_prepare has already called the window cold), then the cold merge (WM 2: returns at once on a warm window).  Both are records
@@ -525,6 +526,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         // are scratch (the row sort reduces every row it sorts; the window's statistics come from kw_compact).  On a warm window each
         // of them returns at once.
         Dev dk = d;
+        dk.kept_compact = d.warm;
         if (d.warm) {
             dk.rowptr = d.k_rowptr; dk.col = d.k_col; dk.csr_from = d.k_from; dk.acc_csr = d.k_acc; dk.max_edges = (u64)d.npb * d.pcap;
             dk.st_sum = e->scr_sum[e->cur]; dk.st_max = e->scr_max[e->cur]; dk.row_mu = e->scr_mu[e->cur]; dk.row_sd = e->scr_mu[e->cur] + d.ncap + 1;

@@ -179,6 +179,9 @@ struct Dev {
     // CSR in one stable pass (no degree histogram, no row scan over partitions, no scatter, no row sort).  Any key the image lacks, a
     // changed node numbering or a raw outbound IP sends the window down the full rebuild, which captures the state anew.
     u32 warm;                                 // 1 = this engine keeps the state
+    u32 kept_compact;                         // this launch builds / merges the KEPT state (set per launch by the host: a warm engine's pass B and rebuild chain, not its
+                                              // "plain" closes): node ids are then COMPACT indices — known id | max_known + label — unless the window has raw outbound IPs
+                                              // (round 6: the kept CSR no longer depends on N_KNOWN / N_LABELS, so a new pod or Host label does not cost a rebuild)
     u32* wk_keys;                             // [npb][k1b_ht] pass B's table image of the last cold window (all ones = empty)
     u32* wk_pos;                              // [npb][k1b_ht] the slot's edge: partition-output index (cold pass B), then its kept-CSR position (kw_capture); SG_NONE = none
     u32* pos_of_slot;                         // [npb * pcap] CSR position the row sort gave the edge of a partition-output slot (cold windows)

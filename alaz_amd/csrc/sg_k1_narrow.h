@@ -713,14 +713,13 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             const u64 a0 = hacc[sl], a1 = hacc[HT + sl], a2 = hacc[2 * HT + sl], a3 = hacc[3 * HT + sl];
             if (anynew && ((hnew[sl >> 5] >> (sl & 31u)) & 1u)) {
                 // A NEW edge (round 6): it leaves in the cold format — endpoints out of the key, a place in the partition's output, its rank
-                // among the new edges of its row (deg2) — and enters the image at once; kw_compact gives it its kept position.  An edge
-                // whose endpoint has no dense id (a label beyond the count) is dropped and counted as the rebuild would (cold: it repeats
-                // the merge and does the accounting), and so is a partition that would keep more than pcap keys.
+                // among the new edges of its row (deg2) — and enters the image at once; kw_compact gives it its kept position.  A
+                // partition that would keep more than pcap keys gives up (cold: the rebuild repeats the merge and does the accounting).
                 const u64 mk = ((u64)p << d.rb) | rem;
                 u32 cf, ct;
                 sg_kunmix((u32)(mk >> nb), (u32)mk & nbmask, nbmask, &cf, &ct);
-                const u32 f = dense_of(d, ref_of_ci(d, cf), nk, nl, nob), to = dense_of(d, ref_of_ci(d, ct), nk, nl, nob);
-                if (f == SG_NONE || to == SG_NONE || atomicAdd(nkeys, 1u) >= d.pcap) { cold = true; continue; }
+                const u32 f = cf, to = ct;                           // COMPACT ids (sg_kept_compact: a warm window has no raw outbound IP), as the kept CSR holds them
+                if (atomicAdd(nkeys, 1u) >= d.pcap) { cold = true; continue; }
                 const u32 di = atomicAdd(out_n, 1u);                 // (< pcap: the partition's keys are)
                 const size_t slot = (size_t)oq * d.pcap + di;
                 const u32 rk = atomicAdd(&d.deg2[SG_DEG_IDX(f, oq & (SG_DEG_REP - 1))], 1u);
@@ -759,7 +758,8 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             const u64 mk = ((u64)p << d.rb) | rem;
             u32 cf, ct;
             sg_kunmix((u32)(mk >> nb), (u32)mk & nbmask, nbmask, &cf, &ct);
-            f[k2] = dense_of(d, ref_of_ci(d, cf), nk, nl, nob); to[k2] = dense_of(d, ref_of_ci(d, ct), nk, nl, nob);
+            if (WM == 2 && d.kept_compact && nob == 0) { f[k2] = cf; to[k2] = ct; }   // the KEPT state is built in compact ids (sg_kernels.h sg_kept_compact)
+            else { f[k2] = dense_of(d, ref_of_ci(d, cf), nk, nl, nob); to[k2] = dense_of(d, ref_of_ci(d, ct), nk, nl, nob); }
             if (f[k2] == SG_NONE || to[k2] == SG_NONE) { atomicAdd(n_drop, (u32)(hacc[sl] & 0xFFFFFFFFull)); continue; }
             oi[k2] = atomicAdd(out_n, 1u);
             if (oi[k2] >= d.pcap) { atomicAdd(n_drop, (u32)(hacc[sl] & 0xFFFFFFFFull)); continue; }

@@ -803,7 +803,8 @@ template <int K1B_U, bool HIST> __global__ __launch_bounds__(1024) void k1b_merg
 // ids of labels follow the known nodes'), and the window has no raw outbound IP (their dense ids are ranks among the window's own).
 __device__ __forceinline__ void kc_warm_decide(const Dev& d, u32 warm_try, u64 n_known, u64 nl, u64 nob) {
     if (!d.warm) return;
-    const bool ok = warm_try && d.ctr[C_KEPT_VALID] && d.ctr[C_KEPT_E] != 0 && d.ctr[C_KEPT_NK] == n_known && d.ctr[C_KEPT_NL] == nl && nob == 0;
+    (void)n_known; (void)nl;                                         // (until round 5 the kept columns were dense ids: N_KNOWN and N_LABELS had to be what they were at capture)
+    const bool ok = warm_try && d.ctr[C_KEPT_VALID] && d.ctr[C_KEPT_E] != 0 && nob == 0;
     d.ctr[C_COLD] = ok ? 0ull : 1ull;
 }
 __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_labels_decl, u32* list, const u32* n_in, u32 list_cap, u32 collect,
@@ -1000,6 +1001,13 @@ __global__ __launch_bounds__(256) void k2_edge_compact(Dev d) {
 //   1  a warm window that met NEW edges (C_DELTA_N != 0): the same kernels on those few edges only — the warm pass B left them in the
 //      partition outputs, ranks from deg2 — and the result is the DELTA CSR (dc_*), which kw_compact merges in;
 //  -1  a warm window without new edges: nothing to do, return at once.
+// COMPACT node ids (round 6).  The kept CSR used to hold DENSE ids — known ids, then labels from N_KNOWN on — so every new pod moved the
+// labels' ids and cost a full rebuild.  It holds compact indices now (known id | max_known + label: what the key mix works on): they never
+// move, they order exactly as the dense ids do (dense = c below max_known, N_KNOWN + (c - max_known) above: monotone), and kw_compact maps
+// them when it writes the window's CSR.  Raw outbound IPs have no such index (theirs is a slot of the window's own table; their dense ids
+// are ranks among the window's): a window that has any is built in dense ids as before and leaves the kept state invalid.
+__device__ __forceinline__ bool sg_kept_compact(const Dev& d) { return d.kept_compact && d.ctr[C_N_OBIP] == 0; }
+__device__ __forceinline__ u32 sg_chain_rows(const Dev& d) { return sg_kept_compact(d) ? d.max_known + d.max_labels : (u32)d.ctr[C_N_NODES]; }   // rows of the CSR a chain launch builds
 __device__ __forceinline__ int sg_chain_mode(const Dev& d) { if (!d.warm || d.ctr[C_COLD]) return 0; return d.ctr[C_DELTA_N] ? 1 : -1; }
 __device__ __forceinline__ Dev sg_delta_view(const Dev& d) { Dev x = d; x.rowptr = d.dc_rowptr; x.col = d.dc_col; x.csr_from = d.dc_from; x.acc_csr = d.dc_acc; x.deg = d.deg2; return x; }
 __global__ __launch_bounds__(K2_DH_THREADS) void k2_deg_hist(Dev d) {
@@ -1070,7 +1078,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev dd, u32 epoch) {
 #pragma unroll
         for (u32 j = 0; j < GLd; j++) v[j] = j < GG ? d.dh_hist[(size_t)(rep * GG + j) * d.dh_ns + row] : 0u;
     }
-    const u32 N = (u32)d.ctr[C_N_NODES];
+    const u32 N = sg_chain_rows(d);
     if (r0 >= N && b != 0) return;                                   // beyond the last row (grid sized for ncap)
     if (t == 0) nlong = 0;
     // 1. replicas -> in-row offsets, row degrees
@@ -1534,7 +1542,7 @@ __device__ __forceinline__ void k2_row_wg(const Dev& d, const EdgeEmitArgs& ea, 
 #define K2_SPLIT_ROW 1024
 // how many hub work items the row sort may use: all of them, when the whole list was recorded and a node bitmap fits the LDS arrays
 __device__ __forceinline__ u32 k2_split_items(const Dev& d) {
-    const u32 BW = ((u32)d.ctr[C_N_NODES] + 31) >> 5;
+    const u32 BW = (sg_chain_rows(d) + 31) >> 5;
     return (d.ctr[C_HUB_ITEMS] <= d.hub_cap && BW <= d.k2_sortw && !SG_ABL(d, 0x800u)) ? (u32)d.ctr[C_HUB_ITEMS] : 0u;
 }
 __device__ __forceinline__ void k2_split_finish(const Dev& d, u32 tid, u32 nt) {
@@ -1717,7 +1725,7 @@ __global__ __launch_bounds__(256) void k2_rowsort_gather(Dev dd) {
     const int cm = sg_chain_mode(dd);
     if (cm < 0) return;
     const Dev d = cm == 1 ? sg_delta_view(dd) : dd;
-    const u32 N = (u32)d.ctr[C_N_NODES], nlong = (u32)d.ctr[C_N_LONG];
+    const u32 N = sg_chain_rows(d), nlong = (u32)d.ctr[C_N_LONG];
     const EdgeEmitArgs ea = {d.acc_csr, d.csr_from, d.eacc, d.ekeys, d.alive_csr, d.variant, d.hist_src, d.hist_csr, d.hist, d.warm ? d.pos_of_slot : nullptr, cm == 1 ? d.dc_slot : nullptr};
     extern __shared__ u32 k2_lds[];                                  // 2 x k2_sortw words (dynamic: a node bitmap of the engine's node capacity fits when it can)
     u32* sk = k2_lds; u32* sv = k2_lds + d.k2_sortw;
@@ -1885,6 +1893,10 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
     u32* ncol = buf ? d.k_col : d.k_col2; u32* nfrom = buf ? d.k_from : d.k_from2; u32* nrp = buf ? d.k_rowptr : d.k_rowptr2;
     u32* nslot = d.k_slot + (size_t)(buf ^ 1u) * KC;
     const u32 M = KE + D, m0 = b * KW_CH, m1 = m0 + KW_CH < M ? m0 + KW_CH : M, cm = m1 - m0;   // (b < ceil(M / KW_CH): the caller saw to it)
+    // the kept and the delta CSR hold COMPACT node ids (sg_kept_compact: a warm window has no raw outbound IP); the window's arrays dense ones
+    const u32 MK = d.max_known, NKn = (u32)d.ctr[C_N_KNOWN], NC = d.max_known + d.max_labels;
+    auto dn = [&](u32 c) -> u32 { return c < MK ? c : NKn + (c - MK); };
+    auto has_dense = [&](u32 c) -> bool { return c < NKn || c >= MK; };   // (compact rows [N_KNOWN, max_known): ids no node has yet)
     const bool lastc = m1 == M;
     if (t < 64) { const u32 r = kw_merge_path(kfrom, kcol, d.dc_from, d.dc_col, KE, D, m0); if (t == 0) dg[0] = r; }
     else if (t < 128) { const u32 r = kw_merge_path(kfrom, kcol, d.dc_from, d.dc_col, KE, D, m1); if (t == 64) dg[1] = r; }
@@ -1982,12 +1994,12 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
             if (ssq) atomicAdd(&a[3], ssq);
             if (mx) atomicMax(&a[4], mx);
         } else {
-            u64* g = d.st_sum + (size_t)row * SG_NODE_STAT_SUM_WORDS;
+            u64* g = d.st_sum + (size_t)dn(row) * SG_NODE_STAT_SUM_WORDS;
             if (cnt_) atomicAdd(&g[ST_OUT_CNT], cnt_);
             if (err) atomicAdd(&g[ST_OUT_ERR], err);
             if (sum) atomicAdd(&g[ST_OUT_SUM], sum);
             if (ssq) atomicAdd(&g[ST_OUT_SSQ], ssq);
-            if (mx) atomicMax(&d.st_max[(size_t)row * 2], mx);
+            if (mx) atomicMax(&d.st_max[(size_t)dn(row) * 2], mx);
         }
     };
     bool wsame[KW_Q], inw[KW_Q];
@@ -2008,7 +2020,7 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
         if (np >= ME) continue;
         inw[q] = true;
         const u64 mx = y[q].x & ~(1ull << 63);
-        d.col[np] = co[q]; d.csr_from[np] = fr[q]; d.alive_csr[np] = 0;
+        d.col[np] = dn(co[q]); d.csr_from[np] = dn(fr[q]); d.alive_csr[np] = 0;
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)np * 4);
         o[0] = x[q]; o[1] = make_ulonglong2(mx, y[q].y);
         if (!wsame[q]) fold(fr[q], x[q].x & 0xFFFFFFFFull, x[q].x >> 32, x[q].y, y[q].y, mx);
@@ -2026,11 +2038,12 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
         const u32 ns = krp[v] + d.dc_rowptr[v];
         nrp[v] = ns;
         const u64 rp = (u64)base + rank_excl(ns - m0);
-        d.rowptr[v] = rp < ME ? (u32)rp : ME;
+        if (has_dense(v)) d.rowptr[dn(v)] = rp < ME ? (u32)rp : ME;
     }
     if (lastc) {
         const u64 Ef = (u64)base + total;
-        for (u32 v = v_hi + 1 + t; v <= N; v += KW_THREADS) { nrp[v] = M; d.rowptr[v] = Ef < ME ? (u32)Ef : ME; }
+        for (u32 v = v_hi + 1 + t; v <= NC; v += KW_THREADS) { nrp[v] = M; if (v < NC && has_dense(v)) d.rowptr[dn(v)] = Ef < ME ? (u32)Ef : ME; }
+        if (t == 0) d.rowptr[N] = Ef < ME ? (u32)Ef : ME;
         if (t == 0) { d.ctr[C_N_EDGES] = Ef < ME ? Ef : ME; d.ctr[C_EDGES_FOUND] = Ef; if (Ef > ME) d.ctr[C_DROPPED_CAP] += Ef - ME; }
     }
     __syncthreads();
@@ -2041,7 +2054,7 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
             const u64* a = kw_racc + (size_t)r * 5;
             const u64 cnt_ = a[0], err = a[1], sum = a[2], ssq = a[3], mx = a[4];
             if (!(cnt_ | err | sum | ssq | mx)) continue;
-            const u32 v = v0 + r;
+            const u32 v = dn(v0 + r);
             u64* g = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
             if (cnt_) atomicAdd(&g[ST_OUT_CNT], cnt_);
             if (err) atomicAdd(&g[ST_OUT_ERR], err);
@@ -2061,7 +2074,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u32 KE = (u32)d.ctr[C_KEPT_E], N = (u32)d.ctr[C_N_NODES];
     const u32 buf = (u32)d.ctr[C_KEPT_BUF] & 1u;                      // the current kept buffer (a delta window writes the other one and k3_in_part flips)
-    const u32 D = (!d.ctr[C_COLD] && d.ctr[C_DELTA_N]) ? d.dc_rowptr[N] : 0u;   // (uniform) new edges of a warm window, sorted by the delta chain
+    const u32 D = (!d.ctr[C_COLD] && d.ctr[C_DELTA_N]) ? d.dc_rowptr[d.max_known + d.max_labels] : 0u;   // (uniform) new edges of a warm window, sorted by the delta chain (compact rows)
     const u32 nchunk = (KE + D) ? (KE + D + KW_CH - 1) / KW_CH : 1u; // (a delta window's chunks cut the MERGE of the kept and the new edges: kw_compact_delta)
     const u32 G = gridDim.x - KW_CAPW;                               // chunk workgroups of the launch
     u32 b = blockIdx.x - KW_CAPW;
@@ -2094,6 +2107,12 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
     }
     if (D) { kw_compact_delta(d, b, epoch, KE, N, D, buf, kw_racc, &pre); SG_STAMP(d, 2, 5); return; }
     const u32* __restrict__ kcol = buf ? d.k_col2 : d.k_col; const u32* __restrict__ kfrom = buf ? d.k_from2 : d.k_from; const u32* __restrict__ krp = buf ? d.k_rowptr2 : d.k_rowptr;
+    // The kept CSR holds COMPACT node ids unless this window has raw outbound IPs (sg_kept_compact: then the rebuild has just written it in
+    // dense ids and the state is invalid anyway); the window's arrays hold dense ids: known ids as they are, labels from N_KNOWN on.
+    const bool cmp = d.ctr[C_N_OBIP] == 0;
+    const u32 MK = d.max_known, NKn = (u32)d.ctr[C_N_KNOWN], NR = cmp ? d.max_known + d.max_labels : N;   // rows of the kept CSR
+    auto dn = [&](u32 c) -> u32 { return (!cmp || c < MK) ? c : NKn + (c - MK); };
+    auto has_dense = [&](u32 c) -> bool { return !cmp || c < NKn || c >= MK; };
     const u32 p0 = b * KW_CH, last = (p0 + KW_CH < KE ? p0 + KW_CH : KE) - 1;
     u32 fr[KW_Q], co[KW_Q]; ulonglong2 x[KW_Q], y[KW_Q]; bool tc[KW_Q];
 #pragma unroll
@@ -2151,7 +2170,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
         const u32 np = base + qpre[q] + wpre[q][wave] + (u32)__popcll(bal[q][wave] & lt);
         if (np >= ME) continue;
         const u64 mx = y[q].x & ~(1ull << 63);
-        d.col[np] = co[q]; d.csr_from[np] = fr[q]; d.alive_csr[np] = 0;
+        d.col[np] = dn(co[q]); d.csr_from[np] = dn(fr[q]); d.alive_csr[np] = 0;
         ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_csr + (size_t)np * 4);
         o[0] = x[q]; o[1] = make_ulonglong2(mx, y[q].y);
         const u64 cnt = x[q].x & 0xFFFFFFFFull, err = x[q].x >> 32;
@@ -2165,12 +2184,12 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
             if (y[q].y) atomicAdd(&a[3], y[q].y);
             if (mx) atomicMax(&a[4], mx);
         } else {
-            u64* g = d.st_sum + (size_t)fr[q] * SG_NODE_STAT_SUM_WORDS;
+            u64* g = d.st_sum + (size_t)dn(fr[q]) * SG_NODE_STAT_SUM_WORDS;
             if (cnt) atomicAdd(&g[ST_OUT_CNT], cnt);
             if (err) atomicAdd(&g[ST_OUT_ERR], err);
             if (x[q].y) atomicAdd(&g[ST_OUT_SUM], x[q].y);
             if (y[q].y) atomicAdd(&g[ST_OUT_SSQ], y[q].y);
-            if (mx) atomicMax(&d.st_max[(size_t)fr[q] * 2], mx);
+            if (mx) atomicMax(&d.st_max[(size_t)dn(fr[q]) * 2], mx);
         }
     }
 #pragma unroll
@@ -2192,11 +2211,12 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
     for (u32 v = v_lo + t; v <= v_hi; v += KW_THREADS) {
         const u32 xl = krp[v] - p0, q = xl / KW_THREADS, tt = xl % KW_THREADS, w2 = tt >> 6, l2 = tt & 63u;
         const u32 rp = base + qpre[q] + wpre[q][w2] + (u32)__popcll(bal[q][w2] & ((1ull << l2) - 1ull));
-        d.rowptr[v] = rp < ME ? rp : ME;
+        if (has_dense(v)) d.rowptr[dn(v)] = rp < ME ? rp : ME;
     }
     if (b == nchunk - 1) {                                           // the last chunk knows E; the rows behind the last kept edge are empty
         const u32 Ef = base + total, E = Ef < ME ? Ef : ME;
-        for (u32 v = v_hi + 1 + t; v <= N; v += KW_THREADS) d.rowptr[v] = E;
+        for (u32 v = v_hi + 1 + t; v < NR; v += KW_THREADS) if (has_dense(v)) d.rowptr[dn(v)] = E;
+        if (t == 0) d.rowptr[N] = E;
         if (t == 0) { d.ctr[C_N_EDGES] = E; d.ctr[C_EDGES_FOUND] = Ef; if (Ef > ME) d.ctr[C_DROPPED_CAP] += (u64)(Ef - ME); }
     }
     __syncthreads();                                                 // every LDS fold is in
@@ -2207,16 +2227,16 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
             const u64* a = kw_racc + (size_t)r * 5;
             const u64 cnt = a[0], err = a[1], sum = a[2], ssq = a[3], mx = a[4];
             if (!(cnt | err | sum | ssq | mx)) continue;
-            const u32 v = v0 + r;
-            u64* g = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
+            const u32 v = v0 + r, vd = dn(v);
+            u64* g = d.st_sum + (size_t)vd * SG_NODE_STAT_SUM_WORDS;
             if (v >= v_lo && v < v_hi) {                             // wholly inside this chunk: nobody else writes the row (the arrays were zeroed by the window reset)
-                g[ST_OUT_CNT] = cnt; g[ST_OUT_ERR] = err; g[ST_OUT_SUM] = sum; g[ST_OUT_SSQ] = ssq; d.st_max[(size_t)v * 2] = mx;
+                g[ST_OUT_CNT] = cnt; g[ST_OUT_ERR] = err; g[ST_OUT_SUM] = sum; g[ST_OUT_SSQ] = ssq; d.st_max[(size_t)vd * 2] = mx;
             } else {
                 if (cnt) atomicAdd(&g[ST_OUT_CNT], cnt);
                 if (err) atomicAdd(&g[ST_OUT_ERR], err);
                 if (sum) atomicAdd(&g[ST_OUT_SUM], sum);
                 if (ssq) atomicAdd(&g[ST_OUT_SSQ], ssq);
-                if (mx) atomicMax(&d.st_max[(size_t)v * 2], mx);
+                if (mx) atomicMax(&d.st_max[(size_t)vd * 2], mx);
             }
         }
     }
@@ -2288,7 +2308,7 @@ __global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
     // a delta window's kw_compact (the launch before this one) has written the kept CSR, grown by the window's new edges, to the other
     // buffer: flip (nothing in this launch reads the kept state; the next window's pass B and kw_compact do)
     if (g == 0 && t == 0 && d.warm && !d.ctr[C_COLD] && d.ctr[C_DELTA_N]) {
-        d.ctr[C_KEPT_E] += (u64)d.dc_rowptr[N];
+        d.ctr[C_KEPT_E] += (u64)d.dc_rowptr[d.max_known + d.max_labels];
         d.ctr[C_KEPT_BUF] ^= 1ull;                                    // (C_DELTA_N stays for the window's reader: sg_stats.windows_delta; kc_prepare re-arms it)
     }
     alive_mark(d, g, G, t);
