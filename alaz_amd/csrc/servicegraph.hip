@@ -547,7 +547,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
             // the window's CSR out of the kept one — every window; behind a rebuild its first workgroups also take the positions the
             // next windows' pass B writes to (kw_capture)
             const unsigned kg = (unsigned)(((u64)d.npb * d.pcap + KW_CH - 1) / KW_CH) + KW_CAPW;
-            hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), (size_t)KW_ROWS * 5 * sizeof(u64), s, d, ++e->kw_epoch, dk.st_sum, dk.st_max, (u64)(e->closes + 1));
+            hipLaunchKernelGGL(kw_compact, dim3(kg), dim3(KW_THREADS), (size_t)KW_ROWS * 5 * sizeof(u64), s, d, ++e->kw_epoch, dk.st_sum, dk.st_max, (u64)(e->closes + 1), e->slots.size() > 1 ? 1u : 0u);
         }
     }
     {

@@ -722,8 +722,11 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
                 if (atomicAdd(nkeys, 1u) >= d.pcap) { cold = true; continue; }
                 const u32 di = atomicAdd(out_n, 1u);                 // (< pcap: the partition's keys are)
                 const size_t slot = (size_t)oq * d.pcap + di;
-                const u32 rk = atomicAdd(&d.deg2[SG_DEG_IDX(f, oq & (SG_DEG_REP - 1))], 1u);
-                d.e_from[slot] = f; d.e_to[slot] = to; d.e_rank[slot] = rk;
+                // (the row's degree among the new edges: a fire-and-forget device atomic — the delta scatter ranks the edges of a row with its
+                // own cursor; the RETURNING atomic the full rebuild's rank needs cost every workgroup with a new key its round trip: + 10 us
+                // on the launch for a thousand new edges, + 28 for forty thousand)
+                atomicAdd(&d.deg2[SG_DEG_IDX(f, oq & (SG_DEG_REP - 1))], 1u);
+                d.e_from[slot] = f; d.e_to[slot] = to;
                 ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
                 o[0] = make_ulonglong2(a0, a1); o[1] = make_ulonglong2(a2 | (1ull << 63), a3);
                 d.dl_img[slot] = oq * HT + sl;

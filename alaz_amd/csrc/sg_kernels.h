@@ -1221,6 +1221,11 @@ __global__ __launch_bounds__(256) void k2_scatter_parts(Dev dd) {
             f[q] = d.e_from[slot[q]]; to[q] = d.e_to[slot[q]]; rk[q] = d.e_rank[slot[q]];
         }
         u32 rp[4], dg[4];
+        if (cm == 1) {                                               // the new edges of a warm window: a row's edges take their places from a cursor (any order: the row sort follows)
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (i0 + 256u * q < n) { const u32 pos = d.rowptr[f[q]] + atomicAdd(&d.cursor[f[q]], 1u); if (pos < d.max_edges) d.cs[pos] = make_uint2(to[q], slot[q]); }
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             rp[q] = d.rowptr[f[q]];
@@ -2064,7 +2069,7 @@ __device__ __forceinline__ void kw_compact_delta(const Dev& d, const u32 b, cons
         }
     }
 }
-__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* scratch_sum, u64* scratch_max, u64 seq) {
+__global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* scratch_sum, u64* scratch_max, u64 seq, u32 shared_chip) {
     extern __shared__ u64 kw_racc[];                                 // [KW_ROWS][5]: cnt, err, sum, ssq, max
     __shared__ u64 bal[KW_Q][KW_NW];
     __shared__ u32 wpre[KW_Q][KW_NW];
@@ -2082,7 +2087,10 @@ __global__ __launch_bounds__(KW_THREADS) void kw_compact(Dev d, u32 epoch, u64* 
     // The grid is sized for the kept arrays' capacity; the chunks behind the last kept edge
     // return at once and free their place, so up to KW_RESIDENT working chunks never wait for one that cannot start,
     // whatever the dispatch order.  (586 same-address ticket draws were ~7 us at the head of every launch.)
-    if (nchunk > KW_RESIDENT) {                                      // (uniform: every workgroup reads the same count)
+    // (shared_chip — an engine with several windows in flight: another slot's look-back kernel may hold CUs at the same time, and two launches
+    // whose resident chunks each wait for a chunk that cannot start would wait for ever; by ticket a chunk only ever waits for chunks that
+    // have started — ADVICE r5)
+    if (nchunk > KW_RESIDENT || shared_chip) {                       // (uniform: every workgroup reads the same count)
         if (t == 0) { const u32 tk = atomicAdd(&d.lb_ticket[1], 1u); if (tk == G - 1) atomicExch(&d.lb_ticket[1], 0u); bdyn = tk; }
         __syncthreads();
         b = bdyn;

@@ -412,12 +412,27 @@ def churn_leg(a, topo, labels, c, device, dev, Ev, nb, steady_ms):
                 torch.cuda.synchronize()
             g.timing_enable(0)
             w2 = np.sort(g.timing_samples(10, W + 8))
+            # where the difference goes: per kernel group (event pairs around every group: a few microseconds each, so in passes of their own),
+            # two more windows with new edges, then the same two with the edges known
+            def groups(batches):
+                g.timing_reset(); g.timing_enable(1)
+                nonlocal wi
+                for b_ in batches:
+                    g.ingest_device(dev[wi % nb].data_ptr(), Ev, 0); wi += 1
+                    g.ingest_device(b_[0].data_ptr(), b_[1], 0)
+                    g.window_run(0)
+                torch.cuda.synchronize(); g.timing_enable(0)
+                return {name: round(g.timing(k)[0] * g.timing(k)[1] / len(batches), 1) for name, k in (("K1a", 1), ("K1b", 7), ("K2", 2), ("K3-in", 8), ("K3-feat", 3), ("K4", 4), ("K5", 5))}
+            more = [batch_of_new_edges(max(1, int(rate * E0))) for _ in range(2)]
+            torch.cuda.synchronize()
+            grp_new, grp_known = groups(more), groups(more)
             out.append({"new_edges_per_window": extra[0][2], "share_of_graph": rate, "windows": W,
                         "ms_per_window_median": round(float(np.median(w)) / 1e3, 5), "ms_per_window_min": round(float(w[0]) / 1e3, 5),
                         "ms_same_windows_edges_known": round(float(np.median(w2)) / 1e3, 5),
                         "vs_same_windows_edges_known": round(float(np.median(w)) / float(np.median(w2)), 3),
                         "vs_steady_window": round(float(np.median(w)) / 1e3 / steady_ms, 3) if steady_ms else None,
                         "new_edges_merged": new_seen,
+                        "us_per_kernel_group": {"with_new_edges": grp_new, "edges_known": grp_known},
                         "paths": {"warm": int(st.windows_warm - before.windows_warm), "of_them_delta": int(st.windows_delta - before.windows_delta),
                                   "cold": int(st.windows_cold - before.windows_cold), "plain": int(st.windows_plain - before.windows_plain)}})
             del extra
