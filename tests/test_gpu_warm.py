@@ -471,3 +471,40 @@ def test_new_edges_beyond_a_partitions_key_budget_fall_back_to_the_rebuild_exact
     assert p.paths == ["cold", "cold", "warm"], p.paths
     assert p.warm.stats().events_dropped_cap == 0
     p.close()
+
+
+@pytest.mark.parametrize("seed", [5, 23])
+def test_random_windows_with_growing_graph_and_growing_cluster(seed):
+    """A randomised stream: twenty windows over a graph whose edge pool grows, with pods and services ADDED between windows (the node count
+    and with it every Host label's dense id moves: the kept state holds compact ids and stays), some windows empty, some a small subset, some
+    with reversed requests and open connections — whatever path a window takes (rebuild, warm, delta) its rows are the oracle's and the
+    rebuilding engine's; after the first window nothing is rebuilt."""
+    rng = np.random.default_rng(seed)
+    topo = replay.make_topology(240, 9000, seed=300 + seed)
+    labels = list(replay.EXTERNAL_HOSTS)
+    E = len(topo.edge_src)
+    order = rng.permutation(E)
+    p = Pair(topo, 2, 1 << 15, labels)
+    pool = 2000
+    extra_pods = 0
+    for w in range(20):
+        if w and extra_pods < 12 and rng.random() < 0.4:              # the cluster grows: a pod or a service nobody talks to yet
+            extra_pods += 1
+            p.ops([("pod" if rng.random() < 0.6 else "svc", "ADD", f"late-{seed}-{extra_pods}", f"10.99.{extra_pods // 250}.{extra_pods % 250 + 1}")])
+        pool = min(E, pool + int(rng.integers(0, 900)))
+        kind = rng.random()
+        if kind < 0.1:
+            ev = _events_on(topo, order[:pool], 10, 1000 * seed + w)[:0]          # an empty window
+        else:
+            take = order[:pool] if kind < 0.7 else rng.choice(order[:pool], size=max(50, pool // 6), replace=False)
+            ev = _events_on(topo, take, int(rng.integers(5_000, 60_000)), 1000 * seed + w)
+        if len(ev) and rng.random() < 0.3:                            # open connections on edges of the window (count-only touches)
+            known = np.isin(ev["daddr"], np.concatenate([topo.pod_ips, topo.svc_ips]))
+            alive = ev[known][:500].copy(); alive["flags"] |= np.uint8(replay.EV_ALIVE); alive["duration_ns"] = 0; alive["host_label"] = 0
+            ev = np.concatenate([ev, alive])
+        p.window(ev)
+        if len(ev): last = ev
+    p.window(last)                                                   # nothing new: warm
+    assert p.paths[0] == "cold" and "cold" not in p.paths[1:], p.paths
+    assert "delta" in p.paths and p.paths[-1] == "warm", p.paths
+    p.close()
