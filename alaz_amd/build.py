@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "servicegraph.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("sg_kernels.h", "sg_k1_narrow.h", "sg_k1_team.h", "sg_device.h", "sg_hash.h", "join_host.hpp", "shard_seq.hpp")] + \
+DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".h", ".hpp"))) + \
        [os.path.join(ROOT, "include", "servicegraph.h")]
 LIB = os.path.join(HERE, "lib", "libservicegraph.so")
 # the development build of the same sources (-DSG_DEV_KNOBS: SG_* tuning knobs read from the environment, SG_ABLATE bits and phase

@@ -2,7 +2,7 @@
 //
 // One sg_engine owns one device: the join tables, the open window's edge table, the closed
 // window's CSR / feature / score buffers, a pinned staging ring for host-fed events and one HIP
-// stream.  All kernels live in sg_kernels.h.  There is no CPU compute path in this file: every
+// stream.  All kernels live in sg_kernels.h and the per-stage headers it includes.  There is no CPU compute path in this file: every
 // entry point that produces results launches HIP kernels, and sg_create() fails without a device.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
