@@ -722,11 +722,9 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
                 if (atomicAdd(nkeys, 1u) >= d.pcap) { cold = true; continue; }
                 const u32 di = atomicAdd(out_n, 1u);                 // (< pcap: the partition's keys are)
                 const size_t slot = (size_t)oq * d.pcap + di;
-                // (the row's degree among the new edges: a fire-and-forget device atomic — the delta scatter ranks the edges of a row with its
-                // own cursor; the RETURNING atomic the full rebuild's rank needs cost every workgroup with a new key its round trip: + 10 us
-                // on the launch for a thousand new edges, + 28 for forty thousand)
-                atomicAdd(&d.deg2[SG_DEG_IDX(f, oq & (SG_DEG_REP - 1))], 1u);
-                d.e_from[slot] = f; d.e_to[slot] = to;
+                const u32 rk = atomicAdd(&d.deg2[SG_DEG_IDX(f, oq & (SG_DEG_REP - 1))], 1u);   // (ranking a row's new edges by a cursor in the delta scatter
+                                                                     //  instead was measured: no gain here, + 40 us when the new edges come as whole new rows)
+                d.e_from[slot] = f; d.e_to[slot] = to; d.e_rank[slot] = rk;
                 ulonglong2* o = reinterpret_cast<ulonglong2*>(d.acc_src + slot * 4);
                 o[0] = make_ulonglong2(a0, a1); o[1] = make_ulonglong2(a2 | (1ull << 63), a3);
                 d.dl_img[slot] = oq * HT + sl;
@@ -742,7 +740,9 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         if (cold || (t == 0 && *n_drop)) d.ctr[C_COLD] = 2;           // (same value from whoever writes it; 2 = found HERE, after a whole merge: the host backs off when that keeps happening)
         if (anynew) {                                                // (uniform)
             __syncthreads();                                         // the new edges are counted
-            if (t == 0) { const u32 dn = *out_n; d.part_n[oq] = dn; if (dn) atomicAdd(&d.ctr[C_DELTA_N], (u64)dn); }   // new edges of this partition (the delta chain reads it)
+            if (t == 0) { const u32 dn = *out_n; d.part_n[oq] = dn; if (dn) d.ctr[C_DELTA_N] = 1; }   // new edges of this partition (the delta chain reads it); C_DELTA_N: a plain
+                                                                     // store of "there are some" — a thousand workgroups' atomic adds on one word queue up behind each other at the L2;
+                                                                     // the delta chain's row scan stores the count
         } else if (t == 0) d.part_n[oq] = 0;
         SG_STAMP(d, 1, 5);
         return;

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(1024) void k2_rowptr(Dev dd, u32 epoch) {
         if (r0 + RPR >= N) {                                    // the workgroup of the last row knows E
             const u32 E = base + total;
             d.rowptr[N] = (u64)E < d.max_edges ? E : (u32)d.max_edges;
+            if (delta) d.ctr[C_DELTA_N] = E;                         // (the warm pass B only said "there are some")
             if (!delta) {                                            // (the delta CSR's size is its last row pointer; the window's counts are kw_compact's)
             d.ctr[C_N_EDGES] = (u64)E < d.max_edges ? E : d.max_edges;
             if (d.variant == 0) { d.ctr[C_EDGES_FOUND] = E; if ((u64)E > d.max_edges) d.ctr[C_DROPPED_CAP] += (u64)E - d.max_edges; }
@@ -433,11 +434,6 @@ __global__ __launch_bounds__(256) void k2_scatter_parts(Dev dd) {
             f[q] = d.e_from[slot[q]]; to[q] = d.e_to[slot[q]]; rk[q] = d.e_rank[slot[q]];
         }
         u32 rp[4], dg[4];
-        if (cm == 1) {                                               // the new edges of a warm window: a row's edges take their places from a cursor (any order: the row sort follows)
-#pragma unroll
-            for (int q = 0; q < 4; q++) if (i0 + 256u * q < n) { const u32 pos = d.rowptr[f[q]] + atomicAdd(&d.cursor[f[q]], 1u); if (pos < d.max_edges) d.cs[pos] = make_uint2(to[q], slot[q]); }
-            continue;
-        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             rp[q] = d.rowptr[f[q]];
