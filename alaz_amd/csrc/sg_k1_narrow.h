@@ -731,8 +731,9 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
                 d.wk_keys[(size_t)oq * HT + sl] = rem;               // (its position: kw_compact, from dl_img)
                 continue;
             }
-            if (pos[k2] >= KE) { cold = true; continue; }             // a key without a kept edge (dropped when the image was taken)
             const bool touched = (a0 & 0xFFFFFFFFull) != 0 || ((htouch[sl >> 5] >> (sl & 31u)) & 1u);
+            if (pos[k2] >= KE) { if (touched) cold = true; continue; }   // a key without a kept edge (dropped for capacity when the image was taken): only a window that
+                                                                     // TOUCHES it must be rebuilt — flagged unconditionally it kept its partition cold for ever
             ulonglong2* o = reinterpret_cast<ulonglong2*>(d.k_acc + (size_t)pos[k2] * 4);
             o[0] = make_ulonglong2(touched ? a0 : 0ull, touched ? a1 : 0ull);
             o[1] = make_ulonglong2(touched ? (a2 | (1ull << 63)) : 0ull, touched ? a3 : 0ull);
