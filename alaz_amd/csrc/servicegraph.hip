@@ -492,7 +492,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
         // of group 7: a window's pass B is the SUM of its group-7 records.
 #define K1B8W_GOP(U_, SPT_, P_, WM_) do { if (share) hipExtLaunchKernelGGL((k1b_stream_merge<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); \
                                      else hipExtLaunchKernelGGL((k1b_stream_merge_wide<U_, SPT_, P_, WM_>), dim3(d.npb), dim3(e->k1b_threads), (uint32_t)e->k1b_lds, s, ta, tb, 0u, db); } while (0)
-#define K1B8W_GO(SPT_, WM_) do { if (e->k1b_pack) K1B8W_GOP(4, SPT_, true, WM_); else K1B8W_GOP(4, SPT_, false, WM_); } while (0)
+#define K1B8W_GO(SPT_, WM_) do { if (e->k1b_pack) K1B8W_GOP(K1B_WARM_U, SPT_, true, WM_); else K1B8W_GOP(K1B_WARM_U, SPT_, false, WM_); } while (0)
 #define K1B8W_GO2(WM_) do { const u32 spt = d.k1b_ht / e->k1b_threads; if (spt >= 4) K1B8W_GO(4, WM_); else if (spt == 2) K1B8W_GO(2, WM_); else K1B8W_GO(1, WM_); } while (0)
         if (d.warm) {
             if (warm_try) {
@@ -903,14 +903,14 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
                               reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, true>),
                               reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 1, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 2, true>), reinterpret_cast<const void*>(k1b_stream_merge_wide<8, 4, true>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
-        for (const void* f : {reinterpret_cast<const void*>(k1b_stream_merge<4, 1, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, false, 1>),
-                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, true, 1>),
-                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, false, 1>),
-                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, true, 1>),
-                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, false, 2>),
-                              reinterpret_cast<const void*>(k1b_stream_merge<4, 1, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 2, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge<4, 4, true, 2>),
-                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, false, 2>),
-                              reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 1, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 2, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<4, 4, true, 2>)})
+        for (const void* f : {reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 1, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 2, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 4, false, 1>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 1, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 2, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 4, true, 1>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 1, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 2, false, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 4, false, 1>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 1, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 2, true, 1>), reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 4, true, 1>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 1, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 2, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 4, false, 2>),
+                              reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 1, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 2, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge<K1B_WARM_U, 4, true, 2>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 1, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 2, false, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 4, false, 2>),
+                              reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 1, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 2, true, 2>), reinterpret_cast<const void*>(k1b_stream_merge_wide<K1B_WARM_U, 4, true, 2>)})
             CH(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->k1b_lds));
         CH(hipFuncSetAttribute(reinterpret_cast<const void*>(kw_compact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)KW_ROWS * 5 * sizeof(u64))));
         e->ecap = K2_TILE;                                              // the global edge table is not used
@@ -952,7 +952,8 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
         size_t eslots = ME;
         if (w.variant == 0) {
             eslots = std::max<size_t>(ME, (size_t)w.npb * w.pcap);
-            if (w.narrow) { LR(dev_alloc(e, &w.slab8, (size_t)w.np * w.nwg * w.punits)); LR(dev_alloc(e, &w.hdr8, (size_t)w.np * w.nwg)); }
+            if (w.narrow) { LR(dev_alloc(e, &w.slab8, (size_t)w.np * w.nwg * w.punits)); LR(dev_alloc(e, &w.hdr8, (size_t)w.np * w.nwg));
+                            if (!sg_knob("SG_K1B_NO_ORDER")) { LR(dev_alloc(e, &w.k1b_cnt, w.np)); LR(dev_alloc(e, &w.k1b_order, w.np)); } }   // (pass B's largest-first order: sg_k2.h kc_prepare)
             else { LR(dev_alloc(e, &w.slab_s, (size_t)w.np * w.nwg * w.pslots)); LR(dev_alloc(e, &w.hdr, (size_t)w.np * w.nwg)); }
             LR(dev_alloc(e, &w.ovf, (size_t)w.ovf_cap * 9));
             LR(dev_alloc(e, &w.ovf_p, (size_t)w.ovf_cap));

@@ -201,6 +201,8 @@ struct Dev {
     u32* dc_ip;                               // [npb * pcap] delta position -> insertion point in the kept CSR (kw_compact's scratch)
     u32* dl_img;                              // [npb * pcap] partition-output slot of a new edge -> its image index
     u32* deg2;                                // [ncap + 1][SG_DEG_REP] row-degree replicas of the new edges (deg belongs to a full rebuild; zeroed by the window reset)
+    u32* k1b_cnt;                             // [np] narrow records pass B read per partition in the LAST window (kc_prepare consumes and zeroes them)
+    u32* k1b_order;                           // [np] the partitions by those counts, largest first: pass B's workgroup i takes partition k1b_order[i] (kc_prepare, every window)
     u64* host_note;                           // page-locked HOST memory (mapped): [0] = sequence number of the last window kw_compact closed, [1] = its C_COLD
                                               // and C_N_OBIP << 8 — how the host learns, without ever waiting for the device, which path its windows take
     u32* lb_ticket;                           // [4] self-resetting workgroup tickets of the look-back kernels whose grid exceeds SG_LB_RESIDENT ([0] k2_rowptr, [1] kw_compact)

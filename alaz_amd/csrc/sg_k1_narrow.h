@@ -17,6 +17,9 @@
 #pragma once
 
 #define K1T_THREADS 1024
+#ifndef K1B_WARM_U
+#define K1B_WARM_U 2            // pass B of an engine that keeps state: 16-byte loads per lane in the rolling buffer (two workgroups per CU: 64 registers)
+#endif
 #define K1T_CHUNK   4096u         // events per chunk at most: four per thread
 #define K1T_TS(NSUB) (K1T_CHUNK * (NSUB))   // records per tile: NSUB chunks (1 or 2)
 #define K1T_NONE    0xFFFFFFFFu
@@ -497,7 +500,8 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     const u32 t = threadIdx.x, NT = blockDim.x;
     // q -> (partition, sub-table): blocks b and b + 8 run on the same XCD (b % 8) and are dispatched back to back
     const u32 S = d.k1b_split, q = blockIdx.x;
-    const u32 p = S == 2 ? ((q >> 4) << 3) | (q & 7u) : q, sidx = S == 2 ? (q >> 3) & 1u : 0u;
+    const u32 pi = S == 2 ? ((q >> 4) << 3) | (q & 7u) : q, sidx = S == 2 ? (q >> 3) & 1u : 0u;
+    const u32 p = d.k1b_order ? d.k1b_order[pi] : pi;               // the partitions in the order of their size in the window before, largest first (kc_prepare)
     const u32 oq = p * S + sidx;                                     // output partition
     const u32 nb = d.nb, nbmask = (1u << nb) - 1u, rbmask = (1u << d.rb) - 1u, sbit = d.rb - 1;
     SG_STAMP(d, 1, 0);
@@ -556,21 +560,9 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     };
     auto mine = [&](u32 rem) -> bool { return S == 1 || ((rem >> sbit) & 1u) == sidx; };
     u32* hacc32 = reinterpret_cast<u32*>(hacc);                       // low word of accumulator j of slot h: 2 * (j*HT + h)
-    [[maybe_unused]] auto add_narrow = [&](u32 lo, u32 hi) {
-        const u32 rem = hi & rbmask;
-        if (!mine(rem) || SG_ABL(d, 0x10u)) return;
-        const u32 h = slot_of(rem);
-        if (h == HT) { atomicAdd(n_drop, 1u); return; }
-        const u32 us = div1000_u32(lo);
-        if constexpr (PACK) atomicAdd(&hacc[HT + h], (u64)lo | (1ull << 48));   // count (bits 48..) and duration sum in one operation
-        else { atomicAdd(&hacc32[2 * h], 1u); atomicAdd(&hacc[HT + h], (u64)lo); }   // count (low word of accumulator 0); duration sum
-        if (hi >> 31) atomicAdd(&hacc32[2 * h + 1], 1u);             // errors (high word of accumulator 0)
-        atomicMax(&hacc32[2 * (2 * HT + h)], lo);                    // max: no wide record has touched the table yet
-        // (measured on one box each: both sums as 32-bit words with a carry, 125.6-130.0 vs 121.3-129.3 us; reading the maximum first and
-        //  sending the atomic only when it would rise, 128.0-129.2 vs 122.6-123.5 us: the merge is not bound by the number or width of
-        //  its LDS atomics.  Without the returning `deg` atomics of the compaction the launch is 91 us instead of 114; without any merge 48.)
-        atomicAdd(&hacc[3 * HT + h], (u64)us * (u64)us);
-    };
+    // (measured on one box each: both sums as 32-bit words with a carry, 125.6-130.0 vs 121.3-129.3 us; reading the maximum first and
+    //  sending the atomic only when it would rise, 128.0-129.2 vs 122.6-123.5 us: the merge is not bound by the number or width of
+    //  its LDS atomics.  Without the returning `deg` atomics of the compaction the launch is 91 us instead of 114; without any merge 48.)
     // the two records of one 16-byte load together: their first probes are in flight at once (a hit at the home slot — seven in ten at this
     // load — then costs the pair one LDS round trip instead of two); whatever the first probe does not settle walks the probe loop as before
     auto apply_narrow = [&](u32 lo, u32 hi, u32 h) {
@@ -582,6 +574,17 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         atomicMax(&hacc32[2 * (2 * HT + h)], lo);
         atomicAdd(&hacc[3 * HT + h], (u64)us * (u64)us);
     };
+    // a slot that read EMPTY: take it (or learn whose it has become); returns the key the slot holds now
+    auto claim = [&](u32 h, u32 rem) -> u32 {
+        u32 k = atomicCAS(&hkey[h], 0xFFFFFFFFu, rem);
+        if (k == 0xFFFFFFFFu) {
+            k = rem;
+            if constexpr (WM == 1) { atomicOr(&hnew[h >> 5], 1u << (h & 31u)); atomicAdd(&htouch[HT / 32], 1u); }
+            if constexpr (WM == 2) atomicAdd(&htouch[HT / 32], 1u);
+        }
+        return k;
+    };
+#ifdef SG_K1B_PROBE_R5                                                    /* (round 5's form, for a same-box A/B of two builds) */
     auto add_narrow2 = [&](u32 lo0, u32 hi0, u32 lo1, u32 hi1, bool second) {
         const u32 rem0 = hi0 & rbmask, rem1 = hi1 & rbmask;
         const bool a0 = mine(rem0) && !SG_ABL(d, 0x10u), a1 = second && mine(rem1) && !SG_ABL(d, 0x10u);
@@ -590,6 +593,38 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         if (a0) apply_narrow(lo0, hi0, k0 == rem0 ? h0 : slot_of(rem0));
         if (a1) apply_narrow(lo1, hi1, k1 == rem1 ? h1 : slot_of(rem1));
     };
+#else
+    // Round 6 (late): the two records walk their probe chains in ONE loop whose branches are wave-uniform (a ballot decides; a lane that has
+    // arrived re-reads its slot), so the lanes' state lives in scalar masks and the exec mask is not rebuilt every trip.  Measured against
+    // round 5's per-record loop on one box (profiles/r06_probe_ab_c3.txt, v0..v4): the launch takes the same 97-99 us either way — 25.3 M
+    // vector wave-instructions per launch in both forms, 15.6 M scalar ones instead of 18.7 M, twice the LDS bank-conflict cycles
+    // (profiles/r06_pair_k1_sq_counters_c3.txt against r06_final_*).  Kept for its registers (48 with the rolling buffer below, 59 before).
+    // What the experiment settled: the merge is bound neither by its probe chains nor by the LDS atomic unit (tools/lds_atomic_probe: a
+    // record's four operations run at 1.5 records per clock and CU on a table like this one, four times what pass B needs) nor by its loads
+    // (the rolling buffer changed nothing), and one table per partition (SG_SPLIT=1: every lane busy, half the waves) takes the same time too;
+    // the vector unit is three quarters busy while two workgroups share a CU, and the launch is two rounds of such workgroups plus a tail
+    // in which the CUs' last workgroups run alone (tools/stamps.py, profiles/r06_blockorder_stamps_c3.txt).
+    auto add_narrow2 = [&](u32 lo0, u32 hi0, u32 lo1, u32 hi1, bool second) {
+        const u32 rem0 = hi0 & rbmask, rem1 = hi1 & rbmask;
+        const bool a0 = mine(rem0) && !SG_ABL(d, 0x10u), a1 = second && mine(rem1) && !SG_ABL(d, 0x10u);
+        u32 h0 = rem0 & hmask, h1 = rem1 & hmask;
+        u32 k0 = lds_fresh_u32(&hkey[h0]), k1 = lds_fresh_u32(&hkey[h1]);
+        bool s0 = a0, s1 = a1;                                       // still looking
+        for (u32 left = HT;;) {
+            const bool e0 = s0 && k0 == 0xFFFFFFFFu, e1 = s1 && k1 == 0xFFFFFFFFu;
+            if (__builtin_amdgcn_ballot_w64(e0 || e1)) {             // (rare on a warm window: a key the table lacks)
+                if (e0) k0 = claim(h0, rem0);
+                if (e1) k1 = claim(h1, rem1);
+            }
+            s0 = s0 && k0 != rem0; s1 = s1 && k1 != rem1;
+            if (!__builtin_amdgcn_ballot_w64(s0 || s1) || --left == 0) break;   // (left == 0: the table is full — what is still looking is dropped)
+            h0 = s0 ? (h0 + 1) & hmask : h0; h1 = s1 ? (h1 + 1) & hmask : h1;
+            k0 = lds_fresh_u32(&hkey[h0]); k1 = lds_fresh_u32(&hkey[h1]);
+        }
+        if (a0) apply_narrow(lo0, hi0, s0 ? HT : h0);
+        if (a1) apply_narrow(lo1, hi1, s1 ? HT : h1);
+    };
+#endif
     auto add_wide = [&](u32 rem, u64 a0, u64 a1, u64 a2, u64 a3) {
         if (!mine(rem)) return;
         const u32 h = slot_of(rem);
@@ -597,12 +632,16 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         atomicAdd(&hacc[h], a0); atomicAdd(&hacc[HT + h], a1); atomicMax(&hacc[2 * HT + h], a2); atomicAdd(&hacc[3 * HT + h], a3);
         if constexpr (WM == 1) { if (!(a0 & 0xFFFFFFFFull)) atomicOr(&htouch[h >> 5], 1u << (h & 31u)); }   // an edge-only record: the edge exists in this window with count 0
     };
+    u32 my_nn = 0;
     for (u32 w = w0; w < d.nwg; w += NT / LPP) {
         const uint2 h = empty ? make_uint2(0u, 0u) : (w == w0 ? h0 : d.hdr8[(size_t)p * d.nwg + w]);   // (no batch this window: the headers are the previous window's)
         const u32 nn = h.x < d.sn ? h.x : d.sn;
         if (!nn) continue;
         const uint4* pairs = reinterpret_cast<const uint4*>(piece8(d, p, w));
         const u32 npair = (nn + 1) >> 1, lastp = npair - 1;
+        if (SG_ABL(d, 0x100u) && sub == 0 && blockIdx.x < 4096) atomicAdd(&d.dbg[((size_t)1 * 4096 + blockIdx.x) * 8 + 6], (u64)nn);   // (tools/stamps.py: narrow records of the partition)
+        if (sub == 0) my_nn += nn;
+#ifdef SG_K1B_NO_PREFETCH                                                /* (round 5's form: a round's loads are waited for before its merges begin) */
         for (u32 r0 = sub; r0 < npair; r0 += LPP * U) {
             uint4 x[U];
             if (w == w0 && r0 == sub) {
@@ -615,13 +654,35 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const u32 r = r0 + u * LPP;
-#ifdef SG_K1B_ONE_PROBE                                                  /* (the one-record-at-a-time form, for a same-box A/B of two builds) */
-                if (r < npair) { add_narrow(x[u].x, x[u].y); if (2 * r + 1 < nn) add_narrow(x[u].z, x[u].w); }
-#else
                 if (r < npair) add_narrow2(x[u].x, x[u].y, x[u].z, x[u].w, 2 * r + 1 < nn);
-#endif
             }
         }
+#else
+        // a rolling buffer of U pairs: a slot is refilled with the pair the lane needs a round later as soon as its content has been taken —
+        // the load's round trip passes behind the merges of the other slots instead of in front of the round.  (Measured: no change in the
+        // launch's time — other waves already covered the wait —; kept because U = 2 in this form needs 48 registers where U = 4 needed 59.)
+        uint4 x[U];
+        if (w == w0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = xf[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) { const u32 r = sub + u * LPP; x[u] = pairs[r < npair ? r : lastp]; }
+        }
+        for (u32 r0 = sub; r0 < npair; r0 += LPP * U) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const u32 r = r0 + u * LPP, rn = r + LPP * U;
+                const uint4 c = x[u];
+                x[u] = pairs[rn < npair ? rn : lastp];
+                if (r < npair) add_narrow2(c.x, c.y, c.z, c.w, 2 * r + 1 < nn);
+            }
+        }
+#endif
+    }
+    if (sidx == 0 && d.k1b_cnt) {                                    // the partition's records, for the next window's order (one add per wave)
+        my_nn = wave_sum_u32(my_nn);
+        if ((t & 63u) == 0 && my_nn) atomicAdd(&d.k1b_cnt[p], my_nn);
     }
     __syncthreads();                                                 // every 32-bit max is in: 64-bit updates may follow
     SG_STAMP(d, 1, 3);

@@ -64,6 +64,45 @@ __global__ __launch_bounds__(1024) void kc_prepare(Dev d, u64 n_known, u64 n_lab
             d.ctr[C_HUB_ITEMS] = 0;                                  // ... and to the hub-block work list
         }
     }
+    // (a') pass B's order: the partitions by the records they held in the window before, largest first.  A window's keys are Zipf-distributed and
+    // so are its partitions (0.7 .. 1.5 x the mean at C3); pass B runs two rounds of workgroups per CU, and a large partition that starts late
+    // is the launch's tail.  Measured on one box (profiles/r06_order_ab.txt): pass B 94.5-95.3 us in this order, 97.8-99.5 in block order.  Whatever
+    // the counts are, the result is a permutation (within a size class the order is that of arrival: the rows do not depend on it).
+    if (d.narrow && d.k1b_order) {
+        // (a counting sort by 256 size classes: two LDS atomics per partition and one wave's scan — this kernel is one workgroup on the
+        // window's critical path; ranking every partition against every other cost it 14 us)
+        __shared__ __attribute__((aligned(16))) u32 hb[256];
+        __shared__ u32 cmax;
+        const u32 NP = d.np;                                         // (<= 2048: two partitions per thread at most)
+        if (t < 256) hb[t] = 0;
+        if (t == 0) cmax = 0;
+        __syncthreads();
+        u32 c[2] = {0u, 0u}, rk[2] = {0u, 0u}, cls[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 2; k++) { const u32 i = t + (u32)k * 1024u; if (i < NP) { c[k] = d.k1b_cnt[i]; d.k1b_cnt[i] = 0u; } }
+        { const u32 m = (u32)wave_max_u64((u64)(c[0] > c[1] ? c[0] : c[1])); if (lane == 0 && m) atomicMax(&cmax, m); }
+        __syncthreads();
+        const float scale = 255.0f / (float)(cmax ? cmax : 1u);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const u32 i = t + (u32)k * 1024u;
+            if (i < NP) { const u32 q = (u32)((float)c[k] * scale); cls[k] = 255u - (q < 255u ? q : 255u); rk[k] = atomicAdd(&hb[cls[k]], 1u); }
+        }
+        __syncthreads();
+        if (wave == 0) {                                             // class sizes -> first positions (four classes per lane)
+            const uint4 v = reinterpret_cast<const uint4*>(hb)[lane];
+            const u32 sum = v.x + v.y + v.z + v.w;
+            u32 incl = sum;
+            incl += dpp32<0x111>(incl); incl += dpp32<0x112>(incl); incl += dpp32<0x114>(incl); incl += dpp32<0x118>(incl);
+            const u32 r0 = rdlane32(incl, 15), r1 = rdlane32(incl, 31), r2 = rdlane32(incl, 47);
+            incl += (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
+            const u32 ex = incl - sum;
+            reinterpret_cast<uint4*>(hb)[lane] = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; k++) { const u32 i = t + (u32)k * 1024u; if (i < NP) d.k1b_order[hb[cls[k]] + rk[k]] = i; }
+    }
     // (b)
     u32 n;
     if (collect == 1) {

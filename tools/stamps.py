@@ -52,6 +52,21 @@ for kid, kname in zip((0, 1), g.k1_kernels()):
         print("  starts on six CUs:", {k: first[k] for k in ks})
         nth = np.array([[v[j] if len(v) > j else np.nan for j in range(4)] for v in first.values()])
         print("  n-th workgroup on its CU starts at (mean us):", np.round(np.nanmean(nth, axis=0), 1), " workgroups per CU min/max:", min(len(v) for v in first.values()), max(len(v) for v in first.values()))
+    if kid == 1 and a[:, 7].max() > 0:
+        # per CU: when its last workgroup ends, how long its slots sit empty; by order of arrival on the CU: duration; the longest workgroups
+        dur = en_ - st_; cus = {}
+        for i in np.argsort(st_): cus.setdefault(int(cu[i]), []).append(i)
+        last_end = np.array([max(en_[i] for i in v) for v in cus.values()]); busy = np.array([sum(dur[i] for i in v) for v in cus.values()])
+        print("  per CU: last end percentiles 0/10/50/90/100:", np.round(np.percentile(last_end, [0, 10, 50, 90, 100]), 1), " sum of workgroup durations 10/50/90:", np.round(np.percentile(busy, [10, 50, 90]), 1))
+        byord = [[dur[v[j]] for v in cus.values() if len(v) > j] for j in range(4)]
+        print("  duration of the n-th workgroup on its CU (mean us):", [round(float(np.mean(x)), 1) if x else None for x in byord])
+        rec = a[:, 6].astype(np.float64)
+        if rec.max() > 0:
+            print("  narrow records per workgroup min/mean/max:", int(rec.min()), round(float(rec.mean())), int(rec.max()), " corr(duration, records):", round(float(np.corrcoef(dur, rec)[0, 1]), 3))
+            ph = (a[:, 3] - a[:, 1]) / 100.0
+            print("  merge phase us vs records, by record-count quintile:", [(int(rec[q].mean()), round(float(ph[q].mean()), 1)) for q in np.array_split(np.argsort(rec), 5)])
+        top = np.argsort(-dur)[:8]
+        print("  longest workgroups (block, start, phases header/merge/wide/out, records):", [(int(np.flatnonzero(live)[i]), round(float(st_[i]), 1), [round(float((a[i, k2] - a[i, k1]) / 100.0), 1) for k1, k2 in ((0, 1), (1, 3), (3, 4), (4, 5))], int(rec[i])) for i in top])
     ts = np.arange(0, en_.max(), 10.0)
     print("  workgroups running at t =", {int(t): int(((st_ <= t) & (en_ > t)).sum()) for t in ts})
 if st[2][:, 0].max() > 0:                                            # kw_compact (warm windows): start, loads in + ballots, look-back done, written + folded, row pointers + barrier, flushed
