@@ -540,38 +540,6 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
     if constexpr (WM == 1) { have_keys = wave_sum_u32(have_keys); if ((t & 63u) == 0 && have_keys) atomicAdd(nkeys, have_keys); }   // (read at the end, behind barriers)
     SG_STAMP(d, 1, 1);
 
-#ifdef SG_K1B_BUCKET4
-    // The table as HT / 4 buckets of four slots: a key's home is bucket rem % (HT / 4), a probe reads a whole bucket (one ds_read_b128), a key
-    // goes to the FIRST empty slot of the first bucket of its sequence that has one.  A slot never changes once it holds a key and the slots
-    // of a bucket fill in order, so two lanes that insert the same key race for the same slot (the CAS settles it) and a reader that finds an
-    // empty slot in a bucket without its key knows the key is absent.  At this load (0.48) the longest chain among a wave's 128 lookups is
-    // 2.2 buckets instead of 6.9 slots — and every lane of a wave walks the loop as long as the longest chain.
-    typedef u32 k4_t __attribute__((ext_vector_type(4)));
-    const u32 bmask4 = (HT >> 2) - 1u;
-    auto read4 = [&](u32 b) -> k4_t { return *reinterpret_cast<const volatile k4_t*>(hkey + 4u * b); };
-    auto has_key = [](const k4_t k, u32 rem) -> bool { const u32 a = k.x ^ rem, b = k.y ^ rem, c = k.z ^ rem, e = k.w ^ rem; const u32 m = a < b ? a : b, n = c < e ? c : e; return (m < n ? m : n) == 0u; };
-    auto has_empty = [](const k4_t k) -> bool { const u32 m = k.x > k.y ? k.x : k.y, n = k.z > k.w ? k.z : k.w; return (m > n ? m : n) == 0xFFFFFFFFu; };
-    auto pick = [](const k4_t k, u32 rem) -> u32 { return k.x == rem ? 0u : (k.y == rem ? 1u : (k.z == rem ? 2u : 3u)); };
-    // bucket b, read as k, has an empty slot and lacks rem: try to take its first empty slot (the caller reads the bucket again either way)
-    auto claim4 = [&](u32 b, const k4_t k, u32 rem) {
-        const u32 h = 4u * b + pick(k, 0xFFFFFFFFu);
-        if (atomicCAS(&hkey[h], 0xFFFFFFFFu, rem) == 0xFFFFFFFFu) {
-            if constexpr (WM == 1) { atomicOr(&hnew[h >> 5], 1u << (h & 31u)); atomicAdd(&htouch[HT / 32], 1u); }   // a key the kept set lacks: a NEW edge of this window (delta, below)
-            if constexpr (WM == 2) atomicAdd(&htouch[HT / 32], 1u);   // keys in the table (the union phase fills what room is left)
-        }
-    };
-    // slot of a key (find or insert), or HT when the table is full
-    auto slot_of = [&](u32 rem) -> u32 {
-        u32 b = rem & bmask4;
-        for (u32 it = 0; it < 2u * HT; it++) {
-            const k4_t k = read4(b);
-            if (has_key(k, rem)) return 4u * b + pick(k, rem);
-            if (has_empty(k)) { claim4(b, k, rem); continue; }
-            b = (b + 1u) & bmask4;
-        }
-        return HT;
-    };
-#else
     // slot of a key (find or insert), or HT when the table is full
     auto slot_of = [&](u32 rem) -> u32 {
         u32 h = rem & hmask;
@@ -590,7 +558,6 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         }
         return HT;
     };
-#endif
     auto mine = [&](u32 rem) -> bool { return S == 1 || ((rem >> sbit) & 1u) == sidx; };
     u32* hacc32 = reinterpret_cast<u32*>(hacc);                       // low word of accumulator j of slot h: 2 * (j*HT + h)
     // (measured on one box each: both sums as 32-bit words with a carry, 125.6-130.0 vs 121.3-129.3 us; reading the maximum first and
@@ -617,27 +584,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
         }
         return k;
     };
-#ifdef SG_K1B_BUCKET4
-    auto add_narrow2 = [&](u32 lo0, u32 hi0, u32 lo1, u32 hi1, bool second) {
-        const u32 rem0 = hi0 & rbmask, rem1 = hi1 & rbmask;
-        const bool a0 = mine(rem0) && !SG_ABL(d, 0x10u), a1 = second && mine(rem1) && !SG_ABL(d, 0x10u);
-        u32 b0 = rem0 & bmask4, b1 = rem1 & bmask4;
-        k4_t k0 = read4(b0), k1 = read4(b1);
-        bool s0 = a0, s1 = a1;                                       // still looking
-        for (u32 left = 2u * HT;;) {                                 // (every branch wave-uniform: a ballot decides; a lane that has arrived re-reads its bucket)
-            s0 = s0 && !has_key(k0, rem0); s1 = s1 && !has_key(k1, rem1);
-            if (!__builtin_amdgcn_ballot_w64(s0 || s1) || --left == 0) break;   // (left == 0: the table is full — what is still looking is dropped)
-            const bool e0 = s0 && has_empty(k0), e1 = s1 && has_empty(k1);
-            if (__builtin_amdgcn_ballot_w64(e0 || e1)) {             // (rare on a warm window: a key the table lacks) take a slot, look at the bucket again
-                if (e0) claim4(b0, k0, rem0);
-                if (e1) claim4(b1, k1, rem1);
-            } else { b0 = s0 ? (b0 + 1u) & bmask4 : b0; b1 = s1 ? (b1 + 1u) & bmask4 : b1; }
-            k0 = read4(b0); k1 = read4(b1);
-        }
-        if (a0) apply_narrow(lo0, hi0, s0 ? HT : 4u * b0 + pick(k0, rem0));
-        if (a1) apply_narrow(lo1, hi1, s1 ? HT : 4u * b1 + pick(k1, rem1));
-    };
-#elif defined(SG_K1B_PROBE_R5)                                            /* (round 5's form, for a same-box A/B of two builds) */
+#ifdef SG_K1B_PROBE_R5                                            /* (round 5's form, for a same-box A/B of two builds) */
     auto add_narrow2 = [&](u32 lo0, u32 hi0, u32 lo1, u32 hi1, bool second) {
         const u32 rem0 = hi0 & rbmask, rem1 = hi1 & rbmask;
         const bool a0 = mine(rem0) && !SG_ABL(d, 0x10u), a1 = second && mine(rem1) && !SG_ABL(d, 0x10u);
@@ -672,7 +619,7 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
             s0 = s0 && k0 != rem0; s1 = s1 && k1 != rem1;
             if (!__builtin_amdgcn_ballot_w64(s0 || s1) || --left == 0) break;   // (left == 0: the table is full — what is still looking is dropped)
             h0 = s0 ? (h0 + 1) & hmask : h0; h1 = s1 ? (h1 + 1) & hmask : h1;
-            k0 = lds_fresh_u32(&hkey[h0]); k1 = lds_fresh_u32(&hkey[h1]);
+            k0 = lds_fresh_u32(&hkey[h0]); k1 = lds_fresh_u32(&hkey[h1]);   // (reads by the lanes still looking only, under exec masks: measured, no difference)
         }
         if (a0) apply_narrow(lo0, hi0, s0 ? HT : h0);
         if (a1) apply_narrow(lo1, hi1, s1 ? HT : h1);
@@ -789,23 +736,6 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
                 const u32 rem = old[k2];
                 if (rem == 0xFFFFFFFFu) continue;
                 bool have = false, room = false;
-#ifdef SG_K1B_BUCKET4
-                u32 b = rem & bmask4;
-                for (u32 it = 0; it < 2u * HT; it++) {
-                    const k4_t k = read4(b);
-                    if (has_key(k, rem)) { have = true; break; }     // (a record of this window has it)
-                    if (has_empty(k)) {
-                        if (!room) {                                 // absent so far: take one of the output's free places, or leave the key behind
-                            if (atomicAdd(&htouch[HT / 32], 1u) >= d.pcap) { atomicSub(&htouch[HT / 32], 1u); break; }
-                            room = true;
-                        }
-                        const u32 h = 4u * b + pick(k, 0xFFFFFFFFu);
-                        if (atomicCAS(&hkey[h], 0xFFFFFFFFu, rem) == 0xFFFFFFFFu) { atomicOr(&htouch[h >> 5], 1u << (h & 31u)); have = true; break; }   // in, marked "not of this window"
-                        continue;                                    // (someone else's key took the slot: look at the bucket again)
-                    }
-                    b = (b + 1u) & bmask4;
-                }
-#else
                 u32 h = rem & hmask;
                 for (u32 it = 0; it < HT; it++) {
                     u32 k = lds_fresh_u32(&hkey[h]);
@@ -820,7 +750,6 @@ __device__ __forceinline__ void k1b8_body(const Dev& d) {
                     if (k == rem) { have = true; break; }            // (a record of this window has it)
                     h = (h + 1) & hmask;
                 }
-#endif
                 if (room && !have) atomicSub(&htouch[HT / 32], 1u);  // (the table itself was full)
             }
         }
