@@ -407,6 +407,47 @@ def test_config3_graph_three_windows_the_engines_own_rule_warm_equals_cold():
     a.close(); b.close()
 
 
+def test_config3_graph_linearity_across_warm_windows_the_union_of_two_traces_adds_up():
+    """A size-independent property at BASELINE config 3's graph, on the warm path (round 6: pass B takes the partitions in the order of their
+    size in the window before — the three windows here have different sizes and different large partitions): window(A), window(B),
+    window(A then B in one window).  Per edge, count / error count / latency sum / sum of squares of the union are the sums of the two
+    windows' and the maximum is their maximum; an edge is in the union's rows iff it is in A's or B's.  Integer, exact."""
+    topo = replay.make_topology(10_000, 1_000_000, replay.SEED_BASE + 3)
+    A, labels = replay.make_events(topo, 3_000_000, replay.SEED_BASE + 3)
+    B, _ = replay.make_events(topo, 2_000_000, replay.SEED_BASE + 78)
+    from alaz_amd import engine
+    g = engine.ServiceGraph(max_known_nodes=topo.n_nodes, max_edges=1_250_000, layers=2, max_labels=128, max_outbound_ips=128,
+                            max_window_events=len(A) + len(B), max_batch=1 << 20)
+    g.set_clock(*CLOCK); g.load_weights(weights.make_weights(2))
+    for i in range(topo.n_pods): g.upsert_pod(int(topo.pod_ips[i]), i)
+    for j in range(topo.n_svcs): g.upsert_service(int(topo.svc_ips[j]), topo.n_pods + j)
+    g.set_label_count(128)
+    assert g.geometry()["warm_windows"] == 1 and g.geometry()["k1_narrow"] == 1
+    out = []
+    for ev in (A, B, np.concatenate([A, B]), A):
+        for i in range(0, len(ev), 1 << 20):
+            while g.ingest(ev[i:i + (1 << 20)]) != 0:
+                pass
+        out.append(g.flush_window().copy())
+    ra, rb, ru, ra2 = out
+    assert ra.tobytes() == ra2.tobytes()                     # (the first window was rebuilt, the last one closed warm)
+    key = lambda r: (r["from_ref"].astype(np.uint64) << np.uint64(32)) | r["to_ref"].astype(np.uint64)
+    ka, kb, ku = key(ra), key(rb), key(ru)
+    assert len(np.unique(ku)) == len(ku) and np.array_equal(np.sort(ku), np.union1d(ka, kb))
+    order = np.argsort(ku); ks = ku[order]
+    ia, ib = np.searchsorted(ks, ka), np.searchsorted(ks, kb)
+    for f in ("count", "err_count", "sum_ns", "sumsq_us"):
+        tot = np.zeros(len(ku), dtype=np.uint64)
+        np.add.at(tot, ia, ra[f].astype(np.uint64)); np.add.at(tot, ib, rb[f].astype(np.uint64))
+        assert np.array_equal(tot, ru[f][order].astype(np.uint64)), f
+    mx = np.zeros(len(ku), dtype=np.uint64)
+    np.maximum.at(mx, ia, ra["max_ns"]); np.maximum.at(mx, ib, rb["max_ns"])
+    assert np.array_equal(mx, ru["max_ns"][order])
+    st = g.stats()
+    assert st.windows_cold == 1 and st.windows_warm == 3 and st.events_dropped_cap == 0
+    g.close()
+
+
 def test_kept_set_beyond_the_resident_chunks_compaction_ordered_by_ticket():
     """2 M kept edges = 977 chunks of `kw_compact`, more than are certainly resident at once (768): its workgroups take their chunk by ticket,
     so that a chunk only ever waits for chunks that have started (the look-back of k2_rowptr beyond 256 workgroups).  One request per edge of
