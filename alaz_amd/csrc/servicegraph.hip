@@ -110,6 +110,7 @@ struct sg_engine {
     bool warm_on = true;                      // sg_set_warm
     u32 cold_streak = 0;                      // consecutive windows whose warm attempt met an unknown key (C_COLD = 2), by the device's note
     u32 kw_epoch = 0;                         // kw_compact launch counter (tags its look-back words)
+    u32 in_fused_slices = 0;                  // != 0 between a one-call pipeline's close and its features: the features sum k3_in_part's partials (k3_in_reduce was not launched)
     u64 closes = 0; u32 timing_stride = 1;    // windows closed so far; the dispatch stamps of K1 (groups 1 and 7) are taken on every timing_stride-th window
     u32 obip_streak = 0; u64 plain_left = 0;  // windows in a row that raw outbound IPs kept cold (same note); windows still to be closed without the kept-CSR detour
     std::vector<char> plain_slot;             // per window slot: its last close was such a plain one (not counted as warm or cold)
@@ -442,7 +443,7 @@ void launch_halo_lists(sg_engine* e, hipStream_t s, u32* req, u32 capp) {
 }
 // ob_mode 1: collect this engine's own raw outbound IPs; 0: caller's union list (d_union, *d_union_n);
 // 2: all-gathered per-shard lists (d_union = [world][stride], element 0 of a row = count)
-int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union_n, u32 ob_mode = 1, u32 stride = 0, u32 gworld = 0) {
+int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union_n, u32 ob_mode = 1, u32 stride = 0, u32 gworld = 0, bool fuse_in = false) {
     int rc = sync_tables(e, s);
     if (rc) return rc;
     // When the kept state does not pay, the window is closed as an engine without it does ("plain": the kept state stays as it is, these
@@ -553,8 +554,18 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
     {
         Timed t3(e, s, 8);                                   // group 8 = in-statistics (group 3 = node + edge features)
         const u32 fin = d.warm ? (u32)std::min<u64>(64, ((u64)d.ncap + 255) / 256) : 1u;   // finishing workgroups: the block-sorted rows (1), every row of a warm window
-        hipLaunchKernelGGL(k3_in_part, dim3(e->k3_ranges * e->k3_slices), dim3(1024), e->k3in_lds, s, d, e->k3_slices);
-        hipLaunchKernelGGL(k3_in_reduce, dim3(grid_for((u64)d.ncap * 6, 256, 1024) + fin), dim3(256), 0, s, d, e->k3_slices, fin);
+        const bool no_fuse = sg_knob("SG_K3_NO_FUSE") != nullptr;      // (development build: the two-launch form beside the fused one on one box)
+        if (fuse_in && !no_fuse) {
+            // the one-call pipelines (nothing reads the in-statistics between the close and the features): the features sum the partials, the
+            // finishing work rides at the end of k3_in_part's launch — fifteen launches per window instead of sixteen
+            const u32 finp = d.warm ? (fin + 3) / 4 : 1u;        // (1024-thread workgroups there)
+            hipLaunchKernelGGL(k3_in_part, dim3(e->k3_ranges * e->k3_slices + finp), dim3(1024), e->k3in_lds, s, d, e->k3_slices, finp);
+            e->in_fused_slices = e->k3_slices;
+        } else {
+            hipLaunchKernelGGL(k3_in_part, dim3(e->k3_ranges * e->k3_slices), dim3(1024), e->k3in_lds, s, d, e->k3_slices, 0u);
+            hipLaunchKernelGGL(k3_in_reduce, dim3(grid_for((u64)d.ncap * 6, 256, 1024) + fin), dim3(256), 0, s, d, e->k3_slices, fin);
+            e->in_fused_slices = 0;
+        }
     }
     HIP_TRY(e, hipGetLastError());
     e->closed = true;
@@ -567,7 +578,8 @@ int do_features(sg_engine* e, hipStream_t s) {
     const Dev& d = e->d;
     Timed t(e, s, 3);
     const int nbn = grid_for(d.ncap, 128), nbe = grid_for(e->cfg.max_edges, 256, 4096);
-    hipLaunchKernelGGL(k3_node_features, dim3(nbn + nbe), dim3(256), 0, s, d, (u32)nbn);
+    hipLaunchKernelGGL(k3_node_features, dim3(nbn + nbe), dim3(256), 0, s, d, (u32)nbn, e->in_fused_slices);
+    e->in_fused_slices = 0;
     HIP_TRY(e, hipGetLastError());
     return SG_OK;
 }
@@ -1422,7 +1434,7 @@ int flush_begin_locked(sg_engine* e, std::unique_lock<std::mutex>& g) {
     struct Open { sg_engine* e; ~Open() { e->closing = false; e->cv.notify_all(); } } open{e};
     hipStream_t s = e->stream;
     int rc;
-    if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
+    if ((rc = do_close(e, s, nullptr, nullptr, 1u, 0u, 0u, true))) return rc;
     if ((rc = do_features(e, s))) return rc;
     for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
     bool did = false;
@@ -1684,7 +1696,7 @@ int sg_window_run(sg_handle e, void* stream) {
     e->cv.wait(g, [&] { return e->pending_copies == 0; });
     hipStream_t s = pick(e, stream);
     int rc;
-    if ((rc = do_close(e, s, nullptr, nullptr, 1u))) return rc;
+    if ((rc = do_close(e, s, nullptr, nullptr, 1u, 0u, 0u, true))) return rc;
     if ((rc = do_features(e, s))) return rc;
     for (u32 l = 0; l < e->cfg.layers; l++) if ((rc = do_layer(e, l, s, true))) return rc;
     bool did = false;

@@ -41,10 +41,18 @@ __device__ __forceinline__ void alive_mark(const Dev& d, u32 g, u32 G, u32 t) {
     }
 }
 
-__global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S) {
+// fin (the one-call pipelines, whose node features sum the slices' partials themselves — k3_node_features — so that k3_in_reduce is not
+// launched): the launch's LAST fin workgroups do what k3_in_reduce's last ones do in the staged pipelines — finish the rows behind
+// kw_compact (degree, mean / deviation, hub work items), or the block-sorted rows of an engine without the kept state.
+__global__ __launch_bounds__(1024) void k3_in_part(Dev d, u32 S, u32 fin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 E = (u32)d.ctr[C_N_EDGES], N = (u32)d.ctr[C_N_NODES];
-    const u32 G = gridDim.x, g = blockIdx.x, t = threadIdx.x;
+    const u32 G = gridDim.x - fin, g = blockIdx.x, t = threadIdx.x;
+    if (g >= G) {
+        if (d.warm) kw_finish_rows(d, (g - G) * 1024 + t, fin * 1024);
+        else if (g == gridDim.x - 1) k2_split_finish(d, t, 1024);
+        return;
+    }
     SG_STAMP(d, 3, 0);
     // a delta window's kw_compact (the launch before this one) has written the kept CSR, grown by the window's new edges, to the other
     // buffer: flip (nothing in this launch reads the kept state; the next window's pass B and kw_compact do)
@@ -140,7 +148,9 @@ __global__ __launch_bounds__(256) void k3_in_reduce(Dev d, u32 S, u32 fin) {
 // Two lanes per node: lane 0 of the pair turns the out-side statistics into features, lane 1 the
 // in-side ones (the fp64 log1p / sqrt chains are the whole cost of this kernel), then they swap.
 // Workgroups [0, nb_nodes) do the nodes; the rest do the edge features (one thread per edge, edge_features()).
-__global__ __launch_bounds__(256) void k3_node_features(Dev d, u32 nb_nodes) {
+// S_in != 0 (the one-call pipelines): the in-side lane of a node sums the S_in slices' partials of k3_in_part itself (and leaves the sums in
+// st_sum / st_max, where the staged pipelines' k3_in_reduce puts them) — one launch and a 24 MB round trip less per window.
+__global__ __launch_bounds__(256) void k3_node_features(Dev d, u32 nb_nodes, u32 S_in) {
     if (blockIdx.x >= nb_nodes) {
         const u32 E = (u32)d.ctr[C_N_EDGES];
         for (u32 p = (blockIdx.x - nb_nodes) * 256 + threadIdx.x; p < E; p += (gridDim.x - nb_nodes) * 256) edge_features(d, p);
@@ -153,9 +163,30 @@ __global__ __launch_bounds__(256) void k3_node_features(Dev d, u32 nb_nodes) {
         const bool live = v < N;
         float a[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (live) {
-            const u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
-            const u64 dg = s[ST_OUT_DEG + side], c = s[ST_OUT_CNT + side], er = s[ST_OUT_ERR + side], sm = s[ST_OUT_SUM + side], sq = s[ST_OUT_SSQ + side];
-            const u64 mx = d.st_max[(size_t)v * 2 + side];
+            u64* s = d.st_sum + (size_t)v * SG_NODE_STAT_SUM_WORDS;
+            u64 dg, c, er, sm, sq, mx;
+            if (S_in && side) {                                      // deg, cnt, err, sum, ssq, max of the node's in-edges: over the slices (integer: order-free)
+                const u32 r = v / K3_IN_NR;
+                const ulonglong2* p = reinterpret_cast<const ulonglong2*>(d.in_part + ((size_t)r * S_in * K3_IN_NR + (v - r * K3_IN_NR)) * 6);
+                const size_t st = (size_t)K3_IN_NR * 3;              // (16-byte words per slice)
+                dg = c = er = sm = sq = mx = 0;
+                u32 sl = 0;
+                for (; sl + 4 <= S_in; sl += 4) {                    // twelve independent loads in flight
+                    ulonglong2 x[4][3];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { x[q][0] = p[(size_t)(sl + q) * st]; x[q][1] = p[(size_t)(sl + q) * st + 1]; x[q][2] = p[(size_t)(sl + q) * st + 2]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { dg += x[q][0].x; c += x[q][0].y; er += x[q][1].x; sm += x[q][1].y; sq += x[q][2].x; mx = x[q][2].y > mx ? x[q][2].y : mx; }
+                }
+                for (; sl < S_in; sl++) {
+                    const ulonglong2 a0 = p[(size_t)sl * st], a1 = p[(size_t)sl * st + 1], a2 = p[(size_t)sl * st + 2];
+                    dg += a0.x; c += a0.y; er += a1.x; sm += a1.y; sq += a2.x; mx = a2.y > mx ? a2.y : mx;
+                }
+                s[ST_IN_DEG] = dg; s[ST_IN_CNT] = c; s[ST_IN_ERR] = er; s[ST_IN_SUM] = sm; s[ST_IN_SSQ] = sq; d.st_max[(size_t)v * 2 + 1] = mx;
+            } else {
+                dg = s[ST_OUT_DEG + side]; c = s[ST_OUT_CNT + side]; er = s[ST_OUT_ERR + side]; sm = s[ST_OUT_SUM + side]; sq = s[ST_OUT_SSQ + side];
+                mx = d.st_max[(size_t)v * 2 + side];
+            }
             a[0] = (float)log1p((double)dg);
             a[1] = (float)log1p((double)c);
             a[2] = (float)log1p(mean_us(sm, c) / 1000.0);
