@@ -25,6 +25,24 @@ __device__ __forceinline__ f32x4 dense_tile_mfma(const float* A, int lda, const 
     return c;
 }
 
+// The same tile with the B operands fetched up front: dense_tile_load_b issues the lane's K / 4 loads of W together (ONE round trip, and
+// none of it depends on the tile's rows, so k4_sage_layer issues them before its phase 1), dense_tile_mfma_pre runs the chain — the same
+// MFMAs in the same k order.  (dense_tile_mfma waits for its loads four at a time: K / 16 dependent round trips per call — eight for a
+// 64-feature layer, four more for the projection: most of what the dense launches took.)
+template <int K>
+__device__ __forceinline__ void dense_tile_load_b(const float* __restrict__ W, int jb, float (&b)[K / 4]) {
+    const int l = threadIdx.x & 63, i = l & 15, kq = l >> 4;
+#pragma unroll
+    for (int kb = 0; kb < K / 4; kb++) b[kb] = W[(size_t)(kb * 4 + kq) * SG_F_HID + jb + i];
+}
+template <int K>
+__device__ __forceinline__ f32x4 dense_tile_mfma_pre(const float* A, int lda, const float (&b)[K / 4], f32x4 c) {
+    const int l = threadIdx.x & 63, i = l & 15, kq = l >> 4;
+#pragma unroll
+    for (int kb = 0; kb < K / 4; kb++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i * lda + kb * 4 + kq], b[kb], c, 0, 0, 0);
+    return c;
+}
+
 // gather-mean of one node into dst[0..FI): executed by one wave.  Neighbour ids are fetched 64 at a
 // time (one coalesced load) and broadcast by shuffle, so the 8 / 16 row loads of an unrolled step
 // are independent and in flight together.  Summation order is the canonical one (slot = i % 16).
@@ -232,6 +250,17 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
     constexpr int WIDE = FI == 32 ? 8 : (NT <= 512 ? 16 : 0);
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* __restrict__ bias = Wl + 2 * FI * SG_F_HID;
+    // (MFMA build: the weights of the wave's 16 columns — and of its share of the projection — are fetched once, ahead of the first tile's rows)
+    float bw[USE_MFMA ? 2 * FI / 4 : 1], bpj[USE_MFMA && PROJ ? SG_F_HID / 4 : 1];
+    float bj0 = 0.0f, bj1 = 0.0f;
+    if constexpr (USE_MFMA) {
+        if (wave < 4) { dense_tile_load_b<2 * FI>(Wl, (int)wave * 16, bw); bj0 = bias[wave * 16 + (lane & 15)]; }
+        if constexpr (PROJ) if (wave < 8) {
+            const float* __restrict__ Wu = Wh; const float* __restrict__ Wv = Wh + SG_F_HID * SG_F_HID;
+            dense_tile_load_b<SG_F_HID>(wave >= 4 ? Wv : Wu, (int)(wave & 3) * 16, bpj);
+            bj1 = wave >= 4 ? 0.0f : (Wv + SG_F_HID * SG_F_HID + SG_F_EDGE * SG_F_HID)[(wave & 3) * 16 + (lane & 15)];
+        }
+    }
     for (u32 tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
         const u32 v0 = tile * 16;
         for (u32 r = wave; r < 16; r += NW) {   // phase 1: self row + gather-mean, one wave per tile row
@@ -244,27 +273,42 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
             float* row = A + r * LDA;
             u32 deg = 0;
             if (sk) { for (u32 k = lane; k < 2 * FI; k += 64) row[k] = 0.0f; }
-            else {
+            else if constexpr (PRE) {
+                static_assert(!PRE || FI <= 64, "one element of the self row and of the mean per lane");
+                // The row's five loads — its self element, its two row pointers, its element of the mean, its first work item — are issued
+                // TOGETHER, whatever the degree turns out to be (every address is valid; lanes beyond FI read element 0): one round trip per
+                // row where the mean behind the degree and the work item behind the comparison were trips of their own; a hub row's block
+                // sums eight at a time (a load behind every addition: nine dependent trips for a row of 3 750 edges, and the tile with such
+                // a row was the launch's tail).
+                const u32 kl = lane < (u32)FI ? lane : 0u;
+                const float xs = hin[(size_t)v * FI + kl];
+                const u32 beg = d.rowptr[v], end = d.rowptr[v + 1];
+                const float xm = d.nmean[(size_t)v * SG_F_HID + kl];
+                const u32 ib = d.hub_base[v];
+                const u32 dg = end - beg;
+                float mean = dg ? xm : 0.0f;
+                if (dg > SG_MEAN_BLOCK) {                            // a hub row: its block sums (k4_gather's work items) in block order, one division
+                    const u32 nblk = (dg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK;
+                    float total = 0.0f;
+                    for (u32 j0 = 0; j0 < nblk; j0 += 8) {
+                        float x[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) x[q] = d.hub_part[(size_t)(ib + (j0 + q < nblk ? j0 + q : nblk - 1)) * SG_F_HID + kl];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) if (j0 + q < nblk) total = (j0 + q) ? total + x[q] : x[q];
+                    }
+                    mean = total / (float)dg;
+                }
+                if (lane < (u32)FI) { row[lane] = xs; row[FI + lane] = mean; }
+            } else {
                 for (u32 k = lane; k < FI; k += 64) row[k] = hin[(size_t)v * FI + k];
                 const u32 beg = d.rowptr[v];
                 deg = d.rowptr[v + 1] - beg;
-                if constexpr (PRE) {
-                    if (deg > SG_MEAN_BLOCK) {                       // a hub row: its block sums (k4_gather's work items) in block order, one division
-                        const u32 nblk = (deg + SG_MEAN_BLOCK - 1) / SG_MEAN_BLOCK, ib = d.hub_base[v];
-                        for (u32 k = lane; k < FI; k += 64) {
-                            float total = d.hub_part[(size_t)ib * SG_F_HID + k];
-                            for (u32 j = 1; j < nblk; j++) total = total + d.hub_part[(size_t)(ib + j) * SG_F_HID + k];
-                            row[FI + k] = total / (float)deg;
-                        }
-                    } else for (u32 k = lane; k < FI; k += 64) row[FI + k] = deg ? d.nmean[(size_t)v * SG_F_HID + k] : 0.0f;
-                    deg = 0;                                         // (nothing left for the hub loop)
-                } else {
                 // block 0 here (one wave per row, all rows at once); the further blocks of a hub row below
                 if (deg) gather_block_sum<FI, WIDE>(hin, d.col + beg, 0, deg < SG_MEAN_BLOCK ? deg : SG_MEAN_BLOCK, row + FI);
                 if (lane < FI) {                                     // (same wave wrote row[FI..): ordered by the LDS counter)
                     const float t = deg ? row[FI + lane] : 0.0f;
                     row[FI + lane] = deg > SG_MEAN_BLOCK ? t : (deg ? t / (float)deg : 0.0f);
-                }
                 }
             }
             if (lane == 0) { skip[r] = sk ? 1u : 0u; vid[r] = v; tdeg[r] = deg; }
@@ -292,11 +336,10 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
         __syncthreads();
         // phase 2: dense 16 x 64 on waves 0..3, wave w -> columns 16w..16w+15
         if (wave < 4) {
-            if (USE_MFMA) {
+            if constexpr (USE_MFMA) {
                 const int jb = wave * 16, i = lane & 15;
-                const float bj = bias[jb + i];
-                f32x4 c = { bj, bj, bj, bj };
-                c = dense_tile_mfma<2 * FI>(A, LDA, Wl, jb, c);
+                f32x4 c = { bj0, bj0, bj0, bj0 };
+                c = dense_tile_mfma_pre<2 * FI>(A, LDA, bw, c);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const u32 row = (lane >> 4) * 4 + r;
@@ -322,7 +365,7 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
                 }
             }
         }
-        if (PROJ) {
+        if constexpr (PROJ) {
             __syncthreads();
             // waves 0..3 -> P columns, waves 4..7 -> Q columns
             const float* __restrict__ Wu = Wh; const float* __restrict__ Wv = Wh + SG_F_HID * SG_F_HID;
@@ -332,10 +375,9 @@ __global__ __launch_bounds__(NT) void k4_sage_layer(Dev d, const float* __restri
                 const int jb = (wave & 3) * 16, i = lane & 15;
                 float* dst = isq ? d.Q : d.P;
                 const float* __restrict__ Wm = isq ? Wv : Wu;
-                if (USE_MFMA) {
-                    const float bj = isq ? 0.0f : b1[jb + i];
-                    f32x4 c = { bj, bj, bj, bj };
-                    c = dense_tile_mfma<SG_F_HID>(H, LDH, Wm, jb, c);
+                if constexpr (USE_MFMA) {
+                    f32x4 c = { bj1, bj1, bj1, bj1 };
+                    c = dense_tile_mfma_pre<SG_F_HID>(H, LDH, bpj, c);
 #pragma unroll
                     for (int r = 0; r < 4; r++) { const u32 row = (lane >> 4) * 4 + r; if (v0 + row < N) dst[(size_t)(v0 + row) * SG_F_HID + SG_PQ_POS(jb + i)] = c[r]; }
                 } else {
