@@ -930,7 +930,11 @@ int sg_create(const sg_config* cfg, sg_handle* out) {
     d.emask = e->ecap - 1;
     d.alive_cap = cfg->max_alive ? cfg->max_alive : 65536u;
     e->k3_ranges = (d.ncap + K3_IN_NR - 1) / K3_IN_NR;
-    e->k3_slices = (u32)std::min<u64>(K3_IN_SMAX, std::max<u64>(8, ME / 8192));
+    // slices of the in-statistics' scan: 8 192 edges each at least; at most 48 where ranges x 48 workgroups (one per CU: 144 KiB of LDS) are ONE
+    // round of the chip — since the node features sum the partials themselves (k3_in_reduce is gone from the one-call pipelines) the shorter scan
+    // wins: same box, C3, K3-in + K3-feat 53.5-54.4 us at 32 slices, 49.6-49.8 at 48, 53.4 at 51 (profiles/r06_k3slices_ab_c3.txt) — else 32 (a
+    // config-5 shard's 49 ranges: more slices only add partials to write and read)
+    e->k3_slices = (u32)std::min<u64>((u64)e->k3_ranges * K3_IN_SMAX <= e->k1b_cus ? K3_IN_SMAX : 32, std::max<u64>(8, ME / 8192));
     if (const char* v = sg_knob("SG_K3_SLICES")) { const u64 x = std::strtoull(v, nullptr, 0); if (x >= 1 && x <= 256) e->k3_slices = (u32)x; }
     e->k3in_lds = (size_t)K3_IN_NR * 48;
     {   // the row sort's two LDS arrays: large enough for a bitmap of the node capacity when that fits (a config-5 shard: 150 k nodes = 4.7 k words)

@@ -12,7 +12,7 @@
 //   k3_in_reduce one thread per (node, word): sums (max for the last word) the slices' partials into st_sum / st_max.
 // Exact (integer sums and max are order-free) and deterministic.
 #define K3_IN_NR    3072      // nodes per range: 3072 x 6 x 8 B = 144 KiB of LDS
-#define K3_IN_SMAX  32        // edge slices at most
+#define K3_IN_SMAX  48        // edge slices at most (48 where ranges x 48 workgroups are one round of the chip, else 32: servicegraph.hip)
 // The window's open connections (SG_EV_ALIVE, f-2) are marked here too: every record's edge exists in
 // the CSR (K1 created it with count 0 if it carried no request); a binary search in the sorted row
 // finds it.  Costs one scalar load when the window has none.
