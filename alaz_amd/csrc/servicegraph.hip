@@ -577,7 +577,7 @@ int do_close(sg_engine* e, hipStream_t s, const u32* d_union, const u32* d_union
 int do_features(sg_engine* e, hipStream_t s) {
     const Dev& d = e->d;
     Timed t(e, s, 3);
-    const int nbn = grid_for(d.ncap, 128), nbe = grid_for(e->cfg.max_edges, 256, 4096);
+    const int nbn = grid_for(d.ncap, 128), nbe = grid_for(e->cfg.max_edges, 256, 4096);   // (the edge workgroups capped at 1 280 / 2 560 — whole rounds: no difference, profiles/r06_grids_ab_c3.txt)
     hipLaunchKernelGGL(k3_node_features, dim3(nbn + nbe), dim3(256), 0, s, d, (u32)nbn, e->in_fused_slices);
     e->in_fused_slices = 0;
     HIP_TRY(e, hipGetLastError());
@@ -625,8 +625,13 @@ int do_score(sg_engine* e, hipStream_t s, bool proj_done, bool fuse_reset, bool*
         else hipLaunchKernelGGL((k5_node_proj<false>), dim3(grid_for(d.ncap, 16)), dim3(256), 0, s, d, d.h[e->cfg.layers], Wh);
     }
     const bool fr = fuse_reset && d.variant == 0;
-    if (fr) hipLaunchKernelGGL(k5_edge_score<true>, dim3(grid_for(e->cfg.max_edges, 32)), dim3(256), 0, s, d, Wh);
-    else hipLaunchKernelGGL(k5_edge_score<false>, dim3(grid_for(e->cfg.max_edges, 32)), dim3(256), 0, s, d, Wh);
+    // ONE round of workgroups: the kernel runs 3 waves per SIMD (144 registers, amdgpu_waves_per_eu(3)) = 3 workgroups of 256 threads per CU at a
+    // time, and its waves stride over the edges — 2 048 workgroups were 2.67 rounds, the last one two-thirds empty.  Same box, C3, two
+    // repetitions: K5 61.1 us at 2 048, 61.7 at 1 024, 58.9 at 1 536, 57.8-57.9 at 768 (profiles/r06_grids_ab_c3.txt)
+    int g5 = grid_for(e->cfg.max_edges, 32, 3 * (int)e->k1b_cus);
+    if (const char* v = sg_knob("SG_K5_GRID")) { const int x = std::atoi(v); if (x >= 1 && x <= 65535) g5 = std::min(grid_for(e->cfg.max_edges, 32, 65535), x); }
+    if (fr) hipLaunchKernelGGL(k5_edge_score<true>, dim3(g5), dim3(256), 0, s, d, Wh);
+    else hipLaunchKernelGGL(k5_edge_score<false>, dim3(g5), dim3(256), 0, s, d, Wh);
     if (did_reset) *did_reset = fr;
     HIP_TRY(e, hipGetLastError());
     return SG_OK;

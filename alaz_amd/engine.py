@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("SG_LIB_PATH") or os.path.join(_HERE, "lib", "libservi
 LIB_DEV_PATH = os.path.join(_HERE, "lib", "libservicegraph_dev.so")
 #: the knobs the development build reads (servicegraph.hip sg_knob); ServiceGraph(dev_knobs=None) picks that build when one of them is set
 DEV_KNOBS = ("SG_ABLATE", "SG_NP", "SG_HT", "SG_CT", "SG_NWG", "SG_NSUB", "SG_SPLIT", "SG_WARM", "SG_K1A", "SG_K1_NARROW", "SG_K1_LEGACY", "SG_K1B_U",
-             "SG_K1B_THREADS", "SG_K1B_PACK", "SG_K1B_NO_ORDER", "SG_L2_GLOBAL", "SG_L2_U32", "SG_DH_G", "SG_K3_SLICES", "SG_K3_NO_FUSE", "SG_K4_FUSED", "SG_K6_ONE_WG", "SG_DENSE_VALU",
+             "SG_K1B_THREADS", "SG_K1B_PACK", "SG_K1B_NO_ORDER", "SG_L2_GLOBAL", "SG_L2_U32", "SG_DH_G", "SG_K3_SLICES", "SG_K3_NO_FUSE", "SG_K4_FUSED", "SG_K5_GRID", "SG_K6_ONE_WG", "SG_DENSE_VALU",
              "SG_COPY_STREAMS", "SG_STAGE_SLOTS", "SG_ARENA")
 
 SG_OK, SG_EINVAL, SG_ENOMEM, SG_ENODEV, SG_ENOSPC, SG_EAGAIN, SG_ESTATE = 0, -22, -12, -19, -28, -11, -71
