@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6 (late): k4_gather as resident workgroups striding over the tiles (4 per CU at its 4 waves per SIMD) instead of one workgroup per tile
 # of four rows (3 766 at C3); one box, the development build (SG_K4G_GRID caps the grid), two repetitions
+# (SG_K4G_GRID was a knob of the development build for this call only; slower, not in the tree)
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out; mkdir -p $O; export TMPDIR=/tmp SG_BENCH_CACHE=/tmp
 V="SG_ABLATE=0;SG_K4G_GRID=1024;SG_K4G_GRID=2048;SG_K4G_GRID=1536;SG_K4G_GRID=512"
 IFS=';' read -ra A <<< "$V"
