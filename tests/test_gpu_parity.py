@@ -215,6 +215,30 @@ def test_k4_gather_launch_equals_the_fused_layer_bitwise():
     assert out[0].tobytes() == out[1].tobytes()
 
 
+def test_in_statistics_slice_counts_give_identical_rows():
+    """The in-statistics are folded per (node range, edge slice) and the node features sum the slices' partials themselves (round 6: k3_in_reduce
+    left the one-call pipelines; 48 slices where they are one round of the chip).  Integer sums and a maximum are order-free, so the rows must
+    not depend on the slice count — 8 (the small-graph default), 33 and 47 (the sums' tail loop: not a multiple of four), 48."""
+    topo = replay.make_topology(600, 60_000, seed=43)
+    ev, labels = replay.make_events(topo, 400_000, seed=44)
+    out = []
+    for slices in (None, "33", "47", "48"):
+        if slices: os.environ["SG_K3_SLICES"] = slices
+        try:
+            g = _engine(topo.n_nodes + 8, 1 << 17, 2, max_window_events=len(ev))
+            HostShim().apply(g, topo.k8s_ops())
+            for i in range(0, len(ev), 1 << 17):
+                assert g.ingest(ev[i:i + (1 << 17)]) == 0
+            g.set_label_count(len(labels))
+            out.append(g.flush_window().copy())
+            g.close()
+        finally:
+            os.environ.pop("SG_K3_SLICES", None)
+    assert len(out[0]) > 30_000
+    for o in out[1:]:
+        assert out[0].tobytes() == o.tobytes()
+
+
 def test_row_sort_by_blocks_equals_the_one_workgroup_row_sort_and_the_oracle():
     """Rows of more than 1024 edges are sorted a 512-edge block per workgroup (k2_row_block: every block ranks against the whole
     row's node bitmap, the row's out-statistics are summed with atomics and the last block derives row_mu / row_sd).  Against
